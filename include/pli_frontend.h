@@ -1,0 +1,286 @@
+/*
+ * pli_frontend.h — C ABI of the MI355X-native point+line front-end.
+ *
+ * This is the drop-in boundary underneath PLI-SLAM's per-frame front-end
+ * (Frame::Frame stereo ctor, reference src/Frame.cc:98-228).  The reference has
+ * no FFI of its own: its boundary is a set of C++ call sites.  Every entry
+ * point below names the reference call it replaces (file:line under the
+ * reference tree).  The C++ adapters in pli_slam_amd/adapters/ keep the
+ * reference's functor signatures and call these functions; INTEGRATION.md
+ * shows the binding a maintainer adds to Frame.cc / Tracking.cc.
+ *
+ * Conventions
+ *   - plain C types only; no exceptions cross the boundary; every function
+ *     returns a pli_status (0 = ok, negative = error).
+ *   - caller owns all buffers; outputs are caller-allocated with a capacity and
+ *     the function returns the produced count.
+ *   - "host" pointers are ordinary memory; "dev" pointers are HIP device
+ *     memory of the context's device.
+ *   - a context owns one HIP stream and all scratch for `max_frames` stereo
+ *     frames of `width x height`; calls on one context are serialised by the
+ *     caller, different contexts are independent (the reference runs its four
+ *     extractors on four threads, Frame.cc:128-135: use one context per thread
+ *     or the batch API, which covers both eyes at once).
+ */
+#ifndef PLI_FRONTEND_H
+#define PLI_FRONTEND_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t pli_status;
+enum {
+  PLI_OK = 0,
+  PLI_ERR_INVALID = -1,     /* bad argument (null pointer, size mismatch, ...)            */
+  PLI_ERR_EMPTY_IMAGE = -2, /* ORBextractor::operator() returns -1, ORBextractor.cc:1072  */
+  PLI_ERR_CAPACITY = -3,    /* caller buffer too small                                     */
+  PLI_ERR_HIP = -4,         /* HIP runtime failure (see pli_last_error)                    */
+  PLI_ERR_NO_DEVICE = -5,   /* no usable gfx950 device: the product path has no CPU fallback */
+  PLI_ERR_STATE = -6        /* call order violated (e.g. stereo match before extract)      */
+};
+
+/* cv::KeyPoint fields that leave the extractor (ORBextractor.cc:868-877,1131):
+ * pt, size, angle, response, octave.  class_id is always -1 there. 24 bytes. */
+typedef struct pli_keypoint {
+  float x, y;
+  float size;
+  float angle;
+  float response;
+  int32_t octave;
+} pli_keypoint;
+
+/* cv::line_descriptor::KeyLine, field for field
+ * (Thirdparty/line_descriptor/include/line_descriptor/descriptor_custom.hpp:105-144). 68 bytes. */
+typedef struct pli_keyline {
+  float angle;
+  int32_t class_id;
+  int32_t octave;
+  float pt_x, pt_y;
+  float response;
+  float size;
+  float startPointX, startPointY, endPointX, endPointY;
+  float sPointInOctaveX, sPointInOctaveY, ePointInOctaveX, ePointInOctaveY;
+  float lineLength;
+  int32_t numOfPixels;
+} pli_keyline;
+
+/* Parameters of the path.  Sources: ORBextractor ctor (ORBextractor.cc:408),
+ * Lineextractor ctor (LineExtractor.h:44), Tracking.cc:75-98,683-736,
+ * Config.cpp:26-160, Examples/Stereo/Config/EuRoC.yaml. */
+typedef struct pli_frontend_config {
+  int32_t width, height;      /* image size the context is built for                     */
+  int32_t max_frames;         /* stereo frames per batch the context can hold (>=1)       */
+  /* ORB */
+  int32_t orb_nfeatures;      /* ORBextractor.nFeatures   (EuRoC.yaml:91)  1200            */
+  float   orb_scale_factor;   /* ORBextractor.scaleFactor (EuRoC.yaml:94)  1.2             */
+  int32_t orb_nlevels;        /* ORBextractor.nLevels     (EuRoC.yaml:97)  8               */
+  int32_t orb_ini_th_fast;    /* ORBextractor.iniThFAST   (EuRoC.yaml:103) 20              */
+  int32_t orb_min_th_fast;    /* ORBextractor.minThFAST   (EuRoC.yaml:104) 7               */
+  /* LSD / LBD */
+  int32_t lsd_nfeatures;      /* EuRoC.yaml:156 (500); 0 = keep all                        */
+  int32_t lsd_refine;         /* only 0 (LSD_REFINE_NONE) is on the reference path         */
+  int32_t lsd_n_bins;         /* 1024                                                      */
+  int32_t max_lines;          /* capacity for detected segments before the top-N cut      */
+  double  min_line_length;    /* 0.025 (x min(W,H))                                        */
+  double  lsd_scale;          /* 1.2                                                       */
+  double  lsd_sigma_scale;    /* 0.6                                                       */
+  double  lsd_quant;          /* 2.0                                                       */
+  double  lsd_ang_th;         /* 22.5                                                      */
+  double  lsd_log_eps;        /* 1.0  (unused with refine 0)                               */
+  double  lsd_density_th;     /* 0.6  (unused with refine 0)                               */
+  /* stereo points (Frame.cc:976-1154) */
+  float   bf;                 /* Camera.bf (EuRoC.yaml:28) 47.90639384423901               */
+  float   fx;                 /* Camera.fx (EuRoC.yaml:9)  435.2046959714599               */
+  int32_t stereo_maxd_inf;    /* 0: maxD = bf/(bf/fx) as intended; 1: maxD = +inf
+                                 (what an uninitialised mb gives)       */
+  /* stereo lines (Frame.cc:1156-1307, LineMatcher.cpp:317-396, Config.cpp) */
+  int32_t matching_s_ws;      /* 10                                                        */
+  int32_t best_lr_matches;    /* 1                                                         */
+  double  line_sim_th;        /* 0.75                                                      */
+  double  stereo_overlap_th;  /* 0.75                                                      */
+  double  min_ratio_12_l;     /* 0.9                                                       */
+  double  ls_min_disp_ratio;  /* 0.7                                                       */
+  double  min_disp;           /* 1.0                                                       */
+  double  line_horiz_th;      /* 0.1                                                       */
+} pli_frontend_config;
+
+/* Fill `cfg` with the values of Examples/Stereo/Config/EuRoC.yaml for a w x h image. */
+void pli_config_default(pli_frontend_config* cfg, int32_t width, int32_t height);
+
+/* Capacities derived from a config (sizes of the per-eye tables). */
+int32_t pli_kp_capacity(const pli_frontend_config* cfg);   /* >= nfeatures + 3*nlevels    */
+int32_t pli_kl_capacity(const pli_frontend_config* cfg);   /* lsd_nfeatures or max_lines  */
+
+/* ------------------------------------------------------------------------ */
+/* Result table: one fixed-stride record per stereo frame, written on the    */
+/* device by pli_batch_run.  Layout (all offsets from the record start, in  */
+/* bytes) is described by pli_table_layout so that the caller can slice it   */
+/* from any language; eye 0 = left, eye 1 = right.                           */
+/* ------------------------------------------------------------------------ */
+typedef struct pli_table_layout {
+  int64_t record_bytes;       /* stride between consecutive frames                         */
+  int32_t kp_cap, kl_cap;
+  int64_t off_counts;         /* int32[8]: n_kp[2], n_kl[2], n_stereo_pts, n_stereo_lines, 2 reserved */
+  int64_t off_kp[2];          /* pli_keypoint[kp_cap]                                       */
+  int64_t off_desc[2];        /* uint8[kp_cap][32]   (mDescriptors / mDescriptorsRight)     */
+  int64_t off_uright;         /* float[kp_cap]       (mvuRight)                             */
+  int64_t off_depth;          /* float[kp_cap]       (mvDepth)                              */
+  int64_t off_kl[2];          /* pli_keyline[kl_cap]                                        */
+  int64_t off_ldesc[2];       /* uint8[kl_cap][32]   (mDescriptors_Line / ..Right_Line)     */
+  int64_t off_disp;           /* float[kl_cap][2]    (mvDisparity_l)                        */
+  int64_t off_le;             /* double[kl_cap][3]   (mvle_l)                               */
+} pli_table_layout;
+
+typedef struct pli_ctx pli_ctx;
+
+/* Create / destroy.  Replaces the construction of the four extractors in
+ * Tracking.cc:87-98,743-749 (tables, rBRIEF pattern, LBD weights go to the device). */
+pli_status pli_ctx_create(const pli_frontend_config* cfg, int32_t device, pli_ctx** out);
+void       pli_ctx_destroy(pli_ctx* ctx);
+const char* pli_last_error(void);                    /* thread-local message             */
+pli_status pli_ctx_layout(const pli_ctx* ctx, pli_table_layout* out);
+/* Use an existing hipStream_t (e.g. the caller framework's current stream). NULL = own stream. */
+pli_status pli_ctx_set_stream(pli_ctx* ctx, void* hip_stream);
+pli_status pli_ctx_sync(pli_ctx* ctx);
+
+/* ------------------------------------------------------------------------ */
+/* Batch (throughput) path: the whole Frame::Frame front-end for `nframes`   */
+/* stereo pairs in one go — ExtractORB x2, ExtractLine x2 (Frame.cc:128-135),*/
+/* ComputeStereoMatches_Lines (:160), ComputeStereoMatches (:163).           */
+/* Images: device pointers, u8, row stride `stride`, consecutive frames      */
+/* `frame_stride` bytes apart.  Output: `dev_table` = nframes records.       */
+/* Asynchronous on the context stream; pli_ctx_sync() to wait.               */
+/* ------------------------------------------------------------------------ */
+enum {
+  PLI_RUN_ORB = 1, PLI_RUN_LINES = 2, PLI_RUN_STEREO_POINTS = 4, PLI_RUN_STEREO_LINES = 8,
+  PLI_RUN_ALL = 15
+};
+pli_status pli_batch_run(pli_ctx* ctx, int32_t nframes,
+                         const uint8_t* dev_left, const uint8_t* dev_right,
+                         int64_t stride, int64_t frame_stride,
+                         uint32_t stages, void* dev_table);
+/* Same with host images and a host table (does the H2D / D2H copies, synchronous). */
+pli_status pli_batch_run_host(pli_ctx* ctx, int32_t nframes,
+                              const uint8_t* left, const uint8_t* right,
+                              int64_t stride, int64_t frame_stride,
+                              uint32_t stages, void* table);
+
+/* ------------------------------------------------------------------------ */
+/* Per-call drop-ins (host buffers, synchronous).                            */
+/* ------------------------------------------------------------------------ */
+
+/* ORBextractor::operator()(image, mask, keypoints, descriptors, vLappingArea)
+ * ORBextractor.h:61-63 / ORBextractor.cc:1068-1150, with vLappingArea = {0,0}
+ * as Frame::ExtractORB passes (Frame.cc:484-491).  `eye` selects which of the
+ * two device-resident table sets (0 = left extractor, 1 = right extractor) is
+ * filled; they feed pli_stereo_match_*.  Returns PLI_ERR_EMPTY_IMAGE for a
+ * null/zero-sized image like the reference's -1. */
+pli_status pli_orb_extract(pli_ctx* ctx, int32_t eye,
+                           const uint8_t* img, int32_t w, int32_t h, int64_t stride,
+                           pli_keypoint* kp, int32_t cap, uint8_t* desc /* cap x 32 */,
+                           int32_t* n);
+
+/* ORBextractor::mvImagePyramid[level] (public member, ORBextractor.h:87) copied
+ * to `dst` (w*h bytes, no border).  Valid after pli_orb_extract on that eye. */
+pli_status pli_orb_pyramid_level(pli_ctx* ctx, int32_t eye, int32_t level,
+                                 uint8_t* dst, int64_t dst_bytes, int32_t* w, int32_t* h);
+
+/* Lineextractor::operator()(image, mask, keylines, descriptors_line)
+ * LineExtractor.h:49-51 / LineExtractor.cc:31-70. */
+pli_status pli_line_extract(pli_ctx* ctx, int32_t eye,
+                            const uint8_t* img, int32_t w, int32_t h, int64_t stride,
+                            pli_keyline* kl, int32_t cap, uint8_t* desc /* cap x 32 */,
+                            int32_t* n);
+
+/* Frame::ComputeStereoMatches() Frame.cc:976-1154 on the tables + pyramids left
+ * on the device by the last pli_orb_extract(eye 0) / (eye 1).
+ * uright/depth: N floats each (N = left keypoint count), -1 = no stereo. */
+pli_status pli_stereo_match_points(pli_ctx* ctx, float* uright, float* depth, int32_t cap);
+
+/* Frame::ComputeStereoMatches_Lines() Frame.cc:1156-1259 on the line tables of
+ * the last pli_line_extract(eye 0) / (eye 1).
+ * disp: N_l x 2 floats (mvDisparity_l, -1 = mono); le: N_l x 3 doubles (mvle_l). */
+pli_status pli_stereo_match_lines(pli_ctx* ctx, float* disp, double* le, int32_t cap);
+
+/* ORBmatcher::DescriptorDistance ORBmatcher.cc:2495-2511 / distance()
+ * LineMatcher.cpp:231-247, batched: dist[i] = hamming(a[i], b[i]), 32-byte rows. */
+pli_status pli_descriptor_distance(pli_ctx* ctx, const uint8_t* a, const uint8_t* b,
+                                   int32_t n, int32_t* dist);
+
+/* cv::BFMatcher(NORM_HAMMING).knnMatch(k=2) as used by matchNNR
+ * LineMatcher.cpp:139-159: per query the two smallest distances, ties to the
+ * lower train index.  idx/dist: nq x 2 (idx -1 / dist INT32_MAX when nt < 2). */
+pli_status pli_hamming_knn2(pli_ctx* ctx, const uint8_t* q, int32_t nq,
+                            const uint8_t* t, int32_t nt, int32_t* idx, int32_t* dist);
+
+/* int match(desc1, desc2, nnr, matches_12) LineMatcher.cpp:201-229 with
+ * Config::bestLRMatches() = best_lr_matches of the context: ratio test both
+ * ways + mutual check.  matches_12: n1 ints (-1 = none).  *nmatches = return value. */
+pli_status pli_match_lines(pli_ctx* ctx, const uint8_t* desc1, int32_t n1,
+                           const uint8_t* desc2, int32_t n2, float nnr,
+                           int32_t* matches_12, int32_t* nmatches);
+
+/* Core of ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono, match12)
+ * ORBmatcher.cc:2179-2323: the caller projects LastFrame's map points with the
+ * predicted pose (SLAM state stays on the host) and passes, per query i in
+ * LastFrame order: projected (u,v), search radius, octave window
+ * [min_level,max_level] (max_level < 0 = unbounded as GetFeaturesInArea
+ * Frame.cc:774-843), the map point descriptor and the predicted right
+ * coordinate ur = u - bf*invz (compared with mvuRight[i2] whenever that is > 0,
+ * :2259-2265).  Queries with valid == 0 (no map point / outlier / behind the
+ * camera) are skipped.  The current frame is described by its keypoints, descriptors,
+ * mvuRight and the image bounds used by the 64x48 grid (mnMinX..mnMaxY).
+ * Reproduces the sequential "already assigned" exclusion, TH_HIGH = 100, the
+ * 30-bin rotation histogram and ComputeThreeMaxima (:2449-2490).
+ * best_idx2[i] = matched current keypoint or -1.  *nmatches as the reference. */
+typedef struct pli_proj_query {
+  float u, v, radius, ur;
+  int32_t min_level, max_level;
+  float angle;          /* LastFrame.mvKeysUn[i].angle */
+  int32_t valid;
+} pli_proj_query;
+pli_status pli_search_by_projection(pli_ctx* ctx,
+                                    const pli_proj_query* q, const uint8_t* qdesc, int32_t nq,
+                                    const pli_keypoint* cur_kp, const uint8_t* cur_desc,
+                                    const float* cur_uright, int32_t ncur,
+                                    float min_x, float max_x, float min_y, float max_y,
+                                    int32_t check_orientation,
+                                    int32_t* best_idx2, int32_t* nmatches);
+
+/* ------------------------------------------------------------------------ */
+/* Measurement hooks (bench.py / tests only).                                */
+/* ------------------------------------------------------------------------ */
+/* When enabled every kernel launch of the context is bracketed by HIP events on
+ * the context stream; pli_prof_report writes "name calls total_ms\n" lines. */
+pli_status pli_prof_enable(pli_ctx* ctx, int32_t on);
+pli_status pli_prof_reset(pli_ctx* ctx);
+pli_status pli_prof_report(pli_ctx* ctx, char* buf, int64_t buf_bytes);
+
+/* Intermediate products, for parity tests against the oracle stage by stage.
+ * `what` is one of PLI_DBG_*; data are copied to `dst` (host).  *out_bytes =
+ * bytes written.  image = frame*2 + eye. */
+enum {
+  PLI_DBG_PYRAMID_LEVEL = 1,   /* arg = level; u8 w*h                                       */
+  PLI_DBG_BLUR_LEVEL = 2,      /* arg = level; u8 w*h (7x7 sigma 2)                         */
+  PLI_DBG_FAST_CANDIDATES = 3, /* arg = level; int32 count then {int32 x,y,score} records, reference order */
+  PLI_DBG_LEVEL_KEYPOINTS = 4, /* arg = level; int32 count then {int32 x,y,score} after the quadtree */
+  PLI_DBG_LSD_SCALED = 5,      /* u8 W'*H' (blur 0.6 + x1.2 resize)                         */
+  PLI_DBG_LSD_ANGLE = 6,       /* float W'*H' degrees, -1024 = NOTDEF                       */
+  PLI_DBG_LSD_SEGMENTS = 7,    /* int32 count then float[4] x1,y1,x2,y2 in detection order  */
+  PLI_DBG_LBD_DXDY = 8,        /* int16 dx[w*h] then int16 dy[w*h]                          */
+  PLI_DBG_LSD_ORDER = 9,       /* int32 count then int32 pixel index of every seed in visiting order */
+  PLI_DBG_LBD_FLOAT = 10       /* float[n][72] LBD band vector before binarisation          */
+};
+pli_status pli_debug_fetch(pli_ctx* ctx, int32_t image, int32_t what, int32_t arg,
+                           void* dst, int64_t dst_bytes, int64_t* out_bytes);
+
+const char* pli_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLI_FRONTEND_H */

@@ -1,0 +1,499 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (never linked into the product library).
+//
+// CPU restatement of the reference matchers on the per-frame path:
+//   ORBmatcher::DescriptorDistance            src/ORBmatcher.cc:2495-2511
+//   distance()                                src/LineMatcher.cpp:231-247
+//   Frame::ComputeStereoMatches               src/Frame.cc:976-1154
+//   Frame::ComputeStereoMatches_Lines         src/Frame.cc:1156-1307
+//   matchGrid(lines)                          src/LineMatcher.cpp:317-396
+//   GridStructure / getLineCoords / LineIterator  src/gridStructure.cpp, src/LineIterator.cpp
+//   matchNNR / match(desc,desc)               src/LineMatcher.cpp:139-159,201-229
+//   ORBmatcher::SearchByProjection(F,F)       src/ORBmatcher.cc:2179-2323 (+ Frame.cc:451-482,774-855, ORBmatcher.cc:2449-2490)
+// The Bresenham cell walk and the grid window query are pinned against the
+// reference's own src/LineIterator.cpp + src/gridStructure.cpp (the only two
+// path files that build without OpenCV): oracle/_ref + tests/golden/grid_*.json.
+// Everything else: PARITY UNPINNED (no reference tests; not buildable here).
+#pragma once
+#include "ocv_prims.hpp"
+#include "../include/pli_frontend.h"
+#include <climits>
+#include <map>
+#include <set>
+#include <unordered_set>
+#include <list>
+
+namespace orc {
+
+static inline int descriptorDistance(const uint8_t* a, const uint8_t* b) {
+  const int32_t* pa = (const int32_t*)a;
+  const int32_t* pb = (const int32_t*)b;
+  int dist = 0;
+  for (int i = 0; i < 8; i++, pa++, pb++) {
+    unsigned int v = *pa ^ *pb;
+    v = v - ((v >> 1) & 0x55555555);
+    v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+    dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+  }
+  return dist;
+}
+
+// ---------------------------------------------------------------------------
+// Frame::ComputeStereoMatches, Frame.cc:976-1154
+// `maxD`: the reference reads mb before it is set; the
+// oracle takes it as a parameter (fx as intended, or +inf).
+// ---------------------------------------------------------------------------
+static inline void computeStereoMatches(const std::vector<pli_keypoint>& mvKeys, const uint8_t* mDescriptors,
+                                        const std::vector<pli_keypoint>& mvKeysRight,
+                                        const uint8_t* mDescriptorsRight, const std::vector<Img8>& pyrL,
+                                        const std::vector<Img8>& pyrR, const std::vector<float>& mvScaleFactors,
+                                        const std::vector<float>& mvInvScaleFactors, float mbf, float maxD,
+                                        std::vector<float>& mvuRight, std::vector<float>& mvDepth,
+                                        std::vector<int>* dbgBestIdx = nullptr, std::vector<int>* dbgSad = nullptr) {
+  const int N = (int)mvKeys.size();
+  mvuRight.assign(N, -1.0f);
+  mvDepth.assign(N, -1.0f);
+  if (dbgBestIdx) dbgBestIdx->assign(N, -1);
+  if (dbgSad) dbgSad->assign(N, -1);
+  const int TH_HIGH = 100, TH_LOW = 50;
+  const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+  const int nRows = pyrL[0].h;
+  std::vector<std::vector<size_t>> vRowIndices(nRows);
+  const int Nr = (int)mvKeysRight.size();
+  for (int iR = 0; iR < Nr; iR++) {
+    const pli_keypoint& kp = mvKeysRight[iR];
+    const float kpY = kp.y;
+    const float r = 2.0f * mvScaleFactors[kp.octave];
+    const int maxr = (int)std::ceil(kpY + r);
+    const int minr = (int)std::floor(kpY - r);
+    for (int yi = minr; yi <= maxr; yi++)
+      if (yi >= 0 && yi < nRows) vRowIndices[yi].push_back(iR);   // reference indexes unchecked (kp >= 16 px inside)
+  }
+  const float minD = 0;
+  std::vector<std::pair<int, int>> vDistIdx;
+  for (int iL = 0; iL < N; iL++) {
+    const pli_keypoint& kpL = mvKeys[iL];
+    const int levelL = kpL.octave;
+    const float vL = kpL.y;
+    const float uL = kpL.x;
+    const std::vector<size_t>& vCandidates = vRowIndices[(int)vL];
+    if (vCandidates.empty()) continue;
+    const float minU = uL - maxD;
+    const float maxU = uL - minD;
+    if (maxU < 0) continue;
+    int bestDist = TH_HIGH;
+    size_t bestIdxR = 0;
+    const uint8_t* dL = mDescriptors + (size_t)iL * 32;
+    for (size_t iC = 0; iC < vCandidates.size(); iC++) {
+      const size_t iR = vCandidates[iC];
+      const pli_keypoint& kpR = mvKeysRight[iR];
+      if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+      const float uR = kpR.x;
+      if (uR >= minU && uR <= maxU) {
+        const int dist = descriptorDistance(dL, mDescriptorsRight + iR * 32);
+        if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+      }
+    }
+    if (bestDist < thOrbDist) {
+      if (dbgBestIdx) (*dbgBestIdx)[iL] = (int)bestIdxR;
+      const float uR0 = mvKeysRight[bestIdxR].x;
+      const float scaleFactor = mvInvScaleFactors[kpL.octave];
+      const float scaleduL = std::round(kpL.x * scaleFactor);
+      const float scaledvL = std::round(kpL.y * scaleFactor);
+      const float scaleduR0 = std::round(uR0 * scaleFactor);
+      const int w = 5;
+      const Img8& imL = pyrL[kpL.octave];
+      const Img8& imR = pyrR[kpL.octave];
+      const int cy = (int)scaledvL, cxl = (int)scaleduL, cxr = (int)scaleduR0;
+      // cv::Mat::rowRange/colRange assert the window is inside the level image; the
+      // reference aborts there.  Oracle (and kernels): such a keypoint gets no stereo.
+      if (cy - w < 0 || cy + w + 1 > imL.h || cxl - w < 0 || cxl + w + 1 > imL.w) continue;
+      int bestDistS = INT_MAX;
+      int bestincR = 0;
+      const int L = 5;
+      float vDists[2 * 5 + 1];
+      const float iniu = scaleduR0 + L - w;
+      const float endu = scaleduR0 + L + w + 1;
+      if (iniu < 0 || endu >= imR.w) continue;
+      if (cxr - L - w < 0) continue;   // same: colRange would assert
+      const int cL = imL.at(cy, cxl);
+      for (int incR = -L; incR <= +L; incR++) {
+        const int cR = imR.at(cy, cxr + incR);
+        int sad = 0;
+        for (int dy = -w; dy <= w; ++dy)
+          for (int dx = -w; dx <= w; ++dx) {
+            int a = (int)imL.at(cy + dy, cxl + dx) - cL;
+            int b = (int)imR.at(cy + dy, cxr + incR + dx) - cR;
+            sad += std::abs(a - b);
+          }
+        float dist = (float)sad;
+        if (dist < bestDistS) { bestDistS = (int)dist; bestincR = incR; }
+        vDists[L + incR] = dist;
+      }
+      if (bestincR == -L || bestincR == L) continue;
+      const float dist1 = vDists[L + bestincR - 1];
+      const float dist2 = vDists[L + bestincR];
+      const float dist3 = vDists[L + bestincR + 1];
+      const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+      if (deltaR < -1 || deltaR > 1) continue;
+      float bestuR = mvScaleFactors[kpL.octave] * ((float)scaleduR0 + (float)bestincR + deltaR);
+      float disparity = (uL - bestuR);
+      if (disparity >= minD && disparity < maxD) {
+        if (disparity <= 0) {
+          disparity = 0.01f;
+          bestuR = (float)((double)uL - 0.01);   // `bestuR = uL-0.01;` is evaluated in double
+        }
+        mvDepth[iL] = mbf / disparity;
+        mvuRight[iL] = bestuR;
+        vDistIdx.push_back(std::pair<int, int>(bestDistS, iL));
+        if (dbgSad) (*dbgSad)[iL] = bestDistS;
+      }
+    }
+  }
+  if (vDistIdx.empty()) return;   // reference: vDistIdx[0] on an empty vector (UB); defined as "nothing to cut"
+  std::sort(vDistIdx.begin(), vDistIdx.end());
+  const float median = (float)vDistIdx[vDistIdx.size() / 2].first;
+  const float thDist = 1.5f * 1.4f * median;
+  for (int i = (int)vDistIdx.size() - 1; i >= 0; i--) {
+    if (vDistIdx[i].first < thDist) break;
+    mvuRight[vDistIdx[i].second] = -1;
+    mvDepth[vDistIdx[i].second] = -1;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// LineIterator (src/LineIterator.cpp:31-77) + getLineCoords (gridStructure.cpp:33-42)
+// ---------------------------------------------------------------------------
+static inline void getLineCoords(double x1_, double y1_, double x2_, double y2_,
+                                 std::vector<std::pair<int, int>>& line_coords) {
+  line_coords.clear();
+  double x1 = x1_, y1 = y1_, x2 = x2_, y2 = y2_;
+  const bool steep = std::abs(y2_ - y1_) > std::abs(x2_ - x1_);
+  if (steep) { std::swap(x1, y1); std::swap(x2, y2); }
+  if (x1 > x2) { std::swap(x1, x2); std::swap(y1, y2); }
+  double dx = x2 - x1;
+  double dy = std::abs(y2 - y1);
+  double error = dx / 2.0;
+  int ystep = (y1 < y2) ? 1 : -1;
+  int x = static_cast<int>(x1);
+  int y = static_cast<int>(y1);
+  int maxX = static_cast<int>(x2);
+  while (x <= maxX) {
+    if (steep) line_coords.push_back(std::make_pair(y, x));
+    else line_coords.push_back(std::make_pair(x, y));
+    error -= dy;
+    if (error < 0) { y += ystep; error += dx; }
+    x++;
+  }
+}
+
+// GridStructure (gridStructure.cpp:44-83): grid[x][y] lists, rows=48, cols=64.
+struct Grid {
+  int rows, cols;
+  std::vector<std::vector<int>> cell;
+  Grid(int r, int c) : rows(r), cols(c), cell((size_t)r * c) {}
+  void push(int x, int y, int idx) {
+    if (x >= 0 && x < cols && y >= 0 && y < rows) cell[(size_t)x * rows + y].push_back(idx);
+  }
+  void get(int x, int y, int wl, int wr, int hu, int hd, std::set<int>& indices) const {
+    int min_x = std::max(0, x - wl);
+    int max_x = std::min(cols, x + wr + 1);
+    int min_y = std::max(0, y - hu);
+    int max_y = std::min(rows, y + hd + 1);
+    for (int x_ = min_x; x_ < max_x; ++x_)
+      for (int y_ = min_y; y_ < max_y; ++y_) {
+        const std::vector<int>& c = cell[(size_t)x_ * rows + y_];
+        indices.insert(c.begin(), c.end());
+      }
+  }
+};
+
+struct LineMatchCfg {
+  int matching_s_ws = 10;
+  bool best_lr_matches = true;
+  double line_sim_th = 0.75, stereo_overlap_th = 0.75, min_ratio_12_l = 0.9, ls_min_disp_ratio = 0.7,
+         min_disp = 1.0, line_horiz_th = 0.1;
+};
+
+static inline void normalize2(double& a, double& b) {
+  double magnitude = std::sqrt(a * a + b * b);
+  a /= magnitude;
+  b /= magnitude;
+}
+
+// matchGrid(lines), LineMatcher.cpp:317-396.  Candidates are iterated in
+// ascending index order (the reference iterates an unordered_set; the result
+// does not depend on the order: ties at the best distance are rejected).
+static inline int matchGridLines(const std::vector<int>& sx, const std::vector<int>& sy, const std::vector<int>& ex,
+                                 const std::vector<int>& ey, const uint8_t* desc1, int n1, const Grid& grid,
+                                 const uint8_t* desc2, int n2, const std::vector<std::pair<double, double>>& dir2,
+                                 const LineMatchCfg& C, std::vector<int>& matches_12) {
+  int matches = 0;
+  matches_12.assign(n1, -1);
+  std::vector<int> matches_21, distances;
+  if (C.best_lr_matches) {
+    matches_21.assign(n2, -1);
+    distances.assign(n2, INT_MAX);
+  }
+  for (int i1 = 0; i1 < n1; ++i1) {
+    int best_d = INT_MAX, best_d2 = INT_MAX, best_idx = -1;
+    double vx = (double)(ex[i1] - sx[i1]), vy = (double)(ey[i1] - sy[i1]);
+    normalize2(vx, vy);
+    std::set<int> candidates;
+    grid.get(sx[i1], sy[i1], C.matching_s_ws, 0, 0, 0, candidates);
+    grid.get(ex[i1], ey[i1], C.matching_s_ws, 0, 0, 0, candidates);
+    if (candidates.empty()) continue;
+    for (int i2 : candidates) {
+      if (i2 < 0 || i2 >= n2) continue;
+      if (std::abs(vx * dir2[i2].first + vy * dir2[i2].second) < C.line_sim_th) continue;
+      const int d = descriptorDistance(desc1 + (size_t)i1 * 32, desc2 + (size_t)i2 * 32);
+      if (C.best_lr_matches) {
+        if (d < distances[i2]) { distances[i2] = d; matches_21[i2] = i1; }
+        else continue;
+      }
+      if (d < best_d) { best_d2 = best_d; best_d = d; best_idx = i2; }
+      else if (d < best_d2) best_d2 = d;
+    }
+    if (best_d < best_d2 * C.min_ratio_12_l) { matches_12[i1] = best_idx; matches++; }
+  }
+  if (C.best_lr_matches) {
+    for (int i1 = 0; i1 < n1; ++i1) {
+      int& i2 = matches_12[i1];
+      if (i2 >= 0 && matches_21[i2] != i1) { i2 = -1; matches--; }
+    }
+  }
+  return matches;
+}
+
+// Frame::lineSegmentOverlapStereo, Frame.cc:1261-1295
+static inline double lineSegmentOverlapStereo(double spl_obs, double epl_obs, double spl_proj, double epl_proj,
+                                              double lineHorizTh) {
+  double overlap = 1.f;
+  if (std::fabs(epl_obs - spl_obs) > lineHorizTh) {
+    double sln = std::min(spl_obs, epl_obs);
+    double eln = std::max(spl_obs, epl_obs);
+    double spn = std::min(spl_proj, epl_proj);
+    double epn = std::max(spl_proj, epl_proj);
+    double length = eln - spn;
+    if ((epn < sln) || (spn > eln)) overlap = 0.f;
+    else {
+      if ((epn > eln) && (spn < sln)) overlap = eln - sln;
+      else overlap = std::min(eln, epn) - std::max(sln, spn);
+    }
+    if (length > 0.01f) overlap = overlap / length;
+    else overlap = 0.f;
+    if (overlap > 1.f) overlap = 1.f;
+  }
+  return overlap;
+}
+
+// Frame::ComputeStereoMatches_Lines, Frame.cc:1156-1259 (doNotDropMonoLines = true)
+static inline void computeStereoMatchesLines(const std::vector<pli_keyline>& KL, const uint8_t* descL,
+                                             const std::vector<pli_keyline>& KR, const uint8_t* descR, int imgW,
+                                             int imgH, const LineMatchCfg& C, std::vector<float>& disp /*n x 2*/,
+                                             std::vector<double>& le /* n x 3 */, std::vector<int>* dbgMatches = nullptr) {
+  const int FRAME_GRID_ROWS = 48, FRAME_GRID_COLS = 64;
+  const int n1 = (int)KL.size(), n2 = (int)KR.size();
+  disp.assign((size_t)n1 * 2, -1.f);
+  le.assign((size_t)n1 * 3, 0.0);
+  if (dbgMatches) dbgMatches->assign(n1, -1);
+  if (KL.empty() || KR.empty()) return;
+  const double inv_width = FRAME_GRID_COLS / static_cast<double>(imgW);
+  const double inv_height = FRAME_GRID_ROWS / static_cast<double>(imgH);
+  std::vector<int> sx(n1), sy(n1), ex(n1), ey(n1);
+  for (int i = 0; i < n1; ++i) {
+    sx[i] = (int)(KL[i].startPointX * inv_width);
+    sy[i] = (int)(KL[i].startPointY * inv_height);
+    ex[i] = (int)(KL[i].endPointX * inv_width);
+    ey[i] = (int)(KL[i].endPointY * inv_height);
+  }
+  Grid grid(FRAME_GRID_ROWS, FRAME_GRID_COLS);
+  std::vector<std::pair<double, double>> directions(n2);
+  std::vector<std::pair<int, int>> line_coords;
+  for (int idx = 0; idx < n2; ++idx) {
+    const pli_keyline& kl = KR[idx];
+    double vx = (kl.endPointX - kl.startPointX) * inv_width, vy = (kl.endPointY - kl.startPointY) * inv_height;
+    normalize2(vx, vy);
+    directions[idx] = std::make_pair(vx, vy);
+    getLineCoords(kl.startPointX * inv_width, kl.startPointY * inv_height, kl.endPointX * inv_width,
+                  kl.endPointY * inv_height, line_coords);
+    for (const std::pair<int, int>& p : line_coords) grid.push(p.first, p.second, idx);
+  }
+  std::vector<int> matches_12;
+  matchGridLines(sx, sy, ex, ey, descL, n1, grid, descR, n2, directions, C, matches_12);
+  if (dbgMatches) *dbgMatches = matches_12;
+  for (int i1 = 0; i1 < n1; ++i1) {
+    const int i2 = matches_12[i1];
+    if (i2 < 0) continue;
+    double sp_l[3] = {KL[i1].startPointX, KL[i1].startPointY, 1.0};
+    double ep_l[3] = {KL[i1].endPointX, KL[i1].endPointY, 1.0};
+    double le_l[3] = {sp_l[1] * ep_l[2] - sp_l[2] * ep_l[1], sp_l[2] * ep_l[0] - sp_l[0] * ep_l[2],
+                      sp_l[0] * ep_l[1] - sp_l[1] * ep_l[0]};
+    double nrm = std::sqrt(le_l[0] * le_l[0] + le_l[1] * le_l[1]);
+    le_l[0] = le_l[0] / nrm; le_l[1] = le_l[1] / nrm; le_l[2] = le_l[2] / nrm;
+    double sp_r[3] = {KR[i2].startPointX, KR[i2].startPointY, 1.0};
+    double ep_r[3] = {KR[i2].endPointX, KR[i2].endPointY, 1.0};
+    double overlap = lineSegmentOverlapStereo(sp_l[1], ep_l[1], sp_r[1], ep_r[1], C.line_horiz_th);
+    // sp_r << (...), sp_l(1), 1.0 : Eigen's comma initialiser evaluates all three
+    // expressions from the OLD sp_r before assigning, then ep_r uses the NEW sp_r.
+    double nsx = (sp_r[0] * (sp_l[1] - ep_r[1]) + ep_r[0] * (sp_r[1] - sp_l[1])) / (sp_r[1] - ep_r[1]);
+    sp_r[0] = nsx; sp_r[1] = sp_l[1];
+    double nex = (sp_r[0] * (ep_l[1] - ep_r[1]) + ep_r[0] * (sp_r[1] - ep_l[1])) / (sp_r[1] - ep_r[1]);
+    ep_r[0] = nex; ep_r[1] = ep_l[1];
+    // filterLineSegmentDisparity, Frame.cc:1297-1307
+    double disp_s = sp_l[0] - sp_r[0];
+    double disp_e = ep_l[0] - ep_r[0];
+    if (std::min(disp_s, disp_e) / std::max(disp_s, disp_e) < C.ls_min_disp_ratio) { disp_s = -1.0; disp_e = -1.0; }
+    if (disp_s >= C.min_disp && disp_e >= C.min_disp && std::abs(sp_l[1] - ep_l[1]) > C.line_horiz_th &&
+        std::abs(sp_r[1] - ep_r[1]) > C.line_horiz_th && overlap > C.stereo_overlap_th) {
+      disp[(size_t)i1 * 2] = (float)disp_s;
+      disp[(size_t)i1 * 2 + 1] = (float)disp_e;
+      le[(size_t)i1 * 3] = le_l[0];
+      le[(size_t)i1 * 3 + 1] = le_l[1];
+      le[(size_t)i1 * 3 + 2] = le_l[2];
+    }
+  }
+}
+
+// cv::BFMatcher(NORM_HAMMING).knnMatch(k=2): two smallest, ties -> lower train index.
+static inline void knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, std::vector<int>& idx,
+                        std::vector<int>& dist) {
+  idx.assign((size_t)nq * 2, -1);
+  dist.assign((size_t)nq * 2, INT_MAX);
+  for (int i = 0; i < nq; ++i) {
+    int b0 = INT_MAX, b1 = INT_MAX, i0 = -1, i1 = -1;
+    for (int j = 0; j < nt; ++j) {
+      int d = descriptorDistance(q + (size_t)i * 32, t + (size_t)j * 32);
+      if (d < b0) { b1 = b0; i1 = i0; b0 = d; i0 = j; }
+      else if (d < b1) { b1 = d; i1 = j; }
+    }
+    idx[2 * i] = i0; idx[2 * i + 1] = i1; dist[2 * i] = b0; dist[2 * i + 1] = b1;
+  }
+}
+
+// matchNNR, LineMatcher.cpp:139-159.  The reference dereferences matches_[idx][1]
+// unconditionally: with fewer than 2 train rows it is UB; defined here as "no match".
+static inline int matchNNR(const uint8_t* d1, int n1, const uint8_t* d2, int n2, float nnr, std::vector<int>& m12) {
+  int matches = 0;
+  m12.assign(n1, -1);
+  if (n2 < 2) return 0;
+  std::vector<int> idx, dist;
+  knn2(d1, n1, d2, n2, idx, dist);
+  for (int i = 0; i < n1; ++i) {
+    if ((float)dist[2 * i] < (float)dist[2 * i + 1] * nnr) { m12[i] = idx[2 * i]; matches++; }
+  }
+  return matches;
+}
+
+// match(desc1, desc2, nnr, matches_12), LineMatcher.cpp:201-229
+static inline int matchLines(const uint8_t* d1, int n1, const uint8_t* d2, int n2, float nnr, bool bestLR,
+                             std::vector<int>& m12) {
+  if (bestLR) {
+    std::vector<int> m21;
+    int matches = matchNNR(d1, n1, d2, n2, nnr, m12);
+    matchNNR(d2, n2, d1, n1, nnr, m21);
+    for (int i1 = 0; i1 < n1; ++i1) {
+      int& i2 = m12[i1];
+      if (i2 >= 0 && m21[i2] != i1) { i2 = -1; matches--; }
+    }
+    return matches;
+  }
+  return matchNNR(d1, n1, d2, n2, nnr, m12);
+}
+
+// ---------------------------------------------------------------------------
+// ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono, match12)
+// ORBmatcher.cc:2179-2323, with the SLAM state reduced to per-query records
+// (see pli_proj_query in include/pli_frontend.h).
+// ---------------------------------------------------------------------------
+static inline int searchByProjection(const pli_proj_query* q, const uint8_t* qdesc, int nq,
+                                     const pli_keypoint* kp, const uint8_t* desc, const float* uright, int ncur,
+                                     float mnMinX, float mnMaxX, float mnMinY, float mnMaxY, bool checkOri,
+                                     std::vector<int>& best_idx2) {
+  const int COLS = 64, ROWS = 48, HISTO_LENGTH = 30, TH_HIGH = 100;
+  best_idx2.assign(nq, -1);
+  const float gwInv = static_cast<float>(COLS) / (mnMaxX - mnMinX);
+  const float ghInv = static_cast<float>(ROWS) / (mnMaxY - mnMinY);
+  // AssignFeaturesToGrid, Frame.cc:451-482 + PosInGrid :845-855
+  std::vector<std::vector<int>> grid((size_t)COLS * ROWS);
+  for (int i = 0; i < ncur; ++i) {
+    int px = (int)std::round((kp[i].x - mnMinX) * gwInv);
+    int py = (int)std::round((kp[i].y - mnMinY) * ghInv);
+    if (px < 0 || px >= COLS || py < 0 || py >= ROWS) continue;
+    grid[(size_t)px * ROWS + py].push_back(i);
+  }
+  std::vector<char> assigned(ncur, 0);
+  std::vector<int> owner(ncur, -1);
+  int nmatches = 0;
+  std::vector<int> rotHist[30];
+  const float factor = 1.0f / HISTO_LENGTH;
+  for (int i = 0; i < nq; ++i) {
+    if (!q[i].valid) continue;
+    const float u = q[i].u, v = q[i].v, radius = q[i].radius;
+    if (u < mnMinX || u > mnMaxX) continue;
+    if (v < mnMinY || v > mnMaxY) continue;
+    // GetFeaturesInArea, Frame.cc:774-843
+    const int minLevel = q[i].min_level, maxLevel = q[i].max_level;
+    const int nMinCellX = std::max(0, (int)std::floor((u - mnMinX - radius) * gwInv));
+    if (nMinCellX >= COLS) continue;
+    const int nMaxCellX = std::min(COLS - 1, (int)std::ceil((u - mnMinX + radius) * gwInv));
+    if (nMaxCellX < 0) continue;
+    const int nMinCellY = std::max(0, (int)std::floor((v - mnMinY - radius) * ghInv));
+    if (nMinCellY >= ROWS) continue;
+    const int nMaxCellY = std::min(ROWS - 1, (int)std::ceil((v - mnMinY + radius) * ghInv));
+    if (nMaxCellY < 0) continue;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    int bestDist = 256, bestIdx2 = -1;
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+      for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+        const std::vector<int>& vCell = grid[(size_t)ix * ROWS + iy];
+        for (int i2 : vCell) {
+          const pli_keypoint& k = kp[i2];
+          if (bCheckLevels) {
+            if (k.octave < minLevel) continue;
+            if (maxLevel >= 0 && k.octave > maxLevel) continue;
+          }
+          const float distx = k.x - u, disty = k.y - v;
+          if (!(std::fabs(distx) < radius && std::fabs(disty) < radius)) continue;
+          if (assigned[i2]) continue;                 // mvpMapPoints[i2] with Observations()>0
+          if (uright[i2] > 0) {
+            const float er = std::fabs(q[i].ur - uright[i2]);
+            if (er > radius) continue;
+          }
+          const int dist = descriptorDistance(qdesc + (size_t)i * 32, desc + (size_t)i2 * 32);
+          if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+      }
+    if (bestIdx2 >= 0 && bestDist <= TH_HIGH) {
+      assigned[bestIdx2] = 1;
+      owner[bestIdx2] = i;
+      nmatches++;
+      if (checkOri) {
+        float rot = q[i].angle - kp[bestIdx2].angle;
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)std::round(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        rotHist[bin].push_back(bestIdx2);
+      }
+    }
+  }
+  if (checkOri) {
+    // ComputeThreeMaxima, ORBmatcher.cc:2449-2490
+    int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      const int s = (int)rotHist[i].size();
+      if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+      else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+      else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+    for (int i = 0; i < HISTO_LENGTH; i++)
+      if (i != ind1 && i != ind2 && i != ind3)
+        for (int idx2 : rotHist[i]) { owner[idx2] = -1; nmatches--; }
+  }
+  for (int i2 = 0; i2 < ncur; ++i2)
+    if (owner[i2] >= 0) best_idx2[owner[i2]] = i2;
+  return nmatches;
+}
+
+}  // namespace orc

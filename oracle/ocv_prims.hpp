@@ -1,0 +1,242 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (never linked into the product library).
+//
+// Restatement of the OpenCV 3.3.1 primitives the reference front-end calls.
+// OpenCV is a third-party dependency of the reference (README.md:18-20,
+// CMakeLists.txt:36 `find_package(OpenCV 3)`; the shipped ELF links
+// libopencv_core3.so.3.3) that is neither vendored under /root/reference nor
+// installed in the build image, so these functions restate its published
+// algorithms ("OpenCV-3.3.1-compatible by intent").
+// PARITY UNPINNED for this file: the reference holds no golden vectors at the
+// OpenCV boundary and OpenCV itself cannot be run here.  Call sites anchoring
+// each primitive are cited per function.
+//
+// Floating point: built with -ffp-contract=off; every expression below is
+// evaluated in the written order with IEEE single/double operations, which is
+// also what the HIP kernels do.
+#pragma once
+#include <cstdint>
+#include <cmath>
+#include <cfloat>
+#include <vector>
+#include <algorithm>
+#include <cstring>
+
+namespace orc {
+
+// cvRound(double) / cvRound(float): nearest, ties to even (SSE cvtsd2si).
+// Call sites: ORBextractor.cc:79,113,117-118,444,1157.
+static inline int cvRound(double v) { return (int)std::nearbyint(v); }
+static inline int cvRoundf(float v) { return (int)std::nearbyintf(v); }
+static inline int cvFloor(double v) { int i = (int)v; return i - (i > v); }
+static inline int cvCeil(double v) { int i = (int)v; return i + (i < v); }
+
+// cv::fastAtan2(y, x) in degrees [0,360). Call sites: ORBextractor.cc:101 and
+// OpenCV's lsd.cpp (ll_angle, region_grow, get_theta).
+static inline float fastAtan2(float y, float x) {
+  const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+  const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+  const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+  const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+  float ax = std::fabs(x), ay = std::fabs(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = ay / (ax + (float)DBL_EPSILON);
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = ax / (ay + (float)DBL_EPSILON);
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+struct Img8 {
+  int w = 0, h = 0;
+  std::vector<uint8_t> d;
+  Img8() {}
+  Img8(int w_, int h_) : w(w_), h(h_), d((size_t)w_ * h_) {}
+  uint8_t* row(int y) { return d.data() + (size_t)y * w; }
+  const uint8_t* row(int y) const { return d.data() + (size_t)y * w; }
+  uint8_t at(int y, int x) const { return d[(size_t)y * w + x]; }
+};
+
+// BORDER_REFLECT_101 index (edge pixel not repeated). copyMakeBorder /
+// GaussianBlur / Sobel default border. Call sites ORBextractor.cc:1115,1167,1172.
+static inline int reflect101(int p, int len) {
+  if (len == 1) return 0;
+  while (p < 0 || p >= len) {
+    if (p < 0) p = -p;
+    else p = 2 * len - 2 - p;
+  }
+  return p;
+}
+
+// cv::resize(src, dst, dsize, fx, fy, INTER_LINEAR) for CV_8UC1: 11-bit fixed
+// point coefficients, horizontal pass to int, vertical pass
+// ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2.
+// `scale_x/scale_y` = source/dest ratio as OpenCV derives it:
+//   dsize given  (ORBextractor.cc:1165): inv = (double)dst/src, scale = 1/inv
+//   fx,fy given  (lsd.cpp resize(..., Size(), SCALE, SCALE)): scale = 1/fx.
+// Coefficient tables as cv::resize builds them (imgproc/src/imgwarp.cpp, 3.3.1):
+// the x table clamps at the borders (sx<0 -> sx=0,fx=0; sx>=w-1 -> sx=w-1,fx=0);
+// the y table is NOT clamped, the row index is clipped when rows are fetched.
+static inline void resizeLinearCoeffs(int ssize, int dsize, double scale, bool clampWeights,
+                                      std::vector<int>& ofs, std::vector<short>& coef) {
+  ofs.resize(dsize);
+  coef.resize(2 * (size_t)dsize);
+  for (int d = 0; d < dsize; ++d) {
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int s = cvFloor(f);
+    f -= s;
+    if (clampWeights) {
+      if (s < 0) { f = 0; s = 0; }
+      if (s >= ssize - 1) { f = 0; s = ssize - 1; }
+    }
+    ofs[d] = s;
+    float c0 = 1.f - f, c1 = f;
+    coef[2 * d] = (short)cvRoundf(c0 * 2048.f);      // saturate_cast<short>
+    coef[2 * d + 1] = (short)cvRoundf(c1 * 2048.f);
+  }
+}
+
+static inline int clipi(int x, int a, int b) { return x >= a ? (x < b ? x : b - 1) : a; }
+
+static inline void resizeLinear8u(const Img8& src, Img8& dst, int dw, int dh,
+                                  double scale_x, double scale_y) {
+  dst = Img8(dw, dh);
+  std::vector<int> xofs, yofs;
+  std::vector<short> alpha, beta;
+  resizeLinearCoeffs(src.w, dw, scale_x, true, xofs, alpha);
+  resizeLinearCoeffs(src.h, dh, scale_y, false, yofs, beta);
+  std::vector<int> r0(dw), r1(dw);
+  for (int dy = 0; dy < dh; ++dy) {
+    int sy0 = clipi(yofs[dy], 0, src.h);
+    int sy1 = clipi(yofs[dy] + 1, 0, src.h);
+    const uint8_t* S0 = src.row(sy0);
+    const uint8_t* S1 = src.row(sy1);
+    for (int dx = 0; dx < dw; ++dx) {
+      int sx = xofs[dx];
+      int sx1 = std::min(sx + 1, src.w - 1);  // at the clamped edge alpha1 == 0
+      int a0 = alpha[2 * dx], a1 = alpha[2 * dx + 1];
+      r0[dx] = S0[sx] * a0 + S0[sx1] * a1;
+      r1[dx] = S1[sx] * a0 + S1[sx1] * a1;
+    }
+    int b0 = beta[2 * dy], b1 = beta[2 * dy + 1];
+    uint8_t* D = dst.row(dy);
+    for (int dx = 0; dx < dw; ++dx) {
+      int v = (((b0 * (r0[dx] >> 4)) >> 16) + ((b1 * (r1[dx] >> 4)) >> 16) + 2) >> 2;
+      D[dx] = (uint8_t)std::min(std::max(v, 0), 255);
+    }
+  }
+}
+
+// cv::getGaussianKernel(n, sigma, CV_32F) then the 8-bit fixed-point
+// conversion used by createSeparableLinearFilter for CV_8U smoothing kernels
+// (convertTo(CV_32S, 256) = cvRound(k*256)).
+static inline std::vector<int> gaussKernelFixed8(int n, double sigma) {
+  std::vector<float> cf(n);
+  double scale2X = -0.5 / (sigma * sigma);
+  double sum = 0;
+  for (int i = 0; i < n; ++i) {
+    double x = i - (n - 1) * 0.5;
+    double t = std::exp(scale2X * x * x);
+    cf[i] = (float)t;
+    sum += cf[i];
+  }
+  sum = 1. / sum;
+  std::vector<int> k(n);
+  for (int i = 0; i < n; ++i) {
+    cf[i] = (float)(cf[i] * sum);
+    k[i] = cvRound((double)cf[i] * 256.0);
+  }
+  return k;
+}
+
+// cv::GaussianBlur(src, dst, Size(n,n), sigma, sigma, BORDER_REFLECT_101) for
+// CV_8UC1 in OpenCV 3.3.1 (filter-engine path, before the 3.4.1 rewrite):
+// int row pass, int column pass, dst = saturate_u8((sum + 2^15) >> 16).
+// Call sites: ORBextractor.cc:1115 (7x7, 2), binary_descriptor_custom.cpp:358
+// (5x5, 1), lsd.cpp (7x7, 0.6).
+static inline void gaussianBlur8u(const Img8& src, Img8& dst, int n, double sigma) {
+  std::vector<int> k = gaussKernelFixed8(n, sigma);
+  int r = n / 2;
+  int w = src.w, h = src.h;
+  std::vector<int> tmp((size_t)w * h);
+  for (int y = 0; y < h; ++y) {
+    const uint8_t* S = src.row(y);
+    for (int x = 0; x < w; ++x) {
+      int s = 0;
+      for (int i = -r; i <= r; ++i) s += k[i + r] * S[reflect101(x + i, w)];
+      tmp[(size_t)y * w + x] = s;
+    }
+  }
+  dst = Img8(w, h);
+  for (int y = 0; y < h; ++y) {
+    uint8_t* D = dst.row(y);
+    for (int x = 0; x < w; ++x) {
+      int s = 0;
+      for (int i = -r; i <= r; ++i) s += k[i + r] * tmp[(size_t)reflect101(y + i, h) * w + x];
+      int v = (s + (1 << 15)) >> 16;
+      D[x] = (uint8_t)std::min(std::max(v, 0), 255);
+    }
+  }
+}
+
+// cv::Sobel(src, dst, CV_16S, dx, dy, 3) with BORDER_REFLECT_101, no scaling.
+// Call sites: binary_descriptor_custom.cpp:395-396.
+static inline void sobel3x3_16s(const Img8& src, std::vector<int16_t>& dxI, std::vector<int16_t>& dyI) {
+  int w = src.w, h = src.h;
+  dxI.assign((size_t)w * h, 0);
+  dyI.assign((size_t)w * h, 0);
+  for (int y = 0; y < h; ++y) {
+    const uint8_t* r0 = src.row(reflect101(y - 1, h));
+    const uint8_t* r1 = src.row(y);
+    const uint8_t* r2 = src.row(reflect101(y + 1, h));
+    for (int x = 0; x < w; ++x) {
+      int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
+      int gx = (r0[xp] - r0[xm]) + 2 * (r1[xp] - r1[xm]) + (r2[xp] - r2[xm]);
+      int gy = (r2[xm] - r0[xm]) + 2 * (r2[x] - r0[x]) + (r2[xp] - r0[xp]);
+      dxI[(size_t)y * w + x] = (int16_t)gx;
+      dyI[(size_t)y * w + x] = (int16_t)gy;
+    }
+  }
+}
+
+// FAST-9/16 ring, OpenCV order (makeOffsets for patternSize 16).
+static const int kFastRing[16][2] = {{0, 3},  {1, 3},   {2, 2},   {3, 1},  {3, 0},  {3, -1},
+                                     {2, -2}, {1, -3},  {0, -3},  {-1, -3}, {-2, -2}, {-3, -1},
+                                     {-3, 0}, {-3, 1},  {-2, 2},  {-1, 3}};
+
+// "arc value" of a pixel: max over the 16 arcs of 9 contiguous ring pixels and
+// both polarities of the minimum |centre - ring| difference with a consistent
+// sign.  The pixel is a FAST-9 corner at threshold t iff arc > t, and OpenCV's
+// cornerScore<16> then returns arc - 1 (cv::FAST, features2d/src/fast.cpp and
+// fast_score.cpp in 3.3.1).  Call sites: ORBextractor.cc:808,827.
+static inline int fastArcValue(const uint8_t* p, int stride) {
+  int d[25];
+  int v = p[0];
+  for (int k = 0; k < 16; ++k) d[k] = v - p[kFastRing[k][1] * stride + kFastRing[k][0]];
+  for (int k = 16; k < 25; ++k) d[k] = d[k - 16];
+  int best = -256;
+  for (int k = 0; k < 16; ++k) {
+    int mn = d[k], mx = d[k];
+    for (int j = 1; j < 9; ++j) { mn = std::min(mn, d[k + j]); mx = std::max(mx, d[k + j]); }
+    best = std::max(best, mn);     // all ring pixels darker than centre by at least mn
+    best = std::max(best, -mx);    // all ring pixels brighter than centre by at least -mx
+  }
+  return best;
+}
+
+// cv::LineIterator(img, pt1, pt2).count for 8-connectivity with both points
+// inside the image: max(|dx|,|dy|) + 1 on cvRound-ed endpoints.
+// Call site: LSDDetector_custom.cpp:295-296.
+static inline int lineIteratorCount(float x1, float y1, float x2, float y2) {
+  int ix1 = cvRoundf(x1), iy1 = cvRoundf(y1), ix2 = cvRoundf(x2), iy2 = cvRoundf(y2);
+  int dx = std::abs(ix2 - ix1), dy = std::abs(iy2 - iy1);
+  return std::max(dx, dy) + 1;
+}
+
+}  // namespace orc
