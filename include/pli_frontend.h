@@ -273,8 +273,11 @@ enum {
   PLI_DBG_LSD_SEGMENTS = 7,    /* int32 count then float[4] x1,y1,x2,y2 in detection order  */
   PLI_DBG_LBD_DXDY = 8,        /* int16 dx[w*h] then int16 dy[w*h]                          */
   PLI_DBG_LSD_ORDER = 9,       /* int32 count then int32 pixel index of every seed in visiting order */
-  PLI_DBG_LBD_FLOAT = 10       /* float[n][72] LBD band vector before binarisation          */
+  PLI_DBG_LBD_FLOAT = 10,      /* float[kl_cap][72] LBD band vector before binarisation     */
+  PLI_DBG_STEREO_SAD = 11      /* int32 sad[kp_cap] (-1 = none) then int32 bestIdxR[kp_cap] of the frame */
 };
+/* Keep the extra intermediates (LSD angle map, LBD float vectors, stereo best index) during runs. */
+pli_status pli_debug_enable(pli_ctx* ctx, int32_t on);
 pli_status pli_debug_fetch(pli_ctx* ctx, int32_t image, int32_t what, int32_t arg,
                            void* dst, int64_t dst_bytes, int64_t* out_bytes);
 

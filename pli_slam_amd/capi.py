@@ -1,0 +1,148 @@
+"""ctypes binding of libpli_frontend.so (the C ABI of include/pli_frontend.h).
+
+This is the host-side plumbing used by the tests, bench.py and the Python
+mirror of the reference interface (pli_slam_amd/frontend.py).  There is no CPU
+fallback: if the HIP library is missing or no gfx950 device is visible every
+entry point raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpli_frontend.so")
+
+KEYPOINT_DT = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                        ("response", "<f4"), ("octave", "<i4")])
+KEYLINE_DT = np.dtype([("angle", "<f4"), ("class_id", "<i4"), ("octave", "<i4"), ("pt_x", "<f4"),
+                       ("pt_y", "<f4"), ("response", "<f4"), ("size", "<f4"),
+                       ("startPointX", "<f4"), ("startPointY", "<f4"), ("endPointX", "<f4"),
+                       ("endPointY", "<f4"), ("sPointInOctaveX", "<f4"), ("sPointInOctaveY", "<f4"),
+                       ("ePointInOctaveX", "<f4"), ("ePointInOctaveY", "<f4"), ("lineLength", "<f4"),
+                       ("numOfPixels", "<i4")])
+PROJ_QUERY_DT = np.dtype([("u", "<f4"), ("v", "<f4"), ("radius", "<f4"), ("ur", "<f4"),
+                          ("min_level", "<i4"), ("max_level", "<i4"), ("angle", "<f4"), ("valid", "<i4")])
+
+PLI_OK = 0
+ERRORS = {-1: "PLI_ERR_INVALID", -2: "PLI_ERR_EMPTY_IMAGE", -3: "PLI_ERR_CAPACITY", -4: "PLI_ERR_HIP",
+          -5: "PLI_ERR_NO_DEVICE", -6: "PLI_ERR_STATE"}
+RUN_ORB, RUN_LINES, RUN_STEREO_POINTS, RUN_STEREO_LINES, RUN_ALL = 1, 2, 4, 8, 15
+(DBG_PYRAMID_LEVEL, DBG_BLUR_LEVEL, DBG_FAST_CANDIDATES, DBG_LEVEL_KEYPOINTS, DBG_LSD_SCALED, DBG_LSD_ANGLE,
+ DBG_LSD_SEGMENTS, DBG_LBD_DXDY, DBG_LSD_ORDER, DBG_LBD_FLOAT, DBG_STEREO_SAD) = range(1, 12)
+
+
+class Config(C.Structure):
+    """pli_frontend_config (include/pli_frontend.h)."""
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32), ("max_frames", C.c_int32),
+        ("orb_nfeatures", C.c_int32), ("orb_scale_factor", C.c_float), ("orb_nlevels", C.c_int32),
+        ("orb_ini_th_fast", C.c_int32), ("orb_min_th_fast", C.c_int32),
+        ("lsd_nfeatures", C.c_int32), ("lsd_refine", C.c_int32), ("lsd_n_bins", C.c_int32),
+        ("max_lines", C.c_int32),
+        ("min_line_length", C.c_double), ("lsd_scale", C.c_double), ("lsd_sigma_scale", C.c_double),
+        ("lsd_quant", C.c_double), ("lsd_ang_th", C.c_double), ("lsd_log_eps", C.c_double),
+        ("lsd_density_th", C.c_double),
+        ("bf", C.c_float), ("fx", C.c_float), ("stereo_maxd_inf", C.c_int32),
+        ("matching_s_ws", C.c_int32), ("best_lr_matches", C.c_int32),
+        ("line_sim_th", C.c_double), ("stereo_overlap_th", C.c_double), ("min_ratio_12_l", C.c_double),
+        ("ls_min_disp_ratio", C.c_double), ("min_disp", C.c_double), ("line_horiz_th", C.c_double),
+    ]
+
+
+class TableLayout(C.Structure):
+    """pli_table_layout."""
+    _fields_ = [
+        ("record_bytes", C.c_int64), ("kp_cap", C.c_int32), ("kl_cap", C.c_int32),
+        ("off_counts", C.c_int64), ("off_kp", C.c_int64 * 2), ("off_desc", C.c_int64 * 2),
+        ("off_uright", C.c_int64), ("off_depth", C.c_int64), ("off_kl", C.c_int64 * 2),
+        ("off_ldesc", C.c_int64 * 2), ("off_disp", C.c_int64), ("off_le", C.c_int64),
+    ]
+
+
+class PliError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("%s (%d): %s" % (ERRORS.get(status, "PLI_ERR"), status, msg))
+        self.status = status
+
+
+_lib = None
+
+_PROTOS = {
+    "pli_config_default": (None, [C.POINTER(Config), C.c_int32, C.c_int32]),
+    "pli_kp_capacity": (C.c_int32, [C.POINTER(Config)]),
+    "pli_kl_capacity": (C.c_int32, [C.POINTER(Config)]),
+    "pli_ctx_create": (C.c_int32, [C.POINTER(Config), C.c_int32, C.POINTER(C.c_void_p)]),
+    "pli_ctx_destroy": (None, [C.c_void_p]),
+    "pli_last_error": (C.c_char_p, []),
+    "pli_ctx_layout": (C.c_int32, [C.c_void_p, C.POINTER(TableLayout)]),
+    "pli_ctx_set_stream": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "pli_ctx_sync": (C.c_int32, [C.c_void_p]),
+    "pli_batch_run": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_uint32,
+                                  C.c_void_p]),
+    "pli_batch_run_host": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                       C.c_uint32, C.c_void_p]),
+    "pli_orb_extract": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p,
+                                    C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]),
+    "pli_orb_pyramid_level": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
+                                          C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "pli_line_extract": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p,
+                                     C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]),
+    "pli_stereo_match_points": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "pli_stereo_match_lines": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "pli_descriptor_distance": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "pli_hamming_knn2": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                     C.c_void_p]),
+    "pli_match_lines": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_void_p,
+                                    C.POINTER(C.c_int32)]),
+    "pli_search_by_projection": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
+                                             C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]),
+    "pli_prof_enable": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "pli_prof_reset": (C.c_int32, [C.c_void_p]),
+    "pli_prof_report": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "pli_debug_enable": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "pli_debug_fetch": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
+                                    C.POINTER(C.c_int64)]),
+    "pli_version": (C.c_char_p, []),
+}
+
+
+def exported_symbols():
+    """Names include/pli_frontend.h declares (used by the CPU-side ABI test)."""
+    return sorted(_PROTOS)
+
+
+def lib():
+    """Load libpli_frontend.so; raise if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libpli_frontend.so is not built (python -c 'import __graft_entry__ as g; g.build()'); "
+                               "the front-end has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != PLI_OK:
+        raise PliError(status, lib().pli_last_error().decode("utf-8", "replace"))
+
+
+def default_config(width, height, **over):
+    c = Config()
+    lib().pli_config_default(C.byref(c), width, height)
+    for k, v in over.items():
+        if not hasattr(c, k):
+            raise AttributeError(k)
+        setattr(c, k, v)
+    return c
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None

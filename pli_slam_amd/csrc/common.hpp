@@ -1,0 +1,64 @@
+// Shared host/device declarations of the MI355X point+line front-end.
+// gfx950 only: wave64, no CUDA compatibility paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <map>
+#include "../../include/pli_frontend.h"
+
+namespace pli {
+
+constexpr int MAX_LEVELS = 16;
+constexpr int CELL_CAP = 512;          // FAST survivors a 30..60 px cell can hold after NMS
+constexpr int GRID_COLS = 64;          // FRAME_GRID_COLS, Frame.h:60
+constexpr int GRID_ROWS = 48;          // FRAME_GRID_ROWS, Frame.h:59
+
+// Geometry of one pyramid level and of its FAST cell grid
+// (ORBextractor.cc:763-806 restated once on the host).
+struct LevelGeom {
+  int w, h, pitch;           // level image
+  int64_t offset;            // byte offset of the level inside one image's pyramid block
+  int minBX, minBY, maxBX, maxBY;
+  int nCols, nRows, wCell, hCell;
+  int cellBase;              // index of this level's first cell in the per-image cell array
+  int nfeatures;             // mnFeaturesPerLevel
+  int kpBase;                // first slot of this level in the per-image keypoint slot array
+  int kpCap;                 // slots (nfeatures + 4)
+  int candBase;              // first entry of this level in the per-image candidate array
+  int candCap;
+  float scale, invScale;     // mvScaleFactor, mvInvScaleFactor
+  int nIni;                  // quadtree root nodes
+  float hX;
+};
+
+// Everything the kernels need to know about the configuration, by value.
+struct DevParams {
+  int W, H;                  // input image
+  int nlevels;
+  int iniTh, minTh;
+  LevelGeom lv[MAX_LEVELS];
+  int cellsPerImage, kpSlotsPerImage, candPerImage;
+  int64_t pyrBlock;          // bytes of one image's pyramid (levels 1..n-1; level 0 aliases the input)
+  int kpCap, klCap;
+  int umax[16];
+  // LSD
+  int LW, LH, lpitch;        // scaled image
+  int g2Thresh;              // defined  <=>  g2 > g2Thresh   (norm > rho)
+  int nBins;
+  int minRegSize;
+  double prec, lsdScale;
+  int maxLines;
+  int lsdNFeatures;
+  double minLength;
+  // stereo
+  float bf, maxD;
+  // line matching
+  int sWs, bestLR;
+  double lineSimTh, overlapTh, ratio12L, minDispRatio, minDisp, horizTh;
+};
+
+}  // namespace pli

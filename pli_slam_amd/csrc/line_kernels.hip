@@ -1,0 +1,545 @@
+// Line front-end kernels for gfx950 (wave64): LSD segment detection + LBD.
+//
+//   (k_blur, k_resize_level from orb_kernels.hip do LSD's 7x7 sigma-0.6 blur and x1.2 resize)
+//   k_lsd_grad      ll_angle: 2x2 gradient, level-line angle, max gradient   (OpenCV lsd.cpp)
+//   k_lsd_hist/scan/scatter   the 1024-bin ordering of seed pixels (bin desc, raster asc)
+//   k_lsd_grow      region_grow + region2rect, refine = NONE
+//   k_keylines      LSDDetectorC::detectImpl KeyLine fill + Lineextractor top-N
+//                   (LSDDetector_custom.cpp:264-308, LineExtractor.cc:53-65)
+//   k_sobel         cv::Sobel 3x3 dx/dy -> i16            (binary_descriptor_custom.cpp:395-396)
+//   k_lbd           BinaryDescriptor::computeLBD + binaryConversion
+//                   (binary_descriptor_custom.cpp:1026-1340, 401-412, 662-666)
+#include "kernels.hpp"
+#include "device_prims.hpp"
+
+namespace pli {
+
+constexpr float LSD_NOTDEF = -1024.f;
+constexpr double D_PI = 3.14159265358979323846;
+constexpr double D_DEG2RAD = D_PI / 180;
+constexpr double D_3_2_PI = (3 * D_PI) / 2;
+constexpr double D_2PI = 2 * D_PI;
+
+// ---------------------------------------------------------------------------
+// k_lsd_grad.  One thread per pixel of the scaled image.
+// ang : level-line angle in degrees (cv::fastAtan2) or -1024 (NOTDEF); the
+//       region grower later overwrites claimed pixels with -1024 (= USED).
+// g2  : gx^2+gy^2 (modgrad = sqrt(g2/4)), 0 on the undefined border.
+// cs  : (float)cos / (float)sin of (float)angle_rad, what region_grow adds per pixel.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ scaled, int64_t imgStride, int W, int H,
+                                                  int pitch, int g2Thresh, float* __restrict__ ang,
+                                                  int* __restrict__ g2o, float2* __restrict__ cs,
+                                                  int* __restrict__ maxG2, float* __restrict__ angDbg, int img0) {
+  const int img = blockIdx.z + img0;
+  const int y = blockIdx.y;
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  int g2 = 0;
+  bool defined = false;
+  if (x < W) {
+    float a = LSD_NOTDEF;
+    float2 c = make_float2(0.f, 0.f);
+    if (x < W - 1 && y < H - 1) {
+      const uint8_t* r0 = scaled + (int64_t)img * imgStride + (int64_t)y * pitch;
+      const uint8_t* r1 = r0 + pitch;
+      int DA = (int)r1[x + 1] - (int)r0[x];
+      int BC = (int)r0[x + 1] - (int)r1[x];
+      int gx = DA + BC, gy = DA - BC;
+      g2 = gx * gx + gy * gy;
+      defined = g2 > g2Thresh;
+      if (defined) {
+        a = fast_atan2_deg((float)gx, (float)(-gy));
+        double ad = (double)a * D_DEG2RAD;
+        double af = (double)(float)ad;
+        c.x = (float)cos(af);
+        c.y = (float)sin(af);
+      }
+    }
+    const int64_t o = (int64_t)img * W * H + (int64_t)y * W + x;
+    ang[o] = a;
+    g2o[o] = g2;
+    cs[o] = c;
+    if (angDbg) angDbg[o] = a;
+  }
+  int m = defined ? g2 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(&maxG2[img], m);
+}
+
+__device__ __forceinline__ int lsd_bin(int g2, double binCoef) {
+  double norm = sqrt((double)g2 / 4.0);
+  return (int)(norm * binCoef);
+}
+__device__ __forceinline__ double lsd_bin_coef(int maxG2, int nBins) {
+  double maxGrad = sqrt((double)maxG2 / 4.0);
+  return maxG2 > 0 ? (double)(nBins - 1) / maxGrad : 0.0;
+}
+
+constexpr int LSD_CHUNK = 1024;
+
+// per-chunk histogram of the bins of the defined pixels
+__global__ __launch_bounds__(256) void k_lsd_hist(const int* __restrict__ g2a, int npix, int g2Thresh, int nBins,
+                                                  const int* __restrict__ maxG2, unsigned short* __restrict__ chunkHist,
+                                                  int nChunks, int img0) {
+  __shared__ int h[1024];
+  const int img = blockIdx.y + img0, chunk = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < nBins; i += 256) h[i] = 0;
+  __syncthreads();
+  const double bc = lsd_bin_coef(maxG2[img], nBins);
+  const int* g = g2a + (int64_t)img * npix;
+  for (int k = 0; k < LSD_CHUNK / 256; ++k) {
+    int i = chunk * LSD_CHUNK + k * 256 + tid;
+    if (i < npix) {
+      int v = g[i];
+      if (v > g2Thresh) atomicAdd(&h[lsd_bin(v, bc)], 1);
+    }
+  }
+  __syncthreads();
+  unsigned short* out = chunkHist + ((int64_t)img * nChunks + chunk) * nBins;
+  for (int i = tid; i < nBins; i += 256) out[i] = (unsigned short)h[i];
+}
+
+// per image: chunkBase[chunk][bin] = start of that chunk's pixels of that bin in the ordered list
+__global__ __launch_bounds__(1024) void k_lsd_scan(const unsigned short* __restrict__ chunkHist, int nChunks, int nBins,
+                                                   int* __restrict__ chunkBase, int* __restrict__ nDefined, int img0) {
+  __shared__ int tot[1024];
+  __shared__ int start[1024];
+  const int img = blockIdx.x + img0, b = threadIdx.x;
+  const unsigned short* hin = chunkHist + (int64_t)img * nChunks * nBins;
+  int* cb = chunkBase + (int64_t)img * nChunks * nBins;
+  int run = 0;
+  if (b < nBins) {
+    for (int c = 0; c < nChunks; ++c) {
+      int v = hin[(int64_t)c * nBins + b];
+      cb[(int64_t)c * nBins + b] = run;
+      run += v;
+    }
+  }
+  tot[b] = b < nBins ? run : 0;
+  __syncthreads();
+  if (b == 0) {
+    int acc = 0;
+    for (int k = nBins - 1; k >= 0; --k) { start[k] = acc; acc += tot[k]; }   // bins in descending order
+    nDefined[img] = acc;
+  }
+  __syncthreads();
+  if (b < nBins) {
+    int s = start[b];
+    for (int c = 0; c < nChunks; ++c) cb[(int64_t)c * nBins + b] += s;
+  }
+}
+
+// stable scatter: one wave per chunk walks its 1024 pixels in raster order
+__global__ __launch_bounds__(64) void k_lsd_scatter(const int* __restrict__ g2a, int npix, int g2Thresh, int nBins,
+                                                    const int* __restrict__ maxG2, const int* __restrict__ chunkBase,
+                                                    int nChunks, int* __restrict__ order, int img0) {
+  __shared__ int base[1024];
+  const int img = blockIdx.y + img0, chunk = blockIdx.x, lane = threadIdx.x;
+  const int* cb = chunkBase + ((int64_t)img * nChunks + chunk) * nBins;
+  for (int i = lane; i < nBins; i += 64) base[i] = cb[i];
+  __syncthreads();
+  const double bc = lsd_bin_coef(maxG2[img], nBins);
+  const int* g = g2a + (int64_t)img * npix;
+  int* ord = order + (int64_t)img * npix;
+  for (int it = 0; it < LSD_CHUNK / 64; ++it) {
+    int i = chunk * LSD_CHUNK + it * 64 + lane;
+    bool def = false;
+    int bin = -1;
+    if (i < npix) {
+      int v = g[i];
+      def = v > g2Thresh;
+      if (def) bin = lsd_bin(v, bc);
+    }
+    unsigned long long todo = __ballot(def);
+    int rank = 0, cnt = 0;
+    bool last = false;
+    while (todo) {
+      int leader = __ffsll((long long)todo) - 1;
+      int b = __shfl(bin, leader, 64);
+      unsigned long long m = __ballot(def && bin == b);
+      if (def && bin == b) {
+        rank = __popcll(m & ((1ull << lane) - 1ull));
+        cnt = __popcll(m);
+        last = (m >> lane) == 1ull;
+      }
+      todo &= ~m;
+    }
+    if (def) ord[base[bin] + rank] = i;
+    __syncthreads();
+    if (def && last) base[bin] += cnt;
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_lsd_grow: region_grow + region2rect.  v1: one walker (lane 0) per image,
+// visiting the ordered seeds serially exactly like the CPU algorithm.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double lsd_angle_diff(double a, double b) {
+  double diff = a - b;
+  while (diff <= -D_PI) diff += D_2PI;
+  while (diff > D_PI) diff -= D_2PI;
+  return fabs(diff);
+}
+
+__device__ void lsd_walk(int W, int H, float* __restrict__ ang, const int* __restrict__ g2a,
+                         const float2* __restrict__ cs, const int* __restrict__ order, int nOrder,
+                         int* __restrict__ reg, int minRegSize, double prec, double scale, float* __restrict__ seg,
+                         int* __restrict__ segRank, int maxSeg, int* nSegOut) {
+  int nseg = 0;
+  for (int i = 0; i < nOrder; ++i) {
+    const int sp = order[i];
+    const float sa = ang[sp];
+    if (sa == LSD_NOTDEF) continue;
+    double reg_angle = (double)sa * D_DEG2RAD;
+    reg[0] = sp;
+    int cnt = 1;
+    float sumdx = (float)cos(reg_angle);
+    float sumdy = (float)sin(reg_angle);
+    ang[sp] = LSD_NOTDEF;
+    for (int k = 0; k < cnt; ++k) {
+      const int p = reg[k];
+      const int py = p / W, px = p - py * W;
+      const int xx_min = max(px - 1, 0), xx_max = min(px + 1, W - 1);
+      const int yy_min = max(py - 1, 0), yy_max = min(py + 1, H - 1);
+      for (int yy = yy_min; yy <= yy_max; ++yy)
+        for (int xx = xx_min; xx <= xx_max; ++xx) {
+          const int q = yy * W + xx;
+          const float a = ang[q];
+          if (a == LSD_NOTDEF) continue;             // undefined or already used
+          double n_theta = reg_angle - (double)a * D_DEG2RAD;
+          if (n_theta < 0) n_theta = -n_theta;
+          if (n_theta > D_3_2_PI) {
+            n_theta -= D_2PI;
+            if (n_theta < 0) n_theta = -n_theta;
+          }
+          if (n_theta <= prec) {
+            ang[q] = LSD_NOTDEF;
+            reg[cnt++] = q;
+            const float2 c = cs[q];
+            sumdx = __fadd_rn(sumdx, c.x);
+            sumdy = __fadd_rn(sumdy, c.y);
+            reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * D_DEG2RAD;
+          }
+        }
+    }
+    if (cnt < minRegSize) continue;
+    // region2rect
+    double x = 0, y = 0, sum = 0;
+    for (int k = 0; k < cnt; ++k) {
+      const int p = reg[k];
+      const int py = p / W, px = p - py * W;
+      const double w = sqrt((double)g2a[p] / 4.0);
+      x += (double)px * w;
+      y += (double)py * w;
+      sum += w;
+    }
+    x /= sum;
+    y /= sum;
+    double Ixx = 0.0, Iyy = 0.0, Ixy = 0.0;
+    for (int k = 0; k < cnt; ++k) {
+      const int p = reg[k];
+      const int py = p / W, px = p - py * W;
+      const double w = sqrt((double)g2a[p] / 4.0);
+      const double dx = (double)px - x, dy = (double)py - y;
+      Ixx += dy * dy * w;
+      Iyy += dx * dx * w;
+      Ixy -= dx * dy * w;
+    }
+    const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
+    double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)fast_atan2_deg((float)(lambda - Ixx), (float)Ixy)
+                                           : (double)fast_atan2_deg((float)Ixy, (float)(lambda - Iyy));
+    theta *= D_DEG2RAD;
+    if (lsd_angle_diff(theta, reg_angle) > prec) theta += D_PI;
+    const double dx = cos(theta), dy = sin(theta);
+    double l_min = 0, l_max = 0;
+    for (int k = 0; k < cnt; ++k) {
+      const int p = reg[k];
+      const int py = p / W, px = p - py * W;
+      const double l = ((double)px - x) * dx + ((double)py - y) * dy;
+      if (l > l_max) l_max = l;
+      else if (l < l_min) l_min = l;
+    }
+    double x1 = x + l_min * dx, y1 = y + l_min * dy, x2 = x + l_max * dx, y2 = y + l_max * dy;
+    x1 += 0.5; y1 += 0.5; x2 += 0.5; y2 += 0.5;
+    if (scale != 1) { x1 /= scale; y1 /= scale; x2 /= scale; y2 /= scale; }
+    if (nseg < maxSeg) {
+      seg[4 * nseg + 0] = (float)x1;
+      seg[4 * nseg + 1] = (float)y1;
+      seg[4 * nseg + 2] = (float)x2;
+      seg[4 * nseg + 3] = (float)y2;
+      if (segRank) segRank[nseg] = i;
+    }
+    ++nseg;
+  }
+  *nSegOut = nseg < maxSeg ? nseg : maxSeg;
+}
+
+__global__ __launch_bounds__(64) void k_lsd_grow(const DevParams* __restrict__ Pp, float* __restrict__ ang,
+                                                 const int* __restrict__ g2a, const float2* __restrict__ cs,
+                                                 const int* __restrict__ order, const int* __restrict__ nDefined,
+                                                 int* __restrict__ regScratch, float* __restrict__ seg,
+                                                 int* __restrict__ nSeg, int maxSeg, int img0) {
+  const DevParams& P = *Pp;
+  const int img = blockIdx.x + img0;
+  if (threadIdx.x != 0) return;
+  const int64_t npix = (int64_t)P.LW * P.LH;
+  lsd_walk(P.LW, P.LH, ang + img * npix, g2a + img * npix, cs + img * npix, order + img * npix, nDefined[img],
+           regScratch + img * npix, P.minRegSize, P.prec, P.lsdScale, seg + (int64_t)img * maxSeg * 4, nullptr, maxSeg,
+           &nSeg[img]);
+}
+
+// ---------------------------------------------------------------------------
+// k_keylines: one workgroup per image.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_keylines(const DevParams* __restrict__ Pp, const float* __restrict__ seg,
+                                                  const int* __restrict__ nSeg, int maxSeg,
+                                                  pli_keyline* __restrict__ tmpKL, uint8_t* __restrict__ table,
+                                                  int64_t recordBytes, int64_t offCounts, int64_t offKl0,
+                                                  int64_t offKl1, int img0) {
+  __shared__ int s_wc[4];
+  __shared__ int s_base;
+  __shared__ float resp[4096];
+  const DevParams& P = *Pp;
+  const int img = blockIdx.x + img0, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int n = nSeg[img];
+  const float* sg = seg + (int64_t)img * maxSeg * 4;
+  pli_keyline* tk = tmpKL + (int64_t)img * P.maxLines;
+  const int imgW = P.W, imgH = P.H;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < n; c0 += 256) {
+    const int i = c0 + tid;
+    bool keep = false;
+    pli_keyline kl;
+    if (i < n) {
+      float e0 = sg[4 * i], e1 = sg[4 * i + 1], e2 = sg[4 * i + 2], e3 = sg[4 * i + 3];
+      if (e0 < 0) e0 = 0;
+      if (e0 >= imgW) e0 = (float)imgW - 1.0f;
+      if (e2 < 0) e2 = 0;
+      if (e2 >= imgW) e2 = (float)imgW - 1.0f;
+      if (e1 < 0) e1 = 0;
+      if (e1 >= imgH) e1 = (float)imgH - 1.0f;
+      if (e3 < 0) e3 = 0;
+      if (e3 >= imgH) e3 = (float)imgH - 1.0f;
+      const double ddx = (double)__fsub_rn(e0, e2), ddy = (double)__fsub_rn(e1, e3);
+      const double length = (double)(float)sqrt(ddx * ddx + ddy * ddy);
+      keep = length > P.minLength;
+      if (keep) {
+        kl.startPointX = e0; kl.startPointY = e1; kl.endPointX = e2; kl.endPointY = e3;
+        kl.sPointInOctaveX = e0; kl.sPointInOctaveY = e1; kl.ePointInOctaveX = e2; kl.ePointInOctaveY = e3;
+        kl.lineLength = (float)length;
+        const int ix1 = cv_round_f(e0), iy1 = cv_round_f(e1), ix2 = cv_round_f(e2), iy2 = cv_round_f(e3);
+        kl.numOfPixels = max(abs(ix2 - ix1), abs(iy2 - iy1)) + 1;
+        kl.angle = (float)atan2((double)__fsub_rn(e3, e1), (double)__fsub_rn(e2, e0));
+        kl.octave = 0;
+        kl.size = __fmul_rn(__fsub_rn(e2, e0), __fsub_rn(e3, e1));
+        kl.response = __fdiv_rn(kl.lineLength, (float)max(imgW, imgH));
+        kl.pt_x = __fdiv_rn(__fadd_rn(e2, e0), 2.f);
+        kl.pt_y = __fdiv_rn(__fadd_rn(e3, e1), 2.f);
+      }
+    }
+    unsigned long long bal = __ballot(keep);
+    if (lane == 0) s_wc[wv] = __popcll(bal);
+    __syncthreads();
+    int pre = s_base;
+    for (int k = 0; k < wv; ++k) pre += s_wc[k];
+    const int pos = pre + __popcll(bal & ((1ull << lane) - 1ull));
+    if (keep && pos < P.maxLines) {
+      kl.class_id = pos;
+      tk[pos] = kl;
+    }
+    __syncthreads();
+    if (tid == 0) s_base += s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
+    __syncthreads();
+  }
+  const int M = min(s_base, P.maxLines);
+  uint8_t* rec = table + (int64_t)(img >> 1) * recordBytes;
+  const int eye = img & 1;
+  pli_keyline* out = reinterpret_cast<pli_keyline*>(rec + (eye ? offKl1 : offKl0));
+  const int nf = P.lsdNFeatures;
+  __threadfence_block();
+  __syncthreads();
+  if (M > nf && nf != 0) {
+    // top-N by response, equal responses keep detection order (stable)
+    for (int i = tid; i < M; i += 256) resp[i] = tk[i].response;
+    __syncthreads();
+    for (int i = tid; i < M; i += 256) {
+      const float r = resp[i];
+      int rank = 0;
+      for (int j = 0; j < M; ++j) {
+        const float rj = resp[j];
+        rank += (rj > r || (rj == r && j < i)) ? 1 : 0;
+      }
+      if (rank < nf) {
+        pli_keyline kl = tk[i];
+        kl.class_id = rank;
+        out[rank] = kl;
+      }
+    }
+    if (tid == 0) reinterpret_cast<int*>(rec + offCounts)[2 + eye] = nf;
+  } else {
+    const int cnt = min(M, P.klCap);
+    for (int i = tid; i < cnt; i += 256) out[i] = tk[i];
+    if (tid == 0) reinterpret_cast<int*>(rec + offCounts)[2 + eye] = cnt;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_sobel: 3x3 Sobel dx, dy (CV_16S) with REFLECT_101 on the blurred image.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sobel(const uint8_t* __restrict__ in, int64_t imgStride, int W, int H,
+                                               int pitch, short* __restrict__ dxo, short* __restrict__ dyo, int img0) {
+  const int img = blockIdx.z + img0, y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= W) return;
+  const uint8_t* base = in + (int64_t)img * imgStride;
+  const uint8_t* r0 = base + (int64_t)reflect101(y - 1, H) * pitch;
+  const uint8_t* r1 = base + (int64_t)y * pitch;
+  const uint8_t* r2 = base + (int64_t)reflect101(y + 1, H) * pitch;
+  const int xm = reflect101(x - 1, W), xp = reflect101(x + 1, W);
+  const int gx = ((int)r0[xp] - (int)r0[xm]) + 2 * ((int)r1[xp] - (int)r1[xm]) + ((int)r2[xp] - (int)r2[xm]);
+  const int gy = ((int)r2[xm] - (int)r0[xm]) + 2 * ((int)r2[x] - (int)r0[x]) + ((int)r2[xp] - (int)r0[xp]);
+  const int64_t o = (int64_t)img * W * H + (int64_t)y * W + x;
+  dxo[o] = (short)gx;
+  dyo[o] = (short)gy;
+}
+
+// ---------------------------------------------------------------------------
+// k_lbd: one wave per line.  Lane h walks row h of the 63-row line support
+// region sequentially (the reference accumulates coordinates and row sums in
+// float, so the order is part of the result); band sums are then accumulated
+// in ascending row order, one lane per (band, quantity).
+// ---------------------------------------------------------------------------
+__constant__ int c_lbd_comb[32][2] = {
+    {0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}, {0, 6}, {1, 2}, {1, 3}, {1, 4}, {1, 5}, {1, 6},
+    {2, 3}, {2, 4}, {2, 5}, {2, 6}, {2, 7}, {2, 8}, {3, 4}, {3, 5}, {3, 6}, {3, 7}, {3, 8},
+    {4, 5}, {4, 6}, {4, 7}, {4, 8}, {5, 6}, {5, 7}, {5, 8}, {6, 7}, {6, 8}, {7, 8}};
+
+
+__global__ __launch_bounds__(64) void k_lbd(const DevParams* __restrict__ Pp, const LbdCoef* __restrict__ coef,
+                                            const short* __restrict__ dxa, const short* __restrict__ dya,
+                                            uint8_t* __restrict__ table, int64_t recordBytes, int64_t offCounts,
+                                            int64_t offKl0, int64_t offKl1, int64_t offLd0, int64_t offLd1,
+                                            float* __restrict__ dbgFloat, int img0) {
+  __shared__ float rowS[63][4];      // pgdL, ngdL, pgdO, ngdO row sums (already x gaussCoefG)
+  __shared__ float band[9][8];       // pgdL, ngdL, pgdL2, ngdL2, pgdO, ngdO, pgdO2, ngdO2
+  __shared__ float des[72];
+  const DevParams& P = *Pp;
+  const int img = blockIdx.y + img0, li = blockIdx.x, lane = threadIdx.x;
+  uint8_t* rec = table + (int64_t)(img >> 1) * recordBytes;
+  const int eye = img & 1;
+  const int n = reinterpret_cast<const int*>(rec + offCounts)[2 + eye];
+  if (li >= n) return;
+  const pli_keyline kl = reinterpret_cast<const pli_keyline*>(rec + (eye ? offKl1 : offKl0))[li];
+  const int W = P.W, H = P.H;
+  const short* pdx = dxa + (int64_t)img * W * H;
+  const short* pdy = dya + (int64_t)img * W * H;
+  const short heightOfLSP = 63, halfHeight = 31;
+  const short imageWidth = (short)(W - 1), imageHeight = (short)(H - 1);
+  const short lengthOfLSP = (short)kl.numOfPixels;
+  const short halfWidth = (short)((lengthOfLSP - 1) / 2);
+  const float midX = (float)(0.5 * ((double)__fadd_rn(kl.sPointInOctaveX, kl.ePointInOctaveX)));
+  const float midY = (float)(0.5 * ((double)__fadd_rn(kl.sPointInOctaveY, kl.ePointInOctaveY)));
+  const float dL0 = (float)cos((double)kl.angle), dL1 = (float)sin((double)kl.angle);
+  const float dO0 = -dL1, dO1 = dL0;
+  if (lane < heightOfLSP) {
+    float sCorX0 = __fadd_rn(__fadd_rn(__fmul_rn(-dL0, (float)halfWidth), __fmul_rn(dL1, (float)halfHeight)), midX);
+    float sCorY0 = __fadd_rn(__fsub_rn(__fmul_rn(-dL1, (float)halfWidth), __fmul_rn(dL0, (float)halfHeight)), midY);
+    for (int h = 0; h < lane; ++h) {
+      sCorX0 = __fsub_rn(sCorX0, dL1);
+      sCorY0 = __fadd_rn(sCorY0, dL0);
+    }
+    float sCorX = sCorX0, sCorY = sCorY0;
+    float pgdL = 0, ngdL = 0, pgdO = 0, ngdO = 0;
+    for (short wID = 0; wID < lengthOfLSP; wID++) {
+      short tempCor = (short)roundf(sCorX);
+      short xCor = (tempCor < 0) ? 0 : (tempCor > imageWidth) ? imageWidth : tempCor;
+      tempCor = (short)roundf(sCorY);
+      short yCor = (tempCor < 0) ? 0 : (tempCor > imageHeight) ? imageHeight : tempCor;
+      const float dx = (float)pdx[(int)yCor * W + xCor];
+      const float dy = (float)pdy[(int)yCor * W + xCor];
+      const float gDL = __fadd_rn(__fmul_rn(dx, dL0), __fmul_rn(dy, dL1));
+      const float gDO = __fadd_rn(__fmul_rn(dx, dO0), __fmul_rn(dy, dO1));
+      if (gDL > 0) pgdL = __fadd_rn(pgdL, gDL); else ngdL = __fsub_rn(ngdL, gDL);
+      if (gDO > 0) pgdO = __fadd_rn(pgdO, gDO); else ngdO = __fsub_rn(ngdO, gDO);
+      sCorX = __fadd_rn(sCorX, dL0);
+      sCorY = __fadd_rn(sCorY, dL1);
+    }
+    const float cg = coef->G[lane];
+    rowS[lane][0] = __fmul_rn(cg, pgdL);
+    rowS[lane][1] = __fmul_rn(cg, ngdL);
+    rowS[lane][2] = __fmul_rn(cg, pgdO);
+    rowS[lane][3] = __fmul_rn(cg, ngdO);
+  }
+  __syncthreads();
+  for (int i = lane; i < 72; i += 64) {
+    const int b = i >> 3, t = i & 7;
+    // t: 0 pgdL 1 ngdL 2 pgdL2 3 ngdL2 4 pgdO 5 ngdO 6 pgdO2 7 ngdO2
+    const int src = (t & 1) + ((t & 4) ? 2 : 0);
+    const bool sq = (t & 2) != 0;
+    float acc = 0;
+    const int h0 = max(0, (b - 1) * 7), h1 = min(62, (b + 2) * 7 - 1);
+    for (int h = h0; h <= h1; ++h) {
+      const int hb = h / 7;
+      const int off = (hb == b) ? 7 : (hb == b + 1 ? 14 : 0);   // own band / row below feeds the band above / row above feeds the band below
+      const float c = coef->L[h % 7 + off];
+      const float r = rowS[h][src];
+      if (sq) acc = __fadd_rn(acc, __fmul_rn(__fmul_rn(c, c), __fmul_rn(r, r)));
+      else acc = __fadd_rn(acc, __fmul_rn(c, r));
+    }
+    band[b][t] = acc;
+  }
+  __syncthreads();
+  const float invN2 = (float)(1.0 / (7 * 2.0)), invN3 = (float)(1.0 / (7 * 3.0));
+  for (int i = lane; i < 72; i += 64) {
+    const int b = i >> 3, j = i & 7;
+    const float invN = (b == 0 || b == 8) ? invN2 : invN3;
+    // des index j: 0 mean pgdL, 1 mean ngdL, 2 mean pgdO, 3 mean ngdO, 4..7 the matching std
+    const int m = j & 3;
+    const int lin = (m & 1) + ((m & 2) ? 4 : 0);       // band[] index of the linear sum
+    const float temp = __fmul_rn(band[b][lin], invN);
+    float v = temp;
+    if (j >= 4) v = sqrtf(__fsub_rn(__fmul_rn(band[b][lin + 2], invN), __fmul_rn(temp, temp)));
+    des[i] = v;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    float tempM = 0, tempS = 0;
+    for (int i = 0; i < 72; i += 8) {
+      tempM = __fadd_rn(tempM, __fmul_rn(des[i], des[i]));
+      tempM = __fadd_rn(tempM, __fmul_rn(des[i + 1], des[i + 1]));
+      tempM = __fadd_rn(tempM, __fmul_rn(des[i + 2], des[i + 2]));
+      tempM = __fadd_rn(tempM, __fmul_rn(des[i + 3], des[i + 3]));
+      tempS = __fadd_rn(tempS, __fmul_rn(des[i + 4], des[i + 4]));
+      tempS = __fadd_rn(tempS, __fmul_rn(des[i + 5], des[i + 5]));
+      tempS = __fadd_rn(tempS, __fmul_rn(des[i + 6], des[i + 6]));
+      tempS = __fadd_rn(tempS, __fmul_rn(des[i + 7], des[i + 7]));
+    }
+    tempM = __fdiv_rn(1.f, sqrtf(tempM));
+    tempS = __fdiv_rn(1.f, sqrtf(tempS));
+    for (int i = 0; i < 72; ++i) {
+      float v = __fmul_rn(des[i], (i & 4) ? tempS : tempM);
+      if ((double)v > 0.4) v = (float)0.4;
+      des[i] = v;
+    }
+    float temp = 0;
+    for (int i = 0; i < 72; ++i) temp = __fadd_rn(temp, __fmul_rn(des[i], des[i]));
+    temp = __fdiv_rn(1.f, sqrtf(temp));
+    for (int i = 0; i < 72; ++i) des[i] = __fmul_rn(des[i], temp);
+  }
+  __syncthreads();
+  if (dbgFloat) {
+    for (int i = lane; i < 72; i += 64) dbgFloat[((int64_t)img * P.klCap + li) * 72 + i] = des[i];
+  }
+  if (lane < 32) {
+    const float* f1 = &des[8 * c_lbd_comb[lane][0]];
+    const float* f2 = &des[8 * c_lbd_comb[lane][1]];
+    unsigned r = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r |= (f1[i] > f2[i]) ? (1u << i) : 0u;
+    (rec + (eye ? offLd1 : offLd0))[(int64_t)li * 32 + lane] = (uint8_t)r;
+  }
+}
+
+}  // namespace pli

@@ -1,0 +1,587 @@
+// Matching kernels for gfx950 (wave64): 256-bit Hamming by XOR + popcount on
+// 4 x u64, wave-wide argmin by 64-bit key reduction.
+//
+//   k_stereo_points + k_stereo_median   Frame::ComputeStereoMatches        (Frame.cc:976-1154)
+//   k_stereo_lines                      Frame::ComputeStereoMatches_Lines  (Frame.cc:1156-1307)
+//                                       + matchGrid(lines) (LineMatcher.cpp:317-396)
+//                                       + GridStructure/LineIterator (gridStructure.cpp, LineIterator.cpp)
+//   k_distance                          ORBmatcher::DescriptorDistance     (ORBmatcher.cc:2495-2511)
+//   k_knn2, k_ratio, k_mutual           matchNNR / match                   (LineMatcher.cpp:139-229)
+//   k_search_by_projection              ORBmatcher::SearchByProjection(F,F)(ORBmatcher.cc:2179-2323)
+#include "kernels.hpp"
+#include "device_prims.hpp"
+#include <climits>
+
+namespace pli {
+
+__device__ __forceinline__ void load_desc(const uint8_t* p, uint64_t d[4]) {
+  const uint64_t* q = reinterpret_cast<const uint64_t*>(p);
+  d[0] = q[0]; d[1] = q[1]; d[2] = q[2]; d[3] = q[3];
+}
+
+// ---------------------------------------------------------------------------
+// Stereo points: one wave per left keypoint.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_stereo_points(const DevParams* __restrict__ Pp, const uint8_t* __restrict__ pyr,
+                                                      uint8_t* __restrict__ table, int64_t recordBytes,
+                                                      int64_t offCounts, int64_t offKp0, int64_t offKp1,
+                                                      int64_t offDesc0, int64_t offDesc1, int64_t offUr,
+                                                      int64_t offDepth, int* __restrict__ sadOut,
+                                                      int* __restrict__ bestIdxOut) {
+  const DevParams& P = *Pp;
+  const int frame = blockIdx.y, iL = blockIdx.x, lane = threadIdx.x;
+  uint8_t* rec = table + (int64_t)frame * recordBytes;
+  const int* counts = reinterpret_cast<const int*>(rec + offCounts);
+  const int N = counts[0], Nr = counts[1];
+  if (iL >= N) return;
+  const pli_keypoint* kpsL = reinterpret_cast<const pli_keypoint*>(rec + offKp0);
+  const pli_keypoint* kpsR = reinterpret_cast<const pli_keypoint*>(rec + offKp1);
+  const uint8_t* descL = rec + offDesc0;
+  const uint8_t* descR = rec + offDesc1;
+  float* uright = reinterpret_cast<float*>(rec + offUr);
+  float* depth = reinterpret_cast<float*>(rec + offDepth);
+  const pli_keypoint kpL = kpsL[iL];
+  const int levelL = kpL.octave;
+  const float vL = kpL.y, uL = kpL.x;
+  const int rowL = (int)vL;
+  const float maxD = P.maxD, minD = 0.f;
+  const float minU = __fsub_rn(uL, maxD), maxU = __fsub_rn(uL, minD);
+  uint64_t dL[4];
+  load_desc(descL + (int64_t)iL * 32, dL);
+  unsigned long long bestKey = ~0ull;
+  if (!(maxU < 0)) {
+    for (int iR = lane; iR < Nr; iR += 64) {
+      const pli_keypoint kpR = kpsR[iR];
+      const float r = __fmul_rn(2.0f, P.lv[kpR.octave].scale);
+      const int maxr = (int)ceilf(__fadd_rn(kpR.y, r));
+      const int minr = (int)floorf(__fsub_rn(kpR.y, r));
+      if (rowL < minr || rowL > maxr) continue;
+      if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+      const float uR = kpR.x;
+      if (uR >= minU && uR <= maxU) {
+        uint64_t dR[4];
+        load_desc(descR + (int64_t)iR * 32, dR);
+        const int dist = hamming256(dL, dR);
+        if (dist < 100) {     // ORBmatcher::TH_HIGH, strict
+          unsigned long long key = ((unsigned long long)dist << 32) | (unsigned)iR;
+          bestKey = key < bestKey ? key : bestKey;
+        }
+      }
+    }
+  }
+  bestKey = wave_min_u64(bestKey);
+  float outU = -1.f, outD = -1.f;
+  int outSad = -1, outIdx = -1;
+  const int thOrbDist = (100 + 50) / 2;
+  if (bestKey != ~0ull && (int)(bestKey >> 32) < thOrbDist) {
+    const int bestIdxR = (int)(bestKey & 0xFFFFFFFFu);
+    outIdx = bestIdxR;
+    const float uR0 = kpsR[bestIdxR].x;
+    const LevelGeom& G = P.lv[levelL];
+    const float scaleFactor = G.invScale;
+    const float scaleduL = roundf(__fmul_rn(kpL.x, scaleFactor));
+    const float scaledvL = roundf(__fmul_rn(kpL.y, scaleFactor));
+    const float scaleduR0 = roundf(__fmul_rn(uR0, scaleFactor));
+    const int w = 5, L = 5;
+    const int cy = (int)scaledvL, cxl = (int)scaleduL, cxr = (int)scaleduR0;
+    bool ok = !(cy - w < 0 || cy + w + 1 > G.h || cxl - w < 0 || cxl + w + 1 > G.w);
+    const float iniu = __fadd_rn(scaleduR0, (float)(L - w));
+    const float endu = __fadd_rn(scaleduR0, (float)(L + w + 1));
+    if (iniu < 0 || endu >= (float)G.w) ok = false;
+    if (cxr - L - w < 0) ok = false;
+    if (ok) {
+      const uint8_t* imL = pyr + (int64_t)(frame * 2) * P.pyrBlock + G.offset;
+      const uint8_t* imR = pyr + (int64_t)(frame * 2 + 1) * P.pyrBlock + G.offset;
+      const int cL = imL[(int64_t)cy * G.pitch + cxl];
+      // each lane owns up to two pixels of the 11x11 window
+      int aL[2], px[2], py[2];
+      bool act[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        int i = lane + 64 * k;
+        act[k] = i < 121;
+        int dy = act[k] ? i / 11 - w : 0, dx = act[k] ? i % 11 - w : 0;
+        px[k] = dx; py[k] = dy;
+        aL[k] = act[k] ? (int)imL[(int64_t)(cy + dy) * G.pitch + cxl + dx] - cL : 0;
+      }
+      float vDists[11];
+      int bestDist = INT_MAX, bestincR = 0;
+#pragma unroll
+      for (int incR = -L; incR <= L; ++incR) {
+        const int cR = imR[(int64_t)cy * G.pitch + cxr + incR];
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          if (act[k]) {
+            int b = (int)imR[(int64_t)(cy + py[k]) * G.pitch + cxr + incR + px[k]] - cR;
+            s += abs(aL[k] - b);
+          }
+        s = wave_sum_i32(s);
+        const float dist = (float)s;
+        if (dist < (float)bestDist) { bestDist = (int)dist; bestincR = incR; }
+        vDists[L + incR] = dist;
+      }
+      if (!(bestincR == -L || bestincR == L)) {
+        float dist1 = 0, dist2 = 0, dist3 = 0;
+#pragma unroll
+        for (int k = 1; k < 10; ++k)
+          if (k == L + bestincR) { dist1 = vDists[k - 1]; dist2 = vDists[k]; dist3 = vDists[k + 1]; }
+        const float deltaR = __fdiv_rn(__fsub_rn(dist1, dist3),
+                                       __fmul_rn(2.0f, __fsub_rn(__fadd_rn(dist1, dist3), __fmul_rn(2.0f, dist2))));
+        if (!(deltaR < -1 || deltaR > 1)) {
+          float bestuR = __fmul_rn(G.scale, __fadd_rn(__fadd_rn(scaleduR0, (float)bestincR), deltaR));
+          float disparity = __fsub_rn(uL, bestuR);
+          if (disparity >= minD && disparity < maxD) {
+            if (disparity <= 0) {
+              disparity = 0.01f;
+              bestuR = (float)((double)uL - 0.01);
+            }
+            outD = __fdiv_rn(P.bf, disparity);
+            outU = bestuR;
+            outSad = bestDist;
+          }
+        }
+      }
+    }
+  }
+  if (lane == 0) {
+    uright[iL] = outU;
+    depth[iL] = outD;
+    sadOut[(int64_t)frame * P.kpCap + iL] = outSad;
+    if (bestIdxOut) bestIdxOut[(int64_t)frame * P.kpCap + iL] = outIdx;
+  }
+}
+
+// median-based outlier cut (Frame.cc:1140-1153), one workgroup per frame
+__global__ __launch_bounds__(256) void k_stereo_median(const DevParams* __restrict__ Pp, uint8_t* __restrict__ table,
+                                                       int64_t recordBytes, int64_t offCounts, int64_t offUr,
+                                                       int64_t offDepth, const int* __restrict__ sadIn) {
+  extern __shared__ int s_sad[];
+  __shared__ int s_m, s_median, s_left;
+  const DevParams& P = *Pp;
+  const int frame = blockIdx.x, tid = threadIdx.x;
+  uint8_t* rec = table + (int64_t)frame * recordBytes;
+  int* counts = reinterpret_cast<int*>(rec + offCounts);
+  const int N = counts[0];
+  float* uright = reinterpret_cast<float*>(rec + offUr);
+  float* depth = reinterpret_cast<float*>(rec + offDepth);
+  const int* sad = sadIn + (int64_t)frame * P.kpCap;
+  if (tid == 0) { s_m = 0; s_median = -1; s_left = 0; }
+  __syncthreads();
+  int loc = 0;
+  for (int i = tid; i < N; i += 256) {
+    int v = sad[i];
+    s_sad[i] = v;
+    loc += v >= 0;
+  }
+  if (loc) atomicAdd(&s_m, loc);
+  __syncthreads();
+  const int M = s_m;
+  if (M == 0) {
+    if (tid == 0) counts[4] = 0;
+    return;
+  }
+  const int kth = M / 2;
+  for (int i = tid; i < N; i += 256) {
+    const int v = s_sad[i];
+    if (v < 0) continue;
+    int lt = 0, le = 0;
+    for (int j = 0; j < N; ++j) {
+      const int u = s_sad[j];
+      if (u < 0) continue;
+      lt += u < v;
+      le += u <= v;
+    }
+    if (lt <= kth && kth < le) s_median = v;     // all writers store the same value
+  }
+  __syncthreads();
+  const float median = (float)s_median;
+  const float thDist = __fmul_rn(__fmul_rn(1.5f, 1.4f), median);
+  loc = 0;
+  for (int i = tid; i < N; i += 256) {
+    const int v = s_sad[i];
+    if (v < 0) continue;
+    if (!((float)v < thDist)) {
+      uright[i] = -1.f;
+      depth[i] = -1.f;
+    } else ++loc;
+  }
+  if (loc) atomicAdd(&s_left, loc);
+  __syncthreads();
+  if (tid == 0) counts[4] = s_left;
+}
+
+// ---------------------------------------------------------------------------
+// Stereo lines: one workgroup per frame.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void normalize2(double& a, double& b) {
+  const double m = sqrt(a * a + b * b);
+  a /= m;
+  b /= m;
+}
+
+__device__ double line_overlap_stereo(double spl_obs, double epl_obs, double spl_proj, double epl_proj, double horizTh) {
+  double overlap = 1.f;
+  if (fabs(epl_obs - spl_obs) > horizTh) {
+    double sln = fmin(spl_obs, epl_obs);
+    double eln = fmax(spl_obs, epl_obs);
+    double spn = fmin(spl_proj, epl_proj);
+    double epn = fmax(spl_proj, epl_proj);
+    double length = eln - spn;
+    if ((epn < sln) || (spn > eln)) overlap = 0.f;
+    else {
+      if ((epn > eln) && (spn < sln)) overlap = eln - sln;
+      else overlap = fmin(eln, epn) - fmax(sln, spn);
+    }
+    if (length > 0.01f) overlap = overlap / length;
+    else overlap = 0.f;
+    if (overlap > 1.f) overlap = 1.f;
+  }
+  return overlap;
+}
+
+__global__ __launch_bounds__(256) void k_stereo_lines(const DevParams* __restrict__ Pp, uint8_t* __restrict__ table,
+                                                      int64_t recordBytes, int64_t offCounts, int64_t offKl0,
+                                                      int64_t offKl1, int64_t offLd0, int64_t offLd1, int64_t offDisp,
+                                                      int64_t offLe, unsigned long long* __restrict__ maskAll,
+                                                      double* __restrict__ dirAll, short* __restrict__ dmatAll,
+                                                      int* __restrict__ m12All, int* __restrict__ m21All) {
+  const DevParams& P = *Pp;
+  const int frame = blockIdx.x, tid = threadIdx.x;
+  uint8_t* rec = table + (int64_t)frame * recordBytes;
+  int* counts = reinterpret_cast<int*>(rec + offCounts);
+  const int n1 = counts[2], n2 = counts[3];
+  const pli_keyline* KL = reinterpret_cast<const pli_keyline*>(rec + offKl0);
+  const pli_keyline* KR = reinterpret_cast<const pli_keyline*>(rec + offKl1);
+  const uint8_t* descL = rec + offLd0;
+  const uint8_t* descR = rec + offLd1;
+  float* disp = reinterpret_cast<float*>(rec + offDisp);
+  double* le = reinterpret_cast<double*>(rec + offLe);
+  const int cap = P.klCap;
+  unsigned long long* mask = maskAll + (int64_t)frame * cap * GRID_ROWS;
+  double* dir = dirAll + (int64_t)frame * cap * 2;
+  short* dmat = dmatAll + (int64_t)frame * cap * cap;
+  int* m12 = m12All + (int64_t)frame * cap;
+  int* m21 = m21All + (int64_t)frame * cap;
+  for (int i = tid; i < n1; i += 256) {
+    disp[2 * i] = -1.f; disp[2 * i + 1] = -1.f;
+    le[3 * i] = 0.0; le[3 * i + 1] = 0.0; le[3 * i + 2] = 0.0;
+    m12[i] = -1;
+  }
+  if (n1 == 0 || n2 == 0) {
+    if (tid == 0) counts[5] = 0;
+    return;
+  }
+  const double inv_width = (double)GRID_COLS / (double)P.W;
+  const double inv_height = (double)GRID_ROWS / (double)P.H;
+  // right lines: direction + Bresenham cell masks (getLineCoords / LineIterator)
+  for (int i2 = tid; i2 < n2; i2 += 256) {
+    const pli_keyline kl = KR[i2];
+    double vx = (double)__fsub_rn(kl.endPointX, kl.startPointX) * inv_width;
+    double vy = (double)__fsub_rn(kl.endPointY, kl.startPointY) * inv_height;
+    normalize2(vx, vy);
+    dir[2 * i2] = vx; dir[2 * i2 + 1] = vy;
+    unsigned long long* mk = mask + (int64_t)i2 * GRID_ROWS;
+    for (int r = 0; r < GRID_ROWS; ++r) mk[r] = 0ull;
+    double x1 = (double)kl.startPointX * inv_width, y1 = (double)kl.startPointY * inv_height;
+    double x2 = (double)kl.endPointX * inv_width, y2 = (double)kl.endPointY * inv_height;
+    const bool steep = fabs(y2 - y1) > fabs(x2 - x1);
+    if (steep) { double t = x1; x1 = y1; y1 = t; t = x2; x2 = y2; y2 = t; }
+    if (x1 > x2) { double t = x1; x1 = x2; x2 = t; t = y1; y1 = y2; y2 = t; }
+    const double dx = x2 - x1, dy = fabs(y2 - y1);
+    double error = dx / 2.0;
+    const int ystep = (y1 < y2) ? 1 : -1;
+    int x = (int)x1, y = (int)y1;
+    const int maxX = (int)x2;
+    while (x <= maxX) {
+      const int cx = steep ? y : x, cy = steep ? x : y;
+      if (cx >= 0 && cx < GRID_COLS && cy >= 0 && cy < GRID_ROWS) mk[cy] |= 1ull << cx;
+      error -= dy;
+      if (error < 0) { y += ystep; error += dx; }
+      x++;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  // pair distances for candidate pairs passing the direction gate, else -1
+  const int ws = P.sWs;
+  for (int pidx = tid; pidx < n1 * n2; pidx += 256) {
+    const int i1 = pidx / n2, i2 = pidx - i1 * n2;
+    const pli_keyline kl = KL[i1];
+    const int sx = (int)((double)kl.startPointX * inv_width), sy = (int)((double)kl.startPointY * inv_height);
+    const int ex = (int)((double)kl.endPointX * inv_width), ey = (int)((double)kl.endPointY * inv_height);
+    const unsigned long long* mk = mask + (int64_t)i2 * GRID_ROWS;
+    bool cand = false;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int qx = e ? ex : sx, qy = e ? ey : sy;
+      const int min_x = max(0, qx - ws), max_x = min(GRID_COLS, qx + 0 + 1);
+      if (qy >= 0 && qy < GRID_ROWS && max_x > min_x) {
+        const unsigned long long hi = max_x >= 64 ? ~0ull : ((1ull << max_x) - 1ull);
+        const unsigned long long wm = hi & ~((1ull << min_x) - 1ull);
+        cand = cand || ((mk[qy] & wm) != 0ull);
+      }
+    }
+    short d = -1;
+    if (cand) {
+      double vx = (double)(ex - sx), vy = (double)(ey - sy);
+      normalize2(vx, vy);
+      const double dt = vx * dir[2 * i2] + vy * dir[2 * i2 + 1];
+      if (!(fabs(dt) < P.lineSimTh)) {
+        uint64_t a[4], b[4];
+        load_desc(descL + (int64_t)i1 * 32, a);
+        load_desc(descR + (int64_t)i2 * 32, b);
+        d = (short)hamming256(a, b);
+      }
+    }
+    dmat[(int64_t)i1 * cap + i2] = d;
+  }
+  __threadfence_block();
+  __syncthreads();
+  // bestLRMatches: a pair only counts if it lowers the running minimum of its column
+  if (P.bestLR) {
+    for (int i2 = tid; i2 < n2; i2 += 256) {
+      int run = INT_MAX, who = -1;
+      for (int i1 = 0; i1 < n1; ++i1) {
+        const int d = dmat[(int64_t)i1 * cap + i2];
+        if (d < 0) continue;
+        if (d < run) { run = d; who = i1; }
+        else dmat[(int64_t)i1 * cap + i2] = -1;
+      }
+      m21[i2] = who;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  for (int i1 = tid; i1 < n1; i1 += 256) {
+    int best_d = INT_MAX, best_d2 = INT_MAX, best_idx = -1;
+    for (int i2 = 0; i2 < n2; ++i2) {
+      const int d = dmat[(int64_t)i1 * cap + i2];
+      if (d < 0) continue;
+      if (d < best_d) { best_d2 = best_d; best_d = d; best_idx = i2; }
+      else if (d < best_d2) best_d2 = d;
+    }
+    int m = -1;
+    if ((double)best_d < (double)best_d2 * P.ratio12L) m = best_idx;
+    if (P.bestLR && m >= 0 && m21[m] != i1) m = -1;
+    m12[i1] = m;
+  }
+  __threadfence_block();
+  __syncthreads();
+  int loc = 0;
+  for (int i1 = tid; i1 < n1; i1 += 256) {
+    const int i2 = m12[i1];
+    if (i2 < 0) continue;
+    const pli_keyline a = KL[i1], b = KR[i2];
+    const double spl0 = a.startPointX, spl1 = a.startPointY, epl0 = a.endPointX, epl1 = a.endPointY;
+    double l0 = spl1 * 1.0 - 1.0 * epl1, l1 = 1.0 * epl0 - spl0 * 1.0, l2 = spl0 * epl1 - spl1 * epl0;
+    const double nrm = sqrt(l0 * l0 + l1 * l1);
+    l0 = l0 / nrm; l1 = l1 / nrm; l2 = l2 / nrm;
+    double spr0 = b.startPointX, spr1 = b.startPointY, epr0 = b.endPointX, epr1 = b.endPointY;
+    const double overlap = line_overlap_stereo(spl1, epl1, spr1, epr1, P.horizTh);
+    const double nsx = (spr0 * (spl1 - epr1) + epr0 * (spr1 - spl1)) / (spr1 - epr1);
+    spr0 = nsx; spr1 = spl1;
+    const double nex = (spr0 * (epl1 - epr1) + epr0 * (spr1 - epl1)) / (spr1 - epr1);
+    epr0 = nex; epr1 = epl1;
+    double disp_s = spl0 - spr0, disp_e = epl0 - epr0;
+    if (fmin(disp_s, disp_e) / fmax(disp_s, disp_e) < P.minDispRatio) { disp_s = -1.0; disp_e = -1.0; }
+    if (disp_s >= P.minDisp && disp_e >= P.minDisp && fabs(spl1 - epl1) > P.horizTh && fabs(spr1 - epr1) > P.horizTh &&
+        overlap > P.overlapTh) {
+      disp[2 * i1] = (float)disp_s;
+      disp[2 * i1 + 1] = (float)disp_e;
+      le[3 * i1] = l0; le[3 * i1 + 1] = l1; le[3 * i1 + 2] = l2;
+      ++loc;
+    }
+  }
+  __shared__ int s_cnt;
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  if (loc) atomicAdd(&s_cnt, loc);
+  __syncthreads();
+  if (tid == 0) counts[5] = s_cnt;
+}
+
+// ---------------------------------------------------------------------------
+// Stateless matchers on caller tables
+// ---------------------------------------------------------------------------
+__global__ void k_distance(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, int n, int* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t x[4], y[4];
+  load_desc(a + (int64_t)i * 32, x);
+  load_desc(b + (int64_t)i * 32, y);
+  out[i] = hamming256(x, y);
+}
+
+// knnMatch(k=2): one wave per query; ties -> lower train index
+__global__ __launch_bounds__(64) void k_knn2(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t, int nt,
+                                             int* __restrict__ idx, int* __restrict__ dist) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  if (i >= nq) return;
+  uint64_t dq[4];
+  load_desc(q + (int64_t)i * 32, dq);
+  unsigned long long k1 = ~0ull, k2 = ~0ull;
+  for (int j = lane; j < nt; j += 64) {
+    uint64_t dt[4];
+    load_desc(t + (int64_t)j * 32, dt);
+    unsigned long long key = ((unsigned long long)hamming256(dq, dt) << 32) | (unsigned)j;
+    if (key < k1) { k2 = k1; k1 = key; }
+    else if (key < k2) k2 = key;
+  }
+  const unsigned long long m1 = wave_min_u64(k1);
+  const unsigned long long c2 = (k1 == m1) ? k2 : k1;
+  const unsigned long long m2 = wave_min_u64(c2);
+  if (lane == 0) {
+    idx[2 * i] = m1 == ~0ull ? -1 : (int)(m1 & 0xFFFFFFFFu);
+    dist[2 * i] = m1 == ~0ull ? INT_MAX : (int)(m1 >> 32);
+    idx[2 * i + 1] = m2 == ~0ull ? -1 : (int)(m2 & 0xFFFFFFFFu);
+    dist[2 * i + 1] = m2 == ~0ull ? INT_MAX : (int)(m2 >> 32);
+  }
+}
+
+// matchNNR ratio test on knn2 output
+__global__ void k_ratio(const int* __restrict__ idx, const int* __restrict__ dist, int n, int nTrain, float nnr,
+                        int* __restrict__ m) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int r = -1;
+  if (nTrain >= 2 && (float)dist[2 * i] < __fmul_rn((float)dist[2 * i + 1], nnr)) r = idx[2 * i];
+  m[i] = r;
+}
+
+__global__ void k_mutual(int* __restrict__ m12, const int* __restrict__ m21, int n1, int* __restrict__ nmatches) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int ok = 0;
+  if (i < n1) {
+    int i2 = m12[i];
+    if (i2 >= 0 && m21 && m21[i2] != i) { m12[i] = -1; i2 = -1; }
+    ok = i2 >= 0;
+  }
+  unsigned long long b = __ballot(ok);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(nmatches, __popcll(b));
+}
+
+// ---------------------------------------------------------------------------
+// SearchByProjection(CurrentFrame, LastFrame): the queries are consumed in
+// order by one wave because a current keypoint taken by an earlier query is
+// not available to later ones; the 64 lanes scan the current keypoints.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_search_by_projection(const pli_proj_query* __restrict__ q,
+                                                             const uint8_t* __restrict__ qdesc, int nq,
+                                                             const pli_keypoint* __restrict__ kp,
+                                                             const uint8_t* __restrict__ desc,
+                                                             const float* __restrict__ uright, int ncur, float minX,
+                                                             float maxX, float minY, float maxY, int checkOri,
+                                                             int* __restrict__ owner /* ncur */,
+                                                             int* __restrict__ bestIdx2 /* nq */,
+                                                             int* __restrict__ nmatchesOut) {
+  __shared__ int hist[30];
+  __shared__ int keep[30];
+  const int lane = threadIdx.x;
+  const float gwInv = __fdiv_rn((float)GRID_COLS, __fsub_rn(maxX, minX));
+  const float ghInv = __fdiv_rn((float)GRID_ROWS, __fsub_rn(maxY, minY));
+  for (int i = lane; i < ncur; i += 64) owner[i] = -1;
+  for (int i = lane; i < nq; i += 64) bestIdx2[i] = -1;
+  if (lane < 30) hist[lane] = 0;
+  __syncthreads();
+  int nmatches = 0;
+  for (int i = 0; i < nq; ++i) {
+    const pli_proj_query Q = q[i];
+    if (!Q.valid) continue;
+    const float u = Q.u, v = Q.v, radius = Q.radius;
+    if (u < minX || u > maxX) continue;
+    if (v < minY || v > maxY) continue;
+    const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(u, minX), radius), gwInv)));
+    if (nMinCellX >= GRID_COLS) continue;
+    const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(u, minX), radius), gwInv)));
+    if (nMaxCellX < 0) continue;
+    const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(v, minY), radius), ghInv)));
+    if (nMinCellY >= GRID_ROWS) continue;
+    const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(v, minY), radius), ghInv)));
+    if (nMaxCellY < 0) continue;
+    const bool bCheckLevels = (Q.min_level > 0) || (Q.max_level >= 0);
+    uint64_t dq[4];
+    load_desc(qdesc + (int64_t)i * 32, dq);
+    unsigned long long best = ~0ull;
+    for (int i2 = lane; i2 < ncur; i2 += 64) {
+      const pli_keypoint k = kp[i2];
+      const int px = (int)roundf(__fmul_rn(__fsub_rn(k.x, minX), gwInv));
+      const int py = (int)roundf(__fmul_rn(__fsub_rn(k.y, minY), ghInv));
+      if (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) continue;   // PosInGrid
+      if (px < nMinCellX || px > nMaxCellX || py < nMinCellY || py > nMaxCellY) continue;
+      if (bCheckLevels) {
+        if (k.octave < Q.min_level) continue;
+        if (Q.max_level >= 0 && k.octave > Q.max_level) continue;
+      }
+      const float distx = __fsub_rn(k.x, u), disty = __fsub_rn(k.y, v);
+      if (!(fabsf(distx) < radius && fabsf(disty) < radius)) continue;
+      if (owner[i2] >= 0) continue;
+      const float ur2 = uright[i2];
+      if (ur2 > 0) {
+        const float er = fabsf(__fsub_rn(Q.ur, ur2));
+        if (er > radius) continue;
+      }
+      uint64_t d2[4];
+      load_desc(desc + (int64_t)i2 * 32, d2);
+      const int dist = hamming256(dq, d2);
+      if (dist < 256) {
+        // first minimum in the reference's visiting order: cells ix asc, iy asc, then insertion order
+        unsigned long long key = ((unsigned long long)dist << 40) | ((unsigned long long)px << 34) |
+                                 ((unsigned long long)py << 28) | (unsigned long long)i2;
+        best = key < best ? key : best;
+      }
+    }
+    best = wave_min_u64(best);
+    if (best != ~0ull && (int)(best >> 40) <= 100) {
+      const int b2 = (int)(best & 0xFFFFFFFull);
+      if (lane == 0) {
+        owner[b2] = i;
+        if (checkOri) {
+          float rot = __fsub_rn(Q.angle, kp[b2].angle);
+          if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+          int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+          if (bin == 30) bin = 0;
+          if (bin >= 0 && bin < 30) hist[bin]++;
+        }
+      }
+      ++nmatches;
+      __threadfence_block();
+    }
+    __syncthreads();
+  }
+  if (checkOri) {
+    if (lane == 0) {
+      int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+      for (int i = 0; i < 30; i++) {
+        const int s = hist[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+      }
+      if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+      else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+      for (int i = 0; i < 30; ++i) keep[i] = (i == ind1 || i == ind2 || i == ind3);
+    }
+    __syncthreads();
+    int removed = 0;
+    for (int i2 = lane; i2 < ncur; i2 += 64) {
+      const int o = owner[i2];
+      if (o < 0) continue;
+      float rot = __fsub_rn(q[o].angle, kp[i2].angle);
+      if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+      int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+      if (bin == 30) bin = 0;
+      if (!(bin >= 0 && bin < 30 && keep[bin])) { owner[i2] = -1; ++removed; }
+    }
+    removed = wave_sum_i32(removed);
+    nmatches -= removed;
+  }
+  __syncthreads();
+  for (int i2 = lane; i2 < ncur; i2 += 64) {
+    const int o = owner[i2];
+    if (o >= 0) bestIdx2[o] = i2;
+  }
+  if (lane == 0) *nmatchesOut = nmatches;
+}
+
+}  // namespace pli

@@ -1,0 +1,734 @@
+// ORB point front-end kernels for gfx950 (wave64).
+//
+//   k_ingest        input images -> level 0 of the device pyramid
+//   k_resize_level  ORBextractor::ComputePyramid            (ORBextractor.cc:1152-1177)
+//   k_fast_cells    per-cell cv::FAST x2 thresholds + NMS   (ORBextractor.cc:787-854)
+//   k_octree        ORBextractor::DistributeOctTree         (ORBextractor.cc:479-761)
+//   k_blur          cv::GaussianBlur u8 fixed point         (ORBextractor.cc:1115, also LSD/LBD)
+//   k_describe      IC_Angle + computeOrbDescriptor + table (ORBextractor.cc:75-145,1105-1147)
+//
+// All arithmetic that decides a result is integer or explicitly ordered IEEE
+// float (see device_prims.hpp); the library is built with -ffp-contract=off.
+#include "kernels.hpp"
+#include "device_prims.hpp"
+
+namespace pli {
+
+__constant__ signed char c_orb_pattern[1024] = {
+#include "../../include/pli_orb_pattern.inc"
+};
+
+// ---------------------------------------------------------------------------
+// k_ingest: copy nframes x 2 images (arbitrary stride) into level 0.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ingest(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
+                                                int64_t stride, int64_t frameStride, uint8_t* __restrict__ pyr,
+                                                int64_t pyrBlock, int W, int H, int pitch, int img0) {
+  const int img = blockIdx.z + img0;
+  const uint8_t* src = ((img & 1) ? right : left) + (int64_t)(img >> 1) * frameStride;
+  uint8_t* dst = pyr + (int64_t)img * pyrBlock;
+  const int y = blockIdx.y;
+  const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (x4 >= W) return;
+  const uint8_t* s = src + (int64_t)y * stride + x4;
+  uint8_t v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = (x4 + k < W) ? s[k] : 0;
+  *reinterpret_cast<uchar4*>(dst + (int64_t)y * pitch + x4) = make_uchar4(v[0], v[1], v[2], v[3]);
+}
+
+// ---------------------------------------------------------------------------
+// k_resize_level: cv::resize INTER_LINEAR u8 (11-bit coefficients built on the
+// host exactly as OpenCV builds them).  One thread = 4 output pixels.
+// tab: xofs[dw] | alpha[2*dw] (as int) | yofs[dh] | beta[2*dh]
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize_level(const uint8_t* __restrict__ srcBase, int64_t srcImgStride,
+                                                      int sw, int sh, int spitch, uint8_t* __restrict__ dstBase,
+                                                      int64_t dstImgStride, int dw, int dh, int dpitch,
+                                                      const int* __restrict__ tab, int img0) {
+  const int img = blockIdx.z + img0;
+  const int dy = blockIdx.y;
+  const int dx0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (dx0 >= dw) return;
+  const int* xofs = tab;
+  const int* alpha = tab + dw;
+  const int* yofs = tab + 3 * dw;
+  const int* beta = tab + 3 * dw + dh;
+  const uint8_t* src = srcBase + (int64_t)img * srcImgStride;
+  int sy = yofs[dy];
+  int sy0 = sy < 0 ? 0 : (sy >= sh ? sh - 1 : sy);
+  int sy1 = sy + 1 < 0 ? 0 : (sy + 1 >= sh ? sh - 1 : sy + 1);
+  const uint8_t* S0 = src + (int64_t)sy0 * spitch;
+  const uint8_t* S1 = src + (int64_t)sy1 * spitch;
+  const int b0 = beta[2 * dy], b1 = beta[2 * dy + 1];
+  uint8_t out[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int dx = dx0 + k;
+    int v = 0;
+    if (dx < dw) {
+      int sx = xofs[dx];
+      int sx1 = sx + 1 < sw ? sx + 1 : sw - 1;
+      int a0 = alpha[2 * dx], a1 = alpha[2 * dx + 1];
+      int r0 = S0[sx] * a0 + S0[sx1] * a1;
+      int r1 = S1[sx] * a0 + S1[sx1] * a1;
+      v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+      v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    }
+    out[k] = (uint8_t)v;
+  }
+  uint8_t* dst = dstBase + (int64_t)img * dstImgStride + (int64_t)dy * dpitch + dx0;
+  *reinterpret_cast<uchar4*>(dst) = make_uchar4(out[0], out[1], out[2], out[3]);
+}
+
+// ---------------------------------------------------------------------------
+// k_fast_cells: one workgroup per FAST cell.
+// The cell sub-image (<= 66 x 66) is staged in LDS; every thread evaluates the
+// 16-pixel ring of its pixels with two 16-bit sign masks (9-contiguous test by
+// shift-and), the exact corner score only for pixels that pass at minTh; 3x3
+// NMS inside the cell interior; the two-threshold rule; then an ordered
+// (raster) compaction with wave ballots + popcounts.
+// Output: packed (y<<20 | x<<8 | score), coordinates relative to (minBX,minBY).
+// ---------------------------------------------------------------------------
+constexpr int FT_PITCH = 72;
+
+__device__ __forceinline__ bool has9(unsigned m16) {
+  unsigned m = m16 | (m16 << 16);
+  unsigned r = m & (m >> 1);
+  r &= r >> 2;
+  r &= r >> 4;      // bit i: bits i..i+7 set
+  r &= m >> 8;      // bit i: bits i..i+8 set
+  return (r & 0xFFFFu) != 0;
+}
+
+// max over the 16 arcs of 9 of the minimum of a[] (a has 16 entries, circular)
+__device__ __forceinline__ int arc9_maxmin(const int a[16]) {
+  int e[24];
+#pragma unroll
+  for (int i = 0; i < 24; ++i) e[i] = a[i & 15];
+  int m2[23], m4[21], m8[17];
+#pragma unroll
+  for (int i = 0; i < 23; ++i) m2[i] = min(e[i], e[i + 1]);
+#pragma unroll
+  for (int i = 0; i < 21; ++i) m4[i] = min(m2[i], m2[i + 2]);
+#pragma unroll
+  for (int i = 0; i < 17; ++i) m8[i] = min(m4[i], m4[i + 4]);
+  int best = -256;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) best = max(best, min(m8[i], e[i + 8]));
+  return best;
+}
+
+__global__ __launch_bounds__(256) void k_fast_cells(const DevParams* __restrict__ Pp, const uint8_t* __restrict__ pyr,
+                                                    uint32_t* __restrict__ cellCand, int* __restrict__ cellCount, int img0) {
+  __shared__ uint8_t tile[FT_PITCH * 68];
+  __shared__ uint8_t score[64 * 64];
+  __shared__ int s_any;
+  __shared__ int s_wcount[4];
+  __shared__ int s_base;
+  const DevParams& P = *Pp;
+  const int img = blockIdx.y + img0;
+  const int cell = blockIdx.x;
+  int lvl = 0;
+#pragma unroll 1
+  for (int l = 1; l < P.nlevels; ++l)
+    if (cell >= P.lv[l].cellBase) lvl = l;
+  const LevelGeom& G = P.lv[lvl];
+  const int c = cell - G.cellBase;
+  const int ci = c / G.nCols, cj = c - ci * G.nCols;
+  const int iniX = G.minBX + cj * G.wCell, iniY = G.minBY + ci * G.hCell;
+  int maxX = iniX + G.wCell + 6, maxY = iniY + G.hCell + 6;
+  const int tid = threadIdx.x;
+  const int64_t cellIdx = (int64_t)img * P.cellsPerImage + cell;
+  if (iniY >= G.maxBY - 3 || iniX >= G.maxBX - 6) {
+    if (tid == 0) cellCount[cellIdx] = 0;
+    return;
+  }
+  if (maxX > G.maxBX) maxX = G.maxBX;
+  if (maxY > G.maxBY) maxY = G.maxBY;
+  const int cw = maxX - iniX, ch = maxY - iniY;
+  const int iw = cw - 6, ih = ch - 6;
+  if (iw <= 0 || ih <= 0) {
+    if (tid == 0) cellCount[cellIdx] = 0;
+    return;
+  }
+  const uint8_t* im = pyr + (int64_t)img * P.pyrBlock + G.offset;
+  for (int i = tid; i < cw * ch; i += 256) {
+    int y = i / cw, x = i - y * cw;
+    tile[y * FT_PITCH + x] = im[(int64_t)(iniY + y) * G.pitch + iniX + x];
+  }
+  if (tid == 0) s_any = 0;
+  __syncthreads();
+  const int minTh = P.minTh, iniTh = P.iniTh;
+  const int npix = iw * ih;
+  for (int i = tid; i < npix; i += 256) {
+    int y = i / iw, x = i - y * iw;
+    const uint8_t* p = &tile[(y + 3) * FT_PITCH + x + 3];
+    const int v = p[0];
+    int d[16];
+    d[0] = v - p[3 * FT_PITCH + 0];   d[1] = v - p[3 * FT_PITCH + 1];   d[2] = v - p[2 * FT_PITCH + 2];
+    d[3] = v - p[1 * FT_PITCH + 3];   d[4] = v - p[3];                  d[5] = v - p[-1 * FT_PITCH + 3];
+    d[6] = v - p[-2 * FT_PITCH + 2];  d[7] = v - p[-3 * FT_PITCH + 1];  d[8] = v - p[-3 * FT_PITCH + 0];
+    d[9] = v - p[-3 * FT_PITCH - 1];  d[10] = v - p[-2 * FT_PITCH - 2]; d[11] = v - p[-1 * FT_PITCH - 3];
+    d[12] = v - p[-3];                d[13] = v - p[1 * FT_PITCH - 3];  d[14] = v - p[2 * FT_PITCH - 2];
+    d[15] = v - p[3 * FT_PITCH - 1];
+    unsigned mDark = 0, mBright = 0;    // ring darker / brighter than the centre by more than minTh
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      mDark |= (unsigned)(d[k] > minTh) << k;
+      mBright |= (unsigned)(-d[k] > minTh) << k;
+    }
+    int sc = 0;
+    const bool cd = has9(mDark), cb = has9(mBright);
+    if (cd || cb) {
+      int arc = -256;
+      if (cd) arc = max(arc, arc9_maxmin(d));
+      if (cb) {
+        int nd[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) nd[k] = -d[k];
+        arc = max(arc, arc9_maxmin(nd));
+      }
+      sc = arc - 1;                      // cornerScore<16>
+    }
+    score[y * 64 + x] = (uint8_t)sc;
+  }
+  __syncthreads();
+  // NMS flags (strictly greater than the 8 neighbours inside the interior), kept in registers per chunk
+  const int nchunks = (npix + 255) / 256;
+  // pass 1: does any survivor reach iniTh ?
+  for (int ck = 0; ck < nchunks; ++ck) {
+    int i = ck * 256 + tid;
+    bool surv = false;
+    if (i < npix) {
+      int y = i / iw, x = i - y * iw;
+      int s = score[y * 64 + x];
+      if (s >= iniTh) {
+        surv = true;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+          for (int dx = -1; dx <= 1; ++dx) {
+            if (dx == 0 && dy == 0) continue;
+            int xx = x + dx, yy = y + dy;
+            int n = (xx < 0 || yy < 0 || xx >= iw || yy >= ih) ? 0 : score[yy * 64 + xx];
+            surv = surv && (s > n);
+          }
+      }
+    }
+    if (surv) s_any = 1;   // benign race: all writers store 1
+  }
+  __syncthreads();
+  const int thr = s_any ? iniTh : 1;     // score > 0 <=> corner at minTh
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  uint32_t* out = cellCand + cellIdx * CELL_CAP;
+  const int lane = tid & 63, wv = tid >> 6;
+  for (int ck = 0; ck < nchunks; ++ck) {
+    int i = ck * 256 + tid;
+    bool surv = false;
+    int s = 0, x = 0, y = 0;
+    if (i < npix) {
+      y = i / iw; x = i - y * iw;
+      s = score[y * 64 + x];
+      if (s >= thr) {
+        surv = true;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+          for (int dx = -1; dx <= 1; ++dx) {
+            if (dx == 0 && dy == 0) continue;
+            int xx = x + dx, yy = y + dy;
+            int n = (xx < 0 || yy < 0 || xx >= iw || yy >= ih) ? 0 : score[yy * 64 + xx];
+            surv = surv && (s > n);
+          }
+      }
+    }
+    unsigned long long bal = __ballot(surv);
+    if (lane == 0) s_wcount[wv] = __popcll(bal);
+    __syncthreads();
+    int pre = s_base;
+    for (int k = 0; k < wv; ++k) pre += s_wcount[k];
+    int pos = pre + __popcll(bal & ((1ull << lane) - 1ull));
+    if (surv && pos < CELL_CAP) {
+      int xr = x + 3 + cj * G.wCell, yr = y + 3 + ci * G.hCell;
+      out[pos] = ((uint32_t)yr << 20) | ((uint32_t)xr << 8) | (uint32_t)s;
+    }
+    __syncthreads();
+    if (tid == 0) s_base += s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
+    __syncthreads();
+  }
+  if (tid == 0) cellCount[cellIdx] = s_base < CELL_CAP ? s_base : CELL_CAP;
+}
+
+// ---------------------------------------------------------------------------
+// k_octree: ORBextractor::DistributeOctTree, one workgroup per (level, image).
+//
+// The reference keeps a std::list of nodes, splits nodes with push_front of
+// the non-empty children and, when the next full pass could overshoot N,
+// splits the largest nodes first until the list reaches N.  Here the list is
+// an array in list order that is rebuilt every round:
+//   new list = [children in reverse creation order] ++ [unsplit nodes, old order]
+// which is exactly what push_front/erase produce.  Creation order = processing
+// order of the parents (list order in a normal pass; size-descending, newest
+// first among equal sizes in the "careful" rounds) then child n1..n4.
+// Keys never move: node_of[key] holds the list position of the key's node.
+// ---------------------------------------------------------------------------
+constexpr int OT_MAXN = 1024;
+
+__device__ __forceinline__ int block_excl_scan_1024(int* a, int n, int* scratch /*>=5 ints*/) {
+  // in-place exclusive scan of a[0..n) (n <= 1024) by 256 threads; returns the total
+  const int tid = threadIdx.x;
+  int v[4], s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int i = tid * 4 + k;
+    v[k] = i < n ? a[i] : 0;
+    s += v[k];
+  }
+  // wave inclusive scan of s
+  int lane = tid & 63, wv = tid >> 6;
+  int inc = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) scratch[wv] = inc;
+  __syncthreads();
+  int wbase = 0;
+  for (int k = 0; k < wv; ++k) wbase += scratch[k];
+  int total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+  int run = wbase + inc - s;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int i = tid * 4 + k;
+    if (i < n) a[i] = run;
+    run += v[k];
+  }
+  __syncthreads();
+  return total;
+}
+
+struct OtNodes {
+  short x0[OT_MAXN], y0[OT_MAXN], x1[OT_MAXN], y1[OT_MAXN];
+  int cnt[OT_MAXN];
+  unsigned char isNew[OT_MAXN];
+};
+
+__global__ __launch_bounds__(256) void k_octree(const DevParams* __restrict__ Pp, const uint32_t* __restrict__ cellCand,
+                                                const int* __restrict__ cellCount, uint32_t* __restrict__ candAll,
+                                                unsigned short* __restrict__ nodeOfAll, int* __restrict__ candCount,
+                                                uint32_t* __restrict__ kpSel, int* __restrict__ kpSelCount, int img0) {
+  __shared__ OtNodes A, B;
+  __shared__ int c4[OT_MAXN * 4];          // per node, keys per quadrant
+  __shared__ int procIdx[OT_MAXN];         // processing order -> node position
+  __shared__ int isSplit[OT_MAXN];         // 1 when the node is split this round (later: creation base)
+  __shared__ int cbase[OT_MAXN];           // creation index of the node's first child
+  __shared__ int unsplitRank[OT_MAXN];
+  __shared__ int scanbuf[OT_MAXN];
+  __shared__ unsigned long long best[OT_MAXN];
+  __shared__ int scratch[8];
+  __shared__ int s_n, s_S, s_T, s_mode, s_done, s_nExp;
+
+  const DevParams& P = *Pp;
+  const int lvl = blockIdx.x, img = blockIdx.y + img0;
+  const LevelGeom& G = P.lv[lvl];
+  const int tid = threadIdx.x;
+  const int N = G.nfeatures;
+  uint32_t* cand = candAll + (int64_t)img * P.candPerImage + G.candBase;
+  unsigned short* nodeOf = nodeOfAll + (int64_t)img * P.candPerImage + G.candBase;
+  uint32_t* sel = kpSel + (int64_t)img * P.kpSlotsPerImage + G.kpBase;
+  const int lc = img * P.nlevels + lvl;
+
+  // ---- gather the cells' keypoints in reference order (cells row-major, raster inside) ----
+  const int ncells = G.nCols * G.nRows;
+  const int* cc = cellCount + (int64_t)img * P.cellsPerImage + G.cellBase;
+  const uint32_t* cin = cellCand + ((int64_t)img * P.cellsPerImage + G.cellBase) * CELL_CAP;
+  int n = 0;
+  for (int base = 0; base < ncells; base += 1024) {
+    int m = min(1024, ncells - base);
+    for (int i = tid; i < m; i += 256) scanbuf[i] = cc[base + i];
+    __syncthreads();
+    int tot = block_excl_scan_1024(scanbuf, m, scratch);
+    for (int i = tid; i < m; i += 256) {
+      int cnt = cc[base + i];
+      int o = n + scanbuf[i];
+      const uint32_t* src = cin + (int64_t)(base + i) * CELL_CAP;
+      for (int k = 0; k < cnt; ++k)
+        if (o + k < G.candCap) cand[o + k] = src[k];
+    }
+    n += tot;
+    __syncthreads();
+  }
+  if (n > G.candCap) n = G.candCap;
+  if (tid == 0) candCount[lc] = n;
+  if (n == 0 || G.nIni <= 0 || N <= 0) {
+    if (tid == 0) kpSelCount[lc] = 0;
+    return;
+  }
+  __threadfence_block();
+  __syncthreads();
+
+  // ---- root nodes (ORBextractor.cc:540-589) ----
+  const int nIni = G.nIni;
+  const float hX = G.hX;
+  for (int i = tid; i < OT_MAXN; i += 256) scanbuf[i] = 0;
+  __syncthreads();
+  for (int k = tid; k < n; k += 256) {
+    int x = (cand[k] >> 8) & 0xFFF;
+    int r = (int)__fdiv_rn((float)x, hX);
+    if (r >= nIni) r = nIni - 1;
+    nodeOf[k] = (unsigned short)r;       // temporarily the root index
+    atomicAdd(&scanbuf[r], 1);
+  }
+  __syncthreads();
+  // compact non-empty roots, keep order
+  if (tid == 0) {
+    int S = 0;
+    for (int i = 0; i < nIni; ++i) {
+      int cnt = scanbuf[i];
+      if (cnt > 0) {
+        A.x0[S] = (short)(int)__fmul_rn(hX, (float)i);
+        A.x1[S] = (short)(int)__fmul_rn(hX, (float)(i + 1));
+        A.y0[S] = 0;
+        A.y1[S] = (short)(G.maxBY - G.minBY);
+        A.cnt[S] = cnt;
+        A.isNew[S] = 0;
+        procIdx[i] = S;                  // root -> list position
+        ++S;
+      } else procIdx[i] = -1;
+    }
+    s_S = S; s_mode = 0; s_done = 0;
+  }
+  __syncthreads();
+  for (int k = tid; k < n; k += 256) nodeOf[k] = (unsigned short)procIdx[nodeOf[k]];
+  __syncthreads();
+
+  OtNodes* cur = &A;
+  OtNodes* nxt = &B;
+  int guard = 0;
+  while (!s_done && guard++ < 64) {
+    const int S = s_S;
+    const int mode = s_mode;
+    // A. split candidates
+    for (int p = tid; p < S; p += 256) {
+      bool cd = cur->cnt[p] > 1 && (mode == 0 || cur->isNew[p]);
+      isSplit[p] = cd ? 1 : 0;
+      c4[4 * p] = c4[4 * p + 1] = c4[4 * p + 2] = c4[4 * p + 3] = 0;
+    }
+    __syncthreads();
+    // B. keys per quadrant (ExtractorNode::DivideNode, :479-535)
+    for (int k = tid; k < n; k += 256) {
+      int p = nodeOf[k];
+      if (!isSplit[p]) continue;
+      uint32_t cv = cand[k];
+      float fx = (float)((cv >> 8) & 0xFFF), fy = (float)(cv >> 20);
+      int halfX = (int)ceilf(__fdiv_rn((float)(cur->x1[p] - cur->x0[p]), 2.f));
+      int halfY = (int)ceilf(__fdiv_rn((float)(cur->y1[p] - cur->y0[p]), 2.f));
+      int mx = cur->x0[p] + halfX, my = cur->y0[p] + halfY;
+      int q = (fx < (float)mx) ? ((fy < (float)my) ? 0 : 2) : ((fy < (float)my) ? 1 : 3);
+      atomicAdd(&c4[4 * p + q], 1);
+    }
+    __syncthreads();
+    // C/D. processing order and the set of nodes actually split
+    int ncand;
+    if (mode == 0) {
+      for (int p = tid; p < S; p += 256) scanbuf[p] = isSplit[p];
+      __syncthreads();
+      ncand = block_excl_scan_1024(scanbuf, S, scratch);
+      for (int p = tid; p < S; p += 256)
+        if (isSplit[p]) procIdx[scanbuf[p]] = p;
+      if (tid == 0) s_T = ncand;
+      __syncthreads();
+    } else {
+      // order by (size desc, list position asc): newest-created first among equals
+      for (int p = tid; p < S; p += 256) scanbuf[p] = isSplit[p];
+      __syncthreads();
+      ncand = block_excl_scan_1024(scanbuf, S, scratch);
+      // rank by counting
+      for (int p = tid; p < S; p += 256) {
+        if (!isSplit[p]) continue;
+        int cp = cur->cnt[p], r = 0;
+        for (int j = 0; j < S; ++j) {
+          if (!isSplit[j]) continue;
+          int cj = cur->cnt[j];
+          r += (cj > cp || (cj == cp && j < p)) ? 1 : 0;
+        }
+        procIdx[r] = p;
+      }
+      __syncthreads();
+      // size after each split in processing order; stop at the first >= N
+      for (int r = tid; r < ncand; r += 256) {
+        int p = procIdx[r];
+        int ne = (c4[4 * p] > 0) + (c4[4 * p + 1] > 0) + (c4[4 * p + 2] > 0) + (c4[4 * p + 3] > 0);
+        scanbuf[r] = ne - 1;
+      }
+      __syncthreads();
+      block_excl_scan_1024(scanbuf, ncand, scratch);
+      if (tid == 0) s_T = ncand;
+      __syncthreads();
+      for (int r = tid; r < ncand; r += 256) {
+        int p = procIdx[r];
+        int ne = (c4[4 * p] > 0) + (c4[4 * p + 1] > 0) + (c4[4 * p + 2] > 0) + (c4[4 * p + 3] > 0);
+        int after = S + scanbuf[r] + ne - 1;       // list size once this node is split
+        if (after >= N) atomicMin(&s_T, r + 1);
+      }
+      __syncthreads();
+      const int T = s_T;
+      for (int r = T + tid; r < ncand; r += 256) isSplit[procIdx[r]] = 0;
+      __syncthreads();
+    }
+    const int T = s_T;
+    // E. creation index of every split node's first child
+    for (int r = tid; r < T; r += 256) {
+      int p = procIdx[r];
+      scanbuf[r] = (c4[4 * p] > 0) + (c4[4 * p + 1] > 0) + (c4[4 * p + 2] > 0) + (c4[4 * p + 3] > 0);
+    }
+    __syncthreads();
+    const int C = block_excl_scan_1024(scanbuf, T, scratch);
+    for (int r = tid; r < T; r += 256) cbase[procIdx[r]] = scanbuf[r];
+    __syncthreads();
+    // F. positions of the unsplit nodes
+    for (int p = tid; p < S; p += 256) scanbuf[p] = isSplit[p] ? 0 : 1;
+    __syncthreads();
+    const int U = block_excl_scan_1024(scanbuf, S, scratch);
+    for (int p = tid; p < S; p += 256) unsplitRank[p] = scanbuf[p];
+    __syncthreads();
+    const int S2 = C + U;
+    // G. build the new list
+    if (S2 <= OT_MAXN) {
+      for (int p = tid; p < S; p += 256) {
+        if (isSplit[p]) {
+          int halfX = (int)ceilf(__fdiv_rn((float)(cur->x1[p] - cur->x0[p]), 2.f));
+          int halfY = (int)ceilf(__fdiv_rn((float)(cur->y1[p] - cur->y0[p]), 2.f));
+          int x0 = cur->x0[p], y0 = cur->y0[p], x1 = cur->x1[p], y1 = cur->y1[p];
+          int mx = x0 + halfX, my = y0 + halfY;
+          int c = cbase[p];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            int cnt = c4[4 * p + q];
+            if (cnt == 0) continue;
+            int pos = C - 1 - c;
+            ++c;
+            nxt->x0[pos] = (short)((q & 1) ? mx : x0);
+            nxt->x1[pos] = (short)((q & 1) ? x1 : mx);
+            nxt->y0[pos] = (short)((q & 2) ? my : y0);
+            nxt->y1[pos] = (short)((q & 2) ? y1 : my);
+            nxt->cnt[pos] = cnt;
+            nxt->isNew[pos] = 1;
+          }
+        } else {
+          int pos = C + unsplitRank[p];
+          nxt->x0[pos] = cur->x0[p]; nxt->x1[pos] = cur->x1[p];
+          nxt->y0[pos] = cur->y0[p]; nxt->y1[pos] = cur->y1[p];
+          nxt->cnt[pos] = cur->cnt[p];
+          nxt->isNew[pos] = 0;
+        }
+      }
+      for (int k = tid; k < n; k += 256) {
+        int p = nodeOf[k];
+        int np;
+        if (isSplit[p]) {
+          uint32_t cv = cand[k];
+          float fx = (float)((cv >> 8) & 0xFFF), fy = (float)(cv >> 20);
+          int halfX = (int)ceilf(__fdiv_rn((float)(cur->x1[p] - cur->x0[p]), 2.f));
+          int halfY = (int)ceilf(__fdiv_rn((float)(cur->y1[p] - cur->y0[p]), 2.f));
+          int mx = cur->x0[p] + halfX, my = cur->y0[p] + halfY;
+          int q = (fx < (float)mx) ? ((fy < (float)my) ? 0 : 2) : ((fy < (float)my) ? 1 : 3);
+          int rq = 0;
+          for (int j = 0; j < q; ++j) rq += c4[4 * p + j] > 0;
+          np = C - 1 - (cbase[p] + rq);
+        } else {
+          np = C + unsplitRank[p];
+        }
+        nodeOf[k] = (unsigned short)np;
+      }
+    }
+    __syncthreads();
+    // H. termination (ORBextractor.cc:665-738)
+    if (tid == 0) s_nExp = 0;
+    __syncthreads();
+    if (S2 <= OT_MAXN) {
+      int loc = 0;
+      for (int p = tid; p < C; p += 256) loc += nxt->cnt[p] > 1;
+      if (loc) atomicAdd(&s_nExp, loc);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      if (S2 > OT_MAXN) { s_done = 1; }     // capacity guard (never reached for nfeatures/level <= 1000)
+      else {
+        s_S = S2;
+        if (S2 >= N || S2 == S) s_done = 1;
+        else if (mode == 0 && (S2 + s_nExp * 3) > N) s_mode = 1;
+      }
+    }
+    __syncthreads();
+    if (S2 <= OT_MAXN) { OtNodes* t = cur; cur = nxt; nxt = t; }
+  }
+  // ---- best response per node, first maximum wins (:741-757) ----
+  const int S = s_S;
+  for (int p = tid; p < S; p += 256) best[p] = 0ull;
+  __syncthreads();
+  for (int k = tid; k < n; k += 256) {
+    uint32_t cv = cand[k];
+    unsigned long long key = ((unsigned long long)(cv & 0xFF) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)k);
+    atomicMax(&best[nodeOf[k]], key);
+  }
+  __syncthreads();
+  for (int p = tid; p < S; p += 256) {
+    unsigned k = 0xFFFFFFFFu - (unsigned)(best[p] & 0xFFFFFFFFull);
+    if (p < G.kpCap) sel[p] = cand[k];
+  }
+  if (tid == 0) kpSelCount[lc] = S < G.kpCap ? S : G.kpCap;
+}
+
+// ---------------------------------------------------------------------------
+// k_blur: separable Gaussian, u8 -> u8, 8-bit fixed-point kernel (radius <= 3),
+// REFLECT_101.  64x32 output tile per workgroup, staged through LDS.
+// Generic over an "image set": nimg images `imgStride` apart, several planes
+// (pyramid levels) described by a tile table.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_blur(const BlurJob* __restrict__ Jp, const uint8_t* __restrict__ in,
+                                              int64_t inImgStride, uint8_t* __restrict__ out,
+                                              int64_t outImgStride, int img0) {
+  __shared__ uint8_t t8[38 * 72];
+  __shared__ int hs[38 * 64];
+  const BlurJob& J = *Jp;
+  const int img = blockIdx.y + img0;
+  int pi = 0;
+#pragma unroll 1
+  for (int l = 1; l < J.nplanes; ++l)
+    if ((int)blockIdx.x >= J.pl[l].tileBase) pi = l;
+  const BlurPlane& PL = J.pl[pi];
+  const int t = blockIdx.x - PL.tileBase;
+  const int ty = t / PL.tilesX, tx = t - ty * PL.tilesX;
+  const int x0 = tx * 64, y0 = ty * 32;
+  const int R = J.radius;
+  const uint8_t* src = in + (int64_t)img * inImgStride + PL.offIn;
+  const int tid = threadIdx.x;
+  const int tw = 64 + 2 * R, th = 32 + 2 * R;
+  for (int i = tid; i < tw * th; i += 256) {
+    int y = i / tw, x = i - y * tw;
+    int sx = reflect101(x0 + x - R, PL.w), sy = reflect101(y0 + y - R, PL.h);
+    t8[y * 72 + x] = src[(int64_t)sy * PL.pitchIn + sx];
+  }
+  __syncthreads();
+  for (int i = tid; i < 64 * th; i += 256) {
+    int y = i >> 6, x = i & 63;
+    int s = 0;
+    for (int k = -R; k <= R; ++k) s += J.k[k + R] * t8[y * 72 + x + R + k];
+    hs[y * 64 + x] = s;
+  }
+  __syncthreads();
+  uint8_t* dst = out + (int64_t)img * outImgStride + PL.offOut;
+  for (int i = tid; i < 64 * 32; i += 256) {
+    int y = i >> 6, x = i & 63;
+    if (x0 + x >= PL.w || y0 + y >= PL.h) continue;
+    int s = 0;
+    for (int k = -R; k <= R; ++k) s += J.k[k + R] * hs[(y + R + k) * 64 + x];
+    int v = (s + (1 << 15)) >> 16;
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    dst[(int64_t)(y0 + y) * PL.pitchOut + x0 + x] = (uint8_t)v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_describe: one wave per selected keypoint slot: IC_Angle on the level image,
+// steered rBRIEF on the blurred level (ballot -> 4 x u64), and the final
+// level-major tables (ORBextractor.cc:1105-1147) straight into the frame record.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_describe(const DevParams* __restrict__ Pp, const uint8_t* __restrict__ pyr,
+                                                 const uint8_t* __restrict__ blur, const uint32_t* __restrict__ kpSel,
+                                                 const int* __restrict__ kpSelCount, uint8_t* __restrict__ table,
+                                                 int64_t recordBytes, int64_t offCounts, int64_t offKp0,
+                                                 int64_t offKp1, int64_t offDesc0, int64_t offDesc1, int img0) {
+  const DevParams& P = *Pp;
+  const int img = blockIdx.y + img0, slot = blockIdx.x;
+  int lvl = 0;
+#pragma unroll 1
+  for (int l = 1; l < P.nlevels; ++l)
+    if (slot >= P.lv[l].kpBase) lvl = l;
+  const LevelGeom& G = P.lv[lvl];
+  const int p = slot - G.kpBase;
+  const int* cnts = kpSelCount + img * P.nlevels;
+  if (p >= cnts[lvl]) return;
+  int before = 0, total = 0;
+  for (int l = 0; l < P.nlevels; ++l) {
+    int c = cnts[l];
+    if (l < lvl) before += c;
+    total += c;
+  }
+  const int lane = threadIdx.x;
+  uint8_t* rec = table + (int64_t)(img >> 1) * recordBytes;
+  const int eye = img & 1;
+  (void)offCounts; (void)total;   // counts are written by k_kp_counts
+  const int outIdx = before + p;
+  if (outIdx >= P.kpCap) return;
+  const uint32_t cv = kpSel[(int64_t)img * P.kpSlotsPerImage + slot];
+  const int kx = (int)((cv >> 8) & 0xFFF) + G.minBX, ky = (int)(cv >> 20) + G.minBY;
+  const int resp = (int)(cv & 0xFF);
+  const uint8_t* im = pyr + (int64_t)img * P.pyrBlock + G.offset;
+  // IC_Angle: moments over the radius-15 disc
+  int m10 = 0, m01 = 0;
+  for (int i = lane; i < 31 * 31; i += 64) {
+    int r = i / 31;
+    int v = r - 15, u = (i - r * 31) - 15;
+    int av = v < 0 ? -v : v;
+    int au = u < 0 ? -u : u;
+    if (au <= P.umax[av]) {
+      int val = im[(int64_t)(ky + v) * G.pitch + kx + u];
+      m10 += u * val;
+      m01 += v * val;
+    }
+  }
+  m10 = wave_sum_i32(m10);
+  m01 = wave_sum_i32(m01);
+  const float angle = fast_atan2_deg((float)m01, (float)m10);
+  // steered rBRIEF
+  const float factorPI = (float)(3.14159265358979323846 / 180.f);
+  const float ang = __fmul_rn(angle, factorPI);
+  const float a = (float)cos((double)ang), b = (float)sin((double)ang);
+  const uint8_t* bl = blur + (int64_t)img * P.pyrBlock + G.offset;
+  const uint8_t* center = bl + (int64_t)ky * G.pitch + kx;
+  unsigned long long words[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const signed char* pt = c_orb_pattern + 4 * (64 * j + lane);
+    float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+    int r0 = cv_round_f(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+    int c0 = cv_round_f(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+    int r1 = cv_round_f(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+    int c1 = cv_round_f(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+    int t0 = center[(int64_t)r0 * G.pitch + c0];
+    int t1 = center[(int64_t)r1 * G.pitch + c1];
+    words[j] = __ballot(t0 < t1);
+  }
+  if (lane == 0) {
+    pli_keypoint kp;
+    kp.x = (float)kx; kp.y = (float)ky;
+    if (lvl != 0) { kp.x = __fmul_rn((float)kx, G.scale); kp.y = __fmul_rn((float)ky, G.scale); }
+    kp.size = (float)(int)__fmul_rn(31.f, G.scale);
+    kp.angle = angle;
+    kp.response = (float)resp;
+    kp.octave = lvl;
+    reinterpret_cast<pli_keypoint*>(rec + (eye ? offKp1 : offKp0))[outIdx] = kp;
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(rec + (eye ? offDesc1 : offDesc0) + (int64_t)outIdx * 32);
+    d[0] = words[0]; d[1] = words[1]; d[2] = words[2]; d[3] = words[3];
+  }
+}
+
+// N (mvKeys.size()) per eye into the frame record
+__global__ void k_kp_counts(const DevParams* __restrict__ Pp, const int* __restrict__ kpSelCount,
+                            uint8_t* __restrict__ table, int64_t recordBytes, int64_t offCounts, int nimg, int img0) {
+  const DevParams& P = *Pp;
+  int img = blockIdx.x * blockDim.x + threadIdx.x;
+  if (img >= nimg) return;
+  img += img0;
+  int total = 0;
+  for (int l = 0; l < P.nlevels; ++l) total += kpSelCount[img * P.nlevels + l];
+  if (total > P.kpCap) total = P.kpCap;
+  reinterpret_cast<int*>(table + (int64_t)(img >> 1) * recordBytes + offCounts)[img & 1] = total;
+}
+
+}  // namespace pli

@@ -1,0 +1,1033 @@
+// Host side of libpli_frontend.so: context, geometry tables, stage scheduling
+// on one HIP stream, and the extern "C" entry points of include/pli_frontend.h.
+// There is no CPU fallback: without a gfx950 device every compute entry point
+// fails with PLI_ERR_NO_DEVICE.
+#include "kernels.hpp"
+#include <cmath>
+#include <cfloat>
+#include <algorithm>
+#include <memory>
+#include <limits>
+
+using namespace pli;
+
+namespace {
+
+thread_local std::string g_err;
+
+#define HIPCHK(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t e__ = (expr);                                                                 \
+    if (e__ != hipSuccess) {                                                                 \
+      g_err = std::string(#expr) + ": " + hipGetErrorString(e__);                            \
+      return PLI_ERR_HIP;                                                                    \
+    }                                                                                        \
+  } while (0)
+
+inline int64_t alignUp(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+inline int cvRoundf(float v) { return (int)std::nearbyintf(v); }
+inline int cvRoundd(double v) { return (int)std::nearbyint(v); }
+inline int cvFloorf(float v) { int i = (int)v; return i - (i > v); }
+
+struct ProfEntry { const char* name; hipEvent_t a, b; };
+
+}  // namespace
+
+struct pli_ctx {
+  pli_frontend_config cfg;
+  DevParams hp;
+  DevParams* dP = nullptr;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool ownStream = true;
+  int NI = 0;
+  pli_table_layout lay;
+  std::vector<void*> allocs;
+  // ORB
+  uint8_t *pyr = nullptr, *blur = nullptr;
+  int* resizeTab[MAX_LEVELS] = {nullptr};
+  uint32_t* cellCand = nullptr; int* cellCount = nullptr;
+  uint32_t* candAll = nullptr; unsigned short* nodeOf = nullptr; int* candCount = nullptr;
+  uint32_t* kpSel = nullptr; int* kpSelCount = nullptr;
+  BlurJob *jobOrb = nullptr, *jobLsd = nullptr, *jobLbd = nullptr;
+  int orbTiles = 0, l0Tiles = 0;
+  // LSD / LBD
+  uint8_t *tmp8 = nullptr, *lsdScaled = nullptr;
+  int64_t tmp8Stride = 0, lsdStride = 0;
+  int tmpPitch = 0;
+  int* lsdTab = nullptr;
+  float* ang = nullptr; int* g2 = nullptr; float2* cs = nullptr; int* maxG2 = nullptr;
+  unsigned short* chunkHist = nullptr; int* chunkBase = nullptr; int* nDefined = nullptr;
+  int* order = nullptr; int* regScratch = nullptr; float* seg = nullptr; int* nSeg = nullptr;
+  int nChunks = 0, maxSeg = 0;
+  pli_keyline* tmpKL = nullptr;
+  short *dx = nullptr, *dy = nullptr;
+  LbdCoef* lbdCoef = nullptr;
+  // stereo
+  int *sad = nullptr, *bestIdx = nullptr;
+  unsigned long long* lmask = nullptr; double* ldir = nullptr; short* dmat = nullptr; int *m12 = nullptr, *m21 = nullptr;
+  // drop-in state
+  uint8_t* inStage[2] = {nullptr, nullptr};
+  uint8_t* ownTable = nullptr;
+  std::vector<uint8_t> hostRec;
+  bool orbDone[2] = {false, false}, lineDone[2] = {false, false};
+  // generic scratch for the stateless matchers
+  void* scratch = nullptr; size_t scratchBytes = 0;
+  // debug
+  bool debug = false;
+  float* angDbg = nullptr; float* lbdFloat = nullptr;
+  // profiling
+  bool prof = false;
+  std::vector<ProfEntry> profLog;
+  std::vector<hipEvent_t> evPool;
+  size_t evNext = 0;
+
+  template <class T> pli_status dalloc(T** p, size_t n) {
+    void* q = nullptr;
+    if (n == 0) n = 1;
+    HIPCHK(hipMalloc(&q, n * sizeof(T)));
+    allocs.push_back(q);
+    *p = (T*)q;
+    return PLI_OK;
+  }
+  hipEvent_t ev() {
+    if (evNext == evPool.size()) {
+      hipEvent_t e;
+      hipEventCreate(&e);
+      evPool.push_back(e);
+    }
+    return evPool[evNext++];
+  }
+  void profBegin(const char* name) {
+    if (!prof) return;
+    ProfEntry pe{name, ev(), ev()};
+    hipEventRecord(pe.a, stream);
+    profLog.push_back(pe);
+  }
+  void profEnd() {
+    if (!prof) return;
+    hipEventRecord(profLog.back().b, stream);
+  }
+};
+
+#define LAUNCH(c, name, kern, grid, block, shmem, ...)                       \
+  do {                                                                       \
+    (c)->profBegin(name);                                                    \
+    hipLaunchKernelGGL(kern, grid, block, shmem, (c)->stream, __VA_ARGS__);  \
+    (c)->profEnd();                                                          \
+    HIPCHK(hipGetLastError());                                               \
+  } while (0)
+
+namespace {
+
+// cv::resize coefficient tables (see oracle/ocv_prims.hpp for the derivation):
+// xofs[dw] | alpha[2*dw] | yofs[dh] | beta[2*dh], all int32.
+std::vector<int> buildResizeTab(int sw, int sh, int dw, int dh, double scale_x, double scale_y) {
+  std::vector<int> t((size_t)3 * dw + 3 * dh);
+  for (int d = 0; d < dw; ++d) {
+    float f = (float)((d + 0.5) * scale_x - 0.5);
+    int s = cvFloorf(f);
+    f -= s;
+    if (s < 0) { f = 0; s = 0; }
+    if (s >= sw - 1) { f = 0; s = sw - 1; }
+    t[d] = s;
+    t[dw + 2 * d] = (short)cvRoundf((1.f - f) * 2048.f);
+    t[dw + 2 * d + 1] = (short)cvRoundf(f * 2048.f);
+  }
+  for (int d = 0; d < dh; ++d) {
+    float f = (float)((d + 0.5) * scale_y - 0.5);
+    int s = cvFloorf(f);
+    f -= s;
+    t[3 * dw + d] = s;
+    t[3 * dw + dh + 2 * d] = (short)cvRoundf((1.f - f) * 2048.f);
+    t[3 * dw + dh + 2 * d + 1] = (short)cvRoundf(f * 2048.f);
+  }
+  return t;
+}
+
+void gaussKernelFixed8(int n, double sigma, int* k) {
+  std::vector<float> cf(n);
+  double scale2X = -0.5 / (sigma * sigma), sum = 0;
+  for (int i = 0; i < n; ++i) {
+    double x = i - (n - 1) * 0.5;
+    cf[i] = (float)std::exp(scale2X * x * x);
+    sum += cf[i];
+  }
+  sum = 1. / sum;
+  for (int i = 0; i < n; ++i) {
+    cf[i] = (float)(cf[i] * sum);
+    k[i] = cvRoundd((double)cf[i] * 256.0);
+  }
+}
+
+pli_status validate(const pli_frontend_config& c) {
+  if (c.width < 64 || c.height < 64 || c.width > 4095 || c.height > 4095) { g_err = "width/height must be in [64,4095]"; return PLI_ERR_INVALID; }
+  if (c.max_frames < 1) { g_err = "max_frames < 1"; return PLI_ERR_INVALID; }
+  if (c.orb_nlevels < 1 || c.orb_nlevels > MAX_LEVELS) { g_err = "orb_nlevels out of range"; return PLI_ERR_INVALID; }
+  if (c.orb_nfeatures < 1 || !(c.orb_scale_factor > 1.f)) { g_err = "orb_nfeatures/scale_factor invalid"; return PLI_ERR_INVALID; }
+  if (c.orb_min_th_fast < 1 || c.orb_ini_th_fast < c.orb_min_th_fast || c.orb_ini_th_fast > 254) { g_err = "FAST thresholds invalid"; return PLI_ERR_INVALID; }
+  if (c.lsd_refine != 0) { g_err = "only lsd_refine = 0 (LSD_REFINE_NONE) is on the reference path"; return PLI_ERR_INVALID; }
+  if (c.lsd_n_bins < 1 || c.lsd_n_bins > 1024) { g_err = "lsd_n_bins must be in [1,1024]"; return PLI_ERR_INVALID; }
+  if (c.max_lines < 1 || c.max_lines > 4096) { g_err = "max_lines must be in [1,4096]"; return PLI_ERR_INVALID; }
+  if (c.lsd_nfeatures < 0 || c.lsd_nfeatures > c.max_lines) { g_err = "lsd_nfeatures must be in [0,max_lines]"; return PLI_ERR_INVALID; }
+  if (!(c.lsd_scale > 0) || !(c.lsd_ang_th > 0 && c.lsd_ang_th < 180)) { g_err = "lsd_scale/ang_th invalid"; return PLI_ERR_INVALID; }
+  return PLI_OK;
+}
+
+pli_status buildGeometry(pli_ctx* c) {
+  const pli_frontend_config& cfg = c->cfg;
+  DevParams& P = c->hp;
+  std::memset(&P, 0, sizeof(P));
+  P.W = cfg.width; P.H = cfg.height;
+  P.nlevels = cfg.orb_nlevels;
+  P.iniTh = cfg.orb_ini_th_fast; P.minTh = cfg.orb_min_th_fast;
+  const int L = P.nlevels;
+  // scale tables and per-level quotas, ORBextractor.cc:413-444
+  std::vector<float> sc(L), inv(L);
+  sc[0] = 1.0f;
+  for (int i = 1; i < L; i++) sc[i] = sc[i - 1] * cfg.orb_scale_factor;
+  for (int i = 0; i < L; i++) inv[i] = 1.0f / sc[i];
+  std::vector<int> quota(L);
+  {
+    float factor = 1.0f / cfg.orb_scale_factor;
+    float nDesired = cfg.orb_nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)L));
+    int sum = 0;
+    for (int l = 0; l < L - 1; l++) {
+      quota[l] = cvRoundf(nDesired);
+      sum += quota[l];
+      nDesired *= factor;
+    }
+    quota[L - 1] = std::max(cfg.orb_nfeatures - sum, 0);
+  }
+  int64_t off = 0;
+  int cellBase = 0, kpBase = 0, candBase = 0;
+  for (int l = 0; l < L; ++l) {
+    LevelGeom& G = P.lv[l];
+    G.scale = sc[l]; G.invScale = inv[l];
+    G.w = cvRoundf((float)P.W * inv[l]);
+    G.h = cvRoundf((float)P.H * inv[l]);
+    G.pitch = (int)alignUp(G.w, 64);
+    G.offset = off;
+    off += (int64_t)G.pitch * G.h;
+    off = alignUp(off, 256);
+    G.minBX = 19 - 3; G.minBY = 19 - 3;
+    G.maxBX = G.w - 19 + 3; G.maxBY = G.h - 19 + 3;
+    const float width = (float)(G.maxBX - G.minBX), height = (float)(G.maxBY - G.minBY);
+    G.nCols = width > 0 ? (int)(width / 30.f) : 0;
+    G.nRows = height > 0 ? (int)(height / 30.f) : 0;
+    if (G.nCols <= 0 || G.nRows <= 0) { G.nCols = 0; G.nRows = 0; G.wCell = 0; G.hCell = 0; }
+    else {
+      G.wCell = (int)std::ceil(width / G.nCols);
+      G.hCell = (int)std::ceil(height / G.nRows);
+    }
+    G.cellBase = cellBase;
+    cellBase += G.nCols * G.nRows;
+    G.nfeatures = quota[l];
+    if (G.nfeatures + 8 > 1000) { g_err = "per-level feature quota above 992 is not supported by k_octree"; return PLI_ERR_INVALID; }
+    G.nIni = (G.maxBY - G.minBY) > 0 ? (int)std::round(static_cast<float>(G.maxBX - G.minBX) / (G.maxBY - G.minBY)) : 0;
+    if (G.nCols == 0) G.nIni = 0;
+    G.hX = G.nIni > 0 ? static_cast<float>(G.maxBX - G.minBX) / G.nIni : 1.f;
+    G.kpBase = kpBase;
+    G.kpCap = std::max(G.nfeatures + 4, 4 * G.nIni + 4);
+    kpBase += G.kpCap;
+    const int perCell = std::min(CELL_CAP, ((G.wCell + 1) / 2) * ((G.hCell + 1) / 2));
+    G.candBase = candBase;
+    G.candCap = G.nCols * G.nRows * perCell;
+    candBase += (int)alignUp(G.candCap, 4);
+  }
+  P.pyrBlock = alignUp(off, 256);
+  P.cellsPerImage = cellBase;
+  P.kpSlotsPerImage = kpBase;
+  P.candPerImage = candBase;
+  P.kpCap = pli_kp_capacity(&cfg);
+  P.klCap = pli_kl_capacity(&cfg);
+  // umax, ORBextractor.cc:451-467
+  {
+    const int HP = 15;
+    int umax[HP + 2] = {0};
+    int v, v0, vmax = cvFloorf(HP * std::sqrt(2.f) / 2 + 1);
+    int vmin = (int)std::ceil(HP * std::sqrt(2.f) / 2);
+    const double hp2 = HP * HP;
+    for (v = 0; v <= vmax; ++v) umax[v] = cvRoundd(std::sqrt(hp2 - v * v));
+    for (v = HP, v0 = 0; v >= vmin; --v) {
+      while (umax[v0] == umax[v0 + 1]) ++v0;
+      umax[v] = v0;
+      ++v0;
+    }
+    for (int i = 0; i < 16; ++i) P.umax[i] = umax[i];
+  }
+  // LSD (OpenCV lsd.cpp flsd)
+  P.lsdScale = cfg.lsd_scale;
+  P.LW = cfg.lsd_scale != 1 ? cvRoundd(P.W * cfg.lsd_scale) : P.W;
+  P.LH = cfg.lsd_scale != 1 ? cvRoundd(P.H * cfg.lsd_scale) : P.H;
+  P.lpitch = (int)alignUp(P.LW, 64);
+  P.prec = 3.14159265358979323846 * cfg.lsd_ang_th / 180;
+  {
+    const double rho = cfg.lsd_quant / std::sin(P.prec);
+    int g = 0;
+    while (std::sqrt(g / 4.0) <= rho) ++g;     // defined  <=>  sqrt(g2/4) > rho
+    P.g2Thresh = g - 1;
+  }
+  P.nBins = cfg.lsd_n_bins;
+  {
+    const double p = cfg.lsd_ang_th / 180;
+    const double LOG_NT = 5 * (std::log10(double(P.LW)) + std::log10(double(P.LH))) / 2 + std::log10(11.0);
+    P.minRegSize = (int)size_t(-LOG_NT / std::log10(p));
+  }
+  P.maxLines = cfg.max_lines;
+  P.lsdNFeatures = cfg.lsd_nfeatures;
+  P.minLength = cfg.min_line_length * (std::min(P.W, P.H));
+  P.bf = cfg.bf;
+  P.maxD = cfg.stereo_maxd_inf ? std::numeric_limits<float>::infinity() : cfg.bf / (cfg.bf / cfg.fx);
+  P.sWs = cfg.matching_s_ws; P.bestLR = cfg.best_lr_matches;
+  P.lineSimTh = cfg.line_sim_th; P.overlapTh = cfg.stereo_overlap_th; P.ratio12L = cfg.min_ratio_12_l;
+  P.minDispRatio = cfg.ls_min_disp_ratio; P.minDisp = cfg.min_disp; P.horizTh = cfg.line_horiz_th;
+  return PLI_OK;
+}
+
+void buildLayout(pli_ctx* c) {
+  pli_table_layout& L = c->lay;
+  const int kc = c->hp.kpCap, lc = c->hp.klCap;
+  int64_t o = 0;
+  auto take = [&](int64_t bytes) { int64_t r = o; o = alignUp(o + bytes, 16); return r; };
+  L.kp_cap = kc; L.kl_cap = lc;
+  L.off_counts = take(8 * 4);
+  L.off_kp[0] = take((int64_t)kc * sizeof(pli_keypoint));
+  L.off_kp[1] = take((int64_t)kc * sizeof(pli_keypoint));
+  L.off_desc[0] = take((int64_t)kc * 32);
+  L.off_desc[1] = take((int64_t)kc * 32);
+  L.off_uright = take((int64_t)kc * 4);
+  L.off_depth = take((int64_t)kc * 4);
+  L.off_kl[0] = take((int64_t)lc * sizeof(pli_keyline));
+  L.off_kl[1] = take((int64_t)lc * sizeof(pli_keyline));
+  L.off_ldesc[0] = take((int64_t)lc * 32);
+  L.off_ldesc[1] = take((int64_t)lc * 32);
+  L.off_disp = take((int64_t)lc * 8);
+  L.off_le = take((int64_t)lc * 24);
+  L.record_bytes = alignUp(o, 256);
+}
+
+pli_status allocAll(pli_ctx* c) {
+  const DevParams& P = c->hp;
+  const int NI = c->NI;
+  pli_status st;
+#define A(ptr, n) if ((st = c->dalloc(&(ptr), (size_t)(n))) != PLI_OK) return st
+  A(c->dP, 1);
+  HIPCHK(hipMemcpy(c->dP, &c->hp, sizeof(DevParams), hipMemcpyHostToDevice));
+  A(c->pyr, (size_t)P.pyrBlock * NI);
+  A(c->blur, (size_t)P.pyrBlock * NI);
+  for (int l = 1; l < P.nlevels; ++l) {
+    const LevelGeom &S = P.lv[l - 1], &D = P.lv[l];
+    std::vector<int> t = buildResizeTab(S.w, S.h, D.w, D.h, 1. / ((double)D.w / S.w), 1. / ((double)D.h / S.h));
+    A(c->resizeTab[l], t.size());
+    HIPCHK(hipMemcpy(c->resizeTab[l], t.data(), t.size() * 4, hipMemcpyHostToDevice));
+  }
+  A(c->cellCand, (size_t)NI * P.cellsPerImage * CELL_CAP);
+  A(c->cellCount, (size_t)NI * P.cellsPerImage);
+  A(c->candAll, (size_t)NI * P.candPerImage);
+  A(c->nodeOf, (size_t)NI * P.candPerImage);
+  A(c->candCount, (size_t)NI * P.nlevels);
+  A(c->kpSel, (size_t)NI * P.kpSlotsPerImage);
+  A(c->kpSelCount, (size_t)NI * P.nlevels);
+  // blur jobs
+  {
+    BlurJob J;
+    std::memset(&J, 0, sizeof(J));
+    J.nplanes = P.nlevels;
+    J.radius = 3;
+    gaussKernelFixed8(7, 2.0, J.k);
+    int tb = 0;
+    for (int l = 0; l < P.nlevels; ++l) {
+      BlurPlane& p = J.pl[l];
+      p.w = P.lv[l].w; p.h = P.lv[l].h; p.pitchIn = p.pitchOut = P.lv[l].pitch;
+      p.offIn = p.offOut = P.lv[l].offset;
+      p.tilesX = (p.w + 63) / 64;
+      p.tileBase = tb;
+      tb += p.tilesX * ((p.h + 31) / 32);
+    }
+    c->orbTiles = tb;
+    A(c->jobOrb, 1);
+    HIPCHK(hipMemcpy(c->jobOrb, &J, sizeof(J), hipMemcpyHostToDevice));
+    // LSD pre-filter: level 0 -> tmp8, kernel size from sigma (lsd.cpp)
+    c->tmpPitch = (int)alignUp(P.W, 64);
+    c->tmp8Stride = alignUp((int64_t)c->tmpPitch * P.H, 256);
+    std::memset(&J, 0, sizeof(J));
+    J.nplanes = 1;
+    const double sigma = (c->cfg.lsd_scale < 1) ? (c->cfg.lsd_sigma_scale / c->cfg.lsd_scale) : c->cfg.lsd_sigma_scale;
+    const unsigned h = (unsigned)std::ceil(sigma * std::sqrt(2 * 3.0 * std::log(10.0)));
+    if (h > 3) { g_err = "LSD pre-filter radius > 3 not supported"; return PLI_ERR_INVALID; }
+    J.radius = (int)h;
+    gaussKernelFixed8(1 + 2 * (int)h, sigma, J.k);
+    J.pl[0].w = P.W; J.pl[0].h = P.H; J.pl[0].pitchIn = P.lv[0].pitch; J.pl[0].pitchOut = c->tmpPitch;
+    J.pl[0].offIn = P.lv[0].offset; J.pl[0].offOut = 0;
+    J.pl[0].tilesX = (P.W + 63) / 64; J.pl[0].tileBase = 0;
+    c->l0Tiles = J.pl[0].tilesX * ((P.H + 31) / 32);
+    A(c->jobLsd, 1);
+    HIPCHK(hipMemcpy(c->jobLsd, &J, sizeof(J), hipMemcpyHostToDevice));
+    // LBD: 5x5 sigma 1 (binary_descriptor_custom.cpp:358)
+    J.radius = 2;
+    std::memset(J.k, 0, sizeof(J.k));
+    gaussKernelFixed8(5, 1.0, J.k);
+    A(c->jobLbd, 1);
+    HIPCHK(hipMemcpy(c->jobLbd, &J, sizeof(J), hipMemcpyHostToDevice));
+  }
+  A(c->tmp8, (size_t)c->tmp8Stride * NI);
+  c->lsdStride = alignUp((int64_t)P.lpitch * P.LH, 256);
+  A(c->lsdScaled, (size_t)c->lsdStride * NI);
+  if (c->cfg.lsd_scale != 1) {
+    std::vector<int> t = buildResizeTab(P.W, P.H, P.LW, P.LH, 1. / c->cfg.lsd_scale, 1. / c->cfg.lsd_scale);
+    A(c->lsdTab, t.size());
+    HIPCHK(hipMemcpy(c->lsdTab, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+  }
+  const size_t npix = (size_t)P.LW * P.LH;
+  A(c->ang, npix * NI);
+  A(c->g2, npix * NI);
+  A(c->cs, npix * NI);
+  A(c->maxG2, NI);
+  c->nChunks = (int)((npix + 1023) / 1024);
+  A(c->chunkHist, (size_t)NI * c->nChunks * P.nBins);
+  A(c->chunkBase, (size_t)NI * c->nChunks * P.nBins);
+  A(c->nDefined, NI);
+  A(c->order, npix * NI);
+  A(c->regScratch, npix * NI);
+  c->maxSeg = 16384;
+  A(c->seg, (size_t)NI * c->maxSeg * 4);
+  A(c->nSeg, NI);
+  A(c->tmpKL, (size_t)NI * P.maxLines);
+  A(c->dx, (size_t)P.W * P.H * NI);
+  A(c->dy, (size_t)P.W * P.H * NI);
+  {
+    // BinaryDescriptor ctor weights, binary_descriptor_custom.cpp:217-259 (integer divisions kept)
+    LbdCoef C;
+    const int widthOfBand = 7, NUM_OF_BANDS = 9;
+    double u = (widthOfBand * 3 - 1) / 2;
+    double sigma = (widthOfBand * 2 + 1) / 2;
+    double invsigma2 = -1 / (2 * sigma * sigma);
+    for (int i = 0; i < widthOfBand * 3; i++) { double dis = i - u; C.L[i] = (float)std::exp(dis * dis * invsigma2); }
+    u = (NUM_OF_BANDS * widthOfBand - 1) / 2;
+    sigma = u;
+    invsigma2 = -1 / (2 * sigma * sigma);
+    for (int i = 0; i < NUM_OF_BANDS * widthOfBand; i++) { double dis = i - u; C.G[i] = (float)std::exp(dis * dis * invsigma2); }
+    A(c->lbdCoef, 1);
+    HIPCHK(hipMemcpy(c->lbdCoef, &C, sizeof(C), hipMemcpyHostToDevice));
+  }
+  const int NF = c->cfg.max_frames;
+  A(c->sad, (size_t)NF * P.kpCap);
+  A(c->bestIdx, (size_t)NF * P.kpCap);
+  A(c->lmask, (size_t)NF * P.klCap * GRID_ROWS);
+  A(c->ldir, (size_t)NF * P.klCap * 2);
+  A(c->dmat, (size_t)NF * P.klCap * P.klCap);
+  A(c->m12, (size_t)NF * P.klCap);
+  A(c->m21, (size_t)NF * P.klCap);
+  A(c->inStage[0], (size_t)P.W * P.H);
+  A(c->inStage[1], (size_t)P.W * P.H);
+  A(c->ownTable, (size_t)c->lay.record_bytes * NF);
+  HIPCHK(hipMemset(c->ownTable, 0, (size_t)c->lay.record_bytes * NF));
+  c->hostRec.resize((size_t)c->lay.record_bytes);
+#undef A
+  return PLI_OK;
+}
+
+// ---- stage scheduling -------------------------------------------------------
+pli_status runIngest(pli_ctx* c, const uint8_t* dl, const uint8_t* dr, int64_t stride, int64_t frameStride, int img0, int nimg) {
+  const DevParams& P = c->hp;
+  dim3 g((P.W + 1023) / 1024, P.H, nimg);
+  LAUNCH(c, "k_ingest", k_ingest, g, dim3(256), 0, dl, dr, stride, frameStride, c->pyr, P.pyrBlock, P.W, P.H, P.lv[0].pitch, img0);
+  return PLI_OK;
+}
+
+pli_status runOrb(pli_ctx* c, int img0, int nimg, uint8_t* table) {
+  const DevParams& P = c->hp;
+  const pli_table_layout& Y = c->lay;
+  for (int l = 1; l < P.nlevels; ++l) {
+    const LevelGeom &S = P.lv[l - 1], &D = P.lv[l];
+    dim3 g((D.w + 1023) / 1024, D.h, nimg);
+    LAUNCH(c, "k_resize_level", k_resize_level, g, dim3(256), 0, c->pyr + S.offset, P.pyrBlock, S.w, S.h, S.pitch,
+           c->pyr + D.offset, P.pyrBlock, D.w, D.h, D.pitch, c->resizeTab[l], img0);
+  }
+  if (P.cellsPerImage > 0)
+    LAUNCH(c, "k_fast_cells", k_fast_cells, dim3(P.cellsPerImage, nimg), dim3(256), 0, c->dP, c->pyr, c->cellCand, c->cellCount, img0);
+  LAUNCH(c, "k_octree", k_octree, dim3(P.nlevels, nimg), dim3(256), 0, c->dP, c->cellCand, c->cellCount, c->candAll,
+         c->nodeOf, c->candCount, c->kpSel, c->kpSelCount, img0);
+  LAUNCH(c, "k_blur_orb", k_blur, dim3(c->orbTiles, nimg), dim3(256), 0, c->jobOrb, c->pyr, P.pyrBlock, c->blur, P.pyrBlock, img0);
+  LAUNCH(c, "k_kp_counts", k_kp_counts, dim3((nimg + 63) / 64), dim3(64), 0, c->dP, c->kpSelCount, table, Y.record_bytes,
+         Y.off_counts, nimg, img0);
+  LAUNCH(c, "k_describe", k_describe, dim3(P.kpSlotsPerImage, nimg), dim3(64), 0, c->dP, c->pyr, c->blur, c->kpSel,
+         c->kpSelCount, table, Y.record_bytes, Y.off_counts, Y.off_kp[0], Y.off_kp[1], Y.off_desc[0], Y.off_desc[1], img0);
+  return PLI_OK;
+}
+
+pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
+  const DevParams& P = c->hp;
+  const pli_table_layout& Y = c->lay;
+  const int npix = P.LW * P.LH;
+  const uint8_t* scaled;
+  int64_t sStride;
+  int sPitch;
+  if (c->cfg.lsd_scale != 1) {
+    LAUNCH(c, "k_blur_lsd", k_blur, dim3(c->l0Tiles, nimg), dim3(256), 0, c->jobLsd, c->pyr, P.pyrBlock, c->tmp8, c->tmp8Stride, img0);
+    dim3 g((P.LW + 1023) / 1024, P.LH, nimg);
+    LAUNCH(c, "k_resize_lsd", k_resize_level, g, dim3(256), 0, c->tmp8, c->tmp8Stride, P.W, P.H, c->tmpPitch, c->lsdScaled,
+           c->lsdStride, P.LW, P.LH, P.lpitch, c->lsdTab, img0);
+    scaled = c->lsdScaled; sStride = c->lsdStride; sPitch = P.lpitch;
+  } else {
+    scaled = c->pyr + P.lv[0].offset; sStride = P.pyrBlock; sPitch = P.lv[0].pitch;
+  }
+  HIPCHK(hipMemsetAsync(c->maxG2 + img0, 0, sizeof(int) * nimg, c->stream));
+  {
+    dim3 g((P.LW + 255) / 256, P.LH, nimg);
+    LAUNCH(c, "k_lsd_grad", k_lsd_grad, g, dim3(256), 0, scaled, sStride, P.LW, P.LH, sPitch, P.g2Thresh, c->ang, c->g2, c->cs,
+           c->maxG2, c->debug ? c->angDbg : (float*)nullptr, img0);
+  }
+  LAUNCH(c, "k_lsd_hist", k_lsd_hist, dim3(c->nChunks, nimg), dim3(256), 0, c->g2, npix, P.g2Thresh, P.nBins, c->maxG2,
+         c->chunkHist, c->nChunks, img0);
+  LAUNCH(c, "k_lsd_scan", k_lsd_scan, dim3(nimg), dim3(1024), 0, c->chunkHist, c->nChunks, P.nBins, c->chunkBase, c->nDefined, img0);
+  LAUNCH(c, "k_lsd_scatter", k_lsd_scatter, dim3(c->nChunks, nimg), dim3(64), 0, c->g2, npix, P.g2Thresh, P.nBins, c->maxG2,
+         c->chunkBase, c->nChunks, c->order, img0);
+  LAUNCH(c, "k_lsd_grow", k_lsd_grow, dim3(nimg), dim3(64), 0, c->dP, c->ang, c->g2, c->cs, c->order, c->nDefined,
+         c->regScratch, c->seg, c->nSeg, c->maxSeg, img0);
+  LAUNCH(c, "k_keylines", k_keylines, dim3(nimg), dim3(256), 0, c->dP, c->seg, c->nSeg, c->maxSeg, c->tmpKL, table,
+         Y.record_bytes, Y.off_counts, Y.off_kl[0], Y.off_kl[1], img0);
+  LAUNCH(c, "k_blur_lbd", k_blur, dim3(c->l0Tiles, nimg), dim3(256), 0, c->jobLbd, c->pyr, P.pyrBlock, c->tmp8, c->tmp8Stride, img0);
+  {
+    dim3 g((P.W + 255) / 256, P.H, nimg);
+    LAUNCH(c, "k_sobel", k_sobel, g, dim3(256), 0, c->tmp8, c->tmp8Stride, P.W, P.H, c->tmpPitch, c->dx, c->dy, img0);
+  }
+  LAUNCH(c, "k_lbd", k_lbd, dim3(P.klCap, nimg), dim3(64), 0, c->dP, c->lbdCoef, c->dx, c->dy, table, Y.record_bytes,
+         Y.off_counts, Y.off_kl[0], Y.off_kl[1], Y.off_ldesc[0], Y.off_ldesc[1], c->debug ? c->lbdFloat : (float*)nullptr, img0);
+  return PLI_OK;
+}
+
+pli_status runStereoPoints(pli_ctx* c, int nframes, uint8_t* table) {
+  const DevParams& P = c->hp;
+  const pli_table_layout& Y = c->lay;
+  LAUNCH(c, "k_stereo_points", k_stereo_points, dim3(P.kpCap, nframes), dim3(64), 0, c->dP, c->pyr, table, Y.record_bytes,
+         Y.off_counts, Y.off_kp[0], Y.off_kp[1], Y.off_desc[0], Y.off_desc[1], Y.off_uright, Y.off_depth, c->sad,
+         c->debug ? c->bestIdx : (int*)nullptr);
+  LAUNCH(c, "k_stereo_median", k_stereo_median, dim3(nframes), dim3(256), (size_t)P.kpCap * 4, c->dP, table, Y.record_bytes,
+         Y.off_counts, Y.off_uright, Y.off_depth, c->sad);
+  return PLI_OK;
+}
+
+pli_status runStereoLines(pli_ctx* c, int nframes, uint8_t* table) {
+  const pli_table_layout& Y = c->lay;
+  LAUNCH(c, "k_stereo_lines", k_stereo_lines, dim3(nframes), dim3(256), 0, c->dP, table, Y.record_bytes, Y.off_counts,
+         Y.off_kl[0], Y.off_kl[1], Y.off_ldesc[0], Y.off_ldesc[1], Y.off_disp, Y.off_le, c->lmask, c->ldir, c->dmat, c->m12, c->m21);
+  return PLI_OK;
+}
+
+pli_status ensureScratch(pli_ctx* c, size_t bytes) {
+  if (bytes <= c->scratchBytes) return PLI_OK;
+  if (c->scratch) hipFree(c->scratch);
+  c->scratch = nullptr; c->scratchBytes = 0;
+  HIPCHK(hipMalloc(&c->scratch, bytes));
+  c->scratchBytes = bytes;
+  return PLI_OK;
+}
+
+pli_status checkImage(pli_ctx* c, const uint8_t* img, int w, int h, int64_t stride) {
+  if (!img || w <= 0 || h <= 0) { g_err = "empty image"; return PLI_ERR_EMPTY_IMAGE; }
+  if (w != c->cfg.width || h != c->cfg.height) { g_err = "image size differs from the context's"; return PLI_ERR_INVALID; }
+  if (stride < w) { g_err = "stride < width"; return PLI_ERR_INVALID; }
+  return PLI_OK;
+}
+
+pli_status stageImage(pli_ctx* c, int eye, const uint8_t* img, int w, int h, int64_t stride) {
+  HIPCHK(hipMemcpy2DAsync(c->inStage[eye], w, img, stride, w, h, hipMemcpyHostToDevice, c->stream));
+  return runIngest(c, c->inStage[0], c->inStage[1], w, 0, eye, 1);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pli_version(void) { return "pli-frontend-mi355x 0.1 (gfx950)"; }
+const char* pli_last_error(void) { return g_err.c_str(); }
+
+void pli_config_default(pli_frontend_config* c, int32_t width, int32_t height) {
+  std::memset(c, 0, sizeof(*c));
+  c->width = width; c->height = height; c->max_frames = 1;
+  c->orb_nfeatures = 1200; c->orb_scale_factor = 1.2f; c->orb_nlevels = 8;
+  c->orb_ini_th_fast = 20; c->orb_min_th_fast = 7;
+  c->lsd_nfeatures = 500; c->lsd_refine = 0; c->lsd_n_bins = 1024; c->max_lines = 4096;
+  c->min_line_length = 0.025; c->lsd_scale = 1.2; c->lsd_sigma_scale = 0.6; c->lsd_quant = 2.0;
+  c->lsd_ang_th = 22.5; c->lsd_log_eps = 1.0; c->lsd_density_th = 0.6;
+  c->bf = 47.90639384423901f; c->fx = 435.2046959714599f; c->stereo_maxd_inf = 0;
+  c->matching_s_ws = 10; c->best_lr_matches = 1;
+  c->line_sim_th = 0.75; c->stereo_overlap_th = 0.75; c->min_ratio_12_l = 0.9;
+  c->ls_min_disp_ratio = 0.7; c->min_disp = 1.0; c->line_horiz_th = 0.1;
+}
+
+int32_t pli_kp_capacity(const pli_frontend_config* c) {
+  // DistributeOctTree can return up to quota+3 keypoints per level (ORBextractor.cc:713-733)
+  return (int32_t)alignUp((int64_t)c->orb_nfeatures + 4 * c->orb_nlevels + 8, 64);
+}
+int32_t pli_kl_capacity(const pli_frontend_config* c) { return c->lsd_nfeatures != 0 ? c->lsd_nfeatures : c->max_lines; }
+
+pli_status pli_ctx_create(const pli_frontend_config* cfg, int32_t device, pli_ctx** out) {
+  if (!cfg || !out) { g_err = "null argument"; return PLI_ERR_INVALID; }
+  *out = nullptr;
+  pli_status st = validate(*cfg);
+  if (st != PLI_OK) return st;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+    g_err = "no HIP device: this library has no CPU path";
+    return PLI_ERR_NO_DEVICE;
+  }
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+    g_err = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+    return PLI_ERR_NO_DEVICE;
+  }
+  HIPCHK(hipSetDevice(device));
+  std::unique_ptr<pli_ctx> c(new pli_ctx());
+  c->cfg = *cfg;
+  c->device = device;
+  c->NI = 2 * cfg->max_frames;
+  st = buildGeometry(c.get());
+  if (st != PLI_OK) return st;
+  buildLayout(c.get());
+  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  st = allocAll(c.get());
+  if (st != PLI_OK) { pli_ctx_destroy(c.release()); return st; }
+  *out = c.release();
+  return PLI_OK;
+}
+
+void pli_ctx_destroy(pli_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  for (void* p : c->allocs) hipFree(p);
+  if (c->scratch) hipFree(c->scratch);
+  for (hipEvent_t e : c->evPool) hipEventDestroy(e);
+  if (c->ownStream && c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+pli_status pli_ctx_layout(const pli_ctx* c, pli_table_layout* out) {
+  if (!c || !out) return PLI_ERR_INVALID;
+  *out = c->lay;
+  return PLI_OK;
+}
+
+pli_status pli_ctx_set_stream(pli_ctx* c, void* s) {
+  if (!c) return PLI_ERR_INVALID;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (s) {
+    if (c->ownStream) hipStreamDestroy(c->stream);
+    c->stream = (hipStream_t)s;
+    c->ownStream = false;
+  } else if (!c->ownStream) {
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->ownStream = true;
+  }
+  return PLI_OK;
+}
+
+pli_status pli_ctx_sync(pli_ctx* c) {
+  if (!c) return PLI_ERR_INVALID;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return PLI_OK;
+}
+
+pli_status pli_batch_run(pli_ctx* c, int32_t nframes, const uint8_t* dl, const uint8_t* dr, int64_t stride,
+                         int64_t frameStride, uint32_t stages, void* table) {
+  if (!c || !dl || !dr || !table) { g_err = "null argument"; return PLI_ERR_INVALID; }
+  if (nframes < 1 || nframes > c->cfg.max_frames) { g_err = "nframes exceeds the context's max_frames"; return PLI_ERR_INVALID; }
+  if (stride < c->cfg.width) { g_err = "stride < width"; return PLI_ERR_INVALID; }
+  HIPCHK(hipSetDevice(c->device));
+  uint8_t* T = (uint8_t*)table;
+  pli_status st;
+  const int nimg = 2 * nframes;
+  if ((st = runIngest(c, dl, dr, stride, frameStride, 0, nimg)) != PLI_OK) return st;
+  if (stages & PLI_RUN_ORB) if ((st = runOrb(c, 0, nimg, T)) != PLI_OK) return st;
+  if (stages & PLI_RUN_LINES) if ((st = runLines(c, 0, nimg, T)) != PLI_OK) return st;
+  if (stages & PLI_RUN_STEREO_LINES) if ((st = runStereoLines(c, nframes, T)) != PLI_OK) return st;
+  if (stages & PLI_RUN_STEREO_POINTS) if ((st = runStereoPoints(c, nframes, T)) != PLI_OK) return st;
+  return PLI_OK;
+}
+
+pli_status pli_batch_run_host(pli_ctx* c, int32_t nframes, const uint8_t* left, const uint8_t* right, int64_t stride,
+                              int64_t frameStride, uint32_t stages, void* table) {
+  if (!c || !left || !right || !table) { g_err = "null argument"; return PLI_ERR_INVALID; }
+  if (nframes < 1 || nframes > c->cfg.max_frames) { g_err = "nframes exceeds the context's max_frames"; return PLI_ERR_INVALID; }
+  HIPCHK(hipSetDevice(c->device));
+  const int W = c->cfg.width, H = c->cfg.height;
+  const size_t imgBytes = (size_t)W * H;
+  pli_status st = ensureScratch(c, 2 * imgBytes * nframes + (size_t)c->lay.record_bytes * nframes);
+  if (st != PLI_OK) return st;
+  uint8_t* dl = (uint8_t*)c->scratch;
+  uint8_t* dr = dl + imgBytes * nframes;
+  uint8_t* dt = dr + imgBytes * nframes;
+  for (int f = 0; f < nframes; ++f) {
+    HIPCHK(hipMemcpy2DAsync(dl + imgBytes * f, W, left + (int64_t)f * frameStride, stride, W, H, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpy2DAsync(dr + imgBytes * f, W, right + (int64_t)f * frameStride, stride, W, H, hipMemcpyHostToDevice, c->stream));
+  }
+  HIPCHK(hipMemsetAsync(dt, 0, (size_t)c->lay.record_bytes * nframes, c->stream));
+  st = pli_batch_run(c, nframes, dl, dr, W, (int64_t)imgBytes, stages, dt);
+  if (st != PLI_OK) return st;
+  HIPCHK(hipMemcpyAsync(table, dt, (size_t)c->lay.record_bytes * nframes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return PLI_OK;
+}
+
+pli_status pli_orb_extract(pli_ctx* c, int32_t eye, const uint8_t* img, int32_t w, int32_t h, int64_t stride,
+                           pli_keypoint* kp, int32_t cap, uint8_t* desc, int32_t* n) {
+  if (!c || eye < 0 || eye > 1 || !n) { g_err = "bad argument"; return PLI_ERR_INVALID; }
+  *n = 0;
+  pli_status st = checkImage(c, img, w, h, stride);
+  if (st != PLI_OK) return st;
+  HIPCHK(hipSetDevice(c->device));
+  if ((st = stageImage(c, eye, img, w, h, stride)) != PLI_OK) return st;
+  if ((st = runOrb(c, eye, 1, c->ownTable)) != PLI_OK) return st;
+  const pli_table_layout& Y = c->lay;
+  int counts[8];
+  HIPCHK(hipMemcpyAsync(counts, c->ownTable + Y.off_counts, sizeof(counts), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const int N = counts[eye];
+  c->orbDone[eye] = true;
+  *n = N;
+  if (N > cap) { g_err = "keypoint buffer too small"; return PLI_ERR_CAPACITY; }
+  if (N > 0) {
+    if (kp) HIPCHK(hipMemcpy(kp, c->ownTable + Y.off_kp[eye], (size_t)N * sizeof(pli_keypoint), hipMemcpyDeviceToHost));
+    if (desc) HIPCHK(hipMemcpy(desc, c->ownTable + Y.off_desc[eye], (size_t)N * 32, hipMemcpyDeviceToHost));
+  }
+  return PLI_OK;
+}
+
+pli_status pli_orb_pyramid_level(pli_ctx* c, int32_t eye, int32_t level, uint8_t* dst, int64_t dstBytes, int32_t* w, int32_t* h) {
+  if (!c || eye < 0 || eye > 1 || level < 0 || level >= c->hp.nlevels) { g_err = "bad argument"; return PLI_ERR_INVALID; }
+  if (!c->orbDone[eye]) { g_err = "pli_orb_extract has not run for this eye"; return PLI_ERR_STATE; }
+  const LevelGeom& G = c->hp.lv[level];
+  if (w) *w = G.w;
+  if (h) *h = G.h;
+  if (!dst) return PLI_OK;
+  if (dstBytes < (int64_t)G.w * G.h) { g_err = "buffer too small"; return PLI_ERR_CAPACITY; }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy2D(dst, G.w, c->pyr + (int64_t)eye * c->hp.pyrBlock + G.offset, G.pitch, G.w, G.h, hipMemcpyDeviceToHost));
+  return PLI_OK;
+}
+
+pli_status pli_line_extract(pli_ctx* c, int32_t eye, const uint8_t* img, int32_t w, int32_t h, int64_t stride,
+                            pli_keyline* kl, int32_t cap, uint8_t* desc, int32_t* n) {
+  if (!c || eye < 0 || eye > 1 || !n) { g_err = "bad argument"; return PLI_ERR_INVALID; }
+  *n = 0;
+  pli_status st = checkImage(c, img, w, h, stride);
+  if (st != PLI_OK) return st;
+  HIPCHK(hipSetDevice(c->device));
+  if ((st = stageImage(c, eye, img, w, h, stride)) != PLI_OK) return st;
+  if ((st = runLines(c, eye, 1, c->ownTable)) != PLI_OK) return st;
+  const pli_table_layout& Y = c->lay;
+  int counts[8];
+  HIPCHK(hipMemcpyAsync(counts, c->ownTable + Y.off_counts, sizeof(counts), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const int N = counts[2 + eye];
+  c->lineDone[eye] = true;
+  *n = N;
+  if (N > cap) { g_err = "keyline buffer too small"; return PLI_ERR_CAPACITY; }
+  if (N > 0) {
+    if (kl) HIPCHK(hipMemcpy(kl, c->ownTable + Y.off_kl[eye], (size_t)N * sizeof(pli_keyline), hipMemcpyDeviceToHost));
+    if (desc) HIPCHK(hipMemcpy(desc, c->ownTable + Y.off_ldesc[eye], (size_t)N * 32, hipMemcpyDeviceToHost));
+  }
+  return PLI_OK;
+}
+
+pli_status pli_stereo_match_points(pli_ctx* c, float* uright, float* depth, int32_t cap) {
+  if (!c) return PLI_ERR_INVALID;
+  if (!c->orbDone[0] || !c->orbDone[1]) { g_err = "pli_orb_extract must run for both eyes first"; return PLI_ERR_STATE; }
+  HIPCHK(hipSetDevice(c->device));
+  pli_status st = runStereoPoints(c, 1, c->ownTable);
+  if (st != PLI_OK) return st;
+  const pli_table_layout& Y = c->lay;
+  int counts[8];
+  HIPCHK(hipMemcpyAsync(counts, c->ownTable + Y.off_counts, sizeof(counts), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const int N = counts[0];
+  if (N > cap) { g_err = "output buffer too small"; return PLI_ERR_CAPACITY; }
+  if (N > 0) {
+    if (uright) HIPCHK(hipMemcpy(uright, c->ownTable + Y.off_uright, (size_t)N * 4, hipMemcpyDeviceToHost));
+    if (depth) HIPCHK(hipMemcpy(depth, c->ownTable + Y.off_depth, (size_t)N * 4, hipMemcpyDeviceToHost));
+  }
+  return PLI_OK;
+}
+
+pli_status pli_stereo_match_lines(pli_ctx* c, float* disp, double* le, int32_t cap) {
+  if (!c) return PLI_ERR_INVALID;
+  if (!c->lineDone[0] || !c->lineDone[1]) { g_err = "pli_line_extract must run for both eyes first"; return PLI_ERR_STATE; }
+  HIPCHK(hipSetDevice(c->device));
+  pli_status st = runStereoLines(c, 1, c->ownTable);
+  if (st != PLI_OK) return st;
+  const pli_table_layout& Y = c->lay;
+  int counts[8];
+  HIPCHK(hipMemcpyAsync(counts, c->ownTable + Y.off_counts, sizeof(counts), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const int N = counts[2];
+  if (N > cap) { g_err = "output buffer too small"; return PLI_ERR_CAPACITY; }
+  if (N > 0) {
+    if (disp) HIPCHK(hipMemcpy(disp, c->ownTable + Y.off_disp, (size_t)N * 8, hipMemcpyDeviceToHost));
+    if (le) HIPCHK(hipMemcpy(le, c->ownTable + Y.off_le, (size_t)N * 24, hipMemcpyDeviceToHost));
+  }
+  return PLI_OK;
+}
+
+pli_status pli_descriptor_distance(pli_ctx* c, const uint8_t* a, const uint8_t* b, int32_t n, int32_t* dist) {
+  if (!c || n < 0 || (n > 0 && (!a || !b || !dist))) { g_err = "bad argument"; return PLI_ERR_INVALID; }
+  if (n == 0) return PLI_OK;
+  HIPCHK(hipSetDevice(c->device));
+  const size_t db = (size_t)n * 32;
+  pli_status st = ensureScratch(c, 2 * db + (size_t)n * 4);
+  if (st != PLI_OK) return st;
+  uint8_t* da = (uint8_t*)c->scratch;
+  uint8_t* dbp = da + db;
+  int* dd = (int*)(dbp + db);
+  HIPCHK(hipMemcpyAsync(da, a, db, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(dbp, b, db, hipMemcpyHostToDevice, c->stream));
+  LAUNCH(c, "k_distance", k_distance, dim3((n + 255) / 256), dim3(256), 0, da, dbp, n, dd);
+  HIPCHK(hipMemcpyAsync(dist, dd, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return PLI_OK;
+}
+
+pli_status pli_hamming_knn2(pli_ctx* c, const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt, int32_t* idx, int32_t* dist) {
+  if (!c || nq < 0 || nt < 0 || (nq > 0 && (!q || !idx || !dist)) || (nt > 0 && !t)) { g_err = "bad argument"; return PLI_ERR_INVALID; }
+  if (nq == 0) return PLI_OK;
+  HIPCHK(hipSetDevice(c->device));
+  const size_t qb = alignUp((size_t)nq * 32, 256), tb = alignUp((size_t)std::max(nt, 1) * 32, 256), ob = (size_t)nq * 8;
+  pli_status st = ensureScratch(c, qb + tb + 2 * ob);
+  if (st != PLI_OK) return st;
+  uint8_t* dq = (uint8_t*)c->scratch;
+  uint8_t* dt = dq + qb;
+  int* di = (int*)(dt + tb);
+  int* dd = di + 2 * nq;
+  HIPCHK(hipMemcpyAsync(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
+  if (nt > 0) HIPCHK(hipMemcpyAsync(dt, t, (size_t)nt * 32, hipMemcpyHostToDevice, c->stream));
+  LAUNCH(c, "k_knn2", k_knn2, dim3(nq), dim3(64), 0, dq, nq, dt, nt, di, dd);
+  HIPCHK(hipMemcpyAsync(idx, di, ob, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(dist, dd, ob, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return PLI_OK;
+}
+
+pli_status pli_match_lines(pli_ctx* c, const uint8_t* d1, int32_t n1, const uint8_t* d2, int32_t n2, float nnr,
+                           int32_t* m12, int32_t* nmatches) {
+  if (!c || n1 < 0 || n2 < 0 || (n1 > 0 && (!d1 || !m12)) || (n2 > 0 && !d2)) { g_err = "bad argument"; return PLI_ERR_INVALID; }
+  if (nmatches) *nmatches = 0;
+  if (n1 == 0) return PLI_OK;
+  HIPCHK(hipSetDevice(c->device));
+  const size_t b1 = alignUp((size_t)n1 * 32, 256), b2 = alignUp((size_t)std::max(n2, 1) * 32, 256);
+  const size_t k1 = alignUp((size_t)n1 * 16, 256), k2 = alignUp((size_t)std::max(n2, 1) * 16, 256);
+  const size_t mm1 = alignUp((size_t)n1 * 4, 256), mm2 = alignUp((size_t)std::max(n2, 1) * 4, 256);
+  pli_status st = ensureScratch(c, b1 + b2 + k1 + k2 + mm1 + mm2 + 256);
+  if (st != PLI_OK) return st;
+  uint8_t* p = (uint8_t*)c->scratch;
+  uint8_t* dd1 = p; p += b1;
+  uint8_t* dd2 = p; p += b2;
+  int* i1 = (int*)p; int* ds1 = i1 + 2 * n1; p += k1;
+  int* i2 = (int*)p; int* ds2 = i2 + 2 * std::max(n2, 1); p += k2;
+  int* dm12 = (int*)p; p += mm1;
+  int* dm21 = (int*)p; p += mm2;
+  int* dcount = (int*)p;
+  HIPCHK(hipMemcpyAsync(dd1, d1, (size_t)n1 * 32, hipMemcpyHostToDevice, c->stream));
+  if (n2 > 0) HIPCHK(hipMemcpyAsync(dd2, d2, (size_t)n2 * 32, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemsetAsync(dcount, 0, 4, c->stream));
+  LAUNCH(c, "k_knn2", k_knn2, dim3(n1), dim3(64), 0, dd1, n1, dd2, n2, i1, ds1);
+  LAUNCH(c, "k_ratio", k_ratio, dim3((n1 + 255) / 256), dim3(256), 0, i1, ds1, n1, n2, nnr, dm12);
+  const bool lr = c->cfg.best_lr_matches != 0;
+  if (lr && n2 > 0) {
+    LAUNCH(c, "k_knn2", k_knn2, dim3(n2), dim3(64), 0, dd2, n2, dd1, n1, i2, ds2);
+    LAUNCH(c, "k_ratio", k_ratio, dim3((n2 + 255) / 256), dim3(256), 0, i2, ds2, n2, n1, nnr, dm21);
+  }
+  LAUNCH(c, "k_mutual", k_mutual, dim3((n1 + 255) / 256), dim3(256), 0, dm12, (lr && n2 > 0) ? dm21 : (int*)nullptr, n1, dcount);
+  int cnt = 0;
+  HIPCHK(hipMemcpyAsync(m12, dm12, (size_t)n1 * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(&cnt, dcount, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (nmatches) *nmatches = cnt;
+  return PLI_OK;
+}
+
+pli_status pli_search_by_projection(pli_ctx* c, const pli_proj_query* q, const uint8_t* qdesc, int32_t nq,
+                                    const pli_keypoint* kp, const uint8_t* desc, const float* uright, int32_t ncur,
+                                    float minX, float maxX, float minY, float maxY, int32_t checkOri,
+                                    int32_t* best, int32_t* nmatches) {
+  if (!c || nq < 0 || ncur < 0 || (nq > 0 && (!q || !qdesc || !best)) || (ncur > 0 && (!kp || !desc || !uright))) { g_err = "bad argument"; return PLI_ERR_INVALID; }
+  if (nmatches) *nmatches = 0;
+  if (nq == 0) return PLI_OK;
+  if (ncur >= (1 << 28)) { g_err = "too many keypoints"; return PLI_ERR_INVALID; }
+  HIPCHK(hipSetDevice(c->device));
+  const int nc = std::max(ncur, 1);
+  const size_t bq = alignUp((size_t)nq * sizeof(pli_proj_query), 256), bqd = alignUp((size_t)nq * 32, 256);
+  const size_t bk = alignUp((size_t)nc * sizeof(pli_keypoint), 256), bd = alignUp((size_t)nc * 32, 256), bu = alignUp((size_t)nc * 4, 256);
+  const size_t bo = alignUp((size_t)nc * 4, 256), bb = alignUp((size_t)nq * 4, 256);
+  pli_status st = ensureScratch(c, bq + bqd + bk + bd + bu + bo + bb + 256);
+  if (st != PLI_OK) return st;
+  uint8_t* p = (uint8_t*)c->scratch;
+  pli_proj_query* dq = (pli_proj_query*)p; p += bq;
+  uint8_t* dqd = p; p += bqd;
+  pli_keypoint* dk = (pli_keypoint*)p; p += bk;
+  uint8_t* ddsc = p; p += bd;
+  float* du = (float*)p; p += bu;
+  int* down = (int*)p; p += bo;
+  int* dbest = (int*)p; p += bb;
+  int* dcnt = (int*)p;
+  HIPCHK(hipMemcpyAsync(dq, q, (size_t)nq * sizeof(pli_proj_query), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(dqd, qdesc, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
+  if (ncur > 0) {
+    HIPCHK(hipMemcpyAsync(dk, kp, (size_t)ncur * sizeof(pli_keypoint), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(ddsc, desc, (size_t)ncur * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(du, uright, (size_t)ncur * 4, hipMemcpyHostToDevice, c->stream));
+  }
+  LAUNCH(c, "k_search_by_projection", k_search_by_projection, dim3(1), dim3(64), 0, dq, dqd, nq, dk, ddsc, du, ncur, minX, maxX,
+         minY, maxY, checkOri, down, dbest, dcnt);
+  int cnt = 0;
+  HIPCHK(hipMemcpyAsync(best, dbest, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(&cnt, dcnt, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (nmatches) *nmatches = cnt;
+  return PLI_OK;
+}
+
+// ---- measurement -----------------------------------------------------------
+pli_status pli_prof_enable(pli_ctx* c, int32_t on) {
+  if (!c) return PLI_ERR_INVALID;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->prof = on != 0;
+  return PLI_OK;
+}
+pli_status pli_prof_reset(pli_ctx* c) {
+  if (!c) return PLI_ERR_INVALID;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->profLog.clear();
+  c->evNext = 0;
+  return PLI_OK;
+}
+pli_status pli_prof_report(pli_ctx* c, char* buf, int64_t bytes) {
+  if (!c || !buf || bytes <= 0) return PLI_ERR_INVALID;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  std::map<std::string, std::pair<int, double>> acc;
+  std::vector<std::string> orderNames;
+  for (const ProfEntry& e : c->profLog) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e.a, e.b) != hipSuccess) continue;
+    auto it = acc.find(e.name);
+    if (it == acc.end()) { acc[e.name] = std::make_pair(1, (double)ms); orderNames.push_back(e.name); }
+    else { it->second.first++; it->second.second += ms; }
+  }
+  std::string s;
+  char line[256];
+  for (const std::string& nme : orderNames) {
+    std::snprintf(line, sizeof(line), "%s %d %.6f\n", nme.c_str(), acc[nme].first, acc[nme].second);
+    s += line;
+  }
+  if ((int64_t)s.size() + 1 > bytes) { g_err = "report buffer too small"; return PLI_ERR_CAPACITY; }
+  std::memcpy(buf, s.c_str(), s.size() + 1);
+  return PLI_OK;
+}
+
+pli_status pli_debug_enable(pli_ctx* c, int32_t on) {
+  if (!c) return PLI_ERR_INVALID;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (on && !c->angDbg) {
+    pli_status st;
+    if ((st = c->dalloc(&c->angDbg, (size_t)c->hp.LW * c->hp.LH * c->NI)) != PLI_OK) return st;
+    if ((st = c->dalloc(&c->lbdFloat, (size_t)c->NI * c->hp.klCap * 72)) != PLI_OK) return st;
+  }
+  c->debug = on != 0;
+  return PLI_OK;
+}
+
+pli_status pli_debug_fetch(pli_ctx* c, int32_t image, int32_t what, int32_t arg, void* dst, int64_t dstBytes, int64_t* outBytes) {
+  if (!c || image < 0 || image >= c->NI || !outBytes) { g_err = "bad argument"; return PLI_ERR_INVALID; }
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const DevParams& P = c->hp;
+  auto need = [&](int64_t n) -> bool { *outBytes = n; return dst && dstBytes >= n; };
+  switch (what) {
+    case PLI_DBG_PYRAMID_LEVEL:
+    case PLI_DBG_BLUR_LEVEL: {
+      if (arg < 0 || arg >= P.nlevels) return PLI_ERR_INVALID;
+      const LevelGeom& G = P.lv[arg];
+      if (!need((int64_t)G.w * G.h)) return dst ? PLI_ERR_CAPACITY : PLI_OK;
+      const uint8_t* base = (what == PLI_DBG_PYRAMID_LEVEL ? c->pyr : c->blur) + (int64_t)image * P.pyrBlock + G.offset;
+      HIPCHK(hipMemcpy2D(dst, G.w, base, G.pitch, G.w, G.h, hipMemcpyDeviceToHost));
+      return PLI_OK;
+    }
+    case PLI_DBG_FAST_CANDIDATES:
+    case PLI_DBG_LEVEL_KEYPOINTS: {
+      if (arg < 0 || arg >= P.nlevels) return PLI_ERR_INVALID;
+      const LevelGeom& G = P.lv[arg];
+      int n = 0;
+      const int* cntp = (what == PLI_DBG_FAST_CANDIDATES ? c->candCount : c->kpSelCount) + image * P.nlevels + arg;
+      HIPCHK(hipMemcpy(&n, cntp, 4, hipMemcpyDeviceToHost));
+      if (!need(4 + (int64_t)n * 12)) return dst ? PLI_ERR_CAPACITY : PLI_OK;
+      std::vector<uint32_t> raw(std::max(n, 1));
+      const uint32_t* src = what == PLI_DBG_FAST_CANDIDATES ? c->candAll + (int64_t)image * P.candPerImage + G.candBase
+                                                            : c->kpSel + (int64_t)image * P.kpSlotsPerImage + G.kpBase;
+      if (n) HIPCHK(hipMemcpy(raw.data(), src, (size_t)n * 4, hipMemcpyDeviceToHost));
+      int* o = (int*)dst;
+      o[0] = n;
+      for (int i = 0; i < n; ++i) { o[1 + 3 * i] = (raw[i] >> 8) & 0xFFF; o[2 + 3 * i] = raw[i] >> 20; o[3 + 3 * i] = raw[i] & 0xFF; }
+      return PLI_OK;
+    }
+    case PLI_DBG_LSD_SCALED: {
+      if (!need((int64_t)P.LW * P.LH)) return dst ? PLI_ERR_CAPACITY : PLI_OK;
+      if (c->cfg.lsd_scale != 1)
+        HIPCHK(hipMemcpy2D(dst, P.LW, c->lsdScaled + (int64_t)image * c->lsdStride, P.lpitch, P.LW, P.LH, hipMemcpyDeviceToHost));
+      else
+        HIPCHK(hipMemcpy2D(dst, P.W, c->pyr + (int64_t)image * P.pyrBlock, P.lv[0].pitch, P.W, P.H, hipMemcpyDeviceToHost));
+      return PLI_OK;
+    }
+    case PLI_DBG_LSD_ANGLE: {
+      if (!c->angDbg) { g_err = "pli_debug_enable was not on during the run"; return PLI_ERR_STATE; }
+      const int64_t n = (int64_t)P.LW * P.LH * 4;
+      if (!need(n)) return dst ? PLI_ERR_CAPACITY : PLI_OK;
+      HIPCHK(hipMemcpy(dst, c->angDbg + (int64_t)image * P.LW * P.LH, n, hipMemcpyDeviceToHost));
+      return PLI_OK;
+    }
+    case PLI_DBG_LSD_SEGMENTS: {
+      int n = 0;
+      HIPCHK(hipMemcpy(&n, c->nSeg + image, 4, hipMemcpyDeviceToHost));
+      if (!need(4 + (int64_t)n * 16)) return dst ? PLI_ERR_CAPACITY : PLI_OK;
+      *(int*)dst = n;
+      if (n) HIPCHK(hipMemcpy((char*)dst + 4, c->seg + (int64_t)image * c->maxSeg * 4, (size_t)n * 16, hipMemcpyDeviceToHost));
+      return PLI_OK;
+    }
+    case PLI_DBG_LSD_ORDER: {
+      int n = 0;
+      HIPCHK(hipMemcpy(&n, c->nDefined + image, 4, hipMemcpyDeviceToHost));
+      if (!need(4 + (int64_t)n * 4)) return dst ? PLI_ERR_CAPACITY : PLI_OK;
+      *(int*)dst = n;
+      if (n) HIPCHK(hipMemcpy((char*)dst + 4, c->order + (int64_t)image * P.LW * P.LH, (size_t)n * 4, hipMemcpyDeviceToHost));
+      return PLI_OK;
+    }
+    case PLI_DBG_LBD_DXDY: {
+      const int64_t n = (int64_t)P.W * P.H * 2;
+      if (!need(2 * n)) return dst ? PLI_ERR_CAPACITY : PLI_OK;
+      HIPCHK(hipMemcpy(dst, c->dx + (int64_t)image * P.W * P.H, n, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy((char*)dst + n, c->dy + (int64_t)image * P.W * P.H, n, hipMemcpyDeviceToHost));
+      return PLI_OK;
+    }
+    case PLI_DBG_LBD_FLOAT: {
+      if (!c->lbdFloat) { g_err = "pli_debug_enable was not on during the run"; return PLI_ERR_STATE; }
+      const int64_t n = (int64_t)P.klCap * 72 * 4;
+      if (!need(n)) return dst ? PLI_ERR_CAPACITY : PLI_OK;
+      HIPCHK(hipMemcpy(dst, c->lbdFloat + (int64_t)image * P.klCap * 72, n, hipMemcpyDeviceToHost));
+      return PLI_OK;
+    }
+    case PLI_DBG_STEREO_SAD: {
+      const int frame = image >> 1;
+      const int64_t n = (int64_t)P.kpCap * 4;
+      if (!need(2 * n)) return dst ? PLI_ERR_CAPACITY : PLI_OK;
+      HIPCHK(hipMemcpy(dst, c->sad + (int64_t)frame * P.kpCap, n, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy((char*)dst + n, c->bestIdx + (int64_t)frame * P.kpCap, n, hipMemcpyDeviceToHost));
+      return PLI_OK;
+    }
+    default:
+      g_err = "unknown debug item";
+      return PLI_ERR_INVALID;
+  }
+}
+
+}  // extern "C"

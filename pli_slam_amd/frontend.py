@@ -1,0 +1,274 @@
+"""Host-side mirror of the reference's front-end interface over the C ABI.
+
+Names and argument meaning follow the reference classes so that parity tests
+read like the reference's call sites:
+
+  ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)(image, mask, vLappingArea)
+      reference include/ORBextractor.h:53-63, src/ORBextractor.cc:1068
+  Lineextractor(lsd_nfeatures, min_line_length, lsd_refine, lsd_scale, ...)(image, mask)
+      reference include/LineExtractor.h:44-51, src/LineExtractor.cc:31
+  Frontend.compute_stereo_matches() / compute_stereo_matches_lines()
+      reference Frame::ComputeStereoMatches / _Lines, src/Frame.cc:976,1156
+  DescriptorDistance, match, SearchByProjection
+      reference src/ORBmatcher.cc:2495,2179 and src/LineMatcher.cpp:201
+
+All arithmetic happens in the HIP library; this file only moves buffers.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import KEYLINE_DT, KEYPOINT_DT, PROJ_QUERY_DT, check, ptr
+
+
+def _u8(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    if img.ndim != 2:
+        raise ValueError("grayscale u8 image expected")
+    return img
+
+
+class Frontend:
+    """One pli_ctx: device buffers + stream for up to `max_frames` stereo frames."""
+
+    def __init__(self, cfg, device=0):
+        self.cfg = cfg
+        self.L = capi.lib()
+        self.h = C.c_void_p()
+        check(self.L.pli_ctx_create(C.byref(cfg), device, C.byref(self.h)))
+        self.layout = capi.TableLayout()
+        check(self.L.pli_ctx_layout(self.h, C.byref(self.layout)))
+        self.kp_cap = self.layout.kp_cap
+        self.kl_cap = self.layout.kl_cap
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.pli_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- per-call drop-ins -------------------------------------------------
+    def orb_extract(self, eye, image):
+        """ORBextractor::operator(); returns (n, keypoints, descriptors). n = -1 for an empty image."""
+        if image is None or getattr(image, "size", 0) == 0:
+            n = C.c_int32()
+            st = self.L.pli_orb_extract(self.h, eye, None, 0, 0, 0, None, 0, None, C.byref(n))
+            if st != -2:
+                check(st)
+            return -1, np.zeros(0, KEYPOINT_DT), np.zeros((0, 32), np.uint8)
+        image = _u8(image)
+        kp = np.zeros(self.kp_cap, KEYPOINT_DT)
+        desc = np.zeros((self.kp_cap, 32), np.uint8)
+        n = C.c_int32()
+        check(self.L.pli_orb_extract(self.h, eye, ptr(image), image.shape[1], image.shape[0], image.strides[0],
+                                     ptr(kp), self.kp_cap, ptr(desc), C.byref(n)))
+        return n.value, kp[:n.value].copy(), desc[:n.value].copy()
+
+    def pyramid_level(self, eye, level):
+        w, h = C.c_int32(), C.c_int32()
+        check(self.L.pli_orb_pyramid_level(self.h, eye, level, None, 0, C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value), np.uint8)
+        check(self.L.pli_orb_pyramid_level(self.h, eye, level, ptr(out), out.size, C.byref(w), C.byref(h)))
+        return out
+
+    def line_extract(self, eye, image):
+        """Lineextractor::operator(); returns (n, keylines, descriptors)."""
+        image = _u8(image)
+        kl = np.zeros(self.kl_cap, KEYLINE_DT)
+        desc = np.zeros((self.kl_cap, 32), np.uint8)
+        n = C.c_int32()
+        check(self.L.pli_line_extract(self.h, eye, ptr(image), image.shape[1], image.shape[0], image.strides[0],
+                                      ptr(kl), self.kl_cap, ptr(desc), C.byref(n)))
+        return n.value, kl[:n.value].copy(), desc[:n.value].copy()
+
+    def compute_stereo_matches(self):
+        """Frame::ComputeStereoMatches: (mvuRight, mvDepth) for the left keypoints."""
+        ur = np.zeros(self.kp_cap, np.float32)
+        dp = np.zeros(self.kp_cap, np.float32)
+        check(self.L.pli_stereo_match_points(self.h, ptr(ur), ptr(dp), self.kp_cap))
+        return ur, dp
+
+    def compute_stereo_matches_lines(self):
+        """Frame::ComputeStereoMatches_Lines: (mvDisparity_l [n,2], mvle_l [n,3])."""
+        disp = np.zeros((self.kl_cap, 2), np.float32)
+        le = np.zeros((self.kl_cap, 3), np.float64)
+        check(self.L.pli_stereo_match_lines(self.h, ptr(disp), ptr(le), self.kl_cap))
+        return disp, le
+
+    # ---- stateless matchers --------------------------------------------------
+    def descriptor_distance(self, a, b):
+        a, b = np.ascontiguousarray(a, np.uint8), np.ascontiguousarray(b, np.uint8)
+        out = np.zeros(a.shape[0], np.int32)
+        check(self.L.pli_descriptor_distance(self.h, ptr(a), ptr(b), a.shape[0], ptr(out)))
+        return out
+
+    def knn2(self, q, t):
+        q, t = np.ascontiguousarray(q, np.uint8), np.ascontiguousarray(t, np.uint8)
+        idx = np.zeros((q.shape[0], 2), np.int32)
+        dist = np.zeros((q.shape[0], 2), np.int32)
+        check(self.L.pli_hamming_knn2(self.h, ptr(q), q.shape[0], ptr(t), t.shape[0], ptr(idx), ptr(dist)))
+        return idx, dist
+
+    def match(self, desc1, desc2, nnr):
+        """int match(desc1, desc2, nnr, matches_12): returns (nmatches, matches_12)."""
+        d1, d2 = np.ascontiguousarray(desc1, np.uint8), np.ascontiguousarray(desc2, np.uint8)
+        m = np.full(d1.shape[0], -1, np.int32)
+        n = C.c_int32()
+        check(self.L.pli_match_lines(self.h, ptr(d1), d1.shape[0], ptr(d2), d2.shape[0], nnr, ptr(m), C.byref(n)))
+        return n.value, m
+
+    def search_by_projection(self, queries, qdesc, cur_kp, cur_desc, cur_uright, bounds, check_orientation=True):
+        q = np.ascontiguousarray(queries, PROJ_QUERY_DT)
+        qd = np.ascontiguousarray(qdesc, np.uint8)
+        kp = np.ascontiguousarray(cur_kp, KEYPOINT_DT)
+        de = np.ascontiguousarray(cur_desc, np.uint8)
+        ur = np.ascontiguousarray(cur_uright, np.float32)
+        best = np.full(q.shape[0], -1, np.int32)
+        n = C.c_int32()
+        check(self.L.pli_search_by_projection(self.h, ptr(q), ptr(qd), q.shape[0], ptr(kp), ptr(de), ptr(ur),
+                                              kp.shape[0], bounds[0], bounds[1], bounds[2], bounds[3],
+                                              int(check_orientation), ptr(best), C.byref(n)))
+        return n.value, best
+
+    # ---- batch path ----------------------------------------------------------
+    def table_bytes(self, nframes):
+        return int(self.layout.record_bytes) * nframes
+
+    def batch_run_host(self, images, stages=capi.RUN_ALL):
+        """images: (nframes, 2, H, W) u8.  Returns the list of parsed frame records."""
+        images = np.ascontiguousarray(images, np.uint8)
+        nf, two, H, W = images.shape
+        assert two == 2
+        left = np.ascontiguousarray(images[:, 0])
+        right = np.ascontiguousarray(images[:, 1])
+        table = np.zeros(self.table_bytes(nf), np.uint8)
+        check(self.L.pli_batch_run_host(self.h, nf, ptr(left), ptr(right), W, W * H, stages, ptr(table)))
+        return [self.parse_record(table, f) for f in range(nf)]
+
+    def batch_run_device(self, nframes, dev_left, dev_right, stride, frame_stride, dev_table, stages=capi.RUN_ALL):
+        """Asynchronous: device pointers (ints) in, device table out; sync() to wait."""
+        check(self.L.pli_batch_run(self.h, nframes, C.c_void_p(dev_left), C.c_void_p(dev_right), stride, frame_stride,
+                                   stages, C.c_void_p(dev_table)))
+
+    def sync(self):
+        check(self.L.pli_ctx_sync(self.h))
+
+    def set_stream(self, hip_stream):
+        check(self.L.pli_ctx_set_stream(self.h, C.c_void_p(hip_stream)))
+
+    def parse_record(self, table, frame):
+        """Slice one frame record (numpy u8 array of the whole table) into named arrays."""
+        Y = self.layout
+        rec = table[frame * Y.record_bytes:(frame + 1) * Y.record_bytes]
+        counts = rec[Y.off_counts:Y.off_counts + 32].view(np.int32)
+        out = {"counts": counts.copy()}
+        for e, name in ((0, "L"), (1, "R")):
+            n = int(counts[e])
+            out["kp" + name] = rec[Y.off_kp[e]:Y.off_kp[e] + 24 * n].view(KEYPOINT_DT).copy()
+            out["desc" + name] = rec[Y.off_desc[e]:Y.off_desc[e] + 32 * n].reshape(n, 32).copy()
+            m = int(counts[2 + e])
+            out["kl" + name] = rec[Y.off_kl[e]:Y.off_kl[e] + 68 * m].view(KEYLINE_DT).copy()
+            out["ldesc" + name] = rec[Y.off_ldesc[e]:Y.off_ldesc[e] + 32 * m].reshape(m, 32).copy()
+        n, m = int(counts[0]), int(counts[2])
+        out["uright"] = rec[Y.off_uright:Y.off_uright + 4 * n].view(np.float32).copy()
+        out["depth"] = rec[Y.off_depth:Y.off_depth + 4 * n].view(np.float32).copy()
+        out["disp"] = rec[Y.off_disp:Y.off_disp + 8 * m].view(np.float32).reshape(m, 2).copy()
+        out["le"] = rec[Y.off_le:Y.off_le + 24 * m].view(np.float64).reshape(m, 3).copy()
+        return out
+
+    # ---- measurement / debug ---------------------------------------------------
+    def prof_enable(self, on=True):
+        check(self.L.pli_prof_enable(self.h, int(on)))
+
+    def prof_reset(self):
+        check(self.L.pli_prof_reset(self.h))
+
+    def prof_report(self):
+        """{kernel name: (calls, total_ms)} measured with HIP events on the context stream."""
+        buf = C.create_string_buffer(1 << 16)
+        check(self.L.pli_prof_report(self.h, buf, len(buf)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, calls, ms = line.split()
+            out[name] = (int(calls), float(ms))
+        return out
+
+    def debug_enable(self, on=True):
+        check(self.L.pli_debug_enable(self.h, int(on)))
+
+    def debug_fetch(self, image, what, arg=0):
+        n = C.c_int64()
+        check(self.L.pli_debug_fetch(self.h, image, what, arg, None, 0, C.byref(n)))
+        buf = np.zeros(max(int(n.value), 1), np.uint8)
+        check(self.L.pli_debug_fetch(self.h, image, what, arg, ptr(buf), buf.size, C.byref(n)))
+        return buf[:n.value]
+
+    def debug_points(self, image, what, level):
+        raw = self.debug_fetch(image, what, level).view(np.int32)
+        return raw[1:1 + 3 * raw[0]].reshape(-1, 3).copy()
+
+
+class ORBextractor:
+    """Mirror of ORB_SLAM3::ORBextractor (include/ORBextractor.h:46-115)."""
+
+    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, image_size, eye=0, frontend=None):
+        w, h = image_size
+        self.eye = eye
+        if frontend is None:
+            cfg = capi.default_config(w, h, orb_nfeatures=nfeatures, orb_scale_factor=scaleFactor,
+                                      orb_nlevels=nlevels, orb_ini_th_fast=iniThFAST, orb_min_th_fast=minThFAST)
+            frontend = Frontend(cfg)
+        self.fe = frontend
+        self.nlevels = nlevels
+        self.scaleFactor = np.float32(scaleFactor)
+
+    def __call__(self, image, mask=None, vLappingArea=(0, 0)):
+        """Returns (monoCount, keypoints, descriptors); -1 for an empty image like the reference."""
+        n, kp, desc = self.fe.orb_extract(self.eye, image)
+        return n, kp, desc
+
+    def GetLevels(self):
+        return self.nlevels
+
+    def GetScaleFactor(self):
+        return float(self.scaleFactor)
+
+    def GetScaleFactors(self):
+        s = [np.float32(1.0)]
+        for _ in range(1, self.nlevels):
+            s.append(np.float32(s[-1] * self.scaleFactor))
+        return np.array(s, np.float32)
+
+    def GetInverseScaleFactors(self):
+        return (np.float32(1.0) / self.GetScaleFactors()).astype(np.float32)
+
+    @property
+    def mvImagePyramid(self):
+        return [self.fe.pyramid_level(self.eye, l) for l in range(self.nlevels)]
+
+
+class Lineextractor:
+    """Mirror of ORB_SLAM3::Lineextractor (include/LineExtractor.h:41-74)."""
+
+    def __init__(self, lsd_nfeatures, min_line_length, lsd_refine, lsd_scale, lsd_sigma_scale, lsd_quant, lsd_ang_th,
+                 lsd_log_eps, lsd_density_th, lsd_n_bins, image_size, eye=0, frontend=None):
+        w, h = image_size
+        self.eye = eye
+        if frontend is None:
+            cfg = capi.default_config(w, h, lsd_nfeatures=lsd_nfeatures, min_line_length=min_line_length,
+                                      lsd_refine=lsd_refine, lsd_scale=lsd_scale, lsd_sigma_scale=lsd_sigma_scale,
+                                      lsd_quant=lsd_quant, lsd_ang_th=lsd_ang_th, lsd_log_eps=lsd_log_eps,
+                                      lsd_density_th=lsd_density_th, lsd_n_bins=lsd_n_bins)
+            frontend = Frontend(cfg)
+        self.fe = frontend
+
+    def __call__(self, image, mask=None):
+        """Returns (keylines, descriptors_line)."""
+        n, kl, desc = self.fe.line_extract(self.eye, image)
+        return kl, desc
