@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Headline benchmark: stereo frames/s of the point+line front-end on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W [--frames-per-gpu F]
+
+One "step" = one pass of the whole per-frame hot path (ORB extract x2, LSD/LBD
+extract x2, stereo point + line matching) over a batch of F synthetic
+EuRoC-shaped stereo frames (752x480, 1200 ORB features, 100 lines) that are
+already resident in HBM, followed for N > 1 by the RCCL gather of the per-frame
+result tables to rank 0.  Weak scaling: every rank processes its own F frames.
+Rank 0 prints ONE JSON line (see the driver contract in the task statement).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+
+
+# algorithmic bytes per stereo frame of the whole path.
+def path_bytes_per_frame(W, H, nlevels, scale, n_kp, n_l, lsd_scale=1.2):
+    P = []
+    s = np.float32(1.0)
+    for l in range(nlevels):
+        inv = np.float32(1.0) / s
+        P.append(int(np.rint(np.float32(W) * inv)) * int(np.rint(np.float32(H) * inv)))
+        s = np.float32(s * np.float32(scale))
+    P0, SP = P[0], sum(P)
+    Pp = int(np.rint(W * lsd_scale)) * int(np.rint(H * lsd_scale))
+    ell = 0.1 * max(W, H)
+    orb = P0 + 2 * (SP - P0) + 2 * SP
+    lsd = P0 + 2 * Pp + 16 * Pp
+    lbd = P0 + 2 * P0 + 4 * P0 + 252 * n_l * ell
+    out = 52 * n_kp + 100 * n_l
+    b_img = orb + lsd + lbd + out
+    return 2 * b_img + 64 * (n_kp + n_l), {"P0": P0, "SP": SP, "Pp": Pp}
+
+
+# Algorithmic bytes of ONE launch of each kernel per image (terms of the §8(d) formula;
+# DESIGN.md "Kernels" lists the derivation).  Used for the roofline of the dominant kernel.
+def kernel_bytes_per_image(name, g, n_kp, n_l, W, H):
+    P0, SP, Pp = g["P0"], g["SP"], g["Pp"]
+    ell = 0.1 * max(W, H)
+    table = {
+        "k_ingest": 2 * P0,
+        "k_resize_level": None,                       # per-level launches, see below
+        "k_fast_cells": SP,                           # read every pyramid pixel once
+        "k_octree": 8 * 10 * n_kp,                    # candidate list in/out
+        "k_blur_orb": 2 * SP,                         # pyramid read + blurred pyramid write
+        "k_describe": SP + 52 * n_kp,                 # blurred pyramid read (patches) + tables
+        "k_kp_counts": 64,
+        "k_blur_lsd": 2 * P0,
+        "k_resize_lsd": P0 + Pp,
+        "k_lsd_grad": Pp + 16 * Pp,                   # scaled u8 read; angle/modgrad/cos/sin write
+        "k_lsd_hist": 4 * Pp,
+        "k_lsd_scan": 0,
+        "k_lsd_scatter": 8 * Pp,
+        "k_lsd_grow": 8 * Pp,                         # f32 angle + f32 modgrad read once
+        "k_lsd_ccl": 8 * Pp,
+        "k_keylines": 100 * n_l,
+        "k_blur_lbd": 2 * P0,
+        "k_sobel": P0 + 4 * P0,
+        "k_lbd": 252 * n_l * ell + 100 * n_l,
+        "k_stereo_points": 64 * n_kp,
+        "k_stereo_median": 8 * n_kp,
+        "k_stereo_lines": 64 * n_l,
+    }
+    return table.get(name)
+
+
+def cpu_baseline(images, cfg_bytes, budget_s=20.0):
+    """The oracle (CPU restatement of the reference path) timed on the host cores of this box."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import pyoracle as po
+    cores = os.cpu_count() or 1
+    nthreads = max(1, min(cores, 64))
+    frames = [po.Frame(po.Config.from_buffer_copy(cfg_bytes)) for _ in range(nthreads)]
+    nimg = images.shape[0]
+    # calibrate on one frame, then size the sample to ~budget_s of wall time
+    t0 = time.perf_counter()
+    frames[0].run(images[0, 0], images[0, 1])
+    t1 = time.perf_counter() - t0
+    total = int(max(nthreads, min(8 * nthreads, budget_s / max(t1, 1e-3) * nthreads * 0.6)))
+
+    def work(tid):
+        k = 0
+        for i in range(tid, total, nthreads):
+            frames[tid].run(images[i % nimg, 0], images[i % nimg, 1])
+            k += 1
+        return k
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(nthreads) as ex:
+        done = sum(ex.map(work, range(nthreads)))
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "stereo frames/s", "cores": nthreads, "kind": "port",
+            "sample": "%d stereo frames (cycled over the GPU batch) on %d threads, one oracle frame pipeline per "
+                      "thread, %.1f s; single frame single thread %.3f s" % (done, nthreads, dt, t1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames-per-gpu", type=int, default=32)
+    ap.add_argument("--width", type=int, default=752)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--nfeatures", type=int, default=1200)
+    ap.add_argument("--nlines", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the front-end has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from pli_slam_amd import capi, synth
+    from pli_slam_amd.frontend import Frontend
+
+    F, W, H = args.frames_per_gpu, args.width, args.height
+    cfg = capi.default_config(W, H, orb_nfeatures=args.nfeatures, lsd_nfeatures=args.nlines, max_frames=F)
+    fe = Frontend(cfg, device=local_rank)
+    images = synth.make_batch(F, W, H, seed0=rank * F)                 # (F, 2, H, W) u8, seeds disjoint per rank
+    d_img = torch.from_numpy(images).to(dev)                           # resident in HBM before timing
+    d_left, d_right = d_img[:, 0].contiguous(), d_img[:, 1].contiguous()
+    rec_bytes = int(fe.layout.record_bytes)
+    d_table = torch.zeros(F * rec_bytes, dtype=torch.uint8, device=dev)
+    gather_list = [torch.empty_like(d_table) for _ in range(world)] if (world > 1 and rank == 0) else None
+    fe.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def step():
+        fe.batch_run_device(F, d_left.data_ptr(), d_right.data_ptr(), W, W * H, d_table.data_ptr())
+        if world > 1:
+            dist.gather(d_table, gather_list, dst=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    fe.prof_reset()
+    fe.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    fe.prof_enable(False)
+    prof = fe.prof_report()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        b_frame, g = path_bytes_per_frame(W, H, cfg.orb_nlevels, cfg.orb_scale_factor, args.nfeatures, args.nlines,
+                                          cfg.lsd_scale)
+        fps = world * F * args.steps / dt
+        # dominant kernel by HIP-event time on the stream it ran on
+        dom = max(prof.items(), key=lambda kv: kv[1][1]) if prof else (None, (0, 0.0))
+        name, (calls, total_ms) = dom
+        per_img = kernel_bytes_per_image(name, g, args.nfeatures, args.nlines, W, H) if name else None
+        avg_s = (total_ms / max(calls, 1)) * 1e-3
+        peak = 8000.0
+        if per_img is not None and avg_s > 0:
+            achieved = per_img * 2 * F / avg_s / 1e9
+        else:
+            achieved = None
+        roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": peak, "unit": "GB/s",
+                "frac": (achieved / peak) if achieved is not None else None, "traffic": None,
+                "avg_launch_ms": avg_s * 1e3, "launches": calls,
+                "path_achieved": fps / world * b_frame / 1e9, "path_frac": fps / world * b_frame / 1e9 / peak,
+                "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in
+                                       sorted(prof.items(), key=lambda kv: -kv[1][1])}}
+        out = {
+            "metric": "stereo frames/sec (ORB+LSD extract+match), 752x480 EuRoC",
+            "value": fps, "unit": "stereo frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "1xMI355X: %dx%d stereo pairs, %d ORB kp (8 levels x1.2) + LSD/LBD (<=%d lines), "
+                                   "extract + stereo Hamming match; batch of %d stereo frames per GPU per step" %
+                                   (W, H, args.nfeatures, args.nlines, F),
+                       "frames_per_gpu": F, "bytes_per_frame": b_frame,
+                       "parallelism": "frame-batch data parallel, %d rank(s), gather of result tables to rank 0" % world},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(images, bytes(cfg))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -21,16 +21,18 @@ constexpr double D_3_2_PI = (3 * D_PI) / 2;
 constexpr double D_2PI = 2 * D_PI;
 
 // ---------------------------------------------------------------------------
-// k_lsd_grad.  One thread per pixel of the scaled image.
-// ang : level-line angle in degrees (cv::fastAtan2) or -1024 (NOTDEF); the
-//       region grower later overwrites claimed pixels with -1024 (= USED).
-// g2  : gx^2+gy^2 (modgrad = sqrt(g2/4)), 0 on the undefined border.
-// cs  : (float)cos / (float)sin of (float)angle_rad, what region_grow adds per pixel.
+// k_lsd_grad.  One thread per pixel of the scaled image.  Per pixel it writes
+//   rec = { ang, c, s, g2 } (16 bytes, what the region grower needs in one load):
+//     ang : level-line angle in degrees (cv::fastAtan2) or -1024 (NOTDEF); the
+//           region grower overwrites claimed pixels with -1024 (= USED)
+//     c,s : (float)cos / (float)sin of (float)angle_rad, what region_grow adds per pixel
+//     g2  : gx^2+gy^2 as int bits (modgrad = sqrt(g2/4))
+//   g2o : the same g2 as a plain int plane for the bin-ordering kernels.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ scaled, int64_t imgStride, int W, int H,
-                                                  int pitch, int g2Thresh, float* __restrict__ ang,
-                                                  int* __restrict__ g2o, float2* __restrict__ cs,
-                                                  int* __restrict__ maxG2, float* __restrict__ angDbg, int img0) {
+                                                  int pitch, int g2Thresh, float4* __restrict__ rec,
+                                                  int* __restrict__ g2o, int* __restrict__ maxG2,
+                                                  float* __restrict__ angDbg, int img0) {
   const int img = blockIdx.z + img0;
   const int y = blockIdx.y;
   const int x = blockIdx.x * 256 + threadIdx.x;
@@ -38,7 +40,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ sc
   bool defined = false;
   if (x < W) {
     float a = LSD_NOTDEF;
-    float2 c = make_float2(0.f, 0.f);
+    float cx = 0.f, sy = 0.f;
     if (x < W - 1 && y < H - 1) {
       const uint8_t* r0 = scaled + (int64_t)img * imgStride + (int64_t)y * pitch;
       const uint8_t* r1 = r0 + pitch;
@@ -51,14 +53,13 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ sc
         a = fast_atan2_deg((float)gx, (float)(-gy));
         double ad = (double)a * D_DEG2RAD;
         double af = (double)(float)ad;
-        c.x = (float)cos(af);
-        c.y = (float)sin(af);
+        cx = (float)cos(af);
+        sy = (float)sin(af);
       }
     }
     const int64_t o = (int64_t)img * W * H + (int64_t)y * W + x;
-    ang[o] = a;
+    rec[o] = make_float4(a, cx, sy, __int_as_float(g2));
     g2o[o] = g2;
-    cs[o] = c;
     if (angDbg) angDbg[o] = a;
   }
   int m = defined ? g2 : 0;
@@ -173,9 +174,25 @@ __global__ __launch_bounds__(64) void k_lsd_scatter(const int* __restrict__ g2a,
 }
 
 // ---------------------------------------------------------------------------
-// k_lsd_grow: region_grow + region2rect.  v1: one walker (lane 0) per image,
-// visiting the ordered seeds serially exactly like the CPU algorithm.
+// k_lsd_grow: region_grow + region2rect (refine = NONE), one wave per image.
+//
+// The algorithm is sequential by definition (seeds in bin order; a region's
+// angle is updated after every accepted pixel), so the wave cooperates on ONE
+// region at a time instead of splitting the image:
+//   * 64 seeds of the ordered list are fetched per vector load; a ballot keeps
+//     the still-unused ones and every later claim clears its bit, so no seed
+//     is ever re-read;
+//   * lanes 0..8 fetch the 3x3 neighbourhood records of the current region
+//     pixel with one 16-byte load each (one memory round trip per pixel);
+//     ballots over "unused & aligned" reproduce the raster-order accept loop,
+//     re-testing only the neighbours after an accepted one against the
+//     updated region angle;
+//   * the region (x|y, g2) queue lives in LDS; the weighted sums of
+//     region2rect are accumulated in list order by three lanes, one per
+//     running sum, from products computed 64 at a time.
 // ---------------------------------------------------------------------------
+constexpr int LSD_QCAP = 4096;
+
 __device__ __forceinline__ double lsd_angle_diff(double a, double b) {
   double diff = a - b;
   while (diff <= -D_PI) diff += D_2PI;
@@ -183,111 +200,180 @@ __device__ __forceinline__ double lsd_angle_diff(double a, double b) {
   return fabs(diff);
 }
 
-__device__ void lsd_walk(int W, int H, float* __restrict__ ang, const int* __restrict__ g2a,
-                         const float2* __restrict__ cs, const int* __restrict__ order, int nOrder,
-                         int* __restrict__ reg, int minRegSize, double prec, double scale, float* __restrict__ seg,
-                         int* __restrict__ segRank, int maxSeg, int* nSegOut) {
+// broadcast from a wave-uniform lane (v_readlane_b32, no LDS crossbar)
+__device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+__device__ __forceinline__ uint2 lsd_qget(const uint2* qs, const uint2* qg, int k) {
+  return k < LSD_QCAP ? qs[k] : qg[k - LSD_QCAP];
+}
+
+__global__ __launch_bounds__(64) void k_lsd_grow(const DevParams* __restrict__ Pp, float4* __restrict__ recAll,
+                                                 const int* __restrict__ orderAll, const int* __restrict__ nDefined,
+                                                 uint2* __restrict__ regOverflow, float* __restrict__ segAll,
+                                                 int* __restrict__ nSeg, int maxSeg, int img0) {
+  __shared__ uint2 qs[LSD_QCAP];
+  __shared__ double st[3][64];
+  const DevParams& P = *Pp;
+  const int img = blockIdx.x + img0;
+  const int lane = threadIdx.x;
+  const int W = P.LW, H = P.LH;
+  const int64_t npix = (int64_t)W * H;
+  float4* rec = recAll + img * npix;
+  const int* order = orderAll + img * npix;
+  uint2* qg = regOverflow + img * npix;
+  float* seg = segAll + (int64_t)img * maxSeg * 4;
+  const int nOrder = nDefined[img];
+  const int minReg = P.minRegSize;
+  const double prec = P.prec, scale = P.lsdScale;
+  const int ndx = lane % 3 - 1, ndy = (lane / 3) % 3 - 1;   // lanes 0..8: raster order of the 3x3 block
   int nseg = 0;
-  for (int i = 0; i < nOrder; ++i) {
-    const int sp = order[i];
-    const float sa = ang[sp];
-    if (sa == LSD_NOTDEF) continue;
-    double reg_angle = (double)sa * D_DEG2RAD;
-    reg[0] = sp;
-    int cnt = 1;
-    float sumdx = (float)cos(reg_angle);
-    float sumdy = (float)sin(reg_angle);
-    ang[sp] = LSD_NOTDEF;
-    for (int k = 0; k < cnt; ++k) {
-      const int p = reg[k];
-      const int py = p / W, px = p - py * W;
-      const int xx_min = max(px - 1, 0), xx_max = min(px + 1, W - 1);
-      const int yy_min = max(py - 1, 0), yy_max = min(py + 1, H - 1);
-      for (int yy = yy_min; yy <= yy_max; ++yy)
-        for (int xx = xx_min; xx <= xx_max; ++xx) {
-          const int q = yy * W + xx;
-          const float a = ang[q];
-          if (a == LSD_NOTDEF) continue;             // undefined or already used
-          double n_theta = reg_angle - (double)a * D_DEG2RAD;
+
+  for (int base = 0; base < nOrder; base += 64) {
+    const int idx = base + lane;
+    const bool valid = idx < nOrder;
+    const int sp_l = valid ? order[idx] : -1;
+    float4 srec = make_float4(LSD_NOTDEF, 0.f, 0.f, 0.f);
+    if (valid) srec = rec[sp_l];
+    // seed sums: float(cos(reg_angle)), float(sin(reg_angle)) with reg_angle = angle as double
+    float scos = 0.f, ssin = 0.f;
+    if (srec.x != LSD_NOTDEF) {
+      const double ra = (double)srec.x * D_DEG2RAD;
+      scos = (float)cos(ra);
+      ssin = (float)sin(ra);
+    }
+    unsigned long long unusedMask = __ballot(srec.x != LSD_NOTDEF);
+    while (unusedMask) {
+      const int j = __ffsll((long long)unusedMask) - 1;
+      unusedMask &= unusedMask - 1ull;
+      const int sp = rl_i(sp_l, j);
+      const float sa = rl_f(srec.x, j);
+      float sumdx = rl_f(scos, j), sumdy = rl_f(ssin, j);
+      const int sg2 = __float_as_int(rl_f(srec.w, j));
+      double reg_angle = (double)sa * D_DEG2RAD;
+      const int spy = sp / W, spx = sp - spy * W;
+      if (lane == 0) {
+        rec[sp].x = LSD_NOTDEF;
+        qs[0] = make_uint2(((unsigned)spy << 16) | (unsigned)spx, (unsigned)sg2);
+      }
+      int cnt = 1;
+      for (int k = 0; k < cnt; ++k) {
+        __syncthreads();                           // one wave per block: orders lane 0's queue writes before the reads
+        const uint2 e = lsd_qget(qs, qg, k);       // uniform address: LDS broadcast
+        const int px = (int)(e.x & 0xFFFFu), py = (int)(e.x >> 16);
+        const int nx = px + ndx, ny = py + ndy;
+        const bool inb = lane < 9 && nx >= 0 && ny >= 0 && nx < W && ny < H;
+        const int qi = ny * W + nx;
+        float4 r = make_float4(LSD_NOTDEF, 0.f, 0.f, 0.f);
+        if (inb) r = rec[qi];
+        const bool cand = r.x != LSD_NOTDEF;
+        const double ad = (double)r.x * D_DEG2RAD;
+        unsigned long long remaining = __ballot(cand);
+        while (remaining) {
+          double n_theta = reg_angle - ad;
           if (n_theta < 0) n_theta = -n_theta;
           if (n_theta > D_3_2_PI) {
             n_theta -= D_2PI;
             if (n_theta < 0) n_theta = -n_theta;
           }
-          if (n_theta <= prec) {
-            ang[q] = LSD_NOTDEF;
-            reg[cnt++] = q;
-            const float2 c = cs[q];
-            sumdx = __fadd_rn(sumdx, c.x);
-            sumdy = __fadd_rn(sumdy, c.y);
-            reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * D_DEG2RAD;
+          const unsigned long long m = __ballot(cand && n_theta <= prec) & remaining;
+          if (!m) break;
+          const int j2 = __ffsll((long long)m) - 1;
+          remaining &= ~((2ull << j2) - 1ull);
+          const int qj = rl_i(qi, j2);
+          const float cj = rl_f(r.y, j2), sj = rl_f(r.z, j2);
+          const unsigned g2j = (unsigned)__float_as_int(rl_f(r.w, j2));
+          const unsigned xyj = ((unsigned)(py + j2 / 3 - 1) << 16) | (unsigned)(px + j2 % 3 - 1);
+          if (lane == j2) rec[qi].x = LSD_NOTDEF;
+          if (lane == 0) {
+            if (cnt < LSD_QCAP) qs[cnt] = make_uint2(xyj, g2j);
+            else qg[cnt - LSD_QCAP] = make_uint2(xyj, g2j);
           }
+          ++cnt;
+          sumdx = __fadd_rn(sumdx, cj);
+          sumdy = __fadd_rn(sumdy, sj);
+          reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * D_DEG2RAD;
+          unusedMask &= ~__ballot(sp_l == qj);
         }
+        if (cnt > LSD_QCAP) __threadfence_block();   // overflow entries are read back through global memory
+      }
+      if (cnt < minReg) continue;
+      // ---- region2rect ----------------------------------------------------
+      // pass 1: x = sum x*w, y = sum y*w, sum = sum w, in list order
+      double acc = 0.0;                                   // lanes 0,1,2 hold x, y, sum
+      for (int c0 = 0; c0 < cnt; c0 += 64) {
+        const int k = c0 + lane;
+        if (k < cnt) {
+          const uint2 e = lsd_qget(qs, qg, k);
+          const double w = sqrt((double)(int)e.y / 4.0);
+          st[0][lane] = (double)(int)(e.x & 0xFFFFu) * w;
+          st[1][lane] = (double)(int)(e.x >> 16) * w;
+          st[2][lane] = w;
+        }
+        __syncthreads();
+        if (lane < 3) {
+          const int m = min(64, cnt - c0);
+          for (int t = 0; t < m; ++t) acc += st[lane][t];
+        }
+        __syncthreads();
+      }
+      const double sum = __shfl(acc, 2, 64);
+      const double x = __shfl(acc, 0, 64) / sum, y = __shfl(acc, 1, 64) / sum;
+      // pass 2: inertia
+      acc = 0.0;                                          // lanes 0,1,2 hold Ixx, Iyy, Ixy
+      for (int c0 = 0; c0 < cnt; c0 += 64) {
+        const int k = c0 + lane;
+        if (k < cnt) {
+          const uint2 e = lsd_qget(qs, qg, k);
+          const double w = sqrt((double)(int)e.y / 4.0);
+          const double dx = (double)(int)(e.x & 0xFFFFu) - x, dy = (double)(int)(e.x >> 16) - y;
+          st[0][lane] = dy * dy * w;
+          st[1][lane] = dx * dx * w;
+          st[2][lane] = dx * dy * w;
+        }
+        __syncthreads();
+        if (lane < 2) {
+          const int m = min(64, cnt - c0);
+          for (int t = 0; t < m; ++t) acc += st[lane][t];
+        } else if (lane == 2) {
+          const int m = min(64, cnt - c0);
+          for (int t = 0; t < m; ++t) acc -= st[2][t];
+        }
+        __syncthreads();
+      }
+      const double Ixx = __shfl(acc, 0, 64), Iyy = __shfl(acc, 1, 64), Ixy = __shfl(acc, 2, 64);
+      const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
+      double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)fast_atan2_deg((float)(lambda - Ixx), (float)Ixy)
+                                             : (double)fast_atan2_deg((float)Ixy, (float)(lambda - Iyy));
+      theta *= D_DEG2RAD;
+      if (lsd_angle_diff(theta, reg_angle) > prec) theta += D_PI;
+      const double dxr = cos(theta), dyr = sin(theta);
+      // pass 3: extent along the main axis (min/max are order independent)
+      double l_min = 0, l_max = 0;
+      for (int k = lane; k < cnt; k += 64) {
+        const uint2 e = lsd_qget(qs, qg, k);
+        const double l = ((double)(int)(e.x & 0xFFFFu) - x) * dxr + ((double)(int)(e.x >> 16) - y) * dyr;
+        l_max = fmax(l_max, l);
+        l_min = fmin(l_min, l);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        l_max = fmax(l_max, __shfl_xor(l_max, o, 64));
+        l_min = fmin(l_min, __shfl_xor(l_min, o, 64));
+      }
+      double x1 = x + l_min * dxr, y1 = y + l_min * dyr, x2 = x + l_max * dxr, y2 = y + l_max * dyr;
+      x1 += 0.5; y1 += 0.5; x2 += 0.5; y2 += 0.5;
+      if (scale != 1) { x1 /= scale; y1 /= scale; x2 /= scale; y2 /= scale; }
+      if (nseg < maxSeg && lane == 0) {
+        seg[4 * nseg + 0] = (float)x1;
+        seg[4 * nseg + 1] = (float)y1;
+        seg[4 * nseg + 2] = (float)x2;
+        seg[4 * nseg + 3] = (float)y2;
+      }
+      ++nseg;
     }
-    if (cnt < minRegSize) continue;
-    // region2rect
-    double x = 0, y = 0, sum = 0;
-    for (int k = 0; k < cnt; ++k) {
-      const int p = reg[k];
-      const int py = p / W, px = p - py * W;
-      const double w = sqrt((double)g2a[p] / 4.0);
-      x += (double)px * w;
-      y += (double)py * w;
-      sum += w;
-    }
-    x /= sum;
-    y /= sum;
-    double Ixx = 0.0, Iyy = 0.0, Ixy = 0.0;
-    for (int k = 0; k < cnt; ++k) {
-      const int p = reg[k];
-      const int py = p / W, px = p - py * W;
-      const double w = sqrt((double)g2a[p] / 4.0);
-      const double dx = (double)px - x, dy = (double)py - y;
-      Ixx += dy * dy * w;
-      Iyy += dx * dx * w;
-      Ixy -= dx * dy * w;
-    }
-    const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
-    double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)fast_atan2_deg((float)(lambda - Ixx), (float)Ixy)
-                                           : (double)fast_atan2_deg((float)Ixy, (float)(lambda - Iyy));
-    theta *= D_DEG2RAD;
-    if (lsd_angle_diff(theta, reg_angle) > prec) theta += D_PI;
-    const double dx = cos(theta), dy = sin(theta);
-    double l_min = 0, l_max = 0;
-    for (int k = 0; k < cnt; ++k) {
-      const int p = reg[k];
-      const int py = p / W, px = p - py * W;
-      const double l = ((double)px - x) * dx + ((double)py - y) * dy;
-      if (l > l_max) l_max = l;
-      else if (l < l_min) l_min = l;
-    }
-    double x1 = x + l_min * dx, y1 = y + l_min * dy, x2 = x + l_max * dx, y2 = y + l_max * dy;
-    x1 += 0.5; y1 += 0.5; x2 += 0.5; y2 += 0.5;
-    if (scale != 1) { x1 /= scale; y1 /= scale; x2 /= scale; y2 /= scale; }
-    if (nseg < maxSeg) {
-      seg[4 * nseg + 0] = (float)x1;
-      seg[4 * nseg + 1] = (float)y1;
-      seg[4 * nseg + 2] = (float)x2;
-      seg[4 * nseg + 3] = (float)y2;
-      if (segRank) segRank[nseg] = i;
-    }
-    ++nseg;
   }
-  *nSegOut = nseg < maxSeg ? nseg : maxSeg;
-}
-
-__global__ __launch_bounds__(64) void k_lsd_grow(const DevParams* __restrict__ Pp, float* __restrict__ ang,
-                                                 const int* __restrict__ g2a, const float2* __restrict__ cs,
-                                                 const int* __restrict__ order, const int* __restrict__ nDefined,
-                                                 int* __restrict__ regScratch, float* __restrict__ seg,
-                                                 int* __restrict__ nSeg, int maxSeg, int img0) {
-  const DevParams& P = *Pp;
-  const int img = blockIdx.x + img0;
-  if (threadIdx.x != 0) return;
-  const int64_t npix = (int64_t)P.LW * P.LH;
-  lsd_walk(P.LW, P.LH, ang + img * npix, g2a + img * npix, cs + img * npix, order + img * npix, nDefined[img],
-           regScratch + img * npix, P.minRegSize, P.prec, P.lsdScale, seg + (int64_t)img * maxSeg * 4, nullptr, maxSeg,
-           &nSeg[img]);
+  if (lane == 0) nSeg[img] = nseg < maxSeg ? nseg : maxSeg;
 }
 
 // ---------------------------------------------------------------------------

@@ -56,9 +56,9 @@ struct pli_ctx {
   int64_t tmp8Stride = 0, lsdStride = 0;
   int tmpPitch = 0;
   int* lsdTab = nullptr;
-  float* ang = nullptr; int* g2 = nullptr; float2* cs = nullptr; int* maxG2 = nullptr;
+  float4* rec = nullptr; int* g2 = nullptr; int* maxG2 = nullptr;
   unsigned short* chunkHist = nullptr; int* chunkBase = nullptr; int* nDefined = nullptr;
-  int* order = nullptr; int* regScratch = nullptr; float* seg = nullptr; int* nSeg = nullptr;
+  int* order = nullptr; uint2* regScratch = nullptr; float* seg = nullptr; int* nSeg = nullptr;
   int nChunks = 0, maxSeg = 0;
   pli_keyline* tmpKL = nullptr;
   short *dx = nullptr, *dy = nullptr;
@@ -380,9 +380,8 @@ pli_status allocAll(pli_ctx* c) {
     HIPCHK(hipMemcpy(c->lsdTab, t.data(), t.size() * 4, hipMemcpyHostToDevice));
   }
   const size_t npix = (size_t)P.LW * P.LH;
-  A(c->ang, npix * NI);
+  A(c->rec, npix * NI);
   A(c->g2, npix * NI);
-  A(c->cs, npix * NI);
   A(c->maxG2, NI);
   c->nChunks = (int)((npix + 1023) / 1024);
   A(c->chunkHist, (size_t)NI * c->nChunks * P.nBins);
@@ -476,7 +475,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   HIPCHK(hipMemsetAsync(c->maxG2 + img0, 0, sizeof(int) * nimg, c->stream));
   {
     dim3 g((P.LW + 255) / 256, P.LH, nimg);
-    LAUNCH(c, "k_lsd_grad", k_lsd_grad, g, dim3(256), 0, scaled, sStride, P.LW, P.LH, sPitch, P.g2Thresh, c->ang, c->g2, c->cs,
+    LAUNCH(c, "k_lsd_grad", k_lsd_grad, g, dim3(256), 0, scaled, sStride, P.LW, P.LH, sPitch, P.g2Thresh, c->rec, c->g2,
            c->maxG2, c->debug ? c->angDbg : (float*)nullptr, img0);
   }
   LAUNCH(c, "k_lsd_hist", k_lsd_hist, dim3(c->nChunks, nimg), dim3(256), 0, c->g2, npix, P.g2Thresh, P.nBins, c->maxG2,
@@ -484,7 +483,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   LAUNCH(c, "k_lsd_scan", k_lsd_scan, dim3(nimg), dim3(1024), 0, c->chunkHist, c->nChunks, P.nBins, c->chunkBase, c->nDefined, img0);
   LAUNCH(c, "k_lsd_scatter", k_lsd_scatter, dim3(c->nChunks, nimg), dim3(64), 0, c->g2, npix, P.g2Thresh, P.nBins, c->maxG2,
          c->chunkBase, c->nChunks, c->order, img0);
-  LAUNCH(c, "k_lsd_grow", k_lsd_grow, dim3(nimg), dim3(64), 0, c->dP, c->ang, c->g2, c->cs, c->order, c->nDefined,
+  LAUNCH(c, "k_lsd_grow", k_lsd_grow, dim3(nimg), dim3(64), 0, c->dP, c->rec, c->order, c->nDefined,
          c->regScratch, c->seg, c->nSeg, c->maxSeg, img0);
   LAUNCH(c, "k_keylines", k_keylines, dim3(nimg), dim3(256), 0, c->dP, c->seg, c->nSeg, c->maxSeg, c->tmpKL, table,
          Y.record_bytes, Y.off_counts, Y.off_kl[0], Y.off_kl[1], img0);
