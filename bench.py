@@ -142,13 +142,13 @@ def main():
     d_left, d_right = d_img[:, 0].contiguous(), d_img[:, 1].contiguous()
     rec_bytes = int(fe.layout.record_bytes)
     d_table = torch.zeros(F * rec_bytes, dtype=torch.uint8, device=dev)
-    gather_list = [torch.empty_like(d_table) for _ in range(world)] if (world > 1 and rank == 0) else None
+    from pli_slam_amd.sharding import gather_tables
     fe.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def step():
         fe.batch_run_device(F, d_left.data_ptr(), d_right.data_ptr(), W, W * H, d_table.data_ptr())
         if world > 1:
-            dist.gather(d_table, gather_list, dst=0)
+            gather_tables(d_table, rec_bytes, F, dst=0)     # RCCL gather of the per-frame tables to rank 0
 
     def fence():
         if world > 1:

@@ -1,0 +1,42 @@
+"""Frame-batch data parallelism across the GPUs of one node.
+
+Extraction and stereo matching are independent per stereo frame, so a batch is
+cut into contiguous shards, one per rank, with no data-path collective; the only
+exchange is the gather of the fixed-stride result tables to one rank
+(torch.distributed: backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(nframes, rank, world):
+    """Contiguous shard [start, start+count) of rank `rank`; the first nframes % world ranks get one extra."""
+    base, extra = divmod(nframes, world)
+    start = rank * base + min(rank, extra)
+    return start, base + (1 if rank < extra else 0)
+
+
+def gather_tables(table, record_bytes, nframes_local, dst=0, group=None):
+    """Gather every rank's result table (1-D uint8 tensor, nframes_local records) on rank `dst`.
+
+    Shards may differ by one frame, so tables are padded to the largest shard and cut again on
+    the root.  Returns the list of per-rank tables (views trimmed to that rank's frame count) on
+    `dst`, None elsewhere.  With world size 1 it returns [table] without communication.
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return [table[: nframes_local * record_bytes]]
+    rank = dist.get_rank(group)
+    counts = torch.tensor([nframes_local], dtype=torch.int64, device=table.device)
+    all_counts = [torch.zeros_like(counts) for _ in range(world)]
+    dist.all_gather(all_counts, counts, group=group)
+    all_counts = [int(c.item()) for c in all_counts]
+    pad = max(all_counts) * record_bytes
+    if table.numel() < pad:
+        table = torch.cat([table, table.new_zeros(pad - table.numel())])
+    send = table[:pad].contiguous()
+    bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return [b[: n * record_bytes] for b, n in zip(bufs, all_counts)]

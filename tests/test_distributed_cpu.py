@@ -1,0 +1,49 @@
+"""world_size-2 gloo test of the frame sharding + table gather used by bench.py for N > 1."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pli_slam_amd.sharding import gather_tables, shard_range
+
+
+def test_shard_range_partitions_the_batch():
+    for n in (0, 1, 7, 32, 255, 256):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+            for (s0, c0), (s1, _) in zip(spans, spans[1:]):
+                assert s1 == s0 + c0
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+    assert shard_range(256, 3, 8) == (96, 32)          # config 4: 256-frame batch, 32 per GPU
+
+
+def _worker(rank, world, path, nframes, rec):
+    dist.init_process_group("gloo", init_method="file://" + path, rank=rank, world_size=world)
+    start, count = shard_range(nframes, rank, world)
+    # a table whose bytes encode (global frame index, byte offset) so misplaced records are detected
+    t = torch.zeros(count * rec, dtype=torch.uint8)
+    for f in range(count):
+        t[f * rec:(f + 1) * rec] = torch.from_numpy(((np.arange(rec) + 31 * (start + f)) % 251).astype(np.uint8))
+    out = gather_tables(t, rec, count, dst=0)
+    if rank == 0:
+        assert len(out) == world
+        full = torch.cat(out)
+        assert full.numel() == nframes * rec
+        for f in range(nframes):
+            want = ((np.arange(rec) + 31 * f) % 251).astype(np.uint8)
+            assert np.array_equal(full[f * rec:(f + 1) * rec].numpy(), want), f
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nframes", [8, 7])
+def test_gather_tables_gloo_world2(nframes):
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(2, os.path.join(d, "rdv"), nframes, 96), nprocs=2, join=True)

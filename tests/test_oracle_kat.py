@@ -1,0 +1,246 @@
+"""Known-answer tests of the oracle (CPU restatement of the reference path).
+
+The reference ships no tests or golden vectors for this path, so these
+are the build's own KATs: each checks the oracle against a value derived
+by hand or by an independent formula, not against the HIP code.
+"""
+import numpy as np
+import pytest
+
+from pli_slam_amd import synth
+
+
+def test_descriptor_distance_kats(oracle):
+    z = np.zeros((1, 32), np.uint8)
+    o = np.full((1, 32), 255, np.uint8)
+    assert oracle.descriptor_distance(z, o)[0] == 256
+    assert oracle.descriptor_distance(z, z)[0] == 0
+    one = z.copy(); one[0, 17] = 0x10
+    assert oracle.descriptor_distance(z, one)[0] == 1
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 256, (500, 32), dtype=np.uint8)
+    b = rng.integers(0, 256, (500, 32), dtype=np.uint8)
+    want = np.unpackbits(a ^ b, axis=1).sum(1)
+    assert np.array_equal(oracle.descriptor_distance(a, b), want)
+
+
+def test_cv_round_half_even(oracle):
+    assert [oracle.cv_round(v) for v in (0.5, 1.5, 2.5, -0.5, -1.5, 2.4999, 2.5001)] == [0, 2, 2, 0, -2, 2, 3]
+
+
+def test_fast_atan2(oracle):
+    # exact axes and quadrants; polynomial error bound of cv::fastAtan2 is ~0.3 degrees
+    assert oracle.fast_atan2(0.0, 1.0) == 0.0
+    assert abs(oracle.fast_atan2(1.0, 0.0) - 90.0) < 1e-4
+    assert abs(oracle.fast_atan2(0.0, -1.0) - 180.0) < 1e-4
+    assert abs(oracle.fast_atan2(-1.0, 0.0) - 270.0) < 1e-4
+    rng = np.random.default_rng(2)
+    for y, x in rng.normal(size=(200, 2)):
+        want = np.degrees(np.arctan2(y, x)) % 360.0
+        got = oracle.fast_atan2(float(y), float(x))
+        assert abs((got - want + 180) % 360 - 180) < 0.3
+
+
+def test_gauss_kernels(oracle):
+    # 8-bit fixed point kernels of the three blurs on the path
+    assert oracle.gauss_kernel(7, 2.0).tolist() == [18, 34, 49, 55, 49, 34, 18]       # ORB, ORBextractor.cc:1115
+    assert oracle.gauss_kernel(5, 1.0).tolist() == [14, 63, 103, 63, 14]              # LBD, binary_descriptor_custom.cpp:358
+    assert oracle.gauss_kernel(7, 0.6).tolist() == [0, 1, 42, 170, 42, 1, 0]          # LSD pre-filter
+
+
+def test_blur_constant_image_is_fixed_point_gain(oracle):
+    img = np.full((40, 50), 100, np.uint8)
+    # sum of the 7x7 sigma-2 integer kernel is 257: (100*257*257 + 2^15) >> 16 = 101
+    assert np.all(oracle.gaussian_blur(img, 7, 2.0) == 101)
+    assert np.all(oracle.gaussian_blur(img, 5, 1.0) == 101)                          # 5x5 sigma-1 kernel sums to 257 too
+    assert np.all(oracle.gaussian_blur(img, 7, 0.6) == 100)                          # LSD pre-filter kernel sums to 256
+
+
+def test_resize_identity_and_downscale(oracle):
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (48, 60), dtype=np.uint8)
+    assert np.array_equal(oracle.resize(img, 60, 48, 1.0, 1.0), img)
+    flat = np.full((48, 60), 77, np.uint8)
+    assert np.all(oracle.resize(flat, 50, 40, 60 / 50, 48 / 40) == 77)
+    assert np.all(oracle.resize(flat, 72, 58, 1 / 1.2, 1 / 1.2) == 77)
+
+
+def test_sobel_ramp(oracle):
+    x = np.tile(np.arange(30, dtype=np.uint8) * 3, (20, 1))
+    dx, dy = oracle.sobel(x)
+    assert np.all(dx[:, 1:-1] == 24) and np.all(dy == 0)     # (1+2+1) * 2*3
+    assert np.all(dx[:, 0] == 0) and np.all(dx[:, -1] == 0)  # REFLECT_101 makes the border derivative vanish
+
+
+def test_fast_arc_values(oracle):
+    img = np.full((15, 15), 100, np.uint8)
+    assert oracle.fast_arc(img, 7, 7) == 0                    # flat: not a corner at any threshold
+    img[7, 7] = 160                                           # bright dot: every ring pixel is darker by 60
+    assert oracle.fast_arc(img, 7, 7) == 60
+    img2 = np.full((15, 15), 100, np.uint8)
+    ring = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3)]
+    for k, (dx, dy) in enumerate(ring):
+        img2[7 + dy, 7 + dx] = 130 + k                        # 9 contiguous brighter pixels, weakest is +30
+    assert oracle.fast_arc(img2, 7, 7) == 30
+    img2[7 + 3, 7 + 0] = 100                                  # break the arc: 8 contiguous only
+    assert oracle.fast_arc(img2, 7, 7) < 1
+
+
+def test_brief_constant_image_is_zero(oracle):
+    img = np.full((64, 64), 90, np.uint8)
+    for ang in (0.0, 37.5, 90.0, 271.0):
+        assert not oracle.orb_descriptor(img, 32, 32, ang).any()
+
+
+def test_brief_rotation_consistency(oracle):
+    # rotating the image by 90 degrees and the keypoint angle by 90 degrees gives the same bits
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (65, 65), dtype=np.uint8)
+    d0 = oracle.orb_descriptor(img, 32, 32, 0.0)
+    rot = np.ascontiguousarray(np.rot90(img, -1))             # 90 degrees clockwise in image coordinates (y down)
+    d90 = oracle.orb_descriptor(rot, 32, 32, 90.0)
+    assert np.array_equal(d0, d90)
+
+
+def test_features_per_level_and_umax(oracle):
+    f = oracle.Frame(oracle.default_config(752, 480))
+    assert f.features_per_level().tolist() == [261, 217, 181, 151, 126, 105, 87, 72]
+    assert f.umax().tolist() == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+
+
+def test_orb_blank_and_empty_images(oracle):
+    f = oracle.Frame(oracle.default_config(320, 240))
+    n, kp, desc = f.orb_extract(0, np.full((240, 320), 128, np.uint8))
+    assert n == 0
+    n, _, _ = f.orb_extract(0, None)
+    assert n == -1                                             # ORBextractor.cc:1072
+
+
+def test_orb_pipeline_invariants(oracle):
+    L, _ = synth.make_stereo_pair(4, 320, 240)
+    cfg = oracle.default_config(320, 240, orb_nfeatures=400)
+    f = oracle.Frame(cfg)
+    n, kp, desc = f.orb_extract(0, L)
+    assert 0 < n <= 400 + 3 * 8
+    assert np.all(np.diff(kp["octave"]) >= 0)                  # level-major output order
+    quota = f.features_per_level()
+    scale = np.float32(1.0)
+    for l in range(8):
+        sel = f.level_points(0, l, selected=True)
+        cand = f.level_points(0, l)
+        assert len(sel) <= max(quota[l] + 3, 8)
+        assert set(map(tuple, sel.tolist())) <= set(map(tuple, cand.tolist()))
+        im = f.pyramid(0, l)
+        k = kp[kp["octave"] == l]
+        xs = np.rint(k["x"] / scale).astype(int); ys = np.rint(k["y"] / scale).astype(int)
+        assert np.all((xs >= 19) & (xs < im.shape[1] - 19) & (ys >= 19) & (ys < im.shape[0] - 19))
+        scale = np.float32(scale * np.float32(1.2))
+    # the extractor is a pure function of the image
+    n2, kp2, desc2 = oracle.Frame(cfg).orb_extract(0, L)
+    assert n2 == n and kp2.tobytes() == kp.tobytes() and np.array_equal(desc, desc2)
+
+
+def test_lsd_rectangle(oracle):
+    img = np.full((240, 320), 40, np.uint8)
+    img[60:180, 80:240] = 200
+    cfg = oracle.default_config(320, 240, lsd_nfeatures=0)
+    f = oracle.Frame(cfg)
+    n, kl, desc = f.line_extract(0, img)
+    segs = f.lsd_segments(0)
+    want = [((80, 60), (240, 60)), ((80, 180), (240, 180)), ((80, 60), (80, 180)), ((240, 60), (240, 180))]
+    for (a, b) in want:
+        best = 1e9
+        for s in segs:
+            for p, q in (((s[0], s[1]), (s[2], s[3])), ((s[2], s[3]), (s[0], s[1]))):
+                # distance of both detected endpoints to the ideal edge line, and coverage of its length
+                def dline(pt):
+                    (x1, y1), (x2, y2) = a, b
+                    return abs((x2 - x1) * (y1 - pt[1]) - (x1 - pt[0]) * (y2 - y1)) / np.hypot(x2 - x1, y2 - y1)
+                cover = np.hypot(p[0] - q[0], p[1] - q[1]) / np.hypot(a[0] - b[0], a[1] - b[1])
+                if cover > 0.9:
+                    best = min(best, max(dline(p), dline(q)))
+        assert best < 1.0, (a, b, best)                        # edges sit between pixel rows: < 1 px off the ideal line
+    assert n >= 4 and desc.shape == (n, 32)
+    assert np.all(kl["numOfPixels"] >= 1) and np.all(kl["lineLength"] > 0.025 * 240)
+
+
+def test_line_topn_is_stable_by_response(oracle):
+    L, _ = synth.make_stereo_pair(2, 320, 240)
+    allc = oracle.default_config(320, 240, lsd_nfeatures=0)
+    topc = oracle.default_config(320, 240, lsd_nfeatures=20)
+    fa, ft = oracle.Frame(allc), oracle.Frame(topc)
+    na, kla, _ = fa.line_extract(0, L)
+    nt, klt, _ = ft.line_extract(0, L)
+    assert nt == 20 and na > 20
+    order = np.argsort(-kla["response"], kind="stable")[:20]
+    assert np.array_equal(klt["startPointX"], kla["startPointX"][order])
+    assert klt["class_id"].tolist() == list(range(20))
+
+
+def test_lbd_weights(oracle):
+    Lw, G = oracle.lbd_weights()
+    # integer-division quirk of the reference: u = 10, sigma = 7 (local); u = sigma = 31 (global)
+    assert np.allclose(Lw, np.exp(-((np.arange(21) - 10.0) ** 2) / (2 * 49.0)).astype(np.float32))
+    assert np.allclose(G, np.exp(-((np.arange(63) - 31.0) ** 2) / (2 * 961.0)).astype(np.float32))
+
+
+def test_stereo_integer_shift(oracle):
+    # right image = left shifted by d px: uRight = uL - d for every matched keypoint
+    d = 12
+    big, _ = synth.make_stereo_pair(6, 320 + d, 240)
+    left = np.ascontiguousarray(big[:, :320])
+    right = np.ascontiguousarray(big[:, d:320 + d])           # a point at uL appears at uL - d
+    f = oracle.Frame(oracle.default_config(320, 240, orb_nfeatures=500))
+    nl, kp, _ = f.orb_extract(0, left)
+    f.orb_extract(1, right)
+    ur, depth, bi, sad = f.stereo_points()
+    m = ur >= 0
+    assert m.sum() > 0.3 * nl
+    err = np.abs((kp["x"][m] - ur[m]) - d)
+    scale = np.float32(1.2) ** kp["octave"][m]
+    assert np.all(err <= 0.6 * scale)                          # coordinates are rounded at the keypoint's pyramid level
+    assert np.median(err) < 0.25
+    assert np.allclose(depth[m], np.float32(oracle.default_config(320, 240).bf) / (kp["x"][m] - ur[m]), rtol=1e-6)
+
+
+def test_match_and_knn_small_cases(oracle):
+    a = np.zeros((3, 32), np.uint8)
+    b = np.zeros((4, 32), np.uint8)
+    a[0, 0] = 0b1; a[1, 0] = 0b11; a[2, :] = 255
+    b[0, 0] = 0b1; b[1, 0] = 0b111; b[2, :] = 255; b[3, :16] = 255
+    idx, dist = oracle.knn2(a, b)
+    assert idx[0].tolist() == [0, 1] and dist[0].tolist() == [0, 2]
+    assert idx[1].tolist() == [0, 1] and dist[1].tolist() == [1, 1]      # tie -> lower train index first
+    assert idx[2].tolist() == [2, 3] and dist[2].tolist() == [0, 128]
+    n, m = oracle.match_lines(a, b, 0.9, True)
+    assert m.tolist() == [0, -1, 2] and n == 2                           # a[1]: 1 < 0.9*1 fails
+
+
+def test_match_grid_prefix_min_rule(oracle):
+    # two left lines see the same right line; the second has the smaller distance.  With bestLRMatches
+    # the first is accepted by the ratio test but loses the mutual check (LineMatcher.cpp:360-393).
+    kl = np.zeros(2, oracle.KEYLINE_DT)
+    kr = np.zeros(1, oracle.KEYLINE_DT)
+    for k, y in ((kl[0:1], 100.0), (kl[1:2], 104.0), (kr[0:1], 102.0)):
+        k["startPointX"], k["startPointY"], k["endPointX"], k["endPointY"] = 300.0, y, 400.0, y + 60.0
+    dl = np.zeros((2, 32), np.uint8); dr = np.zeros((1, 32), np.uint8)
+    dl[0, 0] = 0b111                                                      # distance 3 to the right line
+    dl[1, 0] = 0b1                                                        # distance 1
+    cfg = oracle.default_config(752, 480)
+    disp, le, m = oracle.stereo_lines_tables(cfg, kl, dl, kr, dr, 752, 480)
+    assert m.tolist() == [-1, 0]
+    cfg.best_lr_matches = 0
+    _, _, m = oracle.stereo_lines_tables(cfg, kl, dl, kr, dr, 752, 480)
+    assert m.tolist() == [0, 0]
+
+
+def test_search_by_projection_exclusive_assignment(oracle):
+    kp = np.zeros(2, oracle.KEYPOINT_DT)
+    kp["x"] = [100.0, 103.0]; kp["y"] = [100.0, 100.0]; kp["octave"] = 0; kp["angle"] = 10.0
+    desc = np.zeros((2, 32), np.uint8); desc[1, 0] = 0b1
+    q = np.zeros(2, oracle.PROJ_QUERY_DT)
+    q["u"] = [101.0, 101.0]; q["v"] = 100.0; q["radius"] = 7.0; q["ur"] = 50.0
+    q["min_level"] = -1; q["max_level"] = 1; q["angle"] = 10.0; q["valid"] = 1
+    qd = np.zeros((2, 32), np.uint8)
+    n, best = oracle.search_by_projection(q, qd, kp, desc, np.full(2, -1, np.float32), (0, 752, 0, 480), False)
+    assert best.tolist() == [0, 1] and n == 2      # the second query cannot take keypoint 0 again

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Generates the committed fixtures under tests/golden/.
+
+grid_ref.json      : outputs of the REFERENCE's own src/LineIterator.cpp + src/gridStructure.cpp
+                     (built by oracle/Makefile into oracle/_ref, only where /root/reference exists)
+                     on seeded random segments: Bresenham cell lists and grid-window candidate sets.
+oracle_small.npz   : outputs of the oracle on a 240x160 synthetic stereo pair (drift guard for the
+                     oracle itself; these are NOT reference outputs).
+Dev-time only.  The fixtures are data (inputs + expected outputs); no reference source is stored.
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from oracle import pyoracle as po
+from pli_slam_amd import synth
+
+out = os.path.join(ROOT, "tests", "golden")
+os.makedirs(out, exist_ok=True)
+
+if po.ref() is not None:
+    rng = np.random.default_rng(20261001)
+    cases = []
+    # Bresenham walks: coordinates in the 64x48 grid frame, including degenerate / steep / reversed / out-of-grid ones
+    segs = rng.uniform([-4, -4, -4, -4], [68, 52, 68, 52], (200, 4))
+    segs[:10, 2:] = segs[:10, :2]                      # zero-length
+    segs[10:20, 1] = segs[10:20, 3]                    # horizontal
+    segs[20:30, 0] = segs[20:30, 2]                    # vertical
+    segs[30:40] = np.rint(segs[30:40])                 # integer endpoints
+    for s in segs:
+        cells = po.ref_line_coords(*s)
+        cases.append({"seg": [float(v) for v in s], "cells": cells.tolist()})
+    queries = []
+    for t in range(40):
+        n = int(rng.integers(1, 60))
+        ss = rng.uniform([0, 0, 0, 0], [64, 48, 64, 48], (n, 4))
+        for _ in range(5):
+            qx, qy = int(rng.integers(-2, 70)), int(rng.integers(-2, 52))
+            win = [int(rng.integers(0, 12)), int(rng.integers(0, 3)), int(rng.integers(0, 3)), int(rng.integers(0, 3))]
+            cand = po.ref_grid_query(ss, 48, 64, qx, qy, win)
+            queries.append({"segs": ss.tolist(), "q": [qx, qy], "win": win, "cand": cand.tolist()})
+    json.dump({"source": "reference src/LineIterator.cpp + src/gridStructure.cpp via oracle/_ref/libpli_ref.so",
+               "line_coords": cases, "grid_queries": queries}, open(os.path.join(out, "grid_ref.json"), "w"))
+    print("grid_ref.json: %d walks, %d queries" % (len(cases), len(queries)))
+else:
+    print("oracle/_ref absent: grid_ref.json not regenerated")
+
+W, H = 240, 160
+L, R = synth.make_stereo_pair(11, W, H)
+cfg = po.default_config(W, H, orb_nfeatures=300, lsd_nfeatures=40)
+f = po.Frame(cfg)
+nL, kpL, dL = f.orb_extract(0, L)
+nR, kpR, dR = f.orb_extract(1, R)
+mL, klL, ldL = f.line_extract(0, L)
+mR, klR, ldR = f.line_extract(1, R)
+ur, dp, bi, sad = f.stereo_points()
+disp, le, lm = f.stereo_lines()
+np.savez_compressed(os.path.join(out, "oracle_small.npz"), left=L, right=R, kpL=kpL, dL=dL, kpR=kpR, dR=dR, klL=klL, ldL=ldL,
+                    klR=klR, ldR=ldR, uright=ur, depth=dp, disp=disp, le=le, segL=f.lsd_segments(0))
+print("oracle_small.npz: %d/%d kp, %d/%d lines, %d stereo pts" % (nL, nR, mL, mR, int((ur >= 0).sum())))
