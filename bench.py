@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--nfeatures", type=int, default=1200)
     ap.add_argument("--nlines", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lsd-mode", type=int, default=0, help="0 auto, 1 relaxation, 2 sequential waves")
     args = ap.parse_args()
 
     import torch
@@ -135,7 +136,8 @@ def main():
     from pli_slam_amd.frontend import Frontend
 
     F, W, H = args.frames_per_gpu, args.width, args.height
-    cfg = capi.default_config(W, H, orb_nfeatures=args.nfeatures, lsd_nfeatures=args.nlines, max_frames=F)
+    cfg = capi.default_config(W, H, orb_nfeatures=args.nfeatures, lsd_nfeatures=args.nlines, max_frames=F,
+                              lsd_mode=args.lsd_mode if args.lsd_mode else (2 if 2 * F >= 256 else 1))
     fe = Frontend(cfg, device=local_rank)
     images = synth.make_batch(F, W, H, seed0=rank * F)                 # (F, 2, H, W) u8, seeds disjoint per rank
     d_img = torch.from_numpy(images).to(dev)                           # resident in HBM before timing

@@ -106,6 +106,11 @@ typedef struct pli_frontend_config {
   double  ls_min_disp_ratio;  /* 0.7                                                       */
   double  min_disp;           /* 1.0                                                       */
   double  line_horiz_th;      /* 0.1                                                       */
+  /* execution strategy of the LSD region grower (results are identical):
+     0 = auto (relaxation for batches below 256 images, sequential waves above),
+     1 = rank-ordered relaxation (lsd_relax.hip: low latency), 2 = sequential, one wave per image */
+  int32_t lsd_mode;
+  int32_t reserved0;
 } pli_frontend_config;
 
 /* Fill `cfg` with the values of Examples/Stereo/Config/EuRoC.yaml for a w x h image. */
@@ -274,7 +279,9 @@ enum {
   PLI_DBG_LBD_DXDY = 8,        /* int16 dx[w*h] then int16 dy[w*h]                          */
   PLI_DBG_LSD_ORDER = 9,       /* int32 count then int32 pixel index of every seed in visiting order */
   PLI_DBG_LBD_FLOAT = 10,      /* float[kl_cap][72] LBD band vector before binarisation     */
-  PLI_DBG_STEREO_SAD = 11      /* int32 sad[kp_cap] (-1 = none) then int32 bestIdxR[kp_cap] of the frame */
+  PLI_DBG_STEREO_SAD = 11,     /* int32 sad[kp_cap] (-1 = none) then int32 bestIdxR[kp_cap] of the frame */
+  PLI_DBG_LSD_OWNER = 12,      /* int32 rounds, then int32 owner rank per scaled pixel (0x7fffffff = undefined) */
+  PLI_DBG_LSD_SIZES = 13       /* int32 region size recorded by the last grower of every seed rank */
 };
 /* Keep the extra intermediates (LSD angle map, LBD float vectors, stereo best index) during runs. */
 pli_status pli_debug_enable(pli_ctx* ctx, int32_t on);

@@ -41,6 +41,7 @@ class Config(C.Structure):
         ("matching_s_ws", C.c_int32), ("best_lr_matches", C.c_int32),
         ("line_sim_th", C.c_double), ("stereo_overlap_th", C.c_double), ("min_ratio_12_l", C.c_double),
         ("ls_min_disp_ratio", C.c_double), ("min_disp", C.c_double), ("line_horiz_th", C.c_double),
+        ("lsd_mode", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -57,6 +58,7 @@ def default_config(width, height, **over):
     c.matching_s_ws, c.best_lr_matches = 10, 1
     c.line_sim_th, c.stereo_overlap_th, c.min_ratio_12_l = 0.75, 0.75, 0.9
     c.ls_min_disp_ratio, c.min_disp, c.line_horiz_th = 0.7, 1.0, 0.1
+    c.lsd_mode, c.reserved0 = 0, 0
     for k, v in over.items():
         setattr(c, k, v)
     return c

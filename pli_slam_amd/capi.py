@@ -29,7 +29,7 @@ ERRORS = {-1: "PLI_ERR_INVALID", -2: "PLI_ERR_EMPTY_IMAGE", -3: "PLI_ERR_CAPACIT
           -5: "PLI_ERR_NO_DEVICE", -6: "PLI_ERR_STATE"}
 RUN_ORB, RUN_LINES, RUN_STEREO_POINTS, RUN_STEREO_LINES, RUN_ALL = 1, 2, 4, 8, 15
 (DBG_PYRAMID_LEVEL, DBG_BLUR_LEVEL, DBG_FAST_CANDIDATES, DBG_LEVEL_KEYPOINTS, DBG_LSD_SCALED, DBG_LSD_ANGLE,
- DBG_LSD_SEGMENTS, DBG_LBD_DXDY, DBG_LSD_ORDER, DBG_LBD_FLOAT, DBG_STEREO_SAD) = range(1, 12)
+ DBG_LSD_SEGMENTS, DBG_LBD_DXDY, DBG_LSD_ORDER, DBG_LBD_FLOAT, DBG_STEREO_SAD, DBG_LSD_OWNER, DBG_LSD_SIZES) = range(1, 14)
 
 
 class Config(C.Structure):
@@ -47,6 +47,7 @@ class Config(C.Structure):
         ("matching_s_ws", C.c_int32), ("best_lr_matches", C.c_int32),
         ("line_sim_th", C.c_double), ("stereo_overlap_th", C.c_double), ("min_ratio_12_l", C.c_double),
         ("ls_min_disp_ratio", C.c_double), ("min_disp", C.c_double), ("line_horiz_th", C.c_double),
+        ("lsd_mode", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

@@ -61,4 +61,24 @@ struct DevParams {
   double lineSimTh, overlapTh, ratio12L, minDispRatio, minDisp, horizTh;
 };
 
+// per-image control block of the LSD relaxation (lsd_relax.hip)
+struct JrCtl {
+  int state;       // 0 relaxing, 1 exact owner map found: emit round, 2 done
+  int changed;     // owner_{t-1} != owner_{t-2} somewhere
+  int liveCount;   // seeds alive in owner_{t-1}
+  int next;        // work counter of the grow kernel
+  int arenaHead;   // bump pointer of the queue arena
+  int overflow;    // arena exhausted: the image falls back to the sequential grower
+  int nSegRaw;     // segments emitted (unordered)
+  int rounds;      // round in which the fixed point was detected
+  int bigCount;    // live seeds routed to the wave-cooperative grower
+  int nextBig;     // its work counter
+};
+
+// a live seed, ready to grow (written by k_jr_prepare)
+struct JrSeed {
+  int rank, xy;
+  float ang, sx, sy;
+};
+
 }  // namespace pli

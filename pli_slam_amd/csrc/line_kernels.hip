@@ -31,7 +31,8 @@ constexpr double D_2PI = 2 * D_PI;
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ scaled, int64_t imgStride, int W, int H,
                                                   int pitch, int g2Thresh, float4* __restrict__ rec,
-                                                  int* __restrict__ g2o, int* __restrict__ maxG2,
+                                                  int* __restrict__ g2o, float2* __restrict__ seedcs,
+                                                  int2* __restrict__ own, int* __restrict__ maxG2,
                                                   float* __restrict__ angDbg, int img0) {
   const int img = blockIdx.z + img0;
   const int y = blockIdx.y;
@@ -41,6 +42,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ sc
   if (x < W) {
     float a = LSD_NOTDEF;
     float cx = 0.f, sy = 0.f;
+    float2 scs = make_float2(0.f, 0.f);
     if (x < W - 1 && y < H - 1) {
       const uint8_t* r0 = scaled + (int64_t)img * imgStride + (int64_t)y * pitch;
       const uint8_t* r1 = r0 + pitch;
@@ -55,11 +57,15 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ sc
         double af = (double)(float)ad;
         cx = (float)cos(af);
         sy = (float)sin(af);
+        scs.x = (float)cos(ad);       // region_grow seeds its sums with cos/sin of the unrounded angle
+        scs.y = (float)sin(ad);
       }
     }
     const int64_t o = (int64_t)img * W * H + (int64_t)y * W + x;
     rec[o] = make_float4(a, cx, sy, __int_as_float(g2));
     g2o[o] = g2;
+    seedcs[o] = scs;
+    own[o] = make_int2(0x7FFFFFFF, 0x7FFFFFFF);   // undefined pixels never belong to a region
     if (angDbg) angDbg[o] = a;
   }
   int m = defined ? g2 : 0;
@@ -173,25 +179,7 @@ __global__ __launch_bounds__(64) void k_lsd_scatter(const int* __restrict__ g2a,
   }
 }
 
-// ---------------------------------------------------------------------------
-// k_lsd_grow: region_grow + region2rect (refine = NONE), one wave per image.
-//
-// The algorithm is sequential by definition (seeds in bin order; a region's
-// angle is updated after every accepted pixel), so the wave cooperates on ONE
-// region at a time instead of splitting the image:
-//   * 64 seeds of the ordered list are fetched per vector load; a ballot keeps
-//     the still-unused ones and every later claim clears its bit, so no seed
-//     is ever re-read;
-//   * lanes 0..8 fetch the 3x3 neighbourhood records of the current region
-//     pixel with one 16-byte load each (one memory round trip per pixel);
-//     ballots over "unused & aligned" reproduce the raster-order accept loop,
-//     re-testing only the neighbours after an accepted one against the
-//     updated region angle;
-//   * the region (x|y, g2) queue lives in LDS; the weighted sums of
-//     region2rect are accumulated in list order by three lanes, one per
-//     running sum, from products computed 64 at a time.
-// ---------------------------------------------------------------------------
-constexpr int LSD_QCAP = 4096;
+constexpr int LSD_QCAP = 1024;      // region queue entries kept in LDS (8 KB/wave): longer regions spill to global memory
 
 __device__ __forceinline__ double lsd_angle_diff(double a, double b) {
   double diff = a - b;
@@ -208,6 +196,20 @@ __device__ __forceinline__ uint2 lsd_qget(const uint2* qs, const uint2* qg, int 
   return k < LSD_QCAP ? qs[k] : qg[k - LSD_QCAP];
 }
 
+// ---------------------------------------------------------------------------
+// k_lsd_grow: the sequential form of region_grow + region2rect, one wave per
+// image (used for large batches, where one wave per SIMD per image keeps the
+// chip busy, and as the fallback of the relaxation in lsd_relax.hip).
+//   * 64 seeds of the ordered list are fetched per vector load; a ballot keeps
+//     the still-unused ones and every later claim clears its bit;
+//   * lanes 0..8 fetch the 3x3 neighbourhood records of the current region
+//     pixel with one 16-byte load each; ballots over "unused & aligned"
+//     reproduce the raster-order accept loop, re-testing only the neighbours
+//     after an accepted one against the updated region angle;
+//   * the region (x|y, g2) queue lives in LDS; the weighted sums of region2rect
+//     are accumulated in list order by three lanes from products computed 64 at a time.
+// Claimed pixels are marked by overwriting rec.x with NOTDEF.
+// ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_lsd_grow(const DevParams* __restrict__ Pp, float4* __restrict__ recAll,
                                                  const int* __restrict__ orderAll, const int* __restrict__ nDefined,
                                                  uint2* __restrict__ regOverflow, float* __restrict__ segAll,
@@ -252,10 +254,10 @@ __global__ __launch_bounds__(64) void k_lsd_grow(const DevParams* __restrict__ P
       const int sg2 = __float_as_int(rl_f(srec.w, j));
       double reg_angle = (double)sa * D_DEG2RAD;
       const int spy = sp / W, spx = sp - spy * W;
-      if (lane == 0) {
-        rec[sp].x = LSD_NOTDEF;
-        qs[0] = make_uint2(((unsigned)spy << 16) | (unsigned)spx, (unsigned)sg2);
-      }
+      // single-lane work inside these wave-uniform loops is done by the first ACTIVE lane (or by all lanes with
+      // the same value): a fixed lane such as lane 0 is not guaranteed to be in the exec mask here
+      if (lane == __ffsll((long long)__ballot(true)) - 1) rec[sp].x = LSD_NOTDEF;
+      qs[0] = make_uint2(((unsigned)spy << 16) | (unsigned)spx, (unsigned)sg2);
       int cnt = 1;
       for (int k = 0; k < cnt; ++k) {
         __syncthreads();                           // one wave per block: orders lane 0's queue writes before the reads
@@ -285,10 +287,8 @@ __global__ __launch_bounds__(64) void k_lsd_grow(const DevParams* __restrict__ P
           const unsigned g2j = (unsigned)__float_as_int(rl_f(r.w, j2));
           const unsigned xyj = ((unsigned)(py + j2 / 3 - 1) << 16) | (unsigned)(px + j2 % 3 - 1);
           if (lane == j2) rec[qi].x = LSD_NOTDEF;
-          if (lane == 0) {
-            if (cnt < LSD_QCAP) qs[cnt] = make_uint2(xyj, g2j);
-            else qg[cnt - LSD_QCAP] = make_uint2(xyj, g2j);
-          }
+          if (cnt < LSD_QCAP) qs[cnt] = make_uint2(xyj, g2j);           // same value from every active lane
+          else if (lane == __ffsll((long long)__ballot(true)) - 1) qg[cnt - LSD_QCAP] = make_uint2(xyj, g2j);
           ++cnt;
           sumdx = __fadd_rn(sumdx, cj);
           sumdy = __fadd_rn(sumdy, sj);

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <memory>
 #include <limits>
+#include <cstdlib>
 
 using namespace pli;
 
@@ -57,6 +58,11 @@ struct pli_ctx {
   int tmpPitch = 0;
   int* lsdTab = nullptr;
   float4* rec = nullptr; int* g2 = nullptr; int* maxG2 = nullptr;
+  float2* seedcs = nullptr; int2* own = nullptr; JrSeed* smallSeeds = nullptr; JrSeed* bigSeeds = nullptr; int bigCap = 0;
+  int* lastSize = nullptr; int* arena = nullptr; int arenaCap = 0;
+  JrCtl* jrCtl = nullptr; float4* segRaw = nullptr; int* segRank = nullptr;
+  std::vector<JrCtl> jrHost;
+  int lsdMode = 0;     // 0 auto, 1 relaxation, 2 sequential (cfg.lsd_mode, or PLI_LSD_MODE)
   unsigned short* chunkHist = nullptr; int* chunkBase = nullptr; int* nDefined = nullptr;
   int* order = nullptr; uint2* regScratch = nullptr; float* seg = nullptr; int* nSeg = nullptr;
   int nChunks = 0, maxSeg = 0;
@@ -169,6 +175,7 @@ pli_status validate(const pli_frontend_config& c) {
   if (c.lsd_refine != 0) { g_err = "only lsd_refine = 0 (LSD_REFINE_NONE) is on the reference path"; return PLI_ERR_INVALID; }
   if (c.lsd_n_bins < 1 || c.lsd_n_bins > 1024) { g_err = "lsd_n_bins must be in [1,1024]"; return PLI_ERR_INVALID; }
   if (c.max_lines < 1 || c.max_lines > 4096) { g_err = "max_lines must be in [1,4096]"; return PLI_ERR_INVALID; }
+  if (c.lsd_mode < 0 || c.lsd_mode > 2) { g_err = "lsd_mode must be 0, 1 or 2"; return PLI_ERR_INVALID; }
   if (c.lsd_nfeatures < 0 || c.lsd_nfeatures > c.max_lines) { g_err = "lsd_nfeatures must be in [0,max_lines]"; return PLI_ERR_INVALID; }
   if (!(c.lsd_scale > 0) || !(c.lsd_ang_th > 0 && c.lsd_ang_th < 180)) { g_err = "lsd_scale/ang_th invalid"; return PLI_ERR_INVALID; }
   return PLI_OK;
@@ -382,6 +389,21 @@ pli_status allocAll(pli_ctx* c) {
   const size_t npix = (size_t)P.LW * P.LH;
   A(c->rec, npix * NI);
   A(c->g2, npix * NI);
+  A(c->seedcs, npix * NI);
+  A(c->own, npix * NI);
+  c->lsdMode = c->cfg.lsd_mode;
+  if (const char* e = getenv("PLI_LSD_MODE")) c->lsdMode = atoi(e);
+  if (c->lsdMode != 2) {     // buffers of the relaxation
+    A(c->smallSeeds, npix * NI);
+    c->bigCap = (int)(npix / 32 + 1024);
+    A(c->bigSeeds, (size_t)c->bigCap * NI);
+    A(c->lastSize, npix * NI);
+    c->arenaCap = (int)std::min<size_t>(8 * npix, (size_t)1 << 30);
+    A(c->arena, (size_t)c->arenaCap * NI);
+  }
+  A(c->jrCtl, NI);
+  c->jrHost.resize(NI);
+
   A(c->maxG2, NI);
   c->nChunks = (int)((npix + 1023) / 1024);
   A(c->chunkHist, (size_t)NI * c->nChunks * P.nBins);
@@ -389,9 +411,11 @@ pli_status allocAll(pli_ctx* c) {
   A(c->nDefined, NI);
   A(c->order, npix * NI);
   A(c->regScratch, npix * NI);
-  c->maxSeg = 16384;
+  c->maxSeg = 32768;
   A(c->seg, (size_t)NI * c->maxSeg * 4);
   A(c->nSeg, NI);
+  A(c->segRaw, (size_t)NI * c->maxSeg);
+  A(c->segRank, (size_t)NI * c->maxSeg);
   A(c->tmpKL, (size_t)NI * P.maxLines);
   A(c->dx, (size_t)P.W * P.H * NI);
   A(c->dy, (size_t)P.W * P.H * NI);
@@ -475,7 +499,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   HIPCHK(hipMemsetAsync(c->maxG2 + img0, 0, sizeof(int) * nimg, c->stream));
   {
     dim3 g((P.LW + 255) / 256, P.LH, nimg);
-    LAUNCH(c, "k_lsd_grad", k_lsd_grad, g, dim3(256), 0, scaled, sStride, P.LW, P.LH, sPitch, P.g2Thresh, c->rec, c->g2,
+    LAUNCH(c, "k_lsd_grad", k_lsd_grad, g, dim3(256), 0, scaled, sStride, P.LW, P.LH, sPitch, P.g2Thresh, c->rec, c->g2, c->seedcs, c->own,
            c->maxG2, c->debug ? c->angDbg : (float*)nullptr, img0);
   }
   LAUNCH(c, "k_lsd_hist", k_lsd_hist, dim3(c->nChunks, nimg), dim3(256), 0, c->g2, npix, P.g2Thresh, P.nBins, c->maxG2,
@@ -483,8 +507,51 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   LAUNCH(c, "k_lsd_scan", k_lsd_scan, dim3(nimg), dim3(1024), 0, c->chunkHist, c->nChunks, P.nBins, c->chunkBase, c->nDefined, img0);
   LAUNCH(c, "k_lsd_scatter", k_lsd_scatter, dim3(c->nChunks, nimg), dim3(64), 0, c->g2, npix, P.g2Thresh, P.nBins, c->maxG2,
          c->chunkBase, c->nChunks, c->order, img0);
-  LAUNCH(c, "k_lsd_grow", k_lsd_grow, dim3(nimg), dim3(64), 0, c->dP, c->rec, c->order, c->nDefined,
-         c->regScratch, c->seg, c->nSeg, c->maxSeg, img0);
+  const bool sequential = c->lsdMode == 2 || (c->lsdMode == 0 && nimg >= 256);
+  if (sequential) {
+    LAUNCH(c, "k_lsd_grow", k_lsd_grow, dim3(nimg), dim3(64), 0, c->dP, c->rec, c->order, c->nDefined,
+           c->regScratch, c->seg, c->nSeg, c->maxSeg, img0);
+  } else {
+    // rank-ordered relaxation (lsd_relax.hip): rounds until every image's owner map is a fixed point
+    const int64_t npix64 = (int64_t)npix;
+    const int ctlBlocks = (nimg + 63) / 64;
+    int growBlocks = std::max(1, std::min(256, (npix + 256 * 64 - 1) / (256 * 64)));
+    if (const char* e = getenv("PLI_JR_BLOCKS")) growBlocks = std::max(1, atoi(e));
+    int bigThresh = 48;
+    if (const char* e = getenv("PLI_JR_BIG")) bigThresh = atoi(e);
+    int bigBlocks = 512;
+    if (const char* e = getenv("PLI_JR_BIGBLOCKS")) bigBlocks = std::max(1, atoi(e));
+    bool allDone = false;
+    int t = 1;
+    for (; t <= 4096 && !allDone; ++t) {
+      LAUNCH(c, "k_jr_begin", k_jr_begin, dim3(ctlBlocks), dim3(64), 0, c->jrCtl, nimg, img0, t);
+      LAUNCH(c, "k_jr_prepare", k_jr_prepare, dim3(64, nimg), dim3(256), 0, c->jrCtl, c->order, c->nDefined, c->own,
+             c->rec, c->seedcs, c->lastSize, c->smallSeeds, c->bigSeeds, c->bigCap, npix64, P.LW, bigThresh, img0, t);
+      LAUNCH(c, "k_jr_decide", k_jr_decide, dim3(ctlBlocks), dim3(64), 0, c->jrCtl, nimg, img0, t);
+      static const char* growNames[24] = {"k_jr_grow", "k_jr_grow_r01", "k_jr_grow_r02", "k_jr_grow_r03", "k_jr_grow_r04", "k_jr_grow_r05", "k_jr_grow_r06", "k_jr_grow_r07", "k_jr_grow_r08", "k_jr_grow_r09", "k_jr_grow_r10", "k_jr_grow_r11", "k_jr_grow_r12", "k_jr_grow_r13", "k_jr_grow_r14", "k_jr_grow_r15", "k_jr_grow_r16", "k_jr_grow_r17", "k_jr_grow_r18", "k_jr_grow_r19", "k_jr_grow_r20", "k_jr_grow_r21", "k_jr_grow_r22", "k_jr_grow_r23"};
+      static const bool perRound = getenv("PLI_PROF_ROUNDS") != nullptr;
+      LAUNCH(c, (perRound && t < 24) ? growNames[t] : "k_jr_grow", k_jr_grow, dim3(growBlocks, nimg), dim3(256), 0, c->dP, c->jrCtl,
+             c->rec, c->own, c->smallSeeds, c->lastSize, c->arena, c->arenaCap, c->segRaw, c->segRank, c->maxSeg, img0, t);
+      if (t > 1)
+        LAUNCH(c, "k_jr_grow_big", k_jr_grow_big, dim3(bigBlocks, nimg), dim3(64), 0, c->dP, c->jrCtl, c->rec, c->own,
+               c->bigSeeds, c->bigCap, c->lastSize, c->arena, c->arenaCap, c->segRaw, c->segRank, c->maxSeg, img0, t,
+               c->debug ? (int*)c->regScratch : (int*)nullptr, getenv("PLI_DBG_RANK") ? atoi(getenv("PLI_DBG_RANK")) : -1);
+      if (t >= 8 && (t % 4) == 0) {
+        HIPCHK(hipMemcpyAsync(c->jrHost.data(), c->jrCtl + img0, sizeof(JrCtl) * nimg, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        allDone = true;
+        for (int i = 0; i < nimg; ++i) allDone = allDone && (c->jrHost[i].state >= 1 || c->jrHost[i].overflow);
+      }
+    }
+    LAUNCH(c, "k_jr_sort", k_jr_sort, dim3((c->maxSeg + 255) / 256, nimg), dim3(256), 0, c->jrCtl, c->segRaw, c->segRank, c->maxSeg, c->seg, c->nSeg, img0);
+    // images whose queue arena overflowed (or that did not settle) take the sequential grower
+    for (int i = 0; i < nimg; ++i) {
+      if (c->jrHost[i].overflow || c->jrHost[i].state < 1) {
+        LAUNCH(c, "k_lsd_grow", k_lsd_grow, dim3(1), dim3(64), 0, c->dP, c->rec, c->order, c->nDefined,
+               c->regScratch, c->seg, c->nSeg, c->maxSeg, img0 + i);
+      }
+    }
+  }
   LAUNCH(c, "k_keylines", k_keylines, dim3(nimg), dim3(256), 0, c->dP, c->seg, c->nSeg, c->maxSeg, c->tmpKL, table,
          Y.record_bytes, Y.off_counts, Y.off_kl[0], Y.off_kl[1], img0);
   LAUNCH(c, "k_blur_lbd", k_blur, dim3(c->l0Tiles, nimg), dim3(256), 0, c->jobLbd, c->pyr, P.pyrBlock, c->tmp8, c->tmp8Stride, img0);
@@ -555,6 +622,7 @@ void pli_config_default(pli_frontend_config* c, int32_t width, int32_t height) {
   c->matching_s_ws = 10; c->best_lr_matches = 1;
   c->line_sim_th = 0.75; c->stereo_overlap_th = 0.75; c->min_ratio_12_l = 0.9;
   c->ls_min_disp_ratio = 0.7; c->min_disp = 1.0; c->line_horiz_th = 0.1;
+  c->lsd_mode = 0;
 }
 
 int32_t pli_kp_capacity(const pli_frontend_config* c) {
@@ -1013,6 +1081,36 @@ pli_status pli_debug_fetch(pli_ctx* c, int32_t image, int32_t what, int32_t arg,
       const int64_t n = (int64_t)P.klCap * 72 * 4;
       if (!need(n)) return dst ? PLI_ERR_CAPACITY : PLI_OK;
       HIPCHK(hipMemcpy(dst, c->lbdFloat + (int64_t)image * P.klCap * 72, n, hipMemcpyDeviceToHost));
+      return PLI_OK;
+    }
+    case PLI_DBG_LSD_OWNER: {
+      const int64_t np = (int64_t)P.LW * P.LH;
+      if (!need(4 + np * 4)) return dst ? PLI_ERR_CAPACITY : PLI_OK;
+      JrCtl ctl;
+      HIPCHK(hipMemcpy(&ctl, c->jrCtl + image, sizeof(ctl), hipMemcpyDeviceToHost));
+      std::vector<int2> own(np);
+      HIPCHK(hipMemcpy(own.data(), c->own + image * np, np * 8, hipMemcpyDeviceToHost));
+      int* o = (int*)dst;
+      o[0] = ctl.rounds;
+      const int comp = (ctl.rounds - 1) & 1;          // owner_{t-1} of the round that detected the fixed point
+      for (int64_t i = 0; i < np; ++i) o[1 + i] = comp ? own[i].y : own[i].x;
+      return PLI_OK;
+    }
+    case 15: {   // debug: raw owner pairs
+      const int64_t np = (int64_t)P.LW * P.LH;
+      if (!need(np * 8)) return dst ? PLI_ERR_CAPACITY : PLI_OK;
+      HIPCHK(hipMemcpy(dst, c->own + image * np, np * 8, hipMemcpyDeviceToHost));
+      return PLI_OK;
+    }
+    case 14: {   // debug: captured queue of PLI_DBG_RANK (dev aid)
+      if (!need(4096 * 4)) return dst ? PLI_ERR_CAPACITY : PLI_OK;
+      HIPCHK(hipMemcpy(dst, c->regScratch, 4096 * 4, hipMemcpyDeviceToHost));
+      return PLI_OK;
+    }
+    case PLI_DBG_LSD_SIZES: {
+      const int64_t np = (int64_t)P.LW * P.LH;
+      if (!need(np * 4)) return dst ? PLI_ERR_CAPACITY : PLI_OK;
+      HIPCHK(hipMemcpy(dst, c->lastSize + image * np, np * 4, hipMemcpyDeviceToHost));
       return PLI_OK;
     }
     case PLI_DBG_STEREO_SAD: {
