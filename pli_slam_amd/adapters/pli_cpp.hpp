@@ -1,0 +1,105 @@
+// Header-only C++ host layer over the C ABI (include/pli_frontend.h).
+// No OpenCV types here, so it builds anywhere the library does; the shims with
+// the reference's exact signatures (cv::Mat / cv::KeyPoint / KeyLine) are in
+// orbslam_adapters.hpp and forward to these classes.
+#pragma once
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/pli_frontend.h"
+
+namespace pli {
+
+struct Error : std::runtime_error {
+  pli_status status;
+  Error(pli_status s, const std::string& what) : std::runtime_error(what), status(s) {}
+};
+
+inline void check(pli_status s) {
+  if (s != PLI_OK) throw Error(s, pli_last_error());
+}
+
+// One context = the four extractors of Tracking (ORB left/right, LSD left/right) plus the stereo matchers,
+// sharing device-resident pyramids and tables (reference Tracking.cc:87-98,743-749 and Frame.cc:98-228).
+class Frontend {
+ public:
+  explicit Frontend(const pli_frontend_config& cfg, int device = 0) : cfg_(cfg) {
+    check(pli_ctx_create(&cfg_, device, &ctx_));
+    check(pli_ctx_layout(ctx_, &layout_));
+  }
+  ~Frontend() { pli_ctx_destroy(ctx_); }
+  Frontend(const Frontend&) = delete;
+  Frontend& operator=(const Frontend&) = delete;
+
+  const pli_frontend_config& config() const { return cfg_; }
+  const pli_table_layout& layout() const { return layout_; }
+  pli_ctx* handle() { return ctx_; }
+
+  // ORBextractor::operator(): returns the reference's return value (count, -1 for an empty image)
+  int extractORB(int eye, const uint8_t* img, int w, int h, int64_t stride, std::vector<pli_keypoint>& kps,
+                 std::vector<uint8_t>& desc /* n x 32 */) {
+    kps.resize(layout_.kp_cap);
+    desc.resize((size_t)layout_.kp_cap * 32);
+    int32_t n = 0;
+    pli_status s = pli_orb_extract(ctx_, eye, img, w, h, stride, kps.data(), layout_.kp_cap, desc.data(), &n);
+    if (s == PLI_ERR_EMPTY_IMAGE) { kps.clear(); desc.clear(); return -1; }
+    check(s);
+    kps.resize(n);
+    desc.resize((size_t)n * 32);
+    return n;
+  }
+
+  // Lineextractor::operator()
+  void extractLines(int eye, const uint8_t* img, int w, int h, int64_t stride, std::vector<pli_keyline>& kls,
+                    std::vector<uint8_t>& desc) {
+    kls.resize(layout_.kl_cap);
+    desc.resize((size_t)layout_.kl_cap * 32);
+    int32_t n = 0;
+    check(pli_line_extract(ctx_, eye, img, w, h, stride, kls.data(), layout_.kl_cap, desc.data(), &n));
+    kls.resize(n);
+    desc.resize((size_t)n * 32);
+  }
+
+  // Frame::ComputeStereoMatches
+  void computeStereoMatches(std::vector<float>& uRight, std::vector<float>& depth) {
+    uRight.assign(layout_.kp_cap, -1.f);
+    depth.assign(layout_.kp_cap, -1.f);
+    check(pli_stereo_match_points(ctx_, uRight.data(), depth.data(), layout_.kp_cap));
+  }
+  // Frame::ComputeStereoMatches_Lines
+  void computeStereoMatchesLines(std::vector<float>& disp /* n x 2 */, std::vector<double>& le /* n x 3 */) {
+    disp.assign((size_t)layout_.kl_cap * 2, -1.f);
+    le.assign((size_t)layout_.kl_cap * 3, 0.0);
+    check(pli_stereo_match_lines(ctx_, disp.data(), le.data(), layout_.kl_cap));
+  }
+  // match(desc1, desc2, nnr, matches_12), LineMatcher.cpp:201
+  int matchLines(const uint8_t* d1, int n1, const uint8_t* d2, int n2, float nnr, std::vector<int>& m12) {
+    m12.assign(n1, -1);
+    int32_t n = 0;
+    check(pli_match_lines(ctx_, d1, n1, d2, n2, nnr, m12.data(), &n));
+    return n;
+  }
+  // ORBmatcher::DescriptorDistance
+  int descriptorDistance(const uint8_t* a, const uint8_t* b) {
+    int32_t d = 0;
+    check(pli_descriptor_distance(ctx_, a, b, 1, &d));
+    return d;
+  }
+  // core of ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, ...)
+  int searchByProjection(const std::vector<pli_proj_query>& q, const uint8_t* qdesc, const std::vector<pli_keypoint>& cur,
+                         const uint8_t* curDesc, const float* curURight, float minX, float maxX, float minY, float maxY,
+                         bool checkOrientation, std::vector<int>& bestIdx2) {
+    bestIdx2.assign(q.size(), -1);
+    int32_t n = 0;
+    check(pli_search_by_projection(ctx_, q.data(), qdesc, (int)q.size(), cur.data(), curDesc, curURight, (int)cur.size(),
+                                   minX, maxX, minY, maxY, checkOrientation ? 1 : 0, bestIdx2.data(), &n));
+    return n;
+  }
+
+ private:
+  pli_frontend_config cfg_;
+  pli_table_layout layout_{};
+  pli_ctx* ctx_ = nullptr;
+};
+
+}  // namespace pli
