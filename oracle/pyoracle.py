@@ -51,7 +51,7 @@ def default_config(width, height, **over):
     c.width, c.height, c.max_frames = width, height, 1
     c.orb_nfeatures, c.orb_scale_factor, c.orb_nlevels = 1200, 1.2, 8
     c.orb_ini_th_fast, c.orb_min_th_fast = 20, 7
-    c.lsd_nfeatures, c.lsd_refine, c.lsd_n_bins, c.max_lines = 500, 0, 1024, 4096
+    c.lsd_nfeatures, c.lsd_refine, c.lsd_n_bins, c.max_lines = 500, 0, 1024, max(4096, width * height // 64)
     c.min_line_length, c.lsd_scale, c.lsd_sigma_scale, c.lsd_quant = 0.025, 1.2, 0.6, 2.0
     c.lsd_ang_th, c.lsd_log_eps, c.lsd_density_th = 22.5, 1.0, 0.6
     c.bf, c.fx, c.stereo_maxd_inf = 47.90639384423901, 435.2046959714599, 0

@@ -448,17 +448,23 @@ __global__ __launch_bounds__(256) void k_keylines(const DevParams* __restrict__ 
   __threadfence_block();
   __syncthreads();
   if (M > nf && nf != 0) {
-    // top-N by response, equal responses keep detection order (stable)
-    for (int i = tid; i < M; i += 256) resp[i] = tk[i].response;
-    __syncthreads();
-    for (int i = tid; i < M; i += 256) {
-      const float r = resp[i];
+    // top-N by response, equal responses keep detection order (stable): rank by counting, responses tiled through LDS
+    for (int i0 = 0; i0 < M; i0 += 256) {
+      const int i = i0 + tid;
+      const float r = i < M ? tk[i].response : 0.f;
       int rank = 0;
-      for (int j = 0; j < M; ++j) {
-        const float rj = resp[j];
-        rank += (rj > r || (rj == r && j < i)) ? 1 : 0;
+      for (int j0 = 0; j0 < M; j0 += 4096) {
+        const int m = min(4096, M - j0);
+        __syncthreads();
+        for (int j = tid; j < m; j += 256) resp[j] = tk[j0 + j].response;
+        __syncthreads();
+        if (i < M)
+          for (int j = 0; j < m; ++j) {
+            const float rj = resp[j];
+            rank += (rj > r || (rj == r && j0 + j < i)) ? 1 : 0;
+          }
       }
-      if (rank < nf) {
+      if (i < M && rank < nf) {
         pli_keyline kl = tk[i];
         kl.class_id = rank;
         out[rank] = kl;

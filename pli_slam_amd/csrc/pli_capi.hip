@@ -174,7 +174,7 @@ pli_status validate(const pli_frontend_config& c) {
   if (c.orb_min_th_fast < 1 || c.orb_ini_th_fast < c.orb_min_th_fast || c.orb_ini_th_fast > 254) { g_err = "FAST thresholds invalid"; return PLI_ERR_INVALID; }
   if (c.lsd_refine != 0) { g_err = "only lsd_refine = 0 (LSD_REFINE_NONE) is on the reference path"; return PLI_ERR_INVALID; }
   if (c.lsd_n_bins < 1 || c.lsd_n_bins > 1024) { g_err = "lsd_n_bins must be in [1,1024]"; return PLI_ERR_INVALID; }
-  if (c.max_lines < 1 || c.max_lines > 4096) { g_err = "max_lines must be in [1,4096]"; return PLI_ERR_INVALID; }
+  if (c.max_lines < 1 || c.max_lines > (1 << 20)) { g_err = "max_lines must be in [1,2^20]"; return PLI_ERR_INVALID; }
   if (c.lsd_mode < 0 || c.lsd_mode > 2) { g_err = "lsd_mode must be 0, 1 or 2"; return PLI_ERR_INVALID; }
   if (c.lsd_nfeatures < 0 || c.lsd_nfeatures > c.max_lines) { g_err = "lsd_nfeatures must be in [0,max_lines]"; return PLI_ERR_INVALID; }
   if (!(c.lsd_scale > 0) || !(c.lsd_ang_th > 0 && c.lsd_ang_th < 180)) { g_err = "lsd_scale/ang_th invalid"; return PLI_ERR_INVALID; }
@@ -411,7 +411,7 @@ pli_status allocAll(pli_ctx* c) {
   A(c->nDefined, NI);
   A(c->order, npix * NI);
   A(c->regScratch, npix * NI);
-  c->maxSeg = 32768;
+  c->maxSeg = (int)(npix / std::max(P.minRegSize, 1)) + 64;   // a region needs minRegSize pixels: no image can yield more segments
   A(c->seg, (size_t)NI * c->maxSeg * 4);
   A(c->nSeg, NI);
   A(c->segRaw, (size_t)NI * c->maxSeg);
@@ -615,7 +615,8 @@ void pli_config_default(pli_frontend_config* c, int32_t width, int32_t height) {
   c->width = width; c->height = height; c->max_frames = 1;
   c->orb_nfeatures = 1200; c->orb_scale_factor = 1.2f; c->orb_nlevels = 8;
   c->orb_ini_th_fast = 20; c->orb_min_th_fast = 7;
-  c->lsd_nfeatures = 500; c->lsd_refine = 0; c->lsd_n_bins = 1024; c->max_lines = 4096;
+  c->lsd_nfeatures = 500; c->lsd_refine = 0; c->lsd_n_bins = 1024;
+  c->max_lines = std::max(4096, width * height / 64);   // the reference keeps every segment above the length cut
   c->min_line_length = 0.025; c->lsd_scale = 1.2; c->lsd_sigma_scale = 0.6; c->lsd_quant = 2.0;
   c->lsd_ang_th = 22.5; c->lsd_log_eps = 1.0; c->lsd_density_th = 0.6;
   c->bf = 47.90639384423901f; c->fx = 435.2046959714599f; c->stereo_maxd_inf = 0;

@@ -300,6 +300,25 @@ def test_edge_cases(gpu):
     assert e.value.status == -6
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_lsd_execution_modes_give_identical_results(gpu, mode):
+    """lsd_mode 1 (rank-ordered relaxation) and 2 (sequential waves) are two schedules of the same algorithm."""
+    g = gpu
+    W, H = 752, 480
+    cfg = g.capi.default_config(W, H, orb_nfeatures=1200, lsd_nfeatures=0, max_frames=2, lsd_mode=mode)
+    fe = g.Frontend(cfg)
+    frames = [g.synth.make_stereo_pair(s, W, H) for s in (31, 32)]
+    recs = fe.batch_run_host(np.stack([np.stack(f) for f in frames]), stages=g.capi.RUN_LINES | g.capi.RUN_STEREO_LINES)
+    for rec, (L, R) in zip(recs, frames):
+        fr = g.po.Frame(ocfg(g, cfg))
+        for eye, img, k in ((0, L, "L"), (1, R, "R")):
+            m, kl, ld = fr.line_extract(eye, img)
+            assert m == len(rec["kl" + k]) and m > 500          # lsd_nfeatures = 0 keeps every segment above the length cut
+            assert rec["kl" + k].tobytes() == kl.tobytes() and np.array_equal(rec["ldesc" + k], ld)
+        disp, le, _ = fr.stereo_lines()
+        assert rec["disp"].tobytes() == disp.tobytes() and rec["le"].tobytes() == le.tobytes()
+
+
 def test_stereo_maxd_inf_switch(gpu):
     g = gpu
     W, H = 376, 240
@@ -329,3 +348,7 @@ def test_config5_4k(gpu):
     # idempotence at full size: the same image gives the same tables on a second pass
     n2, kp2, desc2 = fe.orb_extract(1, R)
     assert kp2.tobytes() == kp.tobytes() and np.array_equal(desc2, desc)
+    # LSD/LBD at 4K (4608 x 2592 scaled image, ~10 M seeds) against the oracle
+    m, kl, ld = fe.line_extract(0, L)
+    om, okl, old = fr.line_extract(0, L)
+    assert m == om == 500 and kl.tobytes() == okl.tobytes() and np.array_equal(ld, old)
