@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--nfeatures", type=int, default=1200)
     ap.add_argument("--nlines", type=int, default=100)
     ap.add_argument("--unique-frames", type=int, default=64)
+    ap.add_argument("--streams", type=int, default=1, help="split the per-GPU batch over this many contexts/HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lsd-mode", type=int, default=0, help="0 auto, 1 relaxation, 2 sequential waves")
     args = ap.parse_args()
@@ -137,9 +138,13 @@ def main():
     from pli_slam_amd.frontend import Frontend
 
     F, W, H = args.frames_per_gpu, args.width, args.height
-    cfg = capi.default_config(W, H, orb_nfeatures=args.nfeatures, lsd_nfeatures=args.nlines, max_frames=F,
-                              lsd_mode=args.lsd_mode if args.lsd_mode else (2 if 2 * F >= 256 else 1))
-    fe = Frontend(cfg, device=local_rank)
+    S = max(1, args.streams)
+    assert F % S == 0, "--frames-per-gpu must be a multiple of --streams"
+    Fs = F // S
+    cfg = capi.default_config(W, H, orb_nfeatures=args.nfeatures, lsd_nfeatures=args.nlines, max_frames=Fs,
+                              lsd_mode=args.lsd_mode if args.lsd_mode else (2 if 2 * Fs >= 256 else 1))
+    fes = [Frontend(cfg, device=local_rank) for _ in range(S)]
+    fe = fes[0]
     # synthetic stream: up to 64 distinct seeded stereo pairs per rank (seeds disjoint across ranks), cycled to F frames
     nuniq = min(F, args.unique_frames)
     from concurrent.futures import ThreadPoolExecutor
@@ -152,10 +157,16 @@ def main():
     rec_bytes = int(fe.layout.record_bytes)
     d_table = torch.zeros(F * rec_bytes, dtype=torch.uint8, device=dev)
     from pli_slam_amd.sharding import gather_tables
-    fe.set_stream(torch.cuda.current_stream().cuda_stream)
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(S - 1)]
+    for f_, st_ in zip(fes, streams):
+        f_.set_stream(st_.cuda_stream)
 
     def step():
-        fe.batch_run_device(F, d_left.data_ptr(), d_right.data_ptr(), W, W * H, d_table.data_ptr())
+        for i, f_ in enumerate(fes):
+            f_.batch_run_device(Fs, d_left[i * Fs:].data_ptr(), d_right[i * Fs:].data_ptr(), W, W * H,
+                                d_table[i * Fs * rec_bytes:].data_ptr())
+        for st_ in streams[1:]:
+            torch.cuda.current_stream().wait_stream(st_)
         if world > 1:
             gather_tables(d_table, rec_bytes, F, dst=0)     # RCCL gather of the per-frame tables to rank 0
 
@@ -167,15 +178,20 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    fe.prof_reset()
-    fe.prof_enable(True)
+    for f_ in fes:
+        f_.prof_reset()
+        f_.prof_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
-    fe.prof_enable(False)
-    prof = fe.prof_report()
+    prof = {}
+    for f_ in fes:
+        f_.prof_enable(False)
+        for k_, (c_, ms_) in f_.prof_report().items():
+            a_ = prof.get(k_, (0, 0.0))
+            prof[k_] = (a_[0] + c_, a_[1] + ms_)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -192,7 +208,7 @@ def main():
         avg_s = (total_ms / max(calls, 1)) * 1e-3
         peak = 8000.0
         if per_img is not None and avg_s > 0:
-            achieved = per_img * 2 * F / avg_s / 1e9
+            achieved = per_img * 2 * Fs / avg_s / 1e9
         else:
             achieved = None
         traffic = None     # HBM bytes per launch from the committed PMC passes of the same workload, if any

@@ -256,6 +256,27 @@ pli_status pli_search_by_projection(pli_ctx* ctx,
                                     int32_t check_orientation,
                                     int32_t* best_idx2, int32_t* nmatches);
 
+/* --- local-map tracking (Tracking::SearchLocalPointsAndLines, Tracking.cc:3854,3882) --- */
+
+/* Core of ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, th, ...)
+ * ORBmatcher.cc:44-143 (left / rectified-stereo branch, F.Nleft == -1).  Per map point in view the caller
+ * passes (u,v) = mTrackProjX/Y, radius = r*mvScaleFactors[nPredictedLevel] (r from RadiusByViewingCos, times th),
+ * ur = mTrackProjXR, min_level = nPredictedLevel-1, max_level = nPredictedLevel, valid = in view, not bad, not too far.
+ * cur_occupied[i] != 0 marks current keypoints that already hold a map point with observations (may be NULL).
+ * Best and second-best Hamming distance in GetFeaturesInArea order, TH_HIGH = 100, ratio test only when both are
+ * on the same pyramid level (mfNNratio = nnratio); accepted keypoints become occupied for the following queries.
+ * best_idx2[i] = matched keypoint or -1; *nmatches = return value. */
+pli_status pli_search_local_map(pli_ctx* ctx, const pli_proj_query* q, const uint8_t* qdesc, int32_t nq,
+                                const pli_keypoint* cur_kp, const uint8_t* cur_desc, const float* cur_uright,
+                                const uint8_t* cur_occupied, int32_t ncur,
+                                float min_x, float max_x, float min_y, float max_y, float nnratio,
+                                int32_t* best_idx2, int32_t* nmatches);
+
+/* int match(const vector<MapLine*>&, Frame&, nnr, matches_12) LineMatcher.cpp:161-171: one-directional matchNNR
+ * of the local map lines' descriptors against the frame's (the reference returns before its mutual check). */
+pli_status pli_match_nnr(pli_ctx* ctx, const uint8_t* desc1, int32_t n1, const uint8_t* desc2, int32_t n2, float nnr,
+                         int32_t* matches_12, int32_t* nmatches);
+
 /* ------------------------------------------------------------------------ */
 /* Measurement hooks (bench.py / tests only).                                */
 /* ------------------------------------------------------------------------ */

@@ -496,4 +496,68 @@ static inline int searchByProjection(const pli_proj_query* q, const uint8_t* qde
   return nmatches;
 }
 
+// ---------------------------------------------------------------------------
+// ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, ...) ORBmatcher.cc:44-143
+// (rectified stereo: F.Nleft == -1), SLAM state reduced to per-query records.
+// ---------------------------------------------------------------------------
+static inline int searchLocalMap(const pli_proj_query* q, const uint8_t* qdesc, int nq, const pli_keypoint* kp,
+                                 const uint8_t* desc, const float* uright, const uint8_t* occupied, int ncur,
+                                 float mnMinX, float mnMaxX, float mnMinY, float mnMaxY, float mfNNratio,
+                                 std::vector<int>& best_idx2) {
+  const int COLS = 64, ROWS = 48, TH_HIGH = 100;
+  best_idx2.assign(nq, -1);
+  const float gwInv = static_cast<float>(COLS) / (mnMaxX - mnMinX);
+  const float ghInv = static_cast<float>(ROWS) / (mnMaxY - mnMinY);
+  std::vector<std::vector<int>> grid((size_t)COLS * ROWS);
+  for (int i = 0; i < ncur; ++i) {
+    int px = (int)std::round((kp[i].x - mnMinX) * gwInv);
+    int py = (int)std::round((kp[i].y - mnMinY) * ghInv);
+    if (px < 0 || px >= COLS || py < 0 || py >= ROWS) continue;
+    grid[(size_t)px * ROWS + py].push_back(i);
+  }
+  std::vector<char> taken(ncur, 0);
+  if (occupied) for (int i = 0; i < ncur; ++i) taken[i] = occupied[i] != 0;
+  int nmatches = 0;
+  for (int i = 0; i < nq; ++i) {
+    if (!q[i].valid) continue;
+    const float x = q[i].u, y = q[i].v, r = q[i].radius;
+    const int minLevel = q[i].min_level, maxLevel = q[i].max_level;
+    const int nMinCellX = std::max(0, (int)std::floor((x - mnMinX - r) * gwInv));
+    if (nMinCellX >= COLS) continue;
+    const int nMaxCellX = std::min(COLS - 1, (int)std::ceil((x - mnMinX + r) * gwInv));
+    if (nMaxCellX < 0) continue;
+    const int nMinCellY = std::max(0, (int)std::floor((y - mnMinY - r) * ghInv));
+    if (nMinCellY >= ROWS) continue;
+    const int nMaxCellY = std::min(ROWS - 1, (int)std::ceil((y - mnMinY + r) * ghInv));
+    if (nMaxCellY < 0) continue;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+      for (int iy = nMinCellY; iy <= nMaxCellY; iy++)
+        for (int idx : grid[(size_t)ix * ROWS + iy]) {
+          const pli_keypoint& k = kp[idx];
+          if (bCheckLevels) {
+            if (k.octave < minLevel) continue;
+            if (maxLevel >= 0 && k.octave > maxLevel) continue;
+          }
+          if (!(std::fabs(k.x - x) < r && std::fabs(k.y - y) < r)) continue;
+          if (taken[idx]) continue;
+          if (uright[idx] > 0) {
+            const float er = std::fabs(q[i].ur - uright[idx]);
+            if (er > r) continue;
+          }
+          const int dist = descriptorDistance(qdesc + (size_t)i * 32, desc + (size_t)idx * 32);
+          if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = k.octave; bestIdx = idx; }
+          else if (dist < bestDist2) { bestLevel2 = k.octave; bestDist2 = dist; }
+        }
+    if (bestIdx >= 0 && bestDist <= TH_HIGH) {
+      if (bestLevel == bestLevel2 && (float)bestDist > mfNNratio * (float)bestDist2) continue;
+      taken[bestIdx] = 1;
+      best_idx2[i] = bestIdx;
+      nmatches++;
+    }
+  }
+  return nmatches;
+}
+
 }  // namespace orc

@@ -244,6 +244,20 @@ int orc_search_by_projection(const pli_proj_query* q, const uint8_t* qdesc, int 
   std::memcpy(best_idx2, B.data(), B.size() * 4);
   return r;
 }
+int orc_search_local_map(const pli_proj_query* q, const uint8_t* qdesc, int nq, const pli_keypoint* kp,
+                         const uint8_t* desc, const float* uright, const uint8_t* occupied, int ncur, float minx, float maxx,
+                         float miny, float maxy, float nnratio, int* best_idx2) {
+  std::vector<int> B;
+  int r = searchLocalMap(q, qdesc, nq, kp, desc, uright, occupied, ncur, minx, maxx, miny, maxy, nnratio, B);
+  std::memcpy(best_idx2, B.data(), B.size() * 4);
+  return r;
+}
+int orc_match_nnr(const uint8_t* d1, int n1, const uint8_t* d2, int n2, float nnr, int* m12) {
+  std::vector<int> M;
+  int r = matchNNR(d1, n1, d2, n2, nnr, M);
+  std::memcpy(m12, M.data(), M.size() * 4);
+  return r;
+}
 // Stereo line matching on caller tables (edge-case tests without running LSD).
 int orc_stereo_lines_tables(const pli_frontend_config* cfg, const pli_keyline* kl, const uint8_t* dl, int n1,
                             const pli_keyline* kr, const uint8_t* dr, int n2, int w, int hgt, float* disp, double* le,

@@ -270,6 +270,27 @@ def search_by_projection(q, qdesc, kp, desc, uright, bounds, check_ori=True):
     return n, best
 
 
+def search_local_map(q, qdesc, kp, desc, uright, occupied, bounds, nnratio):
+    q = np.ascontiguousarray(q, PROJ_QUERY_DT)
+    qdesc = np.ascontiguousarray(qdesc, np.uint8)
+    kp = np.ascontiguousarray(kp, KEYPOINT_DT)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    uright = np.ascontiguousarray(uright, np.float32)
+    occ = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+    best = np.full(q.shape[0], -1, np.int32)
+    n = lib().orc_search_local_map(_p(q), _p(qdesc), q.shape[0], _p(kp), _p(desc), _p(uright), _p(occ), kp.shape[0],
+                                   C.c_float(bounds[0]), C.c_float(bounds[1]), C.c_float(bounds[2]), C.c_float(bounds[3]),
+                                   C.c_float(nnratio), _p(best))
+    return n, best
+
+
+def match_nnr(d1, d2, nnr):
+    d1, d2 = np.ascontiguousarray(d1, np.uint8), np.ascontiguousarray(d2, np.uint8)
+    m = np.full(d1.shape[0], -1, np.int32)
+    n = lib().orc_match_nnr(_p(d1), d1.shape[0], _p(d2), d2.shape[0], C.c_float(nnr), _p(m))
+    return n, m
+
+
 def stereo_lines_tables(cfg, kl, dl, kr, dr, w, h):
     kl, kr = np.ascontiguousarray(kl, KEYLINE_DT), np.ascontiguousarray(kr, KEYLINE_DT)
     dl, dr = np.ascontiguousarray(dl, np.uint8), np.ascontiguousarray(dr, np.uint8)

@@ -99,6 +99,11 @@ _PROTOS = {
     "pli_search_by_projection": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
                                              C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]),
+    "pli_search_local_map": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
+                                         C.c_float, C.c_void_p, C.POINTER(C.c_int32)]),
+    "pli_match_nnr": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_void_p,
+                                  C.POINTER(C.c_int32)]),
     "pli_prof_enable": (C.c_int32, [C.c_void_p, C.c_int32]),
     "pli_prof_reset": (C.c_int32, [C.c_void_p]),
     "pli_prof_report": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_int64]),

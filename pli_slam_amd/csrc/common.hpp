@@ -62,17 +62,19 @@ struct DevParams {
 };
 
 // per-image control block of the LSD relaxation (lsd_relax.hip)
+constexpr int JR_K = 32;   // rank buckets: grown one after the other inside a round (Gauss-Seidel across buckets)
 struct JrCtl {
   int state;       // 0 relaxing, 1 exact owner map found: emit round, 2 done
   int changed;     // owner_{t-1} != owner_{t-2} somewhere
-  int liveCount;   // seeds alive in owner_{t-1}
-  int next;        // work counter of the grow kernel
   int arenaHead;   // bump pointer of the queue arena
   int overflow;    // arena exhausted: the image falls back to the sequential grower
   int nSegRaw;     // segments emitted (unordered)
   int rounds;      // round in which the fixed point was detected
-  int bigCount;    // live seeds routed to the wave-cooperative grower
-  int nextBig;     // its work counter
+  int pad0, pad1;
+  int liveCount[JR_K];   // live seeds per bucket for the lane-per-region grower
+  int next[JR_K];        // its work counters
+  int bigCount[JR_K];    // live seeds per bucket for the wave-per-region grower
+  int nextBig[JR_K];
 };
 
 // a live seed, ready to grow (written by k_jr_prepare)

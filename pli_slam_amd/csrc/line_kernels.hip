@@ -55,17 +55,24 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ sc
         a = fast_atan2_deg((float)gx, (float)(-gy));
         double ad = (double)a * D_DEG2RAD;
         double af = (double)(float)ad;
-        cx = (float)cos(af);
-        sy = (float)sin(af);
-        scs.x = (float)cos(ad);       // region_grow seeds its sums with cos/sin of the unrounded angle
-        scs.y = (float)sin(ad);
+        double sn, cn;
+        sincos(af, &sn, &cn);
+        cx = (float)cn;
+        sy = (float)sn;
+        if (seedcs) {                 // region_grow seeds its sums with cos/sin of the unrounded angle
+          sincos(ad, &sn, &cn);
+          scs.x = (float)cn;
+          scs.y = (float)sn;
+        }
       }
     }
     const int64_t o = (int64_t)img * W * H + (int64_t)y * W + x;
     rec[o] = make_float4(a, cx, sy, __int_as_float(g2));
     g2o[o] = g2;
-    seedcs[o] = scs;
-    own[o] = make_int2(0x7FFFFFFF, 0x7FFFFFFF);   // undefined pixels never belong to a region
+    if (seedcs) {                                   // planes of the relaxation (lsd_relax.hip)
+      seedcs[o] = scs;
+      own[o] = make_int2(0x7FFFFFFF, 0x7FFFFFFF);   // undefined pixels never belong to a region
+    }
     if (angDbg) angDbg[o] = a;
   }
   int m = defined ? g2 : 0;
@@ -241,8 +248,10 @@ __global__ __launch_bounds__(64) void k_lsd_grow(const DevParams* __restrict__ P
     float scos = 0.f, ssin = 0.f;
     if (srec.x != LSD_NOTDEF) {
       const double ra = (double)srec.x * D_DEG2RAD;
-      scos = (float)cos(ra);
-      ssin = (float)sin(ra);
+      double sn, cn;
+      sincos(ra, &sn, &cn);
+      scos = (float)cn;
+      ssin = (float)sn;
     }
     unsigned long long unusedMask = __ballot(srec.x != LSD_NOTDEF);
     while (unusedMask) {
@@ -260,8 +269,12 @@ __global__ __launch_bounds__(64) void k_lsd_grow(const DevParams* __restrict__ P
       qs[0] = make_uint2(((unsigned)spy << 16) | (unsigned)spx, (unsigned)sg2);
       int cnt = 1;
       for (int k = 0; k < cnt; ++k) {
-        __syncthreads();                           // one wave per block: orders lane 0's queue writes before the reads
-        const uint2 e = lsd_qget(qs, qg, k);       // uniform address: LDS broadcast
+        // queue entry k: a plain LDS read (in order behind the ds_writes of this wave), global only for the overflow
+        uint2 e;
+        if (k < LSD_QCAP) e = qs[k];
+        else e = qg[k - LSD_QCAP];
+        e.x = __builtin_amdgcn_readfirstlane(e.x);
+        e.y = __builtin_amdgcn_readfirstlane(e.y);
         const int px = (int)(e.x & 0xFFFFu), py = (int)(e.x >> 16);
         const int nx = px + ndx, ny = py + ndy;
         const bool inb = lane < 9 && nx >= 0 && ny >= 0 && nx < W && ny < H;

@@ -52,10 +52,7 @@ __global__ void k_jr_begin(JrCtl* __restrict__ ctl, int nimg, int img0, int t) {
   JrCtl& c = ctl[img0 + i];
   if (t == 1) { c.state = 0; c.changed = 0; c.overflow = 0; c.nSegRaw = 0; c.rounds = 0; }
   if (c.state == 1) c.state = 2;          // the emit round ran in the previous iteration
-  c.liveCount = 0;
-  c.bigCount = 0;
-  c.next = 0;
-  c.nextBig = 0;
+  for (int b = 0; b < JR_K; ++b) { c.liveCount[b] = 0; c.bigCount[b] = 0; c.next[b] = 0; c.nextBig[b] = 0; }
   c.arenaHead = 0;
 }
 
@@ -67,7 +64,7 @@ __global__ __launch_bounds__(256) void k_jr_prepare(JrCtl* __restrict__ ctl, con
                                                     const float4* __restrict__ recAll, const float2* __restrict__ seedAll,
                                                     const int* __restrict__ lastSizeAll, JrSeed* __restrict__ smallAll,
                                                     JrSeed* __restrict__ bigAll, int bigCap, int64_t npix, int W,
-                                                    int bigThresh, int img0, int t) {
+                                                    int bigThresh, int kUse, int img0, int t) {
   const int img = blockIdx.y + img0;
   JrCtl& c = ctl[img];
   if (c.state != 0) return;
@@ -77,8 +74,9 @@ __global__ __launch_bounds__(256) void k_jr_prepare(JrCtl* __restrict__ ctl, con
   const float4* rec = recAll + img * npix;
   const float2* seedcs = seedAll + img * npix;
   const int* lastSize = lastSizeAll + img * npix;
-  JrSeed* smallL = smallAll + img * npix;
-  JrSeed* bigL = bigAll + (int64_t)img * bigCap;
+  JrSeed* smallL = smallAll + img * (npix + 64 * JR_K);      // bucket b starts at b * smallSeg
+  JrSeed* bigL = bigAll + (int64_t)img * bigCap * JR_K;        // bucket b starts at b * bigCap
+  const int smallSeg = (int)(npix / kUse) + 64;
   const int lane = threadIdx.x & 63;
   const int pi = (t - 1) & 1;
   bool changed = false;
@@ -107,23 +105,29 @@ __global__ __launch_bounds__(256) void k_jr_prepare(JrCtl* __restrict__ ctl, con
       const int py = p / W;
       sd.rank = i; sd.xy = (py << 16) | (p - py * W); sd.ang = r.x; sd.sx = sc.x; sd.sy = sc.y;
     }
-    const unsigned long long balS = __ballot(alive && !big), balB = __ballot(big);
-    if (balS) {
-      const int leader = __ffsll((long long)balS) - 1;
-      int base = 0;
-      if (lane == leader) base = atomicAdd(&c.liveCount, __popcll(balS));
-      base = __shfl(base, leader, 64);
-      if (alive && !big) smallL[base + __popcll(balS & ((1ull << lane) - 1ull))] = sd;
-    }
-    if (balB) {
-      const int leader = __ffsll((long long)balB) - 1;
-      int base = 0;
-      if (lane == leader) base = atomicAdd(&c.bigCount, __popcll(balB));
-      base = __shfl(base, leader, 64);
-      const int pos = base + __popcll(balB & ((1ull << lane) - 1ull));
-      if (big) {
-        if (pos < bigCap) bigL[pos] = sd;
-        else c.overflow = 1;
+    // rank bucket of this seed; a wave covers 64 consecutive ranks, i.e. at most two buckets
+    const int bkt = (i < n) ? (int)(((long long)i * kUse) / n) : 0;
+    const int bLo = __shfl(bkt, 0, 64);
+    for (int pass = 0; pass < 2; ++pass) {
+      const int bb = bLo + pass;
+      const unsigned long long balS = __ballot(alive && !big && bkt == bb), balB = __ballot(big && bkt == bb);
+      if (balS) {
+        const int leader = __ffsll((long long)balS) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&c.liveCount[bb], __popcll(balS));
+        base = __shfl(base, leader, 64);
+        if (alive && !big && bkt == bb) smallL[(int64_t)bb * smallSeg + base + __popcll(balS & ((1ull << lane) - 1ull))] = sd;
+      }
+      if (balB) {
+        const int leader = __ffsll((long long)balB) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&c.bigCount[bb], __popcll(balB));
+        base = __shfl(base, leader, 64);
+        const int pos = base + __popcll(balB & ((1ull << lane) - 1ull));
+        if (big && bkt == bb) {
+          if (pos < bigCap) bigL[(int64_t)bb * bigCap + pos] = sd;
+          else c.overflow = 1;
+        }
       }
     }
   }
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(256) void k_jr_grow(const DevParams* __restrict__ P
                                                  const JrSeed* __restrict__ smallAll, int* __restrict__ lastSizeAll,
                                                  int* __restrict__ arenaAll, int arenaCap,
                                                  float4* __restrict__ segRawAll, int* __restrict__ segRankAll,
-                                                 int maxSeg, int img0, int t) {
+                                                 int maxSeg, int img0, int t, int bkt, int kUse) {
   __shared__ int mq[JR_MQ * 256];
   const DevParams& P = *Pp;
   const int img = blockIdx.y + img0;
@@ -166,13 +170,13 @@ __global__ __launch_bounds__(256) void k_jr_grow(const DevParams* __restrict__ P
   const int state = c.state;
   if (state == 2 || c.overflow) return;
   const bool emit = state == 1;
-  const int nlive = c.liveCount;
+  const int nlive = c.liveCount[bkt];
   if ((int)blockIdx.x * 256 >= nlive) return;      // more lanes than seeds
   const int W = P.LW, H = P.LH;
   const int64_t npix = (int64_t)W * H;
   const float4* rec = recAll + img * npix;
   int2* own = ownAll + img * npix;
-  const JrSeed* seeds = smallAll + img * npix;
+  const JrSeed* seeds = smallAll + img * (npix + 64 * JR_K) + (int64_t)bkt * ((int)(npix / kUse) + 64);
   int* lastSize = lastSizeAll + img * npix;
   int* arena = arenaAll + (int64_t)img * arenaCap;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(256) void k_jr_grow(const DevParams* __restrict__ P
 
   for (;;) {
     int base = 0;
-    if (lane == 0) base = atomicAdd(&c.next, 64);
+    if (lane == 0) base = atomicAdd(&c.next[bkt], 64);
     base = __shfl(base, 0, 64);
     if (base >= nlive) break;
     bool active = base + lane < nlive;
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(64) void k_jr_grow_big(const DevParams* __restrict_
                                                     const JrSeed* __restrict__ bigAll, int bigCap,
                                                     int* __restrict__ lastSizeAll, int* __restrict__ arenaAll,
                                                     int arenaCap, float4* __restrict__ segRawAll,
-                                                    int* __restrict__ segRankAll, int maxSeg, int img0, int t,
+                                                    int* __restrict__ segRankAll, int maxSeg, int img0, int t, int bkt,
                                                     int* __restrict__ dbgQ, int dbgRank) {
   __shared__ int qs[JR_BQ];
   __shared__ int blk[JR_BMAXBLK];
@@ -361,13 +365,13 @@ __global__ __launch_bounds__(64) void k_jr_grow_big(const DevParams* __restrict_
   const int state = c.state;
   if (state == 2 || c.overflow) return;
   const bool emit = state == 1;
-  const int nbig = min(c.bigCount, bigCap);
+  const int nbig = min(c.bigCount[bkt], bigCap);
   if ((int)blockIdx.x >= nbig) return;
   const int W = P.LW, H = P.LH;
   const int64_t npix = (int64_t)W * H;
   const float4* rec = recAll + img * npix;
   int2* own = ownAll + img * npix;
-  const JrSeed* seeds = bigAll + (int64_t)img * bigCap;
+  const JrSeed* seeds = bigAll + ((int64_t)img * JR_K + bkt) * bigCap;
   int* lastSize = lastSizeAll + img * npix;
   int* arena = arenaAll + (int64_t)img * arenaCap;
   const int lane = threadIdx.x;
@@ -384,7 +388,7 @@ __global__ __launch_bounds__(64) void k_jr_grow_big(const DevParams* __restrict_
 
   for (;;) {
     int wi = 0;
-    if (lane == 0) wi = atomicAdd(&c.nextBig, 1);
+    if (lane == 0) wi = atomicAdd(&c.nextBig[bkt], 1);
     wi = __shfl(wi, 0, 64);
     if (wi >= nbig) break;
     const JrSeed sd = seeds[wi];

@@ -8,6 +8,7 @@
 //   k_distance                          ORBmatcher::DescriptorDistance     (ORBmatcher.cc:2495-2511)
 //   k_knn2, k_ratio, k_mutual           matchNNR / match                   (LineMatcher.cpp:139-229)
 //   k_search_by_projection              ORBmatcher::SearchByProjection(F,F)(ORBmatcher.cc:2179-2323)
+//   k_search_local_map                  ORBmatcher::SearchByProjection(F,MPs)(ORBmatcher.cc:44-143)
 #include "kernels.hpp"
 #include "device_prims.hpp"
 #include <climits>
@@ -580,6 +581,96 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const pli_proj_quer
   for (int i2 = lane; i2 < ncur; i2 += 64) {
     const int o = owner[i2];
     if (o >= 0) bestIdx2[o] = i2;
+  }
+  if (lane == 0) *nmatchesOut = nmatches;
+}
+
+// ---------------------------------------------------------------------------
+// Local-map search (ORBmatcher.cc:44-143, rectified stereo branch).  One wave walks the
+// map points in order (the assignment of a keypoint is visible to the following points);
+// the lanes share the scan over the frame's keypoints.  The reference's running
+// best / second-best pair is the two smallest (distance, visiting order) keys.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_search_local_map(const pli_proj_query* __restrict__ q,
+                                                         const uint8_t* __restrict__ qdesc, int nq,
+                                                         const pli_keypoint* __restrict__ kp,
+                                                         const uint8_t* __restrict__ desc,
+                                                         const float* __restrict__ uright,
+                                                         const uint8_t* __restrict__ occupied, int ncur, float minX,
+                                                         float maxX, float minY, float maxY, float nnratio,
+                                                         int* __restrict__ owner /* ncur */,
+                                                         int* __restrict__ bestIdx2 /* nq */,
+                                                         int* __restrict__ nmatchesOut) {
+  const int lane = threadIdx.x;
+  const float gwInv = __fdiv_rn((float)GRID_COLS, __fsub_rn(maxX, minX));
+  const float ghInv = __fdiv_rn((float)GRID_ROWS, __fsub_rn(maxY, minY));
+  for (int i = lane; i < ncur; i += 64) owner[i] = (occupied && occupied[i]) ? INT_MAX : -1;
+  for (int i = lane; i < nq; i += 64) bestIdx2[i] = -1;
+  __syncthreads();
+  int nmatches = 0;
+  for (int i = 0; i < nq; ++i) {
+    const pli_proj_query Q = q[i];
+    if (!Q.valid) continue;
+    const float u = Q.u, v = Q.v, radius = Q.radius;
+    const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(u, minX), radius), gwInv)));
+    if (nMinCellX >= GRID_COLS) continue;
+    const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(u, minX), radius), gwInv)));
+    if (nMaxCellX < 0) continue;
+    const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(v, minY), radius), ghInv)));
+    if (nMinCellY >= GRID_ROWS) continue;
+    const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(v, minY), radius), ghInv)));
+    if (nMaxCellY < 0) continue;
+    const bool bCheckLevels = (Q.min_level > 0) || (Q.max_level >= 0);
+    uint64_t dq[4];
+    load_desc(qdesc + (int64_t)i * 32, dq);
+    unsigned long long k1 = ~0ull, k2 = ~0ull;
+    for (int i2 = lane; i2 < ncur; i2 += 64) {
+      const pli_keypoint k = kp[i2];
+      const int px = (int)roundf(__fmul_rn(__fsub_rn(k.x, minX), gwInv));
+      const int py = (int)roundf(__fmul_rn(__fsub_rn(k.y, minY), ghInv));
+      if (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) continue;   // PosInGrid
+      if (px < nMinCellX || px > nMaxCellX || py < nMinCellY || py > nMaxCellY) continue;
+      if (bCheckLevels) {
+        if (k.octave < Q.min_level) continue;
+        if (Q.max_level >= 0 && k.octave > Q.max_level) continue;
+      }
+      const float distx = __fsub_rn(k.x, u), disty = __fsub_rn(k.y, v);
+      if (!(fabsf(distx) < radius && fabsf(disty) < radius)) continue;
+      if (owner[i2] >= 0) continue;
+      const float ur2 = uright[i2];
+      if (ur2 > 0) {
+        const float er = fabsf(__fsub_rn(Q.ur, ur2));
+        if (er > radius) continue;
+      }
+      uint64_t d2[4];
+      load_desc(desc + (int64_t)i2 * 32, d2);
+      const int dist = hamming256(dq, d2);
+      if (dist < 256) {
+        const unsigned long long key = ((unsigned long long)dist << 40) | ((unsigned long long)px << 34) |
+                                       ((unsigned long long)py << 28) | (unsigned long long)i2;
+        if (key < k1) { k2 = k1; k1 = key; }
+        else if (key < k2) k2 = key;
+      }
+    }
+    const unsigned long long m1 = wave_min_u64(k1);
+    const unsigned long long c2 = (k1 == m1) ? k2 : k1;
+    const unsigned long long m2 = wave_min_u64(c2);
+    if (m1 != ~0ull && (int)(m1 >> 40) <= 100) {
+      const int b1 = (int)(m1 & 0xFFFFFFFull);
+      const int bestDist = (int)(m1 >> 40);
+      const int bestLevel = kp[b1].octave;
+      int bestDist2 = 256, bestLevel2 = -1;
+      if (m2 != ~0ull) { bestDist2 = (int)(m2 >> 40); bestLevel2 = kp[(int)(m2 & 0xFFFFFFFull)].octave; }
+      const bool reject = bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2);
+      if (!reject) {
+        // every lane stores the same value (lane 0 need not be active in a divergent wave)
+        owner[b1] = i;
+        bestIdx2[i] = b1;
+        ++nmatches;
+        __threadfence_block();
+      }
+    }
+    __syncthreads();
   }
   if (lane == 0) *nmatchesOut = nmatches;
 }

@@ -389,14 +389,14 @@ pli_status allocAll(pli_ctx* c) {
   const size_t npix = (size_t)P.LW * P.LH;
   A(c->rec, npix * NI);
   A(c->g2, npix * NI);
-  A(c->seedcs, npix * NI);
-  A(c->own, npix * NI);
   c->lsdMode = c->cfg.lsd_mode;
   if (const char* e = getenv("PLI_LSD_MODE")) c->lsdMode = atoi(e);
   if (c->lsdMode != 2) {     // buffers of the relaxation
-    A(c->smallSeeds, npix * NI);
-    c->bigCap = (int)(npix / 32 + 1024);
-    A(c->bigSeeds, (size_t)c->bigCap * NI);
+    A(c->seedcs, npix * NI);
+    A(c->own, npix * NI);
+    A(c->smallSeeds, (npix + 64 * JR_K) * NI);
+    c->bigCap = (int)(npix / 128 + 1024);                 // per rank bucket
+    A(c->bigSeeds, (size_t)c->bigCap * JR_K * NI);
     A(c->lastSize, npix * NI);
     c->arenaCap = (int)std::min<size_t>(8 * npix, (size_t)1 << 30);
     A(c->arena, (size_t)c->arenaCap * NI);
@@ -497,9 +497,11 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     scaled = c->pyr + P.lv[0].offset; sStride = P.pyrBlock; sPitch = P.lv[0].pitch;
   }
   HIPCHK(hipMemsetAsync(c->maxG2 + img0, 0, sizeof(int) * nimg, c->stream));
+  const bool sequential = c->lsdMode == 2 || (c->lsdMode == 0 && nimg >= 256);
+  float2* seedPlane = sequential ? (float2*)nullptr : c->seedcs;
   {
     dim3 g((P.LW + 255) / 256, P.LH, nimg);
-    LAUNCH(c, "k_lsd_grad", k_lsd_grad, g, dim3(256), 0, scaled, sStride, P.LW, P.LH, sPitch, P.g2Thresh, c->rec, c->g2, c->seedcs, c->own,
+    LAUNCH(c, "k_lsd_grad", k_lsd_grad, g, dim3(256), 0, scaled, sStride, P.LW, P.LH, sPitch, P.g2Thresh, c->rec, c->g2, seedPlane, c->own,
            c->maxG2, c->debug ? c->angDbg : (float*)nullptr, img0);
   }
   LAUNCH(c, "k_lsd_hist", k_lsd_hist, dim3(c->nChunks, nimg), dim3(256), 0, c->g2, npix, P.g2Thresh, P.nBins, c->maxG2,
@@ -507,7 +509,6 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   LAUNCH(c, "k_lsd_scan", k_lsd_scan, dim3(nimg), dim3(1024), 0, c->chunkHist, c->nChunks, P.nBins, c->chunkBase, c->nDefined, img0);
   LAUNCH(c, "k_lsd_scatter", k_lsd_scatter, dim3(c->nChunks, nimg), dim3(64), 0, c->g2, npix, P.g2Thresh, P.nBins, c->maxG2,
          c->chunkBase, c->nChunks, c->order, img0);
-  const bool sequential = c->lsdMode == 2 || (c->lsdMode == 0 && nimg >= 256);
   if (sequential) {
     LAUNCH(c, "k_lsd_grow", k_lsd_grow, dim3(nimg), dim3(64), 0, c->dP, c->rec, c->order, c->nDefined,
            c->regScratch, c->seg, c->nSeg, c->maxSeg, img0);
@@ -515,27 +516,29 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     // rank-ordered relaxation (lsd_relax.hip): rounds until every image's owner map is a fixed point
     const int64_t npix64 = (int64_t)npix;
     const int ctlBlocks = (nimg + 63) / 64;
-    int growBlocks = std::max(1, std::min(256, (npix + 256 * 64 - 1) / (256 * 64)));
+    int growBlocks = std::max(1, std::min(256, (npix / 4 + 256 * 8 - 1) / (256 * 8)));
     if (const char* e = getenv("PLI_JR_BLOCKS")) growBlocks = std::max(1, atoi(e));
     int bigThresh = 48;
     if (const char* e = getenv("PLI_JR_BIG")) bigThresh = atoi(e);
-    int bigBlocks = 512;
+    int bigBlocks = 128;
+    int kUse = 1;                                  // rank buckets per round (PLI_JR_K, <= JR_K)
+    if (const char* e = getenv("PLI_JR_K")) kUse = std::max(1, std::min(JR_K, atoi(e)));
     if (const char* e = getenv("PLI_JR_BIGBLOCKS")) bigBlocks = std::max(1, atoi(e));
     bool allDone = false;
     int t = 1;
     for (; t <= 4096 && !allDone; ++t) {
       LAUNCH(c, "k_jr_begin", k_jr_begin, dim3(ctlBlocks), dim3(64), 0, c->jrCtl, nimg, img0, t);
       LAUNCH(c, "k_jr_prepare", k_jr_prepare, dim3(64, nimg), dim3(256), 0, c->jrCtl, c->order, c->nDefined, c->own,
-             c->rec, c->seedcs, c->lastSize, c->smallSeeds, c->bigSeeds, c->bigCap, npix64, P.LW, bigThresh, img0, t);
+             c->rec, c->seedcs, c->lastSize, c->smallSeeds, c->bigSeeds, c->bigCap, npix64, P.LW, bigThresh, kUse, img0, t);
       LAUNCH(c, "k_jr_decide", k_jr_decide, dim3(ctlBlocks), dim3(64), 0, c->jrCtl, nimg, img0, t);
-      static const char* growNames[24] = {"k_jr_grow", "k_jr_grow_r01", "k_jr_grow_r02", "k_jr_grow_r03", "k_jr_grow_r04", "k_jr_grow_r05", "k_jr_grow_r06", "k_jr_grow_r07", "k_jr_grow_r08", "k_jr_grow_r09", "k_jr_grow_r10", "k_jr_grow_r11", "k_jr_grow_r12", "k_jr_grow_r13", "k_jr_grow_r14", "k_jr_grow_r15", "k_jr_grow_r16", "k_jr_grow_r17", "k_jr_grow_r18", "k_jr_grow_r19", "k_jr_grow_r20", "k_jr_grow_r21", "k_jr_grow_r22", "k_jr_grow_r23"};
-      static const bool perRound = getenv("PLI_PROF_ROUNDS") != nullptr;
-      LAUNCH(c, (perRound && t < 24) ? growNames[t] : "k_jr_grow", k_jr_grow, dim3(growBlocks, nimg), dim3(256), 0, c->dP, c->jrCtl,
-             c->rec, c->own, c->smallSeeds, c->lastSize, c->arena, c->arenaCap, c->segRaw, c->segRank, c->maxSeg, img0, t);
-      if (t > 1)
-        LAUNCH(c, "k_jr_grow_big", k_jr_grow_big, dim3(bigBlocks, nimg), dim3(64), 0, c->dP, c->jrCtl, c->rec, c->own,
-               c->bigSeeds, c->bigCap, c->lastSize, c->arena, c->arenaCap, c->segRaw, c->segRank, c->maxSeg, img0, t,
-               c->debug ? (int*)c->regScratch : (int*)nullptr, getenv("PLI_DBG_RANK") ? atoi(getenv("PLI_DBG_RANK")) : -1);
+      for (int bkt = 0; bkt < kUse; ++bkt) {
+        LAUNCH(c, "k_jr_grow", k_jr_grow, dim3(growBlocks, nimg), dim3(256), 0, c->dP, c->jrCtl, c->rec, c->own, c->smallSeeds,
+               c->lastSize, c->arena, c->arenaCap, c->segRaw, c->segRank, c->maxSeg, img0, t, bkt, kUse);
+        if (t > 1)
+          LAUNCH(c, "k_jr_grow_big", k_jr_grow_big, dim3(bigBlocks, nimg), dim3(64), 0, c->dP, c->jrCtl, c->rec, c->own,
+                 c->bigSeeds, c->bigCap, c->lastSize, c->arena, c->arenaCap, c->segRaw, c->segRank, c->maxSeg, img0, t, bkt,
+                 c->debug ? (int*)c->regScratch : (int*)nullptr, getenv("PLI_DBG_RANK") ? atoi(getenv("PLI_DBG_RANK")) : -1);
+      }
       if (t >= 8 && (t % 4) == 0) {
         HIPCHK(hipMemcpyAsync(c->jrHost.data(), c->jrCtl + img0, sizeof(JrCtl) * nimg, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -878,8 +881,8 @@ pli_status pli_hamming_knn2(pli_ctx* c, const uint8_t* q, int32_t nq, const uint
   return PLI_OK;
 }
 
-pli_status pli_match_lines(pli_ctx* c, const uint8_t* d1, int32_t n1, const uint8_t* d2, int32_t n2, float nnr,
-                           int32_t* m12, int32_t* nmatches) {
+static pli_status matchDescriptors(pli_ctx* c, const uint8_t* d1, int32_t n1, const uint8_t* d2, int32_t n2, float nnr,
+                                   bool mutual, int32_t* m12, int32_t* nmatches) {
   if (!c || n1 < 0 || n2 < 0 || (n1 > 0 && (!d1 || !m12)) || (n2 > 0 && !d2)) { g_err = "bad argument"; return PLI_ERR_INVALID; }
   if (nmatches) *nmatches = 0;
   if (n1 == 0) return PLI_OK;
@@ -902,7 +905,7 @@ pli_status pli_match_lines(pli_ctx* c, const uint8_t* d1, int32_t n1, const uint
   HIPCHK(hipMemsetAsync(dcount, 0, 4, c->stream));
   LAUNCH(c, "k_knn2", k_knn2, dim3(n1), dim3(64), 0, dd1, n1, dd2, n2, i1, ds1);
   LAUNCH(c, "k_ratio", k_ratio, dim3((n1 + 255) / 256), dim3(256), 0, i1, ds1, n1, n2, nnr, dm12);
-  const bool lr = c->cfg.best_lr_matches != 0;
+  const bool lr = mutual;
   if (lr && n2 > 0) {
     LAUNCH(c, "k_knn2", k_knn2, dim3(n2), dim3(64), 0, dd2, n2, dd1, n1, i2, ds2);
     LAUNCH(c, "k_ratio", k_ratio, dim3((n2 + 255) / 256), dim3(256), 0, i2, ds2, n2, n1, nnr, dm21);
@@ -914,6 +917,16 @@ pli_status pli_match_lines(pli_ctx* c, const uint8_t* d1, int32_t n1, const uint
   HIPCHK(hipStreamSynchronize(c->stream));
   if (nmatches) *nmatches = cnt;
   return PLI_OK;
+}
+
+pli_status pli_match_lines(pli_ctx* c, const uint8_t* d1, int32_t n1, const uint8_t* d2, int32_t n2, float nnr,
+                           int32_t* m12, int32_t* nmatches) {
+  return matchDescriptors(c, d1, n1, d2, n2, nnr, c && c->cfg.best_lr_matches != 0, m12, nmatches);
+}
+
+pli_status pli_match_nnr(pli_ctx* c, const uint8_t* d1, int32_t n1, const uint8_t* d2, int32_t n2, float nnr,
+                         int32_t* m12, int32_t* nmatches) {
+  return matchDescriptors(c, d1, n1, d2, n2, nnr, false, m12, nmatches);
 }
 
 pli_status pli_search_by_projection(pli_ctx* c, const pli_proj_query* q, const uint8_t* qdesc, int32_t nq,
@@ -949,6 +962,50 @@ pli_status pli_search_by_projection(pli_ctx* c, const pli_proj_query* q, const u
   }
   LAUNCH(c, "k_search_by_projection", k_search_by_projection, dim3(1), dim3(64), 0, dq, dqd, nq, dk, ddsc, du, ncur, minX, maxX,
          minY, maxY, checkOri, down, dbest, dcnt);
+  int cnt = 0;
+  HIPCHK(hipMemcpyAsync(best, dbest, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(&cnt, dcnt, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (nmatches) *nmatches = cnt;
+  return PLI_OK;
+}
+
+pli_status pli_search_local_map(pli_ctx* c, const pli_proj_query* q, const uint8_t* qdesc, int32_t nq,
+                                const pli_keypoint* kp, const uint8_t* desc, const float* uright,
+                                const uint8_t* occupied, int32_t ncur, float minX, float maxX, float minY, float maxY,
+                                float nnratio, int32_t* best, int32_t* nmatches) {
+  if (!c || nq < 0 || ncur < 0 || (nq > 0 && (!q || !qdesc || !best)) || (ncur > 0 && (!kp || !desc || !uright))) { g_err = "bad argument"; return PLI_ERR_INVALID; }
+  if (nmatches) *nmatches = 0;
+  if (nq == 0) return PLI_OK;
+  if (ncur >= (1 << 28)) { g_err = "too many keypoints"; return PLI_ERR_INVALID; }
+  HIPCHK(hipSetDevice(c->device));
+  const int nc = std::max(ncur, 1);
+  const size_t bq = alignUp((size_t)nq * sizeof(pli_proj_query), 256), bqd = alignUp((size_t)nq * 32, 256);
+  const size_t bk = alignUp((size_t)nc * sizeof(pli_keypoint), 256), bd = alignUp((size_t)nc * 32, 256), bu = alignUp((size_t)nc * 4, 256);
+  const size_t bo = alignUp((size_t)nc * 4, 256), bb = alignUp((size_t)nq * 4, 256), bc = alignUp((size_t)nc, 256);
+  pli_status st = ensureScratch(c, bq + bqd + bk + bd + bu + bo + bb + bc + 256);
+  if (st != PLI_OK) return st;
+  uint8_t* p = (uint8_t*)c->scratch;
+  pli_proj_query* dq = (pli_proj_query*)p; p += bq;
+  uint8_t* dqd = p; p += bqd;
+  pli_keypoint* dk = (pli_keypoint*)p; p += bk;
+  uint8_t* ddsc = p; p += bd;
+  float* du = (float*)p; p += bu;
+  int* down = (int*)p; p += bo;
+  int* dbest = (int*)p; p += bb;
+  uint8_t* docc = p; p += bc;
+  int* dcnt = (int*)p;
+  HIPCHK(hipMemcpyAsync(dq, q, (size_t)nq * sizeof(pli_proj_query), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(dqd, qdesc, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
+  if (ncur > 0) {
+    HIPCHK(hipMemcpyAsync(dk, kp, (size_t)ncur * sizeof(pli_keypoint), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(ddsc, desc, (size_t)ncur * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(du, uright, (size_t)ncur * 4, hipMemcpyHostToDevice, c->stream));
+    if (occupied) HIPCHK(hipMemcpyAsync(docc, occupied, (size_t)ncur, hipMemcpyHostToDevice, c->stream));
+  }
+  LAUNCH(c, "k_search_local_map", k_search_local_map, dim3(1), dim3(64), 0, dq, dqd, nq, dk, ddsc, du,
+         (occupied && ncur > 0) ? (const uint8_t*)docc : (const uint8_t*)nullptr, ncur, minX, maxX, minY, maxY, nnratio, down,
+         dbest, dcnt);
   int cnt = 0;
   HIPCHK(hipMemcpyAsync(best, dbest, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(&cnt, dcnt, 4, hipMemcpyDeviceToHost, c->stream));

@@ -136,6 +136,29 @@ class Frontend:
                                               int(check_orientation), ptr(best), C.byref(n)))
         return n.value, best
 
+    def search_local_map(self, queries, qdesc, cur_kp, cur_desc, cur_uright, bounds, nnratio=0.8, cur_occupied=None):
+        """ORBmatcher::SearchByProjection(F, vpMapPoints, th) ORBmatcher.cc:44 — see pli_search_local_map."""
+        q = np.ascontiguousarray(queries, PROJ_QUERY_DT)
+        qd = np.ascontiguousarray(qdesc, np.uint8)
+        kp = np.ascontiguousarray(cur_kp, KEYPOINT_DT)
+        de = np.ascontiguousarray(cur_desc, np.uint8)
+        ur = np.ascontiguousarray(cur_uright, np.float32)
+        occ = None if cur_occupied is None else np.ascontiguousarray(cur_occupied, np.uint8)
+        best = np.full(q.shape[0], -1, np.int32)
+        n = C.c_int32()
+        check(self.L.pli_search_local_map(self.h, ptr(q), ptr(qd), q.shape[0], ptr(kp), ptr(de), ptr(ur), ptr(occ),
+                                          kp.shape[0], bounds[0], bounds[1], bounds[2], bounds[3], nnratio, ptr(best),
+                                          C.byref(n)))
+        return n.value, best
+
+    def match_nnr(self, desc1, desc2, nnr):
+        """match(vpLocalMapLines, CurrentFrame, nnr, matches_12) LineMatcher.cpp:161 (one-way matchNNR)."""
+        d1, d2 = np.ascontiguousarray(desc1, np.uint8), np.ascontiguousarray(desc2, np.uint8)
+        m = np.full(d1.shape[0], -1, np.int32)
+        n = C.c_int32()
+        check(self.L.pli_match_nnr(self.h, ptr(d1), d1.shape[0], ptr(d2), d2.shape[0], nnr, ptr(m), C.byref(n)))
+        return n.value, m
+
     # ---- batch path ----------------------------------------------------------
     def table_bytes(self, nframes):
         return int(self.layout.record_bytes) * nframes

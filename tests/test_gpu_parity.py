@@ -205,6 +205,68 @@ def test_config3_f2f(gpu):
         on, obest = g.po.search_by_projection(q, last["descL"], cur["kpL"], cur["descL"], cur["uright"], bounds, chk)
         assert n == on and np.array_equal(best, obest)
     assert on > 100
+    # local map tracking: SearchByProjection(F, vpMapPoints, th) ORBmatcher.cc:44 with the last frame's
+    # points standing in for the local map (each twice, so that later map points meet occupied keypoints), and
+    # match(MapLines, Frame) LineMatcher.cpp:161
+    rng = np.random.default_rng(3)
+    q2 = np.concatenate([q, q])
+    q2["min_level"] = np.concatenate([kpl["octave"] - 1, kpl["octave"]]); q2["max_level"] = np.concatenate([kpl["octave"], kpl["octave"] + 1])
+    q2["u"][len(q):] += 0.75
+    qd2 = np.concatenate([last["descL"], last["descL"]])
+    occ = (rng.random(len(cur["kpL"])) < 0.3).astype(np.uint8)
+    for nnratio, oc in ((0.8, occ), (0.6, None), (1.0, occ)):
+        n, best = fe.search_local_map(q2, qd2, cur["kpL"], cur["descL"], cur["uright"], bounds, nnratio, oc)
+        on, obest = g.po.search_local_map(q2, qd2, cur["kpL"], cur["descL"], cur["uright"], oc, bounds, nnratio)
+        assert n == on and np.array_equal(best, obest)
+        assert on > 100 and (oc is None or not oc[obest[obest >= 0]].any())
+        hit = obest[obest >= 0]
+        assert len(np.unique(hit)) == len(hit)
+    n, m12 = fe.match_nnr(last["ldescL"], cur["ldescL"], 0.9)
+    on, om12 = g.po.match_nnr(last["ldescL"], cur["ldescL"], 0.9)
+    assert n == on and np.array_equal(m12, om12) and n > 20
+
+
+def test_local_map_search_ties_and_levels(gpu):
+    """Second-best / same-level ratio rule of ORBmatcher.cc:118-138 on engineered tables with many equal distances."""
+    g = gpu
+    fe = g.Frontend(g.capi.default_config(128, 128))
+    rng = np.random.default_rng(11)
+    ncur, nq = 700, 500
+    kp = np.zeros(ncur, g.capi.KEYPOINT_DT)
+    kp["x"] = rng.uniform(0, 640, ncur).astype(np.float32); kp["y"] = rng.uniform(0, 480, ncur).astype(np.float32)
+    kp["octave"] = rng.integers(0, 4, ncur)
+    desc = (rng.integers(0, 2, (ncur, 32)) * 255).astype(np.uint8)       # distances are multiples of 8
+    ur = np.where(rng.random(ncur) < 0.5, kp["x"] - rng.uniform(0, 30, ncur), -1).astype(np.float32)
+    q = np.zeros(nq, g.capi.PROJ_QUERY_DT)
+    src = rng.integers(0, ncur, nq)
+    q["u"] = kp["x"][src] + rng.uniform(-4, 4, nq).astype(np.float32); q["v"] = kp["y"][src] + rng.uniform(-4, 4, nq).astype(np.float32)
+    q["radius"] = rng.uniform(10, 60, nq).astype(np.float32)
+    q["ur"] = q["u"] - rng.uniform(0, 30, nq).astype(np.float32)
+    q["min_level"] = rng.integers(-1, 3, nq); q["max_level"] = q["min_level"] + rng.integers(0, 3, nq)
+    q["valid"] = rng.random(nq) < 0.9
+    qd = desc[src].copy()
+    flip = rng.random((nq, 32)) < 0.25
+    qd[flip] ^= 255
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    tot = 0
+    for nnratio in (0.8, 0.5, 1.0):
+        n, best = fe.search_local_map(q, qd, kp, desc, ur, bounds, nnratio)
+        on, obest = g.po.search_local_map(q, qd, kp, desc, ur, None, bounds, nnratio)
+        assert n == on and np.array_equal(best, obest)
+        tot += on
+    assert tot > 100
+    # queries off the grid, no keypoints, no queries
+    q["u"] = 5000.0
+    n, best = fe.search_local_map(q, qd, kp, desc, ur, bounds, 0.8)
+    assert n == 0 and (best == -1).all()
+    n, best = fe.search_local_map(q[:0], qd[:0], kp, desc, ur, bounds, 0.8)
+    assert n == 0 and len(best) == 0
+    n, m = fe.match_nnr(desc[:50], desc[:0], 0.9)
+    assert n == 0 and (m == -1).all()
+    for nnr in (0.9, 1.0):
+        n, m = fe.match_nnr(qd, desc, nnr)
+        on, om = g.po.match_nnr(qd, desc, nnr)
+        assert n == on and np.array_equal(m, om)
 
 
 # ---------------------------------------------------------------------------------------------

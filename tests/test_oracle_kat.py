@@ -244,3 +244,39 @@ def test_search_by_projection_exclusive_assignment(oracle):
     qd = np.zeros((2, 32), np.uint8)
     n, best = oracle.search_by_projection(q, qd, kp, desc, np.full(2, -1, np.float32), (0, 752, 0, 480), False)
     assert best.tolist() == [0, 1] and n == 2      # the second query cannot take keypoint 0 again
+
+
+def test_search_local_map_ratio_and_levels(oracle):
+    """ORBmatcher.cc:118-138: the ratio test only applies when best and second best are on the same level."""
+    kp = np.zeros(3, oracle.KEYPOINT_DT)
+    kp["x"] = [100.0, 103.0, 98.0]; kp["y"] = 100.0; kp["octave"] = [1, 1, 0]
+    desc = np.zeros((3, 32), np.uint8)
+    desc[0, 0] = 0b1111            # distance 4 to a zero query
+    desc[1, 0] = 0b11111           # distance 5, same level as keypoint 0
+    desc[2, :] = 255               # far away
+    ur = np.full(3, -1, np.float32)
+    q = np.zeros(1, oracle.PROJ_QUERY_DT)
+    q["u"] = 101.0; q["v"] = 100.0; q["radius"] = 7.0; q["min_level"] = 0; q["max_level"] = 1; q["valid"] = 1
+    qd = np.zeros((1, 32), np.uint8)
+    b = (0, 752, 0, 480)
+    n, best = oracle.search_local_map(q, qd, kp, desc, ur, None, b, 0.8)
+    assert n == 1 and best.tolist() == [0]          # 4 <= 0.8*5
+    n, best = oracle.search_local_map(q, qd, kp, desc, ur, None, b, 0.7)
+    assert n == 0 and best.tolist() == [-1]         # 4 > 0.7*5 on the same level
+    kp["octave"][1] = 0
+    n, best = oracle.search_local_map(q, qd, kp, desc, ur, None, b, 0.7)
+    assert n == 1 and best.tolist() == [0]          # different levels: no ratio test
+    # occupied keypoints are skipped; the uRight gate uses the query's radius
+    n, best = oracle.search_local_map(q, qd, kp, desc, ur, np.array([1, 0, 0], np.uint8), b, 0.7)
+    assert best.tolist() == [1]
+    ur[:] = [60.0, -1, -1]; q["ur"] = 50.0
+    n, best = oracle.search_local_map(q, qd, kp, desc, ur, None, b, 0.7)
+    assert best.tolist() == [1]                      # |50-60| > 7 removes keypoint 0
+    # one-way matchNNR keeps non-mutual matches that match() would drop
+    a = np.zeros((2, 32), np.uint8); t = np.zeros((2, 32), np.uint8)
+    a[0, 0] = 0b1; a[1, :4] = 255; t[0, :2] = 255; t[1, :4] = 255
+    # a0->t0: 15 < 0.9*31; a1->t1: 0; but t0->a0: 15 !< 0.9*16, so the mutual check of match() drops a0
+    n, m = oracle.match_nnr(a, t, 0.9)
+    n2, m2 = oracle.match_lines(a, t, 0.9, True)
+    assert m.tolist() == [0, 1] and n == 2
+    assert m2.tolist() == [-1, 1] and n2 == 1
