@@ -95,6 +95,23 @@ class Frontend {
                                    minX, maxX, minY, maxY, checkOrientation ? 1 : 0, bestIdx2.data(), &n));
     return n;
   }
+  // core of ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, ...) ORBmatcher.cc:44
+  int searchLocalMap(const std::vector<pli_proj_query>& q, const uint8_t* qdesc, const std::vector<pli_keypoint>& cur,
+                     const uint8_t* curDesc, const float* curURight, const uint8_t* curOccupied, float minX, float maxX,
+                     float minY, float maxY, float nnratio, std::vector<int>& bestIdx2) {
+    bestIdx2.assign(q.size(), -1);
+    int32_t n = 0;
+    check(pli_search_local_map(ctx_, q.data(), qdesc, (int)q.size(), cur.data(), curDesc, curURight, curOccupied,
+                               (int)cur.size(), minX, maxX, minY, maxY, nnratio, bestIdx2.data(), &n));
+    return n;
+  }
+  // int match(const vector<MapLine*>&, Frame&, nnr, matches_12) LineMatcher.cpp:161 on the descriptor tables
+  int matchNNR(const uint8_t* desc1, int n1, const uint8_t* desc2, int n2, float nnr, std::vector<int>& matches12) {
+    matches12.assign(n1, -1);
+    int32_t n = 0;
+    check(pli_match_nnr(ctx_, desc1, n1, desc2, n2, nnr, matches12.data(), &n));
+    return n;
+  }
 
  private:
   pli_frontend_config cfg_;

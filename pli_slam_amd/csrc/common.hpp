@@ -62,25 +62,32 @@ struct DevParams {
 };
 
 // per-image control block of the LSD relaxation (lsd_relax.hip)
-constexpr int JR_K = 32;   // rank buckets: grown one after the other inside a round (Gauss-Seidel across buckets)
-struct JrCtl {
-  int state;       // 0 relaxing, 1 exact owner map found: emit round, 2 done
+struct RxCtl {
+  int state;       // 0 relaxing, 2 exact owner map found
   int changed;     // owner_{t-1} != owner_{t-2} somewhere
-  int arenaHead;   // bump pointer of the queue arena
-  int overflow;    // arena exhausted: the image falls back to the sequential grower
-  int nSegRaw;     // segments emitted (unordered)
+  int arenaHead;   // bump pointer of the queue arena of the wave grower
+  int overflow;    // a capacity was exhausted: the image falls back to the sequential grower
   int rounds;      // round in which the fixed point was detected
-  int pad0, pad1;
-  int liveCount[JR_K];   // live seeds per bucket for the lane-per-region grower
-  int next[JR_K];        // its work counters
-  int bigCount[JR_K];    // live seeds per bucket for the wave-per-region grower
-  int nextBig[JR_K];
+  int nSmall, nBig, nHand;   // work lists of this round: lane grower, wave grower, regions handed from lane to wave
+  int next, nextBig;         // their work counters
+  int pad[6];
 };
 
-// a live seed, ready to grow (written by k_jr_prepare)
-struct JrSeed {
+// an alive seed, ready to grow (written by k_rx_seed)
+struct RxSeed {
   int rank, xy;
   float ang, sx, sy;
+};
+
+constexpr int RX_QCAP = 32;            // queue entries a lane keeps in LDS
+constexpr int RX_HAND = RX_QCAP - 8;   // a lane hands its region to the wave grower at this size (step boundary)
+
+// a region in mid-growth, handed from the lane grower to the wave grower
+struct RxHand {
+  int rank, k, cnt;
+  float sumdx, sumdy;
+  int box0, box1, pad;
+  int q[RX_QCAP];
 };
 
 }  // namespace pli

@@ -58,10 +58,12 @@ struct pli_ctx {
   int tmpPitch = 0;
   int* lsdTab = nullptr;
   float4* rec = nullptr; int* g2 = nullptr; int* maxG2 = nullptr;
-  float2* seedcs = nullptr; int2* own = nullptr; JrSeed* smallSeeds = nullptr; JrSeed* bigSeeds = nullptr; int bigCap = 0;
+  float2* seedcs = nullptr; int2* own = nullptr; RxSeed* smallSeeds = nullptr; RxSeed* bigSeeds = nullptr; int bigCap = 0;
+  RxHand* hand = nullptr; int handCap = 0; int* rankOf = nullptr; int2* rgBox = nullptr; float4* rgSeg = nullptr; uint8_t* rgClean = nullptr;
+  int* tileMin = nullptr; int tilesW = 0, tilesH = 0; int* rxChunkCnt = nullptr; int rxChunks = 0;
   int* lastSize = nullptr; int* arena = nullptr; int arenaCap = 0;
-  JrCtl* jrCtl = nullptr; float4* segRaw = nullptr; int* segRank = nullptr;
-  std::vector<JrCtl> jrHost;
+  RxCtl* jrCtl = nullptr;
+  std::vector<RxCtl> jrHost;
   int lsdMode = 0;     // 0 auto, 1 relaxation, 2 sequential (cfg.lsd_mode, or PLI_LSD_MODE)
   unsigned short* chunkHist = nullptr; int* chunkBase = nullptr; int* nDefined = nullptr;
   int* order = nullptr; uint2* regScratch = nullptr; float* seg = nullptr; int* nSeg = nullptr;
@@ -394,10 +396,20 @@ pli_status allocAll(pli_ctx* c) {
   if (c->lsdMode != 2) {     // buffers of the relaxation
     A(c->seedcs, npix * NI);
     A(c->own, npix * NI);
-    A(c->smallSeeds, (npix + 64 * JR_K) * NI);
-    c->bigCap = (int)(npix / 128 + 1024);                 // per rank bucket
-    A(c->bigSeeds, (size_t)c->bigCap * JR_K * NI);
-    A(c->lastSize, npix * NI);
+    A(c->smallSeeds, npix * NI);
+    c->bigCap = (int)(npix / RX_HAND + 64);               // a region listed as large had >= RX_HAND pixels of its own
+    A(c->bigSeeds, (size_t)c->bigCap * NI);
+    c->handCap = (int)(npix / RX_HAND + 64);
+    A(c->hand, (size_t)c->handCap * NI);
+    A(c->lastSize, npix * NI);                            // region tables, indexed by seed rank
+    A(c->rgBox, npix * NI);
+    A(c->rgSeg, npix * NI);
+    A(c->rgClean, npix * NI);
+    A(c->rankOf, npix * NI);
+    c->tilesW = (P.LW + 7) / 8; c->tilesH = (P.LH + 7) / 8;
+    A(c->tileMin, (size_t)c->tilesW * c->tilesH * NI);
+    c->rxChunks = (int)((npix + 2047) / 2048);
+    A(c->rxChunkCnt, (size_t)c->rxChunks * NI);
     c->arenaCap = (int)std::min<size_t>(8 * npix, (size_t)1 << 30);
     A(c->arena, (size_t)c->arenaCap * NI);
   }
@@ -414,8 +426,6 @@ pli_status allocAll(pli_ctx* c) {
   c->maxSeg = (int)(npix / std::max(P.minRegSize, 1)) + 64;   // a region needs minRegSize pixels: no image can yield more segments
   A(c->seg, (size_t)NI * c->maxSeg * 4);
   A(c->nSeg, NI);
-  A(c->segRaw, (size_t)NI * c->maxSeg);
-  A(c->segRank, (size_t)NI * c->maxSeg);
   A(c->tmpKL, (size_t)NI * P.maxLines);
   A(c->dx, (size_t)P.W * P.H * NI);
   A(c->dy, (size_t)P.W * P.H * NI);
@@ -480,6 +490,16 @@ pli_status runOrb(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   return PLI_OK;
 }
 
+// LAUNCH plus, under PLI_RX_TRACE, a sync and a line on stderr (finds a kernel that does not return)
+#define TRL(c, name, ...)                                                      \
+  do {                                                                         \
+    LAUNCH(c, name, __VA_ARGS__);                                              \
+    if (trace) {                                                               \
+      HIPCHK(hipStreamSynchronize((c)->stream));                               \
+      std::fprintf(stderr, "[rx] %s done\n", name);                           \
+    }                                                                          \
+  } while (0)
+
 pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   const DevParams& P = c->hp;
   const pli_table_layout& Y = c->lay;
@@ -513,43 +533,57 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     LAUNCH(c, "k_lsd_grow", k_lsd_grow, dim3(nimg), dim3(64), 0, c->dP, c->rec, c->order, c->nDefined,
            c->regScratch, c->seg, c->nSeg, c->maxSeg, img0);
   } else {
-    // rank-ordered relaxation (lsd_relax.hip): rounds until every image's owner map is a fixed point
+    const bool trace = getenv("PLI_RX_TRACE") != nullptr;
+    // incremental rank-ordered relaxation (lsd_relax.hip): rounds until every image's owner map is a fixed point
     const int64_t npix64 = (int64_t)npix;
-    const int ctlBlocks = (nimg + 63) / 64;
-    int growBlocks = std::max(1, std::min(256, (npix / 4 + 256 * 8 - 1) / (256 * 8)));
+    int growBlocks = std::max(16, std::min(256, 2048 / nimg));
     if (const char* e = getenv("PLI_JR_BLOCKS")) growBlocks = std::max(1, atoi(e));
-    int bigThresh = 48;
-    if (const char* e = getenv("PLI_JR_BIG")) bigThresh = atoi(e);
-    int bigBlocks = 128;
-    int kUse = 1;                                  // rank buckets per round (PLI_JR_K, <= JR_K)
-    if (const char* e = getenv("PLI_JR_K")) kUse = std::max(1, std::min(JR_K, atoi(e)));
+    int bigBlocks = std::max(64, std::min(1024, 16384 / nimg));
     if (const char* e = getenv("PLI_JR_BIGBLOCKS")) bigBlocks = std::max(1, atoi(e));
+    int bigThresh = RX_HAND;
+    if (const char* e = getenv("PLI_JR_BIG")) bigThresh = atoi(e);
+    int maxRounds = 96;
+    if (const char* e = getenv("PLI_RX_MAXROUNDS")) maxRounds = std::max(1, atoi(e));
+    const float precDeg = (float)(P.prec * 180.0 / 3.14159265358979323846);
+    HIPCHK(hipMemsetAsync(c->jrCtl + img0, 0, sizeof(RxCtl) * nimg, c->stream));
+    HIPCHK(hipMemsetAsync(c->rankOf + (int64_t)img0 * npix, 0x7F, sizeof(int) * npix64 * nimg, c->stream));
+    TRL(c, "k_rx_rank", k_rx_rank, dim3((npix + 255) / 256, nimg), dim3(256), 0, c->order, c->nDefined, c->rankOf, npix64, img0);
+    const dim3 raster((P.LW + 255) / 256, P.LH, nimg);
+    TRL(c, "k_rx_guess", k_rx_guess, raster, dim3(256), 0, c->rec, c->rankOf, c->own, P.LW, P.LH, precDeg, img0);
     bool allDone = false;
-    int t = 1;
-    for (; t <= 4096 && !allDone; ++t) {
-      LAUNCH(c, "k_jr_begin", k_jr_begin, dim3(ctlBlocks), dim3(64), 0, c->jrCtl, nimg, img0, t);
-      LAUNCH(c, "k_jr_prepare", k_jr_prepare, dim3(64, nimg), dim3(256), 0, c->jrCtl, c->order, c->nDefined, c->own,
-             c->rec, c->seedcs, c->lastSize, c->smallSeeds, c->bigSeeds, c->bigCap, npix64, P.LW, bigThresh, kUse, img0, t);
-      LAUNCH(c, "k_jr_decide", k_jr_decide, dim3(ctlBlocks), dim3(64), 0, c->jrCtl, nimg, img0, t);
-      for (int bkt = 0; bkt < kUse; ++bkt) {
-        LAUNCH(c, "k_jr_grow", k_jr_grow, dim3(growBlocks, nimg), dim3(256), 0, c->dP, c->jrCtl, c->rec, c->own, c->smallSeeds,
-               c->lastSize, c->arena, c->arenaCap, c->segRaw, c->segRank, c->maxSeg, img0, t, bkt, kUse);
-        if (t > 1)
-          LAUNCH(c, "k_jr_grow_big", k_jr_grow_big, dim3(bigBlocks, nimg), dim3(64), 0, c->dP, c->jrCtl, c->rec, c->own,
-                 c->bigSeeds, c->bigCap, c->lastSize, c->arena, c->arenaCap, c->segRaw, c->segRank, c->maxSeg, img0, t, bkt,
-                 c->debug ? (int*)c->regScratch : (int*)nullptr, getenv("PLI_DBG_RANK") ? atoi(getenv("PLI_DBG_RANK")) : -1);
+    for (int t = 1; t <= maxRounds && !allDone; ++t) {
+      TRL(c, "k_rx_diff", k_rx_diff, dim3((P.LW + 31) / 32, c->tilesH, nimg), dim3(256), 0, c->jrCtl, c->own, c->tileMin,
+             P.LW, P.LH, c->tilesW, c->tilesH, img0);
+      if (t >= 2)
+        TRL(c, "k_rx_classify", k_rx_classify, raster, dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->rgBox, c->rgClean,
+               c->tileMin, P.LW, P.LH, c->tilesW, c->tilesH, t, img0);
+      TRL(c, "k_rx_seed", k_rx_seed, raster, dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->rec, c->seedcs, c->lastSize,
+             c->rgClean, c->smallSeeds, c->bigSeeds, c->bigCap, P.LW, P.LH, bigThresh, t, img0);
+      TRL(c, "k_rx_grow", k_rx_grow, dim3(growBlocks, nimg), dim3(256), 0, c->dP, c->jrCtl, c->rec, c->own, c->smallSeeds,
+             c->lastSize, c->rgBox, c->rgSeg, c->hand, c->handCap, img0, t);
+      TRL(c, "k_rx_grow_big", k_rx_grow_big, dim3(bigBlocks, nimg), dim3(64), 0, c->dP, c->jrCtl, c->rec, c->own, c->bigSeeds,
+             c->bigCap, c->hand, c->handCap, c->lastSize, c->rgBox, c->rgSeg, c->arena, c->arenaCap, img0, t);
+      if (trace) {
+        HIPCHK(hipMemcpyAsync(c->jrHost.data(), c->jrCtl + img0, sizeof(RxCtl) * nimg, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        const RxCtl& h = c->jrHost[0];
+        std::fprintf(stderr, "[rx] t=%d state=%d changed=%d overflow=%d small=%d big=%d hand=%d next=%d nextBig=%d pad=%d %d %d %d\n", t, h.state,
+                     h.changed, h.overflow, h.nSmall, h.nBig, h.nHand, h.next, h.nextBig, h.pad[0], h.pad[1], h.pad[2], h.pad[3]);
       }
-      if (t >= 8 && (t % 4) == 0) {
-        HIPCHK(hipMemcpyAsync(c->jrHost.data(), c->jrCtl + img0, sizeof(JrCtl) * nimg, hipMemcpyDeviceToHost, c->stream));
+      if ((t >= 10 && (t % 2) == 0) || t == maxRounds) {
+        HIPCHK(hipMemcpyAsync(c->jrHost.data(), c->jrCtl + img0, sizeof(RxCtl) * nimg, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         allDone = true;
-        for (int i = 0; i < nimg; ++i) allDone = allDone && (c->jrHost[i].state >= 1 || c->jrHost[i].overflow);
+        for (int i = 0; i < nimg; ++i) allDone = allDone && (c->jrHost[i].state == 2 || c->jrHost[i].overflow);
       }
     }
-    LAUNCH(c, "k_jr_sort", k_jr_sort, dim3((c->maxSeg + 255) / 256, nimg), dim3(256), 0, c->jrCtl, c->segRaw, c->segRank, c->maxSeg, c->seg, c->nSeg, img0);
-    // images whose queue arena overflowed (or that did not settle) take the sequential grower
+    TRL(c, "k_rx_count", k_rx_count, dim3(c->rxChunks, nimg), dim3(256), 0, c->jrCtl, c->order, c->nDefined, c->own, c->lastSize,
+           c->rxChunkCnt, c->rxChunks, npix64, P.minRegSize, img0);
+    TRL(c, "k_rx_emit", k_rx_emit, dim3(c->rxChunks, nimg), dim3(256), 0, c->jrCtl, c->order, c->nDefined, c->own, c->lastSize,
+           c->rgSeg, c->rxChunkCnt, c->rxChunks, npix64, P.minRegSize, c->seg, c->nSeg, c->maxSeg, img0);
+    // images that ran out of a capacity (or did not settle) take the sequential grower
     for (int i = 0; i < nimg; ++i) {
-      if (c->jrHost[i].overflow || c->jrHost[i].state < 1) {
+      if (c->jrHost[i].overflow || c->jrHost[i].state != 2) {
         LAUNCH(c, "k_lsd_grow", k_lsd_grow, dim3(1), dim3(64), 0, c->dP, c->rec, c->order, c->nDefined,
                c->regScratch, c->seg, c->nSeg, c->maxSeg, img0 + i);
       }
@@ -1144,7 +1178,7 @@ pli_status pli_debug_fetch(pli_ctx* c, int32_t image, int32_t what, int32_t arg,
     case PLI_DBG_LSD_OWNER: {
       const int64_t np = (int64_t)P.LW * P.LH;
       if (!need(4 + np * 4)) return dst ? PLI_ERR_CAPACITY : PLI_OK;
-      JrCtl ctl;
+      RxCtl ctl;
       HIPCHK(hipMemcpy(&ctl, c->jrCtl + image, sizeof(ctl), hipMemcpyDeviceToHost));
       std::vector<int2> own(np);
       HIPCHK(hipMemcpy(own.data(), c->own + image * np, np * 8, hipMemcpyDeviceToHost));
