@@ -70,7 +70,8 @@ struct RxCtl {
   int rounds;      // round in which the fixed point was detected
   int nSmall, nBig, nHand;   // work lists of this round: lane grower, wave grower, regions handed from lane to wave
   int next, nextBig;         // their work counters
-  int pad[6];
+  int nRect;                 // regions completed in this round that need region2rect
+  int pad[5];
 };
 
 // an alive seed, ready to grow (written by k_rx_seed)
@@ -81,6 +82,12 @@ struct RxSeed {
 
 constexpr int RX_QCAP = 32;            // queue entries a lane keeps in LDS
 constexpr int RX_HAND = RX_QCAP - 8;   // a lane hands its region to the wave grower at this size (step boundary)
+
+// a completed region of at least minRegSize pixels: its pixel list (arena) goes to k_rx_rect
+struct RxRect {
+  int rank, off, cnt;
+  float sumdx, sumdy;
+};
 
 // a region in mid-growth, handed from the lane grower to the wave grower
 struct RxHand {

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k_rx_diff(RxCtl* __restrict__ ctl, const 
   RxCtl& c = ctl[img];
   if (c.state == 2) return;
   const int tid = threadIdx.x;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { c.nSmall = 0; c.nBig = 0; c.nHand = 0; c.next = 0; c.nextBig = 0; c.arenaHead = 0; }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { c.nSmall = 0; c.nBig = 0; c.nHand = 0; c.nRect = 0; c.next = 0; c.nextBig = 0; c.arenaHead = 0; }
   if (tid < 4) tmin[tid] = INT_MAX;
   __syncthreads();
   const int x = blockIdx.x * 32 + (tid & 31), y = blockIdx.y * 8 + (tid >> 5);
@@ -216,8 +216,9 @@ __global__ __launch_bounds__(256) void k_rx_seed(RxCtl* __restrict__ ctl, int2* 
 __global__ __launch_bounds__(256) void k_rx_grow(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
                                                  const float4* __restrict__ recAll, int2* __restrict__ ownAll,
                                                  const RxSeed* __restrict__ smallAll, int* __restrict__ rgSizeAll,
-                                                 int2* __restrict__ rgBoxAll, float4* __restrict__ rgSegAll,
-                                                 RxHand* __restrict__ handAll, int handCap, int img0, int t) {
+                                                 int2* __restrict__ rgBoxAll, RxHand* __restrict__ handAll, int handCap,
+                                                 int* __restrict__ arenaAll, int arenaCap, RxRect* __restrict__ rectAll,
+                                                 int rectCap, int img0, int t) {
   __shared__ int mq[RX_QCAP * 256];
   const DevParams& P = *Pp;
   const int img = blockIdx.y + img0;
@@ -232,8 +233,9 @@ __global__ __launch_bounds__(256) void k_rx_grow(const DevParams* __restrict__ P
   const RxSeed* seeds = smallAll + img * npix;
   int* rgSize = rgSizeAll + img * npix;
   int2* rgBox = rgBoxAll + img * npix;
-  float4* rgSeg = rgSegAll + img * npix;
   RxHand* hand = handAll + (int64_t)img * handCap;
+  int* arena = arenaAll + (int64_t)img * arenaCap;
+  RxRect* rects = rectAll + (int64_t)img * rectCap;
   const int tid = threadIdx.x, lane = tid & 63;
   const int ci = t & 1;                              // owner_t lives in component ci, owner_{t-1} in the other
   const double prec = P.prec;
@@ -328,79 +330,45 @@ __global__ __launch_bounds__(256) void k_rx_grow(const DevParams* __restrict__ P
       rgSize[r] = cnt;
       rgBox[r] = make_int2((by0 << 16) | bx0, (by1 << 16) | bx1);
       if (cnt < minReg) continue;
-      // region2rect, sums in list order (lsd.cpp region2rect / get_theta)
-      double x = 0, y = 0, sum = 0;
-      for (int i = 0; i < cnt; ++i) {
-        const int e = mq[i * 256 + tid];
-        const int ex = e & 0xFFFF, ey = e >> 16;
-        const double w = sqrt((double)__float_as_int(rec[ey * W + ex].w) / 4.0);
-        x += (double)ex * w;
-        y += (double)ey * w;
-        sum += w;
-      }
-      x /= sum;
-      y /= sum;
-      double Ixx = 0.0, Iyy = 0.0, Ixy = 0.0;
-      for (int i = 0; i < cnt; ++i) {
-        const int e = mq[i * 256 + tid];
-        const int ex = e & 0xFFFF, ey = e >> 16;
-        const double w = sqrt((double)__float_as_int(rec[ey * W + ex].w) / 4.0);
-        const double dx = (double)ex - x, dy = (double)ey - y;
-        Ixx += dy * dy * w;
-        Iyy += dx * dx * w;
-        Ixy -= dx * dy * w;
-      }
-      const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
-      double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)fast_atan2_deg((float)(lambda - Ixx), (float)Ixy)
-                                             : (double)fast_atan2_deg((float)Ixy, (float)(lambda - Iyy));
-      theta *= RX_DEG2RAD;
-      if (rx_angle_diff(theta, reg_angle) > prec) theta += RX_PI;
-      const double dxr = cos(theta), dyr = sin(theta);
-      double l_min = 0, l_max = 0;
-      for (int i = 0; i < cnt; ++i) {
-        const int e = mq[i * 256 + tid];
-        const double l = ((double)(e & 0xFFFF) - x) * dxr + ((double)(e >> 16) - y) * dyr;
-        if (l > l_max) l_max = l;
-        else if (l < l_min) l_min = l;
-      }
-      double x1 = x + l_min * dxr, y1 = y + l_min * dyr, x2 = x + l_max * dxr, y2 = y + l_max * dyr;
-      x1 += 0.5; y1 += 0.5; x2 += 0.5; y2 += 0.5;
-      const double scale = P.lsdScale;
-      if (scale != 1) { x1 /= scale; y1 /= scale; x2 /= scale; y2 /= scale; }
-      rgSeg[r] = make_float4((float)x1, (float)y1, (float)x2, (float)y2);
+      // the pixel list goes to k_rx_rect (region2rect)
+      const int off = atomicAdd(&c.arenaHead, cnt);
+      const int slot = atomicAdd(&c.nRect, 1);
+      if (off + cnt > arenaCap || slot >= rectCap) { c.overflow = 1; continue; }
+      for (int i = 0; i < cnt; ++i) arena[off + i] = mq[i * 256 + tid];
+      RxRect& it = rects[slot];
+      it.rank = r; it.off = off; it.cnt = cnt; it.sumdx = sumdx; it.sumdy = sumdy;
     }
   }
 }
 
-// ---- wave-per-region grower ------------------------------------------------------------------------
-// Lanes 0..8 fetch the 3x3 neighbourhood of the current queue entry (record + owner pair) in one round
-// trip; ballots over "available & aligned" reproduce the raster-order accept loop; the queue lives in
-// LDS (first RX_BQ entries) and in arena blocks beyond.  Work items: the seeds listed as large, then the
-// regions handed over by the lane grower in this round.
-constexpr int RX_BQ = 2048;
-constexpr int RX_BBLK = 2048;     // arena block for the overflow of a big region's queue
-constexpr int RX_BMAXBLK = 64;
-
-__device__ __forceinline__ int rx_rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
-__device__ __forceinline__ float rx_rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+// ---- group-per-region grower ------------------------------------------------------------------------
+// A wave carries four regions, one per group of 16 lanes (the issue slots of a wave are the scarce
+// resource here, and a BFS step only has 8 neighbours to look at).  Lanes 0..8 of a group fetch the 3x3
+// neighbourhood of the group's current queue entry (record + owner pair) in one round trip; ballots over
+// "available & aligned", shifted to the group, reproduce the raster-order accept loop.  The queue of a
+// group lives in LDS (first RX_GQ entries) and in arena blocks beyond.  Work items: the seeds listed as
+// large, then the regions handed over by the lane grower in this round.  Everything that is uniform per
+// group (r, cnt, k, sums, angle) is replicated in the group's lanes.
+constexpr int RX_GQ = 512;        // LDS queue entries per group
+constexpr int RX_BBLK = 2048;     // arena block for the overflow of a large region's queue
+constexpr int RX_BMAXBLK = 32;
 
 __global__ __launch_bounds__(64) void k_rx_grow_big(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
                                                     const float4* __restrict__ recAll, int2* __restrict__ ownAll,
                                                     const RxSeed* __restrict__ bigAll, int bigCap,
                                                     const RxHand* __restrict__ handAll, int handCap,
                                                     int* __restrict__ rgSizeAll, int2* __restrict__ rgBoxAll,
-                                                    float4* __restrict__ rgSegAll, int* __restrict__ arenaAll,
-                                                    int arenaCap, int img0, int t) {
-  __shared__ int qs[RX_BQ];
-  __shared__ int blk[RX_BMAXBLK];
-  __shared__ double st[3][64];
+                                                    int* __restrict__ arenaAll, int arenaCap,
+                                                    RxRect* __restrict__ rectAll, int rectCap, int img0, int t) {
+  __shared__ int qs[4][RX_GQ];
+  __shared__ int blk[4][RX_BMAXBLK];
   const DevParams& P = *Pp;
   const int img = blockIdx.y + img0;
   RxCtl& c = ctl[img];
   if (c.state == 2 || c.overflow) return;
   const int nbig = min(c.nBig, bigCap);
   const int nitems = nbig + min(c.nHand, handCap);
-  if ((int)blockIdx.x >= nitems) return;
+  if ((int)blockIdx.x * 4 >= nitems) return;
   const int W = P.LW, H = P.LH;
   const int64_t npix = (int64_t)W * H;
   const float4* rec = recAll + img * npix;
@@ -409,135 +377,174 @@ __global__ __launch_bounds__(64) void k_rx_grow_big(const DevParams* __restrict_
   const RxHand* hand = handAll + (int64_t)img * handCap;
   int* rgSize = rgSizeAll + img * npix;
   int2* rgBox = rgBoxAll + img * npix;
-  float4* rgSeg = rgSegAll + img * npix;
   int* arena = arenaAll + (int64_t)img * arenaCap;
-  const int lane = threadIdx.x;
+  RxRect* rects = rectAll + (int64_t)img * rectCap;
+  const int lane = threadIdx.x, g = lane >> 4, gl = lane & 15, gbase = lane & 48;
   const int ci = t & 1;
   const double prec = P.prec;
   const int minReg = P.minRegSize;
-  const int ndx = lane % 3 - 1, ndy = (lane / 3) % 3 - 1;
+  const int ndx = gl % 3 - 1, ndy = gl / 3 - 1;
+  int* q = qs[g];
+  int* gb = blk[g];
 
   auto qget = [&](int k) -> int {
-    if (k < RX_BQ) return qs[k];
-    const int o = k - RX_BQ;
-    return arena[blk[o / RX_BBLK] + o % RX_BBLK];
+    if (k < RX_GQ) return q[k];
+    const int o = k - RX_GQ;
+    return arena[gb[o / RX_BBLK] + o % RX_BBLK];
   };
 
+  bool active = false, exhausted = false;
+  int r = 0, cnt = 0, k = 0, bx0 = 0, by0 = 0, bx1 = 0, by1 = 0;
+  float sumdx = 0.f, sumdy = 0.f;
+  double reg_angle = 0.0;
   for (;;) {
-    int wi = 0;
-    {   // first ACTIVE lane: lane 0 is not guaranteed to be in the exec mask at the top of this loop (it was not)
-      const int leader = __ffsll((long long)__ballot(true)) - 1;
-      if (lane == leader) wi = atomicAdd(&c.nextBig, 1);
-      wi = __builtin_amdgcn_readlane(wi, leader);
-    }
-    if (wi >= nitems) break;
-    int r, cnt, k0, bx0, by0, bx1, by1;
-    float sumdx, sumdy;
-    double reg_angle;
-    __syncthreads();                                // the previous item's queue is dead
-    if (wi < nbig) {
-      const RxSeed sd = seeds[wi];
-      r = sd.rank;
-      reg_angle = (double)sd.ang * RX_DEG2RAD;
-      sumdx = sd.sx; sumdy = sd.sy;
-      qs[0] = sd.xy;                                // every lane stores the same value
-      cnt = 1; k0 = 0;
-      bx0 = bx1 = sd.xy & 0xFFFF; by0 = by1 = sd.xy >> 16;
-    } else {
-      const RxHand& hd = hand[wi - nbig];
-      r = hd.rank; cnt = hd.cnt; k0 = hd.k;
-      sumdx = hd.sumdx; sumdy = hd.sumdy;
-      reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * RX_DEG2RAD;   // cnt >= 2: the angle is a function of the sums
-      bx0 = hd.box0 & 0xFFFF; by0 = hd.box0 >> 16; bx1 = hd.box1 & 0xFFFF; by1 = hd.box1 >> 16;
-      if (lane < cnt) qs[lane] = hd.q[lane];        // cnt <= RX_QCAP <= 64
-    }
-    r = __builtin_amdgcn_readfirstlane(r);
-    cnt = __builtin_amdgcn_readfirstlane(cnt);
-    k0 = __builtin_amdgcn_readfirstlane(k0);
-    bool dead = false;
-    for (int k = k0; k < cnt && !dead; ++k) {
-      __syncthreads();                              // single-wave block: orders the queue writes before the reads
-      int e;
-      if (k < RX_BQ) e = qs[k];                     // plain ds_read (never a flat access)
+    // ---- groups without a region take the next item ---------------------------------------------
+    if (!active && !exhausted) {
+      int wi = 0;
+      if (gl == 0) wi = atomicAdd(&c.nextBig, 1);
+      wi = __shfl(wi, gbase, 64);
+      if (wi >= nitems) exhausted = true;
       else {
-        const int o = k - RX_BQ;
-        e = arena[blk[o / RX_BBLK] + o % RX_BBLK];
+        active = true;
+        if (wi < nbig) {
+          const RxSeed sd = seeds[wi];
+          r = sd.rank;
+          reg_angle = (double)sd.ang * RX_DEG2RAD;
+          sumdx = sd.sx; sumdy = sd.sy;
+          q[0] = sd.xy;                               // every lane of the group stores the same value
+          cnt = 1; k = 0;
+          bx0 = bx1 = sd.xy & 0xFFFF; by0 = by1 = sd.xy >> 16;
+        } else {
+          const RxHand& hd = hand[wi - nbig];
+          r = hd.rank; cnt = hd.cnt; k = hd.k;
+          sumdx = hd.sumdx; sumdy = hd.sumdy;
+          reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * RX_DEG2RAD;   // cnt >= 2: the angle is a function of the sums
+          bx0 = hd.box0 & 0xFFFF; by0 = hd.box0 >> 16; bx1 = hd.box1 & 0xFFFF; by1 = hd.box1 >> 16;
+          for (int i = gl; i < cnt; i += 16) q[i] = hd.q[i];
+        }
       }
-      e = __builtin_amdgcn_readfirstlane(e);
-      const int px = e & 0xFFFF, py = e >> 16;
+    }
+    if (!__ballot(active)) break;
+    __syncthreads();                                  // single-wave block: queue writes before the reads below
+    // ---- one BFS step of every active group -------------------------------------------------------
+    int px = 0, py = 0, qi = 0;
+    float4 rr = make_float4(RX_NOTDEF, 0.f, 0.f, 0.f);
+    int2 oo = make_int2(0, 0);
+    if (active) {
+      const int e = qget(k);
+      px = e & 0xFFFF; py = e >> 16;
       const int nx = px + ndx, ny = py + ndy;
-      const bool inb = lane < 9 && lane != 4 && nx >= 0 && ny >= 0 && nx < W && ny < H;
-      const int qi = inb ? ny * W + nx : 0;
-      float4 rr = make_float4(RX_NOTDEF, 0.f, 0.f, 0.f);
-      int2 oo = make_int2(0, 0);
+      const bool inb = gl < 9 && gl != 4 && nx >= 0 && ny >= 0 && nx < W && ny < H;
       if (inb) {
+        qi = ny * W + nx;
         rr = rec[qi];
         oo = rx_load_own(&own[qi]);
       }
-      const int prevv = ci ? oo.x : oo.y, curv = ci ? oo.y : oo.x;
-      const bool cand = rr.x != RX_NOTDEF && !(prevv < r || curv <= r);
-      const double ad = (double)rr.x * RX_DEG2RAD;
-      unsigned long long remaining = __ballot(cand);
-      while (remaining) {
-        double n_theta = reg_angle - ad;
+    }
+    const int prevv = ci ? oo.x : oo.y, curv = ci ? oo.y : oo.x;
+    const bool cand = active && rr.x != RX_NOTDEF && !(prevv < r || curv <= r);
+    const double ad = (double)rr.x * RX_DEG2RAD;
+    int rem = (int)((__ballot(cand) >> gbase) & 0x1FFull);      // the group's candidates, raster order
+    bool dead = false;
+    while (__ballot(rem != 0)) {
+      double n_theta = reg_angle - ad;
+      if (n_theta < 0) n_theta = -n_theta;
+      if (n_theta > RX_3_2_PI) {
+        n_theta -= RX_2PI;
         if (n_theta < 0) n_theta = -n_theta;
-        if (n_theta > RX_3_2_PI) {
-          n_theta -= RX_2PI;
-          if (n_theta < 0) n_theta = -n_theta;
+      }
+      const int m = (int)((__ballot(cand && n_theta <= prec) >> gbase) & 0x1FFull) & rem;
+      if (!m) { rem = 0; continue; }
+      const int j2 = __ffs(m) - 1;
+      rem &= ~((2 << j2) - 1);
+      const float cj = __shfl(rr.y, gbase + j2, 64), sj = __shfl(rr.z, gbase + j2, 64);
+      const int ax = px + j2 % 3 - 1, ay = py + j2 / 3 - 1;
+      int old = 0;
+      if (gl == j2) old = __hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      old = __shfl(old, gbase + j2, 64);             // waits for the claim: later owner loads see it
+      if (old <= r) continue;                        // a lower rank took the pixel first in this round
+      const int xyj = (ay << 16) | ax;
+      if (cnt < RX_GQ) {
+        q[cnt] = xyj;                                // every lane of the group stores the same value
+      } else {
+        const int o = cnt - RX_GQ;
+        if (o % RX_BBLK == 0) {
+          int nb = 0;
+          if (o / RX_BBLK >= RX_BMAXBLK) { dead = true; rem = 0; continue; }
+          if (gl == 0) nb = atomicAdd(&c.arenaHead, RX_BBLK);
+          nb = __shfl(nb, gbase, 64);
+          if (nb + RX_BBLK > arenaCap) { dead = true; rem = 0; continue; }
+          gb[o / RX_BBLK] = nb;
         }
-        const unsigned long long m = __ballot(cand && n_theta <= prec) & remaining;
-        if (!m) break;
-        const int j2 = __ffsll((long long)m) - 1;
-        remaining &= ~((2ull << j2) - 1ull);
-        const float cj = rx_rl_f(rr.y, j2), sj = rx_rl_f(rr.z, j2);
-        const int ax = px + j2 % 3 - 1, ay = py + j2 / 3 - 1;
-        const int xyj = (ay << 16) | ax;
-        int old = 0;
-        if (lane == j2) old = __hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        old = rx_rl_i(old, j2);                     // waits for the claim: later owner loads see it
-        if (old <= r) continue;                     // a lower rank took the pixel first in this round
-        if (cnt < RX_BQ) {
-          qs[cnt] = xyj;                            // every lane stores the same value: no dependence on lane 0
-        } else {
-          const int o = cnt - RX_BQ;
-          // NOTE: inside these wave-uniform loops a given lane (e.g. lane 0) is not guaranteed to be in the
-          // exec mask, so single-lane work is done by the first ACTIVE lane and results are broadcast from it.
-          const int leader = __ffsll((long long)__ballot(true)) - 1;
-          if (o % RX_BBLK == 0) {
-            int nb = 0;
-            if (o / RX_BBLK >= RX_BMAXBLK) { dead = true; break; }
-            if (lane == leader) nb = atomicAdd(&c.arenaHead, RX_BBLK);
-            nb = __builtin_amdgcn_readlane(nb, leader);
-            if (nb + RX_BBLK > arenaCap) { dead = true; break; }
-            blk[o / RX_BBLK] = nb;
-            __syncthreads();
+        if (gl == 0) arena[gb[o / RX_BBLK] + o % RX_BBLK] = xyj;
+        __threadfence_block();
+      }
+      ++cnt;
+      bx0 = min(bx0, ax); bx1 = max(bx1, ax); by0 = min(by0, ay); by1 = max(by1, ay);
+      sumdx = __fadd_rn(sumdx, cj);
+      sumdy = __fadd_rn(sumdy, sj);
+      reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * RX_DEG2RAD;
+    }
+    if (active) {
+      ++k;
+      if (dead) { c.overflow = 1; active = false; exhausted = true; }
+      else if (k >= cnt) {
+        // ---- the region is complete ---------------------------------------------------------------
+        active = false;
+        if (gl == 0) {
+          rgSize[r] = cnt;
+          rgBox[r] = make_int2((by0 << 16) | bx0, (by1 << 16) | bx1);
+        }
+        if (cnt >= minReg) {                          // the pixel list goes to k_rx_rect (region2rect)
+          int off = 0, slot = 0;
+          if (gl == 0) { off = atomicAdd(&c.arenaHead, cnt); slot = atomicAdd(&c.nRect, 1); }
+          off = __shfl(off, gbase, 64); slot = __shfl(slot, gbase, 64);
+          if (off + cnt > arenaCap || slot >= rectCap) c.overflow = 1;
+          else {
+            for (int i = gl; i < cnt; i += 16) arena[off + i] = qget(i);
+            if (gl == 0) {
+              RxRect& it = rects[slot];
+              it.rank = r; it.off = off; it.cnt = cnt; it.sumdx = sumdx; it.sumdy = sumdy;
+            }
           }
-          if (lane == leader) arena[blk[o / RX_BBLK] + o % RX_BBLK] = xyj;
-          __threadfence_block();
         }
-        cnt = __builtin_amdgcn_readfirstlane(cnt + 1);
-        bx0 = min(bx0, ax); bx1 = max(bx1, ax); by0 = min(by0, ay); by1 = max(by1, ay);
-        sumdx = __fadd_rn(sumdx, cj);
-        sumdy = __fadd_rn(sumdy, sj);
-        reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * RX_DEG2RAD;
       }
     }
-    if (dead) {
-      if (lane == 0) c.overflow = 1;
-      break;
-    }
-    if (lane == 0) {
-      rgSize[r] = cnt;
-      rgBox[r] = make_int2((by0 << 16) | bx0, (by1 << 16) | bx1);
-    }
-    if (cnt < minReg) continue;
-    // ---- region2rect: three lanes accumulate the running sums in list order -------------------
+  }
+}
+
+// ---- region2rect of the regions completed in this round (lsd.cpp region2rect / get_theta) --------------
+// One wave per region; the running sums are accumulated in list order by three lanes (bit-exact with the
+// sequential loop), the products are computed 64 at a time.
+__global__ __launch_bounds__(64) void k_rx_rect(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
+                                                const float4* __restrict__ recAll, const int* __restrict__ arenaAll,
+                                                int arenaCap, const RxRect* __restrict__ rectAll, int rectCap,
+                                                float4* __restrict__ rgSegAll, int img0) {
+  __shared__ double st[3][64];
+  const DevParams& P = *Pp;
+  const int img = blockIdx.y + img0;
+  const RxCtl& c = ctl[img];
+  if (c.state == 2 || c.overflow) return;
+  const int nrect = min(c.nRect, rectCap);
+  const int W = P.LW;
+  const int64_t npix = (int64_t)W * P.LH;
+  const float4* rec = recAll + img * npix;
+  const int* arena = arenaAll + (int64_t)img * arenaCap;
+  const RxRect* rects = rectAll + (int64_t)img * rectCap;
+  float4* rgSeg = rgSegAll + img * npix;
+  const int lane = threadIdx.x;
+  const double prec = P.prec;
+  for (int wi = blockIdx.x; wi < nrect; wi += gridDim.x) {
+    const RxRect it = rects[wi];
+    const int cnt = it.cnt;
+    const int* lst = arena + it.off;
+    const double reg_angle = (double)fast_atan2_deg(it.sumdy, it.sumdx) * RX_DEG2RAD;
     __syncthreads();
     double acc = 0.0;
     for (int c0 = 0; c0 < cnt; c0 += 64) {
       const int kk = c0 + lane;
       if (kk < cnt) {
-        const int e = qget(kk);
+        const int e = lst[kk];
         const int ex = e & 0xFFFF, ey = e >> 16;
         const double w = sqrt((double)__float_as_int(rec[ey * W + ex].w) / 4.0);
         st[0][lane] = (double)ex * w;
@@ -557,7 +564,7 @@ __global__ __launch_bounds__(64) void k_rx_grow_big(const DevParams* __restrict_
     for (int c0 = 0; c0 < cnt; c0 += 64) {
       const int kk = c0 + lane;
       if (kk < cnt) {
-        const int e = qget(kk);
+        const int e = lst[kk];
         const int ex = e & 0xFFFF, ey = e >> 16;
         const double w = sqrt((double)__float_as_int(rec[ey * W + ex].w) / 4.0);
         const double dx = (double)ex - x, dy = (double)ey - y;
@@ -584,7 +591,7 @@ __global__ __launch_bounds__(64) void k_rx_grow_big(const DevParams* __restrict_
     const double dxr = cos(theta), dyr = sin(theta);
     double l_min = 0, l_max = 0;
     for (int kk = lane; kk < cnt; kk += 64) {
-      const int e = qget(kk);
+      const int e = lst[kk];
       const double l = ((double)(e & 0xFFFF) - x) * dxr + ((double)(e >> 16) - y) * dyr;
       l_max = fmax(l_max, l);
       l_min = fmin(l_min, l);
@@ -598,7 +605,7 @@ __global__ __launch_bounds__(64) void k_rx_grow_big(const DevParams* __restrict_
     x1 += 0.5; y1 += 0.5; x2 += 0.5; y2 += 0.5;
     const double scale = P.lsdScale;
     if (scale != 1) { x1 /= scale; y1 /= scale; x2 /= scale; y2 /= scale; }
-    if (lane == 0) rgSeg[r] = make_float4((float)x1, (float)y1, (float)x2, (float)y2);
+    if (lane == 0) rgSeg[it.rank] = make_float4((float)x1, (float)y1, (float)x2, (float)y2);
   }
 }
 

@@ -9,6 +9,8 @@
 #include <memory>
 #include <limits>
 #include <cstdlib>
+#include <set>
+#include <string>
 
 using namespace pli;
 
@@ -59,7 +61,7 @@ struct pli_ctx {
   int* lsdTab = nullptr;
   float4* rec = nullptr; int* g2 = nullptr; int* maxG2 = nullptr;
   float2* seedcs = nullptr; int2* own = nullptr; RxSeed* smallSeeds = nullptr; RxSeed* bigSeeds = nullptr; int bigCap = 0;
-  RxHand* hand = nullptr; int handCap = 0; int* rankOf = nullptr; int2* rgBox = nullptr; float4* rgSeg = nullptr; uint8_t* rgClean = nullptr;
+  RxHand* hand = nullptr; int handCap = 0; RxRect* rects = nullptr; int rectCap = 0; int* rankOf = nullptr; int2* rgBox = nullptr; float4* rgSeg = nullptr; uint8_t* rgClean = nullptr;
   int* tileMin = nullptr; int tilesW = 0, tilesH = 0; int* rxChunkCnt = nullptr; int rxChunks = 0;
   int* lastSize = nullptr; int* arena = nullptr; int arenaCap = 0;
   RxCtl* jrCtl = nullptr;
@@ -401,6 +403,8 @@ pli_status allocAll(pli_ctx* c) {
     A(c->bigSeeds, (size_t)c->bigCap * NI);
     c->handCap = (int)(npix / RX_HAND + 64);
     A(c->hand, (size_t)c->handCap * NI);
+    c->rectCap = 2 * ((int)(npix / std::max(P.minRegSize, 1)) + 64);
+    A(c->rects, (size_t)c->rectCap * NI);
     A(c->lastSize, npix * NI);                            // region tables, indexed by seed rank
     A(c->rgBox, npix * NI);
     A(c->rgSeg, npix * NI);
@@ -493,7 +497,7 @@ pli_status runOrb(pli_ctx* c, int img0, int nimg, uint8_t* table) {
 // LAUNCH plus, under PLI_RX_TRACE, a sync and a line on stderr (finds a kernel that does not return)
 #define TRL(c, name, ...)                                                      \
   do {                                                                         \
-    LAUNCH(c, name, __VA_ARGS__);                                              \
+    LAUNCH(c, rxn(name), __VA_ARGS__);                                         \
     if (trace) {                                                               \
       HIPCHK(hipStreamSynchronize((c)->stream));                               \
       std::fprintf(stderr, "[rx] %s done\n", name);                           \
@@ -534,12 +538,22 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
            c->regScratch, c->seg, c->nSeg, c->maxSeg, img0);
   } else {
     const bool trace = getenv("PLI_RX_TRACE") != nullptr;
+    const bool perRound = getenv("PLI_RX_PROFROUNDS") != nullptr;    // profile names carry the round number
+    int curT = 0;
+    auto rxn = [&](const char* n) -> const char* {
+      if (!perRound) return n;
+      static std::set<std::string> pool;
+      char b[64];
+      std::snprintf(b, sizeof(b), "%s@%02d", n, curT);
+      return pool.insert(b).first->c_str();
+    };
     // incremental rank-ordered relaxation (lsd_relax.hip): rounds until every image's owner map is a fixed point
     const int64_t npix64 = (int64_t)npix;
     int growBlocks = std::max(16, std::min(256, 2048 / nimg));
     if (const char* e = getenv("PLI_JR_BLOCKS")) growBlocks = std::max(1, atoi(e));
     int bigBlocks = std::max(64, std::min(1024, 16384 / nimg));
     if (const char* e = getenv("PLI_JR_BIGBLOCKS")) bigBlocks = std::max(1, atoi(e));
+    const int rectBlocks = std::max(64, std::min(2048, 32768 / nimg));
     int bigThresh = RX_HAND;
     if (const char* e = getenv("PLI_JR_BIG")) bigThresh = atoi(e);
     int maxRounds = 96;
@@ -552,6 +566,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     TRL(c, "k_rx_guess", k_rx_guess, raster, dim3(256), 0, c->rec, c->rankOf, c->own, P.LW, P.LH, precDeg, img0);
     bool allDone = false;
     for (int t = 1; t <= maxRounds && !allDone; ++t) {
+      curT = t;
       TRL(c, "k_rx_diff", k_rx_diff, dim3((P.LW + 31) / 32, c->tilesH, nimg), dim3(256), 0, c->jrCtl, c->own, c->tileMin,
              P.LW, P.LH, c->tilesW, c->tilesH, img0);
       if (t >= 2)
@@ -560,15 +575,17 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       TRL(c, "k_rx_seed", k_rx_seed, raster, dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->rec, c->seedcs, c->lastSize,
              c->rgClean, c->smallSeeds, c->bigSeeds, c->bigCap, P.LW, P.LH, bigThresh, t, img0);
       TRL(c, "k_rx_grow", k_rx_grow, dim3(growBlocks, nimg), dim3(256), 0, c->dP, c->jrCtl, c->rec, c->own, c->smallSeeds,
-             c->lastSize, c->rgBox, c->rgSeg, c->hand, c->handCap, img0, t);
+             c->lastSize, c->rgBox, c->hand, c->handCap, c->arena, c->arenaCap, c->rects, c->rectCap, img0, t);
       TRL(c, "k_rx_grow_big", k_rx_grow_big, dim3(bigBlocks, nimg), dim3(64), 0, c->dP, c->jrCtl, c->rec, c->own, c->bigSeeds,
-             c->bigCap, c->hand, c->handCap, c->lastSize, c->rgBox, c->rgSeg, c->arena, c->arenaCap, img0, t);
+             c->bigCap, c->hand, c->handCap, c->lastSize, c->rgBox, c->arena, c->arenaCap, c->rects, c->rectCap, img0, t);
+      TRL(c, "k_rx_rect", k_rx_rect, dim3(rectBlocks, nimg), dim3(64), 0, c->dP, c->jrCtl, c->rec, c->arena, c->arenaCap, c->rects,
+          c->rectCap, c->rgSeg, img0);
       if (trace) {
         HIPCHK(hipMemcpyAsync(c->jrHost.data(), c->jrCtl + img0, sizeof(RxCtl) * nimg, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         const RxCtl& h = c->jrHost[0];
         std::fprintf(stderr, "[rx] t=%d state=%d changed=%d overflow=%d small=%d big=%d hand=%d next=%d nextBig=%d pad=%d %d %d %d\n", t, h.state,
-                     h.changed, h.overflow, h.nSmall, h.nBig, h.nHand, h.next, h.nextBig, h.pad[0], h.pad[1], h.pad[2], h.pad[3]);
+                     h.changed, h.overflow, h.nSmall, h.nBig, h.nHand, h.next, h.nextBig, h.nRect, h.pad[0], h.pad[1], h.pad[2]);
       }
       if ((t >= 10 && (t % 2) == 0) || t == maxRounds) {
         HIPCHK(hipMemcpyAsync(c->jrHost.data(), c->jrCtl + img0, sizeof(RxCtl) * nimg, hipMemcpyDeviceToHost, c->stream));
