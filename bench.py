@@ -62,7 +62,18 @@ def kernel_bytes_per_image(name, g, n_kp, n_l, W, H):
         "k_lsd_scan": 0,
         "k_lsd_scatter": 8 * Pp,
         "k_lsd_grow": 8 * Pp,                         # f32 angle + f32 modgrad read once
-        "k_lsd_ccl": 8 * Pp,
+        # relaxation mode (lsd_relax.hip), per launch; the growers touch the same angle/modgrad planes once
+        # per round in the ideal case
+        "k_rx_grow": 8 * Pp,
+        "k_rx_grow_big": 8 * Pp,
+        "k_rx_seed": 12 * Pp,                         # rank + owner pair read
+        "k_rx_classify": 12 * Pp,
+        "k_rx_diff": 8 * Pp,
+        "k_rx_guess": 8 * Pp + 8 * Pp,
+        "k_rx_rank": 8 * Pp,
+        "k_rx_rect": 0,
+        "k_rx_count": 0,
+        "k_rx_emit": 0,
         "k_keylines": 100 * n_l,
         "k_blur_lbd": 2 * P0,
         "k_sobel": P0 + 4 * P0,
@@ -142,7 +153,7 @@ def main():
     assert F % S == 0, "--frames-per-gpu must be a multiple of --streams"
     Fs = F // S
     cfg = capi.default_config(W, H, orb_nfeatures=args.nfeatures, lsd_nfeatures=args.nlines, max_frames=Fs,
-                              lsd_mode=args.lsd_mode if args.lsd_mode else (2 if 2 * Fs >= 256 else 1))
+                              lsd_mode=args.lsd_mode if args.lsd_mode else (2 if 2 * Fs >= 768 else 1))   # = the library's auto rule
     fes = [Frontend(cfg, device=local_rank) for _ in range(S)]
     fe = fes[0]
     # synthetic stream: up to 64 distinct seeded stereo pairs per rank (seeds disjoint across ranks), cycled to F frames

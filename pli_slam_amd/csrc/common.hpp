@@ -71,7 +71,8 @@ struct RxCtl {
   int nSmall, nBig, nHand;   // work lists of this round: lane grower, wave grower, regions handed from lane to wave
   int next, nextBig;         // their work counters
   int nRect;                 // regions completed in this round that need region2rect
-  int pad[5];
+  int races;                 // regions that saw a lower rank slip between their owner load and their claim
+  int pad[4];
 };
 
 // an alive seed, ready to grow (written by k_rx_seed)

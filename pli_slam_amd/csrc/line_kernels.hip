@@ -31,8 +31,7 @@ constexpr double D_2PI = 2 * D_PI;
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ scaled, int64_t imgStride, int W, int H,
                                                   int pitch, int g2Thresh, float4* __restrict__ rec,
-                                                  int* __restrict__ g2o, float2* __restrict__ seedcs,
-                                                  int2* __restrict__ own, int* __restrict__ maxG2,
+                                                  int* __restrict__ g2o, int2* __restrict__ own, int* __restrict__ maxG2,
                                                   float* __restrict__ angDbg, int img0) {
   const int img = blockIdx.z + img0;
   const int y = blockIdx.y;
@@ -42,7 +41,6 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ sc
   if (x < W) {
     float a = LSD_NOTDEF;
     float cx = 0.f, sy = 0.f;
-    float2 scs = make_float2(0.f, 0.f);
     if (x < W - 1 && y < H - 1) {
       const uint8_t* r0 = scaled + (int64_t)img * imgStride + (int64_t)y * pitch;
       const uint8_t* r1 = r0 + pitch;
@@ -59,20 +57,12 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ sc
         sincos(af, &sn, &cn);
         cx = (float)cn;
         sy = (float)sn;
-        if (seedcs) {                 // region_grow seeds its sums with cos/sin of the unrounded angle
-          sincos(ad, &sn, &cn);
-          scs.x = (float)cn;
-          scs.y = (float)sn;
-        }
       }
     }
     const int64_t o = (int64_t)img * W * H + (int64_t)y * W + x;
     rec[o] = make_float4(a, cx, sy, __int_as_float(g2));
     g2o[o] = g2;
-    if (seedcs) {                                   // planes of the relaxation (lsd_relax.hip)
-      seedcs[o] = scs;
-      own[o] = make_int2(0x7FFFFFFF, 0x7FFFFFFF);   // undefined pixels never belong to a region
-    }
+    if (own) own[o] = make_int2(0x7FFFFFFF, 0x7FFFFFFF);   // owner planes of the relaxation (lsd_relax.hip): undefined pixels never belong to a region
     if (angDbg) angDbg[o] = a;
   }
   int m = defined ? g2 : 0;

@@ -32,8 +32,18 @@
 #include "kernels.hpp"
 #include "device_prims.hpp"
 #include <climits>
+#include <type_traits>
 
 namespace pli {
+
+// dev aid: cycle counters of the group grower's step phases (make EXTRA=-DRX_TIMING), reported in RxCtl::pad
+#ifdef RX_TIMING
+#define RX_T(x) const long long x = clock64();
+#define RX_ACC() { tA += t1 - t0; tB += t2 - t1; tC += t3 - t2; tD += t4 - t3; ++nSteps; }
+#else
+#define RX_T(x)
+#define RX_ACC()
+#endif
 
 constexpr float RX_NOTDEF = -1024.f;
 constexpr int RX_INF = 0x7F7F7F7F;          // rank plane of undefined pixels (hipMemset 0x7F)
@@ -49,11 +59,37 @@ __device__ __forceinline__ int2 rx_load_own(const int2* p) {
   return make_int2((int)(v & 0xFFFFFFFFull), (int)(v >> 32));
 }
 
+// LDS read that stays a ds_read: left to itself the compiler merges "queue entry from LDS or from the arena" into
+// a pointer select and one flat load, and the wait of a flat load also covers the global claims in flight
+__device__ __forceinline__ int rx_lds_read(const int* p) {
+  typedef __attribute__((address_space(3))) const volatile int lds_cvint;
+  return *(lds_cvint*)p;
+}
+
 __device__ __forceinline__ double rx_angle_diff(double a, double b) {
   double diff = a - b;
   while (diff <= -RX_PI) diff += RX_2PI;
   while (diff > RX_PI) diff -= RX_2PI;
   return fabs(diff);
+}
+
+// Block-wide stream compaction: position of this thread's element in a list whose counter gets ONE atomic per
+// block (same-address returning atomics serialise at their L2 channel, ~150 ns each).  lds: 17 ints, up to 1024 threads.
+__device__ __forceinline__ int rx_block_append(bool flag, int* counter, int* lds) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
+  const unsigned long long bal = __ballot(flag);
+  if (lane == 0) lds[wv] = __popcll(bal);
+  __syncthreads();
+  if (tid == 0) {
+    int tot = 0;
+    for (int w = 0; w < nw; ++w) tot += lds[w];
+    lds[16] = tot ? atomicAdd(counter, tot) : 0;
+  }
+  __syncthreads();
+  int pos = lds[16] + __popcll(bal & ((1ull << lane) - 1ull));
+  for (int w = 0; w < wv; ++w) pos += lds[w];
+  __syncthreads();
+  return pos;
 }
 
 // ---- setup -------------------------------------------------------------------------------------
@@ -117,7 +153,8 @@ __global__ __launch_bounds__(256) void k_rx_diff(RxCtl* __restrict__ ctl, const 
   if (any && tid == 0) atomicOr(&c.changed, 1);
 }
 
-// fixed point test, and which alive regions would repeat their last run exactly
+// fixed point test, and which alive regions would repeat their last run exactly: those get this round's stamp
+// in rgClean (everything else keeps an older stamp)
 __global__ __launch_bounds__(256) void k_rx_classify(RxCtl* __restrict__ ctl, const int2* __restrict__ ownAll,
                                                      const int* __restrict__ rankAll, const int2* __restrict__ rgBoxAll,
                                                      uint8_t* __restrict__ rgCleanAll, const int* __restrict__ tileMinAll,
@@ -133,41 +170,41 @@ __global__ __launch_bounds__(256) void k_rx_classify(RxCtl* __restrict__ ctl, co
   if (x >= W) return;
   const int64_t base = (int64_t)img * W * H;
   const int p = y * W + x;
-  const int r = rankAll[base + p];
-  if (r == RX_INF) return;
   const int2 o = ownAll[base + p];
-  bool clean = false;
-  if (o.x == r && o.y == r) {                        // alive in both maps: grown (or carried) in round t-1
-    const int2 b = rgBoxAll[base + r];
-    const int tx0 = max((b.x & 0xFFFF) - 1, 0) >> 3, ty0 = max((b.x >> 16) - 1, 0) >> 3;
-    const int tx1 = min((b.y & 0xFFFF) + 1, W - 1) >> 3, ty1 = min((b.y >> 16) + 1, H - 1) >> 3;
-    const int* tm = tileMinAll + (int64_t)img * TW * TH;
-    clean = true;
-    for (int ty = ty0; ty <= ty1 && clean; ++ty)
-      for (int tx = tx0; tx <= tx1; ++tx)
-        if (tm[ty * TW + tx] < r) { clean = false; break; }
-  }
-  rgCleanAll[base + r] = clean ? 1 : 0;
+  if (o.x != o.y) return;
+  const int r = rankAll[base + p];
+  if (o.x != r) return;                              // (undefined pixels: INT_MAX != RX_INF)
+  // alive in both maps: grown (or carried) in round t-1
+  const int2 b = rgBoxAll[base + r];
+  const int tx0 = max((b.x & 0xFFFF) - 1, 0) >> 3, ty0 = max((b.x >> 16) - 1, 0) >> 3;
+  const int tx1 = min((b.y & 0xFFFF) + 1, W - 1) >> 3, ty1 = min((b.y >> 16) + 1, H - 1) >> 3;
+  const int* tm = tileMinAll + (int64_t)img * TW * TH;
+  bool clean = true;
+  for (int ty = ty0; ty <= ty1 && clean; ++ty)
+    for (int tx = tx0; tx <= tx1; ++tx)
+      if (tm[ty * TW + tx] < r) { clean = false; break; }
+  if (clean) rgCleanAll[base + r] = (uint8_t)t;
 }
 
 // owner_t starts as "carried regions keep their pixels, everything else falls back to its own rank";
 // the alive seeds that have to be regrown are listed as ready-to-run records
-__global__ __launch_bounds__(256) void k_rx_seed(RxCtl* __restrict__ ctl, int2* __restrict__ ownAll,
+__global__ __launch_bounds__(1024) void k_rx_seed(RxCtl* __restrict__ ctl, int2* __restrict__ ownAll,
                                                  const int* __restrict__ rankAll, const float4* __restrict__ recAll,
-                                                 const float2* __restrict__ seedAll, const int* __restrict__ rgSizeAll,
+                                                 const int* __restrict__ rgSizeAll,
                                                  const uint8_t* __restrict__ rgCleanAll, RxSeed* __restrict__ smallAll,
                                                  RxSeed* __restrict__ bigAll, int bigCap, int W, int H, int bigThresh,
                                                  int t, int img0) {
+  __shared__ int scan[17];
   const int img = blockIdx.z + img0;
   RxCtl& c = ctl[img];
   if (c.state == 2) return;
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) c.changed = 0;
-  const int y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
-  const int lane = threadIdx.x & 63;
+  const int y = blockIdx.y, x = blockIdx.x * 1024 + threadIdx.x;
   const int64_t npix = (int64_t)W * H;
   const int64_t base = (int64_t)img * npix;
   const int p = y * W + x;
   const int ci = t & 1;
+  const uint8_t stamp = (uint8_t)t;
   bool alive = false, big = false;
   RxSeed sd;
   if (x < W) {
@@ -175,35 +212,30 @@ __global__ __launch_bounds__(256) void k_rx_seed(RxCtl* __restrict__ ctl, int2* 
     if (r != RX_INF) {
       int2 o = ownAll[base + p];
       const int prevv = ci ? o.x : o.y;
-      const bool carried = t >= 2 && rgCleanAll[base + prevv] != 0;
+      const bool carried = t >= 2 && rgCleanAll[base + prevv] == stamp;
       const int cur = carried ? prevv : r;
-      if (ci) o.y = cur; else o.x = cur;
-      ownAll[base + p] = o;
+      if (cur != (ci ? o.y : o.x)) {
+        if (ci) o.y = cur; else o.x = cur;
+        ownAll[base + p] = o;
+      }
       alive = prevv == r && !carried;
       if (alive) {
         big = t >= 2 && rgSizeAll[base + r] >= bigThresh;
-        const float4 rr = recAll[base + p];
-        const float2 sc = seedAll[base + p];
-        sd.rank = r; sd.xy = (y << 16) | x; sd.ang = rr.x; sd.sx = sc.x; sd.sy = sc.y;
+        const float ang = recAll[base + p].x;
+        // region_grow seeds its sums with cos/sin of the unrounded double angle (the per-pixel c,s of rec are of
+        // the float-rounded angle)
+        double sn, cn;
+        sincos((double)ang * RX_DEG2RAD, &sn, &cn);
+        sd.rank = r; sd.xy = (y << 16) | x; sd.ang = ang; sd.sx = (float)cn; sd.sy = (float)sn;
       }
     }
   }
-  const unsigned long long balS = __ballot(alive && !big), balB = __ballot(alive && big);
-  if (balS) {
-    const int leader = __ffsll((long long)balS) - 1;
-    int b0 = 0;
-    if (lane == leader) b0 = atomicAdd(&c.nSmall, __popcll(balS));
-    b0 = __shfl(b0, leader, 64);
-    if (alive && !big) smallAll[base + b0 + __popcll(balS & ((1ull << lane) - 1ull))] = sd;
-  }
-  if (balB) {
-    const int leader = __ffsll((long long)balB) - 1;
-    int b0 = 0;
-    if (lane == leader) b0 = atomicAdd(&c.nBig, __popcll(balB));
-    b0 = __shfl(b0, leader, 64);
-    const int pos = b0 + __popcll(balB & ((1ull << lane) - 1ull));
+  const int ps = rx_block_append(alive && !big, &c.nSmall, scan);
+  if (alive && !big) smallAll[base + ps] = sd;
+  if (t >= 2) {
+    const int pb = rx_block_append(alive && big, &c.nBig, scan);
     if (alive && big) {
-      if (pos < bigCap) bigAll[(int64_t)img * bigCap + pos] = sd;
+      if (pb < bigCap) bigAll[(int64_t)img * bigCap + pb] = sd;
       else c.overflow = 1;
     }
   }
@@ -252,6 +284,11 @@ __global__ __launch_bounds__(256) void k_rx_grow(const DevParams* __restrict__ P
     bool active = base + lane < nlive;
     int r = 0, cnt = 0, k = 0;
     int bx0 = 0, by0 = 0, bx1 = 0, by1 = 0;
+    int mark0 = 1, mark1 = 1;
+    int pend[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) pend[n] = 0x7FFFFFFF;
+    bool raced = false;
     float sumdx = 0.f, sumdy = 0.f;
     double reg_angle = 0.0;
     if (active) {
@@ -285,6 +322,17 @@ __global__ __launch_bounds__(256) void k_rx_grow(const DevParams* __restrict__ P
           no[n] = rx_load_own(&own[q]);
         }
       }
+      // The claims are returning atomics whose results are only folded here, one step later: they return
+      // in issue order with the loads above, so a claim of step k-1 is performed before the loads of step
+      // k+1 are issued; the loads of step k may still miss it, hence the look at the last two steps' queue
+      // entries below.  A lower rank that slipped in between our load and our claim is ignored: such a
+      // region is not final in this round anyway (the lowest non-final region never sees that race,
+      // because the pixels of final lower ranks are already theirs in owner_{t-1}).
+#pragma unroll
+      for (int n = 0; n < 8; ++n) { raced = raced || pend[n] <= r; pend[n] = 0x7FFFFFFF; }
+      const int recent0 = mark1;                        // queue entries [recent0, cnt) were claimed in the last two steps
+      mark1 = mark0;
+      mark0 = cnt;
 #pragma unroll
       for (int n = 0; n < 8; ++n) {
         if (nr[n].x == RX_NOTDEF) continue;
@@ -300,12 +348,13 @@ __global__ __launch_bounds__(256) void k_rx_grow(const DevParams* __restrict__ P
         if (!(n_theta <= prec)) continue;
         const int m = n < 4 ? n : n + 1;
         const int nx = px + m % 3 - 1, ny = py + m / 3 - 1;
+        const int e = (ny << 16) | nx;
+        bool mine = false;
+        for (int i = recent0; i < cnt; ++i) mine = mine || mq[i * 256 + tid] == e;
+        if (mine) continue;                            // claimed a moment ago, the owner load did not see it yet
         const int q = ny * W + nx;
-        // the returned value orders this claim before the owner loads of the next steps (a no-return atomic may
-        // still be in flight when they are issued); a lower rank that got there first keeps the pixel
-        const int old = __hip_atomic_fetch_min(ci ? &own[q].y : &own[q].x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old <= r) continue;
-        mq[cnt * 256 + tid] = (ny << 16) | nx;         // cnt < RX_HAND + 8 <= RX_QCAP at a step boundary
+        pend[n] = __hip_atomic_fetch_min(ci ? &own[q].y : &own[q].x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mq[cnt * 256 + tid] = e;                       // cnt < RX_HAND + 8 <= RX_QCAP at a step boundary
         ++cnt;
         bx0 = min(bx0, nx); bx1 = max(bx1, nx); by0 = min(by0, ny); by1 = max(by1, ny);
         sumdx = __fadd_rn(sumdx, nr[n].y);
@@ -313,8 +362,11 @@ __global__ __launch_bounds__(256) void k_rx_grow(const DevParams* __restrict__ P
         reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * RX_DEG2RAD;
       }
       ++k;
+      if (k < cnt && cnt < RX_HAND) continue;
+#pragma unroll
+      for (int n = 0; n < 8; ++n) raced = raced || pend[n] <= r;
+      if (raced) atomicAdd(&c.races, 1);                 // statistics; also what keeps the claims 'returning'
       if (k < cnt) {
-        if (cnt < RX_HAND) continue;
         // ---- too large for a lane: hand the state over ---------------------------------
         active = false;
         const int slot = atomicAdd(&c.nHand, 1);
@@ -342,14 +394,22 @@ __global__ __launch_bounds__(256) void k_rx_grow(const DevParams* __restrict__ P
 }
 
 // ---- group-per-region grower ------------------------------------------------------------------------
-// A wave carries four regions, one per group of 16 lanes (the issue slots of a wave are the scarce
-// resource here, and a BFS step only has 8 neighbours to look at).  Lanes 0..8 of a group fetch the 3x3
-// neighbourhood of the group's current queue entry (record + owner pair) in one round trip; ballots over
+// A wave carries eight regions, one per group of 8 lanes (the issue slots of a wave are the scarce
+// resource here, and a BFS step has exactly 8 neighbours to look at).  The lanes of a group fetch the 3x3
+// neighbourhood (centre skipped) of the group's current queue entry (record + owner pair) in one round trip; ballots over
 // "available & aligned", shifted to the group, reproduce the raster-order accept loop.  The queue of a
 // group lives in LDS (first RX_GQ entries) and in arena blocks beyond.  Work items: the seeds listed as
 // large, then the regions handed over by the lane grower in this round.  Everything that is uniform per
 // group (r, cnt, k, sums, angle) is replicated in the group's lanes.
-constexpr int RX_GQ = 512;        // LDS queue entries per group
+#ifndef RX_GL_
+#define RX_GL_ 16
+#endif
+#ifndef RX_GQ_
+#define RX_GQ_ 256
+#endif
+constexpr int RX_GL = RX_GL_;     // lanes per group (8 or 16)
+constexpr int RX_NG = 64 / RX_GL; // groups (regions) per wave
+constexpr int RX_GQ = RX_GQ_;      // LDS queue entries per group
 constexpr int RX_BBLK = 2048;     // arena block for the overflow of a large region's queue
 constexpr int RX_BMAXBLK = 32;
 
@@ -360,15 +420,15 @@ __global__ __launch_bounds__(64) void k_rx_grow_big(const DevParams* __restrict_
                                                     int* __restrict__ rgSizeAll, int2* __restrict__ rgBoxAll,
                                                     int* __restrict__ arenaAll, int arenaCap,
                                                     RxRect* __restrict__ rectAll, int rectCap, int img0, int t) {
-  __shared__ int qs[4][RX_GQ];
-  __shared__ int blk[4][RX_BMAXBLK];
+  __shared__ int qs[RX_NG][RX_GQ];
+  __shared__ int blk[RX_NG][RX_BMAXBLK];
   const DevParams& P = *Pp;
   const int img = blockIdx.y + img0;
   RxCtl& c = ctl[img];
   if (c.state == 2 || c.overflow) return;
   const int nbig = min(c.nBig, bigCap);
   const int nitems = nbig + min(c.nHand, handCap);
-  if ((int)blockIdx.x * 4 >= nitems) return;
+  if ((int)blockIdx.x * RX_NG >= nitems) return;
   const int W = P.LW, H = P.LH;
   const int64_t npix = (int64_t)W * H;
   const float4* rec = recAll + img * npix;
@@ -379,21 +439,34 @@ __global__ __launch_bounds__(64) void k_rx_grow_big(const DevParams* __restrict_
   int2* rgBox = rgBoxAll + img * npix;
   int* arena = arenaAll + (int64_t)img * arenaCap;
   RxRect* rects = rectAll + (int64_t)img * rectCap;
-  const int lane = threadIdx.x, g = lane >> 4, gl = lane & 15, gbase = lane & 48;
+  const int lane = threadIdx.x, g = lane / RX_GL, gl = lane % RX_GL, gbase = lane - gl;
+  // this lane's neighbour in the 3x3 block, raster order (8 lanes: the centre is skipped; 16 lanes: lanes 0..8, 4 idle)
+  const int nm = RX_GL == 8 ? (gl < 4 ? gl : gl + 1) : gl;
+  constexpr unsigned long long GMASK = RX_GL == 8 ? 0xFFull : 0x1FFull;
   const int ci = t & 1;
   const double prec = P.prec;
   const int minReg = P.minRegSize;
-  const int ndx = gl % 3 - 1, ndy = gl / 3 - 1;
+  const int ndx = nm % 3 - 1, ndy = nm / 3 - 1;
   int* q = qs[g];
   int* gb = blk[g];
 
+  // the LDS read is unconditional (clamped index) so that it stays a ds_read: a pointer select between LDS and
+  // the arena would become a flat load, whose wait also covers the claims in flight
   auto qget = [&](int k) -> int {
-    if (k < RX_GQ) return q[k];
-    const int o = k - RX_GQ;
-    return arena[gb[o / RX_BBLK] + o % RX_BBLK];
+    int e = rx_lds_read(&q[min(k, RX_GQ - 1)]);
+    if (k >= RX_GQ) {
+      const int o = k - RX_GQ;
+      e = arena[gb[o / RX_BBLK] + o % RX_BBLK];
+    }
+    return e;
   };
 
-  bool active = false, exhausted = false;
+#ifdef RX_TIMING
+  long long tA = 0, tB = 0, tC = 0, tD = 0, tWave0 = clock64();
+  int nSteps = 0;
+#endif
+  bool active = false, exhausted = false, raced = false;
+  int pendOld = 0x7FFFFFFF, mark0 = 0, mark1 = 0;
   int r = 0, cnt = 0, k = 0, bx0 = 0, by0 = 0, bx1 = 0, by1 = 0;
   float sumdx = 0.f, sumdy = 0.f;
   double reg_angle = 0.0;
@@ -412,7 +485,7 @@ __global__ __launch_bounds__(64) void k_rx_grow_big(const DevParams* __restrict_
           reg_angle = (double)sd.ang * RX_DEG2RAD;
           sumdx = sd.sx; sumdy = sd.sy;
           q[0] = sd.xy;                               // every lane of the group stores the same value
-          cnt = 1; k = 0;
+          cnt = 1; k = 0; mark0 = mark1 = 1;
           bx0 = bx1 = sd.xy & 0xFFFF; by0 = by1 = sd.xy >> 16;
         } else {
           const RxHand& hd = hand[wi - nbig];
@@ -420,88 +493,126 @@ __global__ __launch_bounds__(64) void k_rx_grow_big(const DevParams* __restrict_
           sumdx = hd.sumdx; sumdy = hd.sumdy;
           reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * RX_DEG2RAD;   // cnt >= 2: the angle is a function of the sums
           bx0 = hd.box0 & 0xFFFF; by0 = hd.box0 >> 16; bx1 = hd.box1 & 0xFFFF; by1 = hd.box1 >> 16;
-          for (int i = gl; i < cnt; i += 16) q[i] = hd.q[i];
+          for (int i = gl; i < cnt; i += RX_GL) q[i] = hd.q[i];
+          mark0 = mark1 = cnt;                        // the lane grower's claims were performed in its own launch
         }
       }
     }
     if (!__ballot(active)) break;
-    __syncthreads();                                  // single-wave block: queue writes before the reads below
+    // single-wave block: LDS operations of a wave execute in order, so the queue writes of the last step are
+    // visible to the reads below; the compiler only has to keep the order (no s_barrier: __syncthreads would
+    // also wait for the claims in flight)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     // ---- one BFS step of every active group -------------------------------------------------------
-    int px = 0, py = 0, qi = 0;
-    float4 rr = make_float4(RX_NOTDEF, 0.f, 0.f, 0.f);
-    int2 oo = make_int2(0, 0);
-    if (active) {
-      const int e = qget(k);
-      px = e & 0xFFFF; py = e >> 16;
-      const int nx = px + ndx, ny = py + ndy;
-      const bool inb = gl < 9 && gl != 4 && nx >= 0 && ny >= 0 && nx < W && ny < H;
-      if (inb) {
-        qi = ny * W + nx;
-        rr = rec[qi];
-        oo = rx_load_own(&own[qi]);
-      }
-    }
-    const int prevv = ci ? oo.x : oo.y, curv = ci ? oo.y : oo.x;
-    const bool cand = active && rr.x != RX_NOTDEF && !(prevv < r || curv <= r);
-    const double ad = (double)rr.x * RX_DEG2RAD;
-    int rem = (int)((__ballot(cand) >> gbase) & 0x1FFull);      // the group's candidates, raster order
-    bool dead = false;
-    while (__ballot(rem != 0)) {
-      double n_theta = reg_angle - ad;
-      if (n_theta < 0) n_theta = -n_theta;
-      if (n_theta > RX_3_2_PI) {
-        n_theta -= RX_2PI;
-        if (n_theta < 0) n_theta = -n_theta;
-      }
-      const int m = (int)((__ballot(cand && n_theta <= prec) >> gbase) & 0x1FFull) & rem;
-      if (!m) { rem = 0; continue; }
-      const int j2 = __ffs(m) - 1;
-      rem &= ~((2 << j2) - 1);
-      const float cj = __shfl(rr.y, gbase + j2, 64), sj = __shfl(rr.z, gbase + j2, 64);
-      const int ax = px + j2 % 3 - 1, ay = py + j2 / 3 - 1;
-      int old = 0;
-      if (gl == j2) old = __hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      old = __shfl(old, gbase + j2, 64);             // waits for the claim: later owner loads see it
-      if (old <= r) continue;                        // a lower rank took the pixel first in this round
-      const int xyj = (ay << 16) | ax;
-      if (cnt < RX_GQ) {
-        q[cnt] = xyj;                                // every lane of the group stores the same value
-      } else {
-        const int o = cnt - RX_GQ;
-        if (o % RX_BBLK == 0) {
-          int nb = 0;
-          if (o / RX_BBLK >= RX_BMAXBLK) { dead = true; rem = 0; continue; }
-          if (gl == 0) nb = atomicAdd(&c.arenaHead, RX_BBLK);
-          nb = __shfl(nb, gbase, 64);
-          if (nb + RX_BBLK > arenaCap) { dead = true; rem = 0; continue; }
-          gb[o / RX_BBLK] = nb;
+    // Two copies: while every queue of the wave fits in LDS the step has no global access besides the
+    // neighbourhood loads and the claims (any other load would make the compiler wait for the claims too).
+    bool dead = false, accepted = false;
+    int qi = 0;
+    auto step = [&](auto spillTag) {
+      constexpr bool SPILL = decltype(spillTag)::value;
+      RX_T(t0)
+      int px = 0, py = 0, myxy = -1;
+      qi = 0;
+      float4 rr = make_float4(RX_NOTDEF, 0.f, 0.f, 0.f);
+      int2 oo = make_int2(0, 0);
+      if (active) {
+        const int e = SPILL ? qget(k) : rx_lds_read(&q[k]);
+        px = e & 0xFFFF; py = e >> 16;
+        const int nx = px + ndx, ny = py + ndy;
+        const bool inb = (RX_GL == 8 || (gl < 9 && gl != 4)) && nx >= 0 && ny >= 0 && nx < W && ny < H;
+        if (inb) {
+          qi = ny * W + nx;
+          myxy = (ny << 16) | nx;
+          rr = rec[qi];
+          oo = rx_load_own(&own[qi]);
         }
-        if (gl == 0) arena[gb[o / RX_BBLK] + o % RX_BBLK] = xyj;
-        __threadfence_block();
       }
-      ++cnt;
-      bx0 = min(bx0, ax); bx1 = max(bx1, ax); by0 = min(by0, ay); by1 = max(by1, ay);
-      sumdx = __fadd_rn(sumdx, cj);
-      sumdy = __fadd_rn(sumdy, sj);
-      reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * RX_DEG2RAD;
-    }
+      RX_T(t1)
+      // claims are returning atomics folded one step later (see k_rx_grow): the queue entries of the last two
+      // steps stand in for the owner loads that may not have seen them yet
+      raced = raced || pendOld <= r;
+      pendOld = 0x7FFFFFFF;
+      bool mine = false;
+      if (active) {
+        for (int i = mark1; i < cnt; ++i) mine = mine || (SPILL ? qget(i) : rx_lds_read(&q[i])) == myxy;
+        mark1 = mark0;
+        mark0 = cnt;
+      }
+      RX_T(t2)
+      const int prevv = ci ? oo.x : oo.y, curv = ci ? oo.y : oo.x;
+      const bool cand = active && !mine && rr.x != RX_NOTDEF && !(prevv < r || curv <= r);
+      const double ad = (double)rr.x * RX_DEG2RAD;
+      int rem = (int)((__ballot(cand) >> gbase) & GMASK);      // the group's candidates, raster order
+      RX_T(t3)
+      dead = false; accepted = false;
+      while (__ballot(rem != 0)) {
+        double n_theta = reg_angle - ad;
+        if (n_theta < 0) n_theta = -n_theta;
+        if (n_theta > RX_3_2_PI) {
+          n_theta -= RX_2PI;
+          if (n_theta < 0) n_theta = -n_theta;
+        }
+        const int m = (int)((__ballot(cand && n_theta <= prec) >> gbase) & GMASK) & rem;
+        if (!m) { rem = 0; continue; }
+        const int j2 = __ffs(m) - 1;
+        rem &= ~((2 << j2) - 1);
+        const float cj = __shfl(rr.y, gbase + j2, 64), sj = __shfl(rr.z, gbase + j2, 64);
+        const int m2 = RX_GL == 8 ? (j2 < 4 ? j2 : j2 + 1) : j2;
+        const int ax = px + m2 % 3 - 1, ay = py + m2 / 3 - 1;
+        accepted = accepted || gl == j2;               // the claims are issued together after the loop
+        const int xyj = (ay << 16) | ax;
+        if (!SPILL || cnt < RX_GQ) {
+          q[cnt] = xyj;                                // every lane of the group stores the same value
+        } else {
+          const int o = cnt - RX_GQ;
+          if (o % RX_BBLK == 0) {
+            int nb = 0;
+            if (o / RX_BBLK >= RX_BMAXBLK) { dead = true; rem = 0; continue; }
+            if (gl == 0) nb = atomicAdd(&c.arenaHead, RX_BBLK);
+            nb = __shfl(nb, gbase, 64);
+            if (nb + RX_BBLK > arenaCap) { dead = true; rem = 0; continue; }
+            gb[o / RX_BBLK] = nb;
+          }
+          if (gl == 0) arena[gb[o / RX_BBLK] + o % RX_BBLK] = xyj;
+          __threadfence_block();
+        }
+        ++cnt;
+        bx0 = min(bx0, ax); bx1 = max(bx1, ax); by0 = min(by0, ay); by1 = max(by1, ay);
+        sumdx = __fadd_rn(sumdx, cj);
+        sumdy = __fadd_rn(sumdy, sj);
+        reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * RX_DEG2RAD;
+      }
+      RX_T(t4)
+      RX_ACC()
+    };
+    if (__ballot(active && cnt + 9 > RX_GQ)) step(std::true_type{});
+    else step(std::false_type{});
+    if (accepted) pendOld = __hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (active) {
       ++k;
       if (dead) { c.overflow = 1; active = false; exhausted = true; }
       else if (k >= cnt) {
         // ---- the region is complete ---------------------------------------------------------------
         active = false;
+        if (raced || pendOld <= r) atomicAdd(&c.races, 1);   // statistics; also what keeps the claims 'returning'
+        raced = false; pendOld = 0x7FFFFFFF;
         if (gl == 0) {
           rgSize[r] = cnt;
           rgBox[r] = make_int2((by0 << 16) | bx0, (by1 << 16) | bx1);
         }
+#ifdef RX_TIMING
+        if (cnt > 600 && lane == gbase) {
+          c.pad[0] = (int)(tA / nSteps); c.pad[1] = (int)(tB / nSteps); c.pad[2] = (int)(tC / nSteps); c.pad[3] = (int)(tD / nSteps);
+          c.races = nSteps; c.rounds = (int)((clock64() - tWave0) / nSteps);
+        }
+#endif
         if (cnt >= minReg) {                          // the pixel list goes to k_rx_rect (region2rect)
           int off = 0, slot = 0;
           if (gl == 0) { off = atomicAdd(&c.arenaHead, cnt); slot = atomicAdd(&c.nRect, 1); }
           off = __shfl(off, gbase, 64); slot = __shfl(slot, gbase, 64);
           if (off + cnt > arenaCap || slot >= rectCap) c.overflow = 1;
           else {
-            for (int i = gl; i < cnt; i += 16) arena[off + i] = qget(i);
+            for (int i = gl; i < cnt; i += RX_GL) arena[off + i] = qget(i);
             if (gl == 0) {
               RxRect& it = rects[slot];
               it.rank = r; it.off = off; it.cnt = cnt; it.sumdx = sumdx; it.sumdy = sumdy;

@@ -32,6 +32,11 @@ inline int cvRoundf(float v) { return (int)std::nearbyintf(v); }
 inline int cvRoundd(double v) { return (int)std::nearbyint(v); }
 inline int cvFloorf(float v) { int i = (int)v; return i - (i > v); }
 
+// lsd_mode auto: batches of at least this many images (2 per stereo frame) take the sequential wave grower, whose
+// throughput keeps growing with the batch; below it the relaxation is faster (measured: 807 vs 624 frames/s at 256
+// frames, 844 vs 1061 at 512)
+constexpr int RX_AUTO_IMAGES = 768;
+
 struct ProfEntry { const char* name; hipEvent_t a, b; };
 
 }  // namespace
@@ -60,7 +65,7 @@ struct pli_ctx {
   int tmpPitch = 0;
   int* lsdTab = nullptr;
   float4* rec = nullptr; int* g2 = nullptr; int* maxG2 = nullptr;
-  float2* seedcs = nullptr; int2* own = nullptr; RxSeed* smallSeeds = nullptr; RxSeed* bigSeeds = nullptr; int bigCap = 0;
+  int2* own = nullptr; RxSeed* smallSeeds = nullptr; RxSeed* bigSeeds = nullptr; int bigCap = 0;
   RxHand* hand = nullptr; int handCap = 0; RxRect* rects = nullptr; int rectCap = 0; int* rankOf = nullptr; int2* rgBox = nullptr; float4* rgSeg = nullptr; uint8_t* rgClean = nullptr;
   int* tileMin = nullptr; int tilesW = 0, tilesH = 0; int* rxChunkCnt = nullptr; int rxChunks = 0;
   int* lastSize = nullptr; int* arena = nullptr; int arenaCap = 0;
@@ -395,27 +400,27 @@ pli_status allocAll(pli_ctx* c) {
   A(c->g2, npix * NI);
   c->lsdMode = c->cfg.lsd_mode;
   if (const char* e = getenv("PLI_LSD_MODE")) c->lsdMode = atoi(e);
-  if (c->lsdMode != 2) {     // buffers of the relaxation
-    A(c->seedcs, npix * NI);
-    A(c->own, npix * NI);
-    A(c->smallSeeds, npix * NI);
-    c->bigCap = (int)(npix / RX_HAND + 64);               // a region listed as large had >= RX_HAND pixels of its own
-    A(c->bigSeeds, (size_t)c->bigCap * NI);
+  if (c->lsdMode != 2) {     // buffers of the relaxation (in auto mode only batches below RX_AUTO_IMAGES use it)
+    const size_t NR = c->lsdMode == 0 ? std::min<size_t>(NI, RX_AUTO_IMAGES - 1) : NI;
+    A(c->own, npix * NR);
+    A(c->smallSeeds, npix * NR);
+    c->bigCap = (int)(npix / RX_HAND + 64);               // a region listed as large had >= RX_HAND pixels of its own               // a region listed as large had >= RX_HAND pixels of its own
+    A(c->bigSeeds, (size_t)c->bigCap * NR);
     c->handCap = (int)(npix / RX_HAND + 64);
-    A(c->hand, (size_t)c->handCap * NI);
+    A(c->hand, (size_t)c->handCap * NR);
     c->rectCap = 2 * ((int)(npix / std::max(P.minRegSize, 1)) + 64);
-    A(c->rects, (size_t)c->rectCap * NI);
-    A(c->lastSize, npix * NI);                            // region tables, indexed by seed rank
-    A(c->rgBox, npix * NI);
-    A(c->rgSeg, npix * NI);
-    A(c->rgClean, npix * NI);
-    A(c->rankOf, npix * NI);
+    A(c->rects, (size_t)c->rectCap * NR);
+    A(c->lastSize, npix * NR);                            // region tables, indexed by seed rank
+    A(c->rgBox, npix * NR);
+    A(c->rgSeg, npix * NR);
+    A(c->rgClean, npix * NR);
+    A(c->rankOf, npix * NR);
     c->tilesW = (P.LW + 7) / 8; c->tilesH = (P.LH + 7) / 8;
-    A(c->tileMin, (size_t)c->tilesW * c->tilesH * NI);
+    A(c->tileMin, (size_t)c->tilesW * c->tilesH * NR);
     c->rxChunks = (int)((npix + 2047) / 2048);
-    A(c->rxChunkCnt, (size_t)c->rxChunks * NI);
-    c->arenaCap = (int)std::min<size_t>(8 * npix, (size_t)1 << 30);
-    A(c->arena, (size_t)c->arenaCap * NI);
+    A(c->rxChunkCnt, (size_t)c->rxChunks * NR);
+    c->arenaCap = (int)std::min<size_t>(4 * npix, (size_t)1 << 30);
+    A(c->arena, (size_t)c->arenaCap * NR);
   }
   A(c->jrCtl, NI);
   c->jrHost.resize(NI);
@@ -521,11 +526,11 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     scaled = c->pyr + P.lv[0].offset; sStride = P.pyrBlock; sPitch = P.lv[0].pitch;
   }
   HIPCHK(hipMemsetAsync(c->maxG2 + img0, 0, sizeof(int) * nimg, c->stream));
-  const bool sequential = c->lsdMode == 2 || (c->lsdMode == 0 && nimg >= 256);
-  float2* seedPlane = sequential ? (float2*)nullptr : c->seedcs;
+  const bool sequential = c->lsdMode == 2 || (c->lsdMode == 0 && nimg >= RX_AUTO_IMAGES);
+  int2* ownPlane = sequential ? (int2*)nullptr : c->own;
   {
     dim3 g((P.LW + 255) / 256, P.LH, nimg);
-    LAUNCH(c, "k_lsd_grad", k_lsd_grad, g, dim3(256), 0, scaled, sStride, P.LW, P.LH, sPitch, P.g2Thresh, c->rec, c->g2, seedPlane, c->own,
+    LAUNCH(c, "k_lsd_grad", k_lsd_grad, g, dim3(256), 0, scaled, sStride, P.LW, P.LH, sPitch, P.g2Thresh, c->rec, c->g2, ownPlane,
            c->maxG2, c->debug ? c->angDbg : (float*)nullptr, img0);
   }
   LAUNCH(c, "k_lsd_hist", k_lsd_hist, dim3(c->nChunks, nimg), dim3(256), 0, c->g2, npix, P.g2Thresh, P.nBins, c->maxG2,
@@ -561,6 +566,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     const float precDeg = (float)(P.prec * 180.0 / 3.14159265358979323846);
     HIPCHK(hipMemsetAsync(c->jrCtl + img0, 0, sizeof(RxCtl) * nimg, c->stream));
     HIPCHK(hipMemsetAsync(c->rankOf + (int64_t)img0 * npix, 0x7F, sizeof(int) * npix64 * nimg, c->stream));
+    HIPCHK(hipMemsetAsync(c->rgClean + (int64_t)img0 * npix, 0, npix64 * nimg, c->stream));   // round stamps
     TRL(c, "k_rx_rank", k_rx_rank, dim3((npix + 255) / 256, nimg), dim3(256), 0, c->order, c->nDefined, c->rankOf, npix64, img0);
     const dim3 raster((P.LW + 255) / 256, P.LH, nimg);
     TRL(c, "k_rx_guess", k_rx_guess, raster, dim3(256), 0, c->rec, c->rankOf, c->own, P.LW, P.LH, precDeg, img0);
@@ -570,9 +576,9 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       TRL(c, "k_rx_diff", k_rx_diff, dim3((P.LW + 31) / 32, c->tilesH, nimg), dim3(256), 0, c->jrCtl, c->own, c->tileMin,
              P.LW, P.LH, c->tilesW, c->tilesH, img0);
       if (t >= 2)
-        TRL(c, "k_rx_classify", k_rx_classify, raster, dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->rgBox, c->rgClean,
-               c->tileMin, P.LW, P.LH, c->tilesW, c->tilesH, t, img0);
-      TRL(c, "k_rx_seed", k_rx_seed, raster, dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->rec, c->seedcs, c->lastSize,
+        TRL(c, "k_rx_classify", k_rx_classify, raster, dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->rgBox,
+               c->rgClean, c->tileMin, P.LW, P.LH, c->tilesW, c->tilesH, t, img0);
+      TRL(c, "k_rx_seed", k_rx_seed, dim3((P.LW + 1023) / 1024, P.LH, nimg), dim3(1024), 0, c->jrCtl, c->own, c->rankOf, c->rec, c->lastSize,
              c->rgClean, c->smallSeeds, c->bigSeeds, c->bigCap, P.LW, P.LH, bigThresh, t, img0);
       TRL(c, "k_rx_grow", k_rx_grow, dim3(growBlocks, nimg), dim3(256), 0, c->dP, c->jrCtl, c->rec, c->own, c->smallSeeds,
              c->lastSize, c->rgBox, c->hand, c->handCap, c->arena, c->arenaCap, c->rects, c->rectCap, img0, t);
@@ -585,7 +591,8 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
         HIPCHK(hipStreamSynchronize(c->stream));
         const RxCtl& h = c->jrHost[0];
         std::fprintf(stderr, "[rx] t=%d state=%d changed=%d overflow=%d small=%d big=%d hand=%d next=%d nextBig=%d pad=%d %d %d %d\n", t, h.state,
-                     h.changed, h.overflow, h.nSmall, h.nBig, h.nHand, h.next, h.nextBig, h.nRect, h.pad[0], h.pad[1], h.pad[2]);
+                     h.changed, h.overflow, h.nSmall, h.nBig, h.nHand, h.next, h.nextBig, h.races, h.pad[0], h.pad[1], h.pad[2]);
+        std::fprintf(stderr, "[rx]   pad3=%d rounds=%d nRect=%d\n", h.pad[3], h.rounds, h.nRect);
       }
       if ((t >= 10 && (t % 2) == 0) || t == maxRounds) {
         HIPCHK(hipMemcpyAsync(c->jrHost.data(), c->jrCtl + img0, sizeof(RxCtl) * nimg, hipMemcpyDeviceToHost, c->stream));
