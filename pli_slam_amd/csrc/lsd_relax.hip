@@ -236,7 +236,7 @@ __global__ __launch_bounds__(1024) void k_rx_seed(RxCtl* __restrict__ ctl, int2*
     const int pb = rx_block_append(alive && big, &c.nBig, scan);
     if (alive && big) {
       if (pb < bigCap) bigAll[(int64_t)img * bigCap + pb] = sd;
-      else c.overflow = 1;
+      else c.overflow = 2;                           // (codes: 1 hand-over list, 2 large-seed list, 3 arena, 4 rect list, 5 queue blocks)
     }
   }
 }
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void k_rx_grow(const DevParams* __restrict__ P
       // the pixel list goes to k_rx_rect (region2rect)
       const int off = atomicAdd(&c.arenaHead, cnt);
       const int slot = atomicAdd(&c.nRect, 1);
-      if (off + cnt > arenaCap || slot >= rectCap) { c.overflow = 1; continue; }
+      if (off + cnt > arenaCap || slot >= rectCap) { c.overflow = off + cnt > arenaCap ? 3 : 4; continue; }
       for (int i = 0; i < cnt; ++i) arena[off + i] = mq[i * 256 + tid];
       RxRect& it = rects[slot];
       it.rank = r; it.off = off; it.cnt = cnt; it.sumdx = sumdx; it.sumdy = sumdy;
@@ -410,8 +410,8 @@ __global__ __launch_bounds__(256) void k_rx_grow(const DevParams* __restrict__ P
 constexpr int RX_GL = RX_GL_;     // lanes per group (8 or 16)
 constexpr int RX_NG = 64 / RX_GL; // groups (regions) per wave
 constexpr int RX_GQ = RX_GQ_;      // LDS queue entries per group
-constexpr int RX_BBLK = 2048;     // arena block for the overflow of a large region's queue
-constexpr int RX_BMAXBLK = 32;
+constexpr int RX_BBLK = 256;      // arena block for the overflow of a large region's queue
+constexpr int RX_BMAXBLK = 128;   // => regions of up to RX_GQ + 32768 pixels
 
 __global__ __launch_bounds__(64) void k_rx_grow_big(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
                                                     const float4* __restrict__ recAll, int2* __restrict__ ownAll,
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(64) void k_rx_grow_big(const DevParams* __restrict_
     if (accepted) pendOld = __hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (active) {
       ++k;
-      if (dead) { c.overflow = 1; active = false; exhausted = true; }
+      if (dead) { c.overflow = 5; active = false; exhausted = true; }
       else if (k >= cnt) {
         // ---- the region is complete ---------------------------------------------------------------
         active = false;
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(64) void k_rx_grow_big(const DevParams* __restrict_
           int off = 0, slot = 0;
           if (gl == 0) { off = atomicAdd(&c.arenaHead, cnt); slot = atomicAdd(&c.nRect, 1); }
           off = __shfl(off, gbase, 64); slot = __shfl(slot, gbase, 64);
-          if (off + cnt > arenaCap || slot >= rectCap) c.overflow = 1;
+          if (off + cnt > arenaCap || slot >= rectCap) c.overflow = off + cnt > arenaCap ? 3 : 4;
           else {
             for (int i = gl; i < cnt; i += RX_GL) arena[off + i] = qget(i);
             if (gl == 0) {

@@ -419,7 +419,7 @@ pli_status allocAll(pli_ctx* c) {
     A(c->tileMin, (size_t)c->tilesW * c->tilesH * NR);
     c->rxChunks = (int)((npix + 2047) / 2048);
     A(c->rxChunkCnt, (size_t)c->rxChunks * NR);
-    c->arenaCap = (int)std::min<size_t>(4 * npix, (size_t)1 << 30);
+    c->arenaCap = (int)std::min<size_t>(8 * npix, (size_t)1 << 30);
     A(c->arena, (size_t)c->arenaCap * NR);
   }
   A(c->jrCtl, NI);
@@ -594,7 +594,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
                      h.changed, h.overflow, h.nSmall, h.nBig, h.nHand, h.next, h.nextBig, h.races, h.pad[0], h.pad[1], h.pad[2]);
         std::fprintf(stderr, "[rx]   pad3=%d rounds=%d nRect=%d\n", h.pad[3], h.rounds, h.nRect);
       }
-      if ((t >= 10 && (t % 2) == 0) || t == maxRounds) {
+      if ((t >= 4 && (t % 2) == 0) || t == maxRounds) {
         HIPCHK(hipMemcpyAsync(c->jrHost.data(), c->jrCtl + img0, sizeof(RxCtl) * nimg, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         allDone = true;

@@ -381,6 +381,29 @@ def test_lsd_execution_modes_give_identical_results(gpu, mode):
         assert rec["disp"].tobytes() == disp.tobytes() and rec["le"].tobytes() == le.tobytes()
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_lsd_hostile_images(gpu, mode):
+    """Images that stress the relaxation's work lists (noise: hundreds of thousands of tiny regions; checkerboard and
+    stripes: many long regions of equal gradient, i.e. long chains of equal-bin seeds) — same answer as the oracle."""
+    g = gpu
+    W, H = 376, 240
+    rng = np.random.default_rng(5)
+    noise = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W]
+    checker = (((xx // 16) + (yy // 16)) % 2 * 200 + 20).astype(np.uint8)
+    stripes = ((np.sin((xx + 2 * yy) / 5.0) * 0.5 + 0.5) * 255).astype(np.uint8)
+    ramp = ((xx * 255) // (W - 1)).astype(np.uint8)                       # constant gradient: one bin, raster-ordered seeds
+    mixed = np.where(xx < W // 2, noise, stripes).astype(np.uint8)
+    cfg = g.capi.default_config(W, H, orb_nfeatures=300, lsd_nfeatures=0, max_frames=1, lsd_mode=mode)
+    fe = g.Frontend(cfg)
+    for name, img in (("noise", noise), ("checker", checker), ("stripes", stripes), ("ramp", ramp), ("mixed", mixed)):
+        fr = g.po.Frame(ocfg(g, cfg))
+        n, kl, ld = fe.line_extract(0, img)
+        m, okl, old = fr.line_extract(0, img)
+        assert n == m, "%s: %d lines vs oracle %d" % (name, n, m)
+        assert kl.tobytes() == okl.tobytes() and np.array_equal(ld, old), name
+
+
 def test_stereo_maxd_inf_switch(gpu):
     g = gpu
     W, H = 376, 240
