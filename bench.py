@@ -97,7 +97,7 @@ def cpu_baseline(images, cfg_bytes, budget_s=20.0):
     t0 = time.perf_counter()
     frames[0].run(images[0, 0], images[0, 1])
     t1 = time.perf_counter() - t0
-    total = int(max(nthreads, min(8 * nthreads, budget_s / max(t1, 1e-3) * nthreads * 0.6)))
+    total = int(max(nthreads, min(24 * nthreads, budget_s / max(t1, 1e-3) * nthreads * 0.6)))
 
     def work(tid):
         k = 0
@@ -225,8 +225,8 @@ def main():
         traffic = None     # HBM bytes per launch from the committed PMC passes of the same workload, if any
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if tr.get("frames_per_gpu") == F and name in tr["kernels"] and (W, H) == (752, 480):
-                k = tr["kernels"][name]
+            k = tr["workloads"].get(str(F), {}).get(name) if (W, H) == (752, 480) else None
+            if k:
                 traffic = (2 * k["fetch_kb"] + k["write_kb"]) * 1024
         except Exception:
             pass
