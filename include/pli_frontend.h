@@ -256,6 +256,15 @@ pli_status pli_search_by_projection(pli_ctx* ctx,
                                     int32_t check_orientation,
                                     int32_t* best_idx2, int32_t* nmatches);
 
+/* --- the driver's rectification fused into the ingest ---
+ * Replaces cv::remap(imLeft, imLeftRect, M1l, M2l, cv::INTER_LINEAR) / (imRight, ...) of
+ * Examples/Stereo/stereo_euroc.cc:166-167 (maps from cv::initUndistortRectifyMap(..., CV_32F, M1, M2) :117-118).
+ * mapx / mapy: width*height floats each (host), the CV_32FC1 maps of one eye; afterwards every image of that eye
+ * handed to pli_batch_run / pli_batch_run_host / pli_orb_extract / pli_line_extract is the RAW image and level 0
+ * of the pyramid is its rectification (bilinear, 1/32-px coordinates, constant-0 border, OpenCV 3.3.1 fixed point).
+ * NULL, NULL removes the maps of that eye. */
+pli_status pli_set_rectify_maps(pli_ctx* ctx, int32_t eye, const float* mapx, const float* mapy);
+
 /* --- local-map tracking (Tracking::SearchLocalPointsAndLines, Tracking.cc:3854,3882) --- */
 
 /* Core of ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, th, ...)

@@ -239,4 +239,59 @@ static inline int lineIteratorCount(float x1, float y1, float x2, float y2) {
   return std::max(dx, dy) + 1;
 }
 
+// ---------------------------------------------------------------------------
+// cv::remap(src, dst, map1 (CV_32FC1 x), map2 (CV_32FC1 y), INTER_LINEAR), 8U, BORDER_CONSTANT 0 —
+// the stereo driver's rectification (Examples/Stereo/stereo_euroc.cc:166-167).  OpenCV 3.3.1
+// imgwarp.cpp as recalled (parity unpinned): the float maps are converted per pixel to fixed point
+// with cvRound(v * INTER_TAB_SIZE) (INTER_BITS = 5), integer part saturated to short; the bilinear
+// weights come from initInterTab2D: float products of (1 - f/32, f/32), times 2^15,
+// saturate_cast<short>; a block that does not sum to 2^15 is repaired by adding the difference to
+// its largest (or smallest) entry — which happens exactly for f = (0,0), where 32768 saturates to
+// 32767 and the search (whose k1,k2 loops start at ksize/2 = 1) ends on entry [1][1]: {32767,0,0,1}.
+// Result: FixedPtCast<int, uchar, 15>: saturate_u8((sum + 2^14) >> 15).
+// ---------------------------------------------------------------------------
+static inline void remapBilinearWeights(int fx, int fy, int w[4]) {
+  const float sc = 1.f / 32;
+  const float vx[2] = {1.f - fx * sc, fx * sc}, vy[2] = {1.f - fy * sc, fy * sc};
+  int isum = 0;
+  for (int k1 = 0; k1 < 2; ++k1)
+    for (int k2 = 0; k2 < 2; ++k2) {
+      float v = vy[k1] * vx[k2] * 32768.f;
+      int iv = cvRoundf(v);
+      iv = iv > 32767 ? 32767 : (iv < -32768 ? -32768 : iv);
+      w[k1 * 2 + k2] = iv;
+      isum += iv;
+    }
+  if (isum != 32768) {
+    const int diff = isum - 32768;
+    // entries [1][1], [1][2], [2][1], [2][2] of the reference's search lie in this block only for [1][1]; the
+    // others belong to the not yet initialised next block (zero)
+    int M = w[3] > 0 ? w[3] : 0, m = w[3] < 0 ? w[3] : 0;
+    (void)M; (void)m;
+    if (diff < 0) { if (w[3] >= 0) w[3] -= diff; }   // [1][1] is the maximum of {w11, 0, 0, 0}
+    else { if (w[3] <= 0) w[3] -= diff; }
+  }
+}
+
+static inline void remapLinear8u(const Img8& src, const float* mapx, const float* mapy, Img8& dst, int dw, int dh) {
+  dst = Img8(dw, dh);
+  const int W = src.w, H = src.h;
+  for (int y = 0; y < dh; ++y)
+    for (int x = 0; x < dw; ++x) {
+      const int sx = cvRoundf(mapx[(size_t)y * dw + x] * 32), sy = cvRoundf(mapy[(size_t)y * dw + x] * 32);
+      auto sat = [](int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); };
+      const int ix = sat(sx >> 5), iy = sat(sy >> 5);
+      int w[4];
+      remapBilinearWeights(sx & 31, sy & 31, w);
+      int out = 0;
+      if (!(ix >= W || ix + 1 < 0 || iy >= H || iy + 1 < 0)) {
+        auto at = [&](int xx, int yy) -> int { return (xx >= 0 && yy >= 0 && xx < W && yy < H) ? src.at(yy, xx) : 0; };
+        const int sum = at(ix, iy) * w[0] + at(ix + 1, iy) * w[1] + at(ix, iy + 1) * w[2] + at(ix + 1, iy + 1) * w[3];
+        out = (sum + (1 << 14)) >> 15;
+        out = out < 0 ? 0 : (out > 255 ? 255 : out);
+      }
+      dst.row(y)[x] = (uint8_t)out;
+    }
+}
+
 }  // namespace orc

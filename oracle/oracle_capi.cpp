@@ -244,6 +244,15 @@ int orc_search_by_projection(const pli_proj_query* q, const uint8_t* qdesc, int 
   std::memcpy(best_idx2, B.data(), B.size() * 4);
   return r;
 }
+// cv::remap INTER_LINEAR of one 8U image (stereo_euroc.cc:166)
+int orc_remap_linear(const uint8_t* img, int w, int h, int64_t stride, const float* mapx, const float* mapy, uint8_t* dst) {
+  Img8 I = wrap(img, w, h, stride), D;
+  remapLinear8u(I, mapx, mapy, D, w, h);
+  std::memcpy(dst, D.d.data(), D.d.size());
+  return 0;
+}
+int orc_remap_weights(int fx, int fy, int* w) { remapBilinearWeights(fx, fy, w); return 0; }
+
 int orc_search_local_map(const pli_proj_query* q, const uint8_t* qdesc, int nq, const pli_keypoint* kp,
                          const uint8_t* desc, const float* uright, const uint8_t* occupied, int ncur, float minx, float maxx,
                          float miny, float maxy, float nnratio, int* best_idx2) {

@@ -270,6 +270,21 @@ def search_by_projection(q, qdesc, kp, desc, uright, bounds, check_ori=True):
     return n, best
 
 
+def remap_linear(img, mapx, mapy):
+    """cv::remap(img, M1, M2, INTER_LINEAR) on an 8U image (constant-0 border)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    mx, my = np.ascontiguousarray(mapx, np.float32), np.ascontiguousarray(mapy, np.float32)
+    dst = np.zeros_like(img)
+    lib().orc_remap_linear(_p(img), img.shape[1], img.shape[0], C.c_int64(img.strides[0]), _p(mx), _p(my), _p(dst))
+    return dst
+
+
+def remap_weights(fx, fy):
+    w = np.zeros(4, np.int32)
+    lib().orc_remap_weights(fx, fy, _p(w))
+    return w
+
+
 def search_local_map(q, qdesc, kp, desc, uright, occupied, bounds, nnratio):
     q = np.ascontiguousarray(q, PROJ_QUERY_DT)
     qdesc = np.ascontiguousarray(qdesc, np.uint8)

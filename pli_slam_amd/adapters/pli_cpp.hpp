@@ -95,6 +95,8 @@ class Frontend {
                                    minX, maxX, minY, maxY, checkOrientation ? 1 : 0, bestIdx2.data(), &n));
     return n;
   }
+  // cv::remap(im, imRect, M1, M2, INTER_LINEAR) of the stereo driver (stereo_euroc.cc:166), fused into the ingest
+  void setRectifyMaps(int eye, const float* mapx, const float* mapy) { check(pli_set_rectify_maps(ctx_, eye, mapx, mapy)); }
   // core of ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, ...) ORBmatcher.cc:44
   int searchLocalMap(const std::vector<pli_proj_query>& q, const uint8_t* qdesc, const std::vector<pli_keypoint>& cur,
                      const uint8_t* curDesc, const float* curURight, const uint8_t* curOccupied, float minX, float maxX,

@@ -79,6 +79,7 @@ _PROTOS = {
     "pli_ctx_layout": (C.c_int32, [C.c_void_p, C.POINTER(TableLayout)]),
     "pli_ctx_set_stream": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "pli_ctx_sync": (C.c_int32, [C.c_void_p]),
+    "pli_set_rectify_maps": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "pli_batch_run": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_uint32,
                                   C.c_void_p]),
     "pli_batch_run_host": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,

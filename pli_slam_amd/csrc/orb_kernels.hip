@@ -19,21 +19,48 @@ __constant__ signed char c_orb_pattern[1024] = {
 };
 
 // ---------------------------------------------------------------------------
-// k_ingest: copy nframes x 2 images (arbitrary stride) into level 0.
+// k_ingest: copy nframes x 2 images (arbitrary stride) into level 0 — or, when the eye has rectification
+// maps, cv::remap(src, dst, mapx, mapy, INTER_LINEAR) (BORDER_CONSTANT 0) fused into the copy
+// (the driver's rectification, Examples/Stereo/stereo_euroc.cc:166-167).  OpenCV 3.3.1 remap for 8U:
+// coordinates to 1/32 px with cvRound(map*32) (saturated to short), bilinear weights (32-fx)(32-fy)*32 ...
+// as shorts summing to 2^15 — the all-in-one-pixel weight 32768 does not fit a short and initInterTab2D
+// repairs the block to {32767, 0, 0, 1} — result (sum + 2^14) >> 15.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ingest(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
                                                 int64_t stride, int64_t frameStride, uint8_t* __restrict__ pyr,
-                                                int64_t pyrBlock, int W, int H, int pitch, int img0) {
+                                                int64_t pyrBlock, int W, int H, int pitch,
+                                                const float2* __restrict__ mapL, const float2* __restrict__ mapR, int img0) {
   const int img = blockIdx.z + img0;
   const uint8_t* src = ((img & 1) ? right : left) + (int64_t)(img >> 1) * frameStride;
+  const float2* map = (img & 1) ? mapR : mapL;
   uint8_t* dst = pyr + (int64_t)img * pyrBlock;
   const int y = blockIdx.y;
   const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (x4 >= W) return;
-  const uint8_t* s = src + (int64_t)y * stride + x4;
   uint8_t v[4];
+  if (!map) {
+    const uint8_t* s = src + (int64_t)y * stride + x4;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) v[k] = (x4 + k < W) ? s[k] : 0;
+    for (int k = 0; k < 4; ++k) v[k] = (x4 + k < W) ? s[k] : 0;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] = 0;
+      if (x4 + k >= W) continue;
+      const float2 m = map[(int64_t)y * W + x4 + k];
+      const int sx = cv_round_f(__fmul_rn(m.x, 32.f)), sy = cv_round_f(__fmul_rn(m.y, 32.f));
+      const int ix = min(max(sx >> 5, -32768), 32767), iy = min(max(sy >> 5, -32768), 32767);
+      const int fx = sx & 31, fy = sy & 31;
+      int w0 = (32 - fx) * (32 - fy) * 32, w1 = fx * (32 - fy) * 32, w2 = (32 - fx) * fy * 32, w3 = fx * fy * 32;
+      if ((fx | fy) == 0) { w0 = 32767; w3 = 1; }
+      if (ix >= W || ix + 1 < 0 || iy >= H || iy + 1 < 0) continue;        // fully outside: border value 0
+      auto at = [&](int xx, int yy) -> int {
+        return (xx >= 0 && yy >= 0 && xx < W && yy < H) ? (int)src[(int64_t)yy * stride + xx] : 0;
+      };
+      const int sum = at(ix, iy) * w0 + at(ix + 1, iy) * w1 + at(ix, iy + 1) * w2 + at(ix + 1, iy + 1) * w3;
+      v[k] = (uint8_t)min(max((sum + (1 << 14)) >> 15, 0), 255);
+    }
+  }
   *reinterpret_cast<uchar4*>(dst + (int64_t)y * pitch + x4) = make_uchar4(v[0], v[1], v[2], v[3]);
 }
 

@@ -83,6 +83,7 @@ struct pli_ctx {
   unsigned long long* lmask = nullptr; double* ldir = nullptr; short* dmat = nullptr; int *m12 = nullptr, *m21 = nullptr;
   // drop-in state
   uint8_t* inStage[2] = {nullptr, nullptr};
+  float2* rectMap[2] = {nullptr, nullptr};   // per eye: (mapx, mapy) of the driver's rectification, or null
   uint8_t* ownTable = nullptr;
   std::vector<uint8_t> hostRec;
   bool orbDone[2] = {false, false}, lineDone[2] = {false, false};
@@ -474,7 +475,8 @@ pli_status allocAll(pli_ctx* c) {
 pli_status runIngest(pli_ctx* c, const uint8_t* dl, const uint8_t* dr, int64_t stride, int64_t frameStride, int img0, int nimg) {
   const DevParams& P = c->hp;
   dim3 g((P.W + 1023) / 1024, P.H, nimg);
-  LAUNCH(c, "k_ingest", k_ingest, g, dim3(256), 0, dl, dr, stride, frameStride, c->pyr, P.pyrBlock, P.W, P.H, P.lv[0].pitch, img0);
+  LAUNCH(c, "k_ingest", k_ingest, g, dim3(256), 0, dl, dr, stride, frameStride, c->pyr, P.pyrBlock, P.W, P.H, P.lv[0].pitch,
+         (const float2*)c->rectMap[0], (const float2*)c->rectMap[1], img0);
   return PLI_OK;
 }
 
@@ -732,6 +734,7 @@ void pli_ctx_destroy(pli_ctx* c) {
   if (c->scratch) hipFree(c->scratch);
   for (hipEvent_t e : c->evPool) hipEventDestroy(e);
   if (c->ownStream && c->stream) hipStreamDestroy(c->stream);
+  for (int e = 0; e < 2; ++e) if (c->rectMap[e]) hipFree(c->rectMap[e]);
   delete c;
 }
 
@@ -752,6 +755,22 @@ pli_status pli_ctx_set_stream(pli_ctx* c, void* s) {
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->ownStream = true;
   }
+  return PLI_OK;
+}
+
+pli_status pli_set_rectify_maps(pli_ctx* c, int32_t eye, const float* mapx, const float* mapy) {
+  if (!c || eye < 0 || eye > 1 || ((mapx == nullptr) != (mapy == nullptr))) { g_err = "bad argument"; return PLI_ERR_INVALID; }
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (!mapx) {
+    if (c->rectMap[eye]) { hipFree(c->rectMap[eye]); c->rectMap[eye] = nullptr; }
+    return PLI_OK;
+  }
+  const size_t n = (size_t)c->cfg.width * c->cfg.height;
+  if (!c->rectMap[eye]) HIPCHK(hipMalloc(&c->rectMap[eye], n * sizeof(float2)));
+  std::vector<float2> h(n);
+  for (size_t i = 0; i < n; ++i) h[i] = make_float2(mapx[i], mapy[i]);
+  HIPCHK(hipMemcpy(c->rectMap[eye], h.data(), n * sizeof(float2), hipMemcpyHostToDevice));
   return PLI_OK;
 }
 

@@ -136,6 +136,17 @@ class Frontend:
                                               int(check_orientation), ptr(best), C.byref(n)))
         return n.value, best
 
+    def set_rectify_maps(self, eye, mapx, mapy):
+        """cv::remap(im, imRect, M1, M2, INTER_LINEAR) of the stereo driver (stereo_euroc.cc:166) fused into the ingest;
+        (None, None) removes the maps."""
+        if mapx is None:
+            check(self.L.pli_set_rectify_maps(self.h, eye, None, None))
+            return
+        mx = np.ascontiguousarray(mapx, np.float32)
+        my = np.ascontiguousarray(mapy, np.float32)
+        assert mx.shape == my.shape == (self.cfg.height, self.cfg.width)
+        check(self.L.pli_set_rectify_maps(self.h, eye, ptr(mx), ptr(my)))
+
     def search_local_map(self, queries, qdesc, cur_kp, cur_desc, cur_uright, bounds, nnratio=0.8, cur_occupied=None):
         """ORBmatcher::SearchByProjection(F, vpMapPoints, th) ORBmatcher.cc:44 — see pli_search_local_map."""
         q = np.ascontiguousarray(queries, PROJ_QUERY_DT)

@@ -106,3 +106,41 @@ def make_batch(n_frames, w=752, h=480, seed0=0):
     for i in range(n_frames):
         out[i, 0], out[i, 1] = make_stereo_pair(seed0 + i, w, h)
     return out
+
+
+# EuRoC calibration of the reference's Examples/Stereo/Config/EuRoC.yaml (data): K, D (k1 k2 p1 p2 k3), R, P[:3,:3]
+EUROC_CALIB = {
+    0: dict(K=[458.654, 0.0, 367.215, 0.0, 457.296, 248.375, 0.0, 0.0, 1.0],
+            D=[-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0],
+            R=[0.999966347530033, -0.001422739138722922, 0.008079580483432283, 0.001365741834644127,
+               0.9999741760894847, 0.007055629199258132, -0.008089410156878961, -0.007044357138835809,
+               0.9999424675829176],
+            P=[435.2046959714599, 0, 367.4517211914062, 0, 435.2046959714599, 252.2008514404297, 0, 0, 1]),
+    1: dict(K=[457.587, 0.0, 379.999, 0.0, 456.134, 255.238, 0.0, 0.0, 1],
+            D=[-0.28368365, 0.07451284, -0.00010473, -3.555907e-05, 0.0],
+            R=[0.9999633526194376, -0.003625811871560086, 0.007755443660172947, 0.003680398547259526,
+               0.9999684752771629, -0.007035845251224894, -0.007729688520722713, 0.007064130529506649,
+               0.999945173484644],
+            P=[435.2046959714599, 0, 367.4517211914062, 0, 435.2046959714599, 252.2008514404297, 0, 0, 1]),
+}
+
+
+def rectify_maps(eye, width=752, height=480, calib=None):
+    """cv::initUndistortRectifyMap(K, D, R, P[:3,:3], size, CV_32F, M1, M2) (stereo_euroc.cc:117) in float64 numpy:
+    the (mapx, mapy) float32 planes the stereo driver feeds to cv::remap.  Host-side set-up, done once per camera."""
+    c = (calib or EUROC_CALIB)[eye]
+    K = np.array(c["K"], np.float64).reshape(3, 3)
+    k1, k2, p1, p2, k3 = c["D"]
+    iR = np.linalg.inv(np.array(c["P"], np.float64).reshape(3, 3) @ np.array(c["R"], np.float64).reshape(3, 3))
+    j, i = np.meshgrid(np.arange(width, dtype=np.float64), np.arange(height, dtype=np.float64))
+    X = iR[0, 0] * j + iR[0, 1] * i + iR[0, 2]
+    Y = iR[1, 0] * j + iR[1, 1] * i + iR[1, 2]
+    Wd = iR[2, 0] * j + iR[2, 1] * i + iR[2, 2]
+    x, y = X / Wd, Y / Wd
+    x2, y2 = x * x, y * y
+    r2 = x2 + y2
+    _2xy = 2 * x * y
+    kr = 1 + ((k3 * r2 + k2) * r2 + k1) * r2
+    xd = x * kr + p1 * _2xy + p2 * (r2 + 2 * x2)
+    yd = y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy
+    return (K[0, 0] * xd + K[0, 2]).astype(np.float32), (K[1, 1] * yd + K[1, 2]).astype(np.float32)

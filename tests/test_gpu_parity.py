@@ -404,6 +404,44 @@ def test_lsd_hostile_images(gpu, mode):
         assert kl.tobytes() == okl.tobytes() and np.array_equal(ld, old), name
 
 
+def test_rectification_fused_into_ingest(gpu):
+    """SURVEY §8f-3: cv::remap(im, imRect, M1, M2, INTER_LINEAR) of the stereo driver (stereo_euroc.cc:166-167) applied
+    by the ingest kernel: level 0 equals the oracle's remap of the raw image and everything downstream equals the
+    oracle pipeline on the rectified pair."""
+    g = gpu
+    W, H = 752, 480
+    cfg = g.capi.default_config(W, H, orb_nfeatures=1000, lsd_nfeatures=100, max_frames=2)
+    fe = g.Frontend(cfg)
+    fe.debug_enable(True)
+    maps = [g.synth.rectify_maps(e, W, H) for e in (0, 1)]
+    for e in (0, 1):
+        fe.set_rectify_maps(e, *maps[e])
+    frames = [g.synth.make_stereo_pair(s, W, H) for s in (21, 22)]
+    recs = fe.batch_run_host(np.stack([np.stack(f) for f in frames]))
+    for i, (rec, (L, R)) in enumerate(zip(recs, frames)):
+        Lr, Rr = g.po.remap_linear(L, *maps[0]), g.po.remap_linear(R, *maps[1])
+        assert (Lr != L).mean() > 0.5                                    # the maps really move pixels
+        for eye, ref in ((0, Lr), (1, Rr)):
+            lvl0 = fe.debug_fetch(2 * i + eye, g.capi.DBG_PYRAMID_LEVEL, 0)
+            assert np.array_equal(lvl0, ref.ravel()), "frame %d eye %d level 0" % (i, eye)
+        assert_frame_equal(g, rec, g.po.Frame(ocfg(g, cfg)), Lr, Rr, "rectified frame %d" % i)
+    # per-call path, and maps with out-of-image coordinates (constant-0 border)
+    mx, my = maps[0]
+    n, kp, desc = fe.orb_extract(0, frames[0][0])
+    fr = g.po.Frame(ocfg(g, cfg))
+    on, okp, odesc = fr.orb_extract(0, g.po.remap_linear(frames[0][0], mx, my))
+    assert n == on and kp.tobytes() == okp.tobytes() and np.array_equal(desc, odesc)
+    fe.set_rectify_maps(0, mx * np.float32(1.3) - 40, my * np.float32(1.3) - 60)
+    n, kp, desc = fe.orb_extract(0, frames[0][0])
+    ref = g.po.remap_linear(frames[0][0], mx * np.float32(1.3) - 40, my * np.float32(1.3) - 60)
+    assert (ref == 0).mean() > 0.05
+    assert np.array_equal(fe.debug_fetch(0, g.capi.DBG_PYRAMID_LEVEL, 0), ref.ravel())
+    # removing the maps restores the plain copy
+    fe.set_rectify_maps(0, None, None)
+    fe.orb_extract(0, frames[0][0])
+    assert np.array_equal(fe.debug_fetch(0, g.capi.DBG_PYRAMID_LEVEL, 0), frames[0][0].ravel())
+
+
 def test_stereo_maxd_inf_switch(gpu):
     g = gpu
     W, H = 376, 240

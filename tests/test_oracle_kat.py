@@ -280,3 +280,27 @@ def test_search_local_map_ratio_and_levels(oracle):
     n2, m2 = oracle.match_lines(a, t, 0.9, True)
     assert m.tolist() == [0, 1] and n == 2
     assert m2.tolist() == [-1, 1] and n2 == 1
+
+
+def test_remap_linear_properties(oracle):
+    """cv::remap INTER_LINEAR (stereo_euroc.cc:166): weight blocks, identity, half-pixel, constant-0 border."""
+    for fx in range(32):
+        for fy in range(32):
+            w = oracle.remap_weights(fx, fy)
+            assert w.sum() == 32768 and (w >= 0).all() and w.max() <= 32767
+            if (fx, fy) != (0, 0):
+                assert w.tolist() == [(32 - fx) * (32 - fy) * 32, fx * (32 - fy) * 32, (32 - fx) * fy * 32, fx * fy * 32]
+    assert oracle.remap_weights(0, 0).tolist() == [32767, 0, 0, 1]        # 32768 does not fit a short
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (40, 56), dtype=np.uint8)
+    xx, yy = np.meshgrid(np.arange(56, dtype=np.float32), np.arange(40, dtype=np.float32))
+    assert np.array_equal(oracle.remap_linear(img, xx, yy), img)
+    sh = oracle.remap_linear(img, xx + 3, yy - 2)                          # integer shift, zeros shifted in
+    assert np.array_equal(sh[2:, :-3], img[:-2, 3:]) and (sh[:2] == 0).all() and (sh[:, -3:] == 0).all()
+    half = oracle.remap_linear(img, xx + 0.5, yy)                          # (a + b + 1) >> 1, last column against the 0 border
+    exp = (img[:, :-1].astype(int) + img[:, 1:] + 1) >> 1
+    assert np.array_equal(half[:, :-1], exp) and np.array_equal(half[:, -1], (img[:, -1].astype(int) + 1) >> 1)
+    far = oracle.remap_linear(img, xx + 1000, yy)
+    assert (far == 0).all()
+    q = oracle.remap_linear(img, xx + np.float32(1 / 64), yy)              # cvRound(x*32 + 0.5): ties to even
+    assert np.array_equal(q[:, 0::2][:, :27], img[:, 0::2][:, :27])        # even x: 32x+0.5 -> 32x
