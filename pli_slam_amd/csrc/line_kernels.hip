@@ -11,6 +11,7 @@
 //                   (binary_descriptor_custom.cpp:1026-1340, 401-412, 662-666)
 #include "kernels.hpp"
 #include "device_prims.hpp"
+#include <type_traits>
 
 namespace pli {
 
@@ -189,6 +190,13 @@ __device__ __forceinline__ double lsd_angle_diff(double a, double b) {
 __device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
+// LDS read that stays a ds_read (see the note in k_lsd_grow)
+__device__ __forceinline__ uint2 lsd_lds_read2(const uint2* p) {
+  typedef __attribute__((address_space(3))) const volatile unsigned lds_cvu;
+  lds_cvu* q = (lds_cvu*)p;
+  return make_uint2(q[0], q[1]);
+}
+
 __device__ __forceinline__ uint2 lsd_qget(const uint2* qs, const uint2* qg, int k) {
   return k < LSD_QCAP ? qs[k] : qg[k - LSD_QCAP];
 }
@@ -258,11 +266,14 @@ __global__ __launch_bounds__(64) void k_lsd_grow(const DevParams* __restrict__ P
       if (lane == __ffsll((long long)__ballot(true)) - 1) rec[sp].x = LSD_NOTDEF;
       qs[0] = make_uint2(((unsigned)spy << 16) | (unsigned)spx, (unsigned)sg2);
       int cnt = 1;
-      for (int k = 0; k < cnt; ++k) {
-        // queue entry k: a plain LDS read (in order behind the ds_writes of this wave), global only for the overflow
-        uint2 e;
-        if (k < LSD_QCAP) e = qs[k];
-        else e = qg[k - LSD_QCAP];
+      // One BFS step.  Two copies: while the queue fits in LDS the step touches global memory only for the
+      // neighbourhood load and the USED marks.  (A queue read that may come from LDS or from the overflow area
+      // becomes a flat load, and its wait — vmcnt(0) — also covers the USED stores of the previous step: a full
+      // store round trip in front of every neighbourhood load.)
+      auto step = [&](int k, auto spillTag) {
+        constexpr bool SPILL = decltype(spillTag)::value;
+        uint2 e = lsd_lds_read2(&qs[SPILL ? min(k, LSD_QCAP - 1) : k]);
+        if (SPILL && k >= LSD_QCAP) e = qg[k - LSD_QCAP];
         e.x = __builtin_amdgcn_readfirstlane(e.x);
         e.y = __builtin_amdgcn_readfirstlane(e.y);
         const int px = (int)(e.x & 0xFFFFu), py = (int)(e.x >> 16);
@@ -290,7 +301,7 @@ __global__ __launch_bounds__(64) void k_lsd_grow(const DevParams* __restrict__ P
           const unsigned g2j = (unsigned)__float_as_int(rl_f(r.w, j2));
           const unsigned xyj = ((unsigned)(py + j2 / 3 - 1) << 16) | (unsigned)(px + j2 % 3 - 1);
           if (lane == j2) rec[qi].x = LSD_NOTDEF;
-          if (cnt < LSD_QCAP) qs[cnt] = make_uint2(xyj, g2j);           // same value from every active lane
+          if (!SPILL || cnt < LSD_QCAP) qs[cnt] = make_uint2(xyj, g2j);           // same value from every active lane
           else if (lane == __ffsll((long long)__ballot(true)) - 1) qg[cnt - LSD_QCAP] = make_uint2(xyj, g2j);
           ++cnt;
           sumdx = __fadd_rn(sumdx, cj);
@@ -298,7 +309,11 @@ __global__ __launch_bounds__(64) void k_lsd_grow(const DevParams* __restrict__ P
           reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * D_DEG2RAD;
           unusedMask &= ~__ballot(sp_l == qj);
         }
-        if (cnt > LSD_QCAP) __threadfence_block();   // overflow entries are read back through global memory
+        if (SPILL && cnt > LSD_QCAP) __threadfence_block();   // overflow entries are read back through global memory
+      };
+      for (int k = 0; k < cnt; ++k) {
+        if (cnt + 9 > LSD_QCAP) step(k, std::true_type{});
+        else step(k, std::false_type{});
       }
       if (cnt < minReg) continue;
       // ---- region2rect ----------------------------------------------------
