@@ -8,7 +8,7 @@ from pli_slam_amd.frontend import Frontend
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 imgs = synth.make_batch(min(F, 16), 752, 480)
 imgs = imgs[np.arange(F) % imgs.shape[0]]
-fe = Frontend(capi.default_config(752, 480, orb_nfeatures=1200, lsd_nfeatures=100, max_frames=F, lsd_mode=2 if F >= 128 else 1))
+fe = Frontend(capi.default_config(752, 480, orb_nfeatures=1200, lsd_nfeatures=100, max_frames=F))
 fe.batch_run_host(imgs)
 t = time.perf_counter(); n = 3
 for _ in range(n): fe.batch_run_host(imgs)
