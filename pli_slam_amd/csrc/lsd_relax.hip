@@ -36,15 +36,6 @@
 
 namespace pli {
 
-// dev aid: cycle counters of the group grower's step phases (make EXTRA=-DRX_TIMING), reported in RxCtl::pad
-#ifdef RX_TIMING
-#define RX_T(x) const long long x = clock64();
-#define RX_ACC() { tA += t1 - t0; tB += t2 - t1; tC += t3 - t2; tD += t4 - t3; ++nSteps; }
-#else
-#define RX_T(x)
-#define RX_ACC()
-#endif
-
 constexpr float RX_NOTDEF = -1024.f;
 constexpr int RX_INF = 0x7F7F7F7F;          // rank plane of undefined pixels (hipMemset 0x7F)
 constexpr double RX_PI = 3.14159265358979323846;
@@ -461,10 +452,6 @@ __global__ __launch_bounds__(64) void k_rx_grow_big(const DevParams* __restrict_
     return e;
   };
 
-#ifdef RX_TIMING
-  long long tA = 0, tB = 0, tC = 0, tD = 0, tWave0 = clock64();
-  int nSteps = 0;
-#endif
   bool active = false, exhausted = false, raced = false;
   int pendOld = 0x7FFFFFFF, mark0 = 0, mark1 = 0;
   int r = 0, cnt = 0, k = 0, bx0 = 0, by0 = 0, bx1 = 0, by1 = 0;
@@ -510,7 +497,6 @@ __global__ __launch_bounds__(64) void k_rx_grow_big(const DevParams* __restrict_
     int qi = 0;
     auto step = [&](auto spillTag) {
       constexpr bool SPILL = decltype(spillTag)::value;
-      RX_T(t0)
       int px = 0, py = 0, myxy = -1;
       qi = 0;
       float4 rr = make_float4(RX_NOTDEF, 0.f, 0.f, 0.f);
@@ -527,7 +513,6 @@ __global__ __launch_bounds__(64) void k_rx_grow_big(const DevParams* __restrict_
           oo = rx_load_own(&own[qi]);
         }
       }
-      RX_T(t1)
       // claims are returning atomics folded one step later (see k_rx_grow): the queue entries of the last two
       // steps stand in for the owner loads that may not have seen them yet
       raced = raced || pendOld <= r;
@@ -538,12 +523,10 @@ __global__ __launch_bounds__(64) void k_rx_grow_big(const DevParams* __restrict_
         mark1 = mark0;
         mark0 = cnt;
       }
-      RX_T(t2)
       const int prevv = ci ? oo.x : oo.y, curv = ci ? oo.y : oo.x;
       const bool cand = active && !mine && rr.x != RX_NOTDEF && !(prevv < r || curv <= r);
       const double ad = (double)rr.x * RX_DEG2RAD;
       int rem = (int)((__ballot(cand) >> gbase) & GMASK);      // the group's candidates, raster order
-      RX_T(t3)
       dead = false; accepted = false;
       while (__ballot(rem != 0)) {
         double n_theta = reg_angle - ad;
@@ -582,8 +565,6 @@ __global__ __launch_bounds__(64) void k_rx_grow_big(const DevParams* __restrict_
         sumdy = __fadd_rn(sumdy, sj);
         reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * RX_DEG2RAD;
       }
-      RX_T(t4)
-      RX_ACC()
     };
     if (__ballot(active && cnt + 9 > RX_GQ)) step(std::true_type{});
     else step(std::false_type{});
@@ -600,12 +581,6 @@ __global__ __launch_bounds__(64) void k_rx_grow_big(const DevParams* __restrict_
           rgSize[r] = cnt;
           rgBox[r] = make_int2((by0 << 16) | bx0, (by1 << 16) | bx1);
         }
-#ifdef RX_TIMING
-        if (cnt > 600 && lane == gbase) {
-          c.pad[0] = (int)(tA / nSteps); c.pad[1] = (int)(tB / nSteps); c.pad[2] = (int)(tC / nSteps); c.pad[3] = (int)(tD / nSteps);
-          c.races = nSteps; c.rounds = (int)((clock64() - tWave0) / nSteps);
-        }
-#endif
         if (cnt >= minReg) {                          // the pixel list goes to k_rx_rect (region2rect)
           int off = 0, slot = 0;
           if (gl == 0) { off = atomicAdd(&c.arenaHead, cnt); slot = atomicAdd(&c.nRect, 1); }
