@@ -179,7 +179,7 @@ def main():
         for st_ in streams[1:]:
             torch.cuda.current_stream().wait_stream(st_)
         if world > 1:
-            gather_tables(d_table, rec_bytes, F, dst=0)     # RCCL gather of the per-frame tables to rank 0
+            gather_tables(d_table, rec_bytes, F, dst=0, counts=[F] * world)     # RCCL gather of the per-frame tables to rank 0
 
     def fence():
         if world > 1:

@@ -16,21 +16,27 @@ def shard_range(nframes, rank, world):
     return start, base + (1 if rank < extra else 0)
 
 
-def gather_tables(table, record_bytes, nframes_local, dst=0, group=None):
+def gather_tables(table, record_bytes, nframes_local, dst=0, group=None, counts=None):
     """Gather every rank's result table (1-D uint8 tensor, nframes_local records) on rank `dst`.
 
     Shards may differ by one frame, so tables are padded to the largest shard and cut again on
     the root.  Returns the list of per-rank tables (views trimmed to that rank's frame count) on
     `dst`, None elsewhere.  With world size 1 it returns [table] without communication.
+    `counts`: the frame count of every rank when the caller already knows them (equal shards): skips the
+    exchange of the counts and its host synchronisation.
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return [table[: nframes_local * record_bytes]]
     rank = dist.get_rank(group)
-    counts = torch.tensor([nframes_local], dtype=torch.int64, device=table.device)
-    all_counts = [torch.zeros_like(counts) for _ in range(world)]
-    dist.all_gather(all_counts, counts, group=group)
-    all_counts = [int(c.item()) for c in all_counts]
+    if counts is not None:
+        all_counts = [int(c) for c in counts]
+        assert len(all_counts) == world and all_counts[rank] == nframes_local
+    else:
+        mine = torch.tensor([nframes_local], dtype=torch.int64, device=table.device)
+        all_counts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(all_counts, mine, group=group)
+        all_counts = [int(c.item()) for c in all_counts]
     pad = max(all_counts) * record_bytes
     if table.numel() < pad:
         table = torch.cat([table, table.new_zeros(pad - table.numel())])

@@ -30,6 +30,10 @@ def _worker(rank, world, path, nframes, rec):
     for f in range(count):
         t[f * rec:(f + 1) * rec] = torch.from_numpy(((np.arange(rec) + 31 * (start + f)) % 251).astype(np.uint8))
     out = gather_tables(t, rec, count, dst=0)
+    known = gather_tables(t, rec, count, dst=0, counts=[shard_range(nframes, r, world)[1] for r in range(world)])
+    assert (out is None) == (known is None)
+    if out is not None:
+        assert all(torch.equal(a, b) for a, b in zip(out, known))      # counts known in advance: same result, no exchange
     if rank == 0:
         assert len(out) == world
         full = torch.cat(out)
