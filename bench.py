@@ -66,6 +66,7 @@ def kernel_bytes_per_image(name, g, n_kp, n_l, W, H):
         # per round in the ideal case
         "k_rx_grow": 8 * Pp,
         "k_rx_grow_big": 8 * Pp,
+        "k_rx_grow_wave": 8 * Pp,
         "k_rx_seed": 12 * Pp,                         # rank + owner pair read
         "k_rx_classify": 12 * Pp,
         "k_rx_diff": 8 * Pp,

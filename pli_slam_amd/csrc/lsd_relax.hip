@@ -392,25 +392,19 @@ __global__ __launch_bounds__(256) void k_rx_grow(const DevParams* __restrict__ P
 // group lives in LDS (first RX_GQ entries) and in arena blocks beyond.  Work items: the seeds listed as
 // large, then the regions handed over by the lane grower in this round.  Everything that is uniform per
 // group (r, cnt, k, sums, angle) is replicated in the group's lanes.
-#ifndef RX_GL_
-#define RX_GL_ 16
-#endif
-#ifndef RX_GQ_
-#define RX_GQ_ 256
-#endif
-constexpr int RX_GL = RX_GL_;     // lanes per group (8 or 16)
-constexpr int RX_NG = 64 / RX_GL; // groups (regions) per wave
-constexpr int RX_GQ = RX_GQ_;      // LDS queue entries per group
 constexpr int RX_BBLK = 256;      // arena block for the overflow of a large region's queue
 constexpr int RX_BMAXBLK = 128;   // => regions of up to RX_GQ + 32768 pixels
 
-__global__ __launch_bounds__(64) void k_rx_grow_big(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
-                                                    const float4* __restrict__ recAll, int2* __restrict__ ownAll,
-                                                    const RxSeed* __restrict__ bigAll, int bigCap,
-                                                    const RxHand* __restrict__ handAll, int handCap,
-                                                    int* __restrict__ rgSizeAll, int2* __restrict__ rgBoxAll,
-                                                    int* __restrict__ arenaAll, int arenaCap,
-                                                    RxRect* __restrict__ rectAll, int rectCap, int img0, int t) {
+// RX_GL lanes per group (8, 16 or 64 = one region per wave), RX_GQ LDS queue entries per group.
+template <int RX_GL, int RX_GQ>
+__device__ __forceinline__ void rx_grow_groups(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
+                                               const float4* __restrict__ recAll, int2* __restrict__ ownAll,
+                                               const RxSeed* __restrict__ bigAll, int bigCap,
+                                               const RxHand* __restrict__ handAll, int handCap,
+                                               int* __restrict__ rgSizeAll, int2* __restrict__ rgBoxAll,
+                                               int* __restrict__ arenaAll, int arenaCap,
+                                               RxRect* __restrict__ rectAll, int rectCap, int img0, int t) {
+  constexpr int RX_NG = 64 / RX_GL;   // groups (regions) per wave
   __shared__ int qs[RX_NG][RX_GQ];
   __shared__ int blk[RX_NG][RX_BMAXBLK];
   const DevParams& P = *Pp;
@@ -597,6 +591,31 @@ __global__ __launch_bounds__(64) void k_rx_grow_big(const DevParams* __restrict_
       }
     }
   }
+}
+
+// four regions per wave: the throughput form (batches)
+__global__ __launch_bounds__(64) void k_rx_grow_big(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
+                                                    const float4* __restrict__ recAll, int2* __restrict__ ownAll,
+                                                    const RxSeed* __restrict__ bigAll, int bigCap,
+                                                    const RxHand* __restrict__ handAll, int handCap,
+                                                    int* __restrict__ rgSizeAll, int2* __restrict__ rgBoxAll,
+                                                    int* __restrict__ arenaAll, int arenaCap,
+                                                    RxRect* __restrict__ rectAll, int rectCap, int img0, int t) {
+  rx_grow_groups<16, 256>(Pp, ctl, recAll, ownAll, bigAll, bigCap, handAll, handCap, rgSizeAll, rgBoxAll, arenaAll, arenaCap,
+                          rectAll, rectCap, img0, t);
+}
+
+// one region per wave: the latency form (a few images; the longest region of a round is the critical path, and a
+// wave that carries nothing else steps it ~25 % faster)
+__global__ __launch_bounds__(64) void k_rx_grow_wave(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
+                                                     const float4* __restrict__ recAll, int2* __restrict__ ownAll,
+                                                     const RxSeed* __restrict__ bigAll, int bigCap,
+                                                     const RxHand* __restrict__ handAll, int handCap,
+                                                     int* __restrict__ rgSizeAll, int2* __restrict__ rgBoxAll,
+                                                     int* __restrict__ arenaAll, int arenaCap,
+                                                     RxRect* __restrict__ rectAll, int rectCap, int img0, int t) {
+  rx_grow_groups<64, 1024>(Pp, ctl, recAll, ownAll, bigAll, bigCap, handAll, handCap, rgSizeAll, rgBoxAll, arenaAll, arenaCap,
+                           rectAll, rectCap, img0, t);
 }
 
 // ---- region2rect of the regions completed in this round (lsd.cpp region2rect / get_theta) --------------
