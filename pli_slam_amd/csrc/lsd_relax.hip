@@ -424,7 +424,13 @@ __device__ __forceinline__ void rx_grow_groups(const DevParams* __restrict__ Pp,
   int2* rgBox = rgBoxAll + img * npix;
   int* arena = arenaAll + (int64_t)img * arenaCap;
   RxRect* rects = rectAll + (int64_t)img * rectCap;
-  const int lane = threadIdx.x, g = lane / RX_GL, gl = lane % RX_GL, gbase = lane - gl;
+  const int lane = threadIdx.x, g = lane / RX_GL, gl = lane % RX_GL, gbase = RX_GL == 64 ? 0 : lane - gl;
+  // with one group per wave the group-uniform state is wave-uniform: say so (scalar registers, scalar branches)
+  auto U = [](int v) -> int { if constexpr (RX_GL == 64) return __builtin_amdgcn_readfirstlane(v); else return v; };
+  auto Uf = [](float v) -> float { if constexpr (RX_GL == 64) return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); else return v; };
+  auto bcast = [&](float v, int j) -> float {   // value of lane j of this group
+    if constexpr (RX_GL == 64) return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); else return __shfl(v, gbase + j, 64);
+  };
   // this lane's neighbour in the 3x3 block, raster order (8 lanes: the centre is skipped; 16 lanes: lanes 0..8, 4 idle)
   const int nm = RX_GL == 8 ? (gl < 4 ? gl : gl + 1) : gl;
   constexpr unsigned long long GMASK = RX_GL == 8 ? 0xFFull : 0x1FFull;
@@ -456,7 +462,7 @@ __device__ __forceinline__ void rx_grow_groups(const DevParams* __restrict__ Pp,
     if (!active && !exhausted) {
       int wi = 0;
       if (gl == 0) wi = atomicAdd(&c.nextBig, 1);
-      wi = __shfl(wi, gbase, 64);
+      wi = U(__shfl(wi, gbase, 64));
       if (wi >= nitems) exhausted = true;
       else {
         active = true;
@@ -477,8 +483,12 @@ __device__ __forceinline__ void rx_grow_groups(const DevParams* __restrict__ Pp,
           for (int i = gl; i < cnt; i += RX_GL) q[i] = hd.q[i];
           mark0 = mark1 = cnt;                        // the lane grower's claims were performed in its own launch
         }
+        r = U(r); cnt = U(cnt); k = U(k); mark0 = U(mark0); mark1 = U(mark1);
+        bx0 = U(bx0); bx1 = U(bx1); by0 = U(by0); by1 = U(by1);
+        sumdx = Uf(sumdx); sumdy = Uf(sumdy);
       }
     }
+    if constexpr (RX_GL == 64) { active = U(active) != 0; exhausted = U(exhausted) != 0; }
     if (!__ballot(active)) break;
     // single-wave block: LDS operations of a wave execute in order, so the queue writes of the last step are
     // visible to the reads below; the compiler only has to keep the order (no s_barrier: __syncthreads would
@@ -496,7 +506,7 @@ __device__ __forceinline__ void rx_grow_groups(const DevParams* __restrict__ Pp,
       float4 rr = make_float4(RX_NOTDEF, 0.f, 0.f, 0.f);
       int2 oo = make_int2(0, 0);
       if (active) {
-        const int e = SPILL ? qget(k) : rx_lds_read(&q[k]);
+        const int e = U(SPILL ? qget(k) : rx_lds_read(&q[k]));
         px = e & 0xFFFF; py = e >> 16;
         const int nx = px + ndx, ny = py + ndy;
         const bool inb = (RX_GL == 8 || (gl < 9 && gl != 4)) && nx >= 0 && ny >= 0 && nx < W && ny < H;
@@ -533,7 +543,7 @@ __device__ __forceinline__ void rx_grow_groups(const DevParams* __restrict__ Pp,
         if (!m) { rem = 0; continue; }
         const int j2 = __ffs(m) - 1;
         rem &= ~((2 << j2) - 1);
-        const float cj = __shfl(rr.y, gbase + j2, 64), sj = __shfl(rr.z, gbase + j2, 64);
+        const float cj = bcast(rr.y, j2), sj = bcast(rr.z, j2);
         const int m2 = RX_GL == 8 ? (j2 < 4 ? j2 : j2 + 1) : j2;
         const int ax = px + m2 % 3 - 1, ay = py + m2 / 3 - 1;
         accepted = accepted || gl == j2;               // the claims are issued together after the loop
