@@ -30,46 +30,55 @@ constexpr double D_2PI = 2 * D_PI;
 //     g2  : gx^2+gy^2 as int bits (modgrad = sqrt(g2/4))
 //   g2o : the same g2 as a plain int plane for the bin-ordering kernels.
 // ---------------------------------------------------------------------------
+constexpr int LSD_GRAD_ROWS = 16;   // rows per block: one atomicMax per block (same-line atomics serialise in L2)
+
 __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ scaled, int64_t imgStride, int W, int H,
                                                   int pitch, int g2Thresh, float4* __restrict__ rec,
-                                                  int* __restrict__ g2o, int2* __restrict__ own, int* __restrict__ maxG2,
-                                                  float* __restrict__ angDbg, int img0) {
+                                                  int* __restrict__ g2o, int2* __restrict__ own,
+                                                  int* __restrict__ maxG2, float* __restrict__ angDbg, int img0) {
+  __shared__ int wmax[4];
   const int img = blockIdx.z + img0;
-  const int y = blockIdx.y;
   const int x = blockIdx.x * 256 + threadIdx.x;
-  int g2 = 0;
-  bool defined = false;
+  int m = 0;
   if (x < W) {
-    float a = LSD_NOTDEF;
-    float cx = 0.f, sy = 0.f;
-    if (x < W - 1 && y < H - 1) {
-      const uint8_t* r0 = scaled + (int64_t)img * imgStride + (int64_t)y * pitch;
-      const uint8_t* r1 = r0 + pitch;
-      int DA = (int)r1[x + 1] - (int)r0[x];
-      int BC = (int)r0[x + 1] - (int)r1[x];
-      int gx = DA + BC, gy = DA - BC;
-      g2 = gx * gx + gy * gy;
-      defined = g2 > g2Thresh;
-      if (defined) {
-        a = fast_atan2_deg((float)gx, (float)(-gy));
-        double ad = (double)a * D_DEG2RAD;
-        double af = (double)(float)ad;
-        double sn, cn;
-        sincos(af, &sn, &cn);
-        cx = (float)cn;
-        sy = (float)sn;
+    const int yEnd = min((int)(blockIdx.y + 1) * LSD_GRAD_ROWS, H);
+    for (int y = blockIdx.y * LSD_GRAD_ROWS; y < yEnd; ++y) {
+      int g2 = 0;
+      float a = LSD_NOTDEF;
+      float cx = 0.f, sy = 0.f;
+      if (x < W - 1 && y < H - 1) {
+        const uint8_t* r0 = scaled + (int64_t)img * imgStride + (int64_t)y * pitch;
+        const uint8_t* r1 = r0 + pitch;
+        int DA = (int)r1[x + 1] - (int)r0[x];
+        int BC = (int)r0[x + 1] - (int)r1[x];
+        int gx = DA + BC, gy = DA - BC;
+        g2 = gx * gx + gy * gy;
+        if (g2 > g2Thresh) {
+          m = max(m, g2);
+          a = fast_atan2_deg((float)gx, (float)(-gy));
+          double ad = (double)a * D_DEG2RAD;
+          double af = (double)(float)ad;
+          double sn, cn;
+          sincos(af, &sn, &cn);
+          cx = (float)cn;
+          sy = (float)sn;
+        }
       }
+      const int64_t o = (int64_t)img * W * H + (int64_t)y * W + x;
+      rec[o] = make_float4(a, cx, sy, __int_as_float(g2));
+      g2o[o] = g2;
+      if (own) own[o] = make_int2(0x7FFFFFFF, 0x7FFFFFFF);   // owner planes of the relaxation (lsd_relax.hip): undefined pixels never belong to a region
+      if (angDbg) angDbg[o] = a;
     }
-    const int64_t o = (int64_t)img * W * H + (int64_t)y * W + x;
-    rec[o] = make_float4(a, cx, sy, __int_as_float(g2));
-    g2o[o] = g2;
-    if (own) own[o] = make_int2(0x7FFFFFFF, 0x7FFFFFFF);   // owner planes of the relaxation (lsd_relax.hip): undefined pixels never belong to a region
-    if (angDbg) angDbg[o] = a;
   }
-  int m = defined ? g2 : 0;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(&maxG2[img], m);
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+    if (m > 0) atomicMax(&maxG2[img], m);
+  }
 }
 
 __device__ __forceinline__ int lsd_bin(int g2, double binCoef) {

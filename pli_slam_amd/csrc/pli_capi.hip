@@ -531,7 +531,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   const bool sequential = c->lsdMode == 2 || (c->lsdMode == 0 && nimg >= RX_AUTO_IMAGES);
   int2* ownPlane = sequential ? (int2*)nullptr : c->own;
   {
-    dim3 g((P.LW + 255) / 256, P.LH, nimg);
+    dim3 g((P.LW + 255) / 256, (P.LH + 15) / 16, nimg);   // 16 = LSD_GRAD_ROWS
     LAUNCH(c, "k_lsd_grad", k_lsd_grad, g, dim3(256), 0, scaled, sStride, P.LW, P.LH, sPitch, P.g2Thresh, c->rec, c->g2, ownPlane,
            c->maxG2, c->debug ? c->angDbg : (float*)nullptr, img0);
   }
