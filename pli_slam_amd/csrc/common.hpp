@@ -62,18 +62,26 @@ struct DevParams {
 };
 
 // per-image control block of the LSD relaxation (lsd_relax.hip)
-struct RxCtl {
+// Returning atomics on one cache line serialise in its L2 channel (~40 ns each), so every hot counter has its own
+// 128-byte line, and the two counters every finished region needs are one 64-bit word.
+struct alignas(128) RxCtl {
   int state;       // 0 relaxing, 2 exact owner map found
   int changed;     // owner_{t-1} != owner_{t-2} somewhere
-  int arenaHead;   // bump pointer of the queue arena of the wave grower
-  int overflow;    // a capacity was exhausted: the image falls back to the sequential grower
+  int overflow;    // a capacity was exhausted (code): the image falls back to the sequential grower
   int rounds;      // round in which the fixed point was detected
-  int nSmall, nBig, nHand;   // work lists of this round: lane grower, wave grower, regions handed from lane to wave
-  int next, nextBig;         // their work counters
-  int nRect;                 // regions completed in this round that need region2rect
-  int races;                 // regions that saw a lower rank slip between their owner load and their claim
-  int pad[4];
+  int nSmall, nBig;   // work lists of this round: lane grower, wave grower
+  int pad0[26];
+  int nHand;       // regions handed from the lane grower to the wave grower in this round
+  int pad1[31];
+  int nextBig;     // work counter of the wave grower
+  int pad2[31];
+  // rect list entries (high 24 bits) | arena words (low 40 bits): lists for k_rx_rect and queue overflow blocks
+  unsigned long long rectArena;
+  int pad3[30];
+  int races;       // regions that saw a lower rank slip between their owner load and their claim
+  int pad4[31];
 };
+constexpr int RX_ARENA_BITS = 40;
 
 // an alive seed, ready to grow (written by k_rx_seed)
 struct RxSeed {

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_rx_diff(RxCtl* __restrict__ ctl, const 
   RxCtl& c = ctl[img];
   if (c.state == 2) return;
   const int tid = threadIdx.x;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { c.nSmall = 0; c.nBig = 0; c.nHand = 0; c.nRect = 0; c.next = 0; c.nextBig = 0; c.arenaHead = 0; }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { c.nSmall = 0; c.nBig = 0; c.nHand = 0; c.nextBig = 0; c.rectArena = 0ull; }
   if (tid < 4) tmin[tid] = INT_MAX;
   __syncthreads();
   const int x = blockIdx.x * 32 + (tid & 31), y = blockIdx.y * 8 + (tid >> 5);
@@ -263,14 +263,13 @@ __global__ __launch_bounds__(256) void k_rx_grow(const DevParams* __restrict__ P
   const int ci = t & 1;                              // owner_t lives in component ci, owner_{t-1} in the other
   const double prec = P.prec;
   const int minReg = P.minRegSize;
+  int batch = 0;
 
   for (;;) {
-    int base = 0;
-    {
-      const int leader = __ffsll((long long)__ballot(true)) - 1;   // see k_rx_grow_big
-      if (lane == leader) base = atomicAdd(&c.next, 64);
-      base = __builtin_amdgcn_readlane(base, leader);
-    }
+    // batches of 64 seeds are dealt to the waves round robin (no work counter: a returning atomic per batch on a
+    // per-image counter costs more than the imbalance of these short regions)
+    const int base = (batch * (int)(gridDim.x * 4) + (int)blockIdx.x * 4 + (tid >> 6)) * 64;
+    ++batch;
     if (base >= nlive) break;
     bool active = base + lane < nlive;
     int r = 0, cnt = 0, k = 0;
@@ -374,8 +373,9 @@ __global__ __launch_bounds__(256) void k_rx_grow(const DevParams* __restrict__ P
       rgBox[r] = make_int2((by0 << 16) | bx0, (by1 << 16) | bx1);
       if (cnt < minReg) continue;
       // the pixel list goes to k_rx_rect (region2rect)
-      const int off = atomicAdd(&c.arenaHead, cnt);
-      const int slot = atomicAdd(&c.nRect, 1);
+      const unsigned long long ra = atomicAdd(&c.rectArena, (1ull << RX_ARENA_BITS) | (unsigned long long)cnt);
+      const long long off = (long long)(ra & ((1ull << RX_ARENA_BITS) - 1ull));
+      const int slot = (int)(ra >> RX_ARENA_BITS);
       if (off + cnt > arenaCap || slot >= rectCap) { c.overflow = off + cnt > arenaCap ? 3 : 4; continue; }
       for (int i = 0; i < cnt; ++i) arena[off + i] = mq[i * 256 + tid];
       RxRect& it = rects[slot];
@@ -555,9 +555,12 @@ __device__ __forceinline__ void rx_grow_groups(const DevParams* __restrict__ Pp,
           if (o % RX_BBLK == 0) {
             int nb = 0;
             if (o / RX_BBLK >= RX_BMAXBLK) { dead = true; rem = 0; continue; }
-            if (gl == 0) nb = atomicAdd(&c.arenaHead, RX_BBLK);
+            if (gl == 0) {
+              const unsigned long long ra = atomicAdd(&c.rectArena, (unsigned long long)RX_BBLK) & ((1ull << RX_ARENA_BITS) - 1ull);
+              nb = ra + RX_BBLK > (unsigned long long)arenaCap ? -1 : (int)ra;
+            }
             nb = __shfl(nb, gbase, 64);
-            if (nb + RX_BBLK > arenaCap) { dead = true; rem = 0; continue; }
+            if (nb < 0) { dead = true; rem = 0; continue; }
             gb[o / RX_BBLK] = nb;
           }
           if (gl == 0) arena[gb[o / RX_BBLK] + o % RX_BBLK] = xyj;
@@ -587,9 +590,14 @@ __device__ __forceinline__ void rx_grow_groups(const DevParams* __restrict__ Pp,
         }
         if (cnt >= minReg) {                          // the pixel list goes to k_rx_rect (region2rect)
           int off = 0, slot = 0;
-          if (gl == 0) { off = atomicAdd(&c.arenaHead, cnt); slot = atomicAdd(&c.nRect, 1); }
+          if (gl == 0) {
+            const unsigned long long ra = atomicAdd(&c.rectArena, (1ull << RX_ARENA_BITS) | (unsigned long long)cnt);
+            const unsigned long long o64 = ra & ((1ull << RX_ARENA_BITS) - 1ull);
+            off = o64 + cnt > (unsigned long long)arenaCap ? -1 : (int)o64;
+            slot = (int)(ra >> RX_ARENA_BITS);
+          }
           off = __shfl(off, gbase, 64); slot = __shfl(slot, gbase, 64);
-          if (off + cnt > arenaCap || slot >= rectCap) c.overflow = off + cnt > arenaCap ? 3 : 4;
+          if (off < 0 || slot >= rectCap) c.overflow = off < 0 ? 3 : 4;
           else {
             for (int i = gl; i < cnt; i += RX_GL) arena[off + i] = qget(i);
             if (gl == 0) {
@@ -640,7 +648,7 @@ __global__ __launch_bounds__(64) void k_rx_rect(const DevParams* __restrict__ Pp
   const int img = blockIdx.y + img0;
   const RxCtl& c = ctl[img];
   if (c.state == 2 || c.overflow) return;
-  const int nrect = min(c.nRect, rectCap);
+  const int nrect = min((int)(c.rectArena >> RX_ARENA_BITS), rectCap);
   const int W = P.LW;
   const int64_t npix = (int64_t)W * P.LH;
   const float4* rec = recAll + img * npix;

@@ -596,9 +596,9 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
         HIPCHK(hipMemcpyAsync(c->jrHost.data(), c->jrCtl + img0, sizeof(RxCtl) * nimg, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         const RxCtl& h = c->jrHost[0];
-        std::fprintf(stderr, "[rx] t=%d state=%d changed=%d overflow=%d small=%d big=%d hand=%d next=%d nextBig=%d pad=%d %d %d %d\n", t, h.state,
-                     h.changed, h.overflow, h.nSmall, h.nBig, h.nHand, h.next, h.nextBig, h.races, h.pad[0], h.pad[1], h.pad[2]);
-        std::fprintf(stderr, "[rx]   pad3=%d rounds=%d nRect=%d\n", h.pad[3], h.rounds, h.nRect);
+        std::fprintf(stderr, "[rx] t=%d state=%d changed=%d overflow=%d small=%d big=%d hand=%d nextBig=%d rect=%d arena=%lld races=%d\n", t,
+                     h.state, h.changed, h.overflow, h.nSmall, h.nBig, h.nHand, h.nextBig, (int)(h.rectArena >> RX_ARENA_BITS),
+                     (long long)(h.rectArena & ((1ull << RX_ARENA_BITS) - 1ull)), h.races);
       }
       if ((t >= 4 && (t % 2) == 0) || t == maxRounds) {
         HIPCHK(hipMemcpyAsync(c->jrHost.data(), c->jrCtl + img0, sizeof(RxCtl) * nimg, hipMemcpyDeviceToHost, c->stream));
