@@ -404,6 +404,33 @@ def test_lsd_hostile_images(gpu, mode):
         assert kl.tobytes() == okl.tobytes() and np.array_equal(ld, old), name
 
 
+def test_full_size_batch_properties(gpu):
+    """BASELINE config at batch scale (96 EuRoC-size frames, 8 distinct pairs cycled), through size-independent
+    properties: the two LSD schedules write byte-identical tables; a frame's record does not depend on its position
+    in the batch or on its neighbours (duplicates are identical); one record of each distinct pair equals the oracle."""
+    g = gpu
+    W, H, F, U = 752, 480, 96, 8
+    pairs = [g.synth.make_stereo_pair(40 + s, W, H) for s in range(U)]
+    images = np.stack([np.stack(pairs[i % U]) for i in range(F)])
+    tables = {}
+    for mode in (1, 2):
+        cfg = g.capi.default_config(W, H, orb_nfeatures=1200, lsd_nfeatures=100, max_frames=F, lsd_mode=mode)
+        fe = g.Frontend(cfg)
+        left, right = np.ascontiguousarray(images[:, 0]), np.ascontiguousarray(images[:, 1])
+        table = np.zeros(fe.table_bytes(F), np.uint8)
+        g.capi.check(fe.L.pli_batch_run_host(fe.h, F, g.capi.ptr(left), g.capi.ptr(right), W, W * H, g.capi.RUN_ALL,
+                                             g.capi.ptr(table)))
+        tables[mode] = (fe, cfg, table)
+    fe, cfg, t1 = tables[1]
+    assert np.array_equal(t1, tables[2][2]), "relaxation and sequential schedules differ"
+    rb = int(fe.layout.record_bytes)
+    recs = t1.reshape(F, rb)
+    for i in range(U, F):
+        assert np.array_equal(recs[i], recs[i % U]), "record %d differs from its duplicate %d" % (i, i % U)
+    for i in (0, U - 1):
+        assert_frame_equal(g, fe.parse_record(t1, F - U + i), g.po.Frame(ocfg(g, cfg)), pairs[i][0], pairs[i][1], "pair %d" % i)
+
+
 def test_rectification_fused_into_ingest(gpu):
     """SURVEY §8f-3: cv::remap(im, imRect, M1, M2, INTER_LINEAR) of the stereo driver (stereo_euroc.cc:166-167) applied
     by the ingest kernel: level 0 equals the oracle's remap of the raw image and everything downstream equals the
