@@ -265,6 +265,13 @@ pli_status pli_search_by_projection(pli_ctx* ctx,
  * NULL, NULL removes the maps of that eye. */
 pli_status pli_set_rectify_maps(pli_ctx* ctx, int32_t eye, const float* mapx, const float* mapy);
 
+/* --- SURVEY.md §8(f) row 4 (RGB-D front-end): Frame::ComputeStereoFromRGBD(imDepth), Frame.cc:1309-1331 ---
+ * depth: CV_32F depth image registered to the left image (already scaled by mDepthMapFactor, Tracking.cc), row
+ * stride in floats.  For every left keypoint of the last pli_orb_extract(eye 0): d = depth(trunc(v), trunc(u));
+ * d > 0 -> mvDepth = d, mvuRight = x - bf/d, else both -1 (the rectified pipeline: mvKeysUn == mvKeys). */
+pli_status pli_stereo_from_depth(pli_ctx* ctx, const float* depth, int64_t stride_floats, float* uright, float* depth_out,
+                                 int32_t cap);
+
 /* --- local-map tracking (Tracking::SearchLocalPointsAndLines, Tracking.cc:3854,3882) --- */
 
 /* Core of ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, th, ...)

@@ -560,4 +560,21 @@ static inline int searchLocalMap(const pli_proj_query* q, const uint8_t* qdesc, 
   return nmatches;
 }
 
+// Frame::ComputeStereoFromRGBD, Frame.cc:1309-1331 (rectified: mvKeysUn == mvKeys)
+static inline void stereoFromDepth(const pli_keypoint* kp, int n, const float* depth, int64_t stride, int W, int H, float mbf,
+                                   std::vector<float>& mvuRight, std::vector<float>& mvDepth) {
+  mvuRight.assign(n, -1.f);
+  mvDepth.assign(n, -1.f);
+  for (int i = 0; i < n; i++) {
+    const float v = kp[i].y, u = kp[i].x;
+    const int iv = (int)v, iu = (int)u;                  // cv::Mat::at<float>(int, int) called with floats
+    if (iu < 0 || iv < 0 || iu >= W || iv >= H) continue;
+    const float d = depth[(int64_t)iv * stride + iu];
+    if (d > 0) {
+      mvDepth[i] = d;
+      mvuRight[i] = kp[i].x - mbf / d;
+    }
+  }
+}
+
 }  // namespace orc

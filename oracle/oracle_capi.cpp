@@ -244,6 +244,14 @@ int orc_search_by_projection(const pli_proj_query* q, const uint8_t* qdesc, int 
   std::memcpy(best_idx2, B.data(), B.size() * 4);
   return r;
 }
+int orc_stereo_from_depth(const pli_keypoint* kp, int n, const float* depth, int64_t stride, int w, int h, float bf, float* uright,
+                          float* depthOut) {
+  std::vector<float> U, D;
+  stereoFromDepth(kp, n, depth, stride, w, h, bf, U, D);
+  std::memcpy(uright, U.data(), (size_t)n * 4);
+  std::memcpy(depthOut, D.data(), (size_t)n * 4);
+  return n;
+}
 // cv::remap INTER_LINEAR of one 8U image (stereo_euroc.cc:166)
 int orc_remap_linear(const uint8_t* img, int w, int h, int64_t stride, const float* mapx, const float* mapy, uint8_t* dst) {
   Img8 I = wrap(img, w, h, stride), D;

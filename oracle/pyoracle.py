@@ -270,6 +270,15 @@ def search_by_projection(q, qdesc, kp, desc, uright, bounds, check_ori=True):
     return n, best
 
 
+def stereo_from_depth(kp, depth, bf):
+    kp = np.ascontiguousarray(kp, KEYPOINT_DT)
+    d = np.ascontiguousarray(depth, np.float32)
+    ur = np.zeros(kp.shape[0], np.float32)
+    dp = np.zeros(kp.shape[0], np.float32)
+    lib().orc_stereo_from_depth(_p(kp), kp.shape[0], _p(d), C.c_int64(d.shape[1]), d.shape[1], d.shape[0], C.c_float(bf), _p(ur), _p(dp))
+    return ur, dp
+
+
 def remap_linear(img, mapx, mapy):
     """cv::remap(img, M1, M2, INTER_LINEAR) on an 8U image (constant-0 border)."""
     img = np.ascontiguousarray(img, np.uint8)

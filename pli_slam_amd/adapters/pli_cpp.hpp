@@ -95,6 +95,11 @@ class Frontend {
                                    minX, maxX, minY, maxY, checkOrientation ? 1 : 0, bestIdx2.data(), &n));
     return n;
   }
+  // Frame::ComputeStereoFromRGBD(imDepth) Frame.cc:1309 (depth: CV_32F, row stride in floats)
+  void computeStereoFromRGBD(const float* depth, int64_t strideFloats, std::vector<float>& mvuRight, std::vector<float>& mvDepth) {
+    mvuRight.assign(layout_.kp_cap, -1.f); mvDepth.assign(layout_.kp_cap, -1.f);
+    check(pli_stereo_from_depth(ctx_, depth, strideFloats, mvuRight.data(), mvDepth.data(), layout_.kp_cap));
+  }
   // cv::remap(im, imRect, M1, M2, INTER_LINEAR) of the stereo driver (stereo_euroc.cc:166), fused into the ingest
   void setRectifyMaps(int eye, const float* mapx, const float* mapy) { check(pli_set_rectify_maps(ctx_, eye, mapx, mapy)); }
   // core of ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, ...) ORBmatcher.cc:44

@@ -675,4 +675,26 @@ __global__ __launch_bounds__(64) void k_search_local_map(const pli_proj_query* _
   if (lane == 0) *nmatchesOut = nmatches;
 }
 
+// ---------------------------------------------------------------------------
+// Frame::ComputeStereoFromRGBD (Frame.cc:1309-1331): depth of every left keypoint from a registered float
+// depth image, mvuRight = x - bf / d.  (cv::Mat::at<float>(v, u) with float arguments truncates them.)
+// ---------------------------------------------------------------------------
+__global__ void k_stereo_from_depth(const DevParams* __restrict__ Pp, const float* __restrict__ depthImg, int64_t pitch,
+                                    int W, int H, uint8_t* __restrict__ table, int64_t offCounts, int64_t offKp0,
+                                    int64_t offUr, int64_t offDepth) {
+  const DevParams& P = *Pp;
+  const int N = reinterpret_cast<const int*>(table + offCounts)[0];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const pli_keypoint kp = reinterpret_cast<const pli_keypoint*>(table + offKp0)[i];
+  const int u = (int)kp.x, v = (int)kp.y;
+  float ur = -1.f, dp = -1.f;
+  if (u >= 0 && v >= 0 && u < W && v < H) {
+    const float d = depthImg[(int64_t)v * pitch + u];
+    if (d > 0) { dp = d; ur = __fsub_rn(kp.x, __fdiv_rn(P.bf, d)); }
+  }
+  reinterpret_cast<float*>(table + offUr)[i] = ur;
+  reinterpret_cast<float*>(table + offDepth)[i] = dp;
+}
+
 }  // namespace pli

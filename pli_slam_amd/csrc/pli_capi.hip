@@ -905,6 +905,29 @@ pli_status pli_stereo_match_points(pli_ctx* c, float* uright, float* depth, int3
   return PLI_OK;
 }
 
+pli_status pli_stereo_from_depth(pli_ctx* c, const float* depth, int64_t strideFloats, float* uright, float* depthOut, int32_t cap) {
+  if (!c || !depth || strideFloats < c->cfg.width) { g_err = "bad argument"; return PLI_ERR_INVALID; }
+  if (!c->orbDone[0]) { g_err = "pli_orb_extract must run for the left eye first"; return PLI_ERR_STATE; }
+  HIPCHK(hipSetDevice(c->device));
+  const int W = c->cfg.width, H = c->cfg.height;
+  pli_status st = ensureScratch(c, (size_t)W * H * 4);
+  if (st != PLI_OK) return st;
+  HIPCHK(hipMemcpy2DAsync(c->scratch, (size_t)W * 4, depth, (size_t)strideFloats * 4, (size_t)W * 4, H, hipMemcpyHostToDevice, c->stream));
+  const pli_table_layout& Y = c->lay;
+  LAUNCH(c, "k_stereo_from_depth", k_stereo_from_depth, dim3((c->hp.kpCap + 255) / 256), dim3(256), 0, c->dP, (const float*)c->scratch,
+         (int64_t)W, W, H, c->ownTable, Y.off_counts, Y.off_kp[0], Y.off_uright, Y.off_depth);
+  int counts[8];
+  HIPCHK(hipMemcpyAsync(counts, c->ownTable + Y.off_counts, sizeof(counts), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const int N = counts[0];
+  if (N > cap) { g_err = "output buffer too small"; return PLI_ERR_CAPACITY; }
+  if (N > 0) {
+    if (uright) HIPCHK(hipMemcpy(uright, c->ownTable + Y.off_uright, (size_t)N * 4, hipMemcpyDeviceToHost));
+    if (depthOut) HIPCHK(hipMemcpy(depthOut, c->ownTable + Y.off_depth, (size_t)N * 4, hipMemcpyDeviceToHost));
+  }
+  return PLI_OK;
+}
+
 pli_status pli_stereo_match_lines(pli_ctx* c, float* disp, double* le, int32_t cap) {
   if (!c) return PLI_ERR_INVALID;
   if (!c->lineDone[0] || !c->lineDone[1]) { g_err = "pli_line_extract must run for both eyes first"; return PLI_ERR_STATE; }

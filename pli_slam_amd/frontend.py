@@ -136,6 +136,15 @@ class Frontend:
                                               int(check_orientation), ptr(best), C.byref(n)))
         return n.value, best
 
+    def stereo_from_depth(self, depth):
+        """Frame::ComputeStereoFromRGBD (Frame.cc:1309): (mvuRight, mvDepth) of the left keypoints from a float depth image."""
+        d = np.ascontiguousarray(depth, np.float32)
+        assert d.shape == (self.cfg.height, self.cfg.width)
+        ur = np.zeros(self.kp_cap, np.float32)
+        dp = np.zeros(self.kp_cap, np.float32)
+        check(self.L.pli_stereo_from_depth(self.h, ptr(d), d.shape[1], ptr(ur), ptr(dp), self.kp_cap))
+        return ur, dp
+
     def set_rectify_maps(self, eye, mapx, mapy):
         """cv::remap(im, imRect, M1, M2, INTER_LINEAR) of the stereo driver (stereo_euroc.cc:166) fused into the ingest;
         (None, None) removes the maps."""

@@ -431,6 +431,24 @@ def test_full_size_batch_properties(gpu):
         assert_frame_equal(g, fe.parse_record(t1, F - U + i), g.po.Frame(ocfg(g, cfg)), pairs[i][0], pairs[i][1], "pair %d" % i)
 
 
+def test_rgbd_depth_association(gpu):
+    """SURVEY §8f-4: Frame::ComputeStereoFromRGBD (Frame.cc:1309) on the left keypoints."""
+    g = gpu
+    W, H = 640, 480
+    cfg = g.capi.default_config(W, H, orb_nfeatures=1000, lsd_nfeatures=50)
+    fe = g.Frontend(cfg)
+    L, _ = g.synth.make_stereo_pair(17, W, H)
+    n, kp, _ = fe.orb_extract(0, L)
+    rng = np.random.default_rng(1)
+    depth = rng.uniform(0.3, 8.0, (H, W)).astype(np.float32)
+    depth[rng.random((H, W)) < 0.2] = 0                                  # holes of the sensor
+    depth[rng.random((H, W)) < 0.02] = -1
+    ur, dp = fe.stereo_from_depth(depth)
+    our, odp = g.po.stereo_from_depth(kp, depth, cfg.bf)
+    assert n > 500 and ur[:n].tobytes() == our.tobytes() and dp[:n].tobytes() == odp.tobytes()
+    assert 0.1 < (dp[:n] < 0).mean() < 0.4
+
+
 def test_rectification_fused_into_ingest(gpu):
     """SURVEY §8f-3: cv::remap(im, imRect, M1, M2, INTER_LINEAR) of the stereo driver (stereo_euroc.cc:166-167) applied
     by the ingest kernel: level 0 equals the oracle's remap of the raw image and everything downstream equals the
