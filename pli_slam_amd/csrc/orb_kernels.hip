@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256) void k_octree(const DevParams* __restrict__ Pp
 __global__ __launch_bounds__(256) void k_blur(const BlurJob* __restrict__ Jp, const uint8_t* __restrict__ in,
                                               int64_t inImgStride, uint8_t* __restrict__ out,
                                               int64_t outImgStride, int img0) {
-  __shared__ uint8_t t8[38 * 72];
+  __shared__ uint32_t t8[38 * 18];     // (32 + 2R) rows of 72 bytes
   __shared__ int hs[38 * 64];
   const BlurJob& J = *Jp;
   const int img = blockIdx.y + img0;
@@ -634,29 +634,62 @@ __global__ __launch_bounds__(256) void k_blur(const BlurJob* __restrict__ Jp, co
   const int R = J.radius;
   const uint8_t* src = in + (int64_t)img * inImgStride + PL.offIn;
   const int tid = threadIdx.x;
-  const int tw = 64 + 2 * R, th = 32 + 2 * R;
-  for (int i = tid; i < tw * th; i += 256) {
-    int y = i / tw, x = i - y * tw;
-    int sx = reflect101(x0 + x - R, PL.w), sy = reflect101(y0 + y - R, PL.h);
-    t8[y * 72 + x] = src[(int64_t)sy * PL.pitchIn + sx];
+  const int th = 32 + 2 * R;
+  int kc[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) kc[k] = k <= 2 * R ? J.k[k] : 0;
+  uint8_t* t8b = reinterpret_cast<uint8_t*>(t8);
+  // stage (64 + 2R) x (32 + 2R) bytes: thread = (row mod 4, column); columns 64.. are loaded by the first 2R threads
+  {
+    const int x = tid & 63, yy = tid >> 6;
+    const int sx0 = reflect101(x0 + x - R, PL.w), sx1 = reflect101(x0 + x + 64 - R, PL.w);
+    for (int y = yy; y < th; y += 4) {
+      const uint8_t* row = src + (int64_t)reflect101(y0 + y - R, PL.h) * PL.pitchIn;
+      t8b[y * 72 + x] = row[sx0];
+      if (x < 2 * R) t8b[y * 72 + 64 + x] = row[sx1];
+    }
   }
   __syncthreads();
-  for (int i = tid; i < 64 * th; i += 256) {
-    int y = i >> 6, x = i & 63;
-    int s = 0;
-    for (int k = -R; k <= R; ++k) s += J.k[k + R] * t8[y * 72 + x + R + k];
-    hs[y * 64 + x] = s;
+  // horizontal pass: a thread makes 4 adjacent sums from 12 staged bytes
+  {
+    const int j = tid & 15, yy = tid >> 4;
+    for (int y = yy; y < th; y += 16) {
+      const uint32_t w0 = t8[y * 18 + j], w1 = t8[y * 18 + j + 1], w2 = t8[y * 18 + j + 2];
+      int b[12];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { b[i] = (w0 >> (8 * i)) & 255; b[4 + i] = (w1 >> (8 * i)) & 255; b[8 + i] = (w2 >> (8 * i)) & 255; }
+      int s[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < 7; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i] += kc[k] * b[i + k];     // kc[k] = 0 beyond 2R: b[i + k] stays inside the 12 bytes
+      *reinterpret_cast<int4*>(&hs[y * 64 + 4 * j]) = make_int4(s[0], s[1], s[2], s[3]);
+    }
   }
   __syncthreads();
+  // vertical pass: 4 adjacent outputs per thread, one 4-byte store
   uint8_t* dst = out + (int64_t)img * outImgStride + PL.offOut;
-  for (int i = tid; i < 64 * 32; i += 256) {
-    int y = i >> 6, x = i & 63;
-    if (x0 + x >= PL.w || y0 + y >= PL.h) continue;
-    int s = 0;
-    for (int k = -R; k <= R; ++k) s += J.k[k + R] * hs[(y + R + k) * 64 + x];
-    int v = (s + (1 << 15)) >> 16;
-    v = v < 0 ? 0 : (v > 255 ? 255 : v);
-    dst[(int64_t)(y0 + y) * PL.pitchOut + x0 + x] = (uint8_t)v;
+  {
+    const int j = tid & 15, yy = tid >> 4;
+    for (int y = yy; y < 32; y += 16) {
+      if (y0 + y >= PL.h || x0 + 4 * j >= PL.w) continue;
+      int s[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        if (k > 2 * R) break;
+        const int4 v = *reinterpret_cast<const int4*>(&hs[(y + k) * 64 + 4 * j]);
+        s[0] += kc[k] * v.x; s[1] += kc[k] * v.y; s[2] += kc[k] * v.z; s[3] += kc[k] * v.w;
+      }
+      uint8_t o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int v = (s[i] + (1 << 15)) >> 16;
+        o[i] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+      }
+      uint8_t* d = dst + (int64_t)(y0 + y) * PL.pitchOut + x0 + 4 * j;
+      if (x0 + 4 * j + 3 < PL.w) *reinterpret_cast<uchar4*>(d) = make_uchar4(o[0], o[1], o[2], o[3]);
+      else for (int i = 0; i < 4 && x0 + 4 * j + i < PL.w; ++i) d[i] = o[i];
+    }
   }
 }
 
