@@ -156,6 +156,7 @@ __global__ __launch_bounds__(64) void k_lsd_scatter(const int* __restrict__ g2a,
   const double bc = lsd_bin_coef(maxG2[img], nBins);
   const int* g = g2a + (int64_t)img * npix;
   int* ord = order + (int64_t)img * npix;
+  const int nbits = 32 - __clz(max(nBins - 1, 1));
   for (int it = 0; it < LSD_CHUNK / 64; ++it) {
     int i = chunk * LSD_CHUNK + it * 64 + lane;
     bool def = false;
@@ -165,19 +166,19 @@ __global__ __launch_bounds__(64) void k_lsd_scatter(const int* __restrict__ g2a,
       def = v > g2Thresh;
       if (def) bin = lsd_bin(v, bc);
     }
-    unsigned long long todo = __ballot(def);
+    // lanes with the same bin (match-any by bits: one ballot per bin bit instead of one round per distinct bin)
+    unsigned long long peers = __ballot(def);
+    for (int b = 0; b < nbits; ++b) {
+      const bool bit = (bin >> b) & 1;
+      const unsigned long long bal = __ballot(def && bit);
+      peers &= bit ? bal : ~bal;
+    }
     int rank = 0, cnt = 0;
     bool last = false;
-    while (todo) {
-      int leader = __ffsll((long long)todo) - 1;
-      int b = __shfl(bin, leader, 64);
-      unsigned long long m = __ballot(def && bin == b);
-      if (def && bin == b) {
-        rank = __popcll(m & ((1ull << lane) - 1ull));
-        cnt = __popcll(m);
-        last = (m >> lane) == 1ull;
-      }
-      todo &= ~m;
+    if (def) {
+      rank = __popcll(peers & ((1ull << lane) - 1ull));
+      cnt = __popcll(peers);
+      last = (peers >> lane) == 1ull;
     }
     if (def) ord[base[bin] + rank] = i;
     __syncthreads();
