@@ -200,6 +200,14 @@ __device__ __forceinline__ double lsd_angle_diff(double a, double b) {
 __device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
+// LDS traffic of ONE wave is executed in order: a write by some lanes followed by a read by others needs no s_barrier,
+// only the compiler must keep the order (the waves of a block are independent here)
+__device__ __forceinline__ void lsd_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // LDS read that stays a ds_read (see the note in k_lsd_grow)
 __device__ __forceinline__ uint2 lsd_lds_read2(const uint2* p) {
   typedef __attribute__((address_space(3))) const volatile unsigned lds_cvu;
@@ -225,15 +233,20 @@ __device__ __forceinline__ uint2 lsd_qget(const uint2* qs, const uint2* qg, int 
 //     are accumulated in list order by three lanes from products computed 64 at a time.
 // Claimed pixels are marked by overwriting rec.x with NOTDEF.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_lsd_grow(const DevParams* __restrict__ Pp, float4* __restrict__ recAll,
-                                                 const int* __restrict__ orderAll, const int* __restrict__ nDefined,
-                                                 uint2* __restrict__ regOverflow, float* __restrict__ segAll,
-                                                 int* __restrict__ nSeg, int maxSeg, int img0) {
-  __shared__ uint2 qs[LSD_QCAP];
-  __shared__ double st[3][64];
+template <int WPB>   // waves (= images) per block
+__device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp, float4* __restrict__ recAll,
+                                               const int* __restrict__ orderAll, const int* __restrict__ nDefined,
+                                               uint2* __restrict__ regOverflow, float* __restrict__ segAll,
+                                               int* __restrict__ nSeg, int maxSeg, int img0, int nimg) {
+  __shared__ uint2 qsAll[WPB][LSD_QCAP];
+  __shared__ double stAll[WPB][3][64];
   const DevParams& P = *Pp;
-  const int img = blockIdx.x + img0;
-  const int lane = threadIdx.x;
+  const int wv = threadIdx.x >> 6;
+  if ((int)blockIdx.x * WPB + wv >= nimg) return;       // (no block-wide barrier below: the waves are independent)
+  const int img = blockIdx.x * WPB + wv + img0;
+  const int lane = threadIdx.x & 63;
+  uint2* qs = qsAll[wv];
+  double (*st)[64] = stAll[wv];
   const int W = P.LW, H = P.LH;
   const int64_t npix = (int64_t)W * H;
   float4* rec = recAll + img * npix;
@@ -338,12 +351,12 @@ __global__ __launch_bounds__(64) void k_lsd_grow(const DevParams* __restrict__ P
           st[1][lane] = (double)(int)(e.x >> 16) * w;
           st[2][lane] = w;
         }
-        __syncthreads();
+        lsd_wave_sync();
         if (lane < 3) {
           const int m = min(64, cnt - c0);
           for (int t = 0; t < m; ++t) acc += st[lane][t];
         }
-        __syncthreads();
+        lsd_wave_sync();
       }
       const double sum = __shfl(acc, 2, 64);
       const double x = __shfl(acc, 0, 64) / sum, y = __shfl(acc, 1, 64) / sum;
@@ -359,7 +372,7 @@ __global__ __launch_bounds__(64) void k_lsd_grow(const DevParams* __restrict__ P
           st[1][lane] = dx * dx * w;
           st[2][lane] = dx * dy * w;
         }
-        __syncthreads();
+        lsd_wave_sync();
         if (lane < 2) {
           const int m = min(64, cnt - c0);
           for (int t = 0; t < m; ++t) acc += st[lane][t];
@@ -367,7 +380,7 @@ __global__ __launch_bounds__(64) void k_lsd_grow(const DevParams* __restrict__ P
           const int m = min(64, cnt - c0);
           for (int t = 0; t < m; ++t) acc -= st[2][t];
         }
-        __syncthreads();
+        lsd_wave_sync();
       }
       const double Ixx = __shfl(acc, 0, 64), Iyy = __shfl(acc, 1, 64), Ixy = __shfl(acc, 2, 64);
       const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
@@ -402,6 +415,21 @@ __global__ __launch_bounds__(64) void k_lsd_grow(const DevParams* __restrict__ P
     }
   }
   if (lane == 0) nSeg[img] = nseg < maxSeg ? nseg : maxSeg;
+}
+
+// one image per wave; the 2-waves-per-block form keeps the two waves of a block on one CU, which spreads a large
+// batch evenly (2 per SIMD at 1024 frames) however the dispatcher deals the blocks
+__global__ __launch_bounds__(64) void k_lsd_grow(const DevParams* __restrict__ Pp, float4* __restrict__ recAll,
+                                                 const int* __restrict__ orderAll, const int* __restrict__ nDefined,
+                                                 uint2* __restrict__ regOverflow, float* __restrict__ segAll,
+                                                 int* __restrict__ nSeg, int maxSeg, int img0, int nimg) {
+  lsd_grow_image<1>(Pp, recAll, orderAll, nDefined, regOverflow, segAll, nSeg, maxSeg, img0, nimg);
+}
+__global__ __launch_bounds__(128) void k_lsd_grow2(const DevParams* __restrict__ Pp, float4* __restrict__ recAll,
+                                                   const int* __restrict__ orderAll, const int* __restrict__ nDefined,
+                                                   uint2* __restrict__ regOverflow, float* __restrict__ segAll,
+                                                   int* __restrict__ nSeg, int maxSeg, int img0, int nimg) {
+  lsd_grow_image<2>(Pp, recAll, orderAll, nDefined, regOverflow, segAll, nSeg, maxSeg, img0, nimg);
 }
 
 // ---------------------------------------------------------------------------

@@ -541,8 +541,12 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   LAUNCH(c, "k_lsd_scatter", k_lsd_scatter, dim3(c->nChunks, nimg), dim3(64), 0, c->g2, npix, P.g2Thresh, P.nBins, c->maxG2,
          c->chunkBase, c->nChunks, c->order, img0);
   if (sequential) {
-    LAUNCH(c, "k_lsd_grow", k_lsd_grow, dim3(nimg), dim3(64), 0, c->dP, c->rec, c->order, c->nDefined,
-           c->regScratch, c->seg, c->nSeg, c->maxSeg, img0);
+    if (nimg >= 64 && !getenv("PLI_GROW_WPB1"))
+      LAUNCH(c, "k_lsd_grow", k_lsd_grow2, dim3((nimg + 1) / 2), dim3(128), 0, c->dP, c->rec, c->order, c->nDefined,
+             c->regScratch, c->seg, c->nSeg, c->maxSeg, img0, nimg);
+    else
+      LAUNCH(c, "k_lsd_grow", k_lsd_grow, dim3(nimg), dim3(64), 0, c->dP, c->rec, c->order, c->nDefined,
+             c->regScratch, c->seg, c->nSeg, c->maxSeg, img0, nimg);
   } else {
     const bool trace = getenv("PLI_RX_TRACE") != nullptr;
     const bool perRound = getenv("PLI_RX_PROFROUNDS") != nullptr;    // profile names carry the round number
@@ -615,7 +619,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     for (int i = 0; i < nimg; ++i) {
       if (c->jrHost[i].overflow || c->jrHost[i].state != 2) {
         LAUNCH(c, "k_lsd_grow", k_lsd_grow, dim3(1), dim3(64), 0, c->dP, c->rec, c->order, c->nDefined,
-               c->regScratch, c->seg, c->nSeg, c->maxSeg, img0 + i);
+               c->regScratch, c->seg, c->nSeg, c->maxSeg, img0 + i, 1);
       }
     }
   }
