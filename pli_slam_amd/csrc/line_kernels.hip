@@ -334,9 +334,60 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
         }
         if (SPILL && cnt > LSD_QCAP) __threadfence_block();   // overflow entries are read back through global memory
       };
-      for (int k = 0; k < cnt; ++k) {
-        if (cnt + 9 > LSD_QCAP) step(k, std::true_type{});
-        else step(k, std::false_type{});
+      // Batched steps: up to 7 queue entries are popped together, their 7 x 9 neighbourhood records come back in one
+      // round trip, and ONE accept loop walks the combined candidate list in (entry, raster) order = lane order —
+      // exactly the order in which the sequential loop would test them.  A pixel can sit in the list more than
+      // once (neighbour of several entries): it is tested again at each of its turns with the angle of that moment,
+      // as in the sequential loop, and all its later copies are dropped once it is accepted.  Pixels accepted in
+      // the batch are appended to the queue and popped by later batches (FIFO order is unchanged).
+      auto batch = [&](int k, int nb) {
+        const int pi = lane / 9, ni = lane - pi * 9;
+        const bool act = pi < nb;
+        const unsigned ex = lsd_lds_read2(&qs[k + (act ? pi : 0)]).x;
+        const int nx = (int)(ex & 0xFFFFu) + ni % 3 - 1, ny = (int)(ex >> 16) + ni / 3 - 1;
+        const bool inb = act && nx >= 0 && ny >= 0 && nx < W && ny < H;
+        const int qi = inb ? ny * W + nx : -1;
+        float4 r = make_float4(LSD_NOTDEF, 0.f, 0.f, 0.f);
+        if (inb) r = rec[qi];
+        const bool cand = r.x != LSD_NOTDEF;
+        const double ad = (double)r.x * D_DEG2RAD;
+        const unsigned myxy = ((unsigned)ny << 16) | (unsigned)nx;
+        unsigned long long remaining = __ballot(cand);
+        while (remaining) {
+          double n_theta = reg_angle - ad;
+          if (n_theta < 0) n_theta = -n_theta;
+          if (n_theta > D_3_2_PI) {
+            n_theta -= D_2PI;
+            if (n_theta < 0) n_theta = -n_theta;
+          }
+          const unsigned long long m = __ballot(cand && n_theta <= prec) & remaining;
+          if (!m) break;
+          const int j2 = __ffsll((long long)m) - 1;
+          remaining &= ~((2ull << j2) - 1ull);
+          const int qj = rl_i(qi, j2);
+          const float cj = rl_f(r.y, j2), sj = rl_f(r.z, j2);
+          const unsigned g2j = (unsigned)__float_as_int(rl_f(r.w, j2));
+          const unsigned xyj = (unsigned)rl_i((int)myxy, j2);
+          if (lane == j2) rec[qi].x = LSD_NOTDEF;
+          remaining &= ~__ballot(qi == qj);            // the other copies of the accepted pixel
+          qs[cnt] = make_uint2(xyj, g2j);              // same value from every active lane
+          ++cnt;
+          sumdx = __fadd_rn(sumdx, cj);
+          sumdy = __fadd_rn(sumdy, sj);
+          reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * D_DEG2RAD;
+          unusedMask &= ~__ballot(sp_l == qj);
+        }
+      };
+      for (int k = 0; k < cnt;) {
+        if (cnt + 57 <= LSD_QCAP) {                    // a batch can append up to 7 x 8 entries
+          const int nb = min(7, cnt - k);
+          batch(k, nb);
+          k += nb;
+        } else {
+          if (cnt + 9 > LSD_QCAP) step(k, std::true_type{});
+          else step(k, std::false_type{});
+          ++k;
+        }
       }
       if (cnt < minReg) continue;
       // ---- region2rect ----------------------------------------------------
