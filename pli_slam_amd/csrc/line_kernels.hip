@@ -334,14 +334,14 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
         }
         if (SPILL && cnt > LSD_QCAP) __threadfence_block();   // overflow entries are read back through global memory
       };
-      // Batched steps: up to 7 queue entries are popped together, their 7 x 9 neighbourhood records come back in one
+      // Batched steps: up to 8 queue entries are popped together, their 8 x 8 neighbourhood records come back in one
       // round trip, and ONE accept loop walks the combined candidate list in (entry, raster) order = lane order —
       // exactly the order in which the sequential loop would test them.  A pixel can sit in the list more than
       // once (neighbour of several entries): it is tested again at each of its turns with the angle of that moment,
       // as in the sequential loop, and all its later copies are dropped once it is accepted.  Pixels accepted in
       // the batch are appended to the queue and popped by later batches (FIFO order is unchanged).
       auto batch = [&](int k, int nb) {
-        const int pi = lane / 9, ni = lane - pi * 9;
+        const int pi = lane >> 3, ni = (lane & 7) < 4 ? (lane & 7) : (lane & 7) + 1;   // 8 neighbours, raster order, centre skipped
         const bool act = pi < nb;
         const unsigned ex = lsd_lds_read2(&qs[k + (act ? pi : 0)]).x;
         const int nx = (int)(ex & 0xFFFFu) + ni % 3 - 1, ny = (int)(ex >> 16) + ni / 3 - 1;
@@ -379,8 +379,8 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
         }
       };
       for (int k = 0; k < cnt;) {
-        if (cnt + 57 <= LSD_QCAP) {                    // a batch can append up to 7 x 8 entries
-          const int nb = min(7, cnt - k);
+        if (cnt + 65 <= LSD_QCAP) {                    // a batch can append up to 8 x 8 entries
+          const int nb = min(8, cnt - k);
           batch(k, nb);
           k += nb;
         } else {
