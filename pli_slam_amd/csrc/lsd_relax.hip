@@ -431,9 +431,12 @@ __device__ __forceinline__ void rx_grow_groups(const DevParams* __restrict__ Pp,
   auto bcast = [&](float v, int j) -> float {   // value of lane j of this group
     if constexpr (RX_GL == 64) return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); else return __shfl(v, gbase + j, 64);
   };
-  // this lane's neighbour in the 3x3 block, raster order (8 lanes: the centre is skipped; 16 lanes: lanes 0..8, 4 idle)
-  const int nm = RX_GL == 8 ? (gl < 4 ? gl : gl + 1) : gl;
-  constexpr unsigned long long GMASK = RX_GL == 8 ? 0xFFull : 0x1FFull;
+  // Batched steps (as in k_lsd_grow): a group pops up to NP queue entries at a time, 8 lanes per entry (the 3x3
+  // neighbours in raster order, centre skipped); lane order inside the group = the order of the sequential tests.
+  constexpr int NP = RX_GL / 8;
+  constexpr unsigned long long GMASK = RX_GL == 64 ? ~0ull : ((1ull << RX_GL) - 1ull);
+  const int pi = gl >> 3;
+  const int nm = (gl & 7) < 4 ? (gl & 7) : (gl & 7) + 1;
   const int ci = t & 1;
   const double prec = P.prec;
   const int minReg = P.minRegSize;
@@ -453,7 +456,7 @@ __device__ __forceinline__ void rx_grow_groups(const DevParams* __restrict__ Pp,
   };
 
   bool active = false, exhausted = false, raced = false;
-  int pendOld = 0x7FFFFFFF, mark0 = 0, mark1 = 0;
+  int pendOld = 0x7FFFFFFF;
   int r = 0, cnt = 0, k = 0, bx0 = 0, by0 = 0, bx1 = 0, by1 = 0;
   float sumdx = 0.f, sumdy = 0.f;
   double reg_angle = 0.0;
@@ -472,7 +475,7 @@ __device__ __forceinline__ void rx_grow_groups(const DevParams* __restrict__ Pp,
           reg_angle = (double)sd.ang * RX_DEG2RAD;
           sumdx = sd.sx; sumdy = sd.sy;
           q[0] = sd.xy;                               // every lane of the group stores the same value
-          cnt = 1; k = 0; mark0 = mark1 = 1;
+          cnt = 1; k = 0;
           bx0 = bx1 = sd.xy & 0xFFFF; by0 = by1 = sd.xy >> 16;
         } else {
           const RxHand& hd = hand[wi - nbig];
@@ -481,9 +484,8 @@ __device__ __forceinline__ void rx_grow_groups(const DevParams* __restrict__ Pp,
           reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * RX_DEG2RAD;   // cnt >= 2: the angle is a function of the sums
           bx0 = hd.box0 & 0xFFFF; by0 = hd.box0 >> 16; bx1 = hd.box1 & 0xFFFF; by1 = hd.box1 >> 16;
           for (int i = gl; i < cnt; i += RX_GL) q[i] = hd.q[i];
-          mark0 = mark1 = cnt;                        // the lane grower's claims were performed in its own launch
         }
-        r = U(r); cnt = U(cnt); k = U(k); mark0 = U(mark0); mark1 = U(mark1);
+        r = U(r); cnt = U(cnt); k = U(k);
         bx0 = U(bx0); bx1 = U(bx1); by0 = U(by0); by1 = U(by1);
         sumdx = Uf(sumdx); sumdy = Uf(sumdy);
       }
@@ -498,39 +500,35 @@ __device__ __forceinline__ void rx_grow_groups(const DevParams* __restrict__ Pp,
     // Two copies: while every queue of the wave fits in LDS the step has no global access besides the
     // neighbourhood loads and the claims (any other load would make the compiler wait for the claims too).
     bool dead = false, accepted = false;
-    int qi = 0;
+    int qi = 0, nb = 0;
+    // The claims of the previous step are returning atomics: their results are consumed here, before the owner
+    // loads of this step are issued, so those loads see the group's own claims (a lower rank that slipped in
+    // between our load and our claim is ignored: such a region is not final in this round anyway, and the lowest
+    // non-final region never sees that race — the pixels of final lower ranks are already theirs in owner_{t-1}).
+    raced = raced || pendOld <= r;
+    asm volatile("" ::"v"(pendOld) : "memory");
+    pendOld = 0x7FFFFFFF;
     auto step = [&](auto spillTag) {
       constexpr bool SPILL = decltype(spillTag)::value;
-      int px = 0, py = 0, myxy = -1;
-      qi = 0;
+      int myxy = -1;
+      qi = -1;
       float4 rr = make_float4(RX_NOTDEF, 0.f, 0.f, 0.f);
       int2 oo = make_int2(0, 0);
-      if (active) {
-        const int e = U(SPILL ? qget(k) : rx_lds_read(&q[k]));
-        px = e & 0xFFFF; py = e >> 16;
-        const int nx = px + ndx, ny = py + ndy;
-        const bool inb = (RX_GL == 8 || (gl < 9 && gl != 4)) && nx >= 0 && ny >= 0 && nx < W && ny < H;
-        if (inb) {
+      nb = active ? min(NP, cnt - k) : 0;
+      if (pi < nb) {
+        const int e = SPILL ? qget(k + pi) : rx_lds_read(&q[k + pi]);
+        const int nx = (e & 0xFFFF) + ndx, ny = (e >> 16) + ndy;
+        if (nx >= 0 && ny >= 0 && nx < W && ny < H) {
           qi = ny * W + nx;
           myxy = (ny << 16) | nx;
           rr = rec[qi];
           oo = rx_load_own(&own[qi]);
         }
       }
-      // claims are returning atomics folded one step later (see k_rx_grow): the queue entries of the last two
-      // steps stand in for the owner loads that may not have seen them yet
-      raced = raced || pendOld <= r;
-      pendOld = 0x7FFFFFFF;
-      bool mine = false;
-      if (active) {
-        for (int i = mark1; i < cnt; ++i) mine = mine || (SPILL ? qget(i) : rx_lds_read(&q[i])) == myxy;
-        mark1 = mark0;
-        mark0 = cnt;
-      }
       const int prevv = ci ? oo.x : oo.y, curv = ci ? oo.y : oo.x;
-      const bool cand = active && !mine && rr.x != RX_NOTDEF && !(prevv < r || curv <= r);
+      const bool cand = rr.x != RX_NOTDEF && !(prevv < r || curv <= r);
       const double ad = (double)rr.x * RX_DEG2RAD;
-      int rem = (int)((__ballot(cand) >> gbase) & GMASK);      // the group's candidates, raster order
+      unsigned long long rem = (__ballot(cand) >> gbase) & GMASK;      // the group's candidates in test order
       dead = false; accepted = false;
       while (__ballot(rem != 0)) {
         double n_theta = reg_angle - ad;
@@ -539,29 +537,30 @@ __device__ __forceinline__ void rx_grow_groups(const DevParams* __restrict__ Pp,
           n_theta -= RX_2PI;
           if (n_theta < 0) n_theta = -n_theta;
         }
-        const int m = (int)((__ballot(cand && n_theta <= prec) >> gbase) & GMASK) & rem;
+        const unsigned long long m = ((__ballot(cand && n_theta <= prec) >> gbase) & GMASK) & rem;
         if (!m) { rem = 0; continue; }
-        const int j2 = __ffs(m) - 1;
-        rem &= ~((2 << j2) - 1);
+        const int j2 = __ffsll((long long)m) - 1;
+        rem &= ~((2ull << j2) - 1ull);
         const float cj = bcast(rr.y, j2), sj = bcast(rr.z, j2);
-        const int m2 = RX_GL == 8 ? (j2 < 4 ? j2 : j2 + 1) : j2;
-        const int ax = px + m2 % 3 - 1, ay = py + m2 / 3 - 1;
+        const int xyj = __float_as_int(bcast(__int_as_float(myxy), j2));
+        const int qj = __float_as_int(bcast(__int_as_float(qi), j2));
+        rem &= ~((__ballot(qi == qj) >> gbase) & GMASK);             // the other copies of the accepted pixel
+        const int ax = xyj & 0xFFFF, ay = xyj >> 16;
         accepted = accepted || gl == j2;               // the claims are issued together after the loop
-        const int xyj = (ay << 16) | ax;
         if (!SPILL || cnt < RX_GQ) {
           q[cnt] = xyj;                                // every lane of the group stores the same value
         } else {
           const int o = cnt - RX_GQ;
           if (o % RX_BBLK == 0) {
-            int nb = 0;
+            int nbk = 0;
             if (o / RX_BBLK >= RX_BMAXBLK) { dead = true; rem = 0; continue; }
             if (gl == 0) {
               const unsigned long long ra = atomicAdd(&c.rectArena, (unsigned long long)RX_BBLK) & ((1ull << RX_ARENA_BITS) - 1ull);
-              nb = ra + RX_BBLK > (unsigned long long)arenaCap ? -1 : (int)ra;
+              nbk = ra + RX_BBLK > (unsigned long long)arenaCap ? -1 : (int)ra;
             }
-            nb = __shfl(nb, gbase, 64);
-            if (nb < 0) { dead = true; rem = 0; continue; }
-            gb[o / RX_BBLK] = nb;
+            nbk = __shfl(nbk, gbase, 64);
+            if (nbk < 0) { dead = true; rem = 0; continue; }
+            gb[o / RX_BBLK] = nbk;
           }
           if (gl == 0) arena[gb[o / RX_BBLK] + o % RX_BBLK] = xyj;
           __threadfence_block();
@@ -573,16 +572,16 @@ __device__ __forceinline__ void rx_grow_groups(const DevParams* __restrict__ Pp,
         reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * RX_DEG2RAD;
       }
     };
-    if (__ballot(active && cnt + 9 > RX_GQ)) step(std::true_type{});
+    if (__ballot(active && cnt + 8 * NP + 1 > RX_GQ)) step(std::true_type{});
     else step(std::false_type{});
     if (accepted) pendOld = __hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (active) {
-      ++k;
+      k += nb;
       if (dead) { c.overflow = 5; active = false; exhausted = true; }
       else if (k >= cnt) {
         // ---- the region is complete ---------------------------------------------------------------
         active = false;
-        if (raced || pendOld <= r) atomicAdd(&c.races, 1);   // statistics; also what keeps the claims 'returning'
+        if (raced || pendOld <= r) atomicAdd(&c.races, 1);   // statistics
         raced = false; pendOld = 0x7FFFFFFF;
         if (gl == 0) {
           rgSize[r] = cnt;
