@@ -89,7 +89,7 @@ struct RxSeed {
   float ang, sx, sy;
 };
 
-constexpr int RX_QCAP = 32;            // queue entries a lane keeps in LDS
+constexpr int RX_QCAP = 16;            // queue entries a lane keeps in LDS
 constexpr int RX_HAND = RX_QCAP - 8;   // a lane hands its region to the wave grower at this size (step boundary)
 
 // a completed region of at least minRegSize pixels: its pixel list (arena) goes to k_rx_rect
