@@ -610,7 +610,7 @@ __device__ __forceinline__ void rx_grow_groups(const DevParams* __restrict__ Pp,
   }
 }
 
-// four regions per wave: the throughput form (batches)
+// two regions per wave (32-lane groups, 4 queue entries per step): the throughput form (batches)
 __global__ __launch_bounds__(64) void k_rx_grow_big(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
                                                     const float4* __restrict__ recAll, int2* __restrict__ ownAll,
                                                     const RxSeed* __restrict__ bigAll, int bigCap,
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(64) void k_rx_grow_big(const DevParams* __restrict_
                                                     int* __restrict__ rgSizeAll, int2* __restrict__ rgBoxAll,
                                                     int* __restrict__ arenaAll, int arenaCap,
                                                     RxRect* __restrict__ rectAll, int rectCap, int img0, int t) {
-  rx_grow_groups<16, 256>(Pp, ctl, recAll, ownAll, bigAll, bigCap, handAll, handCap, rgSizeAll, rgBoxAll, arenaAll, arenaCap,
+  rx_grow_groups<32, 512>(Pp, ctl, recAll, ownAll, bigAll, bigCap, handAll, handCap, rgSizeAll, rgBoxAll, arenaAll, arenaCap,
                           rectAll, rectCap, img0, t);
 }
 
