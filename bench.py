@@ -62,6 +62,7 @@ def kernel_bytes_per_image(name, g, n_kp, n_l, W, H):
         "k_lsd_scan": 0,
         "k_lsd_scatter": 8 * Pp,
         "k_lsd_grow": 8 * Pp,                         # f32 angle + f32 modgrad read once
+        "k_lsd_grow2": 8 * Pp,                        # the same kernel, two image waves per block (large batches)
         # relaxation mode (lsd_relax.hip), per launch; the growers touch the same angle/modgrad planes once
         # per round in the ideal case
         "k_rx_grow": 8 * Pp,

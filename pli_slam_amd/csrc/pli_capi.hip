@@ -542,7 +542,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
          c->chunkBase, c->nChunks, c->order, img0);
   if (sequential) {
     if (nimg >= 64 && !getenv("PLI_GROW_WPB1"))
-      LAUNCH(c, "k_lsd_grow", k_lsd_grow2, dim3((nimg + 1) / 2), dim3(128), 0, c->dP, c->rec, c->order, c->nDefined,
+      LAUNCH(c, "k_lsd_grow2", k_lsd_grow2, dim3((nimg + 1) / 2), dim3(128), 0, c->dP, c->rec, c->order, c->nDefined,
              c->regScratch, c->seg, c->nSeg, c->maxSeg, img0, nimg);
     else
       LAUNCH(c, "k_lsd_grow", k_lsd_grow, dim3(nimg), dim3(64), 0, c->dP, c->rec, c->order, c->nDefined,
