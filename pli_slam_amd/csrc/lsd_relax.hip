@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256) void k_rx_guess(const float4* __restrict__ rec
 // ---- round bookkeeping -------------------------------------------------------------------------
 // owner_{t-1} against owner_{t-2}: per 8x8 tile the lowest rank that takes part in a change
 __global__ __launch_bounds__(256) void k_rx_diff(RxCtl* __restrict__ ctl, const int2* __restrict__ ownAll,
-                                                 int* __restrict__ tileMinAll, int W, int H, int TW, int TH, int img0) {
+                                                 int* __restrict__ tileMinAll, int* __restrict__ tileActAll, int W, int H,
+                                                 int TW, int TH, int t, int img0) {
   __shared__ int tmin[4];
   const int img = blockIdx.z + img0;
   RxCtl& c = ctl[img];
@@ -139,7 +140,10 @@ __global__ __launch_bounds__(256) void k_rx_diff(RxCtl* __restrict__ ctl, const 
   const int any = __syncthreads_or(ch ? 1 : 0);
   if (tid < 4) {
     const int tx = blockIdx.x * 4 + tid;
-    if (tx < TW) tileMinAll[(int64_t)img * TW * TH + blockIdx.y * TW + tx] = tmin[tid];
+    if (tx < TW) {
+      tileMinAll[(int64_t)img * TW * TH + blockIdx.y * TW + tx] = tmin[tid];
+      if (tmin[tid] != INT_MAX) tileActAll[(int64_t)img * TW * TH + blockIdx.y * TW + tx] = t;   // a changed tile is active
+    }
   }
   if (any && tid == 0) atomicOr(&c.changed, 1);
 }
@@ -229,6 +233,129 @@ __global__ __launch_bounds__(1024) void k_rx_seed(RxCtl* __restrict__ ctl, int2*
       if (pb < bigCap) bigAll[(int64_t)img * bigCap + pb] = sd;
       else c.overflow = 2;                           // (codes: 1 hand-over list, 2 large-seed list, 3 arena, 4 rect list, 5 queue blocks)
     }
+  }
+}
+
+// ---- rounds >= 3: bookkeeping restricted to where something happened ------------------------------------------
+// From round 3 on most of the image is settled.  k_rx_mark looks only at tiles next to a change: a region with a
+// pixel within one pixel of a tile whose change involves a lower rank may see different inputs and is stamped
+// dirty (this is the exact footprint, tighter than the bounding-box rule of k_rx_classify), as are the regions whose
+// seed changed hands (died or newly alive); the tiles under the bounding box of a dirty region become active.
+// k_rx_seed_sparse then rewrites owner_t only in active tiles: everywhere else owner_{t-2} == owner_{t-1} and the
+// owner is carried, i.e. the word that is already there is the right start value.
+__device__ __forceinline__ void rx_mark_dirty(int o, bool withBox, int t, int* __restrict__ rgDirty,
+                                              const int2* __restrict__ rgBox, int* __restrict__ tileAct, int TW, int TH) {
+  if (rgDirty[o] == t) return;
+  if (atomicExch(&rgDirty[o], t) == t) return;      // one marker per region activates the tiles
+  if (!withBox) return;
+  const int2 b = rgBox[o];
+  const int tx0 = min(max((b.x & 0xFFFF) >> 3, 0), TW - 1), ty0 = min(max((b.x >> 16) >> 3, 0), TH - 1);
+  const int tx1 = min(max((b.y & 0xFFFF) >> 3, 0), TW - 1), ty1 = min(max((b.y >> 16) >> 3, 0), TH - 1);
+  for (int ty = ty0; ty <= ty1; ++ty)
+    for (int tx = tx0; tx <= tx1; ++tx) tileAct[ty * TW + tx] = t;
+}
+
+__global__ __launch_bounds__(256) void k_rx_mark(RxCtl* __restrict__ ctl, const int2* __restrict__ ownAll,
+                                                 const int* __restrict__ rankAll, const int2* __restrict__ rgBoxAll,
+                                                 int* __restrict__ rgDirtyAll, const int* __restrict__ tileMinAll,
+                                                 int* __restrict__ tileActAll, int W, int H, int TW, int TH, int t, int img0) {
+  __shared__ int nt[3][6];
+  __shared__ int s_any;
+  const int img = blockIdx.z + img0;
+  RxCtl& c = ctl[img];
+  if (c.state == 2) return;
+  if (c.changed == 0) {                              // owner_{t-1} == owner_{t-2}: exact (every block sees the same flag)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { c.state = 2; c.rounds = t; }
+    return;
+  }
+  const int tid = threadIdx.x;
+  const int* tm = tileMinAll + (int64_t)img * TW * TH;
+  if (tid == 0) s_any = 0;
+  __syncthreads();
+  if (tid < 18) {
+    const int ty = (int)blockIdx.y + tid / 6 - 1, tx = (int)blockIdx.x * 4 + tid % 6 - 1;
+    const int v = (ty >= 0 && ty < TH && tx >= 0 && tx < TW) ? tm[ty * TW + tx] : INT_MAX;
+    nt[tid / 6][tid % 6] = v;
+    if (v != INT_MAX) s_any = 1;
+  }
+  __syncthreads();
+  if (!s_any) return;                                // nothing changed in or next to these four tiles
+  const int x = blockIdx.x * 32 + (tid & 31), y = blockIdx.y * 8 + (tid >> 5);
+  if (x >= W || y >= H) return;
+  const int64_t base = (int64_t)img * W * H;
+  const int r = rankAll[base + y * W + x];
+  if (r == RX_INF) return;
+  const int2 o = ownAll[base + y * W + x];
+  const int ci = t & 1;
+  const int prevv = ci ? o.x : o.y, prev2 = ci ? o.y : o.x;
+  // lowest rank of a change in the tiles within one pixel of (x, y)
+  const int lx = tid & 31, ly = tid >> 5;
+  const int cx0 = (lx + 7) >> 3, cx1 = (lx + 9) >> 3;        // nt column of x-1 and x+1 (nt column 1 = first own tile)
+  const int cy0 = (ly + 7) >> 3, cy1 = (ly + 9) >> 3;
+  const int m = min(min(nt[cy0][cx0], nt[cy0][cx1]), min(nt[cy1][cx0], nt[cy1][cx1]));
+  int* rgDirty = rgDirtyAll + base;
+  const int2* rgBox = rgBoxAll + base;
+  int* tileAct = tileActAll + (int64_t)img * TW * TH;
+  if (m < prevv) rx_mark_dirty(prevv, true, t, rgDirty, rgBox, tileAct, TW, TH);
+  const bool a1 = prevv == r, a2 = prev2 == r;
+  if (a1 != a2) rx_mark_dirty(r, a2, t, rgDirty, rgBox, tileAct, TW, TH);   // died: its last box; newly alive: only this pixel
+}
+
+__global__ __launch_bounds__(256) void k_rx_seed_sparse(RxCtl* __restrict__ ctl, int2* __restrict__ ownAll,
+                                                        const int* __restrict__ rankAll, const float4* __restrict__ recAll,
+                                                        const int* __restrict__ rgSizeAll, const int* __restrict__ rgDirtyAll,
+                                                        const int* __restrict__ tileActAll, RxSeed* __restrict__ smallAll,
+                                                        RxSeed* __restrict__ bigAll, int bigCap, int W, int H, int TW, int TH,
+                                                        int bigThresh, int t, int img0) {
+  __shared__ int scan[17];
+  __shared__ int s_act;
+  const int img = blockIdx.z + img0;
+  RxCtl& c = ctl[img];
+  if (c.state == 2) return;
+  const int tid = threadIdx.x;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) c.changed = 0;
+  if (tid == 0) s_act = 0;
+  __syncthreads();
+  if (tid < 4) {
+    const int tx = blockIdx.x * 4 + tid;
+    if (tx < TW && tileActAll[(int64_t)img * TW * TH + blockIdx.y * TW + tx] == t) s_act = 1;
+  }
+  __syncthreads();
+  if (!s_act) return;
+  const int x = blockIdx.x * 32 + (tid & 31), y = blockIdx.y * 8 + (tid >> 5);
+  const int64_t npix = (int64_t)W * H;
+  const int64_t base = (int64_t)img * npix;
+  const int p = y * W + x;
+  const int ci = t & 1;
+  bool alive = false, big = false;
+  RxSeed sd;
+  if (x < W && y < H) {
+    const int r = rankAll[base + p];
+    if (r != RX_INF) {
+      int2 o = ownAll[base + p];
+      const int prevv = ci ? o.x : o.y;
+      const bool carried = rgDirtyAll[base + prevv] != t;
+      const int cur = carried ? prevv : r;
+      if (cur != (ci ? o.y : o.x)) {
+        if (ci) o.y = cur; else o.x = cur;
+        ownAll[base + p] = o;
+      }
+      alive = prevv == r && !carried;
+      if (alive) {
+        big = rgSizeAll[base + r] >= bigThresh;
+        const float ang = recAll[base + p].x;
+        double sn, cn;
+        sincos((double)ang * RX_DEG2RAD, &sn, &cn);   // see k_rx_seed
+        sd.rank = r; sd.xy = (y << 16) | x; sd.ang = ang; sd.sx = (float)cn; sd.sy = (float)sn;
+      }
+    }
+  }
+  const int ps = rx_block_append(alive && !big, &c.nSmall, scan);
+  if (alive && !big) smallAll[base + ps] = sd;
+  const int pb = rx_block_append(alive && big, &c.nBig, scan);
+  if (alive && big) {
+    if (pb < bigCap) bigAll[(int64_t)img * bigCap + pb] = sd;
+    else c.overflow = 2;
   }
 }
 

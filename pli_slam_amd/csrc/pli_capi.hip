@@ -67,7 +67,7 @@ struct pli_ctx {
   float4* rec = nullptr; int* g2 = nullptr; int* maxG2 = nullptr;
   int2* own = nullptr; RxSeed* smallSeeds = nullptr; RxSeed* bigSeeds = nullptr; int bigCap = 0;
   RxHand* hand = nullptr; int handCap = 0; RxRect* rects = nullptr; int rectCap = 0; int* rankOf = nullptr; int2* rgBox = nullptr; float4* rgSeg = nullptr; uint8_t* rgClean = nullptr;
-  int* tileMin = nullptr; int tilesW = 0, tilesH = 0; int* rxChunkCnt = nullptr; int rxChunks = 0;
+  int* tileMin = nullptr; int* tileAct = nullptr; int* rgDirty = nullptr; int tilesW = 0, tilesH = 0; int* rxChunkCnt = nullptr; int rxChunks = 0;
   int* lastSize = nullptr; int* arena = nullptr; int arenaCap = 0;
   RxCtl* jrCtl = nullptr;
   std::vector<RxCtl> jrHost;
@@ -418,6 +418,8 @@ pli_status allocAll(pli_ctx* c) {
     A(c->rankOf, npix * NR);
     c->tilesW = (P.LW + 7) / 8; c->tilesH = (P.LH + 7) / 8;
     A(c->tileMin, (size_t)c->tilesW * c->tilesH * NR);
+    A(c->tileAct, (size_t)c->tilesW * c->tilesH * NR);
+    A(c->rgDirty, npix * NR);
     c->rxChunks = (int)((npix + 2047) / 2048);
     A(c->rxChunkCnt, (size_t)c->rxChunks * NR);
     c->arenaCap = (int)std::min<size_t>(8 * npix, (size_t)1 << 30);
@@ -549,6 +551,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
              c->regScratch, c->seg, c->nSeg, c->maxSeg, img0, nimg);
   } else {
     const bool trace = getenv("PLI_RX_TRACE") != nullptr;
+    const bool fullPasses = getenv("PLI_RX_FULL") != nullptr;      // dev: full-image bookkeeping in every round
     const bool perRound = getenv("PLI_RX_PROFROUNDS") != nullptr;    // profile names carry the round number
     int curT = 0;
     auto rxn = [&](const char* n) -> const char* {
@@ -573,19 +576,30 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     HIPCHK(hipMemsetAsync(c->jrCtl + img0, 0, sizeof(RxCtl) * nimg, c->stream));
     HIPCHK(hipMemsetAsync(c->rankOf + (int64_t)img0 * npix, 0x7F, sizeof(int) * npix64 * nimg, c->stream));
     HIPCHK(hipMemsetAsync(c->rgClean + (int64_t)img0 * npix, 0, npix64 * nimg, c->stream));   // round stamps
+    HIPCHK(hipMemsetAsync(c->rgDirty + (int64_t)img0 * npix, 0, sizeof(int) * npix64 * nimg, c->stream));
+    HIPCHK(hipMemsetAsync(c->tileAct + (int64_t)img0 * c->tilesW * c->tilesH, 0, sizeof(int) * (size_t)c->tilesW * c->tilesH * nimg, c->stream));
     TRL(c, "k_rx_rank", k_rx_rank, dim3((npix + 255) / 256, nimg), dim3(256), 0, c->order, c->nDefined, c->rankOf, npix64, img0);
     const dim3 raster((P.LW + 255) / 256, P.LH, nimg);
     TRL(c, "k_rx_guess", k_rx_guess, raster, dim3(256), 0, c->rec, c->rankOf, c->own, P.LW, P.LH, precDeg, img0);
     bool allDone = false;
     for (int t = 1; t <= maxRounds && !allDone; ++t) {
       curT = t;
-      TRL(c, "k_rx_diff", k_rx_diff, dim3((P.LW + 31) / 32, c->tilesH, nimg), dim3(256), 0, c->jrCtl, c->own, c->tileMin,
-             P.LW, P.LH, c->tilesW, c->tilesH, img0);
-      if (t >= 2)
-        TRL(c, "k_rx_classify", k_rx_classify, raster, dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->rgBox,
-               c->rgClean, c->tileMin, P.LW, P.LH, c->tilesW, c->tilesH, t, img0);
-      TRL(c, "k_rx_seed", k_rx_seed, dim3((P.LW + 1023) / 1024, P.LH, nimg), dim3(1024), 0, c->jrCtl, c->own, c->rankOf, c->rec, c->lastSize,
-             c->rgClean, c->smallSeeds, c->bigSeeds, c->bigCap, P.LW, P.LH, bigThresh, t, img0);
+      TRL(c, "k_rx_diff", k_rx_diff, dim3((P.LW + 31) / 32, c->tilesH, nimg), dim3(256), 0, c->jrCtl, c->own, c->tileMin, c->tileAct,
+             P.LW, P.LH, c->tilesW, c->tilesH, t, img0);
+      if (t >= 3 && !fullPasses) {
+        // bookkeeping only where something happened (lsd_relax.hip)
+        TRL(c, "k_rx_mark", k_rx_mark, dim3((P.LW + 31) / 32, c->tilesH, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->rgBox,
+            c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0);
+        TRL(c, "k_rx_seed_sparse", k_rx_seed_sparse, dim3((P.LW + 31) / 32, c->tilesH, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf,
+            c->rec, c->lastSize, c->rgDirty, c->tileAct, c->smallSeeds, c->bigSeeds, c->bigCap, P.LW, P.LH, c->tilesW, c->tilesH,
+            bigThresh, t, img0);
+      } else {
+        if (t >= 2)
+          TRL(c, "k_rx_classify", k_rx_classify, raster, dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->rgBox,
+                 c->rgClean, c->tileMin, P.LW, P.LH, c->tilesW, c->tilesH, t, img0);
+        TRL(c, "k_rx_seed", k_rx_seed, dim3((P.LW + 1023) / 1024, P.LH, nimg), dim3(1024), 0, c->jrCtl, c->own, c->rankOf, c->rec, c->lastSize,
+               c->rgClean, c->smallSeeds, c->bigSeeds, c->bigCap, P.LW, P.LH, bigThresh, t, img0);
+      }
       TRL(c, "k_rx_grow", k_rx_grow, dim3(growBlocks, nimg), dim3(256), 0, c->dP, c->jrCtl, c->rec, c->own, c->smallSeeds,
              c->lastSize, c->rgBox, c->hand, c->handCap, c->arena, c->arenaCap, c->rects, c->rectCap, img0, t);
       if (nimg <= 4)
