@@ -155,7 +155,7 @@ def main():
     assert F % S == 0, "--frames-per-gpu must be a multiple of --streams"
     Fs = F // S
     cfg = capi.default_config(W, H, orb_nfeatures=args.nfeatures, lsd_nfeatures=args.nlines, max_frames=Fs,
-                              lsd_mode=args.lsd_mode if args.lsd_mode else (2 if 2 * Fs >= 512 else 1))   # = the library's auto rule
+                              lsd_mode=args.lsd_mode if args.lsd_mode else (2 if 2 * Fs >= 640 else 1))   # = the library's auto rule
     fes = [Frontend(cfg, device=local_rank) for _ in range(S)]
     fe = fes[0]
     # synthetic stream: up to 64 distinct seeded stereo pairs per rank (seeds disjoint across ranks), cycled to F frames

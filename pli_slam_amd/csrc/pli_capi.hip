@@ -33,9 +33,9 @@ inline int cvRoundd(double v) { return (int)std::nearbyint(v); }
 inline int cvFloorf(float v) { int i = (int)v; return i - (i > v); }
 
 // lsd_mode auto: batches of at least this many images (2 per stereo frame) take the sequential wave grower, whose
-// throughput keeps growing with the batch; below it the relaxation is faster (measured: 997 vs 965 frames/s at 256
-// frames, 1044 vs 1644 at 512)
-constexpr int RX_AUTO_IMAGES = 512;
+// throughput keeps growing with the batch; below it the relaxation is faster (measured: 1106 vs 961 frames/s at 256
+// frames, 1141 vs 1287 at 384)
+constexpr int RX_AUTO_IMAGES = 640;
 
 struct ProfEntry { const char* name; hipEvent_t a, b; };
 
