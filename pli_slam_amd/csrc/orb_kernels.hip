@@ -180,8 +180,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams* __restrict_
     return;
   }
   const uint8_t* im = pyr + (int64_t)img * P.pyrBlock + G.offset;
+  // (row, column) of a linear index without an integer division: exact for these sizes (index < 4096, width <= 64)
+  const float invCw = 1.0f / (float)cw, invIw = 1.0f / (float)iw;
   for (int i = tid; i < cw * ch; i += 256) {
-    int y = i / cw, x = i - y * cw;
+    const int y = (int)(((float)i + 0.5f) * invCw), x = i - y * cw;
     tile[y * FT_PITCH + x] = im[(int64_t)(iniY + y) * G.pitch + iniX + x];
   }
   if (tid == 0) s_any = 0;
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams* __restrict_
   const int minTh = P.minTh, iniTh = P.iniTh;
   const int npix = iw * ih;
   for (int i = tid; i < npix; i += 256) {
-    int y = i / iw, x = i - y * iw;
+    const int y = (int)(((float)i + 0.5f) * invIw), x = i - y * iw;
     const uint8_t* p = &tile[(y + 3) * FT_PITCH + x + 3];
     const int v = p[0];
     int d[16];
@@ -221,29 +223,30 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams* __restrict_
     score[y * 64 + x] = (uint8_t)sc;
   }
   __syncthreads();
-  // NMS flags (strictly greater than the 8 neighbours inside the interior), kept in registers per chunk
+  // Non-maximum suppression does not depend on the threshold (a survivor is strictly greater than its 8 neighbours
+  // inside the interior): computed once per corner, kept as bit 7 of ... a flag byte in the (now free) tile buffer.
+  uint8_t* ismax = tile;
   const int nchunks = (npix + 255) / 256;
-  // pass 1: does any survivor reach iniTh ?
   for (int ck = 0; ck < nchunks; ++ck) {
-    int i = ck * 256 + tid;
-    bool surv = false;
+    const int i = ck * 256 + tid;
     if (i < npix) {
-      int y = i / iw, x = i - y * iw;
-      int s = score[y * 64 + x];
-      if (s >= iniTh) {
-        surv = true;
+      const int y = (int)(((float)i + 0.5f) * invIw), x = i - y * iw;
+      const int s = score[y * 64 + x];
+      bool mx = s > 0;
+      if (mx) {
 #pragma unroll
         for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
           for (int dx = -1; dx <= 1; ++dx) {
             if (dx == 0 && dy == 0) continue;
-            int xx = x + dx, yy = y + dy;
-            int n = (xx < 0 || yy < 0 || xx >= iw || yy >= ih) ? 0 : score[yy * 64 + xx];
-            surv = surv && (s > n);
+            const int xx = x + dx, yy = y + dy;
+            const int n = (xx < 0 || yy < 0 || xx >= iw || yy >= ih) ? 0 : score[yy * 64 + xx];
+            mx = mx && (s > n);
           }
       }
+      ismax[i] = mx ? 1 : 0;
+      if (mx && s >= iniTh) s_any = 1;   // benign race: all writers store 1
     }
-    if (surv) s_any = 1;   // benign race: all writers store 1
   }
   __syncthreads();
   const int thr = s_any ? iniTh : 1;     // score > 0 <=> corner at minTh
@@ -252,24 +255,13 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams* __restrict_
   uint32_t* out = cellCand + cellIdx * CELL_CAP;
   const int lane = tid & 63, wv = tid >> 6;
   for (int ck = 0; ck < nchunks; ++ck) {
-    int i = ck * 256 + tid;
+    const int i = ck * 256 + tid;
     bool surv = false;
     int s = 0, x = 0, y = 0;
-    if (i < npix) {
-      y = i / iw; x = i - y * iw;
+    if (i < npix && ismax[i]) {
+      y = (int)(((float)i + 0.5f) * invIw); x = i - y * iw;
       s = score[y * 64 + x];
-      if (s >= thr) {
-        surv = true;
-#pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-          for (int dx = -1; dx <= 1; ++dx) {
-            if (dx == 0 && dy == 0) continue;
-            int xx = x + dx, yy = y + dy;
-            int n = (xx < 0 || yy < 0 || xx >= iw || yy >= ih) ? 0 : score[yy * 64 + xx];
-            surv = surv && (s > n);
-          }
-      }
+      surv = s >= thr;
     }
     unsigned long long bal = __ballot(surv);
     if (lane == 0) s_wcount[wv] = __popcll(bal);
