@@ -250,6 +250,19 @@ def main():
                        "parallelism": "frame-batch data parallel, %d rank(s), gather of result tables to rank 0" % world},
             "roofline": roof,
         }
+        if world == 1 and F > 1:
+            # BASELINE.json configs[1] (a single stereo pair) beside the batch: latency of one pair through the same
+            # library, device buffers, outside the timed region
+            f1 = Frontend(capi.default_config(W, H, orb_nfeatures=args.nfeatures, lsd_nfeatures=args.nlines, max_frames=1),
+                          device=local_rank)
+            f1.set_stream(torch.cuda.current_stream().cuda_stream)
+            t1 = torch.zeros(rec_bytes, dtype=torch.uint8, device=dev)
+            for rep in range(12):
+                if rep == 2:
+                    torch.cuda.synchronize(); ts = time.perf_counter()
+                f1.batch_run_device(1, d_left.data_ptr(), d_right.data_ptr(), W, W * H, t1.data_ptr())
+            torch.cuda.synchronize()
+            out["single_pair"] = {"ms": (time.perf_counter() - ts) / 10 * 1e3, "note": "one stereo pair per call, 10 calls"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(images, bytes(cfg))
         print(json.dumps(out), flush=True)
