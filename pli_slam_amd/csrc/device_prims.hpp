@@ -32,17 +32,14 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
   const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
   const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
-  float ax = fabsf(x), ay = fabsf(y);
-  float a, c, c2;
-  if (ax >= ay) {
-    c = __fdiv_rn(ay, __fadd_rn(ax, (float)DBL_EPSILON));
-    c2 = __fmul_rn(c, c);
-    a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
-  } else {
-    c = __fdiv_rn(ax, __fadd_rn(ay, (float)DBL_EPSILON));
-    c2 = __fmul_rn(c, c);
-    a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
-  }
+  const float ax = fabsf(x), ay = fabsf(y);
+  // one division for both octant cases (the reference's two branches compute min/(max + eps) either way)
+  const bool steep = !(ax >= ay);
+  const float mn = steep ? ax : ay, mx = steep ? ay : ax;
+  const float c = __fdiv_rn(mn, __fadd_rn(mx, (float)DBL_EPSILON));
+  const float c2 = __fmul_rn(c, c);
+  float a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+  if (steep) a = __fsub_rn(90.f, a);
   if (x < 0) a = __fsub_rn(180.f, a);
   if (y < 0) a = __fsub_rn(360.f, a);
   return a;

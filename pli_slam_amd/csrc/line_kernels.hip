@@ -309,11 +309,9 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
         const double ad = (double)r.x * D_DEG2RAD;
         unsigned long long remaining = __ballot(cand);
         while (remaining) {
-          double n_theta = reg_angle - ad;
-          if (n_theta < 0) n_theta = -n_theta;
+          double n_theta = fabs(reg_angle - ad);
           if (n_theta > D_3_2_PI) {
-            n_theta -= D_2PI;
-            if (n_theta < 0) n_theta = -n_theta;
+            n_theta = fabs(n_theta - D_2PI);
           }
           const unsigned long long m = __ballot(cand && n_theta <= prec) & remaining;
           if (!m) break;
@@ -354,11 +352,9 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
         const unsigned myxy = ((unsigned)ny << 16) | (unsigned)nx;
         unsigned long long remaining = __ballot(cand);
         while (remaining) {
-          double n_theta = reg_angle - ad;
-          if (n_theta < 0) n_theta = -n_theta;
+          double n_theta = fabs(reg_angle - ad);
           if (n_theta > D_3_2_PI) {
-            n_theta -= D_2PI;
-            if (n_theta < 0) n_theta = -n_theta;
+            n_theta = fabs(n_theta - D_2PI);
           }
           const unsigned long long m = __ballot(cand && n_theta <= prec) & remaining;
           if (!m) break;

@@ -456,11 +456,9 @@ __global__ __launch_bounds__(256) void k_rx_grow(const DevParams* __restrict__ P
         const int prevv = ci ? no[n].x : no[n].y;
         const int curv = ci ? no[n].y : no[n].x;
         if (prevv < r || curv <= r) continue;          // taken by a lower rank (last round / this round) or already mine
-        double n_theta = reg_angle - (double)nr[n].x * RX_DEG2RAD;
-        if (n_theta < 0) n_theta = -n_theta;
+        double n_theta = fabs(reg_angle - (double)nr[n].x * RX_DEG2RAD);
         if (n_theta > RX_3_2_PI) {
-          n_theta -= RX_2PI;
-          if (n_theta < 0) n_theta = -n_theta;
+          n_theta = fabs(n_theta - RX_2PI);
         }
         if (!(n_theta <= prec)) continue;
         const int m = n < 4 ? n : n + 1;
@@ -658,11 +656,9 @@ __device__ __forceinline__ void rx_grow_groups(const DevParams* __restrict__ Pp,
       unsigned long long rem = (__ballot(cand) >> gbase) & GMASK;      // the group's candidates in test order
       dead = false; accepted = false;
       while (__ballot(rem != 0)) {
-        double n_theta = reg_angle - ad;
-        if (n_theta < 0) n_theta = -n_theta;
+        double n_theta = fabs(reg_angle - ad);
         if (n_theta > RX_3_2_PI) {
-          n_theta -= RX_2PI;
-          if (n_theta < 0) n_theta = -n_theta;
+          n_theta = fabs(n_theta - RX_2PI);
         }
         const unsigned long long m = ((__ballot(cand && n_theta <= prec) >> gbase) & GMASK) & rem;
         if (!m) { rem = 0; continue; }
