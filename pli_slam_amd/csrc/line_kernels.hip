@@ -362,11 +362,11 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
           remaining &= ~((2ull << j2) - 1ull);
           const int qj = rl_i(qi, j2);
           const float cj = rl_f(r.y, j2), sj = rl_f(r.z, j2);
-          const unsigned g2j = (unsigned)__float_as_int(rl_f(r.w, j2));
-          const unsigned xyj = (unsigned)rl_i((int)myxy, j2);
-          if (lane == j2) rec[qi].x = LSD_NOTDEF;
+          if (lane == j2) {                            // lane j2 is in the exec mask: it is a set bit of a ballot
+            rec[qi].x = LSD_NOTDEF;
+            qs[cnt] = make_uint2(myxy, (unsigned)__float_as_int(r.w));
+          }
           remaining &= ~__ballot(qi == qj);            // the other copies of the accepted pixel
-          qs[cnt] = make_uint2(xyj, g2j);              // same value from every active lane
           ++cnt;
           sumdx = __fadd_rn(sumdx, cj);
           sumdy = __fadd_rn(sumdy, sj);
