@@ -167,10 +167,10 @@ __global__ __launch_bounds__(64) void k_lsd_scatter(const int* __restrict__ g2a,
       if (def) bin = lsd_bin(v, bc);
     }
     // lanes with the same bin (match-any by bits: one ballot per bin bit instead of one round per distinct bin)
-    unsigned long long peers = __ballot(def);
+    unsigned long long peers = __builtin_amdgcn_ballot_w64(def);
     for (int b = 0; b < nbits; ++b) {
       const bool bit = (bin >> b) & 1;
-      const unsigned long long bal = __ballot(def && bit);
+      const unsigned long long bal = __builtin_amdgcn_ballot_w64(def && bit);
       peers &= bit ? bal : ~bal;
     }
     int rank = 0, cnt = 0;
@@ -274,7 +274,7 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
       scos = (float)cn;
       ssin = (float)sn;
     }
-    unsigned long long unusedMask = __ballot(srec.x != LSD_NOTDEF);
+    unsigned long long unusedMask = __builtin_amdgcn_ballot_w64(srec.x != LSD_NOTDEF);
     while (unusedMask) {
       const int j = __ffsll((long long)unusedMask) - 1;
       unusedMask &= unusedMask - 1ull;
@@ -286,7 +286,7 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
       const int spy = sp / W, spx = sp - spy * W;
       // single-lane work inside these wave-uniform loops is done by the first ACTIVE lane (or by all lanes with
       // the same value): a fixed lane such as lane 0 is not guaranteed to be in the exec mask here
-      if (lane == __ffsll((long long)__ballot(true)) - 1) rec[sp].x = LSD_NOTDEF;
+      if (lane == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1) rec[sp].x = LSD_NOTDEF;
       qs[0] = make_uint2(((unsigned)spy << 16) | (unsigned)spx, (unsigned)sg2);
       int cnt = 1;
       // One BFS step.  Two copies: while the queue fits in LDS the step touches global memory only for the
@@ -307,13 +307,13 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
         if (inb) r = rec[qi];
         const bool cand = r.x != LSD_NOTDEF;
         const double ad = (double)r.x * D_DEG2RAD;
-        unsigned long long remaining = __ballot(cand);
+        unsigned long long remaining = __builtin_amdgcn_ballot_w64(cand);
         while (remaining) {
           double n_theta = fabs(reg_angle - ad);
           if (n_theta > D_3_2_PI) {
             n_theta = fabs(n_theta - D_2PI);
           }
-          const unsigned long long m = __ballot(cand && n_theta <= prec) & remaining;
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(cand && n_theta <= prec) & remaining;
           if (!m) break;
           const int j2 = __ffsll((long long)m) - 1;
           remaining &= ~((2ull << j2) - 1ull);
@@ -323,12 +323,12 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
           const unsigned xyj = ((unsigned)(py + j2 / 3 - 1) << 16) | (unsigned)(px + j2 % 3 - 1);
           if (lane == j2) rec[qi].x = LSD_NOTDEF;
           if (!SPILL || cnt < LSD_QCAP) qs[cnt] = make_uint2(xyj, g2j);           // same value from every active lane
-          else if (lane == __ffsll((long long)__ballot(true)) - 1) qg[cnt - LSD_QCAP] = make_uint2(xyj, g2j);
+          else if (lane == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1) qg[cnt - LSD_QCAP] = make_uint2(xyj, g2j);
           ++cnt;
           sumdx = __fadd_rn(sumdx, cj);
           sumdy = __fadd_rn(sumdy, sj);
           reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * D_DEG2RAD;
-          unusedMask &= ~__ballot(sp_l == qj);
+          unusedMask &= ~__builtin_amdgcn_ballot_w64(sp_l == qj);
         }
         if (SPILL && cnt > LSD_QCAP) __threadfence_block();   // overflow entries are read back through global memory
       };
@@ -350,13 +350,13 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
         const bool cand = r.x != LSD_NOTDEF;
         const double ad = (double)r.x * D_DEG2RAD;
         const unsigned myxy = ((unsigned)ny << 16) | (unsigned)nx;
-        unsigned long long remaining = __ballot(cand);
+        unsigned long long remaining = __builtin_amdgcn_ballot_w64(cand);
         while (remaining) {
           double n_theta = fabs(reg_angle - ad);
           if (n_theta > D_3_2_PI) {
             n_theta = fabs(n_theta - D_2PI);
           }
-          const unsigned long long m = __ballot(cand && n_theta <= prec) & remaining;
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(cand && n_theta <= prec) & remaining;
           if (!m) break;
           const int j2 = __ffsll((long long)m) - 1;
           remaining &= ~((2ull << j2) - 1ull);
@@ -366,12 +366,12 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
             rec[qi].x = LSD_NOTDEF;
             qs[cnt] = make_uint2(myxy, (unsigned)__float_as_int(r.w));
           }
-          remaining &= ~__ballot(qi == qj);            // the other copies of the accepted pixel
+          remaining &= ~__builtin_amdgcn_ballot_w64(qi == qj);            // the other copies of the accepted pixel
           ++cnt;
           sumdx = __fadd_rn(sumdx, cj);
           sumdy = __fadd_rn(sumdy, sj);
           reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * D_DEG2RAD;
-          unusedMask &= ~__ballot(sp_l == qj);
+          unusedMask &= ~__builtin_amdgcn_ballot_w64(sp_l == qj);
         }
       };
       for (int k = 0; k < cnt;) {
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256) void k_keylines(const DevParams* __restrict__ 
         kl.pt_y = __fdiv_rn(__fadd_rn(e3, e1), 2.f);
       }
     }
-    unsigned long long bal = __ballot(keep);
+    unsigned long long bal = __builtin_amdgcn_ballot_w64(keep);
     if (lane == 0) s_wc[wv] = __popcll(bal);
     __syncthreads();
     int pre = s_base;

@@ -68,7 +68,7 @@ __device__ __forceinline__ double rx_angle_diff(double a, double b) {
 // block (same-address returning atomics serialise at their L2 channel, ~150 ns each).  lds: 17 ints, up to 1024 threads.
 __device__ __forceinline__ int rx_block_append(bool flag, int* counter, int* lds) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
-  const unsigned long long bal = __ballot(flag);
+  const unsigned long long bal = __builtin_amdgcn_ballot_w64(flag);
   if (lane == 0) lds[wv] = __popcll(bal);
   __syncthreads();
   if (tid == 0) {
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void k_rx_grow(const DevParams* __restrict__ P
       by0 = by1 = sd.xy >> 16;
       cnt = 1;
     }
-    while (__ballot(active)) {
+    while (__builtin_amdgcn_ballot_w64(active)) {
       if (!active) continue;
       // ---- one BFS step of this lane's region ----------------------------------------
       const int xy = mq[k * 256 + tid];
@@ -616,7 +616,7 @@ __device__ __forceinline__ void rx_grow_groups(const DevParams* __restrict__ Pp,
       }
     }
     if constexpr (RX_GL == 64) { active = U(active) != 0; exhausted = U(exhausted) != 0; }
-    if (!__ballot(active)) break;
+    if (!__builtin_amdgcn_ballot_w64(active)) break;
     // single-wave block: LDS operations of a wave execute in order, so the queue writes of the last step are
     // visible to the reads below; the compiler only has to keep the order (no s_barrier: __syncthreads would
     // also wait for the claims in flight)
@@ -653,21 +653,21 @@ __device__ __forceinline__ void rx_grow_groups(const DevParams* __restrict__ Pp,
       const int prevv = ci ? oo.x : oo.y, curv = ci ? oo.y : oo.x;
       const bool cand = rr.x != RX_NOTDEF && !(prevv < r || curv <= r);
       const double ad = (double)rr.x * RX_DEG2RAD;
-      unsigned long long rem = (__ballot(cand) >> gbase) & GMASK;      // the group's candidates in test order
+      unsigned long long rem = (__builtin_amdgcn_ballot_w64(cand) >> gbase) & GMASK;      // the group's candidates in test order
       dead = false; accepted = false;
-      while (__ballot(rem != 0)) {
+      while (__builtin_amdgcn_ballot_w64(rem != 0)) {
         double n_theta = fabs(reg_angle - ad);
         if (n_theta > RX_3_2_PI) {
           n_theta = fabs(n_theta - RX_2PI);
         }
-        const unsigned long long m = ((__ballot(cand && n_theta <= prec) >> gbase) & GMASK) & rem;
+        const unsigned long long m = ((__builtin_amdgcn_ballot_w64(cand && n_theta <= prec) >> gbase) & GMASK) & rem;
         if (!m) { rem = 0; continue; }
         const int j2 = __ffsll((long long)m) - 1;
         rem &= ~((2ull << j2) - 1ull);
         const float cj = bcast(rr.y, j2), sj = bcast(rr.z, j2);
         const int xyj = __float_as_int(bcast(__int_as_float(myxy), j2));
         const int qj = __float_as_int(bcast(__int_as_float(qi), j2));
-        rem &= ~((__ballot(qi == qj) >> gbase) & GMASK);             // the other copies of the accepted pixel
+        rem &= ~((__builtin_amdgcn_ballot_w64(qi == qj) >> gbase) & GMASK);             // the other copies of the accepted pixel
         const int ax = xyj & 0xFFFF, ay = xyj >> 16;
         accepted = accepted || gl == j2;               // the claims are issued together after the loop
         if (!SPILL || cnt < RX_GQ) {
@@ -695,7 +695,7 @@ __device__ __forceinline__ void rx_grow_groups(const DevParams* __restrict__ Pp,
         reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * RX_DEG2RAD;
       }
     };
-    if (__ballot(active && cnt + 8 * NP + 1 > RX_GQ)) step(std::true_type{});
+    if (__builtin_amdgcn_ballot_w64(active && cnt + 8 * NP + 1 > RX_GQ)) step(std::true_type{});
     else step(std::false_type{});
     if (accepted) pendOld = __hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (active) {
@@ -906,7 +906,7 @@ __global__ __launch_bounds__(256) void k_rx_emit(const RxCtl* __restrict__ ctl, 
   for (int j = 0; j < RX_CCHUNK / 256; ++j) {
     const int i = blockIdx.x * RX_CCHUNK + j * 256 + tid;
     const bool e = rx_emits(orderAll + img * npix, ownAll + img * npix, rgSizeAll + img * npix, i, n, minReg);
-    const unsigned long long bal = __ballot(e);
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(e);
     __syncthreads();
     if (lane == 0) wsum[wv] = __popcll(bal);
     __syncthreads();
