@@ -250,7 +250,7 @@ def main():
                        "parallelism": "frame-batch data parallel, %d rank(s), gather of result tables to rank 0" % world},
             "roofline": roof,
         }
-        if world == 1 and F > 1:
+        if world == 1 and F > 1 and not args.no_cpu_baseline:
             # BASELINE.json configs[1] (a single stereo pair) beside the batch: latency of one pair through the same
             # library, device buffers, outside the timed region
             f1 = Frontend(capi.default_config(W, H, orb_nfeatures=args.nfeatures, lsd_nfeatures=args.nlines, max_frames=1),
