@@ -293,6 +293,25 @@ pli_status pli_search_local_map(pli_ctx* ctx, const pli_proj_query* q, const uin
 pli_status pli_match_nnr(pli_ctx* ctx, const uint8_t* desc1, int32_t n1, const uint8_t* desc2, int32_t n2, float nnr,
                          int32_t* matches_12, int32_t* nmatches);
 
+/* --- bag-of-words of a frame (Frame::ComputeBoW, Frame.cc:858-870) ---
+ * DBoW2::TemplatedVocabulary<cv::Mat, FORB> (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h): a k-ary tree of 256-bit
+ * descriptors.  pli_vocab_create takes the node list exactly as loadFromTextFile (:1350-1433) reads it from
+ * ORBvoc.txt: node i+1 of the file (node 0 is the root) has parent[i], its 32 descriptor bytes, its weight and its
+ * "is a word" flag; children keep file order; word ids are assigned to flagged nodes in file order. */
+typedef struct pli_vocab pli_vocab;
+pli_status pli_vocab_create(pli_ctx* ctx, int32_t k, int32_t L, int32_t nnodes, const int32_t* parent,
+                            const uint8_t* is_leaf, const uint8_t* desc, const double* weight, pli_vocab** out);
+void pli_vocab_destroy(pli_vocab* v);
+
+/* The per-feature part of transform(features, BowVector&, FeatureVector&, levelsup) (:1139-1208): the descent
+ * transform(feature, id, weight, &nid, levelsup) (:1230-1272) of every descriptor — at each level the child with the
+ * smallest Hamming distance, the first one on ties — giving word_id[i], weight[i] (the word's idf weight; 0 =
+ * stopped word) and node_id[i] (the ancestor at level L - levelsup, 0 if that is the root).  The accumulation into
+ * the two std::maps and the L1 normalisation are done by the caller in feature order (adapters/pli_cpp.hpp does it
+ * with the reference's own arithmetic). */
+pli_status pli_bow_transform(pli_ctx* ctx, const pli_vocab* vocab, const uint8_t* desc, int32_t n, int32_t levelsup,
+                             int32_t* word_id, double* weight, int32_t* node_id);
+
 /* ------------------------------------------------------------------------ */
 /* Measurement hooks (bench.py / tests only).                                */
 /* ------------------------------------------------------------------------ */

@@ -577,4 +577,63 @@ static inline void stereoFromDepth(const pli_keypoint* kp, int n, const float* d
   }
 }
 
+// ---------------------------------------------------------------------------
+// DBoW2::TemplatedVocabulary<cv::Mat, FORB> (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h) as far as
+// Frame::ComputeBoW (Frame.cc:858-870) uses it: the tree as loadFromTextFile builds it (:1350-1433), the
+// descent transform(feature, id, weight, nid, levelsup) (:1230-1272), and
+// transform(features, BowVector, FeatureVector, levelsup) (:1139-1208) for the ORB vocabulary's
+// TF_IDF weighting and L1 scoring (mustNormalize -> BowVector::normalize(L1), BowVector.cpp:59-81).
+// ---------------------------------------------------------------------------
+struct BowVocabulary {
+  struct Node { int parent = 0; std::vector<int> children; uint8_t desc[32] = {0}; double weight = 0; int word_id = -1; };
+  int m_k = 0, m_L = 0;
+  std::vector<Node> m_nodes;
+  int nwords = 0;
+  void load(int k, int L, int n, const int* parent, const uint8_t* isLeaf, const uint8_t* desc, const double* weight) {
+    m_k = k; m_L = L;
+    m_nodes.assign(1, Node());
+    nwords = 0;
+    for (int i = 0; i < n; ++i) {
+      const int nid = (int)m_nodes.size();
+      m_nodes.resize(nid + 1);
+      m_nodes[nid].parent = parent[i];
+      m_nodes[parent[i]].children.push_back(nid);
+      std::memcpy(m_nodes[nid].desc, desc + (size_t)i * 32, 32);
+      m_nodes[nid].weight = weight[i];
+      if (isLeaf[i]) m_nodes[nid].word_id = nwords++;
+    }
+  }
+  void transformFeature(const uint8_t* feature, int& word_id, double& weight, int* nid, int levelsup) const {
+    const int nid_level = m_L - levelsup;
+    if (nid_level <= 0 && nid) *nid = 0;
+    int final_id = 0, current_level = 0;
+    do {
+      ++current_level;
+      const std::vector<int>& nodes = m_nodes[final_id].children;
+      final_id = nodes[0];
+      double best_d = descriptorDistance(feature, m_nodes[final_id].desc);
+      for (size_t j = 1; j < nodes.size(); ++j) {
+        const double d = descriptorDistance(feature, m_nodes[nodes[j]].desc);
+        if (d < best_d) { best_d = d; final_id = nodes[j]; }
+      }
+      if (nid && current_level == nid_level) *nid = final_id;
+    } while (!m_nodes[final_id].children.empty());
+    word_id = m_nodes[final_id].word_id;
+    weight = m_nodes[final_id].weight;
+  }
+  void transform(const uint8_t* features, int n, std::map<unsigned, double>& v, std::map<unsigned, std::vector<unsigned>>& fv,
+                 int levelsup) const {
+    v.clear(); fv.clear();
+    if (m_nodes.size() <= 1) return;
+    for (int i = 0; i < n; ++i) {
+      int id = 0, nid = 0; double w = 0;
+      transformFeature(features + (size_t)i * 32, id, w, &nid, levelsup);
+      if (w > 0) { v[(unsigned)id] += w; fv[(unsigned)nid].push_back((unsigned)i); }     // addWeight / addFeature
+    }
+    double norm = 0.0;                                     // L1, in word order
+    for (auto& kv : v) norm += std::fabs(kv.second);
+    if (norm > 0.0) for (auto& kv : v) kv.second /= norm;
+  }
+};
+
 }  // namespace orc

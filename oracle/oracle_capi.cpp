@@ -252,6 +252,25 @@ int orc_stereo_from_depth(const pli_keypoint* kp, int n, const float* depth, int
   std::memcpy(depthOut, D.data(), (size_t)n * 4);
   return n;
 }
+// DBoW2 vocabulary: per-feature descent and the normalised BowVector (words ascending)
+void* orc_vocab_create(int k, int L, int n, const int* parent, const uint8_t* isLeaf, const uint8_t* desc, const double* weight) {
+  BowVocabulary* v = new BowVocabulary();
+  v->load(k, L, n, parent, isLeaf, desc, weight);
+  return v;
+}
+void orc_vocab_destroy(void* v) { delete (BowVocabulary*)v; }
+int orc_bow_descend(void* vv, const uint8_t* feat, int n, int levelsup, int* word, double* weight, int* node) {
+  const BowVocabulary* v = (const BowVocabulary*)vv;
+  for (int i = 0; i < n; ++i) v->transformFeature(feat + (size_t)i * 32, word[i], weight[i], &node[i], levelsup);
+  return n;
+}
+int orc_bow_vector(void* vv, const uint8_t* feat, int n, int levelsup, unsigned* words, double* values, int cap) {
+  std::map<unsigned, double> bow; std::map<unsigned, std::vector<unsigned>> fv;
+  ((const BowVocabulary*)vv)->transform(feat, n, bow, fv, levelsup);
+  int k = 0;
+  for (auto& kv : bow) { if (k < cap) { words[k] = kv.first; values[k] = kv.second; } ++k; }
+  return k;
+}
 // cv::remap INTER_LINEAR of one 8U image (stereo_euroc.cc:166)
 int orc_remap_linear(const uint8_t* img, int w, int h, int64_t stride, const float* mapx, const float* mapy, uint8_t* dst) {
   Img8 I = wrap(img, w, h, stride), D;

@@ -270,6 +270,37 @@ def search_by_projection(q, qdesc, kp, desc, uright, bounds, check_ori=True):
     return n, best
 
 
+class Vocabulary:
+    """DBoW2 vocabulary tree (node list as in ORBvoc.txt: parent, is-word flag, 32-byte descriptor, weight)."""
+
+    def __init__(self, k, L, parent, is_leaf, desc, weight):
+        parent = np.ascontiguousarray(parent, np.int32); is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+        desc = np.ascontiguousarray(desc, np.uint8); weight = np.ascontiguousarray(weight, np.float64)
+        L_ = lib()
+        L_.orc_vocab_create.restype = C.c_void_p
+        self.h = C.c_void_p(L_.orc_vocab_create(k, L, parent.shape[0], _p(parent), _p(is_leaf), _p(desc), _p(weight)))
+
+    def __del__(self):
+        try:
+            lib().orc_vocab_destroy(self.h)
+        except Exception:
+            pass
+
+    def descend(self, feat, levelsup=4):
+        feat = np.ascontiguousarray(feat, np.uint8)
+        n = feat.shape[0]
+        word = np.zeros(n, np.int32); weight = np.zeros(n, np.float64); node = np.zeros(n, np.int32)
+        lib().orc_bow_descend(self.h, _p(feat), n, levelsup, _p(word), _p(weight), _p(node))
+        return word, weight, node
+
+    def bow_vector(self, feat, levelsup=4):
+        feat = np.ascontiguousarray(feat, np.uint8)
+        n = feat.shape[0]
+        words = np.zeros(max(n, 1), np.uint32); vals = np.zeros(max(n, 1), np.float64)
+        k = lib().orc_bow_vector(self.h, _p(feat), n, levelsup, _p(words), _p(vals), max(n, 1))
+        return words[:k].copy(), vals[:k].copy()
+
+
 def stereo_from_depth(kp, depth, bf):
     kp = np.ascontiguousarray(kp, KEYPOINT_DT)
     d = np.ascontiguousarray(depth, np.float32)

@@ -3,6 +3,8 @@
 // the reference's exact signatures (cv::Mat / cv::KeyPoint / KeyLine) are in
 // orbslam_adapters.hpp and forward to these classes.
 #pragma once
+#include <cmath>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -124,6 +126,47 @@ class Frontend {
   pli_frontend_config cfg_;
   pli_table_layout layout_{};
   pli_ctx* ctx_ = nullptr;
+};
+
+// DBoW2::TemplatedVocabulary<cv::Mat, FORB> as Frame::ComputeBoW uses it (Frame.cc:858-870): the descents run on the
+// device (pli_bow_transform); BowVector::addWeight / FeatureVector::addFeature in feature order and the L1
+// normalisation in word order are the reference's own host arithmetic (TemplatedVocabulary.h:1139-1208,
+// BowVector.cpp:33-81), so the two maps are identical to DBoW2's.
+using BowVector = std::map<unsigned, double>;
+using FeatureVector = std::map<unsigned, std::vector<unsigned>>;
+
+class Vocabulary {
+ public:
+  // node list as loadFromTextFile reads it from ORBvoc.txt: node i+1 has parent[i], isLeaf[i], desc[32*i..], weight[i]
+  Vocabulary(Frontend& fe, int k, int L, int nnodes, const int32_t* parent, const uint8_t* isLeaf, const uint8_t* desc,
+             const double* weight) : fe_(fe) {
+    check(pli_vocab_create(fe.handle(), k, L, nnodes, parent, isLeaf, desc, weight, &v_));
+  }
+  ~Vocabulary() { pli_vocab_destroy(v_); }
+  Vocabulary(const Vocabulary&) = delete;
+  Vocabulary& operator=(const Vocabulary&) = delete;
+
+  // transform(features, v, fv, levelsup) for TF-IDF weighting and L1 scoring (the ORB / LBD vocabularies)
+  void transform(const uint8_t* desc, int n, BowVector& v, FeatureVector& fv, int levelsup) const {
+    v.clear();
+    fv.clear();
+    std::vector<int32_t> word(n), node(n);
+    std::vector<double> w(n);
+    check(pli_bow_transform(fe_.handle(), v_, desc, n, levelsup, word.data(), w.data(), node.data()));
+    for (int i = 0; i < n; ++i)
+      if (w[i] > 0) {                       // not a stopped word
+        v[(unsigned)word[i]] += w[i];
+        fv[(unsigned)node[i]].push_back((unsigned)i);
+      }
+    double norm = 0.0;
+    for (auto& kv : v) norm += std::fabs(kv.second);
+    if (norm > 0.0)
+      for (auto& kv : v) kv.second /= norm;
+  }
+
+ private:
+  Frontend& fe_;
+  pli_vocab* v_ = nullptr;
 };
 
 }  // namespace pli

@@ -106,6 +106,11 @@ _PROTOS = {
                                          C.c_float, C.c_void_p, C.POINTER(C.c_int32)]),
     "pli_match_nnr": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_void_p,
                                   C.POINTER(C.c_int32)]),
+    "pli_vocab_create": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.POINTER(C.c_void_p)]),
+    "pli_vocab_destroy": (None, [C.c_void_p]),
+    "pli_bow_transform": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]),
     "pli_prof_enable": (C.c_int32, [C.c_void_p, C.c_int32]),
     "pli_prof_reset": (C.c_int32, [C.c_void_p]),
     "pli_prof_report": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_int64]),

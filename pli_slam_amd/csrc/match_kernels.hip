@@ -697,4 +697,40 @@ __global__ void k_stereo_from_depth(const DevParams* __restrict__ Pp, const floa
   reinterpret_cast<float*>(table + offDepth)[i] = dp;
 }
 
+// ---------------------------------------------------------------------------
+// DBoW2 vocabulary descent (TemplatedVocabulary.h:1230-1272): one wave per feature; at every level the lanes take
+// one child each (k <= 64), a 64-bit (distance, position) key wave-min picks the nearest child, the first on ties.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_bow_descend(const uint8_t* __restrict__ feat, int n, const int* __restrict__ childOff,
+                                                    const int* __restrict__ childList, const uint8_t* __restrict__ nodeDesc,
+                                                    const int* __restrict__ nodeWord, const double* __restrict__ nodeWeight,
+                                                    int nidLevel, int* __restrict__ wordId, double* __restrict__ weight,
+                                                    int* __restrict__ nodeId) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  if (i >= n) return;
+  uint64_t f[4];
+  load_desc(feat + (int64_t)i * 32, f);
+  int cur = 0, level = 0, nid = 0;
+  for (;;) {
+    const int c0 = childOff[cur], c1 = childOff[cur + 1];
+    if (c0 == c1) break;                                   // Node::isLeaf(): no children
+    ++level;
+    unsigned long long best = ~0ull;
+    for (int c = c0 + lane; c < c1; c += 64) {
+      uint64_t d[4];
+      load_desc(nodeDesc + (int64_t)childList[c] * 32, d);
+      const unsigned long long key = ((unsigned long long)hamming256(f, d) << 32) | (unsigned)(c - c0);
+      best = key < best ? key : best;
+    }
+    best = wave_min_u64(best);
+    cur = childList[c0 + (int)(best & 0xFFFFFFFFull)];
+    if (level == nidLevel) nid = cur;
+  }
+  if (lane == 0) {
+    wordId[i] = nodeWord[cur];
+    weight[i] = nodeWeight[cur];
+    nodeId[i] = nid;
+  }
+}
+
 }  // namespace pli

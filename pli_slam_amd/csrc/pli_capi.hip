@@ -1136,6 +1136,81 @@ pli_status pli_search_local_map(pli_ctx* c, const pli_proj_query* q, const uint8
   return PLI_OK;
 }
 
+// ---- bag of words (DBoW2 vocabulary tree) -------------------------------------
+struct pli_vocab {
+  int device = 0, k = 0, L = 0, nnodes = 0, nwords = 0;     // nnodes counts the root
+  int* childOff = nullptr; int* childList = nullptr; uint8_t* desc = nullptr; int* word = nullptr; double* weight = nullptr;
+};
+
+void pli_vocab_destroy(pli_vocab* v) {
+  if (!v) return;
+  hipSetDevice(v->device);
+  hipFree(v->childOff); hipFree(v->childList); hipFree(v->desc); hipFree(v->word); hipFree(v->weight);
+  delete v;
+}
+
+pli_status pli_vocab_create(pli_ctx* c, int32_t k, int32_t L, int32_t n, const int32_t* parent, const uint8_t* isLeaf,
+                            const uint8_t* desc, const double* weight, pli_vocab** out) {
+  if (!c || !out || n < 1 || !parent || !isLeaf || !desc || !weight || k < 1 || L < 1) { g_err = "bad argument"; return PLI_ERR_INVALID; }
+  *out = nullptr;
+  const int N = n + 1;                                      // + root (TemplatedVocabulary.h:1387)
+  std::vector<int> cnt(N + 1, 0), off(N + 1, 0), list(n), word(N, -1);
+  std::vector<double> w(N, 0.0);
+  std::vector<uint8_t> d((size_t)N * 32, 0);
+  int nwords = 0;
+  for (int i = 0; i < n; ++i) {
+    const int nid = i + 1, pid = parent[i];
+    if (pid < 0 || pid >= nid) { g_err = "vocabulary: a node's parent must precede it"; return PLI_ERR_INVALID; }
+    cnt[pid]++;
+    std::memcpy(&d[(size_t)nid * 32], desc + (size_t)i * 32, 32);
+    w[nid] = weight[i];
+    if (isLeaf[i]) word[nid] = nwords++;                   // word ids in file order (:1421-1427)
+  }
+  for (int i = 0; i < N; ++i) off[i + 1] = off[i] + cnt[i];
+  std::vector<int> fill(off.begin(), off.end() - 1);
+  for (int i = 0; i < n; ++i) list[fill[parent[i]]++] = i + 1;   // children in file order (:1402)
+  for (int i = 1; i < N; ++i)
+    if (cnt[i] == 0 && word[i] < 0) { g_err = "vocabulary: a node without children is not flagged as a word"; return PLI_ERR_INVALID; }
+  HIPCHK(hipSetDevice(c->device));
+  std::unique_ptr<pli_vocab, void (*)(pli_vocab*)> v(new pli_vocab(), pli_vocab_destroy);
+  v->device = c->device; v->k = k; v->L = L; v->nnodes = N; v->nwords = nwords;
+  HIPCHK(hipMalloc(&v->childOff, (size_t)(N + 1) * 4));
+  HIPCHK(hipMalloc(&v->childList, (size_t)n * 4));
+  HIPCHK(hipMalloc(&v->desc, (size_t)N * 32));
+  HIPCHK(hipMalloc(&v->word, (size_t)N * 4));
+  HIPCHK(hipMalloc(&v->weight, (size_t)N * 8));
+  HIPCHK(hipMemcpy(v->childOff, off.data(), (size_t)(N + 1) * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(v->childList, list.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(v->desc, d.data(), (size_t)N * 32, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(v->word, word.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(v->weight, w.data(), (size_t)N * 8, hipMemcpyHostToDevice));
+  *out = v.release();
+  return PLI_OK;
+}
+
+pli_status pli_bow_transform(pli_ctx* c, const pli_vocab* v, const uint8_t* desc, int32_t n, int32_t levelsup, int32_t* wordId,
+                             double* weight, int32_t* nodeId) {
+  if (!c || !v || n < 0 || (n > 0 && (!desc || !wordId || !weight || !nodeId))) { g_err = "bad argument"; return PLI_ERR_INVALID; }
+  if (n == 0) return PLI_OK;
+  HIPCHK(hipSetDevice(c->device));
+  const size_t bd = alignUp((size_t)n * 32, 256), bw = alignUp((size_t)n * 4, 256), bf = alignUp((size_t)n * 8, 256);
+  pli_status st = ensureScratch(c, bd + 2 * bw + bf);
+  if (st != PLI_OK) return st;
+  uint8_t* p = (uint8_t*)c->scratch;
+  uint8_t* dd = p; p += bd;
+  double* dwt = (double*)p; p += bf;
+  int* dword = (int*)p; p += bw;
+  int* dnode = (int*)p;
+  HIPCHK(hipMemcpyAsync(dd, desc, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
+  LAUNCH(c, "k_bow_descend", k_bow_descend, dim3(n), dim3(64), 0, dd, n, v->childOff, v->childList, v->desc, v->word, v->weight,
+         v->L - levelsup, dword, dwt, dnode);
+  HIPCHK(hipMemcpyAsync(wordId, dword, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(weight, dwt, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(nodeId, dnode, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return PLI_OK;
+}
+
 // ---- measurement -----------------------------------------------------------
 pli_status pli_prof_enable(pli_ctx* c, int32_t on) {
   if (!c) return PLI_ERR_INVALID;

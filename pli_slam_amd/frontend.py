@@ -136,6 +136,25 @@ class Frontend:
                                               int(check_orientation), ptr(best), C.byref(n)))
         return n.value, best
 
+    def vocab_create(self, k, L, parent, is_leaf, desc, weight):
+        """DBoW2 vocabulary (node list as in ORBvoc.txt); returns an opaque handle for bow_transform."""
+        parent = np.ascontiguousarray(parent, np.int32); is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+        desc = np.ascontiguousarray(desc, np.uint8); weight = np.ascontiguousarray(weight, np.float64)
+        h = C.c_void_p()
+        check(self.L.pli_vocab_create(self.h, k, L, parent.shape[0], ptr(parent), ptr(is_leaf), ptr(desc), ptr(weight), C.byref(h)))
+        return h
+
+    def vocab_destroy(self, h):
+        self.L.pli_vocab_destroy(h)
+
+    def bow_transform(self, vocab, desc, levelsup=4):
+        """Per-feature descent of DBoW2's transform(): (word_id, weight, node_id) arrays."""
+        d = np.ascontiguousarray(desc, np.uint8)
+        n = d.shape[0]
+        word = np.zeros(n, np.int32); weight = np.zeros(n, np.float64); node = np.zeros(n, np.int32)
+        check(self.L.pli_bow_transform(self.h, vocab, ptr(d), n, levelsup, ptr(word), ptr(weight), ptr(node)))
+        return word, weight, node
+
     def stereo_from_depth(self, depth):
         """Frame::ComputeStereoFromRGBD (Frame.cc:1309): (mvuRight, mvDepth) of the left keypoints from a float depth image."""
         d = np.ascontiguousarray(depth, np.float32)

@@ -144,3 +144,29 @@ def rectify_maps(eye, width=752, height=480, calib=None):
     xd = x * kr + p1 * _2xy + p2 * (r2 + 2 * x2)
     yd = y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy
     return (K[0, 0] * xd + K[0, 2]).astype(np.float32), (K[1, 1] * yd + K[1, 2]).astype(np.float32)
+
+
+def make_vocabulary(k=10, L=3, seed=0, ragged=True, stop_fraction=0.05):
+    """A random DBoW2-style vocabulary tree in ORBvoc.txt node order (breadth-first, like DBoW2's HKmeansStep output):
+    returns (k, L, parent, is_leaf, desc, weight).  `ragged`: some inner nodes get fewer than k children and some
+    branches end early (the real file is not a complete tree either); a fraction of the words is stopped (weight 0)."""
+    rng = np.random.default_rng(seed)
+    parent, is_leaf, desc, weight = [], [], [], []
+    frontier = [(0, 0, rng.integers(0, 256, 32, dtype=np.uint8))]            # (node id, level, descriptor)
+    next_id = 1
+    while frontier:
+        nid, lvl, d = frontier.pop(0)
+        nchild = k if not ragged else int(rng.integers(2, k + 1))
+        for _ in range(nchild):
+            cd = d.copy()
+            flips = rng.integers(0, 256, size=max(1, 48 >> lvl))                # children are perturbed copies of the parent
+            for b in flips:
+                cd[b >> 3] ^= np.uint8(1 << (b & 7))
+            leaf = (lvl + 1 == L) or (ragged and lvl + 1 >= 2 and rng.random() < 0.1)
+            parent.append(nid); is_leaf.append(1 if leaf else 0); desc.append(cd)
+            weight.append(0.0 if (leaf and rng.random() < stop_fraction) else (float(rng.uniform(0.5, 9.0)) if leaf else 0.0))
+            if not leaf:
+                frontier.append((next_id, lvl + 1, cd))
+            next_id += 1
+    return (k, L, np.array(parent, np.int32), np.array(is_leaf, np.uint8), np.stack(desc).astype(np.uint8),
+            np.array(weight, np.float64))

@@ -431,6 +431,45 @@ def test_full_size_batch_properties(gpu):
         assert_frame_equal(g, fe.parse_record(t1, F - U + i), g.po.Frame(ocfg(g, cfg)), pairs[i][0], pairs[i][1], "pair %d" % i)
 
 
+def test_bow_vocabulary_descent(gpu):
+    """SURVEY §8f-2: the per-feature part of DBoW2's transform (Frame::ComputeBoW, Frame.cc:858) on synthetic
+    vocabularies of ORBvoc.txt shape (k = 10; ragged trees, stopped words), ORB and LBD descriptors of a real frame."""
+    g = gpu
+    W, H = 752, 480
+    cfg = g.capi.default_config(W, H, orb_nfeatures=1200, lsd_nfeatures=0)
+    fe = g.Frontend(cfg)
+    L_, _ = g.synth.make_stereo_pair(5, W, H)
+    _, _, orb = fe.orb_extract(0, L_)
+    _, _, lbd = fe.line_extract(0, L_)
+    for (k, depth, seed, ragged) in ((10, 4, 1, True), (10, 3, 2, False), (3, 6, 3, True), (64, 2, 4, False)):
+        vk, vL, parent, is_leaf, vdesc, weight = g.synth.make_vocabulary(k, depth, seed, ragged)
+        ov = g.po.Vocabulary(vk, vL, parent, is_leaf, vdesc, weight)
+        gv = fe.vocab_create(vk, vL, parent, is_leaf, vdesc, weight)
+        rng = np.random.default_rng(seed)
+        near = vdesc[rng.integers(0, len(vdesc), 300)].copy()            # descriptors near tree nodes: deep, tie-rich descents
+        near[:, rng.integers(0, 32)] ^= 0x11
+        for feats in (orb, lbd, near, vdesc[:50]):
+            for levelsup in (4, 1, 0, 9):
+                word, wt, node = fe.bow_transform(gv, feats, levelsup)
+                oword, owt, onode = ov.descend(feats, levelsup)
+                assert np.array_equal(word, oword) and np.array_equal(node, onode) and wt.tobytes() == owt.tobytes()
+            # the caller's accumulation (BowVector::addWeight in feature order, L1 norm in word order) on the device result
+            word, wt, node = fe.bow_transform(gv, feats, 4)
+            bow = {}
+            for w_, v_ in zip(word.tolist(), wt.tolist()):
+                if v_ > 0:
+                    bow[w_] = bow.get(w_, 0.0) + v_
+            norm = 0.0
+            for w_ in sorted(bow):
+                norm += abs(bow[w_])
+            ws, vals = ov.bow_vector(feats, 4)
+            assert sorted(bow) == ws.tolist()
+            assert np.array([bow[w_] / norm for w_ in sorted(bow)], np.float64).tobytes() == vals.tobytes()
+        fe.vocab_destroy(gv)
+    w0, _, _ = fe.bow_transform(fe.vocab_create(*g.synth.make_vocabulary(10, 3, 7)), orb[:0], 4)
+    assert len(w0) == 0
+
+
 def test_rgbd_depth_association(gpu):
     """SURVEY §8f-4: Frame::ComputeStereoFromRGBD (Frame.cc:1309) on the left keypoints."""
     g = gpu

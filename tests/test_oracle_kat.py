@@ -304,3 +304,29 @@ def test_remap_linear_properties(oracle):
     assert (far == 0).all()
     q = oracle.remap_linear(img, xx + np.float32(1 / 64), yy)              # cvRound(x*32 + 0.5): ties to even
     assert np.array_equal(q[:, 0::2][:, :27], img[:, 0::2][:, :27])        # even x: 32x+0.5 -> 32x
+
+
+def test_bow_vocabulary_descent_and_vector(oracle):
+    """DBoW2 transform (TemplatedVocabulary.h:1139-1272) on a hand-made tree: nearest child, first one on ties,
+    node at level L - levelsup, stopped words, TF-IDF sums and L1 normalisation in word order."""
+    z = np.zeros(32, np.uint8)
+    def d(*bits):
+        v = z.copy()
+        for b in bits:
+            v[b >> 3] |= 1 << (b & 7)
+        return v
+    # root -> A(1), B(2); A -> a0(3), a1(4); B -> b0(5), b1(6)     (file order = breadth first); L = 2
+    parent = [0, 0, 1, 1, 2, 2]
+    is_leaf = [0, 0, 1, 1, 1, 1]
+    desc = [d(), d(0, 1, 2, 3), d(8), d(9), d(0, 1, 2, 3, 8), d(0, 1, 2, 3, 9)]
+    weight = [0, 0, 2.0, 0.0, 3.0, 5.0]                                  # a1 is a stopped word
+    v = oracle.Vocabulary(2, 2, parent, is_leaf, np.stack(desc), weight)
+    f = np.stack([d(8), d(9), d(0, 1, 2, 3, 8), d(0, 1), d(0, 1, 2, 3, 9), d(0, 1, 2, 3, 9)])
+    word, wt, node = v.descend(f, levelsup=1)
+    assert word.tolist() == [0, 1, 2, 0, 3, 3]                            # d(0,1): tie between A and B -> A (first), then a0/a1 tie -> a0
+    assert wt.tolist() == [2.0, 0.0, 3.0, 2.0, 5.0, 5.0]
+    assert node.tolist() == [1, 1, 2, 1, 2, 2]                            # level L - 1 = 1
+    assert v.descend(f, levelsup=2)[2].tolist() == [0] * 6                # level 0: the root
+    words, vals = v.bow_vector(f, levelsup=1)
+    assert words.tolist() == [0, 2, 3]                                    # the stopped word does not appear
+    assert vals.tolist() == [4.0 / 17.0, 3.0 / 17.0, 10.0 / 17.0]
