@@ -11,7 +11,8 @@ bad = 0
 for (W, H) in ((752, 480), (640, 480), (1280, 720), (320, 200)):
     fes = {m: Frontend(capi.default_config(W, H, lsd_nfeatures=0, max_frames=1, lsd_mode=m)) for m in (1, 2)}
     fr = po.Frame(po.Config.from_buffer_copy(bytes(fes[1].cfg)))
-    for seed in range(100, 100 + (6 if W < 1000 else 3)):
+    base = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    for seed in range(base, base + (6 if W < 1000 else 3)):
         L, R = synth.make_stereo_pair(seed, W, H)
         for img in (L, R):
             m, okl, old = fr.line_extract(0, img)
