@@ -172,6 +172,24 @@ def test_other_shapes_and_parameters(gpu, seed, W, H, nf, nl):
     assert_frame_equal(g, rec, g.po.Frame(ocfg(g, cfg)), L, R, "seed %d %dx%d" % (seed, W, H))
 
 
+@pytest.mark.parametrize("over", [
+    dict(orb_scale_factor=1.5, orb_nlevels=5, orb_ini_th_fast=30, orb_min_th_fast=10, lsd_scale=1.0, lsd_ang_th=15.0),
+    dict(orb_scale_factor=1.1, orb_nlevels=10, lsd_scale=0.8, lsd_quant=1.0, lsd_n_bins=512, min_line_length=0.05),
+    dict(orb_nlevels=3, lsd_scale=1.5, lsd_sigma_scale=0.8, lsd_ang_th=30.0, lsd_mode=2, matching_s_ws=5, line_sim_th=0.6,
+         best_lr_matches=0),
+])
+def test_non_default_algorithm_parameters(gpu, over):
+    """The yaml-tunable parameters of both extractors and the line matcher away from their defaults
+    (pyramid shape, FAST thresholds, LSD scale = 1 / < 1 / > 1, angle tolerance, quantisation, bins, length cut)."""
+    g = gpu
+    W, H = 640, 400
+    cfg = g.capi.default_config(W, H, orb_nfeatures=700, lsd_nfeatures=0, max_frames=1, **over)
+    L, R = g.synth.make_stereo_pair(9, W, H)
+    rec = g.Frontend(cfg).batch_run_host(np.stack([L, R])[None])[0]
+    assert_frame_equal(g, rec, g.po.Frame(ocfg(g, cfg)), L, R, str(over))
+    assert len(rec["kpL"]) > 100 and len(rec["klL"]) > 20
+
+
 # ---------------------------------------------------------------------------------------------
 # config 3: 1280x720, 8 levels, 2000 kp + 200 lines, frame-to-frame track match
 # ---------------------------------------------------------------------------------------------
