@@ -157,7 +157,8 @@ pli_status pli_ctx_sync(pli_ctx* ctx);
 /* stereo pairs in one go — ExtractORB x2, ExtractLine x2 (Frame.cc:128-135),*/
 /* ComputeStereoMatches_Lines (:160), ComputeStereoMatches (:163).           */
 /* Images: device pointers, u8, row stride `stride`, consecutive frames      */
-/* `frame_stride` bytes apart.  Output: `dev_table` = nframes records.       */
+/* `frame_stride` bytes apart (no alignment needed).  Output: `dev_table` =  */
+/* nframes records, 16-byte aligned (PLI_ERR_INVALID otherwise).             */
 /* Asynchronous on the context stream; pli_ctx_sync() to wait.               */
 /* ------------------------------------------------------------------------ */
 enum {

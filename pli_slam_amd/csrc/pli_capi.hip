@@ -48,6 +48,7 @@ struct pli_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool ownStream = true;
+  bool syncDebug = getenv("PLI_SYNC_DEBUG") != nullptr;
   int NI = 0;
   pli_table_layout lay;
   std::vector<void*> allocs;
@@ -132,6 +133,11 @@ struct pli_ctx {
     hipLaunchKernelGGL(kern, grid, block, shmem, (c)->stream, __VA_ARGS__);  \
     (c)->profEnd();                                                          \
     HIPCHK(hipGetLastError());                                               \
+    if ((c)->syncDebug) {   /* PLI_SYNC_DEBUG: find the kernel that faults */ \
+      std::fprintf(stderr, "[pli] %s ...", name);                            \
+      HIPCHK(hipStreamSynchronize((c)->stream));                             \
+      std::fprintf(stderr, " ok\n");                                         \
+    }                                                                        \
   } while (0)
 
 namespace {
@@ -807,6 +813,7 @@ pli_status pli_batch_run(pli_ctx* c, int32_t nframes, const uint8_t* dl, const u
   if (!c || !dl || !dr || !table) { g_err = "null argument"; return PLI_ERR_INVALID; }
   if (nframes < 1 || nframes > c->cfg.max_frames) { g_err = "nframes exceeds the context's max_frames"; return PLI_ERR_INVALID; }
   if (stride < c->cfg.width) { g_err = "stride < width"; return PLI_ERR_INVALID; }
+  if (((uintptr_t)table & 15) != 0) { g_err = "the table must be 16-byte aligned"; return PLI_ERR_INVALID; }
   HIPCHK(hipSetDevice(c->device));
   uint8_t* T = (uint8_t*)table;
   pli_status st;
@@ -826,11 +833,12 @@ pli_status pli_batch_run_host(pli_ctx* c, int32_t nframes, const uint8_t* left, 
   HIPCHK(hipSetDevice(c->device));
   const int W = c->cfg.width, H = c->cfg.height;
   const size_t imgBytes = (size_t)W * H;
-  pli_status st = ensureScratch(c, 2 * imgBytes * nframes + (size_t)c->lay.record_bytes * nframes);
+  const size_t imgsBytes = alignUp(2 * imgBytes * nframes, 256);     // the table needs its natural alignment (odd image sizes!)
+  pli_status st = ensureScratch(c, imgsBytes + (size_t)c->lay.record_bytes * nframes);
   if (st != PLI_OK) return st;
   uint8_t* dl = (uint8_t*)c->scratch;
   uint8_t* dr = dl + imgBytes * nframes;
-  uint8_t* dt = dr + imgBytes * nframes;
+  uint8_t* dt = dl + imgsBytes;
   for (int f = 0; f < nframes; ++f) {
     HIPCHK(hipMemcpy2DAsync(dl + imgBytes * f, W, left + (int64_t)f * frameStride, stride, W, H, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpy2DAsync(dr + imgBytes * f, W, right + (int64_t)f * frameStride, stride, W, H, hipMemcpyHostToDevice, c->stream));

@@ -163,7 +163,7 @@ def test_golden_vectors_small(gpu):
 
 
 @pytest.mark.parametrize("seed,W,H,nf,nl", [(1, 752, 480, 1000, 500), (2, 640, 480, 800, 0), (3, 376, 240, 500, 60),
-                                           (4, 200, 136, 150, 30)])
+                                           (4, 200, 136, 150, 30), (5, 643, 481, 600, 0), (6, 333, 245, 300, 40)])
 def test_other_shapes_and_parameters(gpu, seed, W, H, nf, nl):
     g = gpu
     cfg = g.capi.default_config(W, H, orb_nfeatures=nf, lsd_nfeatures=nl, max_frames=1)
@@ -356,6 +356,15 @@ def test_edge_cases(gpu):
         fe.orb_extract(0, np.zeros((H + 1, W), np.uint8))
     assert g.capi.lib().pli_batch_run(fe.h, 1, None, None, W, W * H, 15, None) == -1
     assert g.capi.lib().pli_batch_run_host(fe.h, 5, C.c_void_p(1), C.c_void_p(1), W, W * H, 15, C.c_void_p(1)) == -1   # > max_frames
+    # a result table that is not 16-byte aligned is refused (the records hold 8-byte fields)
+    import torch
+    dimg = torch.zeros(2 * W * H, dtype=torch.uint8, device="cuda")
+    dtab = torch.zeros(fe.table_bytes(1) + 16, dtype=torch.uint8, device="cuda")
+    assert g.capi.lib().pli_batch_run(fe.h, 1, C.c_void_p(dimg.data_ptr()), C.c_void_p(dimg.data_ptr() + W * H), W, W * H, 15,
+                                      C.c_void_p(dtab.data_ptr() + 1)) == -1
+    assert g.capi.lib().pli_batch_run(fe.h, 1, C.c_void_p(dimg.data_ptr()), C.c_void_p(dimg.data_ptr() + W * H), W, W * H, 15,
+                                      C.c_void_p(dtab.data_ptr() + 16)) == 0
+    fe.sync()
     # one eye featureless: left has features, right is blank -> no stereo, still consistent with the oracle
     L, _ = g.synth.make_stereo_pair(12, W, H)
     rec = fe.batch_run_host(np.stack([L, blank])[None])[0]
