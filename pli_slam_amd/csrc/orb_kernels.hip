@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void k_octree(const DevParams* __restrict__ Pp
   }
   if (n > G.candCap) n = G.candCap;
   if (tid == 0) candCount[lc] = n;
-  if (n == 0 || G.nIni <= 0 || N <= 0) {
+  if (n == 0 || G.nIni <= 0) {     // (a quota of 0 still runs the first expansion, like the reference loop)
     if (tid == 0) kpSelCount[lc] = 0;
     return;
   }

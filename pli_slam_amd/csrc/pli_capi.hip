@@ -718,8 +718,19 @@ void pli_config_default(pli_frontend_config* c, int32_t width, int32_t height) {
 }
 
 int32_t pli_kp_capacity(const pli_frontend_config* c) {
-  // DistributeOctTree can return up to quota+3 keypoints per level (ORBextractor.cc:713-733)
-  return (int32_t)alignUp((int64_t)c->orb_nfeatures + 4 * c->orb_nlevels + 8, 64);
+  // DistributeOctTree returns up to quota+3 keypoints per level (ORBextractor.cc:713-733) — or, when the quota is tiny,
+  // the 4 children of each of its nIni = round(width/height) root nodes (:540-589, first expansion)
+  int64_t extra = 0;
+  float sc = 1.0f;
+  for (int l = 0; l < c->orb_nlevels; ++l) {
+    const float inv = 1.0f / sc;
+    const int w = cvRoundf((float)c->width * inv), h = cvRoundf((float)c->height * inv);
+    const int bw = w - 32, bh = h - 32;                     // maxBorder - minBorder, EDGE_THRESHOLD - 3 = 16 each side
+    const int nIni = (bw > 0 && bh > 0) ? (int)std::round((float)bw / (float)bh) : 0;
+    extra += std::max(4, 4 * nIni);
+    sc *= c->orb_scale_factor;
+  }
+  return (int32_t)alignUp((int64_t)c->orb_nfeatures + extra + 8, 64);
 }
 int32_t pli_kl_capacity(const pli_frontend_config* c) { return c->lsd_nfeatures != 0 ? c->lsd_nfeatures : c->max_lines; }
 

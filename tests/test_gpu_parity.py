@@ -172,6 +172,24 @@ def test_other_shapes_and_parameters(gpu, seed, W, H, nf, nl):
     assert_frame_equal(g, rec, g.po.Frame(ocfg(g, cfg)), L, R, "seed %d %dx%d" % (seed, W, H))
 
 
+def test_tiny_budgets_and_small_images(gpu):
+    """A per-level quota of 0-3 keypoints (DistributeOctTree still expands its root nodes once: up to 4 * nIni per
+    level, ORBextractor.cc:540-589) and images whose top pyramid levels have no FAST cells at all."""
+    g = gpu
+    W, H = 376, 240
+    L, R = g.synth.make_stereo_pair(4, W, H)
+    cfg = g.capi.default_config(W, H, orb_nfeatures=12, lsd_nfeatures=3)
+    rec = g.Frontend(cfg).batch_run_host(np.stack([L, R])[None])[0]
+    assert_frame_equal(g, rec, g.po.Frame(ocfg(g, cfg)), L, R, "12 keypoints")
+    assert len(rec["kpL"]) > 12                                           # more than asked for, like the reference
+    L4, R4 = g.synth.make_stereo_pair(3, 512, 384)
+    for step, (w, h) in ((4, (128, 96)), (2, (256, 192))):
+        Ls, Rs = np.ascontiguousarray(L4[::step, ::step]), np.ascontiguousarray(R4[::step, ::step])
+        cfg = g.capi.default_config(w, h, orb_nfeatures=200, lsd_nfeatures=0)
+        rec = g.Frontend(cfg).batch_run_host(np.stack([Ls, Rs])[None])[0]
+        assert_frame_equal(g, rec, g.po.Frame(ocfg(g, cfg)), Ls, Rs, "%dx%d" % (w, h))
+
+
 @pytest.mark.parametrize("over", [
     dict(orb_scale_factor=1.5, orb_nlevels=5, orb_ini_th_fast=30, orb_min_th_fast=10, lsd_scale=1.0, lsd_ang_th=15.0),
     dict(orb_scale_factor=1.1, orb_nlevels=10, lsd_scale=0.8, lsd_quant=1.0, lsd_n_bins=512, min_line_length=0.05),
