@@ -301,7 +301,8 @@ __global__ __launch_bounds__(256) void k_rx_mark(RxCtl* __restrict__ ctl, const 
   if (a1 != a2) rx_mark_dirty(r, a2, t, rgDirty, rgBox, tileAct, TW, TH);   // died: its last box; newly alive: only this pixel
 }
 
-__global__ __launch_bounds__(256) void k_rx_seed_sparse(RxCtl* __restrict__ ctl, int2* __restrict__ ownAll,
+// (32 x 32 pixels = 16 tiles per block: one list atomic per 1024 pixels)
+__global__ __launch_bounds__(1024) void k_rx_seed_sparse(RxCtl* __restrict__ ctl, int2* __restrict__ ownAll,
                                                         const int* __restrict__ rankAll, const float4* __restrict__ recAll,
                                                         const int* __restrict__ rgSizeAll, const int* __restrict__ rgDirtyAll,
                                                         const int* __restrict__ tileActAll, RxSeed* __restrict__ smallAll,
@@ -316,13 +317,13 @@ __global__ __launch_bounds__(256) void k_rx_seed_sparse(RxCtl* __restrict__ ctl,
   if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) c.changed = 0;
   if (tid == 0) s_act = 0;
   __syncthreads();
-  if (tid < 4) {
-    const int tx = blockIdx.x * 4 + tid;
-    if (tx < TW && tileActAll[(int64_t)img * TW * TH + blockIdx.y * TW + tx] == t) s_act = 1;
+  if (tid < 16) {
+    const int tx = blockIdx.x * 4 + (tid & 3), ty = blockIdx.y * 4 + (tid >> 2);
+    if (tx < TW && ty < TH && tileActAll[(int64_t)img * TW * TH + ty * TW + tx] == t) s_act = 1;
   }
   __syncthreads();
   if (!s_act) return;
-  const int x = blockIdx.x * 32 + (tid & 31), y = blockIdx.y * 8 + (tid >> 5);
+  const int x = blockIdx.x * 32 + (tid & 31), y = blockIdx.y * 32 + (tid >> 5);
   const int64_t npix = (int64_t)W * H;
   const int64_t base = (int64_t)img * npix;
   const int p = y * W + x;

@@ -596,7 +596,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
         // bookkeeping only where something happened (lsd_relax.hip)
         TRL(c, "k_rx_mark", k_rx_mark, dim3((P.LW + 31) / 32, c->tilesH, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->rgBox,
             c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0);
-        TRL(c, "k_rx_seed_sparse", k_rx_seed_sparse, dim3((P.LW + 31) / 32, c->tilesH, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf,
+        TRL(c, "k_rx_seed_sparse", k_rx_seed_sparse, dim3((P.LW + 31) / 32, (P.LH + 31) / 32, nimg), dim3(1024), 0, c->jrCtl, c->own, c->rankOf,
             c->rec, c->lastSize, c->rgDirty, c->tileAct, c->smallSeeds, c->bigSeeds, c->bigCap, P.LW, P.LH, c->tilesW, c->tilesH,
             bigThresh, t, img0);
       } else {
