@@ -169,21 +169,28 @@ def main():
     d_left, d_right = d_img[:, 0].contiguous(), d_img[:, 1].contiguous()
     rec_bytes = int(fe.layout.record_bytes)
     d_table = torch.zeros(F * rec_bytes, dtype=torch.uint8, device=dev)
-    from pli_slam_amd.sharding import gather_tables
+    from pli_slam_amd.sharding import TableGatherer
+    # N > 1: the result tables are gathered to rank 0 over RCCL, double buffered, so that the gather of one step travels
+    # while the kernels of the next run; every gather is complete before the closing barrier of the timed region
+    gath = TableGatherer(F * rec_bytes, dev) if world > 1 else None
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(S - 1)]
     for f_, st_ in zip(fes, streams):
         f_.set_stream(st_.cuda_stream)
 
     def step():
+        slot = gath.acquire() if gath else 0
+        tbl = gath.table(slot) if gath else d_table
         for i, f_ in enumerate(fes):
             f_.batch_run_device(Fs, d_left[i * Fs:].data_ptr(), d_right[i * Fs:].data_ptr(), W, W * H,
-                                d_table[i * Fs * rec_bytes:].data_ptr())
+                                tbl[i * Fs * rec_bytes:].data_ptr())
         for st_ in streams[1:]:
             torch.cuda.current_stream().wait_stream(st_)
-        if world > 1:
-            gather_tables(d_table, rec_bytes, F, dst=0, counts=[F] * world)     # RCCL gather of the per-frame tables to rank 0
+        if gath:
+            gath.submit(slot)
 
     def fence():
+        if gath:
+            gath.drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

@@ -46,3 +46,55 @@ def gather_tables(table, record_bytes, nframes_local, dst=0, group=None, counts=
     if rank != dst:
         return None
     return [b[: n * record_bytes] for b, n in zip(bufs, all_counts)]
+
+
+class TableGatherer:
+    """Double-buffered, asynchronous gather of equal-sized shards to rank `dst`: the gather of step i travels over
+    xGMI while the kernels of step i+1 run (a result table is only waited for when its buffer is reused).
+
+        g = TableGatherer(record_bytes * frames_per_rank, device)
+        for i in range(steps):
+            slot = g.acquire()            # waits for the gather that last used this slot
+            ... launch the kernels that fill  g.table(slot) ...
+            g.submit(slot)
+        g.drain()                         # all gathers done; on dst, g.gathered(slot) holds every rank's table
+    """
+
+    def __init__(self, table_bytes, device, depth=2, dst=0, group=None):
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.dst, self.group, self.depth = dst, group, depth
+        self.tables = [torch.zeros(table_bytes, dtype=torch.uint8, device=device) for _ in range(depth)]
+        self.bufs = [None] * depth
+        if self.world > 1 and self.rank == dst:
+            self.bufs = [[torch.empty(table_bytes, dtype=torch.uint8, device=device) for _ in range(self.world)]
+                         for _ in range(depth)]
+        self.works = [None] * depth
+        self.next = 0
+
+    def table(self, slot):
+        return self.tables[slot]
+
+    def acquire(self):
+        slot = self.next
+        self.next = (self.next + 1) % self.depth
+        if self.works[slot] is not None:
+            self.works[slot].wait()
+            self.works[slot] = None
+        return slot
+
+    def submit(self, slot):
+        if self.world > 1:
+            self.works[slot] = dist.gather(self.tables[slot], self.bufs[slot], dst=self.dst, group=self.group, async_op=True)
+
+    def drain(self):
+        for slot in range(self.depth):
+            if self.works[slot] is not None:
+                self.works[slot].wait()
+                self.works[slot] = None
+
+    def gathered(self, slot):
+        """On dst: the list of every rank's table of that slot (world size 1: just the local table)."""
+        if self.world == 1:
+            return [self.tables[slot]]
+        return self.bufs[slot] if self.rank == self.dst else None

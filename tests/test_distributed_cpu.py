@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from pli_slam_amd.sharding import gather_tables, shard_range
+from pli_slam_amd.sharding import TableGatherer, gather_tables, shard_range
 
 
 def test_shard_range_partitions_the_batch():
@@ -51,3 +51,29 @@ def _worker(rank, world, path, nframes, rec):
 def test_gather_tables_gloo_world2(nframes):
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(2, os.path.join(d, "rdv"), nframes, 96), nprocs=2, join=True)
+
+
+def _worker_async(rank, world, path, steps, nbytes):
+    dist.init_process_group("gloo", init_method="file://" + path, rank=rank, world_size=world)
+    g = TableGatherer(nbytes, torch.device("cpu"), depth=2, dst=0)
+    seen = {}
+    for i in range(steps):
+        slot = g.acquire()
+        if rank == 0 and i >= 2:                     # the gather that used this slot two steps ago is complete here
+            seen[i - 2] = [b.clone() for b in g.gathered(slot)]
+        g.table(slot).copy_(torch.full((nbytes,), (17 * i + 3 * rank) % 251, dtype=torch.uint8))   # "the kernels of step i"
+        g.submit(slot)
+    g.drain()
+    if rank == 0:
+        for i in range(max(0, steps - 2), steps):
+            seen[i] = [b.clone() for b in g.gathered(i % 2)]
+        for i in range(steps):
+            for r in range(world):
+                assert int(seen[i][r][0]) == (17 * i + 3 * r) % 251 and bool((seen[i][r] == seen[i][r][0]).all()), (i, r)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_async_double_buffered_gather_gloo_world2():
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_async, args=(2, os.path.join(d, "rdv"), 5, 4096), nprocs=2, join=True)
