@@ -698,6 +698,195 @@ __global__ void k_stereo_from_depth(const DevParams* __restrict__ Pp, const floa
 }
 
 // ---------------------------------------------------------------------------
+// Two-phase form of the two projection searches (used when the frame's keypoints fit the LDS owner table).
+// Which keypoints a query may take (grid window, pyramid levels, radius, uRight gate) and their Hamming distances do
+// not depend on the other queries; only "already taken" does.  Phase 1 (one wave per query, all queries in parallel)
+// lists the candidates of every query as (distance, visiting order, index) keys; phase 2 (one wave, queries in
+// order) takes the smallest key whose keypoint is still free — the reference's running minimum in visiting order —
+// with the owner table in LDS and the next query's keys already in flight.
+// ---------------------------------------------------------------------------
+constexpr int PROJ_K = 64;          // candidates kept per query; more -> that query is rescanned in phase 2
+
+__device__ __forceinline__ bool proj_window(const pli_proj_query& Q, float minX, float maxX, float minY, float maxY,
+                                            float gwInv, float ghInv, bool checkBounds, int& c0, int& c1, int& r0, int& r1) {
+  if (!Q.valid) return false;
+  const float u = Q.u, v = Q.v, radius = Q.radius;
+  if (checkBounds && (u < minX || u > maxX || v < minY || v > maxY)) return false;
+  c0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(u, minX), radius), gwInv)));
+  if (c0 >= GRID_COLS) return false;
+  c1 = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(u, minX), radius), gwInv)));
+  if (c1 < 0) return false;
+  r0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(v, minY), radius), ghInv)));
+  if (r0 >= GRID_ROWS) return false;
+  r1 = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(v, minY), radius), ghInv)));
+  return r1 >= 0;
+}
+
+// key of keypoint i2 for query Q (~0: not a candidate); everything except "already taken"
+__device__ __forceinline__ unsigned long long proj_key(const pli_proj_query& Q, const uint64_t dq[4], int i2,
+                                                       const pli_keypoint* __restrict__ kp, const uint8_t* __restrict__ desc,
+                                                       const float* __restrict__ uright, float minX, float minY, float gwInv,
+                                                       float ghInv, int c0, int c1, int r0, int r1) {
+  const pli_keypoint k = kp[i2];
+  const int px = (int)roundf(__fmul_rn(__fsub_rn(k.x, minX), gwInv));
+  const int py = (int)roundf(__fmul_rn(__fsub_rn(k.y, minY), ghInv));
+  if (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) return ~0ull;   // PosInGrid
+  if (px < c0 || px > c1 || py < r0 || py > r1) return ~0ull;
+  if ((Q.min_level > 0) || (Q.max_level >= 0)) {
+    if (k.octave < Q.min_level) return ~0ull;
+    if (Q.max_level >= 0 && k.octave > Q.max_level) return ~0ull;
+  }
+  if (!(fabsf(__fsub_rn(k.x, Q.u)) < Q.radius && fabsf(__fsub_rn(k.y, Q.v)) < Q.radius)) return ~0ull;
+  const float ur2 = uright[i2];
+  if (ur2 > 0 && fabsf(__fsub_rn(Q.ur, ur2)) > Q.radius) return ~0ull;
+  uint64_t d2[4];
+  load_desc(desc + (int64_t)i2 * 32, d2);
+  const int dist = hamming256(dq, d2);
+  return ((unsigned long long)dist << 40) | ((unsigned long long)px << 34) | ((unsigned long long)py << 28) | (unsigned long long)i2;
+}
+
+__global__ __launch_bounds__(64) void k_proj_candidates(const pli_proj_query* __restrict__ q, const uint8_t* __restrict__ qdesc,
+                                                        int nq, const pli_keypoint* __restrict__ kp,
+                                                        const uint8_t* __restrict__ desc, const float* __restrict__ uright,
+                                                        int ncur, float minX, float maxX, float minY, float maxY,
+                                                        int checkBounds, int distLimit, unsigned long long* __restrict__ candKeys,
+                                                        int* __restrict__ candCount) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  if (i >= nq) return;
+  const float gwInv = __fdiv_rn((float)GRID_COLS, __fsub_rn(maxX, minX));
+  const float ghInv = __fdiv_rn((float)GRID_ROWS, __fsub_rn(maxY, minY));
+  const pli_proj_query Q = q[i];
+  int c0, c1, r0, r1;
+  int count = 0;
+  if (proj_window(Q, minX, maxX, minY, maxY, gwInv, ghInv, checkBounds != 0, c0, c1, r0, r1)) {
+    uint64_t dq[4];
+    load_desc(qdesc + (int64_t)i * 32, dq);
+    for (int b = 0; b < ncur; b += 64) {
+      const int i2 = b + lane;
+      unsigned long long key = ~0ull;
+      if (i2 < ncur) key = proj_key(Q, dq, i2, kp, desc, uright, minX, minY, gwInv, ghInv, c0, c1, r0, r1);
+      const bool keep = key != ~0ull && (int)(key >> 40) <= distLimit;
+      const unsigned long long bal = __builtin_amdgcn_ballot_w64(keep);
+      const int pos = count + __popcll(bal & ((1ull << lane) - 1ull));
+      if (keep && pos < PROJ_K) candKeys[(int64_t)i * PROJ_K + pos] = key;
+      count += __popcll(bal);
+    }
+  }
+  if (lane == 0) candCount[i] = count <= PROJ_K ? count : -1;
+}
+
+// mode 0: SearchByProjection(CurrentFrame, LastFrame) (ORBmatcher.cc:2179-2323); mode 1: (Frame, MapPoints) (:44-143)
+__global__ __launch_bounds__(64) void k_proj_assign(const pli_proj_query* __restrict__ q, const uint8_t* __restrict__ qdesc, int nq,
+                                                    const pli_keypoint* __restrict__ kp, const uint8_t* __restrict__ desc,
+                                                    const float* __restrict__ uright, const uint8_t* __restrict__ occupied,
+                                                    int ncur, float minX, float maxX, float minY, float maxY, int mode,
+                                                    int checkOri, float nnratio, const unsigned long long* __restrict__ candKeys,
+                                                    const int* __restrict__ candCount, int* __restrict__ bestIdx2,
+                                                    int* __restrict__ nmatchesOut) {
+  extern __shared__ int owner[];     // ncur entries: -1 free, else the query that took the keypoint (INT_MAX: occupied before)
+  __shared__ int hist[30];
+  __shared__ int keep[30];
+  const int lane = threadIdx.x;
+  const float gwInv = __fdiv_rn((float)GRID_COLS, __fsub_rn(maxX, minX));
+  const float ghInv = __fdiv_rn((float)GRID_ROWS, __fsub_rn(maxY, minY));
+  for (int i = lane; i < ncur; i += 64) owner[i] = (occupied && occupied[i]) ? INT_MAX : -1;
+  for (int i = lane; i < nq; i += 64) bestIdx2[i] = -1;
+  if (lane < 30) hist[lane] = 0;
+  __syncthreads();
+  int nmatches = 0;
+  int cntNext = nq > 0 ? candCount[0] : 0;
+  unsigned long long keyNext = (nq > 0 && lane < cntNext) ? candKeys[lane] : ~0ull;
+  for (int i = 0; i < nq; ++i) {
+    const int cnt = cntNext;
+    unsigned long long key = keyNext;
+    if (i + 1 < nq) {                                   // the next query's keys travel while this one is decided
+      cntNext = candCount[i + 1];
+      keyNext = lane < cntNext ? candKeys[(int64_t)(i + 1) * PROJ_K + lane] : ~0ull;
+    }
+    unsigned long long k1 = ~0ull, k2 = ~0ull;
+    if (cnt >= 0) {
+      if (key != ~0ull && owner[(int)(key & 0xFFFFFFFull)] >= 0) key = ~0ull;
+      k1 = key;
+    } else {                                            // more than PROJ_K candidates: scan the frame for this query
+      const pli_proj_query Q = q[i];
+      int c0, c1, r0, r1;
+      if (proj_window(Q, minX, maxX, minY, maxY, gwInv, ghInv, mode == 0, c0, c1, r0, r1)) {
+        uint64_t dq[4];
+        load_desc(qdesc + (int64_t)i * 32, dq);
+        for (int i2 = lane; i2 < ncur; i2 += 64) {
+          if (owner[i2] >= 0) continue;
+          const unsigned long long kk = proj_key(Q, dq, i2, kp, desc, uright, minX, minY, gwInv, ghInv, c0, c1, r0, r1);
+          if (kk < k1) { k2 = k1; k1 = kk; }
+          else if (kk < k2) k2 = kk;
+        }
+      }
+    }
+    const unsigned long long m1 = wave_min_u64(k1);
+    if (m1 != ~0ull && (int)(m1 >> 40) <= 100) {
+      const int b1 = (int)(m1 & 0xFFFFFFFull);
+      bool accept = true;
+      if (mode == 1) {
+        const unsigned long long c2 = (k1 == m1) ? k2 : k1;
+        const unsigned long long m2 = wave_min_u64(c2);
+        const int bestDist = (int)(m1 >> 40), bestLevel = kp[b1].octave;
+        int bestDist2 = 256, bestLevel2 = -1;
+        if (m2 != ~0ull) { bestDist2 = (int)(m2 >> 40); bestLevel2 = kp[(int)(m2 & 0xFFFFFFFull)].octave; }
+        accept = !(bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2));
+      }
+      if (accept) {
+        owner[b1] = i;                                  // every lane stores the same value
+        if (mode == 1) bestIdx2[i] = b1;
+        if (mode == 0 && checkOri && lane == 0) {
+          float rot = __fsub_rn(q[i].angle, kp[b1].angle);
+          if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+          int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+          if (bin == 30) bin = 0;
+          if (bin >= 0 && bin < 30) hist[bin]++;
+        }
+        ++nmatches;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // single wave: LDS is executed in order
+  }
+  __syncthreads();
+  if (mode == 0) {
+    if (checkOri) {
+      if (lane == 0) {
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < 30; i++) {
+          const int s = hist[i];
+          if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+          else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+          else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+        for (int i = 0; i < 30; ++i) keep[i] = (i == ind1 || i == ind2 || i == ind3);
+      }
+      __syncthreads();
+      int removed = 0;
+      for (int i2 = lane; i2 < ncur; i2 += 64) {
+        const int o = owner[i2];
+        if (o < 0 || o == INT_MAX) continue;
+        float rot = __fsub_rn(q[o].angle, kp[i2].angle);
+        if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+        int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+        if (bin == 30) bin = 0;
+        if (!(bin >= 0 && bin < 30 && keep[bin])) { owner[i2] = -1; ++removed; }
+      }
+      removed = wave_sum_i32(removed);
+      nmatches -= removed;
+      __syncthreads();
+    }
+    for (int i2 = lane; i2 < ncur; i2 += 64) {
+      const int o = owner[i2];
+      if (o >= 0 && o != INT_MAX) bestIdx2[o] = i2;
+    }
+  }
+  if (lane == 0) *nmatchesOut = nmatches;
+}
+
+// ---------------------------------------------------------------------------
 // DBoW2 vocabulary descent (TemplatedVocabulary.h:1230-1272): one wave per feature; at every level the lanes take
 // one child each (k <= 64), a 64-bit (distance, position) key wave-min picks the nearest child, the first on ties.
 // ---------------------------------------------------------------------------

@@ -1070,61 +1070,28 @@ pli_status pli_match_nnr(pli_ctx* c, const uint8_t* d1, int32_t n1, const uint8_
   return matchDescriptors(c, d1, n1, d2, n2, nnr, false, m12, nmatches);
 }
 
-pli_status pli_search_by_projection(pli_ctx* c, const pli_proj_query* q, const uint8_t* qdesc, int32_t nq,
-                                    const pli_keypoint* kp, const uint8_t* desc, const float* uright, int32_t ncur,
-                                    float minX, float maxX, float minY, float maxY, int32_t checkOri,
-                                    int32_t* best, int32_t* nmatches) {
-  if (!c || nq < 0 || ncur < 0 || (nq > 0 && (!q || !qdesc || !best)) || (ncur > 0 && (!kp || !desc || !uright))) { g_err = "bad argument"; return PLI_ERR_INVALID; }
-  if (nmatches) *nmatches = 0;
-  if (nq == 0) return PLI_OK;
-  if (ncur >= (1 << 28)) { g_err = "too many keypoints"; return PLI_ERR_INVALID; }
-  HIPCHK(hipSetDevice(c->device));
-  const int nc = std::max(ncur, 1);
-  const size_t bq = alignUp((size_t)nq * sizeof(pli_proj_query), 256), bqd = alignUp((size_t)nq * 32, 256);
-  const size_t bk = alignUp((size_t)nc * sizeof(pli_keypoint), 256), bd = alignUp((size_t)nc * 32, 256), bu = alignUp((size_t)nc * 4, 256);
-  const size_t bo = alignUp((size_t)nc * 4, 256), bb = alignUp((size_t)nq * 4, 256);
-  pli_status st = ensureScratch(c, bq + bqd + bk + bd + bu + bo + bb + 256);
-  if (st != PLI_OK) return st;
-  uint8_t* p = (uint8_t*)c->scratch;
-  pli_proj_query* dq = (pli_proj_query*)p; p += bq;
-  uint8_t* dqd = p; p += bqd;
-  pli_keypoint* dk = (pli_keypoint*)p; p += bk;
-  uint8_t* ddsc = p; p += bd;
-  float* du = (float*)p; p += bu;
-  int* down = (int*)p; p += bo;
-  int* dbest = (int*)p; p += bb;
-  int* dcnt = (int*)p;
-  HIPCHK(hipMemcpyAsync(dq, q, (size_t)nq * sizeof(pli_proj_query), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(dqd, qdesc, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
-  if (ncur > 0) {
-    HIPCHK(hipMemcpyAsync(dk, kp, (size_t)ncur * sizeof(pli_keypoint), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(ddsc, desc, (size_t)ncur * 32, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(du, uright, (size_t)ncur * 4, hipMemcpyHostToDevice, c->stream));
-  }
-  LAUNCH(c, "k_search_by_projection", k_search_by_projection, dim3(1), dim3(64), 0, dq, dqd, nq, dk, ddsc, du, ncur, minX, maxX,
-         minY, maxY, checkOri, down, dbest, dcnt);
-  int cnt = 0;
-  HIPCHK(hipMemcpyAsync(best, dbest, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(&cnt, dcnt, 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  if (nmatches) *nmatches = cnt;
-  return PLI_OK;
-}
+// Both projection searches: mode 0 frame-to-frame (ORBmatcher.cc:2179-2323), mode 1 local map (:44-143).
+// Frames whose keypoints fit the LDS owner table take the two-phase form (candidates in parallel, then the ordered
+// assignment); larger ones the single-wave kernels that scan the frame per query.
+constexpr int PROJ_LDS_KEYPOINTS = 15360;
+constexpr int PROJ_CAND = 64;                 // PROJ_K of match_kernels.hip
 
-pli_status pli_search_local_map(pli_ctx* c, const pli_proj_query* q, const uint8_t* qdesc, int32_t nq,
-                                const pli_keypoint* kp, const uint8_t* desc, const float* uright,
-                                const uint8_t* occupied, int32_t ncur, float minX, float maxX, float minY, float maxY,
-                                float nnratio, int32_t* best, int32_t* nmatches) {
+static pli_status projectionSearch(pli_ctx* c, int mode, const pli_proj_query* q, const uint8_t* qdesc, int32_t nq,
+                                   const pli_keypoint* kp, const uint8_t* desc, const float* uright, const uint8_t* occupied,
+                                   int32_t ncur, float minX, float maxX, float minY, float maxY, int32_t checkOri,
+                                   float nnratio, int32_t* best, int32_t* nmatches) {
   if (!c || nq < 0 || ncur < 0 || (nq > 0 && (!q || !qdesc || !best)) || (ncur > 0 && (!kp || !desc || !uright))) { g_err = "bad argument"; return PLI_ERR_INVALID; }
   if (nmatches) *nmatches = 0;
   if (nq == 0) return PLI_OK;
   if (ncur >= (1 << 28)) { g_err = "too many keypoints"; return PLI_ERR_INVALID; }
   HIPCHK(hipSetDevice(c->device));
   const int nc = std::max(ncur, 1);
+  const bool twoPhase = ncur <= PROJ_LDS_KEYPOINTS;
   const size_t bq = alignUp((size_t)nq * sizeof(pli_proj_query), 256), bqd = alignUp((size_t)nq * 32, 256);
   const size_t bk = alignUp((size_t)nc * sizeof(pli_keypoint), 256), bd = alignUp((size_t)nc * 32, 256), bu = alignUp((size_t)nc * 4, 256);
   const size_t bo = alignUp((size_t)nc * 4, 256), bb = alignUp((size_t)nq * 4, 256), bc = alignUp((size_t)nc, 256);
-  pli_status st = ensureScratch(c, bq + bqd + bk + bd + bu + bo + bb + bc + 256);
+  const size_t bkeys = twoPhase ? alignUp((size_t)nq * PROJ_CAND * 8, 256) : 0, bcc = twoPhase ? alignUp((size_t)nq * 4, 256) : 0;
+  pli_status st = ensureScratch(c, bq + bqd + bk + bd + bu + bo + bb + bc + bkeys + bcc + 256);
   if (st != PLI_OK) return st;
   uint8_t* p = (uint8_t*)c->scratch;
   pli_proj_query* dq = (pli_proj_query*)p; p += bq;
@@ -1135,6 +1102,8 @@ pli_status pli_search_local_map(pli_ctx* c, const pli_proj_query* q, const uint8
   int* down = (int*)p; p += bo;
   int* dbest = (int*)p; p += bb;
   uint8_t* docc = p; p += bc;
+  unsigned long long* dkeys = (unsigned long long*)p; p += bkeys;
+  int* dcc = (int*)p; p += bcc;
   int* dcnt = (int*)p;
   HIPCHK(hipMemcpyAsync(dq, q, (size_t)nq * sizeof(pli_proj_query), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(dqd, qdesc, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
@@ -1144,15 +1113,42 @@ pli_status pli_search_local_map(pli_ctx* c, const pli_proj_query* q, const uint8
     HIPCHK(hipMemcpyAsync(du, uright, (size_t)ncur * 4, hipMemcpyHostToDevice, c->stream));
     if (occupied) HIPCHK(hipMemcpyAsync(docc, occupied, (size_t)ncur, hipMemcpyHostToDevice, c->stream));
   }
-  LAUNCH(c, "k_search_local_map", k_search_local_map, dim3(1), dim3(64), 0, dq, dqd, nq, dk, ddsc, du,
-         (occupied && ncur > 0) ? (const uint8_t*)docc : (const uint8_t*)nullptr, ncur, minX, maxX, minY, maxY, nnratio, down,
-         dbest, dcnt);
+  const uint8_t* occ = (mode == 1 && occupied && ncur > 0) ? (const uint8_t*)docc : (const uint8_t*)nullptr;
+  if (twoPhase) {
+    // a second-best farther than 100 / nnratio can no longer reject a best of <= 100 (ORBmatcher.cc:124-126)
+    int limit = 100;
+    if (mode == 1) limit = (nnratio > 0.4f) ? std::min(255, (int)(100.0f / nnratio) + 2) : 255;
+    LAUNCH(c, "k_proj_candidates", k_proj_candidates, dim3(nq), dim3(64), 0, dq, dqd, nq, dk, ddsc, du, ncur, minX, maxX, minY, maxY,
+           mode == 0 ? 1 : 0, limit, dkeys, dcc);
+    LAUNCH(c, "k_proj_assign", k_proj_assign, dim3(1), dim3(64), (size_t)nc * 4, dq, dqd, nq, dk, ddsc, du, occ, ncur, minX, maxX,
+           minY, maxY, mode, checkOri, nnratio, dkeys, dcc, dbest, dcnt);
+  } else if (mode == 0) {
+    LAUNCH(c, "k_search_by_projection", k_search_by_projection, dim3(1), dim3(64), 0, dq, dqd, nq, dk, ddsc, du, ncur, minX, maxX,
+           minY, maxY, checkOri, down, dbest, dcnt);
+  } else {
+    LAUNCH(c, "k_search_local_map", k_search_local_map, dim3(1), dim3(64), 0, dq, dqd, nq, dk, ddsc, du, occ, ncur, minX, maxX,
+           minY, maxY, nnratio, down, dbest, dcnt);
+  }
   int cnt = 0;
   HIPCHK(hipMemcpyAsync(best, dbest, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(&cnt, dcnt, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (nmatches) *nmatches = cnt;
   return PLI_OK;
+}
+
+pli_status pli_search_by_projection(pli_ctx* c, const pli_proj_query* q, const uint8_t* qdesc, int32_t nq,
+                                    const pli_keypoint* kp, const uint8_t* desc, const float* uright, int32_t ncur,
+                                    float minX, float maxX, float minY, float maxY, int32_t checkOri,
+                                    int32_t* best, int32_t* nmatches) {
+  return projectionSearch(c, 0, q, qdesc, nq, kp, desc, uright, nullptr, ncur, minX, maxX, minY, maxY, checkOri, 0.0f, best, nmatches);
+}
+
+pli_status pli_search_local_map(pli_ctx* c, const pli_proj_query* q, const uint8_t* qdesc, int32_t nq,
+                                const pli_keypoint* kp, const uint8_t* desc, const float* uright,
+                                const uint8_t* occupied, int32_t ncur, float minX, float maxX, float minY, float maxY,
+                                float nnratio, int32_t* best, int32_t* nmatches) {
+  return projectionSearch(c, 1, q, qdesc, nq, kp, desc, uright, occupied, ncur, minX, maxX, minY, maxY, 0, nnratio, best, nmatches);
 }
 
 // ---- bag of words (DBoW2 vocabulary tree) -------------------------------------

@@ -305,6 +305,44 @@ def test_local_map_search_ties_and_levels(gpu):
         assert n == on and np.array_equal(m, om)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("ncur,nq", [(3000, 1500), (17000, 600)])
+def test_projection_searches_dense_windows(gpu, ncur, nq):
+    """Both projection searches with windows that hold more candidates than the per-query candidate list keeps
+    (rescanned in the ordered phase) and, at 17000 keypoints, the frame too large for the LDS owner table."""
+    g = gpu
+    fe = g.Frontend(g.capi.default_config(128, 128))
+    rng = np.random.default_rng(ncur)
+    kp = np.zeros(ncur, g.capi.KEYPOINT_DT)
+    kp["x"] = rng.uniform(0, 640, ncur).astype(np.float32); kp["y"] = rng.uniform(0, 480, ncur).astype(np.float32)
+    kp["octave"] = rng.integers(0, 8, ncur); kp["angle"] = rng.uniform(0, 360, ncur).astype(np.float32)
+    desc = rng.integers(0, 256, (ncur, 32), dtype=np.uint8)
+    desc[:, 8:] = desc[0, 8:]                                            # close descriptors: most candidates pass the limit
+    ur = np.where(rng.random(ncur) < 0.5, kp["x"] - rng.uniform(0, 30, ncur), -1).astype(np.float32)
+    occ = (rng.random(ncur) < 0.2).astype(np.uint8)
+    q = np.zeros(nq, g.capi.PROJ_QUERY_DT)
+    src = rng.integers(0, ncur, nq)
+    q["u"] = kp["x"][src] + rng.uniform(-4, 4, nq).astype(np.float32); q["v"] = kp["y"][src] + rng.uniform(-4, 4, nq).astype(np.float32)
+    q["radius"] = np.where(rng.random(nq) < 0.5, rng.uniform(5, 30, nq), rng.uniform(60, 200, nq)).astype(np.float32)
+    q["ur"] = q["u"] - rng.uniform(0, 30, nq).astype(np.float32)
+    q["min_level"] = rng.integers(-1, 3, nq); q["max_level"] = np.where(rng.random(nq) < 0.3, -1, q["min_level"] + rng.integers(0, 6, nq))
+    q["angle"] = (kp["angle"][src] + rng.choice([0.0, 0.0, 0.0, 90.0, 200.0], nq)).astype(np.float32) % 360
+    q["valid"] = rng.random(nq) < 0.95
+    qd = desc[src].copy()
+    qd[:, :3] ^= rng.integers(0, 256, (nq, 3), dtype=np.uint8)
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    for nnratio in (0.8, 0.3):
+        n, best = fe.search_local_map(q, qd, kp, desc, ur, bounds, nnratio, cur_occupied=occ)
+        on, obest = g.po.search_local_map(q, qd, kp, desc, ur, occ, bounds, nnratio)
+        assert n == on and np.array_equal(best, obest)
+    assert on > nq // 20
+    for ori in (True, False):
+        n, best = fe.search_by_projection(q, qd, kp, desc, ur, bounds, ori)
+        on, obest = g.po.search_by_projection(q, qd, kp, desc, ur, bounds, ori)
+        assert n == on and np.array_equal(best, obest)
+    assert on > nq // 20
+
+
 # ---------------------------------------------------------------------------------------------
 # matchers on engineered descriptor tables (ties, empties)
 # ---------------------------------------------------------------------------------------------
