@@ -187,6 +187,18 @@ __global__ __launch_bounds__(64) void k_lsd_scatter(const int* __restrict__ g2a,
   }
 }
 
+// -DLSD_STATS (make EXTRA=-DLSD_STATS): per-image counts of the sequential grower, read by tools/lsd_stats.py
+#ifdef LSD_STATS
+__device__ unsigned long long g_lsdStats[16];
+extern "C" void pli_lsd_stats(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lsdStats), 128); unsigned long long z[16] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lsdStats), z, 128); }
+#define LSTAT(i, v) do { if (lane == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1) stt[i] += (v); } while (0)
+#define LCLOCK() __builtin_readcyclecounter()
+#define LTIME(i, t0) do { stt[i] += __builtin_readcyclecounter() - (t0); } while (0)
+#else
+#define LSTAT(i, v) do {} while (0)
+#define LCLOCK() 0ull
+#define LTIME(i, t0) do {} while (0)
+#endif
 constexpr int LSD_QCAP = 1024;      // region queue entries kept in LDS (8 KB/wave): longer regions spill to global memory
 
 __device__ __forceinline__ double lsd_angle_diff(double a, double b) {
@@ -215,8 +227,11 @@ __device__ __forceinline__ uint2 lsd_lds_read2(const uint2* p) {
   return make_uint2(q[0], q[1]);
 }
 
+// (the LDS read is unconditional so that it stays a ds_read instead of a flat load)
 __device__ __forceinline__ uint2 lsd_qget(const uint2* qs, const uint2* qg, int k) {
-  return k < LSD_QCAP ? qs[k] : qg[k - LSD_QCAP];
+  uint2 e = lsd_lds_read2(&qs[min(k, LSD_QCAP - 1)]);
+  if (k >= LSD_QCAP) e = qg[k - LSD_QCAP];
+  return e;
 }
 
 // ---------------------------------------------------------------------------
@@ -258,8 +273,14 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
   const double prec = P.prec, scale = P.lsdScale;
   const int ndx = lane % 3 - 1, ndy = (lane / 3) % 3 - 1;   // lanes 0..8: raster order of the 3x3 block
   int nseg = 0;
+#ifdef LSD_STATS
+  unsigned long long stt[16] = {};
+  const unsigned long long tKernel = LCLOCK();
+#endif
+  LSTAT(7, nOrder);
 
   for (int base = 0; base < nOrder; base += 64) {
+    const unsigned long long tSeed = LCLOCK();
     const int idx = base + lane;
     const bool valid = idx < nOrder;
     const int sp_l = valid ? order[idx] : -1;
@@ -275,6 +296,7 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
       ssin = (float)sn;
     }
     unsigned long long unusedMask = __builtin_amdgcn_ballot_w64(srec.x != LSD_NOTDEF);
+    LTIME(9, tSeed);
     while (unusedMask) {
       const int j = __ffsll((long long)unusedMask) - 1;
       unusedMask &= unusedMask - 1ull;
@@ -289,6 +311,7 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
       if (lane == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1) rec[sp].x = LSD_NOTDEF;
       qs[0] = make_uint2(((unsigned)spy << 16) | (unsigned)spx, (unsigned)sg2);
       int cnt = 1;
+      LSTAT(0, 1);
       // One BFS step.  Two copies: while the queue fits in LDS the step touches global memory only for the
       // neighbourhood load and the USED marks.  (A queue read that may come from LDS or from the overflow area
       // becomes a flat load, and its wait — vmcnt(0) — also covers the USED stores of the previous step: a full
@@ -339,6 +362,7 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
       // as in the sequential loop, and all its later copies are dropped once it is accepted.  Pixels accepted in
       // the batch are appended to the queue and popped by later batches (FIFO order is unchanged).
       auto batch = [&](int k, int nb) {
+        const unsigned long long tB0 = LCLOCK();
         const int pi = lane >> 3, ni = (lane & 7) < 4 ? (lane & 7) : (lane & 7) + 1;   // 8 neighbours, raster order, centre skipped
         const bool act = pi < nb;
         const unsigned ex = lsd_lds_read2(&qs[k + (act ? pi : 0)]).x;
@@ -351,6 +375,8 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
         const double ad = (double)r.x * D_DEG2RAD;
         const unsigned myxy = ((unsigned)ny << 16) | (unsigned)nx;
         unsigned long long remaining = __builtin_amdgcn_ballot_w64(cand);
+        LTIME(10, tB0);
+        const unsigned long long tB1 = LCLOCK();
         while (remaining) {
           double n_theta = fabs(reg_angle - ad);
           if (n_theta > D_3_2_PI) {
@@ -373,10 +399,12 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
           reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * D_DEG2RAD;
           unusedMask &= ~__builtin_amdgcn_ballot_w64(sp_l == qj);
         }
+        LTIME(11, tB1);
       };
       for (int k = 0; k < cnt;) {
         if (cnt + 65 <= LSD_QCAP) {                    // a batch can append up to 8 x 8 entries
           const int nb = min(8, cnt - k);
+          LSTAT(1, 1);
           batch(k, nb);
           k += nb;
         } else {
@@ -385,23 +413,38 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
           ++k;
         }
       }
+      LSTAT(3, cnt);
+      if (cnt == 1) LSTAT(5, 1);
+      if (cnt <= 4) LSTAT(6, 1);
       if (cnt < minReg) continue;
+      LSTAT(4, 1);
+      LSTAT(2, cnt);
+      const unsigned long long tRect = LCLOCK();
       // ---- region2rect ----------------------------------------------------
       // pass 1: x = sum x*w, y = sum y*w, sum = sum w, in list order
       double acc = 0.0;                                   // lanes 0,1,2 hold x, y, sum
       for (int c0 = 0; c0 < cnt; c0 += 64) {
         const int k = c0 + lane;
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0;              // lanes past the end add +0.0 (the sums are never -0.0)
         if (k < cnt) {
           const uint2 e = lsd_qget(qs, qg, k);
           const double w = sqrt((double)(int)e.y / 4.0);
-          st[0][lane] = (double)(int)(e.x & 0xFFFFu) * w;
-          st[1][lane] = (double)(int)(e.x >> 16) * w;
-          st[2][lane] = w;
+          v0 = (double)(int)(e.x & 0xFFFFu) * w;
+          v1 = (double)(int)(e.x >> 16) * w;
+          v2 = w;
         }
+        st[0][lane] = v0; st[1][lane] = v1; st[2][lane] = v2;
         lsd_wave_sync();
         if (lane < 3) {
-          const int m = min(64, cnt - c0);
-          for (int t = 0; t < m; ++t) acc += st[lane][t];
+          // list-order sum, eight terms per trip: the LDS reads of a trip are issued together, the adds stay in order
+          const int m = (min(64, cnt - c0) + 7) & ~7;
+          for (int t = 0; t < m; t += 8) {
+            double a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = st[lane][t + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += a[u];
+          }
         }
         lsd_wave_sync();
       }
@@ -411,21 +454,31 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
       acc = 0.0;                                          // lanes 0,1,2 hold Ixx, Iyy, Ixy
       for (int c0 = 0; c0 < cnt; c0 += 64) {
         const int k = c0 + lane;
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0;              // past the end: acc + 0.0 and acc - 0.0 leave acc as it is
         if (k < cnt) {
           const uint2 e = lsd_qget(qs, qg, k);
           const double w = sqrt((double)(int)e.y / 4.0);
           const double dx = (double)(int)(e.x & 0xFFFFu) - x, dy = (double)(int)(e.x >> 16) - y;
-          st[0][lane] = dy * dy * w;
-          st[1][lane] = dx * dx * w;
-          st[2][lane] = dx * dy * w;
+          v0 = dy * dy * w;
+          v1 = dx * dx * w;
+          v2 = dx * dy * w;
         }
+        st[0][lane] = v0; st[1][lane] = v1; st[2][lane] = v2;
         lsd_wave_sync();
-        if (lane < 2) {
-          const int m = min(64, cnt - c0);
-          for (int t = 0; t < m; ++t) acc += st[lane][t];
-        } else if (lane == 2) {
-          const int m = min(64, cnt - c0);
-          for (int t = 0; t < m; ++t) acc -= st[2][t];
+        if (lane < 3) {
+          const int m = (min(64, cnt - c0) + 7) & ~7;
+          for (int t = 0; t < m; t += 8) {
+            double a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = st[lane][t + u];
+            if (lane < 2) {
+#pragma unroll
+              for (int u = 0; u < 8; ++u) acc += a[u];
+            } else {
+#pragma unroll
+              for (int u = 0; u < 8; ++u) acc -= a[u];
+            }
+          }
         }
         lsd_wave_sync();
       }
@@ -435,7 +488,8 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
                                              : (double)fast_atan2_deg((float)Ixy, (float)(lambda - Iyy));
       theta *= D_DEG2RAD;
       if (lsd_angle_diff(theta, reg_angle) > prec) theta += D_PI;
-      const double dxr = cos(theta), dyr = sin(theta);
+      double dxr, dyr;
+      sincos(theta, &dyr, &dxr);
       // pass 3: extent along the main axis (min/max are order independent)
       double l_min = 0, l_max = 0;
       for (int k = lane; k < cnt; k += 64) {
@@ -459,9 +513,14 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
         seg[4 * nseg + 3] = (float)y2;
       }
       ++nseg;
+      LTIME(12, tRect);
     }
   }
   if (lane == 0) nSeg[img] = nseg < maxSeg ? nseg : maxSeg;
+#ifdef LSD_STATS
+  LTIME(8, tKernel);
+  if (lane == 0) for (int i = 0; i < 16; ++i) atomicAdd(&g_lsdStats[i], stt[i]);
+#endif
 }
 
 // one image per wave; the 2-waves-per-block form keeps the two waves of a block on one CU, which spreads a large

@@ -789,18 +789,27 @@ __global__ __launch_bounds__(64) void k_rx_rect(const DevParams* __restrict__ Pp
     double acc = 0.0;
     for (int c0 = 0; c0 < cnt; c0 += 64) {
       const int kk = c0 + lane;
+      double v0 = 0.0, v1 = 0.0, v2 = 0.0;                // lanes past the end add +0.0 (the sums are never -0.0)
       if (kk < cnt) {
         const int e = lst[kk];
         const int ex = e & 0xFFFF, ey = e >> 16;
         const double w = sqrt((double)__float_as_int(rec[ey * W + ex].w) / 4.0);
-        st[0][lane] = (double)ex * w;
-        st[1][lane] = (double)ey * w;
-        st[2][lane] = w;
+        v0 = (double)ex * w;
+        v1 = (double)ey * w;
+        v2 = w;
       }
+      st[0][lane] = v0; st[1][lane] = v1; st[2][lane] = v2;
       __syncthreads();
       if (lane < 3) {
-        const int mm = min(64, cnt - c0);
-        for (int tt = 0; tt < mm; ++tt) acc += st[lane][tt];
+        // list-order sum, eight terms per trip: the LDS reads of a trip are issued together, the adds stay in order
+        const int mm = (min(64, cnt - c0) + 7) & ~7;
+        for (int tt = 0; tt < mm; tt += 8) {
+          double a[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) a[u] = st[lane][tt + u];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc += a[u];
+        }
       }
       __syncthreads();
     }
@@ -809,22 +818,32 @@ __global__ __launch_bounds__(64) void k_rx_rect(const DevParams* __restrict__ Pp
     acc = 0.0;
     for (int c0 = 0; c0 < cnt; c0 += 64) {
       const int kk = c0 + lane;
+      double v0 = 0.0, v1 = 0.0, v2 = 0.0;                // past the end: acc + 0.0 and acc - 0.0 leave acc as it is
       if (kk < cnt) {
         const int e = lst[kk];
         const int ex = e & 0xFFFF, ey = e >> 16;
         const double w = sqrt((double)__float_as_int(rec[ey * W + ex].w) / 4.0);
         const double dx = (double)ex - x, dy = (double)ey - y;
-        st[0][lane] = dy * dy * w;
-        st[1][lane] = dx * dx * w;
-        st[2][lane] = dx * dy * w;
+        v0 = dy * dy * w;
+        v1 = dx * dx * w;
+        v2 = dx * dy * w;
       }
+      st[0][lane] = v0; st[1][lane] = v1; st[2][lane] = v2;
       __syncthreads();
-      if (lane < 2) {
-        const int mm = min(64, cnt - c0);
-        for (int tt = 0; tt < mm; ++tt) acc += st[lane][tt];
-      } else if (lane == 2) {
-        const int mm = min(64, cnt - c0);
-        for (int tt = 0; tt < mm; ++tt) acc -= st[2][tt];
+      if (lane < 3) {
+        const int mm = (min(64, cnt - c0) + 7) & ~7;
+        for (int tt = 0; tt < mm; tt += 8) {
+          double a[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) a[u] = st[lane][tt + u];
+          if (lane < 2) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += a[u];
+          } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc -= a[u];
+          }
+        }
       }
       __syncthreads();
     }
@@ -834,7 +853,8 @@ __global__ __launch_bounds__(64) void k_rx_rect(const DevParams* __restrict__ Pp
                                            : (double)fast_atan2_deg((float)Ixy, (float)(lambda - Iyy));
     theta *= RX_DEG2RAD;
     if (rx_angle_diff(theta, reg_angle) > prec) theta += RX_PI;
-    const double dxr = cos(theta), dyr = sin(theta);
+    double dxr, dyr;
+    sincos(theta, &dyr, &dxr);
     double l_min = 0, l_max = 0;
     for (int kk = lane; kk < cnt; kk += 64) {
       const int e = lst[kk];

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Dev tool (GPU box, library built with EXTRA=-DLSD_STATS): per-image counts of the sequential LSD grower."""
+import os, sys, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from pli_slam_amd import capi, synth
+from pli_slam_amd.frontend import Frontend
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+cfg = capi.default_config(752, 480, max_frames=F, lsd_mode=2)
+fe = Frontend(cfg)
+uniq = np.stack([np.stack(synth.make_stereo_pair(s_, 752, 480)) for s_ in range(min(F, 32))])
+frames = uniq[np.arange(F) % len(uniq)]
+fe.batch_run_host(frames)
+out = (C.c_ulonglong * 16)()
+fe.L.pli_lsd_stats(out)
+fe.batch_run_host(frames)
+fe.L.pli_lsd_stats(out)
+n = 2 * F
+names = ["regions", "batches", "px in kept regions", "px in all regions", "kept regions", "regions of 1", "regions <= 4", "defined px"]
+for k, v in zip(names, out):
+    print("%-22s %10.1f per image" % (k, v / n))
+tn = ["kernel", "seed batch fetch", "batch: queue read + neighbour load", "batch: accept loop", "region2rect"]
+for k, v in zip(tn, list(out)[8:13]):
+    print("%-36s %10.3f Mcycles per image (%.1f %%)" % (k, v / n / 1e6, 100.0 * v / max(out[8], 1)))
