@@ -16,6 +16,7 @@ constexpr int MAX_LEVELS = 16;
 constexpr int CELL_CAP = 512;          // FAST survivors a 30..60 px cell can hold after NMS
 constexpr int GRID_COLS = 64;          // FRAME_GRID_COLS, Frame.h:60
 constexpr int GRID_ROWS = 48;          // FRAME_GRID_ROWS, Frame.h:59
+constexpr int LSD_CHUNK = 4096;        // pixels per chunk of the ordered-list build (histogram, scan, stable scatter)
 
 // Geometry of one pyramid level and of its FAST cell grid
 // (ORBextractor.cc:763-806 restated once on the host).

@@ -90,7 +90,14 @@ __device__ __forceinline__ double lsd_bin_coef(int maxG2, int nBins) {
   return maxG2 > 0 ? (double)(nBins - 1) / maxGrad : 0.0;
 }
 
-constexpr int LSD_CHUNK = 1024;
+// LDS traffic of ONE wave is executed in order: a write by some lanes followed by a read by others needs no s_barrier,
+// only the compiler must keep the order
+__device__ __forceinline__ void lsd_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 
 // per-chunk histogram of the bins of the defined pixels
 __global__ __launch_bounds__(256) void k_lsd_hist(const int* __restrict__ g2a, int npix, int g2Thresh, int nBins,
@@ -124,6 +131,7 @@ __global__ __launch_bounds__(1024) void k_lsd_scan(const unsigned short* __restr
   int* cb = chunkBase + (int64_t)img * nChunks * nBins;
   int run = 0;
   if (b < nBins) {
+#pragma unroll 8
     for (int c = 0; c < nChunks; ++c) {
       int v = hin[(int64_t)c * nBins + b];
       cb[(int64_t)c * nBins + b] = run;
@@ -140,6 +148,7 @@ __global__ __launch_bounds__(1024) void k_lsd_scan(const unsigned short* __restr
   __syncthreads();
   if (b < nBins) {
     int s = start[b];
+#pragma unroll 8
     for (int c = 0; c < nChunks; ++c) cb[(int64_t)c * nBins + b] += s;
   }
 }
@@ -147,9 +156,15 @@ __global__ __launch_bounds__(1024) void k_lsd_scan(const unsigned short* __restr
 // stable scatter: one wave per chunk walks its 1024 pixels in raster order
 __global__ __launch_bounds__(64) void k_lsd_scatter(const int* __restrict__ g2a, int npix, int g2Thresh, int nBins,
                                                     const int* __restrict__ maxG2, const int* __restrict__ chunkBase,
-                                                    int nChunks, int* __restrict__ order, int img0) {
+                                                    int nChunks, int* __restrict__ order, int img0, int nimg) {
   __shared__ int base[1024];
-  const int img = blockIdx.y + img0, chunk = blockIdx.x, lane = threadIdx.x;
+  // XCD-aware order: workgroup L runs on XCD L % 8, so all chunks of an image are dealt to ONE XCD (consecutive slots of
+  // that XCD, i.e. close in time): the 4-byte stores of different chunks into the same lines of the ordered list then
+  // merge in that XCD's L2 instead of leaving partial lines in eight L2s.  Launched with 8 * ceil(nimg / 8) * nChunks blocks.
+  const int L = blockIdx.x, slot = L >> 3;
+  const int li = (L & 7) + 8 * (slot / nChunks), chunk = slot % nChunks, lane = threadIdx.x;
+  if (li >= nimg) return;
+  const int img = li + img0;
   const int* cb = chunkBase + ((int64_t)img * nChunks + chunk) * nBins;
   for (int i = lane; i < nBins; i += 64) base[i] = cb[i];
   __syncthreads();
@@ -157,33 +172,42 @@ __global__ __launch_bounds__(64) void k_lsd_scatter(const int* __restrict__ g2a,
   const int* g = g2a + (int64_t)img * npix;
   int* ord = order + (int64_t)img * npix;
   const int nbits = 32 - __clz(max(nBins - 1, 1));
-  for (int it = 0; it < LSD_CHUNK / 64; ++it) {
-    int i = chunk * LSD_CHUNK + it * 64 + lane;
-    bool def = false;
-    int bin = -1;
-    if (i < npix) {
-      int v = g[i];
-      def = v > g2Thresh;
-      if (def) bin = lsd_bin(v, bc);
+  constexpr int GRP = 16;                        // rows of 64 pixels whose loads are in flight together
+  for (int it0 = 0; it0 < LSD_CHUNK / 64; it0 += GRP) {
+    if (chunk * LSD_CHUNK + it0 * 64 >= npix) break;
+    int vals[GRP];
+#pragma unroll
+    for (int u = 0; u < GRP; ++u) {
+      const int i = chunk * LSD_CHUNK + (it0 + u) * 64 + lane;
+      vals[u] = i < npix ? g[i] : 0;             // (g2Thresh >= 0: a zero is never "defined")
     }
-    // lanes with the same bin (match-any by bits: one ballot per bin bit instead of one round per distinct bin)
-    unsigned long long peers = __builtin_amdgcn_ballot_w64(def);
-    for (int b = 0; b < nbits; ++b) {
-      const bool bit = (bin >> b) & 1;
-      const unsigned long long bal = __builtin_amdgcn_ballot_w64(def && bit);
-      peers &= bit ? bal : ~bal;
+#pragma unroll
+    for (int u = 0; u < GRP; ++u) {
+      const int i = chunk * LSD_CHUNK + (it0 + u) * 64 + lane;
+      const int v = vals[u];
+      const bool def = i < npix && v > g2Thresh;
+      const int bin = def ? lsd_bin(v, bc) : -1;
+      // lanes with the same bin (match-any by bits: one ballot per bin bit instead of one round per distinct bin)
+      unsigned long long peers = __builtin_amdgcn_ballot_w64(def);
+      if (!peers) continue;
+      for (int b = 0; b < nbits; ++b) {
+        const bool bit = (bin >> b) & 1;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(def && bit);
+        peers &= bit ? bal : ~bal;
+      }
+      int rank = 0, cnt = 0;
+      bool last = false;
+      if (def) {
+        rank = __popcll(peers & ((1ull << lane) - 1ull));
+        cnt = __popcll(peers);
+        last = (peers >> lane) == 1ull;
+      }
+      if (def) ord[base[bin] + rank] = i;
+      // single-wave block: the LDS operations of a wave execute in order (a block barrier would also wait for the stores)
+      lsd_wave_sync();
+      if (def && last) base[bin] += cnt;
+      lsd_wave_sync();
     }
-    int rank = 0, cnt = 0;
-    bool last = false;
-    if (def) {
-      rank = __popcll(peers & ((1ull << lane) - 1ull));
-      cnt = __popcll(peers);
-      last = (peers >> lane) == 1ull;
-    }
-    if (def) ord[base[bin] + rank] = i;
-    __syncthreads();
-    if (def && last) base[bin] += cnt;
-    __syncthreads();
   }
 }
 
@@ -212,13 +236,6 @@ __device__ __forceinline__ double lsd_angle_diff(double a, double b) {
 __device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
-// LDS traffic of ONE wave is executed in order: a write by some lanes followed by a read by others needs no s_barrier,
-// only the compiler must keep the order (the waves of a block are independent here)
-__device__ __forceinline__ void lsd_wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // LDS read that stays a ds_read (see the note in k_lsd_grow)
 __device__ __forceinline__ uint2 lsd_lds_read2(const uint2* p) {

@@ -435,7 +435,7 @@ pli_status allocAll(pli_ctx* c) {
   c->jrHost.resize(NI);
 
   A(c->maxG2, NI);
-  c->nChunks = (int)((npix + 1023) / 1024);
+  c->nChunks = (int)((npix + LSD_CHUNK - 1) / LSD_CHUNK);
   A(c->chunkHist, (size_t)NI * c->nChunks * P.nBins);
   A(c->chunkBase, (size_t)NI * c->nChunks * P.nBins);
   A(c->nDefined, NI);
@@ -546,8 +546,8 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   LAUNCH(c, "k_lsd_hist", k_lsd_hist, dim3(c->nChunks, nimg), dim3(256), 0, c->g2, npix, P.g2Thresh, P.nBins, c->maxG2,
          c->chunkHist, c->nChunks, img0);
   LAUNCH(c, "k_lsd_scan", k_lsd_scan, dim3(nimg), dim3(1024), 0, c->chunkHist, c->nChunks, P.nBins, c->chunkBase, c->nDefined, img0);
-  LAUNCH(c, "k_lsd_scatter", k_lsd_scatter, dim3(c->nChunks, nimg), dim3(64), 0, c->g2, npix, P.g2Thresh, P.nBins, c->maxG2,
-         c->chunkBase, c->nChunks, c->order, img0);
+  LAUNCH(c, "k_lsd_scatter", k_lsd_scatter, dim3((unsigned)(8 * ((nimg + 7) / 8) * c->nChunks)), dim3(64), 0, c->g2, npix, P.g2Thresh,
+         P.nBins, c->maxG2, c->chunkBase, c->nChunks, c->order, img0, nimg);
   if (sequential) {
     if (nimg >= 64 && !getenv("PLI_GROW_WPB1"))
       LAUNCH(c, "k_lsd_grow2", k_lsd_grow2, dim3((nimg + 1) / 2), dim3(128), 0, c->dP, c->rec, c->order, c->nDefined,
