@@ -148,10 +148,13 @@ __device__ __forceinline__ int arc9_maxmin(const int a[16]) {
 
 __global__ __launch_bounds__(256) void k_fast_cells(const DevParams* __restrict__ Pp, const uint8_t* __restrict__ pyr,
                                                     uint32_t* __restrict__ cellCand, int* __restrict__ cellCount, int img0) {
-  __shared__ uint8_t tile[FT_PITCH * 68];
+  __shared__ __attribute__((aligned(16))) uint8_t tile[FT_PITCH * 68];
   __shared__ uint8_t score[64 * 64];
+  __shared__ unsigned short clist[64 * 64];   // corners at minTh: pixel index | dark << 12 | bright << 13
+  __shared__ int s_nc;
   __shared__ int s_any;
-  __shared__ int s_wcount[4];
+  __shared__ int s_wc[64];     // survivors per (chunk, wave)
+  __shared__ int s_off[64];    // their exclusive prefix
   __shared__ int s_base;
   const DevParams& P = *Pp;
   const int img = blockIdx.y + img0;
@@ -181,18 +184,50 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams* __restrict_
   }
   const uint8_t* im = pyr + (int64_t)img * P.pyrBlock + G.offset;
   // (row, column) of a linear index without an integer division: exact for these sizes (index < 4096, width <= 64)
-  const float invCw = 1.0f / (float)cw, invIw = 1.0f / (float)iw;
-  for (int i = tid; i < cw * ch; i += 256) {
-    const int y = (int)(((float)i + 0.5f) * invCw), x = i - y * cw;
-    tile[y * FT_PITCH + x] = im[(int64_t)(iniY + y) * G.pitch + iniX + x];
+  // the rows of a level start 64-byte aligned, so the misalignment of the cell is the same in every row: the tile
+  // keeps it (column ox = first cell column) and is filled with aligned 4-byte loads
+  const int ox = iniX & 3, nd = (cw + ox + 3) >> 2;
+  const float invNd = 1.0f / (float)nd, invIw = 1.0f / (float)iw;
+  for (int i = tid; i < nd * ch; i += 256) {
+    const int y = (int)(((float)i + 0.5f) * invNd), k = i - y * nd;
+    reinterpret_cast<uint32_t*>(tile)[y * (FT_PITCH / 4) + k] =
+        *reinterpret_cast<const uint32_t*>(im + (int64_t)(iniY + y) * G.pitch + (iniX - ox) + 4 * k);
   }
-  if (tid == 0) s_any = 0;
+  if (tid == 0) { s_any = 0; s_nc = 0; }
   __syncthreads();
   const int minTh = P.minTh, iniTh = P.iniTh;
   const int npix = iw * ih;
+  // pass 1, every pixel: the two 16-bit sign masks of the ring at minTh (one add/sub and one v_alignbit per test:
+  // mask = mask << 1 | sign) and the 9-contiguous test; corners are listed, everything else scores 0
   for (int i = tid; i < npix; i += 256) {
     const int y = (int)(((float)i + 0.5f) * invIw), x = i - y * iw;
-    const uint8_t* p = &tile[(y + 3) * FT_PITCH + x + 3];
+    const uint8_t* p = &tile[(y + 3) * FT_PITCH + x + 3 + ox];
+    const int v = p[0];
+    const int tD = v - minTh - 1, tB = v + minTh + 1;     // ring darker: r <= tD; brighter: r >= tB
+    unsigned mDark = 0, mBright = 0;
+#define FT_RING(o)                                                                        \
+    {                                                                                     \
+      const int r = p[o];                                                                 \
+      mDark = __builtin_amdgcn_alignbit(mDark, (unsigned)(r - tD - 1), 31);   /* sign: r <= tD  <=> v - r > minTh */ \
+      mBright = __builtin_amdgcn_alignbit(mBright, (unsigned)(tB - r - 1), 31); /* sign: r >= tB <=> r - v > minTh */ \
+    }
+    FT_RING(3 * FT_PITCH + 0) FT_RING(3 * FT_PITCH + 1) FT_RING(2 * FT_PITCH + 2) FT_RING(1 * FT_PITCH + 3)
+    FT_RING(3) FT_RING(-1 * FT_PITCH + 3) FT_RING(-2 * FT_PITCH + 2) FT_RING(-3 * FT_PITCH + 1)
+    FT_RING(-3 * FT_PITCH + 0) FT_RING(-3 * FT_PITCH - 1) FT_RING(-2 * FT_PITCH - 2) FT_RING(-1 * FT_PITCH - 3)
+    FT_RING(-3) FT_RING(1 * FT_PITCH - 3) FT_RING(2 * FT_PITCH - 2) FT_RING(3 * FT_PITCH - 1)
+#undef FT_RING
+    const bool cd = has9(mDark & 0xFFFFu), cb = has9(mBright & 0xFFFFu);   // (bit order reversed: a contiguous arc stays one)
+    score[y * 64 + x] = 0;
+    if (cd || cb) clist[atomicAdd(&s_nc, 1)] = (unsigned short)(i | (cd ? 0x1000 : 0) | (cb ? 0x2000 : 0));
+  }
+  __syncthreads();
+  // pass 2, corners only (densely packed lanes): the exact corner score
+  const int nc = s_nc;
+  for (int j = tid; j < nc; j += 256) {
+    const int e = clist[j], i = e & 0xFFF;
+    const bool cd = (e & 0x1000) != 0, cb = (e & 0x2000) != 0;
+    const int y = (int)(((float)i + 0.5f) * invIw), x = i - y * iw;
+    const uint8_t* p = &tile[(y + 3) * FT_PITCH + x + 3 + ox];
     const int v = p[0];
     int d[16];
     d[0] = v - p[3 * FT_PITCH + 0];   d[1] = v - p[3 * FT_PITCH + 1];   d[2] = v - p[2 * FT_PITCH + 2];
@@ -201,32 +236,22 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams* __restrict_
     d[9] = v - p[-3 * FT_PITCH - 1];  d[10] = v - p[-2 * FT_PITCH - 2]; d[11] = v - p[-1 * FT_PITCH - 3];
     d[12] = v - p[-3];                d[13] = v - p[1 * FT_PITCH - 3];  d[14] = v - p[2 * FT_PITCH - 2];
     d[15] = v - p[3 * FT_PITCH - 1];
-    unsigned mDark = 0, mBright = 0;    // ring darker / brighter than the centre by more than minTh
+    int arc = -256;
+    if (cd) arc = max(arc, arc9_maxmin(d));
+    if (cb) {
+      int nd[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      mDark |= (unsigned)(d[k] > minTh) << k;
-      mBright |= (unsigned)(-d[k] > minTh) << k;
+      for (int k = 0; k < 16; ++k) nd[k] = -d[k];
+      arc = max(arc, arc9_maxmin(nd));
     }
-    int sc = 0;
-    const bool cd = has9(mDark), cb = has9(mBright);
-    if (cd || cb) {
-      int arc = -256;
-      if (cd) arc = max(arc, arc9_maxmin(d));
-      if (cb) {
-        int nd[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) nd[k] = -d[k];
-        arc = max(arc, arc9_maxmin(nd));
-      }
-      sc = arc - 1;                      // cornerScore<16>
-    }
-    score[y * 64 + x] = (uint8_t)sc;
+    score[y * 64 + x] = (uint8_t)(arc - 1);            // cornerScore<16>
   }
   __syncthreads();
   // Non-maximum suppression does not depend on the threshold (a survivor is strictly greater than its 8 neighbours
-  // inside the interior): computed once per corner, kept as bit 7 of ... a flag byte in the (now free) tile buffer.
-  uint8_t* ismax = tile;
+  // inside the interior): one flag bit per pixel of this thread (pixel i = ck * 256 + tid, at most 16 chunks).
   const int nchunks = (npix + 255) / 256;
+  unsigned mxBits = 0;
+#pragma unroll 1
   for (int ck = 0; ck < nchunks; ++ck) {
     const int i = ck * 256 + tid;
     if (i < npix) {
@@ -244,38 +269,60 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams* __restrict_
             mx = mx && (s > n);
           }
       }
-      ismax[i] = mx ? 1 : 0;
-      if (mx && s >= iniTh) s_any = 1;   // benign race: all writers store 1
+      if (mx) {
+        mxBits |= 1u << ck;
+        if (s >= iniTh) s_any = 1;           // benign race: all writers store 1
+      }
     }
   }
   __syncthreads();
   const int thr = s_any ? iniTh : 1;     // score > 0 <=> corner at minTh
-  if (tid == 0) s_base = 0;
+  // ordered (raster) compaction in one go: per (chunk, wave) survivor counts by ballot, one 64-entry scan, then the writes
+  const int lane = tid & 63, wv = tid >> 6;
+  unsigned survBits = 0;
+  unsigned long long rk = 0;             // rank inside (chunk, wave): 16 x 4 bits would overflow (0..63) -> two words of 8 x 8 bits
+  unsigned long long rk2 = 0;
+#pragma unroll 1
+  for (int ck = 0; ck < nchunks; ++ck) {
+    bool surv = false;
+    if ((mxBits >> ck) & 1u) {
+      const int i = ck * 256 + tid;
+      const int y = (int)(((float)i + 0.5f) * invIw), x = i - y * iw;
+      surv = score[y * 64 + x] >= thr;
+    }
+    const unsigned long long bal = __ballot(surv);
+    if (lane == 0) s_wc[ck * 4 + wv] = __popcll(bal);
+    if (surv) {
+      survBits |= 1u << ck;
+      const unsigned long long r = (unsigned long long)__popcll(bal & ((1ull << lane) - 1ull));
+      if (ck < 8) rk |= r << (8 * ck); else rk2 |= r << (8 * (ck - 8));
+    }
+  }
+  __syncthreads();
+  if (wv == 0) {
+    const int v = lane < nchunks * 4 ? s_wc[lane] : 0;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    s_off[lane] = inc - v;
+    if (lane == 63) s_base = inc;
+  }
   __syncthreads();
   uint32_t* out = cellCand + cellIdx * CELL_CAP;
-  const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll 1
   for (int ck = 0; ck < nchunks; ++ck) {
+    if (!((survBits >> ck) & 1u)) continue;
     const int i = ck * 256 + tid;
-    bool surv = false;
-    int s = 0, x = 0, y = 0;
-    if (i < npix && ismax[i]) {
-      y = (int)(((float)i + 0.5f) * invIw); x = i - y * iw;
-      s = score[y * 64 + x];
-      surv = s >= thr;
+    const int y = (int)(((float)i + 0.5f) * invIw), x = i - y * iw;
+    const int r = (int)(((ck < 8 ? rk >> (8 * ck) : rk2 >> (8 * (ck - 8)))) & 0xFFull);
+    const int pos = s_off[ck * 4 + wv] + r;
+    if (pos < CELL_CAP) {
+      const int xr = x + 3 + cj * G.wCell, yr = y + 3 + ci * G.hCell;
+      out[pos] = ((uint32_t)yr << 20) | ((uint32_t)xr << 8) | (uint32_t)score[y * 64 + x];
     }
-    unsigned long long bal = __ballot(surv);
-    if (lane == 0) s_wcount[wv] = __popcll(bal);
-    __syncthreads();
-    int pre = s_base;
-    for (int k = 0; k < wv; ++k) pre += s_wcount[k];
-    int pos = pre + __popcll(bal & ((1ull << lane) - 1ull));
-    if (surv && pos < CELL_CAP) {
-      int xr = x + 3 + cj * G.wCell, yr = y + 3 + ci * G.hCell;
-      out[pos] = ((uint32_t)yr << 20) | ((uint32_t)xr << 8) | (uint32_t)s;
-    }
-    __syncthreads();
-    if (tid == 0) s_base += s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
-    __syncthreads();
   }
   if (tid == 0) cellCount[cellIdx] = s_base < CELL_CAP ? s_base : CELL_CAP;
 }
@@ -293,8 +340,6 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams* __restrict_
 // first among equal sizes in the "careful" rounds) then child n1..n4.
 // Keys never move: node_of[key] holds the list position of the key's node.
 // ---------------------------------------------------------------------------
-constexpr int OT_MAXN = 1024;
-
 __device__ __forceinline__ int block_excl_scan_1024(int* a, int n, int* scratch /*>=5 ints*/) {
   // in-place exclusive scan of a[0..n) (n <= 1024) by 256 threads; returns the total
   const int tid = threadIdx.x;
@@ -329,17 +374,23 @@ __device__ __forceinline__ int block_excl_scan_1024(int* a, int n, int* scratch 
   return total;
 }
 
+template <int MAXN>
 struct OtNodes {
-  short x0[OT_MAXN], y0[OT_MAXN], x1[OT_MAXN], y1[OT_MAXN];
-  int cnt[OT_MAXN];
-  unsigned char isNew[OT_MAXN];
+  short x0[MAXN], y0[MAXN], x1[MAXN], y1[MAXN];
+  int cnt[MAXN];
+  unsigned char isNew[MAXN];
 };
 
-__global__ __launch_bounds__(256) void k_octree(const DevParams* __restrict__ Pp, const uint32_t* __restrict__ cellCand,
-                                                const int* __restrict__ cellCount, uint32_t* __restrict__ candAll,
-                                                unsigned short* __restrict__ nodeOfAll, int* __restrict__ candCount,
-                                                uint32_t* __restrict__ kpSel, int* __restrict__ kpSelCount, int img0) {
-  __shared__ OtNodes A, B;
+// MAXN: node capacity of the list = LDS footprint (the list ends at N..N+3 nodes, N = the level's quota; the host
+// picks the smallest instance that holds the largest quota: 70 KB of LDS at 1024 nodes allow 2 workgroups per CU,
+// 22 KB at 320 allow 7)
+template <int MAXN>
+__device__ __forceinline__ void octree_level(const DevParams* __restrict__ Pp, const uint32_t* __restrict__ cellCand,
+                                             const int* __restrict__ cellCount, uint32_t* __restrict__ candAll,
+                                             unsigned short* __restrict__ nodeOfAll, int* __restrict__ candCount,
+                                             uint32_t* __restrict__ kpSel, int* __restrict__ kpSelCount, int img0) {
+  constexpr int OT_MAXN = MAXN;
+  __shared__ OtNodes<MAXN> A, B;
   __shared__ int c4[OT_MAXN * 4];          // per node, keys per quadrant
   __shared__ int procIdx[OT_MAXN];         // processing order -> node position
   __shared__ int isSplit[OT_MAXN];         // 1 when the node is split this round (later: creation base)
@@ -365,8 +416,8 @@ __global__ __launch_bounds__(256) void k_octree(const DevParams* __restrict__ Pp
   const int* cc = cellCount + (int64_t)img * P.cellsPerImage + G.cellBase;
   const uint32_t* cin = cellCand + ((int64_t)img * P.cellsPerImage + G.cellBase) * CELL_CAP;
   int n = 0;
-  for (int base = 0; base < ncells; base += 1024) {
-    int m = min(1024, ncells - base);
+  for (int base = 0; base < ncells; base += OT_MAXN) {
+    int m = min(OT_MAXN, ncells - base);
     for (int i = tid; i < m; i += 256) scanbuf[i] = cc[base + i];
     __syncthreads();
     int tot = block_excl_scan_1024(scanbuf, m, scratch);
@@ -424,8 +475,8 @@ __global__ __launch_bounds__(256) void k_octree(const DevParams* __restrict__ Pp
   for (int k = tid; k < n; k += 256) nodeOf[k] = (unsigned short)procIdx[nodeOf[k]];
   __syncthreads();
 
-  OtNodes* cur = &A;
-  OtNodes* nxt = &B;
+  OtNodes<MAXN>* cur = &A;
+  OtNodes<MAXN>* nxt = &B;
   int guard = 0;
   while (!s_done && guard++ < 64) {
     const int S = s_S;
@@ -583,7 +634,7 @@ __global__ __launch_bounds__(256) void k_octree(const DevParams* __restrict__ Pp
       }
     }
     __syncthreads();
-    if (S2 <= OT_MAXN) { OtNodes* t = cur; cur = nxt; nxt = t; }
+    if (S2 <= OT_MAXN) { OtNodes<MAXN>* t = cur; cur = nxt; nxt = t; }
   }
   // ---- best response per node, first maximum wins (:741-757) ----
   const int S = s_S;
@@ -600,6 +651,25 @@ __global__ __launch_bounds__(256) void k_octree(const DevParams* __restrict__ Pp
     if (p < G.kpCap) sel[p] = cand[k];
   }
   if (tid == 0) kpSelCount[lc] = S < G.kpCap ? S : G.kpCap;
+}
+
+__global__ __launch_bounds__(256) void k_octree(const DevParams* __restrict__ Pp, const uint32_t* __restrict__ cellCand,
+                                                    const int* __restrict__ cellCount, uint32_t* __restrict__ candAll,
+                                                    unsigned short* __restrict__ nodeOfAll, int* __restrict__ candCount,
+                                                    uint32_t* __restrict__ kpSel, int* __restrict__ kpSelCount, int img0) {
+  octree_level<1024>(Pp, cellCand, cellCount, candAll, nodeOfAll, candCount, kpSel, kpSelCount, img0);
+}
+__global__ __launch_bounds__(256) void k_octree_512(const DevParams* __restrict__ Pp, const uint32_t* __restrict__ cellCand,
+                                                    const int* __restrict__ cellCount, uint32_t* __restrict__ candAll,
+                                                    unsigned short* __restrict__ nodeOfAll, int* __restrict__ candCount,
+                                                    uint32_t* __restrict__ kpSel, int* __restrict__ kpSelCount, int img0) {
+  octree_level<512>(Pp, cellCand, cellCount, candAll, nodeOfAll, candCount, kpSel, kpSelCount, img0);
+}
+__global__ __launch_bounds__(256) void k_octree_320(const DevParams* __restrict__ Pp, const uint32_t* __restrict__ cellCand,
+                                                    const int* __restrict__ cellCount, uint32_t* __restrict__ candAll,
+                                                    unsigned short* __restrict__ nodeOfAll, int* __restrict__ candCount,
+                                                    uint32_t* __restrict__ kpSel, int* __restrict__ kpSelCount, int img0) {
+  octree_level<320>(Pp, cellCand, cellCount, candAll, nodeOfAll, candCount, kpSel, kpSelCount, img0);
 }
 
 // ---------------------------------------------------------------------------

@@ -499,8 +499,17 @@ pli_status runOrb(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   }
   if (P.cellsPerImage > 0)
     LAUNCH(c, "k_fast_cells", k_fast_cells, dim3(P.cellsPerImage, nimg), dim3(256), 0, c->dP, c->pyr, c->cellCand, c->cellCount, img0);
-  LAUNCH(c, "k_octree", k_octree, dim3(P.nlevels, nimg), dim3(256), 0, c->dP, c->cellCand, c->cellCount, c->candAll,
+  {
+    // node capacity of the octree instance: the list ends at quota..quota+3 nodes (first pass: 4 per root)
+    int need = 0;
+    for (int l = 0; l < P.nlevels; ++l) need = std::max(need, std::max(P.lv[l].nfeatures + 8, 4 * P.lv[l].nIni + 8));
+    if (need <= 320) LAUNCH(c, "k_octree", k_octree_320, dim3(P.nlevels, nimg), dim3(256), 0, c->dP, c->cellCand, c->cellCount, c->candAll,
          c->nodeOf, c->candCount, c->kpSel, c->kpSelCount, img0);
+    else if (need <= 512) LAUNCH(c, "k_octree", k_octree_512, dim3(P.nlevels, nimg), dim3(256), 0, c->dP, c->cellCand, c->cellCount, c->candAll,
+         c->nodeOf, c->candCount, c->kpSel, c->kpSelCount, img0);
+    else LAUNCH(c, "k_octree", k_octree, dim3(P.nlevels, nimg), dim3(256), 0, c->dP, c->cellCand, c->cellCount, c->candAll,
+         c->nodeOf, c->candCount, c->kpSel, c->kpSelCount, img0);
+  }
   LAUNCH(c, "k_blur_orb", k_blur, dim3(c->orbTiles, nimg), dim3(256), 0, c->jobOrb, c->pyr, P.pyrBlock, c->blur, P.pyrBlock, img0);
   LAUNCH(c, "k_kp_counts", k_kp_counts, dim3((nimg + 63) / 64), dim3(64), 0, c->dP, c->kpSelCount, table, Y.record_bytes,
          Y.off_counts, nimg, img0);
