@@ -4,7 +4,7 @@
   python bench.py --gpus N --steps K --warmup W [--frames-per-gpu F]
 
 One "step" = one pass of the whole per-frame hot path (ORB extract x2, LSD/LBD
-extract x2, stereo point + line matching) over a batch of F (default 1024)
+extract x2, stereo point + line matching) over a batch of F (default 2048)
 synthetic EuRoC-shaped stereo frames (752x480, 1200 ORB features, 100 lines) that
 are already resident in HBM, followed for N > 1 by the RCCL gather of the per-frame
 result tables to rank 0.  Weak scaling: every rank processes its own F frames.
@@ -122,7 +122,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames-per-gpu", type=int, default=1024)
+    ap.add_argument("--frames-per-gpu", type=int, default=2048)
     ap.add_argument("--width", type=int, default=752)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--nfeatures", type=int, default=1200)
