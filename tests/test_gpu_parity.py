@@ -514,6 +514,27 @@ def test_full_size_batch_properties(gpu):
         assert_frame_equal(g, fe.parse_record(t1, F - U + i), g.po.Frame(ocfg(g, cfg)), pairs[i][0], pairs[i][1], "pair %d" % i)
 
 
+@pytest.mark.gpu
+def test_large_batch_schedule(gpu):
+    """The large-batch schedule of lsd_mode auto (>= 320 frames: sequential image waves, two per block) on 336 small
+    frames: duplicates identical, distinct pairs equal to the oracle."""
+    g = gpu
+    W, H, F, U = 240, 180, 336, 6
+    pairs = [g.synth.make_stereo_pair(70 + s, W, H) for s in range(U)]
+    images = np.stack([np.stack(pairs[i % U]) for i in range(F)])
+    cfg = g.capi.default_config(W, H, orb_nfeatures=300, lsd_nfeatures=40, max_frames=F)
+    fe = g.Frontend(cfg)
+    left, right = np.ascontiguousarray(images[:, 0]), np.ascontiguousarray(images[:, 1])
+    table = np.zeros(fe.table_bytes(F), np.uint8)
+    g.capi.check(fe.L.pli_batch_run_host(fe.h, F, g.capi.ptr(left), g.capi.ptr(right), W, W * H, g.capi.RUN_ALL,
+                                         g.capi.ptr(table)))
+    recs = table.reshape(F, int(fe.layout.record_bytes))
+    for i in range(U, F):
+        assert np.array_equal(recs[i], recs[i % U]), "record %d differs from its duplicate %d" % (i, i % U)
+    for i in range(U):
+        assert_frame_equal(g, fe.parse_record(table, F - U + i), g.po.Frame(ocfg(g, cfg)), pairs[i][0], pairs[i][1], "pair %d" % i)
+
+
 def test_bow_vocabulary_descent(gpu):
     """SURVEY §8f-2: the per-feature part of DBoW2's transform (Frame::ComputeBoW, Frame.cc:858) on synthetic
     vocabularies of ORBvoc.txt shape (k = 10; ragged trees, stopped words), ORB and LBD descriptors of a real frame."""
