@@ -661,7 +661,7 @@ __global__ __launch_bounds__(256) void k_keylines(const DevParams* __restrict__ 
 // k_sobel: 3x3 Sobel dx, dy (CV_16S) with REFLECT_101 on the blurred image.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_sobel(const uint8_t* __restrict__ in, int64_t imgStride, int W, int H,
-                                               int pitch, short* __restrict__ dxo, short* __restrict__ dyo, int img0) {
+                                               int pitch, short2* __restrict__ dxy, int img0) {
   const int img = blockIdx.z + img0, y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
   if (x >= W) return;
   const uint8_t* base = in + (int64_t)img * imgStride;
@@ -672,8 +672,7 @@ __global__ __launch_bounds__(256) void k_sobel(const uint8_t* __restrict__ in, i
   const int gx = ((int)r0[xp] - (int)r0[xm]) + 2 * ((int)r1[xp] - (int)r1[xm]) + ((int)r2[xp] - (int)r2[xm]);
   const int gy = ((int)r2[xm] - (int)r0[xm]) + 2 * ((int)r2[x] - (int)r0[x]) + ((int)r2[xp] - (int)r0[xp]);
   const int64_t o = (int64_t)img * W * H + (int64_t)y * W + x;
-  dxo[o] = (short)gx;
-  dyo[o] = (short)gy;
+  dxy[o] = make_short2((short)gx, (short)gy);        // interleaved: k_lbd gathers both with one 4-byte load
 }
 
 // ---------------------------------------------------------------------------
@@ -689,7 +688,7 @@ __constant__ int c_lbd_comb[32][2] = {
 
 
 __global__ __launch_bounds__(64) void k_lbd(const DevParams* __restrict__ Pp, const LbdCoef* __restrict__ coef,
-                                            const short* __restrict__ dxa, const short* __restrict__ dya,
+                                            const short2* __restrict__ dxya,
                                             uint8_t* __restrict__ table, int64_t recordBytes, int64_t offCounts,
                                             int64_t offKl0, int64_t offKl1, int64_t offLd0, int64_t offLd1,
                                             float* __restrict__ dbgFloat, int img0) {
@@ -704,8 +703,7 @@ __global__ __launch_bounds__(64) void k_lbd(const DevParams* __restrict__ Pp, co
   if (li >= n) return;
   const pli_keyline kl = reinterpret_cast<const pli_keyline*>(rec + (eye ? offKl1 : offKl0))[li];
   const int W = P.W, H = P.H;
-  const short* pdx = dxa + (int64_t)img * W * H;
-  const short* pdy = dya + (int64_t)img * W * H;
+  const short2* pdxy = dxya + (int64_t)img * W * H;
   const short heightOfLSP = 63, halfHeight = 31;
   const short imageWidth = (short)(W - 1), imageHeight = (short)(H - 1);
   const short lengthOfLSP = (short)kl.numOfPixels;
@@ -723,13 +721,15 @@ __global__ __launch_bounds__(64) void k_lbd(const DevParams* __restrict__ Pp, co
     }
     float sCorX = sCorX0, sCorY = sCorY0;
     float pgdL = 0, ngdL = 0, pgdO = 0, ngdO = 0;
+    // (unrolled: the gathers of several steps are in flight together, the float sums stay in walking order)
+#pragma unroll 8
     for (short wID = 0; wID < lengthOfLSP; wID++) {
       short tempCor = (short)roundf(sCorX);
       short xCor = (tempCor < 0) ? 0 : (tempCor > imageWidth) ? imageWidth : tempCor;
       tempCor = (short)roundf(sCorY);
       short yCor = (tempCor < 0) ? 0 : (tempCor > imageHeight) ? imageHeight : tempCor;
-      const float dx = (float)pdx[(int)yCor * W + xCor];
-      const float dy = (float)pdy[(int)yCor * W + xCor];
+      const short2 g = pdxy[(int)yCor * W + xCor];
+      const float dx = (float)g.x, dy = (float)g.y;
       const float gDL = __fadd_rn(__fmul_rn(dx, dL0), __fmul_rn(dy, dL1));
       const float gDO = __fadd_rn(__fmul_rn(dx, dO0), __fmul_rn(dy, dO1));
       if (gDL > 0) pgdL = __fadd_rn(pgdL, gDL); else ngdL = __fsub_rn(ngdL, gDL);

@@ -77,7 +77,7 @@ struct pli_ctx {
   int* order = nullptr; uint2* regScratch = nullptr; float* seg = nullptr; int* nSeg = nullptr;
   int nChunks = 0, maxSeg = 0;
   pli_keyline* tmpKL = nullptr;
-  short *dx = nullptr, *dy = nullptr;
+  short2* dxy = nullptr;           // Sobel (dx, dy) of level 0, interleaved
   LbdCoef* lbdCoef = nullptr;
   // stereo
   int *sad = nullptr, *bestIdx = nullptr;
@@ -445,8 +445,7 @@ pli_status allocAll(pli_ctx* c) {
   A(c->seg, (size_t)NI * c->maxSeg * 4);
   A(c->nSeg, NI);
   A(c->tmpKL, (size_t)NI * P.maxLines);
-  A(c->dx, (size_t)P.W * P.H * NI);
-  A(c->dy, (size_t)P.W * P.H * NI);
+  A(c->dxy, (size_t)P.W * P.H * NI);
   {
     // BinaryDescriptor ctor weights, binary_descriptor_custom.cpp:217-259 (integer divisions kept)
     LbdCoef C;
@@ -657,9 +656,9 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   LAUNCH(c, "k_blur_lbd", k_blur, dim3(c->l0Tiles, nimg), dim3(256), 0, c->jobLbd, c->pyr, P.pyrBlock, c->tmp8, c->tmp8Stride, img0);
   {
     dim3 g((P.W + 255) / 256, P.H, nimg);
-    LAUNCH(c, "k_sobel", k_sobel, g, dim3(256), 0, c->tmp8, c->tmp8Stride, P.W, P.H, c->tmpPitch, c->dx, c->dy, img0);
+    LAUNCH(c, "k_sobel", k_sobel, g, dim3(256), 0, c->tmp8, c->tmp8Stride, P.W, P.H, c->tmpPitch, c->dxy, img0);
   }
-  LAUNCH(c, "k_lbd", k_lbd, dim3(P.klCap, nimg), dim3(64), 0, c->dP, c->lbdCoef, c->dx, c->dy, table, Y.record_bytes,
+  LAUNCH(c, "k_lbd", k_lbd, dim3(P.klCap, nimg), dim3(64), 0, c->dP, c->lbdCoef, c->dxy, table, Y.record_bytes,
          Y.off_counts, Y.off_kl[0], Y.off_kl[1], Y.off_ldesc[0], Y.off_ldesc[1], c->debug ? c->lbdFloat : (float*)nullptr, img0);
   return PLI_OK;
 }
@@ -1351,8 +1350,11 @@ pli_status pli_debug_fetch(pli_ctx* c, int32_t image, int32_t what, int32_t arg,
     case PLI_DBG_LBD_DXDY: {
       const int64_t n = (int64_t)P.W * P.H * 2;
       if (!need(2 * n)) return dst ? PLI_ERR_CAPACITY : PLI_OK;
-      HIPCHK(hipMemcpy(dst, c->dx + (int64_t)image * P.W * P.H, n, hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy((char*)dst + n, c->dy + (int64_t)image * P.W * P.H, n, hipMemcpyDeviceToHost));
+      // device layout: interleaved (dx, dy) pairs; the caller gets the dx plane followed by the dy plane
+      std::vector<short> tmp((size_t)P.W * P.H * 2);
+      HIPCHK(hipMemcpy(tmp.data(), c->dxy + (int64_t)image * P.W * P.H, 2 * n, hipMemcpyDeviceToHost));
+      short* o = (short*)dst;
+      for (int64_t i = 0; i < (int64_t)P.W * P.H; ++i) { o[i] = tmp[2 * i]; o[(int64_t)P.W * P.H + i] = tmp[2 * i + 1]; }
       return PLI_OK;
     }
     case PLI_DBG_LBD_FLOAT: {
