@@ -700,6 +700,9 @@ __global__ __launch_bounds__(256) void k_blur(const BlurJob* __restrict__ Jp, co
   int kc[7];
 #pragma unroll
   for (int k = 0; k < 7; ++k) kc[k] = k <= 2 * R ? J.k[k] : 0;
+  const bool narrow = (kc[0] | kc[1] | kc[2] | kc[3] | kc[4] | kc[5] | kc[6]) < 256;
+  const uint32_t kLo = (uint32_t)kc[0] | ((uint32_t)kc[1] << 8) | ((uint32_t)kc[2] << 16) | ((uint32_t)kc[3] << 24);
+  const uint32_t kHi = (uint32_t)kc[4] | ((uint32_t)kc[5] << 8) | ((uint32_t)kc[6] << 16);
   uint8_t* t8b = reinterpret_cast<uint8_t*>(t8);
   // stage (64 + 2R) x (32 + 2R) bytes: thread = (row mod 4, column); columns 64.. are loaded by the first 2R threads
   {
@@ -717,14 +720,27 @@ __global__ __launch_bounds__(256) void k_blur(const BlurJob* __restrict__ Jp, co
     const int j = tid & 15, yy = tid >> 4;
     for (int y = yy; y < th; y += 16) {
       const uint32_t w0 = t8[y * 18 + j], w1 = t8[y * 18 + j + 1], w2 = t8[y * 18 + j + 2];
-      int b[12];
+      // output i = taps 0..3 on the bytes i..i+3 + taps 4..6 on the bytes i+4..i+6: two unaligned dwords
+      // (v_alignbyte) and two v_dot4_u32_u8 (the 8-bit coefficients of a row sit in two dwords; 0 beyond 2R)
+      int s[4];
+      if (narrow) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { b[i] = (w0 >> (8 * i)) & 255; b[4 + i] = (w1 >> (8 * i)) & 255; b[8 + i] = (w2 >> (8 * i)) & 255; }
-      int s[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t lo = i ? __builtin_amdgcn_alignbyte(w1, w0, i) : w0;
+          const uint32_t hi = i ? __builtin_amdgcn_alignbyte(w2, w1, i) : w1;
+          s[i] = (int)__builtin_amdgcn_udot4(hi, kHi, __builtin_amdgcn_udot4(lo, kLo, 0u, false), false);
+        }
+      } else {                                           // a coefficient of 256 (a sigma so small that the kernel is a delta)
+        int b[12];
 #pragma unroll
-      for (int k = 0; k < 7; ++k)
+        for (int i = 0; i < 4; ++i) { b[i] = (w0 >> (8 * i)) & 255; b[4 + i] = (w1 >> (8 * i)) & 255; b[8 + i] = (w2 >> (8 * i)) & 255; }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s[i] += kc[k] * b[i + k];     // kc[k] = 0 beyond 2R: b[i + k] stays inside the 12 bytes
+        for (int i = 0; i < 4; ++i) {
+          s[i] = 0;
+#pragma unroll
+          for (int k = 0; k < 7; ++k) s[i] += kc[k] * b[i + k];
+        }
+      }
       *reinterpret_cast<int4*>(&hs[y * 64 + 4 * j]) = make_int4(s[0], s[1], s[2], s[3]);
     }
   }
@@ -794,7 +810,7 @@ __global__ __launch_bounds__(64) void k_describe(const DevParams* __restrict__ P
   // IC_Angle: moments over the radius-15 disc
   int m10 = 0, m01 = 0;
   for (int i = lane; i < 31 * 31; i += 64) {
-    int r = i / 31;
+    int r = (i * 2115) >> 16;                    // i / 31, exact for i < 1024
     int v = r - 15, u = (i - r * 31) - 15;
     int av = v < 0 ? -v : v;
     int au = u < 0 ? -u : u;
@@ -810,7 +826,9 @@ __global__ __launch_bounds__(64) void k_describe(const DevParams* __restrict__ P
   // steered rBRIEF
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
   const float ang = __fmul_rn(angle, factorPI);
-  const float a = (float)cos((double)ang), b = (float)sin((double)ang);
+  double sn, cs;
+  sincos((double)ang, &sn, &cs);
+  const float a = (float)cs, b = (float)sn;
   const uint8_t* bl = blur + (int64_t)img * P.pyrBlock + G.offset;
   const uint8_t* center = bl + (int64_t)ky * G.pitch + kx;
   unsigned long long words[4];
