@@ -681,7 +681,7 @@ __global__ __launch_bounds__(256) void k_octree_320(const DevParams* __restrict_
 __global__ __launch_bounds__(256) void k_blur(const BlurJob* __restrict__ Jp, const uint8_t* __restrict__ in,
                                               int64_t inImgStride, uint8_t* __restrict__ out,
                                               int64_t outImgStride, int img0) {
-  __shared__ uint32_t t8[38 * 18];     // (32 + 2R) rows of 72 bytes
+  __shared__ uint32_t t8[38 * 18 + 2];  // (32 + 2R) rows of 72 bytes (+ the dword a zero-weight tap of the last row may touch)
   __shared__ int hs[38 * 64];
   const BlurJob& J = *Jp;
   const int img = blockIdx.y + img0;
@@ -704,41 +704,47 @@ __global__ __launch_bounds__(256) void k_blur(const BlurJob* __restrict__ Jp, co
   const uint32_t kLo = (uint32_t)kc[0] | ((uint32_t)kc[1] << 8) | ((uint32_t)kc[2] << 16) | ((uint32_t)kc[3] << 24);
   const uint32_t kHi = (uint32_t)kc[4] | ((uint32_t)kc[5] << 8) | ((uint32_t)kc[6] << 16);
   uint8_t* t8b = reinterpret_cast<uint8_t*>(t8);
-  // stage (64 + 2R) x (32 + 2R) bytes: thread = (row mod 4, column); columns 64.. are loaded by the first 2R threads
-  {
+  // stage rows y0-R .. y0+31+R, columns x0-4 .. x0+67 (18 dwords per row; byte b of a row = column x0 - 4 + b)
+  if (x0 >= 4 && x0 + 68 <= PL.w) {
+    // interior columns: aligned 4-byte loads (x0 is a multiple of 64, the rows are 64-byte aligned)
+    for (int i = tid; i < th * 18; i += 256) {
+      const int y = (int)(((float)i + 0.5f) * (1.0f / 18.0f)), d = i - y * 18;     // exact for i < 38 * 18
+      const uint8_t* row = src + (int64_t)reflect101(y0 + y - R, PL.h) * PL.pitchIn;
+      t8[i] = *reinterpret_cast<const uint32_t*>(row + x0 - 4 + 4 * d);
+    }
+  } else {
+    // border columns: bytes with REFLECT_101; thread = (row mod 4, column), columns 64.. by the first 2R threads
     const int x = tid & 63, yy = tid >> 6;
     const int sx0 = reflect101(x0 + x - R, PL.w), sx1 = reflect101(x0 + x + 64 - R, PL.w);
     for (int y = yy; y < th; y += 4) {
       const uint8_t* row = src + (int64_t)reflect101(y0 + y - R, PL.h) * PL.pitchIn;
-      t8b[y * 72 + x] = row[sx0];
-      if (x < 2 * R) t8b[y * 72 + 64 + x] = row[sx1];
+      t8b[y * 72 + 4 - R + x] = row[sx0];
+      if (x < 2 * R) t8b[y * 72 + 68 - R + x] = row[sx1];
     }
   }
   __syncthreads();
-  // horizontal pass: a thread makes 4 adjacent sums from 12 staged bytes
+  // horizontal pass: a thread makes 4 adjacent sums; output i of group j takes the bytes 4j + i + 4 - R + k, k = 0..2R
   {
     const int j = tid & 15, yy = tid >> 4;
     for (int y = yy; y < th; y += 16) {
-      const uint32_t w0 = t8[y * 18 + j], w1 = t8[y * 18 + j + 1], w2 = t8[y * 18 + j + 2];
-      // output i = taps 0..3 on the bytes i..i+3 + taps 4..6 on the bytes i+4..i+6: two unaligned dwords
-      // (v_alignbyte) and two v_dot4_u32_u8 (the 8-bit coefficients of a row sit in two dwords; 0 beyond 2R)
+      const uint32_t w0 = t8[y * 18 + j], w1 = t8[y * 18 + j + 1], w2 = t8[y * 18 + j + 2], w3 = t8[y * 18 + j + 3];
       int s[4];
-      if (narrow) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const uint32_t lo = i ? __builtin_amdgcn_alignbyte(w1, w0, i) : w0;
-          const uint32_t hi = i ? __builtin_amdgcn_alignbyte(w2, w1, i) : w1;
+      for (int i = 0; i < 4; ++i) {
+        const int off = i + 4 - R;                       // 1..6
+        const bool q = off >= 4;
+        const uint32_t a0 = q ? w1 : w0, a1 = q ? w2 : w1, a2 = q ? w3 : w2;
+        const uint32_t lo = __builtin_amdgcn_alignbyte(a1, a0, off & 3);
+        const uint32_t hi = __builtin_amdgcn_alignbyte(a2, a1, off & 3);
+        if (narrow) {
+          // taps 0..3 on one unaligned dword, taps 4..6 on the next: two v_dot4_u32_u8 (coefficients 0 beyond 2R)
           s[i] = (int)__builtin_amdgcn_udot4(hi, kHi, __builtin_amdgcn_udot4(lo, kLo, 0u, false), false);
-        }
-      } else {                                           // a coefficient of 256 (a sigma so small that the kernel is a delta)
-        int b[12];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { b[i] = (w0 >> (8 * i)) & 255; b[4 + i] = (w1 >> (8 * i)) & 255; b[8 + i] = (w2 >> (8 * i)) & 255; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        } else {                                         // a coefficient of 256 (a sigma so small that the kernel is a delta)
           s[i] = 0;
 #pragma unroll
-          for (int k = 0; k < 7; ++k) s[i] += kc[k] * b[i + k];
+          for (int k = 0; k < 4; ++k) s[i] += kc[k] * (int)((lo >> (8 * k)) & 255u);
+#pragma unroll
+          for (int k = 4; k < 7; ++k) s[i] += kc[k] * (int)((hi >> (8 * (k - 4))) & 255u);
         }
       }
       *reinterpret_cast<int4*>(&hs[y * 64 + 4 * j]) = make_int4(s[0], s[1], s[2], s[3]);
