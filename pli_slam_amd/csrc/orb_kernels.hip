@@ -66,46 +66,83 @@ __global__ __launch_bounds__(256) void k_ingest(const uint8_t* __restrict__ left
 
 // ---------------------------------------------------------------------------
 // k_resize_level: cv::resize INTER_LINEAR u8 (11-bit coefficients built on the
-// host exactly as OpenCV builds them).  One thread = 4 output pixels.
+// host exactly as OpenCV builds them).
 // tab: xofs[dw] | alpha[2*dw] (as int) | yofs[dh] | beta[2*dh]
+// A workgroup makes a 256 x 16 block of the output: the source window of the block is staged in LDS with aligned
+// 4-byte loads (0.4 loads per output pixel instead of four byte gathers), a thread keeps the column coefficients of
+// its 4 adjacent outputs in registers for its 4 rows.  Windows that do not fit (scale factors above ~2.4) read
+// the source directly.
 // ---------------------------------------------------------------------------
+constexpr int RZ_W = 640;     // bytes per staged source row
+constexpr int RZ_H = 44;      // staged source rows
+
 __global__ __launch_bounds__(256) void k_resize_level(const uint8_t* __restrict__ srcBase, int64_t srcImgStride,
                                                       int sw, int sh, int spitch, uint8_t* __restrict__ dstBase,
                                                       int64_t dstImgStride, int dw, int dh, int dpitch,
                                                       const int* __restrict__ tab, int img0) {
+  __shared__ uint32_t S[RZ_H * RZ_W / 4];
   const int img = blockIdx.z + img0;
-  const int dy = blockIdx.y;
-  const int dx0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (dx0 >= dw) return;
+  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+  const int dxa = blockIdx.x * 256, dya = blockIdx.y * 16;
   const int* xofs = tab;
   const int* alpha = tab + dw;
   const int* yofs = tab + 3 * dw;
   const int* beta = tab + 3 * dw + dh;
   const uint8_t* src = srcBase + (int64_t)img * srcImgStride;
-  int sy = yofs[dy];
-  int sy0 = sy < 0 ? 0 : (sy >= sh ? sh - 1 : sy);
-  int sy1 = sy + 1 < 0 ? 0 : (sy + 1 >= sh ? sh - 1 : sy + 1);
-  const uint8_t* S0 = src + (int64_t)sy0 * spitch;
-  const uint8_t* S1 = src + (int64_t)sy1 * spitch;
-  const int b0 = beta[2 * dy], b1 = beta[2 * dy + 1];
-  uint8_t out[4];
+  auto clampRow = [&](int y) { return y < 0 ? 0 : (y >= sh ? sh - 1 : y); };
+  // source window of the block
+  const int dxb = min(dxa + 255, dw - 1), dyb = min(dya + 15, dh - 1);
+  const int colBase = xofs[dxa] & ~3;
+  const int ndw = (min(xofs[dxb] + 1, sw - 1) - colBase + 4) >> 2;
+  const int rya = clampRow(yofs[dya]), nrows = clampRow(yofs[dyb] + 1) - rya + 1;
+  const bool staged = ndw * 4 <= RZ_W && nrows <= RZ_H;
+  if (staged) {
+    const float invNdw = 1.0f / (float)ndw;
+    for (int i = tid; i < ndw * nrows; i += 256) {
+      const int r = (int)(((float)i + 0.5f) * invNdw), d = i - r * ndw;          // exact: i < 160 * 44
+      S[r * (RZ_W / 4) + d] = *reinterpret_cast<const uint32_t*>(src + (int64_t)(rya + r) * spitch + colBase + 4 * d);
+    }
+    __syncthreads();
+  }
+  const int dx0 = dxa + tx * 4;
+  if (dx0 >= dw) return;
+  int sx[4], sx1[4], a0[4], a1[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    int dx = dx0 + k;
-    int v = 0;
-    if (dx < dw) {
-      int sx = xofs[dx];
-      int sx1 = sx + 1 < sw ? sx + 1 : sw - 1;
-      int a0 = alpha[2 * dx], a1 = alpha[2 * dx + 1];
-      int r0 = S0[sx] * a0 + S0[sx1] * a1;
-      int r1 = S1[sx] * a0 + S1[sx1] * a1;
-      v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-      v = v < 0 ? 0 : (v > 255 ? 255 : v);
-    }
-    out[k] = (uint8_t)v;
+    const int dx = min(dx0 + k, dw - 1);
+    sx[k] = xofs[dx];
+    sx1[k] = sx[k] + 1 < sw ? sx[k] + 1 : sw - 1;
+    a0[k] = alpha[2 * dx];
+    a1[k] = alpha[2 * dx + 1];
   }
-  uint8_t* dst = dstBase + (int64_t)img * dstImgStride + (int64_t)dy * dpitch + dx0;
-  *reinterpret_cast<uchar4*>(dst) = make_uchar4(out[0], out[1], out[2], out[3]);
+  const uint8_t* Sb = reinterpret_cast<const uint8_t*>(S);
+#pragma unroll 1
+  for (int r = 0; r < 4; ++r) {
+    const int dy = dya + ty + 4 * r;
+    if (dy >= dh) break;
+    const int sy = yofs[dy];
+    const int sy0 = clampRow(sy), sy1 = clampRow(sy + 1);
+    const int b0 = beta[2 * dy], b1 = beta[2 * dy + 1];
+    uint8_t out[4];
+    auto row = [&](auto p0, auto p1) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r0 = p0[sx[k]] * a0[k] + p0[sx1[k]] * a1[k];
+        const int r1 = p1[sx[k]] * a0[k] + p1[sx1[k]] * a1[k];
+        int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        out[k] = (uint8_t)v;
+      }
+    };
+    if (staged) {
+      typedef __attribute__((address_space(3))) const uint8_t lds_u8;
+      row((lds_u8*)(Sb + (sy0 - rya) * RZ_W) - colBase, (lds_u8*)(Sb + (sy1 - rya) * RZ_W) - colBase);
+    } else {
+      row(src + (int64_t)sy0 * spitch, src + (int64_t)sy1 * spitch);
+    }
+    uint8_t* dst = dstBase + (int64_t)img * dstImgStride + (int64_t)dy * dpitch + dx0;
+    *reinterpret_cast<uchar4*>(dst) = make_uchar4(out[0], out[1], out[2], out[3]);
+  }
 }
 
 // ---------------------------------------------------------------------------

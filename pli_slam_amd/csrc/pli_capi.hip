@@ -492,7 +492,7 @@ pli_status runOrb(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   const pli_table_layout& Y = c->lay;
   for (int l = 1; l < P.nlevels; ++l) {
     const LevelGeom &S = P.lv[l - 1], &D = P.lv[l];
-    dim3 g((D.w + 1023) / 1024, D.h, nimg);
+    dim3 g((D.w + 255) / 256, (D.h + 15) / 16, nimg);
     LAUNCH(c, "k_resize_level", k_resize_level, g, dim3(256), 0, c->pyr + S.offset, P.pyrBlock, S.w, S.h, S.pitch,
            c->pyr + D.offset, P.pyrBlock, D.w, D.h, D.pitch, c->resizeTab[l], img0);
   }
@@ -536,7 +536,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   int sPitch;
   if (c->cfg.lsd_scale != 1) {
     LAUNCH(c, "k_blur_lsd", k_blur, dim3(c->l0Tiles, nimg), dim3(256), 0, c->jobLsd, c->pyr, P.pyrBlock, c->tmp8, c->tmp8Stride, img0);
-    dim3 g((P.LW + 1023) / 1024, P.LH, nimg);
+    dim3 g((P.LW + 255) / 256, (P.LH + 15) / 16, nimg);
     LAUNCH(c, "k_resize_lsd", k_resize_level, g, dim3(256), 0, c->tmp8, c->tmp8Stride, P.W, P.H, c->tmpPitch, c->lsdScaled,
            c->lsdStride, P.LW, P.LH, P.lpitch, c->lsdTab, img0);
     scaled = c->lsdScaled; sStride = c->lsdStride; sPitch = P.lpitch;
