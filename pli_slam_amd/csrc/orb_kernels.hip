@@ -850,18 +850,28 @@ __global__ __launch_bounds__(64) void k_describe(const DevParams* __restrict__ P
   const int kx = (int)((cv >> 8) & 0xFFF) + G.minBX, ky = (int)(cv >> 20) + G.minBY;
   const int resp = (int)(cv & 0xFF);
   const uint8_t* im = pyr + (int64_t)img * P.pyrBlock + G.offset;
-  // IC_Angle: moments over the radius-15 disc
+  // IC_Angle: moments over the radius-15 disc.  The disc rows (umax) go through LDS so that the 16 pixel loads of a lane
+  // do not each wait for a table load: they are issued together.
+  __shared__ int s_umax[16];
+  if (lane < 16) s_umax[lane] = P.umax[lane];
+  __syncthreads();
   int m10 = 0, m01 = 0;
-  for (int i = lane; i < 31 * 31; i += 64) {
-    int r = (i * 2115) >> 16;                    // i / 31, exact for i < 1024
-    int v = r - 15, u = (i - r * 31) - 15;
-    int av = v < 0 ? -v : v;
-    int au = u < 0 ? -u : u;
-    if (au <= P.umax[av]) {
-      int val = im[(int64_t)(ky + v) * G.pitch + kx + u];
-      m10 += u * val;
-      m01 += v * val;
-    }
+  int val[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int i = lane + 64 * k;
+    const int r = (i * 2115) >> 16;                // i / 31, exact for i < 1024
+    const int v = r - 15, u = (i - r * 31) - 15;
+    const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
+    val[k] = 0;
+    if (i < 31 * 31 && au <= s_umax[av]) val[k] = im[(int64_t)(ky + v) * G.pitch + kx + u];
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int i = lane + 64 * k;
+    const int r = (i * 2115) >> 16;
+    m10 += ((i - r * 31) - 15) * val[k];
+    m01 += (r - 15) * val[k];
   }
   m10 = wave_sum_i32(m10);
   m01 = wave_sum_i32(m01);
