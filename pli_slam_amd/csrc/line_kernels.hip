@@ -662,17 +662,33 @@ __global__ __launch_bounds__(256) void k_keylines(const DevParams* __restrict__ 
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_sobel(const uint8_t* __restrict__ in, int64_t imgStride, int W, int H,
                                                int pitch, short2* __restrict__ dxy, int img0) {
-  const int img = blockIdx.z + img0, y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
-  if (x >= W) return;
+  // 4 adjacent pixels per thread: 6 bytes of each of the three rows, one 16-byte store of interleaved (dx, dy)
+  const int img = blockIdx.z + img0, y = blockIdx.y, x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (x0 >= W) return;
   const uint8_t* base = in + (int64_t)img * imgStride;
   const uint8_t* r0 = base + (int64_t)reflect101(y - 1, H) * pitch;
   const uint8_t* r1 = base + (int64_t)y * pitch;
   const uint8_t* r2 = base + (int64_t)reflect101(y + 1, H) * pitch;
-  const int xm = reflect101(x - 1, W), xp = reflect101(x + 1, W);
-  const int gx = ((int)r0[xp] - (int)r0[xm]) + 2 * ((int)r1[xp] - (int)r1[xm]) + ((int)r2[xp] - (int)r2[xm]);
-  const int gy = ((int)r2[xm] - (int)r0[xm]) + 2 * ((int)r2[x] - (int)r0[x]) + ((int)r2[xp] - (int)r0[xp]);
-  const int64_t o = (int64_t)img * W * H + (int64_t)y * W + x;
-  dxy[o] = make_short2((short)gx, (short)gy);        // interleaved: k_lbd gathers both with one 4-byte load
+  int a[6], b[6], c[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int xx = reflect101(min(x0 + k - 1, W), W);       // (columns past the image are not stored)
+    a[k] = r0[xx]; b[k] = r1[xx]; c[k] = r2[xx];
+  }
+  short2 o[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int gx = (a[k + 2] - a[k]) + 2 * (b[k + 2] - b[k]) + (c[k + 2] - c[k]);
+    const int gy = (c[k] - a[k]) + 2 * (c[k + 1] - a[k + 1]) + (c[k + 2] - a[k + 2]);
+    o[k] = make_short2((short)gx, (short)gy);      // interleaved: k_lbd gathers both with one 4-byte load
+  }
+  short2* dst = dxy + (int64_t)img * W * H + (int64_t)y * W + x0;
+  if (x0 + 3 < W && (((int64_t)y * W + x0) & 3) == 0 && ((int64_t)W * H & 3) == 0) {
+    *reinterpret_cast<int4*>(dst) = make_int4(*reinterpret_cast<int*>(&o[0]), *reinterpret_cast<int*>(&o[1]),
+                                              *reinterpret_cast<int*>(&o[2]), *reinterpret_cast<int*>(&o[3]));
+  } else {
+    for (int k = 0; k < 4 && x0 + k < W; ++k) dst[k] = o[k];
+  }
 }
 
 // ---------------------------------------------------------------------------

@@ -50,10 +50,15 @@ __global__ __launch_bounds__(64) void k_stereo_points(const DevParams* __restric
   uint64_t dL[4];
   load_desc(descL + (int64_t)iL * 32, dL);
   unsigned long long bestKey = ~0ull;
+  // (row band half-height per level through LDS: the scan below then has no load that waits for another)
+  __shared__ float s_r[MAX_LEVELS];
+  if (lane < MAX_LEVELS) s_r[lane] = lane < P.nlevels ? __fmul_rn(2.0f, P.lv[lane].scale) : 0.f;
+  __syncthreads();
   if (!(maxU < 0)) {
+#pragma unroll 4
     for (int iR = lane; iR < Nr; iR += 64) {
       const pli_keypoint kpR = kpsR[iR];
-      const float r = __fmul_rn(2.0f, P.lv[kpR.octave].scale);
+      const float r = s_r[kpR.octave];
       const int maxr = (int)ceilf(__fadd_rn(kpR.y, r));
       const int minr = (int)floorf(__fsub_rn(kpR.y, r));
       if (rowL < minr || rowL > maxr) continue;

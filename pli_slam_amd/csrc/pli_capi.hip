@@ -655,7 +655,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
          Y.record_bytes, Y.off_counts, Y.off_kl[0], Y.off_kl[1], img0);
   LAUNCH(c, "k_blur_lbd", k_blur, dim3(c->l0Tiles, nimg), dim3(256), 0, c->jobLbd, c->pyr, P.pyrBlock, c->tmp8, c->tmp8Stride, img0);
   {
-    dim3 g((P.W + 255) / 256, P.H, nimg);
+    dim3 g((P.W + 1023) / 1024, P.H, nimg);
     LAUNCH(c, "k_sobel", k_sobel, g, dim3(256), 0, c->tmp8, c->tmp8Stride, P.W, P.H, c->tmpPitch, c->dxy, img0);
   }
   LAUNCH(c, "k_lbd", k_lbd, dim3(P.klCap, nimg), dim3(64), 0, c->dP, c->lbdCoef, c->dxy, table, Y.record_bytes,
