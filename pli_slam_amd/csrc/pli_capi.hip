@@ -554,7 +554,11 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   LAUNCH(c, "k_lsd_hist", k_lsd_hist, dim3(c->nChunks, nimg), dim3(256), 0, c->g2, npix, P.g2Thresh, P.nBins, c->maxG2,
          c->chunkHist, c->nChunks, img0);
   LAUNCH(c, "k_lsd_scan", k_lsd_scan, dim3(nimg), dim3(1024), 0, c->chunkHist, c->nChunks, P.nBins, c->chunkBase, c->nDefined, img0);
-  LAUNCH(c, "k_lsd_scatter", k_lsd_scatter, dim3((unsigned)(8 * ((nimg + 7) / 8) * c->nChunks)), dim3(64), 0, c->g2, npix, P.g2Thresh,
+  // 16 KB of unused dynamic LDS per single-wave workgroup caps the scatter at 8 waves per CU: with all chunks of an image on
+  // one XCD (see the kernel) that keeps the ordered lists "open" in an XCD's 4 MB L2 to ~2 images, so the 4-byte stores of
+  // different chunks merge into whole lines before they are evicted (2048 frames: 21.8 -> 15.3 ms; 32 KB starves the CUs)
+  constexpr size_t scatterOccupancyPad = 16384;
+  LAUNCH(c, "k_lsd_scatter", k_lsd_scatter, dim3((unsigned)(8 * ((nimg + 7) / 8) * c->nChunks)), dim3(64), scatterOccupancyPad, c->g2, npix, P.g2Thresh,
          P.nBins, c->maxG2, c->chunkBase, c->nChunks, c->order, img0, nimg);
   if (sequential) {
     if (nimg >= 64 && !getenv("PLI_GROW_WPB1"))
