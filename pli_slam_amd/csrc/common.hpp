@@ -52,6 +52,8 @@ struct DevParams {
   int nBins;
   int minRegSize;
   double prec, lsdScale;
+  float alignLo, alignHi;     // cos^2(prec + margin), cos^2(prec - margin): bounds of the vector form of the alignment test
+  int alignFilter, alignPad;  // 0: prec too wide for the vector form, every test takes the exact path
   int maxLines;
   int lsdNFeatures;
   double minLength;

@@ -288,6 +288,8 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
   const int nOrder = nDefined[img];
   const int minReg = P.minRegSize;
   const double prec = P.prec, scale = P.lsdScale;
+  const float alignLo = P.alignLo, alignHi = P.alignHi;
+  const bool useFilter = P.alignFilter != 0;
   const int ndx = lane % 3 - 1, ndy = (lane / 3) % 3 - 1;   // lanes 0..8: raster order of the 3x3 block
   int nseg = 0;
 #ifdef LSD_STATS
@@ -321,7 +323,8 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
       const float sa = rl_f(srec.x, j);
       float sumdx = rl_f(scos, j), sumdy = rl_f(ssin, j);
       const int sg2 = __float_as_int(rl_f(srec.w, j));
-      double reg_angle = (double)sa * D_DEG2RAD;
+      double reg_angle = (double)sa * D_DEG2RAD;     // the seed's own angle until the first pixel is added
+      bool angValid = true;                          // reg_angle is current (it is a function of the sums otherwise)
       const int spy = sp / W, spx = sp - spy * W;
       // single-lane work inside these wave-uniform loops is done by the first ACTIVE lane (or by all lanes with
       // the same value): a fixed lane such as lane 0 is not guaranteed to be in the exec mask here
@@ -348,6 +351,10 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
         const bool cand = r.x != LSD_NOTDEF;
         const double ad = (double)r.x * D_DEG2RAD;
         unsigned long long remaining = __builtin_amdgcn_ballot_w64(cand);
+        if (!angValid) {
+          reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * D_DEG2RAD;
+          angValid = true;
+        }
         while (remaining) {
           double n_theta = fabs(reg_angle - ad);
           if (n_theta > D_3_2_PI) {
@@ -389,20 +396,37 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
         float4 r = make_float4(LSD_NOTDEF, 0.f, 0.f, 0.f);
         if (inb) r = rec[qi];
         const bool cand = r.x != LSD_NOTDEF;
-        const double ad = (double)r.x * D_DEG2RAD;
         const unsigned myxy = ((unsigned)ny << 16) | (unsigned)nx;
         unsigned long long remaining = __builtin_amdgcn_ballot_w64(cand);
         LTIME(10, tB0);
         const unsigned long long tB1 = LCLOCK();
+        // The alignment test in vector form (see DevParams::alignLo): "surely aligned" and "surely not" need no
+        // region angle, so the arctangent after every accepted pixel is only evaluated for the rare pixel whose
+        // angle falls inside the margin — that one is decided by the reference's expression.
         while (remaining) {
-          double n_theta = fabs(reg_angle - ad);
-          if (n_theta > D_3_2_PI) {
-            n_theta = fabs(n_theta - D_2PI);
-          }
-          const unsigned long long m = __builtin_amdgcn_ballot_w64(cand && n_theta <= prec) & remaining;
+          const float n2 = __fadd_rn(__fmul_rn(sumdx, sumdx), __fmul_rn(sumdy, sumdy));
+          const float dot = __fadd_rn(__fmul_rn(sumdx, r.y), __fmul_rn(sumdy, r.z));
+          const float d2 = __fmul_rn(dot, dot);
+          // (plain lane masks combined with scalar ops: no per-lane short-circuit branches; `remaining` only holds candidates)
+          unsigned long long mm = __builtin_amdgcn_ballot_w64(dot > 0.f) & __builtin_amdgcn_ballot_w64(d2 >= __fmul_rn(alignLo, n2));
+          if (!useFilter) mm = ~0ull;
+          const unsigned long long m = mm & remaining;
           if (!m) break;
           const int j2 = __ffsll((long long)m) - 1;
           remaining &= ~((2ull << j2) - 1ull);
+          unsigned long long sure = __builtin_amdgcn_ballot_w64(d2 >= __fmul_rn(alignHi, n2));
+          if (!useFilter) sure = 0ull;
+          if (!((sure >> j2) & 1ull)) {
+            if (!angValid) {
+              reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * D_DEG2RAD;
+              angValid = true;
+            }
+            double n_theta = fabs(reg_angle - (double)rl_f(r.x, j2) * D_DEG2RAD);
+            if (n_theta > D_3_2_PI) {
+              n_theta = fabs(n_theta - D_2PI);
+            }
+            if (!(n_theta <= prec)) continue;
+          }
           const int qj = rl_i(qi, j2);
           const float cj = rl_f(r.y, j2), sj = rl_f(r.z, j2);
           if (lane == j2) {                            // lane j2 is in the exec mask: it is a set bit of a ballot
@@ -413,7 +437,7 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
           ++cnt;
           sumdx = __fadd_rn(sumdx, cj);
           sumdy = __fadd_rn(sumdy, sj);
-          reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * D_DEG2RAD;
+          angValid = false;
           unusedMask &= ~__builtin_amdgcn_ballot_w64(sp_l == qj);
         }
         LTIME(11, tB1);
@@ -434,6 +458,7 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
       if (cnt == 1) LSTAT(5, 1);
       if (cnt <= 4) LSTAT(6, 1);
       if (cnt < minReg) continue;
+      if (!angValid) reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * D_DEG2RAD;
       LSTAT(4, 1);
       LSTAT(2, cnt);
       const unsigned long long tRect = LCLOCK();

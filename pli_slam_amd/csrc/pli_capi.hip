@@ -286,6 +286,18 @@ pli_status buildGeometry(pli_ctx* c) {
   P.lpitch = (int)alignUp(P.LW, 64);
   P.prec = 3.14159265358979323846 * cfg.lsd_ang_th / 180;
   {
+    // Vector form of isAligned (lsd.cpp region_grow): the angle between the region's (sumdx, sumdy) and a pixel's
+    // (cos, sin) is within prec  <=>  dot > 0 and dot^2 >= cos^2(prec) |sum|^2.  The sequential grower uses it with a
+    // margin on both sides (fastAtan2 is within 0.01 deg of atan2) and decides only the pixels inside the margin with
+    // the reference's own expression.
+    const double margin = 0.05 * 3.14159265358979323846 / 180;
+    P.alignFilter = (P.prec + margin < 1.5) && (P.prec - margin > 0.01);
+    const double cl = std::cos(P.prec + margin), ch = std::cos(P.prec - margin);
+    P.alignLo = P.alignFilter ? (float)(cl * cl * (1 - 1e-5)) : 0.f;
+    P.alignHi = P.alignFilter ? (float)(ch * ch * (1 + 1e-5)) : 0.f;
+    P.alignPad = 0;
+  }
+  {
     const double rho = cfg.lsd_quant / std::sin(P.prec);
     int g = 0;
     while (std::sqrt(g / 4.0) <= rho) ++g;     // defined  <=>  sqrt(g2/4) > rho
