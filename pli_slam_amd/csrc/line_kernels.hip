@@ -404,17 +404,19 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
         // region angle, so the arctangent after every accepted pixel is only evaluated for the rare pixel whose
         // angle falls inside the margin — that one is decided by the reference's expression.
         while (remaining) {
-          const float n2 = __fadd_rn(__fmul_rn(sumdx, sumdx), __fmul_rn(sumdy, sumdy));
-          const float dot = __fadd_rn(__fmul_rn(sumdx, r.y), __fmul_rn(sumdy, r.z));
-          const float d2 = __fmul_rn(dot, dot);
+          // dot > 0 and dot^2 >= T  <=>  dot * |dot| >= T (T > 0).  This filter only has to be conservative (the margin is
+          // three orders above float rounding), so it may use fused multiply-adds.
+          const float n2 = __builtin_fmaf(sumdx, sumdx, sumdy * sumdy);
+          const float dot = __builtin_fmaf(sumdx, r.y, sumdy * r.z);
+          const float sd2 = dot * __builtin_fabsf(dot);
           // (plain lane masks combined with scalar ops: no per-lane short-circuit branches; `remaining` only holds candidates)
-          unsigned long long mm = __builtin_amdgcn_ballot_w64(dot > 0.f) & __builtin_amdgcn_ballot_w64(d2 >= __fmul_rn(alignLo, n2));
+          unsigned long long mm = __builtin_amdgcn_ballot_w64(sd2 >= alignLo * n2);
           if (!useFilter) mm = ~0ull;
           const unsigned long long m = mm & remaining;
           if (!m) break;
           const int j2 = __ffsll((long long)m) - 1;
           remaining &= ~((2ull << j2) - 1ull);
-          unsigned long long sure = __builtin_amdgcn_ballot_w64(d2 >= __fmul_rn(alignHi, n2));
+          unsigned long long sure = __builtin_amdgcn_ballot_w64(sd2 >= alignHi * n2);
           if (!useFilter) sure = 0ull;
           if (!((sure >> j2) & 1ull)) {
             if (!angValid) {
