@@ -290,6 +290,8 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
   const double prec = P.prec, scale = P.lsdScale;
   const float alignLo = P.alignLo, alignHi = P.alignHi;
   const bool useFilter = P.alignFilter != 0;
+  const bool smallImg = npix < (1 << 21);
+  const float invW = 1.0f / (float)W;
   const int ndx = lane % 3 - 1, ndy = (lane / 3) % 3 - 1;   // lanes 0..8: raster order of the 3x3 block
   int nseg = 0;
 #ifdef LSD_STATS
@@ -325,7 +327,8 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
       const int sg2 = __float_as_int(rl_f(srec.w, j));
       double reg_angle = (double)sa * D_DEG2RAD;     // the seed's own angle until the first pixel is added
       bool angValid = true;                          // reg_angle is current (it is a function of the sums otherwise)
-      const int spy = sp / W, spx = sp - spy * W;
+      // (row of a linear index without an integer division: exact while W * H < 2^21, see the bound in DESIGN.md §5)
+      const int spy = smallImg ? (int)(((float)sp + 0.5f) * invW) : sp / W, spx = sp - spy * W;
       // single-lane work inside these wave-uniform loops is done by the first ACTIVE lane (or by all lanes with
       // the same value): a fixed lane such as lane 0 is not guaranteed to be in the exec mask here
       if (lane == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1) rec[sp].x = LSD_NOTDEF;
@@ -492,8 +495,10 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
         }
         lsd_wave_sync();
       }
-      const double sum = __shfl(acc, 2, 64);
-      const double x = __shfl(acc, 0, 64) / sum, y = __shfl(acc, 1, 64) / sum;
+      // (wave-uniform f64 arithmetic costs a full wave instruction per operation: the two centroid divisions are one
+      // division in lanes 0 and 1, the four end-point divisions below one division in lanes 0..3)
+      const double cq = acc / __shfl(acc, 2, 64);
+      const double x = __shfl(cq, 0, 64), y = __shfl(cq, 1, 64);
       // pass 2: inertia
       acc = 0.0;                                          // lanes 0,1,2 hold Ixx, Iyy, Ixy
       for (int c0 = 0; c0 < cnt; c0 += 64) {
@@ -528,8 +533,8 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
       }
       const double Ixx = __shfl(acc, 0, 64), Iyy = __shfl(acc, 1, 64), Ixy = __shfl(acc, 2, 64);
       const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
-      double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)fast_atan2_deg((float)(lambda - Ixx), (float)Ixy)
-                                             : (double)fast_atan2_deg((float)Ixy, (float)(lambda - Iyy));
+      const bool wide = fabs(Ixx) > fabs(Iyy);
+      double theta = (double)fast_atan2_deg(wide ? (float)(lambda - Ixx) : (float)Ixy, wide ? (float)Ixy : (float)(lambda - Iyy));
       theta *= D_DEG2RAD;
       if (lsd_angle_diff(theta, reg_angle) > prec) theta += D_PI;
       double dxr, dyr;
@@ -547,15 +552,11 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
         l_max = fmax(l_max, __shfl_xor(l_max, o, 64));
         l_min = fmin(l_min, __shfl_xor(l_min, o, 64));
       }
-      double x1 = x + l_min * dxr, y1 = y + l_min * dyr, x2 = x + l_max * dxr, y2 = y + l_max * dyr;
-      x1 += 0.5; y1 += 0.5; x2 += 0.5; y2 += 0.5;
-      if (scale != 1) { x1 /= scale; y1 /= scale; x2 /= scale; y2 /= scale; }
-      if (nseg < maxSeg && lane == 0) {
-        seg[4 * nseg + 0] = (float)x1;
-        seg[4 * nseg + 1] = (float)y1;
-        seg[4 * nseg + 2] = (float)x2;
-        seg[4 * nseg + 3] = (float)y2;
-      }
+      // lanes 0..3: x1, y1, x2, y2
+      double e = ((lane & 1) ? y : x) + ((lane & 2) ? l_max : l_min) * ((lane & 1) ? dyr : dxr);
+      e += 0.5;
+      if (scale != 1) e /= scale;
+      if (nseg < maxSeg && lane < 4) seg[4 * nseg + lane] = (float)e;
       ++nseg;
       LTIME(12, tRect);
     }
