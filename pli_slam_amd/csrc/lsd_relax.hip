@@ -813,8 +813,9 @@ __global__ __launch_bounds__(64) void k_rx_rect(const DevParams* __restrict__ Pp
       }
       __syncthreads();
     }
-    const double sum = __shfl(acc, 2, 64);
-    const double x = __shfl(acc, 0, 64) / sum, y = __shfl(acc, 1, 64) / sum;
+    // (the two centroid divisions are one division in lanes 0 and 1, the four end-point divisions one in lanes 0..3)
+    const double cq = acc / __shfl(acc, 2, 64);
+    const double x = __shfl(cq, 0, 64), y = __shfl(cq, 1, 64);
     acc = 0.0;
     for (int c0 = 0; c0 < cnt; c0 += 64) {
       const int kk = c0 + lane;
@@ -849,8 +850,8 @@ __global__ __launch_bounds__(64) void k_rx_rect(const DevParams* __restrict__ Pp
     }
     const double Ixx = __shfl(acc, 0, 64), Iyy = __shfl(acc, 1, 64), Ixy = __shfl(acc, 2, 64);
     const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
-    double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)fast_atan2_deg((float)(lambda - Ixx), (float)Ixy)
-                                           : (double)fast_atan2_deg((float)Ixy, (float)(lambda - Iyy));
+    const bool wide = fabs(Ixx) > fabs(Iyy);
+    double theta = (double)fast_atan2_deg(wide ? (float)(lambda - Ixx) : (float)Ixy, wide ? (float)Ixy : (float)(lambda - Iyy));
     theta *= RX_DEG2RAD;
     if (rx_angle_diff(theta, reg_angle) > prec) theta += RX_PI;
     double dxr, dyr;
@@ -867,11 +868,12 @@ __global__ __launch_bounds__(64) void k_rx_rect(const DevParams* __restrict__ Pp
       l_max = fmax(l_max, __shfl_xor(l_max, o, 64));
       l_min = fmin(l_min, __shfl_xor(l_min, o, 64));
     }
-    double x1 = x + l_min * dxr, y1 = y + l_min * dyr, x2 = x + l_max * dxr, y2 = y + l_max * dyr;
-    x1 += 0.5; y1 += 0.5; x2 += 0.5; y2 += 0.5;
+    // lanes 0..3: x1, y1, x2, y2
+    double e = ((lane & 1) ? y : x) + ((lane & 2) ? l_max : l_min) * ((lane & 1) ? dyr : dxr);
+    e += 0.5;
     const double scale = P.lsdScale;
-    if (scale != 1) { x1 /= scale; y1 /= scale; x2 /= scale; y2 /= scale; }
-    if (lane == 0) rgSeg[it.rank] = make_float4((float)x1, (float)y1, (float)x2, (float)y2);
+    if (scale != 1) e /= scale;
+    if (lane < 4) reinterpret_cast<float*>(&rgSeg[it.rank])[lane] = (float)e;
   }
 }
 
