@@ -454,12 +454,14 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
           batch(k, nb);
           k += nb;
         } else {
+          LSTAT(13, 1);
           if (cnt + 9 > LSD_QCAP) step(k, std::true_type{});
           else step(k, std::false_type{});
           ++k;
         }
       }
       LSTAT(3, cnt);
+      if (cnt + 65 > LSD_QCAP) { LSTAT(14, cnt); LSTAT(15, 1); }
       if (cnt == 1) LSTAT(5, 1);
       if (cnt <= 4) LSTAT(6, 1);
       if (cnt < minReg) continue;
