@@ -515,6 +515,24 @@ def test_full_size_batch_properties(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ang", [2.0, 45.0, 80.0, 86.5, 130.0])
+def test_sequential_grower_angle_tolerances(gpu, ang):
+    """The sequential grower decides alignment in vector form (dot^2 against cos^2(prec +- margin) |sum|^2) and takes the
+    reference's expression inside the margin; from prec + margin >= 1.5 rad (85.9 deg) on only the reference's expression
+    is used.  Both regimes and the narrow end against the oracle."""
+    g = gpu
+    W, H = 376, 240
+    cfg = g.capi.default_config(W, H, orb_nfeatures=200, lsd_nfeatures=0, max_frames=1, lsd_mode=2, lsd_ang_th=ang)
+    fe = g.Frontend(cfg)
+    fr = g.po.Frame(ocfg(g, cfg))
+    for seed in (90, 91):
+        L, _ = g.synth.make_stereo_pair(seed, W, H)
+        n, kl, ld = fe.line_extract(0, L)
+        m, okl, old = fr.line_extract(0, L)
+        assert n == m and kl.tobytes() == okl.tobytes() and np.array_equal(ld, old), "ang_th %g seed %d" % (ang, seed)
+
+
+@pytest.mark.gpu
 def test_large_batch_schedule(gpu):
     """The large-batch schedule of lsd_mode auto (>= 320 frames: sequential image waves, two per block) on 336 small
     frames: duplicates identical, distinct pairs equal to the oracle."""

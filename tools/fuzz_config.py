@@ -48,6 +48,8 @@ run("LSD scale 0.5", lsd_scale=0.5)
 run("LSD scale 2.0", lsd_scale=2.0)
 run("LSD angle tolerance 5 deg", lsd_ang_th=5.0)
 run("LSD angle tolerance 60 deg", lsd_ang_th=60.0)
+for ang in (1.0, 5.0, 22.5, 45.0, 60.0, 85.0, 86.5, 120.0):       # sequential waves: vector-form alignment test; >= 85.9 deg: exact path only
+    run("sequential waves, angle tolerance %g deg" % ang, lsd_ang_th=ang, lsd_mode=2)
 run("LSD quant 0.5", lsd_quant=0.5)
 run("LSD quant 8", lsd_quant=8.0)
 run("min line length 0.3", min_line_length=0.3)
