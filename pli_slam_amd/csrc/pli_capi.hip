@@ -77,6 +77,7 @@ struct pli_ctx {
   RxCtl* jrCtl = nullptr;
   std::vector<RxCtl> jrHost;
   int lsdMode = 0;     // 0 auto, 1 relaxation, 2 sequential (cfg.lsd_mode, or PLI_LSD_MODE)
+  int rxLastRounds = 0; // rounds the relaxation ran in the previous call (where the host starts looking at the state)
   unsigned short* chunkHist = nullptr; int* chunkBase = nullptr; int* nDefined = nullptr;
   int* order = nullptr; uint2* regScratch = nullptr; float* seg = nullptr; int* nSeg = nullptr;
   int nChunks = 0, maxSeg = 0;
@@ -616,6 +617,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     const dim3 raster((P.LW + 255) / 256, P.LH, nimg);
     TRL(c, "k_rx_guess", k_rx_guess, raster, dim3(256), 0, c->rec, c->rankOf, c->own, P.LW, P.LH, precDeg, img0);
     bool allDone = false;
+    const int firstLook = c->rxLastRounds > 0 ? std::max(4, c->rxLastRounds) : 4;
     for (int t = 1; t <= maxRounds && !allDone; ++t) {
       curT = t;
       TRL(c, "k_rx_diff", k_rx_diff, dim3((P.LW + 31) / 32, c->tilesH, nimg), dim3(256), 0, c->jrCtl, c->own, c->tileMin, c->tileAct,
@@ -652,11 +654,18 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
                      h.state, h.changed, h.overflow, h.nSmall, h.nBig, h.nHand, h.nextBig, (int)(h.rectArena >> RX_ARENA_BITS),
                      (long long)(h.rectArena & ((1ull << RX_ARENA_BITS) - 1ull)), h.races);
       }
-      if ((t >= 4 && (t % 2) == 0) || t == maxRounds) {
+      // the host looks at the state every second round, starting where the previous call on this context ended (a
+      // stream of similar frames settles after a similar number of rounds; each look drains the stream)
+      if ((t >= firstLook && ((t - firstLook) % 2) == 0) || t == maxRounds) {
         HIPCHK(hipMemcpyAsync(c->jrHost.data(), c->jrCtl + img0, sizeof(RxCtl) * nimg, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         allDone = true;
-        for (int i = 0; i < nimg; ++i) allDone = allDone && (c->jrHost[i].state == 2 || c->jrHost[i].overflow);
+        int settled = 0;
+        for (int i = 0; i < nimg; ++i) {
+          allDone = allDone && (c->jrHost[i].state == 2 || c->jrHost[i].overflow);
+          settled = std::max(settled, c->jrHost[i].rounds);
+        }
+        if (allDone) c->rxLastRounds = settled;       // the round in which the last image reached its fixed point
       }
     }
     TRL(c, "k_rx_count", k_rx_count, dim3(c->rxChunks, nimg), dim3(256), 0, c->jrCtl, c->order, c->nDefined, c->own, c->lastSize,
