@@ -741,23 +741,26 @@ __global__ __launch_bounds__(256) void k_blur(const BlurJob* __restrict__ Jp, co
   const uint32_t kLo = (uint32_t)kc[0] | ((uint32_t)kc[1] << 8) | ((uint32_t)kc[2] << 16) | ((uint32_t)kc[3] << 24);
   const uint32_t kHi = (uint32_t)kc[4] | ((uint32_t)kc[5] << 8) | ((uint32_t)kc[6] << 16);
   uint8_t* t8b = reinterpret_cast<uint8_t*>(t8);
-  // stage rows y0-R .. y0+31+R, columns x0-4 .. x0+67 (18 dwords per row; byte b of a row = column x0 - 4 + b)
-  if (x0 >= 4 && x0 + 68 <= PL.w) {
-    // interior columns: aligned 4-byte loads (x0 is a multiple of 64, the rows are 64-byte aligned)
-    for (int i = tid; i < th * 18; i += 256) {
-      const int y = (int)(((float)i + 0.5f) * (1.0f / 18.0f)), d = i - y * 18;     // exact for i < 38 * 18
-      const uint8_t* row = src + (int64_t)reflect101(y0 + y - R, PL.h) * PL.pitchIn;
-      t8[i] = *reinterpret_cast<const uint32_t*>(row + x0 - 4 + 4 * d);
+  // stage rows y0-R .. y0+31+R, columns x0-4 .. x0+67 (18 dwords per row; byte b of a row = column x0 - 4 + b): a dword
+  // that lies inside the image is one aligned 4-byte load (x0 is a multiple of 64, the rows are 64-byte aligned), a dword
+  // that crosses the left or right border is put together from REFLECT_101 bytes
+  for (int i = tid; i < th * 18; i += 256) {
+    const int y = (int)(((float)i + 0.5f) * (1.0f / 18.0f)), d = i - y * 18;     // exact for i < 38 * 18
+    const uint8_t* row = src + (int64_t)reflect101(y0 + y - R, PL.h) * PL.pitchIn;
+    const int px = x0 - 4 + 4 * d;
+    uint32_t v;
+    if (px >= 0 && px + 3 < PL.w) {
+      v = *reinterpret_cast<const uint32_t*>(row + px);
+    } else {
+      v = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        // (columns further than R outside the image are never used by a stored output: clamped to keep the reflection single)
+        const int xx = reflect101(min(max(px + k, -R), PL.w - 1 + R), PL.w);
+        v |= (uint32_t)row[xx] << (8 * k);
+      }
     }
-  } else {
-    // border columns: bytes with REFLECT_101; thread = (row mod 4, column), columns 64.. by the first 2R threads
-    const int x = tid & 63, yy = tid >> 6;
-    const int sx0 = reflect101(x0 + x - R, PL.w), sx1 = reflect101(x0 + x + 64 - R, PL.w);
-    for (int y = yy; y < th; y += 4) {
-      const uint8_t* row = src + (int64_t)reflect101(y0 + y - R, PL.h) * PL.pitchIn;
-      t8b[y * 72 + 4 - R + x] = row[sx0];
-      if (x < 2 * R) t8b[y * 72 + 68 - R + x] = row[sx1];
-    }
+    t8[i] = v;
   }
   __syncthreads();
   // horizontal pass: a thread makes 4 adjacent sums; output i of group j takes the bytes 4j + i + 4 - R + k, k = 0..2R
