@@ -160,6 +160,10 @@ pli_status pli_ctx_sync(pli_ctx* ctx);
 /* `frame_stride` bytes apart (no alignment needed).  Output: `dev_table` =  */
 /* nframes records, 16-byte aligned (PLI_ERR_INVALID otherwise).             */
 /* Asynchronous on the context stream; pli_ctx_sync() to wait.               */
+/* Monocular / RGB-D colour streams (Frame.cc:231,334: one image per frame):  */
+/* pass frame 0 as `left`, frame 1 as `right`, frame_stride = two frames,     */
+/* nframes = half the stream, stages = PLI_RUN_ORB | PLI_RUN_LINES — frames   */
+/* 2i and 2i+1 then fill the two eye slots of record i.                       */
 /* ------------------------------------------------------------------------ */
 enum {
   PLI_RUN_ORB = 1, PLI_RUN_LINES = 2, PLI_RUN_STEREO_POINTS = 4, PLI_RUN_STEREO_LINES = 8,

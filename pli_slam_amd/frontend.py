@@ -213,6 +213,25 @@ class Frontend:
         check(self.L.pli_batch_run_host(self.h, nf, ptr(left), ptr(right), W, W * H, stages, ptr(table)))
         return [self.parse_record(table, f) for f in range(nf)]
 
+    def batch_run_mono_host(self, images, stages=capi.RUN_ORB | capi.RUN_LINES):
+        """A monocular (or RGB-D colour) stream through the batch entry point: the frames 2i and 2i+1 take the two eye
+        slots of record i (left pointer = frame 0, right pointer = frame 1, frame stride = two frames), the stereo stages
+        stay off.  images: (nframes, H, W) u8, nframes even.  Returns one dict per frame: kp, desc, kl, ldesc — what the
+        monocular Frame constructor (Frame.cc:334) extracts."""
+        images = np.ascontiguousarray(images, np.uint8)
+        nf, H, W = images.shape
+        assert nf % 2 == 0 and not (stages & (capi.RUN_STEREO_POINTS | capi.RUN_STEREO_LINES))
+        table = np.zeros(self.table_bytes(nf // 2), np.uint8)
+        base = images.ctypes.data
+        check(self.L.pli_batch_run_host(self.h, nf // 2, C.c_void_p(base), C.c_void_p(base + W * H), W, 2 * W * H, stages,
+                                        ptr(table)))
+        out = []
+        for f in range(nf):
+            r = self.parse_record(table, f // 2)
+            e = "LR"[f & 1]
+            out.append({"kp": r["kp" + e], "desc": r["desc" + e], "kl": r["kl" + e], "ldesc": r["ldesc" + e]})
+        return out
+
     def batch_run_device(self, nframes, dev_left, dev_right, stride, frame_stride, dev_table, stages=capi.RUN_ALL):
         """Asynchronous: device pointers (ints) in, device table out; sync() to wait."""
         check(self.L.pli_batch_run(self.h, nframes, C.c_void_p(dev_left), C.c_void_p(dev_right), stride, frame_stride,

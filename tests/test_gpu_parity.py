@@ -515,6 +515,25 @@ def test_full_size_batch_properties(gpu):
 
 
 @pytest.mark.gpu
+def test_mono_stream_through_batch_entry(gpu):
+    """SURVEY §8f-4, monocular / RGB-D colour streams: consecutive frames take the two eye slots of a record
+    (pointer arithmetic on the existing batch entry point, stereo stages off); every frame equals the oracle's
+    single-image extraction (what Frame.cc:334 / :231 run)."""
+    g = gpu
+    W, H, NF = 376, 240, 6
+    frames = np.stack([g.synth.make_stereo_pair(120 + i, W, H)[i & 1] for i in range(NF)])
+    cfg = g.capi.default_config(W, H, orb_nfeatures=500, lsd_nfeatures=50, max_frames=NF // 2)
+    fe = g.Frontend(cfg)
+    out = fe.batch_run_mono_host(frames)
+    fr = g.po.Frame(ocfg(g, cfg))
+    for f in range(NF):
+        n, kp, desc = fr.orb_extract(0, frames[f])
+        assert n == len(out[f]["kp"]) and kp.tobytes() == out[f]["kp"].tobytes() and np.array_equal(desc, out[f]["desc"]), "orb frame %d" % f
+        m, kl, ld = fr.line_extract(0, frames[f])
+        assert m == len(out[f]["kl"]) and kl.tobytes() == out[f]["kl"].tobytes() and np.array_equal(ld, out[f]["ldesc"]), "lines frame %d" % f
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ang", [2.0, 45.0, 80.0, 86.5, 130.0])
 def test_sequential_grower_angle_tolerances(gpu, ang):
     """The sequential grower decides alignment in vector form (dot^2 against cos^2(prec +- margin) |sum|^2) and takes the
