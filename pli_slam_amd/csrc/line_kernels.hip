@@ -214,6 +214,8 @@ __global__ __launch_bounds__(64) void k_lsd_scatter(const int* __restrict__ g2a,
 // -DLSD_STATS (make EXTRA=-DLSD_STATS): per-image counts of the sequential grower, read by tools/lsd_stats.py
 #ifdef LSD_STATS
 __device__ unsigned long long g_lsdStats[16];
+__device__ unsigned long long g_lsdStatsMax;
+extern "C" unsigned long long pli_lsd_stats_max() { unsigned long long v = 0, z = 0; (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_lsdStatsMax), 8); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lsdStatsMax), &z, 8); return v; }
 extern "C" void pli_lsd_stats(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lsdStats), 128); unsigned long long z[16] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lsdStats), z, 128); }
 #define LSTAT(i, v) do { if (lane == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1) stt[i] += (v); } while (0)
 #define LCLOCK() __builtin_readcyclecounter()
@@ -567,6 +569,7 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
 #ifdef LSD_STATS
   LTIME(8, tKernel);
   if (lane == 0) for (int i = 0; i < 16; ++i) atomicAdd(&g_lsdStats[i], stt[i]);
+  if (lane == 0) atomicMax(&g_lsdStatsMax, stt[8]);
 #endif
 }
 
