@@ -117,6 +117,36 @@ def cpu_baseline(images, cfg_bytes, budget_s=20.0):
                       "thread, %.1f s; single frame single thread %.3f s" % (done, nthreads, dt, t1)}
 
 
+def parity_check(fe, cfg, d_table, images, F, nuniq, rec_bytes):
+    """The table of the last timed step against the oracle (part of the cpu_baseline leg, outside the timed region):
+    every record must equal the first record of its image pair, and the first and last distinct pairs must equal the
+    oracle's frame (keypoints, descriptors, keylines, LBD, uRight/depth, line disparities), byte for byte."""
+    import torch
+    from oracle import pyoracle as po
+    recs = d_table.view(F, rec_bytes)
+    idx = torch.arange(F, device=recs.device) % nuniq
+    dup_bad = int((recs != recs[idx]).any(dim=1).sum().item())
+    host = recs[:nuniq].cpu().numpy().reshape(-1)
+    checked, bad = 0, 0
+    for i in sorted({0, nuniq - 1}):
+        r = fe.parse_record(host, i)
+        fr = po.Frame(po.Config.from_buffer_copy(bytes(cfg)))
+        ok = True
+        for eye, k in ((0, "L"), (1, "R")):
+            n, kp, desc = fr.orb_extract(eye, images[i, eye])
+            ok &= n == len(r["kp" + k]) and kp.tobytes() == r["kp" + k].tobytes() and np.array_equal(desc, r["desc" + k])
+            m, kl, ld = fr.line_extract(eye, images[i, eye])
+            ok &= m == len(r["kl" + k]) and kl.tobytes() == r["kl" + k].tobytes() and np.array_equal(ld, r["ldesc" + k])
+        ur, dp, _, _ = fr.stereo_points()
+        ok &= ur.tobytes() == r["uright"].tobytes() and dp.tobytes() == r["depth"].tobytes()
+        disp, le, _ = fr.stereo_lines()
+        ok &= disp.tobytes() == r["disp"].tobytes()
+        checked += 1
+        bad += 0 if ok else 1
+    return {"ok": dup_bad == 0 and bad == 0, "records": F, "records_differing_from_first_copy": dup_bad,
+            "pairs_checked_against_oracle": checked, "pairs_mismatching": bad}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -272,6 +302,7 @@ def main():
             out["single_pair"] = {"ms": (time.perf_counter() - ts) / 10 * 1e3, "note": "one stereo pair per call, 10 calls"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(images, bytes(cfg))
+            out["parity"] = parity_check(fe, cfg, d_table, images, F, nuniq, rec_bytes)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
