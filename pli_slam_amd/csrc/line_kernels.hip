@@ -824,29 +824,30 @@ __global__ __launch_bounds__(64) void k_lbd(const DevParams* __restrict__ Pp, co
     des[i] = v;
   }
   __syncthreads();
-  if (lane == 0) {
+  {
+    // The three normalisation sums run over the 72 entries in index order (float addition order is part of the result).
+    // Every lane keeps its entries in registers, the squares are computed in parallel and the ordered sums read them
+    // with v_readlane (a scalar operand per term) instead of one dependent LDS read per term.
+    const float d0 = des[lane], d1 = lane < 8 ? des[64 + lane] : 0.f;            // entry lane and entry 64 + lane
+    const float q0 = __fmul_rn(d0, d0), q1 = __fmul_rn(d1, d1);
     float tempM = 0, tempS = 0;
-    for (int i = 0; i < 72; i += 8) {
-      tempM = __fadd_rn(tempM, __fmul_rn(des[i], des[i]));
-      tempM = __fadd_rn(tempM, __fmul_rn(des[i + 1], des[i + 1]));
-      tempM = __fadd_rn(tempM, __fmul_rn(des[i + 2], des[i + 2]));
-      tempM = __fadd_rn(tempM, __fmul_rn(des[i + 3], des[i + 3]));
-      tempS = __fadd_rn(tempS, __fmul_rn(des[i + 4], des[i + 4]));
-      tempS = __fadd_rn(tempS, __fmul_rn(des[i + 5], des[i + 5]));
-      tempS = __fadd_rn(tempS, __fmul_rn(des[i + 6], des[i + 6]));
-      tempS = __fadd_rn(tempS, __fmul_rn(des[i + 7], des[i + 7]));
+#pragma unroll
+    for (int i = 0; i < 72; ++i) {
+      const float q = rl_f(i < 64 ? q0 : q1, i & 63);
+      if (i & 4) tempS = __fadd_rn(tempS, q); else tempM = __fadd_rn(tempM, q);
     }
     tempM = __fdiv_rn(1.f, sqrtf(tempM));
     tempS = __fdiv_rn(1.f, sqrtf(tempS));
-    for (int i = 0; i < 72; ++i) {
-      float v = __fmul_rn(des[i], (i & 4) ? tempS : tempM);
-      if ((double)v > 0.4) v = (float)0.4;
-      des[i] = v;
-    }
+    float v0 = __fmul_rn(d0, (lane & 4) ? tempS : tempM), v1 = __fmul_rn(d1, (lane & 4) ? tempS : tempM);   // (64 + lane) & 4 == lane & 4
+    if ((double)v0 > 0.4) v0 = (float)0.4;
+    if ((double)v1 > 0.4) v1 = (float)0.4;
+    const float p0 = __fmul_rn(v0, v0), p1 = __fmul_rn(v1, v1);
     float temp = 0;
-    for (int i = 0; i < 72; ++i) temp = __fadd_rn(temp, __fmul_rn(des[i], des[i]));
+#pragma unroll
+    for (int i = 0; i < 72; ++i) temp = __fadd_rn(temp, rl_f(i < 64 ? p0 : p1, i & 63));
     temp = __fdiv_rn(1.f, sqrtf(temp));
-    for (int i = 0; i < 72; ++i) des[i] = __fmul_rn(des[i], temp);
+    des[lane] = __fmul_rn(v0, temp);
+    if (lane < 8) des[64 + lane] = __fmul_rn(v1, temp);
   }
   __syncthreads();
   if (dbgFloat) {
