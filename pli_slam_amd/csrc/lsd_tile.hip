@@ -1,0 +1,378 @@
+// LSD region growing as a TILE-SEQUENTIAL rank-ordered relaxation (lsd_mode 3) — exact at convergence,
+// like lsd_relax.hip, but with the sequential order kept INSIDE every tile:
+//
+//   * the scaled image is cut into tiles of ts x ts pixels; one wave per tile walks the seeds of ITS tile in rank
+//     order (k_tx_sort builds the per-tile lists once) and grows each alive one with the batched wave-wide steps of
+//     the sequential grower (8 queue entries x 8 neighbours per round trip, line_kernels.hip);
+//   * ownership is the relaxation's: owner_t[q] = rank of the region that takes q in round t, claimed with
+//     atomicMin; a pixel is used for region r iff owner_{t-1}[q] < r or a lower rank claimed it in this round.
+//     The claims of the wave's own earlier regions are always visible to it, so every dependency chain that stays
+//     inside a tile is resolved in ONE round; only chains that cross tile borders need further rounds.
+//
+// Correctness is the relaxation's induction on rank (lsd_relax.hip header): if every rank below r is final in
+// owner_{t-1}, region r reads only final data in round t (claims seen in the round are claims of lower ranks and
+// persist in owner_t) and is computed exactly, for ANY owner_0 and any interleaving of the tile waves; hence
+// owner_t == owner_{t-1} implies the sequential result.  Measured on the EuRoC-shaped stream (CPU simulation
+// tools/sim/sim_tile_relax.cpp and the GPU counters agree): 7-8 rounds instead of 13-17, 1.4x the sequential
+// steps in round 1 (tiles of 64) and a few per cent of them from round 3 on, where only the regions next to a
+// change are regrown (k_rx_diff / k_rx_mark of lsd_relax.hip decide which, k_tx_prep pre-claims the others).
+//
+// owner_0 is the trivial map (every pixel its own region): rounds 1 and 2 regrow everything, round t >= 3 only
+// what k_rx_mark stamps dirty.
+#include "kernels.hpp"
+#include "device_prims.hpp"
+#include <climits>
+#include <type_traits>
+
+namespace pli {
+
+constexpr float TX_NOTDEF = -1024.f;
+constexpr int TX_INF = 0x7F7F7F7F;          // rank plane of undefined pixels (hipMemset 0x7F)
+constexpr double TX_PI = 3.14159265358979323846;
+constexpr double TX_DEG2RAD = TX_PI / 180;
+constexpr double TX_3_2_PI = (3 * TX_PI) / 2;
+constexpr double TX_2PI = 2 * TX_PI;
+constexpr int TX_GQ = 1024;       // queue entries of a region kept in LDS
+constexpr int TX_BBLK = 256;      // arena block for the overflow of a large region's queue
+constexpr int TX_BMAXBLK = 128;   // => regions of up to TX_GQ + 32768 pixels
+
+__device__ __forceinline__ int2 tx_load_own(const int2* p) {
+  // bypass the per-CU L1: claims (atomics) are performed in L2 / memory
+  unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+  return make_int2((int)(v & 0xFFFFFFFFull), (int)(v >> 32));
+}
+__device__ __forceinline__ int tx_lds_read(const int* p) {
+  typedef __attribute__((address_space(3))) const volatile int lds_cvint;
+  return *(lds_cvint*)p;
+}
+__device__ __forceinline__ int tx_rl(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float tx_rlf(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+// ---------------------------------------------------------------------------
+// k_tx_sort: the seeds of every tile in rank order.  One workgroup per tile: the ranks of the tile's pixels are
+// sorted in LDS (bitonic, ts*ts keys); list entry = (rank, pixel).  Also writes owner_0 = (rank, rank).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tx_sort(const int* __restrict__ rankAll, const int* __restrict__ orderAll,
+                                                 int2* __restrict__ ownAll, int2* __restrict__ listAll,
+                                                 int* __restrict__ tileCntAll, int W, int H, int ts, int ntx, int nty, int img0) {
+  extern __shared__ unsigned keys[];
+  __shared__ int s_cnt;
+  const int img = blockIdx.y + img0, tile = blockIdx.x, tid = threadIdx.x;
+  const int n2 = ts * ts;
+  const int tx0 = (tile % ntx) * ts, ty0 = (tile / ntx) * ts;
+  const int64_t npix = (int64_t)W * H;
+  const int* rank = rankAll + img * npix;
+  int2* own = ownAll + img * npix;
+  if (tid == 0) s_cnt = 0;
+  for (int i = tid; i < n2; i += 256) {
+    const int x = tx0 + i % ts, y = ty0 + i / ts;
+    unsigned k = 0xFFFFFFFFu;
+    if (x < W && y < H) {
+      const int r = rank[y * W + x];
+      if (r != TX_INF) {
+        k = (unsigned)r;
+        own[y * W + x] = make_int2(r, r);
+      }
+    }
+    keys[i] = k;
+  }
+  __syncthreads();
+  for (int k = 2; k <= n2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < n2; i += 256) {
+        const int p = i ^ j;
+        if (p > i) {
+          const unsigned a = keys[i], b = keys[p];
+          const bool asc = (i & k) == 0;
+          if ((a > b) == asc) { keys[i] = b; keys[p] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  int2* list = listAll + ((int64_t)img * ntx * nty + tile) * n2;
+  const int* order = orderAll + img * npix;
+  for (int i = tid; i < n2; i += 256) {
+    const unsigned k = keys[i];
+    if (k != 0xFFFFFFFFu) {
+      list[i] = make_int2((int)k, order[k]);
+      if (i + 1 == n2 || keys[i + 1] == 0xFFFFFFFFu) s_cnt = i + 1;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) tileCntAll[(int64_t)img * ntx * nty + tile] = s_cnt;
+}
+
+// ---------------------------------------------------------------------------
+// k_tx_prep (rounds >= 3, after k_rx_diff and k_rx_mark): owner_t is rewritten in the active 8x8 cells only:
+// a pixel whose previous owner is carried (not stamped dirty) stays with it, any other falls back to its own
+// rank.  Elsewhere owner_{t-2} == owner_{t-1} and the owner is carried: the word that is there is right.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_tx_prep(RxCtl* __restrict__ ctl, int2* __restrict__ ownAll,
+                                                 const int* __restrict__ rankAll, const int* __restrict__ rgDirtyAll,
+                                                 const int* __restrict__ tileActAll, int W, int H, int TW, int TH, int t, int img0) {
+  __shared__ int s_act;
+  const int img = blockIdx.z + img0;
+  RxCtl& c = ctl[img];
+  if (c.state == 2) return;
+  const int tid = threadIdx.x;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) c.changed = 0;
+  if (tid == 0) s_act = 0;
+  __syncthreads();
+  if (tid < 16) {
+    const int tx = blockIdx.x * 4 + (tid & 3), ty = blockIdx.y * 4 + (tid >> 2);
+    if (tx < TW && ty < TH && tileActAll[(int64_t)img * TW * TH + ty * TW + tx] == t) s_act = 1;
+  }
+  __syncthreads();
+  if (!s_act) return;
+  const int x = blockIdx.x * 32 + (tid & 31), y = blockIdx.y * 32 + (tid >> 5);
+  if (x >= W || y >= H) return;
+  const int64_t base = (int64_t)img * W * H;
+  const int p = y * W + x;
+  const int r = rankAll[base + p];
+  if (r == TX_INF) return;
+  const int ci = t & 1;
+  int2 o = ownAll[base + p];
+  const int prevv = ci ? o.x : o.y;
+  const int cur = rgDirtyAll[base + prevv] != t ? prevv : r;
+  if (cur != (ci ? o.y : o.x)) {
+    if (ci) o.y = cur; else o.x = cur;
+    ownAll[base + p] = o;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_tx_grow: one wave per tile walks the tile's seeds in rank order.
+// ---------------------------------------------------------------------------
+template <bool SPARSE>
+__device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
+                                             const float4* __restrict__ recAll, int2* __restrict__ ownAll,
+                                             const int2* __restrict__ listAll, const int* __restrict__ tileCntAll,
+                                             int ts, int ntx, int nty, int* __restrict__ rgSizeAll,
+                                             int2* __restrict__ rgBoxAll, const int* __restrict__ rgDirtyAll,
+                                             const int* __restrict__ tileActAll, int TW, int TH,
+                                             int* __restrict__ arenaAll, int arenaCap, RxRect* __restrict__ rectAll,
+                                             int rectCap, int img0, int t) {
+  __shared__ int q[TX_GQ];
+  __shared__ int gb[TX_BMAXBLK];
+  const DevParams& P = *Pp;
+  const int img = blockIdx.y + img0, tile = blockIdx.x;
+  RxCtl& c = ctl[img];
+  if (c.state == 2 || c.overflow) return;
+  const int ntile = ntx * nty;
+  const int n = tileCntAll[(int64_t)img * ntile + tile];
+  if (n == 0) return;
+  const int lane = threadIdx.x;
+  const int W = P.LW, H = P.LH;
+  const int64_t npix = (int64_t)W * H;
+  if (SPARSE) {
+    // a dirty region activates the cells under its bounding box, its seed's cell among them: no active cell, nothing to do
+    const int cpt = ts >> 3;                              // 8x8 cells per tile side (ts = 32 or 64: up to 64 cells)
+    const int cx = (tile % ntx) * cpt + lane % cpt, cy = (tile / ntx) * cpt + lane / cpt;
+    const bool act = lane < cpt * cpt && cx < TW && cy < TH && tileActAll[(int64_t)img * TW * TH + cy * TW + cx] == t;
+    if (!__builtin_amdgcn_ballot_w64(act)) return;
+  }
+  const float4* rec = recAll + img * npix;
+  int2* own = ownAll + img * npix;
+  const int2* list = listAll + ((int64_t)img * ntile + tile) * ts * ts;
+  int* rgSize = rgSizeAll + img * npix;
+  int2* rgBox = rgBoxAll + img * npix;
+  const int* rgDirty = rgDirtyAll + img * npix;
+  int* arena = arenaAll + (int64_t)img * arenaCap;
+  RxRect* rects = rectAll + (int64_t)img * rectCap;
+  const int ci = t & 1;                                   // owner_t lives in component ci, owner_{t-1} in the other
+  const double prec = P.prec;
+  const int minReg = P.minRegSize;
+  const float alignLo = P.alignLo, alignHi = P.alignHi;
+  const bool useFilter = P.alignFilter != 0;
+  const int pi = lane >> 3;
+  const int nm = (lane & 7) < 4 ? (lane & 7) : (lane & 7) + 1;      // 8 neighbours, raster order, centre skipped
+  const int ndx = nm % 3 - 1, ndy = nm / 3 - 1;
+
+  auto qget = [&](int k) -> int {
+    int e = tx_lds_read(&q[min(k, TX_GQ - 1)]);
+    if (k >= TX_GQ) {
+      const int o = k - TX_GQ;
+      e = arena[gb[o / TX_BBLK] + o % TX_BBLK];
+    }
+    return e;
+  };
+
+  for (int base = 0; base < n; base += 64) {
+    const bool valid = base + lane < n;
+    int2 se = make_int2(TX_INF, -1);
+    if (valid) se = list[base + lane];
+    bool d = valid;
+    if (SPARSE) d = valid && rgDirty[se.x] == t;
+    float4 srec = make_float4(TX_NOTDEF, 0.f, 0.f, 0.f);
+    int2 so = make_int2(0, 0);
+    if (d) {
+      srec = rec[se.y];
+      so = tx_load_own(&own[se.y]);
+    }
+    const bool alive = d && (ci ? so.x : so.y) == se.x && (ci ? so.y : so.x) == se.x;
+    // region_grow seeds its sums with cos/sin of the unrounded double angle
+    float scos = 0.f, ssin = 0.f;
+    if (alive) {
+      double sn, cn;
+      sincos((double)srec.x * TX_DEG2RAD, &sn, &cn);
+      scos = (float)cn;
+      ssin = (float)sn;
+    }
+    unsigned long long unusedMask = __builtin_amdgcn_ballot_w64(alive);
+    while (unusedMask) {
+      const int j = __ffsll((long long)unusedMask) - 1;
+      unusedMask &= unusedMask - 1ull;
+      const int r = tx_rl(se.x, j), sp = tx_rl(se.y, j);
+      const float sa = tx_rlf(srec.x, j);
+      float sumdx = tx_rlf(scos, j), sumdy = tx_rlf(ssin, j);
+      double reg_angle = (double)sa * TX_DEG2RAD;
+      bool angValid = true;
+      const int spy = sp / W, spx = sp - spy * W;
+      q[0] = (spy << 16) | spx;                           // every lane stores the same value
+      int cnt = 1, k = 0;
+      int bx0 = spx, bx1 = spx, by0 = spy, by1 = spy;
+      int pendOld = 0x7FFFFFFF;
+      bool dead = false;
+      while (k < cnt && !dead) {
+        // single-wave block: the LDS operations of a wave execute in order (the compiler only has to keep the order)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        // The claims of the previous step are returning atomics: their results are consumed here, before the owner
+        // loads of this step are issued, so those loads see the region's own claims.
+        asm volatile("" ::"v"(pendOld) : "memory");
+        pendOld = 0x7FFFFFFF;
+        bool accepted = false;
+        int qi = -1, nb = 0;
+        auto step = [&](auto spillTag) {
+          constexpr bool SPILL = decltype(spillTag)::value;
+          int myxy = -1;
+          float4 rr = make_float4(TX_NOTDEF, 0.f, 0.f, 0.f);
+          int2 oo = make_int2(0, 0);
+          nb = min(8, cnt - k);
+          if (pi < nb) {
+            const int e = SPILL ? qget(k + pi) : tx_lds_read(&q[k + pi]);
+            const int nx = (e & 0xFFFF) + ndx, ny = (e >> 16) + ndy;
+            if (nx >= 0 && ny >= 0 && nx < W && ny < H) {
+              qi = ny * W + nx;
+              myxy = (ny << 16) | nx;
+              rr = rec[qi];
+              oo = tx_load_own(&own[qi]);
+            }
+          }
+          const int prevv = ci ? oo.x : oo.y, curv = ci ? oo.y : oo.x;
+          const bool cand = rr.x != TX_NOTDEF && !(prevv < r || curv <= r);
+          unsigned long long remaining = __builtin_amdgcn_ballot_w64(cand);
+          while (remaining) {
+            // the alignment test in vector form with the exact expression inside the margin (see k_lsd_grow)
+            const float n2 = __builtin_fmaf(sumdx, sumdx, sumdy * sumdy);
+            const float dot = __builtin_fmaf(sumdx, rr.y, sumdy * rr.z);
+            const float sd2 = dot * __builtin_fabsf(dot);
+            unsigned long long mm = __builtin_amdgcn_ballot_w64(sd2 >= alignLo * n2);
+            if (!useFilter) mm = ~0ull;
+            const unsigned long long m = mm & remaining;
+            if (!m) break;
+            const int j2 = __ffsll((long long)m) - 1;
+            remaining &= ~((2ull << j2) - 1ull);
+            unsigned long long sure = __builtin_amdgcn_ballot_w64(sd2 >= alignHi * n2);
+            if (!useFilter) sure = 0ull;
+            if (!((sure >> j2) & 1ull)) {
+              if (!angValid) {
+                reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * TX_DEG2RAD;
+                angValid = true;
+              }
+              double n_theta = fabs(reg_angle - (double)tx_rlf(rr.x, j2) * TX_DEG2RAD);
+              if (n_theta > TX_3_2_PI) {
+                n_theta = fabs(n_theta - TX_2PI);
+              }
+              if (!(n_theta <= prec)) continue;
+            }
+            const int qj = tx_rl(qi, j2);
+            const int xyj = tx_rl(myxy, j2);
+            const float cj = tx_rlf(rr.y, j2), sj = tx_rlf(rr.z, j2);
+            accepted = accepted || lane == j2;          // the claims are issued together after the loop
+            remaining &= ~__builtin_amdgcn_ballot_w64(qi == qj);          // the other copies of the accepted pixel
+            if (!SPILL || cnt < TX_GQ) {
+              q[cnt] = xyj;                              // every active lane stores the same value
+            } else {
+              const int o = cnt - TX_GQ;
+              if (o % TX_BBLK == 0) {
+                if (o / TX_BBLK >= TX_BMAXBLK) { dead = true; break; }
+                int nbk = 0;
+                if (lane == j2) {                        // lane j2 is active: it is a set bit of a ballot
+                  const unsigned long long ra = atomicAdd(&c.rectArena, (unsigned long long)TX_BBLK) & ((1ull << RX_ARENA_BITS) - 1ull);
+                  nbk = ra + TX_BBLK > (unsigned long long)arenaCap ? -1 : (int)ra;
+                }
+                nbk = tx_rl(nbk, j2);
+                if (nbk < 0) { dead = true; break; }
+                gb[o / TX_BBLK] = nbk;
+              }
+              if (lane == j2) arena[gb[o / TX_BBLK] + o % TX_BBLK] = xyj;
+              __threadfence_block();
+            }
+            ++cnt;
+            const int ax = xyj & 0xFFFF, ay = xyj >> 16;
+            bx0 = min(bx0, ax); bx1 = max(bx1, ax); by0 = min(by0, ay); by1 = max(by1, ay);
+            sumdx = __fadd_rn(sumdx, cj);
+            sumdy = __fadd_rn(sumdy, sj);
+            angValid = false;
+            unusedMask &= ~__builtin_amdgcn_ballot_w64(se.y == qj);   // a seed of this row that was just taken
+          }
+        };
+        if (cnt + 8 * 8 + 1 > TX_GQ) step(std::true_type{});
+        else step(std::false_type{});
+        if (accepted) pendOld = __hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        k += nb;
+      }
+      asm volatile("" ::"v"(pendOld) : "memory");
+      if (dead) { c.overflow = 5; return; }
+      // ---- the region is complete ----
+      const bool first = lane == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1;   // the first ACTIVE lane
+      if (first) {
+        rgSize[r] = cnt;
+        rgBox[r] = make_int2((by0 << 16) | bx0, (by1 << 16) | bx1);
+      }
+      if (cnt >= minReg) {                              // the pixel list goes to k_rx_rect (region2rect)
+        int off = 0, slot = 0;
+        if (first) {
+          const unsigned long long ra = atomicAdd(&c.rectArena, (1ull << RX_ARENA_BITS) | (unsigned long long)cnt);
+          const unsigned long long o64 = ra & ((1ull << RX_ARENA_BITS) - 1ull);
+          off = o64 + cnt > (unsigned long long)arenaCap ? -1 : (int)o64;
+          slot = (int)(ra >> RX_ARENA_BITS);
+        }
+        const int fl = __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1;
+        off = tx_rl(off, fl); slot = tx_rl(slot, fl);
+        if (off < 0 || slot >= rectCap) { c.overflow = off < 0 ? 3 : 4; return; }
+        for (int i = lane; i < cnt; i += 64) arena[off + i] = qget(i);
+        if (first) {
+          RxRect& it = rects[slot];
+          it.rank = r; it.off = off; it.cnt = cnt; it.sumdx = sumdx; it.sumdy = sumdy;
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_tx_grow(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
+                                                const float4* __restrict__ recAll, int2* __restrict__ ownAll,
+                                                const int2* __restrict__ listAll, const int* __restrict__ tileCntAll,
+                                                int ts, int ntx, int nty, int* __restrict__ rgSizeAll,
+                                                int2* __restrict__ rgBoxAll, const int* __restrict__ rgDirtyAll,
+                                                const int* __restrict__ tileActAll, int TW, int TH,
+                                                int* __restrict__ arenaAll, int arenaCap, RxRect* __restrict__ rectAll,
+                                                int rectCap, int img0, int t) {
+  tx_grow_tile<false>(Pp, ctl, recAll, ownAll, listAll, tileCntAll, ts, ntx, nty, rgSizeAll, rgBoxAll, rgDirtyAll, tileActAll,
+                      TW, TH, arenaAll, arenaCap, rectAll, rectCap, img0, t);
+}
+__global__ __launch_bounds__(64) void k_tx_grow_sparse(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
+                                                       const float4* __restrict__ recAll, int2* __restrict__ ownAll,
+                                                       const int2* __restrict__ listAll, const int* __restrict__ tileCntAll,
+                                                       int ts, int ntx, int nty, int* __restrict__ rgSizeAll,
+                                                       int2* __restrict__ rgBoxAll, const int* __restrict__ rgDirtyAll,
+                                                       const int* __restrict__ tileActAll, int TW, int TH,
+                                                       int* __restrict__ arenaAll, int arenaCap, RxRect* __restrict__ rectAll,
+                                                       int rectCap, int img0, int t) {
+  tx_grow_tile<true>(Pp, ctl, recAll, ownAll, listAll, tileCntAll, ts, ntx, nty, rgSizeAll, rgBoxAll, rgDirtyAll, tileActAll,
+                     TW, TH, arenaAll, arenaCap, rectAll, rectCap, img0, t);
+}
+
+}  // namespace pli

@@ -75,6 +75,7 @@ struct pli_ctx {
   int* tileMin = nullptr; int* tileAct = nullptr; int* rgDirty = nullptr; int tilesW = 0, tilesH = 0; int* rxChunkCnt = nullptr; int rxChunks = 0;
   int* lastSize = nullptr; int* arena = nullptr; int arenaCap = 0;
   RxCtl* jrCtl = nullptr;
+  int2* txList = nullptr; int* txTileCnt = nullptr; int txTs = 64, txNtx = 0, txNty = 0;   // tile-sequential relaxation (lsd_tile.hip)
   std::vector<RxCtl> jrHost;
   int lsdMode = 0;     // 0 auto, 1 relaxation, 2 sequential (cfg.lsd_mode, or PLI_LSD_MODE)
   int rxLastRounds = 0; // rounds the relaxation ran in the previous call (where the host starts looking at the state)
@@ -196,7 +197,7 @@ pli_status validate(const pli_frontend_config& c) {
   if (c.lsd_refine != 0) { g_err = "only lsd_refine = 0 (LSD_REFINE_NONE) is on the reference path"; return PLI_ERR_INVALID; }
   if (c.lsd_n_bins < 1 || c.lsd_n_bins > 1024) { g_err = "lsd_n_bins must be in [1,1024]"; return PLI_ERR_INVALID; }
   if (c.max_lines < 1 || c.max_lines > (1 << 20)) { g_err = "max_lines must be in [1,2^20]"; return PLI_ERR_INVALID; }
-  if (c.lsd_mode < 0 || c.lsd_mode > 2) { g_err = "lsd_mode must be 0, 1 or 2"; return PLI_ERR_INVALID; }
+  if (c.lsd_mode < 0 || c.lsd_mode > 3) { g_err = "lsd_mode must be 0, 1, 2 or 3"; return PLI_ERR_INVALID; }
   if (c.lsd_nfeatures < 0 || c.lsd_nfeatures > c.max_lines) { g_err = "lsd_nfeatures must be in [0,max_lines]"; return PLI_ERR_INVALID; }
   if (!(c.lsd_scale > 0) || !(c.lsd_ang_th > 0 && c.lsd_ang_th < 180)) { g_err = "lsd_scale/ang_th invalid"; return PLI_ERR_INVALID; }
   return PLI_OK;
@@ -423,7 +424,11 @@ pli_status allocAll(pli_ctx* c) {
   A(c->rec, npix * NI);
   A(c->g2, npix * NI);
   c->lsdMode = c->cfg.lsd_mode;
-  if (const char* e = getenv("PLI_LSD_MODE")) c->lsdMode = atoi(e);
+  if (const char* e = getenv("PLI_LSD_MODE")) {
+    const int m = atoi(e);
+    if (m < 0 || m > 3) { g_err = "PLI_LSD_MODE must be 0, 1, 2 or 3"; return PLI_ERR_INVALID; }
+    c->lsdMode = m;
+  }
   if (c->lsdMode != 2) {     // buffers of the relaxation (in auto mode only batches below RX_AUTO_IMAGES use it)
     const size_t NR = c->lsdMode == 0 ? std::min<size_t>(NI, RX_AUTO_IMAGES - 1) : NI;
     A(c->own, npix * NR);
@@ -447,6 +452,11 @@ pli_status allocAll(pli_ctx* c) {
     A(c->rxChunkCnt, (size_t)c->rxChunks * NR);
     c->arenaCap = (int)std::min<size_t>(8 * npix, (size_t)1 << 30);
     A(c->arena, (size_t)c->arenaCap * NR);
+    c->txTs = 64;
+    if (const char* e = getenv("PLI_TX_TS")) c->txTs = atoi(e) == 32 ? 32 : 64;
+    c->txNtx = (P.LW + c->txTs - 1) / c->txTs; c->txNty = (P.LH + c->txTs - 1) / c->txTs;
+    A(c->txList, (size_t)c->txNtx * c->txNty * c->txTs * c->txTs * NR);
+    A(c->txTileCnt, (size_t)c->txNtx * c->txNty * NR);
   }
   A(c->jrCtl, NI);
   c->jrHost.resize(NI);
@@ -615,9 +625,61 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     HIPCHK(hipMemsetAsync(c->tileAct + (int64_t)img0 * c->tilesW * c->tilesH, 0, sizeof(int) * (size_t)c->tilesW * c->tilesH * nimg, c->stream));
     TRL(c, "k_rx_rank", k_rx_rank, dim3((npix + 255) / 256, nimg), dim3(256), 0, c->order, c->nDefined, c->rankOf, npix64, img0);
     const dim3 raster((P.LW + 255) / 256, P.LH, nimg);
-    TRL(c, "k_rx_guess", k_rx_guess, raster, dim3(256), 0, c->rec, c->rankOf, c->own, P.LW, P.LH, precDeg, img0);
+    const bool tile = c->lsdMode == 3;
     bool allDone = false;
     const int firstLook = c->rxLastRounds > 0 ? std::max(4, c->rxLastRounds) : 4;
+    auto look = [&](int t) -> pli_status {
+      // the host looks at the state every second round, starting where the previous call on this context ended (a
+      // stream of similar frames settles after a similar number of rounds; each look drains the stream)
+      if ((t >= firstLook && ((t - firstLook) % 2) == 0) || t == maxRounds) {
+        HIPCHK(hipMemcpyAsync(c->jrHost.data(), c->jrCtl + img0, sizeof(RxCtl) * nimg, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        allDone = true;
+        int settled = 0;
+        for (int i = 0; i < nimg; ++i) {
+          allDone = allDone && (c->jrHost[i].state == 2 || c->jrHost[i].overflow);
+          settled = std::max(settled, c->jrHost[i].rounds);
+        }
+        if (allDone) c->rxLastRounds = settled;       // the round in which the last image reached its fixed point
+      }
+      return PLI_OK;
+    };
+    if (tile) {
+      // tile-sequential relaxation (lsd_tile.hip): per-tile seed lists once, then rounds of one wave per tile
+      const int ts = c->txTs, ntile = c->txNtx * c->txNty;
+      TRL(c, "k_tx_sort", k_tx_sort, dim3(ntile, nimg), dim3(256), (size_t)ts * ts * 4, c->rankOf, c->order, c->own, c->txList,
+          c->txTileCnt, P.LW, P.LH, ts, c->txNtx, c->txNty, img0);
+      for (int t = 1; t <= maxRounds && !allDone; ++t) {
+        curT = t;
+        TRL(c, "k_rx_diff", k_rx_diff, dim3((P.LW + 31) / 32, c->tilesH, nimg), dim3(256), 0, c->jrCtl, c->own, c->tileMin, c->tileAct,
+            P.LW, P.LH, c->tilesW, c->tilesH, t, img0);
+        if (t >= 3) {
+          TRL(c, "k_rx_mark", k_rx_mark, dim3((P.LW + 31) / 32, c->tilesH, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->rgBox,
+              c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0);
+          TRL(c, "k_tx_prep", k_tx_prep, dim3((P.LW + 31) / 32, (P.LH + 31) / 32, nimg), dim3(1024), 0, c->jrCtl, c->own, c->rankOf,
+              c->rgDirty, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0);
+          TRL(c, "k_tx_grow_sparse", k_tx_grow_sparse, dim3(ntile, nimg), dim3(64), 0, c->dP, c->jrCtl, c->rec, c->own, c->txList,
+              c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty, c->tileAct, c->tilesW, c->tilesH, c->arena,
+              c->arenaCap, c->rects, c->rectCap, img0, t);
+        } else {
+          TRL(c, "k_tx_grow", k_tx_grow, dim3(ntile, nimg), dim3(64), 0, c->dP, c->jrCtl, c->rec, c->own, c->txList,
+              c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty, c->tileAct, c->tilesW, c->tilesH, c->arena,
+              c->arenaCap, c->rects, c->rectCap, img0, t);
+        }
+        TRL(c, "k_rx_rect", k_rx_rect, dim3(rectBlocks, nimg), dim3(64), 0, c->dP, c->jrCtl, c->rec, c->arena, c->arenaCap, c->rects,
+            c->rectCap, c->rgSeg, img0);
+        if (trace) {
+          HIPCHK(hipMemcpyAsync(c->jrHost.data(), c->jrCtl + img0, sizeof(RxCtl) * nimg, hipMemcpyDeviceToHost, c->stream));
+          HIPCHK(hipStreamSynchronize(c->stream));
+          const RxCtl& h = c->jrHost[0];
+          std::fprintf(stderr, "[tx] t=%d state=%d changed=%d overflow=%d rect=%d arena=%lld\n", t, h.state, h.changed, h.overflow,
+                       (int)(h.rectArena >> RX_ARENA_BITS), (long long)(h.rectArena & ((1ull << RX_ARENA_BITS) - 1ull)));
+        }
+        pli_status ls = look(t);
+        if (ls != PLI_OK) return ls;
+      }
+    } else {
+    TRL(c, "k_rx_guess", k_rx_guess, raster, dim3(256), 0, c->rec, c->rankOf, c->own, P.LW, P.LH, precDeg, img0);
     for (int t = 1; t <= maxRounds && !allDone; ++t) {
       curT = t;
       TRL(c, "k_rx_diff", k_rx_diff, dim3((P.LW + 31) / 32, c->tilesH, nimg), dim3(256), 0, c->jrCtl, c->own, c->tileMin, c->tileAct,
@@ -654,19 +716,8 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
                      h.state, h.changed, h.overflow, h.nSmall, h.nBig, h.nHand, h.nextBig, (int)(h.rectArena >> RX_ARENA_BITS),
                      (long long)(h.rectArena & ((1ull << RX_ARENA_BITS) - 1ull)), h.races);
       }
-      // the host looks at the state every second round, starting where the previous call on this context ended (a
-      // stream of similar frames settles after a similar number of rounds; each look drains the stream)
-      if ((t >= firstLook && ((t - firstLook) % 2) == 0) || t == maxRounds) {
-        HIPCHK(hipMemcpyAsync(c->jrHost.data(), c->jrCtl + img0, sizeof(RxCtl) * nimg, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        allDone = true;
-        int settled = 0;
-        for (int i = 0; i < nimg; ++i) {
-          allDone = allDone && (c->jrHost[i].state == 2 || c->jrHost[i].overflow);
-          settled = std::max(settled, c->jrHost[i].rounds);
-        }
-        if (allDone) c->rxLastRounds = settled;       // the round in which the last image reached its fixed point
-      }
+      { pli_status ls_ = look(t); if (ls_ != PLI_OK) return ls_; }
+    }
     }
     TRL(c, "k_rx_count", k_rx_count, dim3(c->rxChunks, nimg), dim3(256), 0, c->jrCtl, c->order, c->nDefined, c->own, c->lastSize,
            c->rxChunkCnt, c->rxChunks, npix64, P.minRegSize, img0);

@@ -446,9 +446,10 @@ def test_edge_cases(gpu):
     assert e.value.status == -6
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_lsd_execution_modes_give_identical_results(gpu, mode):
-    """lsd_mode 1 (rank-ordered relaxation) and 2 (sequential waves) are two schedules of the same algorithm."""
+    """lsd_mode 1 (rank-ordered relaxation), 2 (sequential waves) and 3 (tile-sequential relaxation) are three schedules of
+    the same algorithm."""
     g = gpu
     W, H = 752, 480
     cfg = g.capi.default_config(W, H, orb_nfeatures=1200, lsd_nfeatures=0, max_frames=2, lsd_mode=mode)
@@ -465,7 +466,7 @@ def test_lsd_execution_modes_give_identical_results(gpu, mode):
         assert rec["disp"].tobytes() == disp.tobytes() and rec["le"].tobytes() == le.tobytes()
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_lsd_hostile_images(gpu, mode):
     """Images that stress the relaxation's work lists (noise: hundreds of thousands of tiny regions; checkerboard and
     stripes: many long regions of equal gradient, i.e. long chains of equal-bin seeds) — same answer as the oracle."""
@@ -497,7 +498,7 @@ def test_full_size_batch_properties(gpu):
     pairs = [g.synth.make_stereo_pair(40 + s, W, H) for s in range(U)]
     images = np.stack([np.stack(pairs[i % U]) for i in range(F)])
     tables = {}
-    for mode in (1, 2):
+    for mode in (1, 2, 3):
         cfg = g.capi.default_config(W, H, orb_nfeatures=1200, lsd_nfeatures=100, max_frames=F, lsd_mode=mode)
         fe = g.Frontend(cfg)
         left, right = np.ascontiguousarray(images[:, 0]), np.ascontiguousarray(images[:, 1])
@@ -507,6 +508,7 @@ def test_full_size_batch_properties(gpu):
         tables[mode] = (fe, cfg, table)
     fe, cfg, t1 = tables[1]
     assert np.array_equal(t1, tables[2][2]), "relaxation and sequential schedules differ"
+    assert np.array_equal(t1, tables[3][2]), "tile-sequential relaxation and sequential schedules differ"
     rb = int(fe.layout.record_bytes)
     recs = t1.reshape(F, rb)
     for i in range(U, F):

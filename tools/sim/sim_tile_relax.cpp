@@ -1,0 +1,248 @@
+// Dev tool (CPU): simulates candidate parallel schedules of LSD region growing on one image and checks them
+// against the sequential result, counting rounds and work.  Uses the oracle's ll_angle / ordering.
+//   g++ -O2 -std=c++17 -I../../oracle -I../../include sim_tile_relax.cpp -o /tmp/sim_tile_relax
+//   /tmp/sim_tile_relax img.raw W H [tile]
+#include "line_oracle.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <numeric>
+
+using namespace orc;
+
+struct Field {
+  int W, H;
+  std::vector<double> ang;      // radians or NOTDEF
+  std::vector<float> c, s;      // per-pixel (float)cos/(float)sin of (double)(float)angle
+  std::vector<int> order, rankOf;
+  double prec;
+  int minReg;
+};
+
+static bool aligned(const Field& F, int q, double theta) {
+  const double a = F.ang[q];
+  if (a == kNOTDEF) return false;
+  double n = theta - a;
+  if (n < 0) n = -n;
+  if (n > kM_3_2_PI) { n -= kM_2__PI; if (n < 0) n = -n; }
+  return n <= F.prec;
+}
+
+// Grow region of rank r; used(q) decides; claim(q) records.  Returns the pixel list.
+template <class Used, class Claim>
+static void grow(const Field& F, int r, Used used, Claim claim, std::vector<int>& reg, long& tests) {
+  const int W = F.W, H = F.H;
+  const int sp = F.order[r];
+  reg.clear();
+  double reg_angle = F.ang[sp];
+  float sumdx = float(std::cos(reg_angle)), sumdy = float(std::sin(reg_angle));
+  reg.push_back(sp);
+  claim(sp);
+  for (size_t k = 0; k < reg.size(); ++k) {
+    const int px = reg[k] % W, py = reg[k] / W;
+    for (int yy = std::max(py - 1, 0); yy <= std::min(py + 1, H - 1); ++yy)
+      for (int xx = std::max(px - 1, 0); xx <= std::min(px + 1, W - 1); ++xx) {
+        const int q = yy * W + xx;
+        ++tests;
+        if (!used(q) && aligned(F, q, reg_angle)) {
+          claim(q);
+          reg.push_back(q);
+          sumdx += F.c[q];
+          sumdy += F.s[q];
+          reg_angle = fastAtan2(sumdy, sumdx) * kDEG_TO_RADS;
+        }
+      }
+  }
+}
+
+int main(int argc, char** argv) {
+  setvbuf(stdout, nullptr, _IONBF, 0);
+  if (argc < 4) { std::fprintf(stderr, "usage: img.raw W H [tile]\n"); return 2; }
+  const int iw = atoi(argv[2]), ih = atoi(argv[3]);
+  const int TS = argc > 4 ? atoi(argv[4]) : 64;
+  Img8 img(iw, ih);
+  FILE* f = fopen(argv[1], "rb");
+  if (!f || fread(img.d.data(), 1, img.d.size(), f) != img.d.size()) { std::fprintf(stderr, "read failed\n"); return 2; }
+  fclose(f);
+  LsdParams P;
+  LsdDebug D;
+  lsdDetect(img, P, D);
+  Field F;
+  F.W = D.W; F.H = D.H;
+  const int W = F.W, H = F.H, N = W * H;
+  F.ang.assign(N, kNOTDEF); F.c.assign(N, 0); F.s.assign(N, 0);
+  for (int i = 0; i < N; ++i)
+    if (D.angleDeg[i] != -1024.f) {
+      F.ang[i] = D.angleDeg[i] * kDEG_TO_RADS;
+      F.c[i] = (float)std::cos((double)float(F.ang[i]));
+      F.s[i] = (float)std::sin((double)float(F.ang[i]));
+    }
+  // the oracle's order covers every pixel with x<W-1,y<H-1; keep the defined ones only (the undefined never seed)
+  for (int p : D.order) if (F.ang[p] != kNOTDEF) F.order.push_back(p);
+  const int R = (int)F.order.size();
+  F.rankOf.assign(N, INT32_MAX);
+  for (int r = 0; r < R; ++r) F.rankOf[F.order[r]] = r;
+  F.prec = kPI * P.ang_th / 180;
+  {
+    const double p = P.ang_th / 180;
+    const double LOG_NT = 5 * (std::log10(double(W)) + std::log10(double(H))) / 2 + std::log10(11.0);
+    F.minReg = (int)size_t(-LOG_NT / std::log10(p));
+  }
+  std::printf("image %dx%d scaled %dx%d, defined %d, minReg %d, tile %d\n", iw, ih, W, H, R, F.minReg, TS);
+
+  // ---- truth: sequential ----
+  std::vector<int> truth(N, INT32_MAX);
+  std::vector<int> reg;
+  long tests = 0, regions = 0, bigRegions = 0, bigPix = 0, accepts = 0;
+  std::map<int, int> sizeHist;
+  for (int r = 0; r < R; ++r) {
+    if (truth[F.order[r]] != INT32_MAX) continue;
+    grow(F, r, [&](int q) { return truth[q] != INT32_MAX; }, [&](int q) { truth[q] = r; }, reg, tests);
+    ++regions;
+    accepts += (long)reg.size();
+    sizeHist[std::min((int)reg.size(), 32)]++;
+    if ((int)reg.size() >= F.minReg) { ++bigRegions; bigPix += (long)reg.size(); }
+  }
+  std::printf("sequential: %ld regions (%ld >= minReg holding %ld px), %ld pixels, %ld neighbour tests\n", regions, bigRegions, bigPix,
+              accepts, tests);
+  std::printf("size histogram (size:count, 32 = 32+):");
+  for (auto& kv : sizeHist) std::printf(" %d:%d", kv.first, kv.second);
+  std::printf("\n");
+
+  // ---- tile-sequential relaxation ----
+  const int TW = (W + TS - 1) / TS, TH = (H + TS - 1) / TS, NT = TW * TH;
+  std::vector<std::vector<int>> tileSeeds(NT);          // ranks, ascending
+  for (int r = 0; r < R; ++r) {
+    const int p = F.order[r];
+    tileSeeds[(p / W / TS) * TW + (p % W) / TS].push_back(r);
+  }
+  for (int rule = 0; rule < 2; ++rule) {
+    std::vector<int> prev(N, INT32_MAX), cur(N);
+    std::printf("tile-sequential relaxation, rule %c:\n", rule ? 'B' : 'A');
+    for (int t = 1; t <= 40; ++t) {
+      std::fill(cur.begin(), cur.end(), INT32_MAX);
+      long grown = 0, acc = 0, tst = 0;
+      std::vector<int> mine(N, INT32_MAX);      // claims visible inside the running tile-wave (reset per tile via list)
+      std::vector<int> touched;
+      std::vector<char> doneRank;               // rule B: rank already processed this round by the running tile
+      for (int T = 0; T < NT; ++T) {
+        touched.clear();
+        const std::vector<int>& S = tileSeeds[T];
+        const int tx0 = (T % TW) * TS, ty0 = (T / TW) * TS;
+        for (int r : S) {
+          const int sp = F.order[r];
+          auto used = [&](int q) {
+            if (mine[q] <= r) return true;                   // claimed earlier this round by this tile-wave (lower rank)
+            const int po = prev[q];
+            if (po < r) {
+              if (rule == 1) {
+                // the previous owner is a seed of THIS tile with a lower rank: it has already been regrown this round by
+                // this wave, and did not claim q (else mine[q] < r) -> q is free as far as that region is concerned
+                const int op = F.order[po];
+                const int ox = op % W, oy = op / W;
+                if (ox >= tx0 && ox < tx0 + TS && oy >= ty0 && oy < ty0 + TS) return false;
+              }
+              return true;
+            }
+            return false;
+          };
+          if (used(sp)) continue;
+          grow(F, r, used, [&](int q) { if (mine[q] == INT32_MAX) touched.push_back(q); mine[q] = std::min(mine[q], r); }, reg, tst);
+          ++grown;
+          acc += (long)reg.size();
+        }
+        for (int q : touched) { cur[q] = std::min(cur[q], mine[q]); mine[q] = INT32_MAX; }
+      }
+      long changed = 0, wrong = 0;
+      std::vector<char> tileChanged(NT, 0);
+      for (int q = 0; q < N; ++q) {
+        if (cur[q] != prev[q]) { ++changed; tileChanged[(q / W / TS) * TW + (q % W) / TS] = 1; }
+        if (cur[q] != truth[q]) ++wrong;
+      }
+      int tc = 0;
+      for (char c : tileChanged) tc += c;
+      std::printf("  round %2d: grown %6ld regions, %7ld px, changed %7ld px in %4d/%d tiles, wrong vs truth %7ld\n", t, grown, acc,
+                  changed, tc, NT, wrong);
+      prev.swap(cur);
+      if (changed == 0) break;
+    }
+  }
+
+  // ---- lane speculation inside a sequential wave: super-rows of 64 live seeds, cap C ----
+  for (int C : {4, 6, 8, 12}) {
+    std::vector<int> own(N, INT32_MAX);
+    long rows = 0, lanesLive = 0, lanesBig = 0, lanesLoser = 0, lanesClean = 0, lanesKilled = 0, regrowAcc = 0, cleanAcc = 0, specPops = 0;
+    int r = 0;
+    std::vector<int> lane(64);
+    std::vector<std::vector<int>> R_(64);
+    std::vector<int> status(64);      // 0 clean small, 1 big, 2 loser
+    std::vector<int> tag(N, -1);
+    while (r < R) {
+      int n = 0;
+      while (r < R && n < 64) { if (own[F.order[r]] == INT32_MAX) lane[n++] = r; ++r; }
+      if (!n) break;
+      ++rows;
+      lanesLive += n;
+      long maxPops = 0;
+      for (int j = 0; j < n; ++j) {
+        // speculative growth against the committed state, cap C
+        std::vector<int>& rg = R_[j];
+        rg.clear();
+        const int rk = lane[j];
+        const int sp = F.order[rk];
+        double reg_angle = F.ang[sp];
+        float sumdx = float(std::cos(reg_angle)), sumdy = float(std::sin(reg_angle));
+        rg.push_back(sp);
+        bool big = false;
+        size_t k = 0;
+        for (; k < rg.size() && !big; ++k) {
+          const int px = rg[k] % W, py = rg[k] / W;
+          for (int yy = std::max(py - 1, 0); yy <= std::min(py + 1, H - 1) && !big; ++yy)
+            for (int xx = std::max(px - 1, 0); xx <= std::min(px + 1, W - 1); ++xx) {
+              const int q = yy * W + xx;
+              if (own[q] != INT32_MAX) continue;
+              if (std::find(rg.begin(), rg.end(), q) != rg.end()) continue;
+              if (aligned(F, q, reg_angle)) {
+                if ((int)rg.size() == C) { big = true; break; }
+                rg.push_back(q);
+                sumdx += F.c[q]; sumdy += F.s[q];
+                reg_angle = fastAtan2(sumdy, sumdx) * kDEG_TO_RADS;
+              }
+            }
+        }
+        maxPops = std::max<long>(maxPops, (long)k);
+        status[j] = big ? 1 : 0;
+      }
+      specPops += maxPops;
+      // tags: arbitrary winner among the small lanes (here: the last writer), losers = lanes that do not own all their pixels
+      for (int j = 0; j < n; ++j) if (status[j] == 0) for (int q : R_[j]) tag[q] = j;
+      for (int j = 0; j < n; ++j) if (status[j] == 0) for (int q : R_[j]) if (tag[q] != j) { status[j] = 2; break; }
+      // ordered resolution
+      for (int j = 0; j < n; ++j) {
+        const int rk = lane[j];
+        if (status[j] == 0) {
+          for (int q : R_[j]) own[q] = rk;
+          ++lanesClean;
+          cleanAcc += (long)R_[j].size();
+          continue;
+        }
+        if (status[j] == 1) ++lanesBig; else ++lanesLoser;
+        if (own[F.order[rk]] != INT32_MAX) { ++lanesKilled; continue; }
+        long tt = 0;
+        grow(F, rk, [&](int q) { return own[q] != INT32_MAX; },
+             [&](int q) {
+               own[q] = rk;
+               const int L = tag[q];
+               if (L > j && L < n && status[L] == 0 && std::find(R_[L].begin(), R_[L].end(), q) != R_[L].end()) status[L] = 2;
+             }, reg, tt);
+        regrowAcc += (long)reg.size();
+      }
+      for (int j = 0; j < n; ++j) for (int q : R_[j]) tag[q] = -1;
+    }
+    long wrong = 0;
+    for (int q = 0; q < N; ++q) if (own[q] != truth[q]) ++wrong;
+    std::printf("lane speculation C=%2d: %ld super-rows, live %ld: clean %ld (%ld px), big %ld, losers %ld (killed %ld), wave-wide regrown px %ld, "
+                "spec pops %ld, wrong %ld\n", C, rows, lanesLive, lanesClean, cleanAcc, lanesBig, lanesLoser, lanesKilled, regrowAcc, specPops, wrong);
+  }
+  return 0;
+}
