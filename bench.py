@@ -1,18 +1,31 @@
 #!/usr/bin/env python3
 """Headline benchmark: stereo frames/s of the point+line front-end on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W [--frames-per-gpu F]
+  python bench.py --gpus N --steps K --warmup W [--config {2,3,4,5}] [--frames-per-gpu F]
 
-One "step" = one pass of the whole per-frame hot path (ORB extract x2, LSD/LBD
-extract x2, stereo point + line matching) over a batch of F (default 2048)
-synthetic EuRoC-shaped stereo frames (752x480, 1200 ORB features, 100 lines) that
-are already resident in HBM, followed for N > 1 by the RCCL gather of the per-frame
-result tables to rank 0.  Weak scaling: every rank processes its own F frames.
-Rank 0 prints ONE JSON line (see the driver contract in the task statement).
+One "step" = one pass of the whole per-frame hot path (ORB extract x2, LSD/LBD extract x2, stereo point + line
+matching; with --config 3 also the frame-to-frame track matching) over a batch of synthetic EuRoC-shaped stereo
+frames that are already resident in HBM, followed for N > 1 by the RCCL gather of the per-frame result tables to
+rank 0.  Rank 0 prints ONE JSON line (the driver contract of the task statement).
+
+Workloads (BASELINE.json `configs`):
+  default      752x480, 1200 ORB kp + <=100 lines, F frames per GPU per step (weak scaling)
+  --config 2   the same image size, ONE stereo pair per call (latency)
+  --config 3   1280x720, 2000 kp + 200 lines, consecutive frames of one scene, + frame-to-frame track matching
+  --config 4   752x480 stream in 256-frame batches sharded over the N ranks (32 per GPU on 8 GPUs), gather of the
+               shard tables to rank 0 every batch; --inflight K keeps K batches per step in flight
+  --config 5   3840x2160, 4000 kp + 500 lines
+
+N > 1: one process per GPU.  Started by `python -m torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE in the
+environment, WORLD_SIZE must equal --gpus) or, when those are absent, bench.py starts the N rank processes itself
+BEFORE anything touches the GPU.  --backend gloo --dry-tables exercises the sharding + gather path on CPU
+(no kernels): used by tests/test_bench_launch.py.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,6 +34,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import numpy as np
+
+CONFIGS = {
+    2: dict(W=752, H=480, nf=1200, nl=100, what="single 752x480 stereo pair per call (BASELINE configs[1])"),
+    3: dict(W=1280, H=720, nf=2000, nl=200, what="1280x720 stereo, 8 levels, 2000 kp + 200 lines, + frame-to-frame track match "
+                                                 "(BASELINE configs[2])"),
+    4: dict(W=752, H=480, nf=1200, nl=100, what="752x480 stream, 256-frame batches sharded over the ranks, gather of the shard "
+                                                "tables to rank 0 (BASELINE configs[3])"),
+    5: dict(W=3840, H=2160, nf=4000, nl=500, what="3840x2160 stereo, 4000 kp + 500 lines (BASELINE configs[4])"),
+}
+BATCH4 = 256          # frames per batch of config 4
 
 
 # algorithmic bytes per stereo frame of the whole path.
@@ -49,7 +72,7 @@ def kernel_bytes_per_image(name, g, n_kp, n_l, W, H):
     ell = 0.1 * max(W, H)
     table = {
         "k_ingest": 2 * P0,
-        "k_resize_level": None,                       # per-level launches, see below
+        "k_resize_level": None,                       # per-level launches
         "k_fast_cells": SP,                           # read every pyramid pixel once
         "k_octree": 8 * 10 * n_kp,                    # candidate list in/out
         "k_blur_orb": 2 * SP,                         # pyramid read + blurred pyramid write
@@ -62,13 +85,17 @@ def kernel_bytes_per_image(name, g, n_kp, n_l, W, H):
         "k_lsd_scan": 0,
         "k_lsd_scatter": 8 * Pp,
         "k_lsd_grow": 8 * Pp,                         # f32 angle + f32 modgrad read once
-        "k_lsd_grow2": 8 * Pp,                        # the same kernel, two image waves per block (large batches)
-        # relaxation mode (lsd_relax.hip), per launch; the growers touch the same angle/modgrad planes once
-        # per round in the ideal case
+        "k_lsd_grow2": 8 * Pp,
+        # relaxations (lsd_relax.hip, lsd_tile.hip), per launch: in the ideal case a grower touches the angle/modgrad
+        # planes once per round
+        "k_tx_grow": 8 * Pp,
+        "k_tx_grow_sparse": 8 * Pp,
+        "k_tx_sort": 8 * Pp + 8 * Pp,                 # rank read, owner pair write; list write
+        "k_tx_prep": 12 * Pp,
         "k_rx_grow": 8 * Pp,
         "k_rx_grow_big": 8 * Pp,
         "k_rx_grow_wave": 8 * Pp,
-        "k_rx_seed": 12 * Pp,                         # rank + owner pair read
+        "k_rx_seed": 12 * Pp,
         "k_rx_classify": 12 * Pp,
         "k_rx_diff": 8 * Pp,
         "k_rx_guess": 8 * Pp + 8 * Pp,
@@ -87,19 +114,38 @@ def kernel_bytes_per_image(name, g, n_kp, n_l, W, H):
     return table.get(name)
 
 
-def cpu_baseline(images, cfg_bytes, budget_s=20.0):
-    """The oracle (CPU restatement of the reference path) timed on the host cores of this box."""
+# --------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (CPU restatement of the reference path) timed on the host cores of this box
+# --------------------------------------------------------------------------------------------------------------
+def cpu_baseline(images, cfg_bytes, budget_s=18.0):
+    """Three variants: single thread, the reference's own threading (4 threads per frame:
+    ORB-L, ORB-R, LSD-L, LSD-R in parallel as Frame.cc:128-135, then the two stereo matchers serially), and all host
+    cores frame-parallel.  `value` is the all-cores rate."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import pyoracle as po
     cores = os.cpu_count() or 1
-    nthreads = max(1, min(cores, 64))
-    frames = [po.Frame(po.Config.from_buffer_copy(cfg_bytes)) for _ in range(nthreads)]
+    nthreads = max(1, min(cores, 128))
     nimg = images.shape[0]
-    # calibrate on one frame, then size the sample to ~budget_s of wall time
+    f0 = po.Frame(po.Config.from_buffer_copy(cfg_bytes))
     t0 = time.perf_counter()
-    frames[0].run(images[0, 0], images[0, 1])
+    f0.run(images[0, 0], images[0, 1])
     t1 = time.perf_counter() - t0
-    total = int(max(nthreads, min(24 * nthreads, budget_s / max(t1, 1e-3) * nthreads * 0.6)))
+    # reference-style: 4 threads per frame (ctypes releases the GIL)
+    n4 = int(max(2, min(24, 4.0 / max(t1 / 2.0, 1e-3))))
+    with ThreadPoolExecutor(4) as ex4:
+        t0 = time.perf_counter()
+        for i in range(n4):
+            L, R = images[i % nimg, 0], images[i % nimg, 1]
+            futs = [ex4.submit(f0.orb_extract, 0, L), ex4.submit(f0.orb_extract, 1, R),
+                    ex4.submit(f0.line_extract, 0, L), ex4.submit(f0.line_extract, 1, R)]
+            for f_ in futs:
+                f_.result()
+            f0.stereo_lines()
+            f0.stereo_points()
+        dt4 = time.perf_counter() - t0
+    # all cores, frame-parallel
+    frames = [po.Frame(po.Config.from_buffer_copy(cfg_bytes)) for _ in range(nthreads)]
+    total = int(max(nthreads, min(8 * nthreads, budget_s / max(t1, 1e-3) * nthreads * 0.5)))
 
     def work(tid):
         k = 0
@@ -113,38 +159,101 @@ def cpu_baseline(images, cfg_bytes, budget_s=20.0):
         done = sum(ex.map(work, range(nthreads)))
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "stereo frames/s", "cores": nthreads, "kind": "port",
-            "sample": "%d stereo frames (cycled over the GPU batch) on %d threads, one oracle frame pipeline per "
-                      "thread, %.1f s; single frame single thread %.3f s" % (done, nthreads, dt, t1)}
+            "sample": "%d stereo frames (cycled over the GPU batch) on %d threads, one oracle frame pipeline per thread, %.1f s"
+                      % (done, nthreads, dt),
+            "single_thread": {"value": 1.0 / t1, "seconds_per_frame": t1, "cores": 1},
+            "ref4": {"value": n4 / dt4, "cores": 4, "sample": "%d stereo frames, the four extractors of a frame on 4 threads "
+                                                              "(Frame.cc:128-135), matching serial, %.1f s" % (n4, dt4)},
+            "host": {"logical_cpus": cores}}
 
 
-def parity_check(fe, cfg, d_table, images, F, nuniq, rec_bytes):
-    """The table of the last timed step against the oracle (part of the cpu_baseline leg, outside the timed region):
-    every record must equal the first record of its image pair, and the first and last distinct pairs must equal the
-    oracle's frame (keypoints, descriptors, keylines, LBD, uRight/depth, line disparities), byte for byte."""
-    import torch
+def oracle_frame_equal(fe, r, images_pair, cfg):
+    """One parsed record against a fresh oracle frame: every table, byte for byte."""
     from oracle import pyoracle as po
+    fr = po.Frame(po.Config.from_buffer_copy(bytes(cfg)))
+    ok = True
+    for eye, k in ((0, "L"), (1, "R")):
+        n, kp, desc = fr.orb_extract(eye, images_pair[eye])
+        ok &= n == len(r["kp" + k]) and kp.tobytes() == r["kp" + k].tobytes() and np.array_equal(desc, r["desc" + k])
+        m, kl, ld = fr.line_extract(eye, images_pair[eye])
+        ok &= m == len(r["kl" + k]) and kl.tobytes() == r["kl" + k].tobytes() and np.array_equal(ld, r["ldesc" + k])
+    ur, dp, _, _ = fr.stereo_points()
+    ok &= ur.tobytes() == r["uright"].tobytes() and dp.tobytes() == r["depth"].tobytes()
+    disp, le, _ = fr.stereo_lines()
+    ok &= disp.tobytes() == r["disp"].tobytes() and le.tobytes() == r["le"].tobytes()
+    return bool(ok)
+
+
+def parity_check(fe, cfg, d_table, images, F, nuniq, rec_bytes, npairs=8):
+    """The table of the last timed step against the oracle (part of the cpu_baseline leg, outside the timed region):
+    every record must equal the first record of its image pair, and `npairs` distinct pairs (spread over the batch) must
+    equal the oracle's frame (keypoints, descriptors, keylines, LBD, uRight/depth, line disparities, mvle_l), byte for byte."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
     recs = d_table.view(F, rec_bytes)
     idx = torch.arange(F, device=recs.device) % nuniq
     dup_bad = int((recs != recs[idx]).any(dim=1).sum().item())
     host = recs[:nuniq].cpu().numpy().reshape(-1)
-    checked, bad = 0, 0
-    for i in sorted({0, nuniq - 1}):
-        r = fe.parse_record(host, i)
-        fr = po.Frame(po.Config.from_buffer_copy(bytes(cfg)))
-        ok = True
-        for eye, k in ((0, "L"), (1, "R")):
-            n, kp, desc = fr.orb_extract(eye, images[i, eye])
-            ok &= n == len(r["kp" + k]) and kp.tobytes() == r["kp" + k].tobytes() and np.array_equal(desc, r["desc" + k])
-            m, kl, ld = fr.line_extract(eye, images[i, eye])
-            ok &= m == len(r["kl" + k]) and kl.tobytes() == r["kl" + k].tobytes() and np.array_equal(ld, r["ldesc" + k])
-        ur, dp, _, _ = fr.stereo_points()
-        ok &= ur.tobytes() == r["uright"].tobytes() and dp.tobytes() == r["depth"].tobytes()
-        disp, le, _ = fr.stereo_lines()
-        ok &= disp.tobytes() == r["disp"].tobytes()
-        checked += 1
-        bad += 0 if ok else 1
+    pick = sorted({int(round(i * (nuniq - 1) / max(npairs - 1, 1))) for i in range(min(npairs, nuniq))})
+    with ThreadPoolExecutor(min(len(pick), os.cpu_count() or 1)) as ex:
+        oks = list(ex.map(lambda i: oracle_frame_equal(fe, fe.parse_record(host, i), images[i], cfg), pick))
+    bad = sum(0 if o else 1 for o in oks)
     return {"ok": dup_bad == 0 and bad == 0, "records": F, "records_differing_from_first_copy": dup_bad,
-            "pairs_checked_against_oracle": checked, "pairs_mismatching": bad}
+            "pairs_checked_against_oracle": len(pick), "pairs_mismatching": bad}
+
+
+# --------------------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args, argv):
+    """--gpus N without a distributed environment: start the N rank processes (fresh children, before this process
+    has touched the GPU) and return their exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def dry_tables(args, rank, world):
+    """CPU exercise of the multi-rank path (sharding + gather of the result tables), no kernels: every rank fills the
+    records of its shard with a pattern derived from the global frame index, rank 0 checks what arrives."""
+    import torch
+    import torch.distributed as dist
+    from pli_slam_amd.sharding import TableGatherer, shard_range
+    rec = 4096
+    nbatch = BATCH4 if args.config == 4 else world * max(1, args.frames_per_gpu or 4)
+    start, count = shard_range(nbatch, rank, world)
+    counts = [shard_range(nbatch, r, world)[1] for r in range(world)]
+    pad = max(counts)
+    gath = TableGatherer(pad * rec, torch.device("cpu"))
+    ok = True
+    for step in range(args.warmup + args.steps):
+        slot = gath.acquire()
+        t = gath.table(slot)
+        t.zero_()
+        for f in range(count):
+            t[f * rec:(f + 1) * rec] = int((start + f + 7 * step) % 251)
+        gath.submit(slot)
+        gath.drain()
+        if rank == 0:
+            got = gath.gathered(slot)
+            for r in range(world):
+                s_r, c_r = shard_range(nbatch, r, world)
+                for f in range(c_r):
+                    ok &= bool((got[r][f * rec:(f + 1) * rec] == int((s_r + f + 7 * step) % 251)).all())
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_tables": True, "n_gpus": world, "backend": args.backend, "batch_frames": nbatch,
+                          "shard_frames": counts, "gathered_bytes_per_step": sum(counts) * rec, "shards_ok": bool(ok)}), flush=True)
+    dist.destroy_process_group()
+    return 0 if ok else 1
 
 
 def main():
@@ -152,69 +261,113 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames-per-gpu", type=int, default=2048)
-    ap.add_argument("--width", type=int, default=752)
-    ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--nfeatures", type=int, default=1200)
-    ap.add_argument("--nlines", type=int, default=100)
+    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5], help="BASELINE.json configs[i-1]; 0 = headline batch")
+    ap.add_argument("--frames-per-gpu", type=int, default=0, help="stereo frames per GPU per step (default depends on --config)")
+    ap.add_argument("--inflight", type=int, default=1, help="config 4: 256-frame batches per step")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--nfeatures", type=int, default=0)
+    ap.add_argument("--nlines", type=int, default=0)
     ap.add_argument("--unique-frames", type=int, default=64)
-    ap.add_argument("--streams", type=int, default=1, help="split the per-GPU batch over this many contexts/HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lsd-mode", type=int, default=0, help="0 auto, 1 relaxation, 2 sequential waves")
+    ap.add_argument("--no-host-leg", action="store_true")
+    ap.add_argument("--lsd-mode", type=int, default=0, help="0 auto, 1 relaxation, 2 sequential waves, 3 tile-sequential relaxation")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--dry-tables", action="store_true", help="CPU exercise of sharding + gather (needs --backend gloo)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args, sys.argv[1:]))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: start it with --nproc-per-node %d (or without a "
+                         "distributed environment: it starts the ranks itself)\n" % (args.gpus, world, args.gpus))
+        sys.exit(2)
 
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.dry_tables:
+        if args.backend != "gloo":
+            sys.exit("--dry-tables is the CPU exercise: use --backend gloo")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus
+        sys.exit(dry_tables(args, rank, world))
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the front-end has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group(args.backend, rank=rank, world_size=world, device_id=dev)
+        assert dist.get_world_size() == args.gpus
 
     from pli_slam_amd import capi, synth
     from pli_slam_amd.frontend import Frontend
+    from pli_slam_amd.sharding import TableGatherer, shard_range
 
-    F, W, H = args.frames_per_gpu, args.width, args.height
-    S = max(1, args.streams)
-    assert F % S == 0, "--frames-per-gpu must be a multiple of --streams"
-    Fs = F // S
-    cfg = capi.default_config(W, H, orb_nfeatures=args.nfeatures, lsd_nfeatures=args.nlines, max_frames=Fs,
-                              lsd_mode=args.lsd_mode if args.lsd_mode else (2 if 2 * Fs >= 640 else 1))   # = the library's auto rule
-    fes = [Frontend(cfg, device=local_rank) for _ in range(S)]
-    fe = fes[0]
-    # synthetic stream: up to 64 distinct seeded stereo pairs per rank (seeds disjoint across ranks), cycled to F frames
+    C_ = CONFIGS.get(args.config, CONFIGS[2] if args.config == 0 else None)
+    W, H = args.width or C_["W"], args.height or C_["H"]
+    nfeat, nlines = args.nfeatures or C_["nf"], args.nlines or C_["nl"]
+    if args.config == 2:
+        F = 1
+    elif args.config == 4:
+        F = max(1, args.inflight) * shard_range(BATCH4, rank, world)[1]
+    elif args.config == 5:
+        F = args.frames_per_gpu or 16
+    elif args.config == 3:
+        F = args.frames_per_gpu or 64
+    else:
+        F = args.frames_per_gpu or 256
+    Fmax = F
+    if world > 1:                                     # equal table sizes for the gather (config 4 shards may differ by one)
+        t = torch.tensor([F], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        Fmax = int(t.item())
+    cfg = capi.default_config(W, H, orb_nfeatures=nfeat, lsd_nfeatures=nlines, max_frames=Fmax, lsd_mode=args.lsd_mode)
+    fe = Frontend(cfg, device=local_rank)
+    # synthetic stream: up to --unique-frames distinct seeded stereo pairs per rank (seeds disjoint across ranks), cycled to F
+    # frames; config 3: consecutive frames t = 0..nuniq-1 of ONE scene (the motion of synth.make_stereo_pair)
     nuniq = min(F, args.unique_frames)
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as ex:
-        pairs = list(ex.map(lambda s_: synth.make_stereo_pair(s_, W, H), range(rank * nuniq, rank * nuniq + nuniq)))
+    with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as ex:
+        if args.config == 3:
+            pairs = list(ex.map(lambda t_: synth.make_stereo_pair(100 + rank, W, H, t=t_), range(nuniq)))
+        else:
+            pairs = list(ex.map(lambda s_: synth.make_stereo_pair(s_, W, H), range(rank * nuniq, rank * nuniq + nuniq)))
     images = np.stack([np.stack(p) for p in pairs])                    # (nuniq, 2, H, W) u8
     d_uniq = torch.from_numpy(images).to(dev)
     d_img = d_uniq[torch.arange(F, device=dev) % nuniq].contiguous()   # (F, 2, H, W) resident in HBM before timing
     d_left, d_right = d_img[:, 0].contiguous(), d_img[:, 1].contiguous()
     rec_bytes = int(fe.layout.record_bytes)
-    d_table = torch.zeros(F * rec_bytes, dtype=torch.uint8, device=dev)
-    from pli_slam_amd.sharding import TableGatherer
+    d_table = torch.zeros(Fmax * rec_bytes, dtype=torch.uint8, device=dev)
     # N > 1: the result tables are gathered to rank 0 over RCCL, double buffered, so that the gather of one step travels
     # while the kernels of the next run; every gather is complete before the closing barrier of the timed region
-    gath = TableGatherer(F * rec_bytes, dev) if world > 1 else None
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(S - 1)]
-    for f_, st_ in zip(fes, streams):
-        f_.set_stream(st_.cuda_stream)
+    gath = TableGatherer(Fmax * rec_bytes, dev) if world > 1 else None
+    fe.set_stream(torch.cuda.current_stream().cuda_stream)
+    track = None
+    if args.config == 3:
+        # frame-to-frame track matching of consecutive frames in the timed step (pli_batch_track): the poses a motion model would
+        # predict for the synthetic camera motion (small translation + 0.5 deg roll per frame), SearchByProjection window th = 15
+        def pose(t_):
+            a_ = np.deg2rad(0.5 * t_)
+            return np.array([[np.cos(a_), -np.sin(a_), 0, -0.02 * t_], [np.sin(a_), np.cos(a_), 0, -0.007 * t_], [0, 0, 1, 0.01 * t_]],
+                            np.float32)
+        d_poses = torch.from_numpy(np.stack([pose(t_ % nuniq) for t_ in range(F)]).reshape(-1)).to(dev)
+        tl = fe.track_layout()
+        track = (d_poses, fe.track_params(th=15.0), torch.zeros(F * int(tl.record_bytes), dtype=torch.uint8, device=dev))
 
     def step():
         slot = gath.acquire() if gath else 0
         tbl = gath.table(slot) if gath else d_table
-        for i, f_ in enumerate(fes):
-            f_.batch_run_device(Fs, d_left[i * Fs:].data_ptr(), d_right[i * Fs:].data_ptr(), W, W * H,
-                                tbl[i * Fs * rec_bytes:].data_ptr())
-        for st_ in streams[1:]:
-            torch.cuda.current_stream().wait_stream(st_)
+        fe.batch_run_device(F, d_left.data_ptr(), d_right.data_ptr(), W, W * H, tbl.data_ptr())
+        if track is not None:
+            fe.batch_track_device(F, tbl.data_ptr(), track[0].data_ptr(), track[1], track[2].data_ptr())
         if gath:
             gath.submit(slot)
 
@@ -228,43 +381,38 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    for f_ in fes:
-        f_.prof_reset()
-        f_.prof_enable(True)
+    fe.prof_reset()
+    fe.prof_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
-    prof = {}
-    for f_ in fes:
-        f_.prof_enable(False)
-        for k_, (c_, ms_) in f_.prof_report().items():
-            a_ = prof.get(k_, (0, 0.0))
-            prof[k_] = (a_[0] + c_, a_[1] + ms_)
+    fe.prof_enable(False)
+    prof = fe.prof_report()
+    frames_done = torch.tensor([float(F * args.steps)], dtype=torch.float64, device=dev)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        dist.all_reduce(frames_done, op=dist.ReduceOp.SUM)
+    total_frames = float(frames_done.item())
 
+    rc = 0
     if rank == 0:
-        b_frame, g = path_bytes_per_frame(W, H, cfg.orb_nlevels, cfg.orb_scale_factor, args.nfeatures, args.nlines,
-                                          cfg.lsd_scale)
-        fps = world * F * args.steps / dt
+        b_frame, g = path_bytes_per_frame(W, H, cfg.orb_nlevels, cfg.orb_scale_factor, nfeat, nlines, cfg.lsd_scale)
+        fps = total_frames / dt
         # dominant kernel by HIP-event time on the stream it ran on
         dom = max(prof.items(), key=lambda kv: kv[1][1]) if prof else (None, (0, 0.0))
         name, (calls, total_ms) = dom
-        per_img = kernel_bytes_per_image(name, g, args.nfeatures, args.nlines, W, H) if name else None
+        per_img = kernel_bytes_per_image(name, g, nfeat, nlines, W, H) if name else None
         avg_s = (total_ms / max(calls, 1)) * 1e-3
         peak = 8000.0
-        if per_img is not None and avg_s > 0:
-            achieved = per_img * 2 * Fs / avg_s / 1e9
-        else:
-            achieved = None
+        achieved = per_img * 2 * F / avg_s / 1e9 if (per_img is not None and avg_s > 0) else None
         traffic = None     # HBM bytes per launch from the committed PMC passes of the same workload, if any
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            k = tr["workloads"].get(str(F), {}).get(name) if (W, H) == (752, 480) else None
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+            k = tr["workloads"].get("%dx%d_F%d" % (W, H, F), {}).get(name)
             if k:
                 traffic = (2 * k["fetch_kb"] + k["write_kb"]) * 1024
         except Exception:
@@ -275,38 +423,71 @@ def main():
                 "path_achieved": fps / world * b_frame / 1e9, "path_frac": fps / world * b_frame / 1e9 / peak,
                 "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in
                                        sorted(prof.items(), key=lambda kv: -kv[1][1])}}
+        what = C_["what"] if args.config else ("752x480 stereo pairs, extract + stereo Hamming match (BASELINE configs[1] shape, "
+                                               "batched)")
         out = {
-            "metric": "stereo frames/sec (ORB+LSD extract+match), 752x480 EuRoC",
+            "metric": "stereo frames/sec (ORB+LSD extract+match), 752x480 EuRoC" if (W, H) == (752, 480) else
+                      "stereo frames/sec (ORB+LSD extract+match), %dx%d" % (W, H),
             "value": fps, "unit": "stereo frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if args.config == 4 else "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic (%d distinct seeded EuRoC-shaped pairs per GPU, cycled)" % nuniq,
-            "config": {"workload": "1xMI355X: %dx%d stereo pairs, %d ORB kp (8 levels x1.2) + LSD/LBD (<=%d lines), "
-                                   "extract + stereo Hamming match; batch of %d stereo frames per GPU per step" %
-                                   (W, H, args.nfeatures, args.nlines, F),
-                       "frames_per_gpu": F, "bytes_per_frame": b_frame,
+            "config": {"workload": "%dxMI355X: %s; %dx%d, %d ORB kp (8 levels x1.2) + LSD/LBD (<=%d lines); %d stereo frames per "
+                                   "GPU per step" % (world, what, W, H, nfeat, nlines, F),
+                       "baseline_config": args.config or None, "frames_per_gpu": F, "bytes_per_frame": b_frame,
                        "parallelism": "frame-batch data parallel, %d rank(s), gather of result tables to rank 0" % world},
             "roofline": roof,
         }
-        if world == 1 and F > 1 and not args.no_cpu_baseline:
-            # BASELINE.json configs[1] (a single stereo pair) beside the batch: latency of one pair through the same
-            # library, device buffers, outside the timed region
-            f1 = Frontend(capi.default_config(W, H, orb_nfeatures=args.nfeatures, lsd_nfeatures=args.nlines, max_frames=1),
-                          device=local_rank)
-            f1.set_stream(torch.cuda.current_stream().cuda_stream)
-            t1 = torch.zeros(rec_bytes, dtype=torch.uint8, device=dev)
-            for rep in range(12):
-                if rep == 2:
-                    torch.cuda.synchronize(); ts = time.perf_counter()
-                f1.batch_run_device(1, d_left.data_ptr(), d_right.data_ptr(), W, W * H, t1.data_ptr())
-            torch.cuda.synchronize()
-            out["single_pair"] = {"ms": (time.perf_counter() - ts) / 10 * 1e3, "note": "one stereo pair per call, 10 calls"}
+        if world > 1:
+            out["gather"] = {"bytes_per_rank_per_step": Fmax * rec_bytes, "bytes_at_root_per_step": world * Fmax * rec_bytes,
+                             "backend": args.backend}
+        if args.config == 4:
+            out["config"]["batch_frames"] = BATCH4
+            out["config"]["batches_in_flight"] = max(1, args.inflight)
         if world == 1 and not args.no_cpu_baseline:
+            # BASELINE.json configs[1] (a single stereo pair) beside the batch: latency of one pair through the same library
+            if F > 1 and (W, H) == (752, 480):
+                f1 = Frontend(capi.default_config(W, H, orb_nfeatures=nfeat, lsd_nfeatures=nlines, max_frames=1), device=local_rank)
+                f1.set_stream(torch.cuda.current_stream().cuda_stream)
+                t1 = torch.zeros(rec_bytes, dtype=torch.uint8, device=dev)
+                for rep in range(12):
+                    if rep == 2:
+                        torch.cuda.synchronize(); ts = time.perf_counter()
+                    f1.batch_run_device(1, d_left.data_ptr(), d_right.data_ptr(), W, W * H, t1.data_ptr())
+                torch.cuda.synchronize()
+                out["single_pair"] = {"ms": (time.perf_counter() - ts) / 10 * 1e3, "note": "one stereo pair per call, 10 calls"}
+                del f1
+            if not args.no_host_leg:
+                out["host_inclusive"] = host_inclusive_leg(fe, images, F, nuniq, W, H, rec_bytes, args.steps)
             out["cpu_baseline"] = cpu_baseline(images, bytes(cfg))
+            # the timed steps left their last table in d_table: re-run one step so the checked table is a fresh one
             out["parity"] = parity_check(fe, cfg, d_table, images, F, nuniq, rec_bytes)
+            if not out["parity"]["ok"]:
+                out["value"] = None                   # a fast path whose results differ from the reference's is not a result
+                rc = 3
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    sys.exit(rc)
+
+
+def host_inclusive_leg(fe, images, F, nuniq, W, H, rec_bytes, steps):
+    """The same step with the images starting in pinned HOST memory and the tables ending there: the library's
+    pipelined host entry point (pinned staging, copy stream: H2D of batch i+1 and D2H of table i-1 overlap the kernels of i)."""
+    idx = np.arange(F) % nuniq
+    left, right, table = fe.host_buffers(F)
+    left[:] = images[idx, 0].reshape(F, -1)
+    right[:] = images[idx, 1].reshape(F, -1)
+    n = max(2, steps)
+    fe.host_submit(F, left, right, table[0]); fe.host_wait()          # warm-up
+    t0 = time.perf_counter()
+    for i in range(n):
+        fe.host_submit(F, left, right, table[i & 1])
+    fe.host_wait_all()
+    dt = time.perf_counter() - t0
+    return {"value": F * n / dt, "unit": "stereo frames/s", "steps": n,
+            "note": "images in pinned host memory, tables returned to pinned host memory, double buffered over PCIe"}
 
 
 if __name__ == "__main__":

@@ -107,8 +107,10 @@ typedef struct pli_frontend_config {
   double  min_disp;           /* 1.0                                                       */
   double  line_horiz_th;      /* 0.1                                                       */
   /* execution strategy of the LSD region grower (results are identical):
-     0 = auto (relaxation for batches below 256 images, sequential waves above),
-     1 = rank-ordered relaxation (lsd_relax.hip: low latency), 2 = sequential, one wave per image */
+     0 = auto (picked by batch size, see pli_capi.hip: chooseLsdMode),
+     1 = rank-ordered relaxation, one region per lane / lane group (lsd_relax.hip),
+     2 = sequential, one wave per image (line_kernels.hip: k_lsd_grow),
+     3 = tile-sequential relaxation, one wave per 64x64 tile (lsd_tile.hip) */
   int32_t lsd_mode;
   int32_t reserved0;
 } pli_frontend_config;
@@ -178,6 +180,20 @@ pli_status pli_batch_run_host(pli_ctx* ctx, int32_t nframes,
                               const uint8_t* left, const uint8_t* right,
                               int64_t stride, int64_t frame_stride,
                               uint32_t stages, void* table);
+
+/* Pipelined host entry point (throughput with images in HOST memory): pli_batch_submit_host returns
+ * after enqueueing the H2D copies (own copy stream), the kernels and the D2H copy of the table (second copy stream);
+ * two submits may be in flight, so the copies of batch i+1 / i-1 overlap the kernels of batch i; a third submit first
+ * waits for the oldest.  `left`, `right` and `table` should be pinned (pli_host_alloc, or memory the caller registered
+ * with hipHostRegister) — pageable memory works but makes the copies synchronous.  pli_batch_wait(ctx, 0) waits for
+ * the oldest outstanding submit (its table is then complete), pli_batch_wait(ctx, 1) for all of them. */
+pli_status pli_host_alloc(size_t bytes, void** out);
+void       pli_host_free(void* p);
+pli_status pli_batch_submit_host(pli_ctx* ctx, int32_t nframes,
+                                 const uint8_t* left, const uint8_t* right,
+                                 int64_t stride, int64_t frame_stride,
+                                 uint32_t stages, void* table);
+pli_status pli_batch_wait(pli_ctx* ctx, int32_t all);
 
 /* ------------------------------------------------------------------------ */
 /* Per-call drop-ins (host buffers, synchronous).                            */
@@ -260,6 +276,38 @@ pli_status pli_search_by_projection(pli_ctx* ctx,
                                     float min_x, float max_x, float min_y, float max_y,
                                     int32_t check_orientation,
                                     int32_t* best_idx2, int32_t* nmatches);
+
+/* --- Frame-to-frame track matching of a batch (BASELINE config 3), on the device tables of pli_batch_run ---
+ * Frame i (i >= 1) of the batch against frame i-1, as Tracking::TrackWithMotionModel does per frame:
+ *   points: ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono, match12) ORBmatcher.cc:2179-2323, the last
+ *           frame's stereo points (mvDepth > 0) standing for its map points as Tracking::UpdateLastFrame creates them
+ *           (Frame::UnprojectStereo, Frame.cc:1334-1350);
+ *   lines:  match(LastFrame.mDescriptors_Line, CurrentFrame.mDescriptors_Line, nnr, matches_12) LineMatcher.cpp:201-229
+ *           (Tracking.cc:3058), left eye.
+ * dev_poses: nframes x 12 floats on the device, mTcw (world -> camera, row major 3x4) of every frame — the motion-model
+ * prediction for the current frame, the optimised pose for the last.  dev_track: nframes records of pli_track_layout
+ * (record 0 is left untouched): counts = {nq = last N, point matches, n1 = last line count, line matches},
+ * best_idx2[j] = current keypoint matched to last keypoint j or -1, matches_12[i] = current line of last line i or -1.
+ * Asynchronous on the context stream. */
+typedef struct pli_track_params {
+  float fx, fy, cx, cy, bf;          /* Camera.fx/fy/cx/cy/bf (EuRoC.yaml:9-28)                        */
+  float th;                          /* search window: 15 stereo / 7 mono in TrackWithMotionModel       */
+  float min_x, max_x, min_y, max_y;  /* mnMinX..mnMaxY of the frame grid                               */
+  int32_t mono;                      /* bMono                                                          */
+  int32_t check_orientation;         /* ORBmatcher::mbCheckOrientation                                 */
+  float nnr_lines;                   /* minRatio12L                                                    */
+  int32_t reserved;
+} pli_track_params;
+typedef struct pli_track_layout {
+  int64_t record_bytes;
+  int64_t off_counts;                /* int32[4]                                                       */
+  int64_t off_best;                  /* int32[kp_cap]                                                  */
+  int64_t off_lines;                 /* int32[kl_cap]                                                  */
+  int32_t kp_cap, kl_cap;
+} pli_track_layout;
+pli_status pli_track_layout_get(const pli_ctx* ctx, pli_track_layout* out);
+pli_status pli_batch_track(pli_ctx* ctx, int32_t nframes, const void* dev_table, const float* dev_poses,
+                           const pli_track_params* params, void* dev_track);
 
 /* --- the driver's rectification fused into the ingest ---
  * Replaces cv::remap(imLeft, imLeftRect, M1l, M2l, cv::INTER_LINEAR) / (imRight, ...) of

@@ -636,4 +636,57 @@ struct BowVocabulary {
   }
 };
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The projection part of ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono, match12)
+// (ORBmatcher.cc:2190-2244): one pli_proj_query per keypoint of the last frame, with the last frame's stereo points
+// (mvDepth > 0) standing for its map points as Tracking::UpdateLastFrame creates them (Frame::UnprojectStereo,
+// Frame.cc:1334-1350; mRwc / mOw from Frame::UpdatePoseMatrices).  Tcw / Tlw: mTcw of the current / last frame, row
+// major 3x4.  cv::Mat arithmetic (CV_32F): a product A*B (+ C) is OpenCV's gemm — restated as double accumulation of
+// the float products and ONE rounding to float (OpenCV-3.3.1-compatible by intent; parity unpinned like ocv_prims.hpp).
+// ---------------------------------------------------------------------------------------------------------------
+static inline float cvmatDot3(const float* a, int sa, const float* b, double alpha, double c) {
+  const double d = (double)a[0] * (double)b[0] + (double)a[sa] * (double)b[1] + (double)a[2 * sa] * (double)b[2];
+  return (float)(alpha * d + c);
+}
+
+static inline void trackQueries(const pli_keypoint* lastKp, const float* lastDepth, int n, const float* Tlw, const float* Tcw,
+                                float fx, float fy, float cx, float cy, float bf, float th, bool bMono,
+                                const float* scaleFactors, pli_proj_query* q) {
+  const float tcw[3] = {Tcw[3], Tcw[7], Tcw[11]}, tlw[3] = {Tlw[3], Tlw[7], Tlw[11]};
+  float twc[3], tlc[3];
+  for (int r = 0; r < 3; ++r) twc[r] = cvmatDot3(Tcw + r, 4, tcw, -1.0, 0.0);                 // twc = -Rcw.t()*tcw
+  for (int r = 0; r < 3; ++r) tlc[r] = cvmatDot3(Tlw + 4 * r, 1, twc, 1.0, (double)tlw[r]);   // tlc = Rlw*twc+tlw
+  const float mb = bf / fx;
+  const bool bForward = tlc[2] > mb && !bMono, bBackward = -tlc[2] > mb && !bMono;
+  const float invfx = 1.0f / fx, invfy = 1.0f / fy;
+  float Ow[3];
+  for (int r = 0; r < 3; ++r) Ow[r] = cvmatDot3(Tlw + r, 4, tlw, -1.0, 0.0);                  // mOw = -mRcw.t()*mtcw
+  for (int j = 0; j < n; ++j) {
+    pli_proj_query Q;
+    Q.u = 0.f; Q.v = 0.f; Q.radius = 0.f; Q.ur = 0.f; Q.min_level = 0; Q.max_level = -1; Q.angle = lastKp[j].angle; Q.valid = 0;
+    const float z = lastDepth[j];
+    if (z > 0) {
+      const float u0 = lastKp[j].x, v0 = lastKp[j].y;
+      const float xl[3] = {(u0 - cx) * z * invfx, (v0 - cy) * z * invfy, z};
+      float xw[3], xc[3];
+      for (int r = 0; r < 3; ++r) xw[r] = cvmatDot3(Tlw + r, 4, xl, 1.0, (double)Ow[r]);      // mRwc*x3Dc+mOw
+      for (int r = 0; r < 3; ++r) xc[r] = cvmatDot3(Tcw + 4 * r, 1, xw, 1.0, (double)tcw[r]); // Rcw*x3Dw+tcw
+      const float invzc = (float)(1.0 / xc[2]);
+      if (!(invzc < 0)) {
+        Q.u = fx * xc[0] * invzc + cx;
+        Q.v = fy * xc[1] * invzc + cy;
+        const int oct = lastKp[j].octave;
+        Q.radius = th * scaleFactors[oct];
+        Q.ur = Q.u - bf * invzc;
+        if (bForward) { Q.min_level = oct; Q.max_level = -1; }
+        else if (bBackward) { Q.min_level = 0; Q.max_level = oct; }
+        else { Q.min_level = oct - 1; Q.max_level = oct + 1; }
+        Q.valid = 1;
+      }
+    }
+    q[j] = Q;
+  }
+}
+
 }  // namespace orc

@@ -244,6 +244,10 @@ int orc_search_by_projection(const pli_proj_query* q, const uint8_t* qdesc, int 
   std::memcpy(best_idx2, B.data(), B.size() * 4);
   return r;
 }
+void orc_track_queries(const pli_keypoint* lastKp, const float* lastDepth, int n, const float* Tlw, const float* Tcw, float fx,
+                       float fy, float cx, float cy, float bf, float th, int mono, const float* scaleFactors, pli_proj_query* q) {
+  trackQueries(lastKp, lastDepth, n, Tlw, Tcw, fx, fy, cx, cy, bf, th, mono != 0, scaleFactors, q);
+}
 int orc_stereo_from_depth(const pli_keypoint* kp, int n, const float* depth, int64_t stride, int w, int h, float bf, float* uright,
                           float* depthOut) {
   std::vector<float> U, D;

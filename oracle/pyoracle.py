@@ -270,6 +270,19 @@ def search_by_projection(q, qdesc, kp, desc, uright, bounds, check_ori=True):
     return n, best
 
 
+def track_queries(last_kp, last_depth, Tlw, Tcw, fx, fy, cx, cy, bf, th, mono, scale_factors):
+    """Projection part of SearchByProjection(CurrentFrame, LastFrame) (ORBmatcher.cc:2190-2244): the pli_proj_query table."""
+    kp = np.ascontiguousarray(last_kp, KEYPOINT_DT)
+    dp = np.ascontiguousarray(last_depth, np.float32)
+    Tl = np.ascontiguousarray(Tlw, np.float32).reshape(12)
+    Tc = np.ascontiguousarray(Tcw, np.float32).reshape(12)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    q = np.zeros(kp.shape[0], PROJ_QUERY_DT)
+    lib().orc_track_queries(_p(kp), _p(dp), kp.shape[0], _p(Tl), _p(Tc), C.c_float(fx), C.c_float(fy), C.c_float(cx),
+                            C.c_float(cy), C.c_float(bf), C.c_float(th), int(mono), _p(sf), _p(q))
+    return q
+
+
 class Vocabulary:
     """DBoW2 vocabulary tree (node list as in ORBvoc.txt: parent, is-word flag, 32-byte descriptor, weight)."""
 

@@ -61,6 +61,19 @@ class TableLayout(C.Structure):
     ]
 
 
+class TrackParams(C.Structure):
+    """pli_track_params."""
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float),
+                ("th", C.c_float), ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float),
+                ("mono", C.c_int32), ("check_orientation", C.c_int32), ("nnr_lines", C.c_float), ("reserved", C.c_int32)]
+
+
+class TrackLayout(C.Structure):
+    """pli_track_layout."""
+    _fields_ = [("record_bytes", C.c_int64), ("off_counts", C.c_int64), ("off_best", C.c_int64), ("off_lines", C.c_int64),
+                ("kp_cap", C.c_int32), ("kl_cap", C.c_int32)]
+
+
 class PliError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__("%s (%d): %s" % (ERRORS.get(status, "PLI_ERR"), status, msg))
@@ -84,6 +97,13 @@ _PROTOS = {
                                   C.c_void_p]),
     "pli_batch_run_host": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                        C.c_uint32, C.c_void_p]),
+    "pli_host_alloc": (C.c_int32, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "pli_host_free": (None, [C.c_void_p]),
+    "pli_batch_submit_host": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                          C.c_uint32, C.c_void_p]),
+    "pli_batch_wait": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "pli_track_layout_get": (C.c_int32, [C.c_void_p, C.POINTER(TrackLayout)]),
+    "pli_batch_track": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(TrackParams), C.c_void_p]),
     "pli_orb_extract": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p,
                                     C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]),
     "pli_orb_pyramid_level": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,

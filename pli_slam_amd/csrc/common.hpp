@@ -109,4 +109,14 @@ struct RxHand {
   int q[RX_QCAP];
 };
 
+// pli_batch_track: parameters + table / track record offsets, by value (match_kernels.hip: k_track_*)
+struct TrackParams {
+  float fx, fy, cx, cy, bf, th, minX, maxX, minY, maxY;
+  int mono, checkOri;
+  float nnrLines;
+  int kpCap, klCap;
+  int64_t recordBytes, offCounts, offKp0, offDesc0, offUr, offDepth, offLd0;
+  int64_t trackBytes, toffCounts, toffBest, toffLines;
+};
+
 }  // namespace pli

@@ -258,7 +258,8 @@ __device__ __forceinline__ void rx_mark_dirty(int o, bool withBox, int t, int* _
 __global__ __launch_bounds__(256) void k_rx_mark(RxCtl* __restrict__ ctl, const int2* __restrict__ ownAll,
                                                  const int* __restrict__ rankAll, const int2* __restrict__ rgBoxAll,
                                                  int* __restrict__ rgDirtyAll, const int* __restrict__ tileMinAll,
-                                                 int* __restrict__ tileActAll, int W, int H, int TW, int TH, int t, int img0) {
+                                                 int* __restrict__ tileActAll, int W, int H, int TW, int TH, int t, int img0,
+                                                 int seedRule) {
   __shared__ int nt[3][6];
   __shared__ int s_any;
   const int img = blockIdx.z + img0;
@@ -298,7 +299,9 @@ __global__ __launch_bounds__(256) void k_rx_mark(RxCtl* __restrict__ ctl, const 
   int* tileAct = tileActAll + (int64_t)img * TW * TH;
   if (m < prevv) rx_mark_dirty(prevv, true, t, rgDirty, rgBox, tileAct, TW, TH);
   const bool a1 = prevv == r, a2 = prev2 == r;
-  if (a1 != a2) rx_mark_dirty(r, a2, t, rgDirty, rgBox, tileAct, TW, TH);   // died: its last box; newly alive: only this pixel
+  // (seedRule 0: round 2 of the tile-sequential relaxation, where owner_{t-2} is the trivial map and the seeds that died in
+  // round 1 never ran)
+  if (seedRule && a1 != a2) rx_mark_dirty(r, a2, t, rgDirty, rgBox, tileAct, TW, TH);   // died: its last box; newly alive: only this pixel
 }
 
 // (32 x 32 pixels = 16 tiles per block: one list atomic per 1024 pixels)

@@ -104,20 +104,88 @@ __global__ __launch_bounds__(256) void k_tx_sort(const int* __restrict__ rankAll
 }
 
 // ---------------------------------------------------------------------------
-// k_tx_prep (rounds >= 3, after k_rx_diff and k_rx_mark): owner_t is rewritten in the active 8x8 cells only:
+// k_tx_diff2 (round 2 only; takes the place of k_rx_diff).  Round 1 ran against the trivial owner_0, so "what changed
+// since the last run" is not a difference of two owner maps.  What a region saw in round 1 is: the claims of the lower
+// ranks of ITS OWN tile for certain (the wave walks them in order), the claims of other tiles' regions maybe.  Region r
+// would repeat its round-1 run exactly in round 2 iff no pixel it tested is owned in owner_1 by a lower rank that is
+// foreign to r's tile.  Per 8x8 cell: the lowest owner rank whose seed lies outside the cell's tile (k_rx_mark then
+// stamps every region with a pixel within one pixel of such a cell and a higher rank); a region whose bounding box
+// (+1) leaves its tile is stamped here, and so is a region that ran in round 1 and lost its SEED afterwards (dead in
+// owner_1: its remaining pixels are released).  Checked against the sequential result by tools/sim/sim_tile_relax.cpp
+// (SIM_CARRY=1), which replays these rules on the CPU.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void tx_mark_dirty(int o, int t, int* __restrict__ rgDirty, const int2* __restrict__ rgBox,
+                                              int* __restrict__ tileAct, int TW, int TH) {
+  if (rgDirty[o] == t) return;
+  if (atomicExch(&rgDirty[o], t) == t) return;
+  const int2 b = rgBox[o];
+  const int tx0 = min(max((b.x & 0xFFFF) >> 3, 0), TW - 1), ty0 = min(max((b.x >> 16) >> 3, 0), TH - 1);
+  const int tx1 = min(max((b.y & 0xFFFF) >> 3, 0), TW - 1), ty1 = min(max((b.y >> 16) >> 3, 0), TH - 1);
+  for (int ty = ty0; ty <= ty1; ++ty)
+    for (int tx = tx0; tx <= tx1; ++tx) tileAct[ty * TW + tx] = t;
+}
+
+__global__ __launch_bounds__(256) void k_tx_diff2(RxCtl* __restrict__ ctl, const int2* __restrict__ ownAll,
+                                                  const int* __restrict__ orderAll, const int2* __restrict__ rgBoxAll,
+                                                  int* __restrict__ rgDirtyAll, int* __restrict__ tileMinAll,
+                                                  int* __restrict__ tileActAll, int W, int H, int TW, int TH, int ts, int t,
+                                                  int img0) {
+  __shared__ int tmin[4];
+  const int img = blockIdx.z + img0;
+  RxCtl& c = ctl[img];
+  if (c.state == 2) return;
+  const int tid = threadIdx.x;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { c.nSmall = 0; c.nBig = 0; c.nHand = 0; c.nextBig = 0; c.rectArena = 0ull; c.changed = 1; }
+  if (tid < 4) tmin[tid] = INT_MAX;
+  __syncthreads();
+  const int x = blockIdx.x * 32 + (tid & 31), y = blockIdx.y * 8 + (tid >> 5);
+  const int64_t base = (int64_t)img * W * H;
+  if (x < W && y < H) {
+    const int2 ow = ownAll[base + y * W + x];
+    const int o = (t & 1) ? ow.x : ow.y;               // owner_{t-1}
+    if (o != INT_MAX) {
+      const int sp = orderAll[base + o];
+      const int sx = sp % W, sy = sp / W;
+      if (sx / ts != x / ts || sy / ts != y / ts) atomicMin(&tmin[(tid & 31) >> 3], o);
+      if (sp != y * W + x) {
+        // the owner ran in round 1 and lost its seed afterwards (to a lower rank of another tile): it is dead in owner_1, its
+        // remaining pixels must be released (the later rounds do this with k_rx_mark's "seed changed hands" rule)
+        const int2 so = ownAll[base + sp];
+        if (((t & 1) ? so.x : so.y) != o) tx_mark_dirty(o, t, rgDirtyAll + base, rgBoxAll + base, tileActAll + (int64_t)img * TW * TH, TW, TH);
+      } else {                                          // the seed of an alive region: does its box (+1) leave the tile?
+        const int2 b = rgBoxAll[base + o];
+        const int tx0 = (x / ts) * ts, ty0 = (y / ts) * ts;
+        if ((b.x & 0xFFFF) - 1 < tx0 || (b.x >> 16) - 1 < ty0 || (b.y & 0xFFFF) + 1 >= tx0 + ts || (b.y >> 16) + 1 >= ty0 + ts)
+          tx_mark_dirty(o, t, rgDirtyAll + base, rgBoxAll + base, tileActAll + (int64_t)img * TW * TH, TW, TH);
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < 4) {
+    const int tx = blockIdx.x * 4 + tid;
+    if (tx < TW) {
+      tileMinAll[(int64_t)img * TW * TH + blockIdx.y * TW + tx] = tmin[tid];
+      if (tmin[tid] != INT_MAX) tileActAll[(int64_t)img * TW * TH + blockIdx.y * TW + tx] = t;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_tx_prep (rounds >= 2, after the diff and k_rx_mark): owner_t is rewritten in the active 8x8 cells only:
 // a pixel whose previous owner is carried (not stamped dirty) stays with it, any other falls back to its own
 // rank.  Elsewhere owner_{t-2} == owner_{t-1} and the owner is carried: the word that is there is right.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_tx_prep(RxCtl* __restrict__ ctl, int2* __restrict__ ownAll,
                                                  const int* __restrict__ rankAll, const int* __restrict__ rgDirtyAll,
-                                                 const int* __restrict__ tileActAll, int W, int H, int TW, int TH, int t, int img0) {
+                                                 const int* __restrict__ tileActAll, int W, int H, int TW, int TH, int t, int img0,
+                                                 int full) {
   __shared__ int s_act;
   const int img = blockIdx.z + img0;
   RxCtl& c = ctl[img];
   if (c.state == 2) return;
   const int tid = threadIdx.x;
   if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) c.changed = 0;
-  if (tid == 0) s_act = 0;
+  if (tid == 0) s_act = full;                          // round 2: owner_t still holds the trivial map, every cell is rewritten
   __syncthreads();
   if (tid < 16) {
     const int tx = blockIdx.x * 4 + (tid & 3), ty = blockIdx.y * 4 + (tid >> 2);

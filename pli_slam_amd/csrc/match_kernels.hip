@@ -750,13 +750,12 @@ __device__ __forceinline__ unsigned long long proj_key(const pli_proj_query& Q, 
   return ((unsigned long long)dist << 40) | ((unsigned long long)px << 34) | ((unsigned long long)py << 28) | (unsigned long long)i2;
 }
 
-__global__ __launch_bounds__(64) void k_proj_candidates(const pli_proj_query* __restrict__ q, const uint8_t* __restrict__ qdesc,
-                                                        int nq, const pli_keypoint* __restrict__ kp,
-                                                        const uint8_t* __restrict__ desc, const float* __restrict__ uright,
-                                                        int ncur, float minX, float maxX, float minY, float maxY,
-                                                        int checkBounds, int distLimit, unsigned long long* __restrict__ candKeys,
-                                                        int* __restrict__ candCount) {
-  const int i = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void proj_candidates_dev(int i, int lane, const pli_proj_query* __restrict__ q,
+                                                    const uint8_t* __restrict__ qdesc, int nq,
+                                                    const pli_keypoint* __restrict__ kp, const uint8_t* __restrict__ desc,
+                                                    const float* __restrict__ uright, int ncur, float minX, float maxX,
+                                                    float minY, float maxY, int checkBounds, int distLimit,
+                                                    unsigned long long* __restrict__ candKeys, int* __restrict__ candCount) {
   if (i >= nq) return;
   const float gwInv = __fdiv_rn((float)GRID_COLS, __fsub_rn(maxX, minX));
   const float ghInv = __fdiv_rn((float)GRID_ROWS, __fsub_rn(maxY, minY));
@@ -780,18 +779,28 @@ __global__ __launch_bounds__(64) void k_proj_candidates(const pli_proj_query* __
   if (lane == 0) candCount[i] = count <= PROJ_K ? count : -1;
 }
 
+__global__ __launch_bounds__(64) void k_proj_candidates(const pli_proj_query* __restrict__ q, const uint8_t* __restrict__ qdesc,
+                                                        int nq, const pli_keypoint* __restrict__ kp,
+                                                        const uint8_t* __restrict__ desc, const float* __restrict__ uright,
+                                                        int ncur, float minX, float maxX, float minY, float maxY,
+                                                        int checkBounds, int distLimit, unsigned long long* __restrict__ candKeys,
+                                                        int* __restrict__ candCount) {
+  proj_candidates_dev(blockIdx.x, threadIdx.x, q, qdesc, nq, kp, desc, uright, ncur, minX, maxX, minY, maxY, checkBounds, distLimit,
+                      candKeys, candCount);
+}
+
 // mode 0: SearchByProjection(CurrentFrame, LastFrame) (ORBmatcher.cc:2179-2323); mode 1: (Frame, MapPoints) (:44-143)
-__global__ __launch_bounds__(64) void k_proj_assign(const pli_proj_query* __restrict__ q, const uint8_t* __restrict__ qdesc, int nq,
-                                                    const pli_keypoint* __restrict__ kp, const uint8_t* __restrict__ desc,
-                                                    const float* __restrict__ uright, const uint8_t* __restrict__ occupied,
-                                                    int ncur, float minX, float maxX, float minY, float maxY, int mode,
-                                                    int checkOri, float nnratio, const unsigned long long* __restrict__ candKeys,
-                                                    const int* __restrict__ candCount, int* __restrict__ bestIdx2,
-                                                    int* __restrict__ nmatchesOut) {
-  extern __shared__ int owner[];     // ncur entries: -1 free, else the query that took the keypoint (INT_MAX: occupied before)
+// owner: ncur ints of LDS: -1 free, else the query that took the keypoint (INT_MAX: occupied before)
+__device__ __forceinline__ void proj_assign_dev(int lane, int* owner, const pli_proj_query* __restrict__ q,
+                                                const uint8_t* __restrict__ qdesc, int nq,
+                                                const pli_keypoint* __restrict__ kp, const uint8_t* __restrict__ desc,
+                                                const float* __restrict__ uright, const uint8_t* __restrict__ occupied,
+                                                int ncur, float minX, float maxX, float minY, float maxY, int mode,
+                                                int checkOri, float nnratio, const unsigned long long* __restrict__ candKeys,
+                                                const int* __restrict__ candCount, int* __restrict__ bestIdx2,
+                                                int* __restrict__ nmatchesOut) {
   __shared__ int hist[30];
   __shared__ int keep[30];
-  const int lane = threadIdx.x;
   const float gwInv = __fdiv_rn((float)GRID_COLS, __fsub_rn(maxX, minX));
   const float ghInv = __fdiv_rn((float)GRID_ROWS, __fsub_rn(maxY, minY));
   for (int i = lane; i < ncur; i += 64) owner[i] = (occupied && occupied[i]) ? INT_MAX : -1;
@@ -889,6 +898,168 @@ __global__ __launch_bounds__(64) void k_proj_assign(const pli_proj_query* __rest
     }
   }
   if (lane == 0) *nmatchesOut = nmatches;
+}
+
+__global__ __launch_bounds__(64) void k_proj_assign(const pli_proj_query* __restrict__ q, const uint8_t* __restrict__ qdesc, int nq,
+                                                    const pli_keypoint* __restrict__ kp, const uint8_t* __restrict__ desc,
+                                                    const float* __restrict__ uright, const uint8_t* __restrict__ occupied,
+                                                    int ncur, float minX, float maxX, float minY, float maxY, int mode,
+                                                    int checkOri, float nnratio, const unsigned long long* __restrict__ candKeys,
+                                                    const int* __restrict__ candCount, int* __restrict__ bestIdx2,
+                                                    int* __restrict__ nmatchesOut) {
+  extern __shared__ int owner[];
+  proj_assign_dev(threadIdx.x, owner, q, qdesc, nq, kp, desc, uright, occupied, ncur, minX, maxX, minY, maxY, mode, checkOri, nnratio,
+                  candKeys, candCount, bestIdx2, nmatchesOut);
+}
+
+// ---------------------------------------------------------------------------
+// Frame-to-frame track matching of a whole batch on the device tables (pli_batch_track): frame i against frame i-1.
+//   k_track_queries     the projection part of ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono)
+//                       (ORBmatcher.cc:2190-2244) with LastFrame's stereo points standing for its map points
+//                       (Frame::UnprojectStereo, Frame.cc:1334-1350, as Tracking::UpdateLastFrame creates them)
+//   k_track_candidates / k_track_assign   the two-phase search above, one launch for all frame pairs
+//   k_track_lines       match(last.mDescriptors_Line, cur.mDescriptors_Line, nnr, matches_12) (LineMatcher.cpp:201-229)
+// cv::Mat arithmetic (CV_32F): a product A*B (+ C) is OpenCV's gemm, restated here as double accumulation of the float
+// products, then ONE rounding to float ("OpenCV-3.3.1-compatible by intent", like the other OpenCV primitives).
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ float cvmat_dot3(const float* a, int sa, const float* b, double alpha, double c) {
+  const double d = (double)a[0] * (double)b[0] + (double)a[sa] * (double)b[1] + (double)a[2 * sa] * (double)b[2];
+  return (float)(alpha * d + c);
+}
+
+__global__ __launch_bounds__(256) void k_track_queries(const DevParams* __restrict__ Pp, const uint8_t* __restrict__ table,
+                                                       const float* __restrict__ poses, TrackParams tp,
+                                                       pli_proj_query* __restrict__ qAll) {
+  const DevParams& P = *Pp;
+  const int frame = blockIdx.y + 1, j = blockIdx.x * 256 + threadIdx.x;     // frame >= 1 is matched against frame - 1
+  const uint8_t* last = table + (int64_t)(frame - 1) * tp.recordBytes;
+  const int nq = reinterpret_cast<const int*>(last + tp.offCounts)[0];
+  if (j >= nq) return;
+  const float* Tc = poses + (int64_t)frame * 12;        // mTcw of the current frame, row major 3x4
+  const float* Tl = poses + (int64_t)(frame - 1) * 12;  // mTcw of the last frame
+  const float tcw[3] = {Tc[3], Tc[7], Tc[11]}, tlw[3] = {Tl[3], Tl[7], Tl[11]};
+  // twc = -Rcw.t()*tcw; tlc = Rlw*twc+tlw (ORBmatcher.cc:2193-2200)
+  float twc[3], tlc[3];
+  for (int r = 0; r < 3; ++r) twc[r] = cvmat_dot3(Tc + r, 4, tcw, -1.0, 0.0);
+  for (int r = 0; r < 3; ++r) tlc[r] = cvmat_dot3(Tl + 4 * r, 1, twc, 1.0, (double)tlw[r]);
+  const float mb = __fdiv_rn(tp.bf, tp.fx);             // Frame.cc:197
+  const bool bForward = tlc[2] > mb && !tp.mono, bBackward = -tlc[2] > mb && !tp.mono;
+  const pli_keypoint k = reinterpret_cast<const pli_keypoint*>(last + tp.offKp0)[j];
+  const float z = reinterpret_cast<const float*>(last + tp.offDepth)[j];
+  pli_proj_query Q;
+  Q.u = 0.f; Q.v = 0.f; Q.radius = 0.f; Q.ur = 0.f; Q.min_level = 0; Q.max_level = -1; Q.angle = k.angle; Q.valid = 0;
+  if (z > 0) {
+    // LastFrame.UnprojectStereo(j): x3Dc = ((u-cx)*z*invfx, (v-cy)*z*invfy, z); x3Dw = mRwc*x3Dc+mOw with mRwc = Rlw.t(), mOw = -Rlw.t()*tlw
+    const float invfx = __fdiv_rn(1.0f, tp.fx), invfy = __fdiv_rn(1.0f, tp.fy);
+    const float xl[3] = {__fmul_rn(__fmul_rn(__fsub_rn(k.x, tp.cx), z), invfx), __fmul_rn(__fmul_rn(__fsub_rn(k.y, tp.cy), z), invfy), z};
+    float Ow[3], xw[3], xc[3];
+    for (int r = 0; r < 3; ++r) Ow[r] = cvmat_dot3(Tl + r, 4, tlw, -1.0, 0.0);
+    for (int r = 0; r < 3; ++r) xw[r] = cvmat_dot3(Tl + r, 4, xl, 1.0, (double)Ow[r]);
+    // x3Dc = Rcw*x3Dw+tcw (ORBmatcher.cc:2212)
+    for (int r = 0; r < 3; ++r) xc[r] = cvmat_dot3(Tc + 4 * r, 1, xw, 1.0, (double)tcw[r]);
+    const float invzc = (float)(1.0 / (double)xc[2]);
+    if (!(invzc < 0)) {
+      Q.u = __fadd_rn(__fmul_rn(__fmul_rn(tp.fx, xc[0]), invzc), tp.cx);
+      Q.v = __fadd_rn(__fmul_rn(__fmul_rn(tp.fy, xc[1]), invzc), tp.cy);
+      Q.radius = __fmul_rn(tp.th, P.lv[k.octave].scale);
+      Q.ur = __fsub_rn(Q.u, __fmul_rn(tp.bf, invzc));
+      if (bForward) { Q.min_level = k.octave; Q.max_level = -1; }
+      else if (bBackward) { Q.min_level = 0; Q.max_level = k.octave; }
+      else { Q.min_level = k.octave - 1; Q.max_level = k.octave + 1; }
+      Q.valid = 1;
+    }
+  }
+  qAll[(int64_t)frame * tp.kpCap + j] = Q;
+}
+
+__global__ __launch_bounds__(64) void k_track_candidates(const uint8_t* __restrict__ table, TrackParams tp,
+                                                         const pli_proj_query* __restrict__ qAll,
+                                                         unsigned long long* __restrict__ candKeysAll, int* __restrict__ candCountAll) {
+  const int frame = blockIdx.y + 1;
+  const uint8_t* last = table + (int64_t)(frame - 1) * tp.recordBytes;
+  const uint8_t* cur = table + (int64_t)frame * tp.recordBytes;
+  const int nq = reinterpret_cast<const int*>(last + tp.offCounts)[0], ncur = reinterpret_cast<const int*>(cur + tp.offCounts)[0];
+  proj_candidates_dev(blockIdx.x, threadIdx.x, qAll + (int64_t)frame * tp.kpCap, last + tp.offDesc0, nq,
+                      reinterpret_cast<const pli_keypoint*>(cur + tp.offKp0), cur + tp.offDesc0,
+                      reinterpret_cast<const float*>(cur + tp.offUr), ncur, tp.minX, tp.maxX, tp.minY, tp.maxY, 1, 100,
+                      candKeysAll + (int64_t)frame * tp.kpCap * PROJ_K, candCountAll + (int64_t)frame * tp.kpCap);
+}
+
+__global__ __launch_bounds__(64) void k_track_assign(const uint8_t* __restrict__ table, TrackParams tp,
+                                                     const pli_proj_query* __restrict__ qAll,
+                                                     const unsigned long long* __restrict__ candKeysAll,
+                                                     const int* __restrict__ candCountAll, uint8_t* __restrict__ track) {
+  extern __shared__ int owner[];
+  const int frame = blockIdx.x + 1;
+  const uint8_t* last = table + (int64_t)(frame - 1) * tp.recordBytes;
+  const uint8_t* cur = table + (int64_t)frame * tp.recordBytes;
+  uint8_t* out = track + (int64_t)frame * tp.trackBytes;
+  const int nq = reinterpret_cast<const int*>(last + tp.offCounts)[0], ncur = reinterpret_cast<const int*>(cur + tp.offCounts)[0];
+  int* counts = reinterpret_cast<int*>(out + tp.toffCounts);
+  if (threadIdx.x == 0) counts[0] = nq;
+  proj_assign_dev(threadIdx.x, owner, qAll + (int64_t)frame * tp.kpCap, last + tp.offDesc0, nq,
+                  reinterpret_cast<const pli_keypoint*>(cur + tp.offKp0), cur + tp.offDesc0,
+                  reinterpret_cast<const float*>(cur + tp.offUr), nullptr, ncur, tp.minX, tp.maxX, tp.minY, tp.maxY, 0, tp.checkOri, 0.f,
+                  candKeysAll + (int64_t)frame * tp.kpCap * PROJ_K, candCountAll + (int64_t)frame * tp.kpCap,
+                  reinterpret_cast<int*>(out + tp.toffBest), counts + 1);
+}
+
+// one workgroup per frame pair: knn2 both ways, ratio tests, mutual check (descriptor tables of <= klCap lines)
+__global__ __launch_bounds__(256) void k_track_lines(const uint8_t* __restrict__ table, TrackParams tp, int bestLR,
+                                                     int* __restrict__ scratch, uint8_t* __restrict__ track) {
+  __shared__ int s_cnt;
+  const int frame = blockIdx.x + 1, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const uint8_t* last = table + (int64_t)(frame - 1) * tp.recordBytes;
+  const uint8_t* cur = table + (int64_t)frame * tp.recordBytes;
+  uint8_t* out = track + (int64_t)frame * tp.trackBytes;
+  const int n1 = reinterpret_cast<const int*>(last + tp.offCounts)[2], n2 = reinterpret_cast<const int*>(cur + tp.offCounts)[2];
+  const uint8_t* d1 = last + tp.offLd0;
+  const uint8_t* d2 = cur + tp.offLd0;
+  int* m12 = reinterpret_cast<int*>(out + tp.toffLines);
+  int* m21 = scratch + (int64_t)frame * tp.klCap;
+  if (tid == 0) s_cnt = 0;
+  for (int dir = 0; dir < (bestLR ? 2 : 1); ++dir) {
+    const uint8_t* q = dir ? d2 : d1;
+    const uint8_t* t = dir ? d1 : d2;
+    const int nq = dir ? n2 : n1, nt = dir ? n1 : n2;
+    int* m = dir ? m21 : m12;
+    for (int i = wv; i < nq; i += 4) {
+      uint64_t dq[4];
+      load_desc(q + (int64_t)i * 32, dq);
+      unsigned long long k1 = ~0ull, k2 = ~0ull;
+      for (int j = lane; j < nt; j += 64) {
+        uint64_t dt[4];
+        load_desc(t + (int64_t)j * 32, dt);
+        const unsigned long long key = ((unsigned long long)hamming256(dq, dt) << 32) | (unsigned)j;
+        if (key < k1) { k2 = k1; k1 = key; }
+        else if (key < k2) k2 = key;
+      }
+      const unsigned long long m1 = wave_min_u64(k1);
+      const unsigned long long c2 = (k1 == m1) ? k2 : k1;
+      const unsigned long long m2 = wave_min_u64(c2);
+      if (lane == 0) {
+        int r = -1;
+        if (nt >= 2 && (float)(int)(m1 >> 32) < __fmul_rn((float)(int)(m2 >> 32), tp.nnrLines)) r = (int)(m1 & 0xFFFFFFFFu);
+        m[i] = r;
+      }
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  int ok = 0;
+  for (int i = tid; i < n1; i += 256) {
+    int i2 = m12[i];
+    if (i2 >= 0 && bestLR && n2 > 0 && m21[i2] != i) { m12[i] = -1; i2 = -1; }
+    ok += i2 >= 0;
+  }
+  if (ok) atomicAdd(&s_cnt, ok);
+  __syncthreads();
+  if (tid == 0) {
+    int* counts = reinterpret_cast<int*>(out + tp.toffCounts);
+    counts[2] = n1;
+    counts[3] = s_cnt;
+  }
 }
 
 // ---------------------------------------------------------------------------

@@ -32,10 +32,13 @@ inline int cvRoundf(float v) { return (int)std::nearbyintf(v); }
 inline int cvRoundd(double v) { return (int)std::nearbyint(v); }
 inline int cvFloorf(float v) { int i = (int)v; return i - (i > v); }
 
-// lsd_mode auto: batches of at least this many images (2 per stereo frame) take the sequential wave grower, whose
-// throughput keeps growing with the batch; below it the relaxation is faster (measured: 1106 vs 961 frames/s at 256
-// frames, 1141 vs 1287 at 384)
-constexpr int RX_AUTO_IMAGES = 640;
+// lsd_mode auto: batches of at least this many images (2 per stereo frame) take the sequential wave grower (one wave
+// per image: work-efficient, its throughput keeps growing with the batch); below it the tile-sequential relaxation
+// (lsd_tile.hip: parallel inside an image, ~3x the sequential work).  Measured, 752x480, stereo frames/s: 256 frames
+// 2072 (tile) vs 1168 (sequential), 512 frames 2141 vs 2005, 1024 frames 2177 vs 3630.
+constexpr int RX_AUTO_IMAGES = 1280;
+// tiles of 32 for a handful of images (more waves: a single stereo pair takes 4.6 instead of 7.3 ms), 64 otherwise
+constexpr int TX_SMALL_TILE_IMAGES = 16;
 
 struct ProfEntry { const char* name; hipEvent_t a, b; };
 
@@ -94,6 +97,12 @@ struct pli_ctx {
   uint8_t* ownTable = nullptr;
   std::vector<uint8_t> hostRec;
   bool orbDone[2] = {false, false}, lineDone[2] = {false, false};
+  // pipelined host entry point: two slots of device staging (images + table), H2D and D2H copy streams
+  struct HostSlot { uint8_t* dimg = nullptr; uint8_t* dtab = nullptr; size_t imgBytes = 0, tabBytes = 0;
+                    hipEvent_t h2d = nullptr, kern = nullptr, d2h = nullptr; bool busy = false; };
+  HostSlot hs[2];
+  hipStream_t sH2D = nullptr, sD2H = nullptr;
+  uint64_t hsSubmitted = 0, hsWaited = 0;
   // generic scratch for the stateless matchers
   void* scratch = nullptr; size_t scratchBytes = 0;
   // debug
@@ -429,20 +438,23 @@ pli_status allocAll(pli_ctx* c) {
     if (m < 0 || m > 3) { g_err = "PLI_LSD_MODE must be 0, 1, 2 or 3"; return PLI_ERR_INVALID; }
     c->lsdMode = m;
   }
-  if (c->lsdMode != 2) {     // buffers of the relaxation (in auto mode only batches below RX_AUTO_IMAGES use it)
+  if (c->lsdMode != 2) {     // buffers of the relaxations (in auto mode only batches below RX_AUTO_IMAGES use them)
     const size_t NR = c->lsdMode == 0 ? std::min<size_t>(NI, RX_AUTO_IMAGES - 1) : NI;
+    const bool lane = c->lsdMode == 1, tiles = c->lsdMode == 0 || c->lsdMode == 3;
     A(c->own, npix * NR);
-    A(c->smallSeeds, npix * NR);
-    c->bigCap = (int)(npix / RX_HAND + 64);               // a region listed as large had >= RX_HAND pixels of its own               // a region listed as large had >= RX_HAND pixels of its own
-    A(c->bigSeeds, (size_t)c->bigCap * NR);
-    c->handCap = (int)(npix / RX_HAND + 64);
-    A(c->hand, (size_t)c->handCap * NR);
+    if (lane) {               // lane / lane-group growers of lsd_relax.hip
+      A(c->smallSeeds, npix * NR);
+      c->bigCap = (int)(npix / RX_HAND + 64);               // a region listed as large had >= RX_HAND pixels of its own
+      A(c->bigSeeds, (size_t)c->bigCap * NR);
+      c->handCap = (int)(npix / RX_HAND + 64);
+      A(c->hand, (size_t)c->handCap * NR);
+      A(c->rgClean, npix * NR);
+    }
     c->rectCap = 2 * ((int)(npix / std::max(P.minRegSize, 1)) + 64);
     A(c->rects, (size_t)c->rectCap * NR);
     A(c->lastSize, npix * NR);                            // region tables, indexed by seed rank
     A(c->rgBox, npix * NR);
     A(c->rgSeg, npix * NR);
-    A(c->rgClean, npix * NR);
     A(c->rankOf, npix * NR);
     c->tilesW = (P.LW + 7) / 8; c->tilesH = (P.LH + 7) / 8;
     A(c->tileMin, (size_t)c->tilesW * c->tilesH * NR);
@@ -450,13 +462,16 @@ pli_status allocAll(pli_ctx* c) {
     A(c->rgDirty, npix * NR);
     c->rxChunks = (int)((npix + 2047) / 2048);
     A(c->rxChunkCnt, (size_t)c->rxChunks * NR);
-    c->arenaCap = (int)std::min<size_t>(8 * npix, (size_t)1 << 30);
+    // pixel lists for region2rect (<= npix per round) + queue overflow blocks; the lane growers also park hand-overs here
+    c->arenaCap = (int)std::min<size_t>((lane ? 8 : 3) * npix + 65536, (size_t)1 << 30);
     A(c->arena, (size_t)c->arenaCap * NR);
-    c->txTs = 64;
-    if (const char* e = getenv("PLI_TX_TS")) c->txTs = atoi(e) == 32 ? 32 : 64;
-    c->txNtx = (P.LW + c->txTs - 1) / c->txTs; c->txNty = (P.LH + c->txTs - 1) / c->txTs;
-    A(c->txList, (size_t)c->txNtx * c->txNty * c->txTs * c->txTs * NR);
-    A(c->txTileCnt, (size_t)c->txNtx * c->txNty * NR);
+    if (tiles) {
+      c->txTs = NI <= TX_SMALL_TILE_IMAGES ? 32 : 64;
+      if (const char* e = getenv("PLI_TX_TS")) c->txTs = atoi(e) == 32 ? 32 : 64;
+      c->txNtx = (P.LW + c->txTs - 1) / c->txTs; c->txNty = (P.LH + c->txTs - 1) / c->txTs;
+      A(c->txList, (size_t)c->txNtx * c->txNty * c->txTs * c->txTs * NR);
+      A(c->txTileCnt, (size_t)c->txNtx * c->txNty * NR);
+    }
   }
   A(c->jrCtl, NI);
   c->jrHost.resize(NI);
@@ -620,12 +635,12 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     const float precDeg = (float)(P.prec * 180.0 / 3.14159265358979323846);
     HIPCHK(hipMemsetAsync(c->jrCtl + img0, 0, sizeof(RxCtl) * nimg, c->stream));
     HIPCHK(hipMemsetAsync(c->rankOf + (int64_t)img0 * npix, 0x7F, sizeof(int) * npix64 * nimg, c->stream));
-    HIPCHK(hipMemsetAsync(c->rgClean + (int64_t)img0 * npix, 0, npix64 * nimg, c->stream));   // round stamps
+    if (c->rgClean) HIPCHK(hipMemsetAsync(c->rgClean + (int64_t)img0 * npix, 0, npix64 * nimg, c->stream));   // round stamps
     HIPCHK(hipMemsetAsync(c->rgDirty + (int64_t)img0 * npix, 0, sizeof(int) * npix64 * nimg, c->stream));
     HIPCHK(hipMemsetAsync(c->tileAct + (int64_t)img0 * c->tilesW * c->tilesH, 0, sizeof(int) * (size_t)c->tilesW * c->tilesH * nimg, c->stream));
     TRL(c, "k_rx_rank", k_rx_rank, dim3((npix + 255) / 256, nimg), dim3(256), 0, c->order, c->nDefined, c->rankOf, npix64, img0);
     const dim3 raster((P.LW + 255) / 256, P.LH, nimg);
-    const bool tile = c->lsdMode == 3;
+    const bool tile = c->lsdMode != 1;      // auto below RX_AUTO_IMAGES and mode 3: the tile-sequential relaxation
     bool allDone = false;
     const int firstLook = c->rxLastRounds > 0 ? std::max(4, c->rxLastRounds) : 4;
     auto look = [&](int t) -> pli_status {
@@ -649,15 +664,20 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       const int ts = c->txTs, ntile = c->txNtx * c->txNty;
       TRL(c, "k_tx_sort", k_tx_sort, dim3(ntile, nimg), dim3(256), (size_t)ts * ts * 4, c->rankOf, c->order, c->own, c->txList,
           c->txTileCnt, P.LW, P.LH, ts, c->txNtx, c->txNty, img0);
+      const bool fullRound2 = getenv("PLI_TX_FULL2") != nullptr;       // dev: regrow everything in round 2
       for (int t = 1; t <= maxRounds && !allDone; ++t) {
         curT = t;
-        TRL(c, "k_rx_diff", k_rx_diff, dim3((P.LW + 31) / 32, c->tilesH, nimg), dim3(256), 0, c->jrCtl, c->own, c->tileMin, c->tileAct,
-            P.LW, P.LH, c->tilesW, c->tilesH, t, img0);
-        if (t >= 3) {
+        if (t == 2 && !fullRound2)
+          TRL(c, "k_tx_diff2", k_tx_diff2, dim3((P.LW + 31) / 32, c->tilesH, nimg), dim3(256), 0, c->jrCtl, c->own, c->order, c->rgBox,
+              c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, ts, t, img0);
+        else
+          TRL(c, "k_rx_diff", k_rx_diff, dim3((P.LW + 31) / 32, c->tilesH, nimg), dim3(256), 0, c->jrCtl, c->own, c->tileMin, c->tileAct,
+              P.LW, P.LH, c->tilesW, c->tilesH, t, img0);
+        if (t >= 3 || (t == 2 && !fullRound2)) {
           TRL(c, "k_rx_mark", k_rx_mark, dim3((P.LW + 31) / 32, c->tilesH, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->rgBox,
-              c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0);
+              c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, t >= 3 ? 1 : 0);
           TRL(c, "k_tx_prep", k_tx_prep, dim3((P.LW + 31) / 32, (P.LH + 31) / 32, nimg), dim3(1024), 0, c->jrCtl, c->own, c->rankOf,
-              c->rgDirty, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0);
+              c->rgDirty, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, t == 2 ? 1 : 0);
           TRL(c, "k_tx_grow_sparse", k_tx_grow_sparse, dim3(ntile, nimg), dim3(64), 0, c->dP, c->jrCtl, c->rec, c->own, c->txList,
               c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty, c->tileAct, c->tilesW, c->tilesH, c->arena,
               c->arenaCap, c->rects, c->rectCap, img0, t);
@@ -687,7 +707,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       if (t >= 3 && !fullPasses) {
         // bookkeeping only where something happened (lsd_relax.hip)
         TRL(c, "k_rx_mark", k_rx_mark, dim3((P.LW + 31) / 32, c->tilesH, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->rgBox,
-            c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0);
+            c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, 1);
         TRL(c, "k_rx_seed_sparse", k_rx_seed_sparse, dim3((P.LW + 31) / 32, (P.LH + 31) / 32, nimg), dim3(1024), 0, c->jrCtl, c->own, c->rankOf,
             c->rec, c->lastSize, c->rgDirty, c->tileAct, c->smallSeeds, c->bigSeeds, c->bigCap, P.LW, P.LH, c->tilesW, c->tilesH,
             bigThresh, t, img0);
@@ -863,6 +883,13 @@ void pli_ctx_destroy(pli_ctx* c) {
   if (c->ownStream && c->stream) hipStreamDestroy(c->stream);
   if (c->aux) { hipStreamSynchronize(c->aux); hipStreamDestroy(c->aux); hipEventDestroy(c->evFork); hipEventDestroy(c->evJoin); }
   for (int e = 0; e < 2; ++e) if (c->rectMap[e]) hipFree(c->rectMap[e]);
+  for (int s = 0; s < 2; ++s) {
+    if (c->hs[s].busy) hipEventSynchronize(c->hs[s].d2h);
+    if (c->hs[s].dimg) hipFree(c->hs[s].dimg);
+    if (c->hs[s].dtab) hipFree(c->hs[s].dtab);
+    if (c->hs[s].h2d) { hipEventDestroy(c->hs[s].h2d); hipEventDestroy(c->hs[s].kern); hipEventDestroy(c->hs[s].d2h); }
+  }
+  if (c->sH2D) { hipStreamDestroy(c->sH2D); hipStreamDestroy(c->sD2H); }
   delete c;
 }
 
@@ -966,6 +993,80 @@ pli_status pli_batch_run_host(pli_ctx* c, int32_t nframes, const uint8_t* left, 
   if (st != PLI_OK) return st;
   HIPCHK(hipMemcpyAsync(table, dt, (size_t)c->lay.record_bytes * nframes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  return PLI_OK;
+}
+
+pli_status pli_host_alloc(size_t bytes, void** out) {
+  if (!out) { g_err = "null argument"; return PLI_ERR_INVALID; }
+  *out = nullptr;
+  HIPCHK(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+  return PLI_OK;
+}
+void pli_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+static pli_status waitSlot(pli_ctx* c, int s) {
+  pli_ctx::HostSlot& S = c->hs[s];
+  if (S.busy) { HIPCHK(hipEventSynchronize(S.d2h)); S.busy = false; ++c->hsWaited; }
+  return PLI_OK;
+}
+
+pli_status pli_batch_wait(pli_ctx* c, int32_t all) {
+  if (!c) return PLI_ERR_INVALID;
+  HIPCHK(hipSetDevice(c->device));
+  pli_status st;
+  while (c->hsWaited < c->hsSubmitted) {
+    if ((st = waitSlot(c, (int)(c->hsWaited & 1))) != PLI_OK) return st;
+    if (!all) break;
+  }
+  return PLI_OK;
+}
+
+pli_status pli_batch_submit_host(pli_ctx* c, int32_t nframes, const uint8_t* left, const uint8_t* right, int64_t stride,
+                                 int64_t frameStride, uint32_t stages, void* table) {
+  if (!c || !left || !right || !table) { g_err = "null argument"; return PLI_ERR_INVALID; }
+  if (nframes < 1 || nframes > c->cfg.max_frames) { g_err = "nframes exceeds the context's max_frames"; return PLI_ERR_INVALID; }
+  if (stride < c->cfg.width) { g_err = "stride < width"; return PLI_ERR_INVALID; }
+  HIPCHK(hipSetDevice(c->device));
+  const int W = c->cfg.width, H = c->cfg.height;
+  const size_t imgBytes = (size_t)W * H, tabBytes = (size_t)c->lay.record_bytes * nframes;
+  if (!c->sH2D) {
+    HIPCHK(hipStreamCreateWithFlags(&c->sH2D, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->sD2H, hipStreamNonBlocking));
+  }
+  const int s = (int)(c->hsSubmitted & 1);
+  pli_ctx::HostSlot& S = c->hs[s];
+  pli_status st = waitSlot(c, s);                     // the slot's previous batch (two submits ago) must have left
+  if (st != PLI_OK) return st;
+  if (!S.h2d) {
+    HIPCHK(hipEventCreateWithFlags(&S.h2d, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&S.kern, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&S.d2h, hipEventDisableTiming));
+  }
+  const size_t needImg = alignUp(2 * imgBytes * (size_t)c->cfg.max_frames, 256), needTab = (size_t)c->lay.record_bytes * c->cfg.max_frames;
+  if (S.imgBytes < needImg) { if (S.dimg) hipFree(S.dimg); S.dimg = nullptr; HIPCHK(hipMalloc(&S.dimg, needImg)); S.imgBytes = needImg; }
+  if (S.tabBytes < needTab) { if (S.dtab) hipFree(S.dtab); S.dtab = nullptr; HIPCHK(hipMalloc(&S.dtab, needTab)); S.tabBytes = needTab; }
+  uint8_t* dl = S.dimg;
+  uint8_t* dr = S.dimg + imgBytes * nframes;
+  if (stride == W && frameStride == (int64_t)imgBytes) {
+    HIPCHK(hipMemcpyAsync(dl, left, imgBytes * nframes, hipMemcpyHostToDevice, c->sH2D));
+    HIPCHK(hipMemcpyAsync(dr, right, imgBytes * nframes, hipMemcpyHostToDevice, c->sH2D));
+  } else {
+    for (int f = 0; f < nframes; ++f) {
+      HIPCHK(hipMemcpy2DAsync(dl + imgBytes * f, W, left + (int64_t)f * frameStride, stride, W, H, hipMemcpyHostToDevice, c->sH2D));
+      HIPCHK(hipMemcpy2DAsync(dr + imgBytes * f, W, right + (int64_t)f * frameStride, stride, W, H, hipMemcpyHostToDevice, c->sH2D));
+    }
+  }
+  HIPCHK(hipEventRecord(S.h2d, c->sH2D));
+  HIPCHK(hipStreamWaitEvent(c->stream, S.h2d, 0));
+  HIPCHK(hipMemsetAsync(S.dtab, 0, tabBytes, c->stream));
+  st = pli_batch_run(c, nframes, dl, dr, W, (int64_t)imgBytes, stages, S.dtab);
+  if (st != PLI_OK) return st;
+  HIPCHK(hipEventRecord(S.kern, c->stream));
+  HIPCHK(hipStreamWaitEvent(c->sD2H, S.kern, 0));
+  HIPCHK(hipMemcpyAsync(table, S.dtab, tabBytes, hipMemcpyDeviceToHost, c->sD2H));
+  HIPCHK(hipEventRecord(S.d2h, c->sD2H));
+  S.busy = true;
+  ++c->hsSubmitted;
   return PLI_OK;
 }
 
@@ -1256,6 +1357,61 @@ pli_status pli_search_local_map(pli_ctx* c, const pli_proj_query* q, const uint8
                                 const uint8_t* occupied, int32_t ncur, float minX, float maxX, float minY, float maxY,
                                 float nnratio, int32_t* best, int32_t* nmatches) {
   return projectionSearch(c, 1, q, qdesc, nq, kp, desc, uright, occupied, ncur, minX, maxX, minY, maxY, 0, nnratio, best, nmatches);
+}
+
+// ---- frame-to-frame track matching of a batch (match_kernels.hip: k_track_*) ------------------------
+static void trackLayout(const pli_ctx* c, pli_track_layout& L) {
+  int64_t o = 0;
+  auto take = [&](int64_t bytes) { int64_t r = o; o = alignUp(o + bytes, 16); return r; };
+  L.kp_cap = c->hp.kpCap; L.kl_cap = c->hp.klCap;
+  L.off_counts = take(16);
+  L.off_best = take((int64_t)L.kp_cap * 4);
+  L.off_lines = take((int64_t)L.kl_cap * 4);
+  L.record_bytes = alignUp(o, 256);
+}
+
+pli_status pli_track_layout_get(const pli_ctx* c, pli_track_layout* out) {
+  if (!c || !out) return PLI_ERR_INVALID;
+  trackLayout(c, *out);
+  return PLI_OK;
+}
+
+pli_status pli_batch_track(pli_ctx* c, int32_t nframes, const void* table, const float* poses, const pli_track_params* tpar,
+                           void* track) {
+  if (!c || !table || !poses || !tpar || !track) { g_err = "null argument"; return PLI_ERR_INVALID; }
+  if (nframes < 1 || nframes > c->cfg.max_frames) { g_err = "nframes exceeds the context's max_frames"; return PLI_ERR_INVALID; }
+  if (!(tpar->max_x > tpar->min_x) || !(tpar->max_y > tpar->min_y) || !(tpar->fx > 0) || !(tpar->fy > 0)) { g_err = "bad track parameters"; return PLI_ERR_INVALID; }
+  if (nframes < 2) return PLI_OK;
+  HIPCHK(hipSetDevice(c->device));
+  const DevParams& P = c->hp;
+  if ((size_t)P.kpCap * 4 > 160 * 1024 - 1024) { g_err = "too many keypoints for the LDS owner table of the batch track matcher"; return PLI_ERR_INVALID; }
+  pli_track_layout TL;
+  trackLayout(c, TL);
+  TrackParams tp;
+  tp.fx = tpar->fx; tp.fy = tpar->fy; tp.cx = tpar->cx; tp.cy = tpar->cy; tp.bf = tpar->bf; tp.th = tpar->th;
+  tp.minX = tpar->min_x; tp.maxX = tpar->max_x; tp.minY = tpar->min_y; tp.maxY = tpar->max_y;
+  tp.mono = tpar->mono; tp.checkOri = tpar->check_orientation; tp.nnrLines = tpar->nnr_lines;
+  tp.kpCap = P.kpCap; tp.klCap = P.klCap;
+  const pli_table_layout& Y = c->lay;
+  tp.recordBytes = Y.record_bytes; tp.offCounts = Y.off_counts; tp.offKp0 = Y.off_kp[0]; tp.offDesc0 = Y.off_desc[0];
+  tp.offUr = Y.off_uright; tp.offDepth = Y.off_depth; tp.offLd0 = Y.off_ldesc[0];
+  tp.trackBytes = TL.record_bytes; tp.toffCounts = TL.off_counts; tp.toffBest = TL.off_best; tp.toffLines = TL.off_lines;
+  const size_t NF = (size_t)nframes;
+  const size_t bq = alignUp(NF * P.kpCap * sizeof(pli_proj_query), 256), bk = alignUp(NF * P.kpCap * 64 * 8, 256),
+               bc = alignUp(NF * P.kpCap * 4, 256), bl = alignUp(NF * std::max(P.klCap, 1) * 4, 256);
+  pli_status st = ensureScratch(c, bq + bk + bc + bl);
+  if (st != PLI_OK) return st;
+  uint8_t* p = (uint8_t*)c->scratch;
+  pli_proj_query* dq = (pli_proj_query*)p; p += bq;
+  unsigned long long* dkeys = (unsigned long long*)p; p += bk;
+  int* dcc = (int*)p; p += bc;
+  int* dl = (int*)p;
+  const uint8_t* T = (const uint8_t*)table;
+  LAUNCH(c, "k_track_queries", k_track_queries, dim3((P.kpCap + 255) / 256, nframes - 1), dim3(256), 0, c->dP, T, poses, tp, dq);
+  LAUNCH(c, "k_track_candidates", k_track_candidates, dim3(P.kpCap, nframes - 1), dim3(64), 0, T, tp, dq, dkeys, dcc);
+  LAUNCH(c, "k_track_assign", k_track_assign, dim3(nframes - 1), dim3(64), (size_t)P.kpCap * 4, T, tp, dq, dkeys, dcc, (uint8_t*)track);
+  LAUNCH(c, "k_track_lines", k_track_lines, dim3(nframes - 1), dim3(256), 0, T, tp, c->cfg.best_lr_matches != 0 ? 1 : 0, dl, (uint8_t*)track);
+  return PLI_OK;
 }
 
 // ---- bag of words (DBoW2 vocabulary tree) -------------------------------------

@@ -46,6 +46,9 @@ class Frontend:
         if getattr(self, "h", None) and self.h.value:
             self.L.pli_ctx_destroy(self.h)
             self.h = C.c_void_p()
+        for p in getattr(self, "_pinned", []):
+            self.L.pli_host_free(p)
+        self._pinned = []
 
     def __del__(self):
         try:
@@ -239,6 +242,59 @@ class Frontend:
 
     def sync(self):
         check(self.L.pli_ctx_sync(self.h))
+
+    # ---- frame-to-frame track matching of a batch (BASELINE config 3) ------------------------------------------
+    def track_layout(self):
+        tl = capi.TrackLayout()
+        check(self.L.pli_track_layout_get(self.h, C.byref(tl)))
+        return tl
+
+    def track_params(self, th=15.0, mono=False, check_orientation=True, nnr_lines=0.9, cx=None, cy=None, fy=None):
+        """pli_track_params with the context's camera (fx, bf) and the image rectangle as the frame grid bounds."""
+        W, H = self.cfg.width, self.cfg.height
+        return capi.TrackParams(fx=self.cfg.fx, fy=self.cfg.fx if fy is None else fy, cx=W / 2.0 if cx is None else cx,
+                                cy=H / 2.0 if cy is None else cy, bf=self.cfg.bf, th=th, min_x=0.0, max_x=float(W), min_y=0.0,
+                                max_y=float(H), mono=int(mono), check_orientation=int(check_orientation), nnr_lines=nnr_lines,
+                                reserved=0)
+
+    def batch_track_device(self, nframes, dev_table, dev_poses, params, dev_track):
+        """Asynchronous: frame i against frame i-1 on the device tables (pointers as ints)."""
+        check(self.L.pli_batch_track(self.h, nframes, C.c_void_p(dev_table), C.c_void_p(dev_poses), C.byref(params),
+                                     C.c_void_p(dev_track)))
+
+    def parse_track(self, track, frame):
+        tl = self.track_layout()
+        rec = track[frame * tl.record_bytes:(frame + 1) * tl.record_bytes]
+        counts = rec[tl.off_counts:tl.off_counts + 16].view(np.int32).copy()
+        return {"counts": counts, "best": rec[tl.off_best:tl.off_best + 4 * int(counts[0])].view(np.int32).copy(),
+                "lines": rec[tl.off_lines:tl.off_lines + 4 * int(counts[2])].view(np.int32).copy()}
+
+    # ---- pipelined host entry point (pinned buffers, copies overlap the kernels) ---------------------------
+    def pinned(self, nbytes):
+        """numpy u8 view of `nbytes` of pinned host memory (pli_host_alloc); freed with the Frontend."""
+        p = C.c_void_p()
+        check(self.L.pli_host_alloc(nbytes, C.byref(p)))
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(nbytes,))
+
+    def host_buffers(self, nframes):
+        """(left, right, tables): pinned (nframes, H*W) image planes and two pinned result tables."""
+        n = self.cfg.width * self.cfg.height
+        left = self.pinned(nframes * n).reshape(nframes, n)
+        right = self.pinned(nframes * n).reshape(nframes, n)
+        tables = [self.pinned(self.table_bytes(nframes)) for _ in range(2)]
+        return left, right, tables
+
+    def host_submit(self, nframes, left, right, table, stages=capi.RUN_ALL):
+        W, H = self.cfg.width, self.cfg.height
+        check(self.L.pli_batch_submit_host(self.h, nframes, ptr(left), ptr(right), W, W * H, stages, ptr(table)))
+
+    def host_wait(self):
+        check(self.L.pli_batch_wait(self.h, 0))
+
+    def host_wait_all(self):
+        check(self.L.pli_batch_wait(self.h, 1))
 
     def set_stream(self, hip_stream):
         check(self.L.pli_ctx_set_stream(self.h, C.c_void_p(hip_stream)))

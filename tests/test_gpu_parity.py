@@ -556,10 +556,10 @@ def test_sequential_grower_angle_tolerances(gpu, ang):
 
 @pytest.mark.gpu
 def test_large_batch_schedule(gpu):
-    """The large-batch schedule of lsd_mode auto (>= 320 frames: sequential image waves, two per block) on 336 small
+    """The large-batch schedule of lsd_mode auto (>= 640 frames: sequential image waves, two per block) on 660 small
     frames: duplicates identical, distinct pairs equal to the oracle."""
     g = gpu
-    W, H, F, U = 240, 180, 336, 6
+    W, H, F, U = 240, 180, 660, 6
     pairs = [g.synth.make_stereo_pair(70 + s, W, H) for s in range(U)]
     images = np.stack([np.stack(pairs[i % U]) for i in range(F)])
     cfg = g.capi.default_config(W, H, orb_nfeatures=300, lsd_nfeatures=40, max_frames=F)
@@ -703,3 +703,96 @@ def test_config5_4k(gpu):
     m, kl, ld = fe.line_extract(0, L)
     om, okl, old = fr.line_extract(0, L)
     assert m == om == 500 and kl.tobytes() == okl.tobytes() and np.array_equal(ld, old)
+
+
+def test_pipelined_host_entry_point(gpu):
+    """pli_batch_submit_host / pli_batch_wait (pinned staging, copy streams): three batches in flight through two slots give
+    the tables of the synchronous entry point, in order."""
+    g = gpu
+    W, H, F = 376, 240, 3
+    cfg = g.capi.default_config(W, H, orb_nfeatures=400, lsd_nfeatures=40, max_frames=F)
+    fe = g.Frontend(cfg)
+    batches = [np.stack([np.stack(g.synth.make_stereo_pair(60 + 3 * b + i, W, H)) for i in range(F)]) for b in range(3)]
+    want = []
+    for imgs in batches:
+        left, right = np.ascontiguousarray(imgs[:, 0]), np.ascontiguousarray(imgs[:, 1])
+        t = np.zeros(fe.table_bytes(F), np.uint8)
+        g.capi.check(fe.L.pli_batch_run_host(fe.h, F, g.capi.ptr(left), g.capi.ptr(right), W, W * H, g.capi.RUN_ALL, g.capi.ptr(t)))
+        want.append(t)
+    n = W * H
+    lefts = [fe.pinned(F * n).reshape(F, n) for _ in range(3)]
+    rights = [fe.pinned(F * n).reshape(F, n) for _ in range(3)]
+    tabs = [fe.pinned(fe.table_bytes(F)) for _ in range(3)]
+    for b, imgs in enumerate(batches):
+        lefts[b][:] = imgs[:, 0].reshape(F, n)
+        rights[b][:] = imgs[:, 1].reshape(F, n)
+        tabs[b][:] = 0xEE
+    for b in range(3):
+        fe.host_submit(F, lefts[b], rights[b], tabs[b])          # the third submit waits for the first slot
+    fe.host_wait_all()
+    for b in range(3):
+        assert np.array_equal(tabs[b], want[b]), "batch %d" % b
+    # strided host images (row stride > width) take the 2D-copy path
+    wide = np.zeros((F, 2, H, W + 24), np.uint8)
+    wide[:, :, :, :W] = batches[0]
+    tp = fe.pinned(fe.table_bytes(F))
+    g.capi.check(fe.L.pli_batch_submit_host(fe.h, F, g.capi.ptr(wide[:, 0]), C.c_void_p(wide.ctypes.data + H * (W + 24)), W + 24,
+                                            2 * H * (W + 24), g.capi.RUN_ALL, g.capi.ptr(tp)))
+    fe.host_wait()
+    assert np.array_equal(tp, want[0])
+
+
+def test_batch_track_config3(gpu):
+    """pli_batch_track on the device tables of a batch of consecutive 1280x720 frames (BASELINE config 3): frame i against
+    frame i-1 — SearchByProjection(CurrentFrame, LastFrame) with the projection done on the device, and match() of the line
+    descriptors — equals the oracle's restatement, for the three motion cases (neutral window, forward, backward)."""
+    import torch
+    g = gpu
+    W, H, F = 1280, 720, 4
+    cfg = g.capi.default_config(W, H, orb_nfeatures=2000, lsd_nfeatures=200, max_frames=F)
+    fe = g.Frontend(cfg)
+    frames = [g.synth.make_stereo_pair(8, W, H, t=t) for t in range(F)]
+    imgs = np.stack([np.stack(f) for f in frames])
+    left, right = np.ascontiguousarray(imgs[:, 0]), np.ascontiguousarray(imgs[:, 1])
+    table = np.zeros(fe.table_bytes(F), np.uint8)
+    g.capi.check(fe.L.pli_batch_run_host(fe.h, F, g.capi.ptr(left), g.capi.ptr(right), W, W * H, g.capi.RUN_ALL, g.capi.ptr(table)))
+    recs = [fe.parse_record(table, f) for f in range(F)]
+
+    def pose(t, tz):
+        a = np.deg2rad(0.5 * t)
+        T = np.eye(4, dtype=np.float64)
+        T[:3, :3] = [[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]]
+        T[:3, 3] = [-0.02 * t, -0.007 * t, tz]
+        return T[:3].astype(np.float32)
+    poses = np.stack([pose(0, 0.0), pose(1, 0.01), pose(2, -0.35), pose(3, 0.05)])      # neutral, forward (tlc.z > mb), backward
+    tp = fe.track_params(th=15.0, mono=False, check_orientation=True, nnr_lines=0.9, cx=W / 2.0 - 3.5, cy=H / 2.0 + 2.25)
+    tl = fe.track_layout()
+    d_table = torch.from_numpy(table).cuda()
+    d_poses = torch.from_numpy(poses.reshape(-1)).cuda()
+    d_track = torch.zeros(F * tl.record_bytes, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    fe.batch_track_device(F, d_table.data_ptr(), d_poses.data_ptr(), tp, d_track.data_ptr())
+    fe.sync()
+    track = d_track.cpu().numpy()
+    sf = np.cumprod(np.concatenate([[np.float32(1.0)], np.full(7, np.float32(1.2), np.float32)])).astype(np.float32)
+    bounds = (0.0, float(W), 0.0, float(H))
+    seen = set()
+    for f in range(1, F):
+        last, cur = recs[f - 1], recs[f]
+        tr = fe.parse_track(track, f)
+        q = g.po.track_queries(last["kpL"], last["depth"], poses[f - 1], poses[f], tp.fx, tp.fy, tp.cx, tp.cy, tp.bf, tp.th, False, sf)
+        v = q["valid"] > 0
+        oc = last["kpL"]["octave"][v]
+        if np.array_equal(q["min_level"][v], oc - 1) and np.array_equal(q["max_level"][v], oc + 1):
+            seen.add("neutral")
+        elif np.array_equal(q["min_level"][v], oc) and (q["max_level"][v] < 0).all():
+            seen.add("forward")
+        elif (q["min_level"][v] == 0).all() and np.array_equal(q["max_level"][v], oc):
+            seen.add("backward")
+        on, obest = g.po.search_by_projection(q, last["descL"], cur["kpL"], cur["descL"], cur["uright"], bounds, True)
+        assert tr["counts"][0] == len(last["kpL"]) and tr["counts"][1] == on, (f, tr["counts"], on)
+        assert np.array_equal(tr["best"], obest), "frame %d point track matches" % f
+        ln, lm = g.po.match_lines(last["ldescL"], cur["ldescL"], 0.9, True)
+        assert tr["counts"][2] == len(last["ldescL"]) and tr["counts"][3] == ln and np.array_equal(tr["lines"], lm), "frame %d lines" % f
+        assert on > 50 and ln > 10
+    assert seen == {"neutral", "forward", "backward"}, seen

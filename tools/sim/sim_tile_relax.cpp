@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <map>
 #include <numeric>
+#include <utility>
 
 using namespace orc;
 
@@ -165,6 +166,138 @@ int main(int argc, char** argv) {
                   changed, tc, NT, wrong);
       prev.swap(cur);
       if (changed == 0) break;
+    }
+  }
+
+
+  // ---- tile-sequential relaxation WITH carrying (the GPU schedule): rounds 1 full, round 2 by the foreign-owner rule,
+  //      rounds >= 3 by the change rule; cells of 8x8; checks owner map AND every alive region's last-run list ----
+  if (getenv("SIM_CARRY")) {
+    const int CW = (W + 7) / 8, CH = (H + 7) / 8;
+    std::vector<int> prev(N), cur(N), prev2(N);
+    for (int q = 0; q < N; ++q) prev[q] = F.rankOf[q];          // trivial owner_0 (INT_MAX for undefined)
+    std::vector<std::vector<int>> lastRun(R);                    // pixel list of the last run of every region
+    std::vector<int> lastRound(R, 0);
+    const bool full2 = getenv("SIM_FULL2") != nullptr;
+    std::vector<int> boxes(4 * (size_t)R, 0);
+    // truth lists
+    std::vector<std::vector<int>> truthRun(R);
+    {
+      std::vector<int> own(N, INT32_MAX);
+      long tt = 0;
+      for (int r = 0; r < R; ++r) {
+        if (own[F.order[r]] != INT32_MAX) continue;
+        grow(F, r, [&](int q) { return own[q] != INT32_MAX; }, [&](int q) { own[q] = r; }, reg, tt);
+        truthRun[r] = reg;
+      }
+    }
+    auto tileOf = [&](int p) { return (p / W / TS) * TW + (p % W) / TS; };
+    for (int t = 1; t <= 40; ++t) {
+      std::vector<char> dirty(R, (t <= 1 || (t == 2 && full2)) ? 1 : 0);
+      std::vector<int> cellMin(CW * CH, INT32_MAX);
+      long changed = 0;
+      if (t == 2) {
+        for (int q = 0; q < N; ++q) {
+          const int o = prev[q];
+          if (o == INT32_MAX) continue;
+          if (prev[F.order[o]] != o) dirty[o] = 1;     // the owner died after it ran: its pixels are released
+          if (tileOf(F.order[o]) != tileOf(q)) cellMin[(q / W / 8) * CW + (q % W) / 8] = std::min(cellMin[(q / W / 8) * CW + (q % W) / 8], o);
+          if (F.order[o] == q) {
+            const int T = tileOf(q), tx0 = (T % TW) * TS, ty0 = (T / TW) * TS;
+            const int* b = &boxes[4 * (size_t)o];
+            if (b[0] - 1 < tx0 || b[1] - 1 < ty0 || b[2] + 1 >= tx0 + TS || b[3] + 1 >= ty0 + TS) dirty[o] = 1;
+          }
+        }
+        changed = 1;
+      } else if (t >= 3) {
+        for (int q = 0; q < N; ++q)
+          if (prev[q] != prev2[q]) {
+            ++changed;
+            int& m = cellMin[(q / W / 8) * CW + (q % W) / 8];
+            m = std::min(m, std::min(prev[q], prev2[q]));
+          }
+        if (!changed) {
+          std::printf("  carry: fixed point detected at round %d\n", t);
+          int shown = 0;
+          for (int r = 0; r < R && shown < 6; ++r)
+            if (prev[F.order[r]] == r && lastRun[r] != truthRun[r]) {
+              ++shown;
+              const int sp = F.order[r];
+              std::printf("   bad region r=%d seed (%d,%d) tile %d last run in round %d: %zu px, truth %zu px\n", r, sp % W, sp / W, tileOf(sp),
+                          lastRound[r], lastRun[r].size(), truthRun[r].size());
+              for (size_t k = 0; k < std::max(lastRun[r].size(), truthRun[r].size()); ++k) {
+                const int a = k < lastRun[r].size() ? lastRun[r][k] : -1, b = k < truthRun[r].size() ? truthRun[r][k] : -1;
+                if (a != b) {
+                  std::printf("     first difference at list position %zu: last (%d,%d) truth (%d,%d)\n", k, a % W, a / W, b % W, b / W);
+                  for (int q : {a, b}) if (q >= 0) {
+                    const int o = prev[q];
+                    std::printf("       pixel (%d,%d): rank %d, final owner %d (seed tile %d), truth owner %d, pixel tile %d\n", q % W, q / W, F.rankOf[q], o,
+                                o == INT32_MAX ? -1 : tileOf(F.order[o]), truth[q], tileOf(q));
+                  }
+                  break;
+                }
+              }
+            }
+          break;
+        }
+      }
+      if (t >= 2) {
+        for (int q = 0; q < N; ++q) {
+          const int o = prev[q];
+          if (o == INT32_MAX) continue;
+          const int x = q % W, y = q / W;
+          int m = INT32_MAX;
+          for (int dy = -1; dy <= 1; dy += 2)
+            for (int dx = -1; dx <= 1; dx += 2) {
+              const int xx = std::min(std::max(x + dx, 0), W - 1), yy = std::min(std::max(y + dy, 0), H - 1);
+              m = std::min(m, cellMin[(yy / 8) * CW + xx / 8]);
+            }
+          if (m < o) dirty[o] = 1;
+          if (t >= 3) {
+            const int r = F.rankOf[q];
+            const bool a1 = prev[q] == r, a2 = prev2[q] == r;
+            if (a1 != a2) dirty[r] = 1;
+          }
+        }
+      }
+      // owner_t start: carried regions keep their pixels, everything else its own rank
+      for (int q = 0; q < N; ++q) {
+        const int o = prev[q];
+        cur[q] = o == INT32_MAX ? INT32_MAX : (dirty[o] ? F.rankOf[q] : o);
+      }
+      long grown = 0, acc = 0, tst = 0;
+      for (int T = 0; T < NT; ++T) {
+        std::vector<std::pair<int, int>> claims;
+        std::vector<int> mineIdx;
+        static std::vector<int> mine;
+        if ((int)mine.size() != N) mine.assign(N, INT32_MAX);
+        for (int r : tileSeeds[T]) {
+          const int sp = F.order[r];
+          if (!dirty[r] || prev[sp] != r) continue;
+          auto used = [&](int q) { return mine[q] <= r || prev[q] < r || cur[q] < r; };   // (cur: the pre-claims of carried lower ranks)
+          if (mine[sp] < r || cur[sp] < r) continue;
+          grow(F, r, used, [&](int q) { if (mine[q] == INT32_MAX) mineIdx.push_back(q); mine[q] = std::min(mine[q], r); }, reg, tst);
+          lastRun[r] = reg;
+          lastRound[r] = t;
+          int* b = &boxes[4 * (size_t)r];
+          b[0] = b[2] = reg[0] % W; b[1] = b[3] = reg[0] / W;
+          for (int q : reg) { b[0] = std::min(b[0], q % W); b[2] = std::max(b[2], q % W); b[1] = std::min(b[1], q / W); b[3] = std::max(b[3], q / W); }
+          ++grown; acc += (long)reg.size();
+        }
+        for (int q : mineIdx) { claims.push_back({q, mine[q]}); mine[q] = INT32_MAX; }
+        // claims of this tile land after the tile is done (no in-round visibility across tiles in this model)
+        static std::vector<std::pair<int, int>> all;
+        if (T == 0) all.clear();
+        all.insert(all.end(), claims.begin(), claims.end());
+        if (T == NT - 1) for (auto& c : all) cur[c.first] = std::min(cur[c.first], c.second);
+      }
+      long wrong = 0, wrongRuns = 0;
+      for (int q = 0; q < N; ++q) if (cur[q] != truth[q]) ++wrong;
+      for (int r = 0; r < R; ++r) if (cur[F.order[r]] == r && lastRun[r] != truthRun[r]) ++wrongRuns;
+      std::printf("  carry round %2d: grown %6ld regions, %7ld px, changed-in %7ld, owner wrong %6ld, alive regions with a wrong last run %5ld\n",
+                  t, grown, acc, changed, wrong, wrongRuns);
+      prev2 = prev;
+      prev = cur;
     }
   }
 
