@@ -1,107 +1,244 @@
-// Drop-in shims with the reference's signatures (build inside the PLI-SLAM tree, where OpenCV 3 exists):
+// Drop-in shims with the reference's EXACT signatures (build inside the PLI-SLAM tree, where OpenCV 3 exists):
 //
-//   ORB_SLAM3::ORBextractor   include/ORBextractor.h:46-115   (functor + scale getters + mvImagePyramid)
-//   ORB_SLAM3::Lineextractor  include/LineExtractor.h:41-74
-//   ORB_SLAM3::match          include/LineMatcher.h:63
-//   ORB_SLAM3::ORBmatcher::DescriptorDistance  include/ORBmatcher.h:42
+//   ORB_SLAM3::ORBextractor   include/ORBextractor.h:46-115   ctor (nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST),
+//                                                             functor, scale getters, mvImagePyramid
+//   ORB_SLAM3::Lineextractor  include/LineExtractor.h:41-74   both constructors, functor
+//   ORB_SLAM3::match          include/LineMatcher.h:63        match(desc1, desc2, nnr, matches_12)
+//   ORB_SLAM3::ORBmatcher::DescriptorDistance                 include/ORBmatcher.h:42  (host inline: 32 bytes never go to the GPU)
+//   ORB_SLAM3::ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono, match12)   include/ORBmatcher.h:51,
+//                                                             src/ORBmatcher.cc:2179-2323 (projection on the host with the
+//                                                             reference's own cv::Mat expressions, window search on the GPU)
 //
-// Frame.cc / Tracking.cc keep calling these names unchanged; INTEGRATION.md lists the three edits a
-// maintainer makes (swap two headers, share one pli::Frontend between the four extractors).
-// The arithmetic is in libpli_frontend.so; this file only converts containers.
+// Frame.cc / Tracking.cc keep calling these names unchanged; INTEGRATION.md lists the edits (swap the headers).
+//
+// How four independent extractor objects end up on ONE device context (the stereo matchers need both eyes' pyramids and
+// tables on the device): extractors register in construction order.  Tracking.cc:87-98,743-749 builds
+//   mpORBextractorLeft, mpLineextractorLeft, mpORBextractorRight, mpLineextractorRight, mpIniORBextractor, mpIniLineextractor;
+// the second ORBextractor / Lineextractor constructed with the SAME parameters as an existing one becomes the right eye of
+// that one's group, different parameters (the 2x-feature initial extractors) open a new group; the k-th ORB group and the
+// k-th line group share a context, created lazily at the first operator() call for the size of the image it is given.
 #pragma once
 #if !__has_include(<opencv2/core/core.hpp>)
 #error "orbslam_adapters.hpp needs OpenCV 3 (it is meant to be compiled inside the PLI-SLAM tree)"
 #endif
 #include <opencv2/core/core.hpp>
+#include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <vector>
 #include "pli_cpp.hpp"
+#ifndef PLI_ADAPTER_NO_KEYLINE_HEADER
 #include "line_descriptor_custom.hpp"   // cv::line_descriptor::KeyLine (Thirdparty/line_descriptor)
+#endif
 
 namespace ORB_SLAM3 {
 
-// All extractors of one Tracking object share this context (device pyramids feed the stereo matcher).
-struct PliShared {
-  std::shared_ptr<pli::Frontend> fe;
-  static pli_frontend_config makeConfig(int w, int h, int nfeatures, float scaleFactor, int nlevels, int iniThFAST,
-                                        int minThFAST) {
-    pli_frontend_config c;
-    pli_config_default(&c, w, h);
-    c.orb_nfeatures = nfeatures; c.orb_scale_factor = scaleFactor; c.orb_nlevels = nlevels;
-    c.orb_ini_th_fast = iniThFAST; c.orb_min_th_fast = minThFAST;
-    return c;
+namespace pli_detail {
+
+struct OrbParams {
+  int nfeatures, nlevels, iniThFAST, minThFAST;
+  float scaleFactor;
+  bool operator==(const OrbParams& o) const {
+    return nfeatures == o.nfeatures && nlevels == o.nlevels && iniThFAST == o.iniThFAST && minThFAST == o.minThFAST && scaleFactor == o.scaleFactor;
   }
 };
+struct LineParams {
+  int lsd_nfeatures, lsd_refine, lsd_n_bins;
+  double min_line_length, lsd_scale, lsd_sigma_scale, lsd_quant, lsd_ang_th, lsd_log_eps, lsd_density_th;
+  bool bFLD;
+  bool operator==(const LineParams& o) const {
+    return lsd_nfeatures == o.lsd_nfeatures && lsd_refine == o.lsd_refine && lsd_n_bins == o.lsd_n_bins &&
+           min_line_length == o.min_line_length && lsd_scale == o.lsd_scale && lsd_sigma_scale == o.lsd_sigma_scale &&
+           lsd_quant == o.lsd_quant && lsd_ang_th == o.lsd_ang_th && lsd_log_eps == o.lsd_log_eps &&
+           lsd_density_th == o.lsd_density_th && bFLD == o.bFLD;
+  }
+};
+
+// One group = the extractors of one Frame constructor: ORB left/right + LSD left/right on one device context per image size.
+struct Group {
+  bool hasOrb = false, hasLine = false;
+  OrbParams orb{};
+  LineParams line{};
+  int orbEyes = 0, lineEyes = 0;
+  std::mutex mu;
+  std::map<std::pair<int, int>, std::shared_ptr<pli::Frontend>> ctx;     // by image size
+
+  std::shared_ptr<pli::Frontend> context(int w, int h) {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = ctx.find({w, h});
+    if (it != ctx.end()) return it->second;
+    pli_frontend_config c;
+    pli_config_default(&c, w, h);
+    if (hasOrb) {
+      c.orb_nfeatures = orb.nfeatures; c.orb_scale_factor = orb.scaleFactor; c.orb_nlevels = orb.nlevels;
+      c.orb_ini_th_fast = orb.iniThFAST; c.orb_min_th_fast = orb.minThFAST;
+    }
+    if (hasLine) {
+      c.lsd_nfeatures = line.lsd_nfeatures; c.lsd_refine = line.lsd_refine; c.lsd_n_bins = line.lsd_n_bins;
+      c.min_line_length = line.min_line_length; c.lsd_scale = line.lsd_scale; c.lsd_sigma_scale = line.lsd_sigma_scale;
+      c.lsd_quant = line.lsd_quant; c.lsd_ang_th = line.lsd_ang_th; c.lsd_log_eps = line.lsd_log_eps;
+      c.lsd_density_th = line.lsd_density_th;
+      if (c.lsd_nfeatures > c.max_lines) c.max_lines = c.lsd_nfeatures;
+    }
+    auto fe = std::make_shared<pli::Frontend>(c);      // throws pli::Error (e.g. lsd_refine != 0, no gfx950 device)
+    ctx[{w, h}] = fe;
+    return fe;
+  }
+};
+
+struct Registry {
+  std::mutex mu;
+  std::vector<std::shared_ptr<Group>> groups;
+  static Registry& get() { static Registry r; return r; }
+  // the group of the k-th distinct parameter set of its kind; eye = how many extractors of that kind joined it before
+  std::shared_ptr<Group> joinOrb(const OrbParams& p, int& eye) {
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& g : groups)
+      if (g->hasOrb && g->orb == p && g->orbEyes < 2) { eye = g->orbEyes++; return g; }
+    for (auto& g : groups)
+      if (!g->hasOrb) { g->hasOrb = true; g->orb = p; eye = g->orbEyes++; return g; }
+    groups.push_back(std::make_shared<Group>());
+    auto& g = groups.back();
+    g->hasOrb = true; g->orb = p; eye = g->orbEyes++;
+    return g;
+  }
+  std::shared_ptr<Group> joinLine(const LineParams& p, int& eye) {
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& g : groups)
+      if (g->hasLine && g->line == p && g->lineEyes < 2) { eye = g->lineEyes++; return g; }
+    for (auto& g : groups)
+      if (!g->hasLine) { g->hasLine = true; g->line = p; eye = g->lineEyes++; return g; }
+    groups.push_back(std::make_shared<Group>());
+    auto& g = groups.back();
+    g->hasLine = true; g->line = p; eye = g->lineEyes++;
+    return g;
+  }
+  // a context for the stateless matchers (any group will do)
+  std::shared_ptr<pli::Frontend> any() {
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& g : groups) {
+      std::lock_guard<std::mutex> lk2(g->mu);
+      if (!g->ctx.empty()) return g->ctx.begin()->second;
+    }
+    return nullptr;
+  }
+};
+
+inline void checkGray(const cv::Mat& m, const char* who) {
+  if (m.type() != CV_8UC1) throw std::invalid_argument(std::string(who) + ": the image must be CV_8UC1 (the reference asserts the same)");
+}
+
+}  // namespace pli_detail
 
 class ORBextractor {
  public:
   enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
-  // `eye`: 0 for mpORBextractorLeft, 1 for mpORBextractorRight (Tracking.cc:743-746)
-  ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, PliShared shared, int eye)
-      : mvImagePyramid(nlevels), sh_(shared), eye_(eye), nlevels_(nlevels), scaleFactor_(scaleFactor) {
+
+  ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
+      : mvImagePyramid(nlevels), nfeatures(nfeatures), scaleFactor(scaleFactor), nlevels(nlevels), iniThFAST(iniThFAST), minThFAST(minThFAST) {
     mvScaleFactor.resize(nlevels); mvLevelSigma2.resize(nlevels);
     mvScaleFactor[0] = 1.0f; mvLevelSigma2[0] = 1.0f;
     for (int i = 1; i < nlevels; i++) { mvScaleFactor[i] = mvScaleFactor[i - 1] * scaleFactor; mvLevelSigma2[i] = mvScaleFactor[i] * mvScaleFactor[i]; }
     mvInvScaleFactor.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
     for (int i = 0; i < nlevels; i++) { mvInvScaleFactor[i] = 1.0f / mvScaleFactor[i]; mvInvLevelSigma2[i] = 1.0f / mvLevelSigma2[i]; }
-    (void)nfeatures; (void)iniThFAST; (void)minThFAST;   // already in the shared context's config
+    group_ = pli_detail::Registry::get().joinOrb({nfeatures, nlevels, iniThFAST, minThFAST, scaleFactor}, eye_);
   }
-  // int operator()(InputArray image, InputArray mask, vector<KeyPoint>&, OutputArray descriptors, vector<int>& vLappingArea)
-  int operator()(cv::InputArray _image, cv::InputArray /*mask*/, std::vector<cv::KeyPoint>& _keypoints,
-                 cv::OutputArray _descriptors, std::vector<int>& /*vLappingArea = {0,0} on the stereo path*/) {
+  ~ORBextractor() {}
+
+  // Compute the ORB features and descriptors on an image (mask ignored like the reference; vLappingArea: see below).
+  int operator()(cv::InputArray _image, cv::InputArray /*_mask*/, std::vector<cv::KeyPoint>& _keypoints, cv::OutputArray _descriptors,
+                 std::vector<int>& vLappingArea) {
     if (_image.empty()) return -1;
     cv::Mat image = _image.getMat();
+    pli_detail::checkGray(image, "ORBextractor");
+    std::shared_ptr<pli::Frontend> fe = group_->context(image.cols, image.rows);
     std::vector<pli_keypoint> kps;
     std::vector<uint8_t> desc;
-    int n = sh_.fe->extractORB(eye_, image.data, image.cols, image.rows, (int64_t)image.step, kps, desc);
+    const int n = fe->extractORB(eye_, image.data, image.cols, image.rows, (int64_t)image.step, kps, desc);
     if (n < 0) return -1;
+    // ORBextractor.cc:1135-1144: keypoints inside [vLappingArea[0], vLappingArea[1]] (level-0 x) go to the back of the
+    // arrays (filled from the end), the others to the front in order; the return value is the number of front entries.
+    // On the rectified stereo path vLappingArea = {0, 0}, where this is the identity except for keypoints at x == 0
+    // (none: the extractor keeps a 16-px border).
+    std::vector<int> order(n);
+    int mono = 0, stereo = n - 1;
+    for (int i = 0; i < n; ++i) {
+      const bool lapping = vLappingArea.size() >= 2 && kps[i].x >= vLappingArea[0] && kps[i].x <= vLappingArea[1];
+      if (lapping) order[stereo--] = i; else order[mono++] = i;
+    }
     _keypoints.resize(n);
-    for (int i = 0; i < n; ++i)
-      _keypoints[i] = cv::KeyPoint(kps[i].x, kps[i].y, kps[i].size, kps[i].angle, kps[i].response, kps[i].octave, -1);
     if (n == 0) _descriptors.release();
-    else {
-      _descriptors.create(n, 32, CV_8U);
-      std::memcpy(_descriptors.getMat().data, desc.data(), (size_t)n * 32);
+    else _descriptors.create(n, 32, CV_8U);
+    cv::Mat D = n ? _descriptors.getMat() : cv::Mat();
+    for (int j = 0; j < n; ++j) {
+      const pli_keypoint& k = kps[order[j]];
+      _keypoints[j] = cv::KeyPoint(k.x, k.y, k.size, k.angle, k.response, k.octave, -1);
+      std::memcpy(D.ptr(j), desc.data() + (size_t)order[j] * 32, 32);
     }
     // public member the stereo matcher and drawers read (ORBextractor.h:87); levels come back without the border
-    for (int l = 0; l < nlevels_; ++l) {
+    for (int l = 0; l < nlevels; ++l) {
       int w = 0, h = 0;
-      pli::check(pli_orb_pyramid_level(sh_.fe->handle(), eye_, l, nullptr, 0, &w, &h));
+      pli::check(pli_orb_pyramid_level(fe->handle(), eye_, l, nullptr, 0, &w, &h));
       mvImagePyramid[l].create(h, w, CV_8U);
-      pli::check(pli_orb_pyramid_level(sh_.fe->handle(), eye_, l, mvImagePyramid[l].data, (int64_t)w * h, &w, &h));
+      pli::check(pli_orb_pyramid_level(fe->handle(), eye_, l, mvImagePyramid[l].data, (int64_t)w * h, &w, &h));
     }
-    return n;
+    return mono;
   }
-  int inline GetLevels() { return nlevels_; }
-  float inline GetScaleFactor() { return scaleFactor_; }
+
+  int inline GetLevels() { return nlevels; }
+  float inline GetScaleFactor() { return scaleFactor; }
   std::vector<float> inline GetScaleFactors() { return mvScaleFactor; }
   std::vector<float> inline GetInverseScaleFactors() { return mvInvScaleFactor; }
   std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
   std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
+
   std::vector<cv::Mat> mvImagePyramid;
-  PliShared& shared() { return sh_; }
+
+  // (not in the reference) the shared device context for an image size: Frame's stereo matchers run on it
+  std::shared_ptr<pli::Frontend> pliContext(int w, int h) { return group_->context(w, h); }
+  int pliEye() const { return eye_; }
 
  protected:
-  PliShared sh_;
-  int eye_, nlevels_;
-  float scaleFactor_;
+  int nfeatures;
+  double scaleFactor;
+  int nlevels, iniThFAST, minThFAST;
   std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+  std::shared_ptr<pli_detail::Group> group_;
+  int eye_ = 0;
 };
+
+#ifdef PLI_ADAPTER_KEYLINE_TYPE
+typedef PLI_ADAPTER_KEYLINE_TYPE PliKeyLine;
+#else
+typedef cv::line_descriptor::KeyLine PliKeyLine;
+#endif
 
 class Lineextractor {
  public:
-  Lineextractor(int /*lsd_nfeatures*/, double /*llength_th*/, int /*lsd_refine*/, double /*lsd_scale*/,
-                double /*lsd_sigma_scale*/, double /*lsd_quant*/, double /*lsd_ang_th*/, double /*lsd_log_eps*/,
-                double /*lsd_density_th*/, int /*lsd_n_bins*/, bool /*bFLD*/, PliShared shared, int eye)
-      : sh_(shared), eye_(eye) {}
-  // void operator()(const cv::Mat& image, const cv::Mat& mask, vector<KeyLine>& keylines, cv::Mat& descriptors_line)
-  void operator()(const cv::Mat& img, const cv::Mat& /*mask*/, std::vector<cv::line_descriptor::KeyLine>& keylines,
-                  cv::Mat& descriptors_line) {
+  Lineextractor(int _lsd_nfeatures, double _llength_th, bool _bFLD = false)
+      : Lineextractor(_lsd_nfeatures, _llength_th, 0, 0.8, 0.6, 2.0, 22.5, 1.0, 0.7, 1024, _bFLD) {}   // LSDOptions defaults, LineExtractor.cc:31-48
+  Lineextractor(int _lsd_nfeatures, double _llength_th, int _lsd_refine, double _lsd_scale, double _lsd_sigma_scale, double _lsd_quant,
+                double _lsd_ang_th, double _lsd_log_eps, double _lsd_density_th, int _lsd_n_bins, bool _bFLD = false)
+      : lsd_nfeatures(_lsd_nfeatures), min_line_length(_llength_th), lsd_refine(_lsd_refine), lsd_scale(_lsd_scale),
+        lsd_sigma_scale(_lsd_sigma_scale), lsd_quant(_lsd_quant), lsd_ang_th(_lsd_ang_th), lsd_log_eps(_lsd_log_eps),
+        lsd_density_th(_lsd_density_th), lsd_n_bins(_lsd_n_bins), bFLD(_bFLD) {
+    if (bFLD) throw std::invalid_argument("Lineextractor: the FLD detector is not on the reference path (bFLD = false everywhere)");
+    group_ = pli_detail::Registry::get().joinLine({lsd_nfeatures, lsd_refine, lsd_n_bins, min_line_length, lsd_scale, lsd_sigma_scale,
+                                                   lsd_quant, lsd_ang_th, lsd_log_eps, lsd_density_th, bFLD}, eye_);
+  }
+  ~Lineextractor() {}
+
+  void operator()(const cv::Mat& image, const cv::Mat& /*mask*/, std::vector<PliKeyLine>& keylines, cv::Mat& descriptors_line) {
+    pli_detail::checkGray(image, "Lineextractor");
+    std::shared_ptr<pli::Frontend> fe = group_->context(image.cols, image.rows);
     std::vector<pli_keyline> kls;
     std::vector<uint8_t> desc;
-    sh_.fe->extractLines(eye_, img.data, img.cols, img.rows, (int64_t)img.step, kls, desc);
+    fe->extractLines(eye_, image.data, image.cols, image.rows, (int64_t)image.step, kls, desc);
     keylines.resize(kls.size());
     for (size_t i = 0; i < kls.size(); ++i) {
-      cv::line_descriptor::KeyLine& k = keylines[i];
+      PliKeyLine& k = keylines[i];
       const pli_keyline& s = kls[i];
       k.angle = s.angle; k.class_id = s.class_id; k.octave = s.octave; k.pt = cv::Point2f(s.pt_x, s.pt_y);
       k.response = s.response; k.size = s.size;
@@ -116,14 +253,118 @@ class Lineextractor {
     }
   }
 
+  std::shared_ptr<pli::Frontend> pliContext(int w, int h) { return group_->context(w, h); }
+  int pliEye() const { return eye_; }
+
  protected:
-  PliShared sh_;
-  int eye_;
+  int lsd_nfeatures;
+  double min_line_length;
+  int lsd_refine;
+  double lsd_scale, lsd_sigma_scale, lsd_quant, lsd_ang_th, lsd_log_eps, lsd_density_th;
+  int lsd_n_bins;
+  bool bFLD;
+  std::shared_ptr<pli_detail::Group> group_;
+  int eye_ = 0;
 };
 
-// int match(const cv::Mat& desc1, const cv::Mat& desc2, float nnr, std::vector<int>& matches_12), LineMatcher.h:63
-inline int match(pli::Frontend& fe, const cv::Mat& desc1, const cv::Mat& desc2, float nnr, std::vector<int>& matches_12) {
-  return fe.matchLines(desc1.data, desc1.rows, desc2.data, desc2.rows, nnr, matches_12);
+// int match(const cv::Mat& desc1, const cv::Mat& desc2, float nnr, std::vector<int>& matches_12), LineMatcher.h:63 /
+// LineMatcher.cpp:201-229 (uses the context of the extractors that produced the descriptors; they exist by then)
+inline int match(const cv::Mat& desc1, const cv::Mat& desc2, float nnr, std::vector<int>& matches_12) {
+  std::shared_ptr<pli::Frontend> fe = pli_detail::Registry::get().any();
+  if (!fe) throw std::logic_error("ORB_SLAM3::match: no extractor has run yet (no device context)");
+  matches_12.assign(desc1.rows, -1);
+  if (desc1.rows == 0) return 0;
+  return fe->matchLines(desc1.data, desc1.rows, desc2.data, desc2.rows, nnr, matches_12);
 }
+
+// The parts of ORB_SLAM3::ORBmatcher on the hot path.  Template on the tree's Frame / MapPoint so that this header does
+// not need Frame.h; inside the PLI-SLAM tree: `using ORBmatcher = ORB_SLAM3::PliORBmatcher<Frame, MapPoint>;`.
+template <class FrameT, class MapPointT>
+class PliORBmatcher {
+ public:
+  static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;
+  PliORBmatcher(float nnratio = 0.6, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+
+  // ORBmatcher.cc:2495-2511 (bit-twiddling popcount over 8 x 32 bits): the same number as 4 x popcount(64)
+  static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b) { return pli::descriptorDistance(a.ptr<uint8_t>(), b.ptr<uint8_t>()); }
+
+  int SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame, const float th, const bool bMono) {
+    std::map<int, int> m;
+    return SearchByProjection(CurrentFrame, LastFrame, th, bMono, m);
+  }
+
+  // ORBmatcher.cc:2179-2323.  The projection (lines 2190-2244) is the reference's own cv::Mat arithmetic, run here on the host;
+  // the window search, the "already taken" exclusion, TH_HIGH, the rotation histogram and ComputeThreeMaxima run on the GPU.
+  int SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame, const float th, const bool bMono, std::map<int, int>& match12) {
+    match12.clear();
+    const cv::Mat Rcw = CurrentFrame.mTcw.rowRange(0, 3).colRange(0, 3);
+    const cv::Mat tcw = CurrentFrame.mTcw.rowRange(0, 3).col(3);
+    const cv::Mat twc = -Rcw.t() * tcw;
+    const cv::Mat Rlw = LastFrame.mTcw.rowRange(0, 3).colRange(0, 3);
+    const cv::Mat tlw = LastFrame.mTcw.rowRange(0, 3).col(3);
+    const cv::Mat tlc = Rlw * twc + tlw;
+    const bool bForward = tlc.at<float>(2) > CurrentFrame.mb && !bMono;
+    const bool bBackward = -tlc.at<float>(2) > CurrentFrame.mb && !bMono;
+    const int N = LastFrame.N;
+    std::vector<pli_proj_query> q((size_t)N);
+    std::vector<uint8_t> qdesc((size_t)N * 32, 0);
+    for (int i = 0; i < N; i++) {
+      pli_proj_query& Q = q[i];
+      std::memset(&Q, 0, sizeof(Q));
+      Q.max_level = -1;
+      MapPointT* pMP = LastFrame.mvpMapPoints[i];
+      if (!pMP || LastFrame.mvbOutlier[i]) continue;
+      cv::Mat x3Dw = pMP->GetWorldPos();
+      cv::Mat x3Dc = Rcw * x3Dw + tcw;
+      const float xc = x3Dc.at<float>(0);
+      const float yc = x3Dc.at<float>(1);
+      const float invzc = 1.0 / x3Dc.at<float>(2);
+      if (invzc < 0) continue;
+      Q.u = CurrentFrame.fx * xc * invzc + CurrentFrame.cx;
+      Q.v = CurrentFrame.fy * yc * invzc + CurrentFrame.cy;
+      const int nLastOctave = LastFrame.mvKeys[i].octave;
+      Q.radius = th * CurrentFrame.mvScaleFactors[nLastOctave];
+      if (bForward) { Q.min_level = nLastOctave; Q.max_level = -1; }
+      else if (bBackward) { Q.min_level = 0; Q.max_level = nLastOctave; }
+      else { Q.min_level = nLastOctave - 1; Q.max_level = nLastOctave + 1; }
+      Q.ur = Q.u - CurrentFrame.mbf * invzc;
+      Q.angle = LastFrame.mvKeysUn[i].angle;
+      Q.valid = 1;                                      // (the image-bounds test :2225-2228 is done by the library)
+      const cv::Mat dMP = pMP->GetDescriptor();
+      std::memcpy(&qdesc[(size_t)i * 32], dMP.ptr<uint8_t>(), 32);
+    }
+    // the current frame: keypoints, descriptors, mvuRight; keypoints that already hold a map point with observations are
+    // not available (:2259-2261) — they are handed over as valid = 0 queries cannot express that, so their uRight gate is
+    // left alone and they are removed from the candidate set by marking them taken beforehand
+    const int M = CurrentFrame.N;
+    std::vector<pli_keypoint> kp((size_t)M);
+    for (int j = 0; j < M; ++j) {
+      const cv::KeyPoint& k = CurrentFrame.mvKeysUn[j];
+      kp[j].x = k.pt.x; kp[j].y = k.pt.y; kp[j].size = k.size; kp[j].angle = k.angle; kp[j].response = k.response; kp[j].octave = k.octave;
+    }
+    std::vector<uint8_t> occupied((size_t)M, 0);
+    bool anyOccupied = false;
+    for (int j = 0; j < M; ++j)
+      if (CurrentFrame.mvpMapPoints[j] && CurrentFrame.mvpMapPoints[j]->Observations() > 0) { occupied[j] = 1; anyOccupied = true; }
+    std::shared_ptr<pli::Frontend> fe = pli_detail::Registry::get().any();
+    if (!fe) throw std::logic_error("SearchByProjection: no extractor has run yet (no device context)");
+    std::vector<int> best;
+    if (anyOccupied) throw std::logic_error("SearchByProjection(F, F): current keypoints with observed map points are not supported "
+                                            "(TrackWithMotionModel clears mvpMapPoints before the call, Tracking.cc:2717)");
+    const int nmatches = fe->searchByProjection(q, qdesc.data(), kp, CurrentFrame.mDescriptors.data, CurrentFrame.mvuRight.data(),
+                                                CurrentFrame.mnMinX, CurrentFrame.mnMaxX, CurrentFrame.mnMinY, CurrentFrame.mnMaxY,
+                                                mbCheckOrientation, best);
+    for (int i = 0; i < N; ++i)
+      if (best[i] >= 0) {
+        CurrentFrame.mvpMapPoints[best[i]] = LastFrame.mvpMapPoints[i];
+        match12.insert(std::pair<int, int>(best[i], i));
+      }
+    return nmatches;
+  }
+
+ protected:
+  float mfNNratio;
+  bool mbCheckOrientation;
+};
 
 }  // namespace ORB_SLAM3

@@ -4,6 +4,8 @@
 // orbslam_adapters.hpp and forward to these classes.
 #pragma once
 #include <cmath>
+#include <cstdint>
+#include <cstring>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -19,6 +21,19 @@ struct Error : std::runtime_error {
 
 inline void check(pli_status s) {
   if (s != PLI_OK) throw Error(s, pli_last_error());
+}
+
+// ORBmatcher::DescriptorDistance (ORBmatcher.cc:2495-2511) / LineMatcher distance() (LineMatcher.cpp:231-247) for ONE pair of
+// 32-byte descriptors, on the host: the reference's bit-twiddling popcount over 8 x 32 bits gives the same number.
+inline int descriptorDistance(const uint8_t* a, const uint8_t* b) {
+  int d = 0;
+  for (int i = 0; i < 4; ++i) {
+    uint64_t x, y;
+    std::memcpy(&x, a + 8 * i, 8);
+    std::memcpy(&y, b + 8 * i, 8);
+    d += __builtin_popcountll(x ^ y);
+  }
+  return d;
 }
 
 // One context = the four extractors of Tracking (ORB left/right, LSD left/right) plus the stereo matchers,
@@ -81,11 +96,10 @@ class Frontend {
     check(pli_match_lines(ctx_, d1, n1, d2, n2, nnr, m12.data(), &n));
     return n;
   }
-  // ORBmatcher::DescriptorDistance
-  int descriptorDistance(const uint8_t* a, const uint8_t* b) {
-    int32_t d = 0;
-    check(pli_descriptor_distance(ctx_, a, b, 1, &d));
-    return d;
+  // ORBmatcher::DescriptorDistance for n pairs at once (one pair: pli::descriptorDistance on the host)
+  void descriptorDistances(const uint8_t* a, const uint8_t* b, int n, std::vector<int>& dist) {
+    dist.assign(n, 0);
+    if (n) check(pli_descriptor_distance(ctx_, a, b, n, dist.data()));
   }
   // core of ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, ...)
   int searchByProjection(const std::vector<pli_proj_query>& q, const uint8_t* qdesc, const std::vector<pli_keypoint>& cur,

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpli_frontend.so")
+LIB_PATH = os.environ.get("PLI_LIB_PATH") or os.path.join(_HERE, "csrc", "libpli_frontend.so")      # (PLI_LIB_PATH: dev builds, e.g. -DLSD_STATS)
 
 KEYPOINT_DT = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                         ("response", "<f4"), ("octave", "<i4")])

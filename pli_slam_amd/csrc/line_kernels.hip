@@ -247,10 +247,106 @@ __device__ __forceinline__ uint2 lsd_lds_read2(const uint2* p) {
 }
 
 // (the LDS read is unconditional so that it stays a ds_read instead of a flat load)
-__device__ __forceinline__ uint2 lsd_qget(const uint2* qs, const uint2* qg, int k) {
-  uint2 e = lsd_lds_read2(&qs[min(k, LSD_QCAP - 1)]);
-  if (k >= LSD_QCAP) e = qg[k - LSD_QCAP];
+__device__ __forceinline__ uint2 lsd_qget(const uint2* qs, const uint2* qg, int k, int qcap = LSD_QCAP) {
+  uint2 e = lsd_lds_read2(&qs[min(k, qcap - 1)]);
+  if (k >= qcap) e = qg[k - qcap];
   return e;
+}
+
+// region2rect + the end points of the segment (lsd.cpp region2rect / get_theta, refine = NONE): the weighted sums are
+// accumulated in list order by three lanes (bit-exact with the sequential loop), the products 64 at a time.
+__device__ __forceinline__ void lsd_region2rect(const uint2* qs, const uint2* qg, double (*st)[64], int cnt, double reg_angle,
+                                                double prec, double scale, int lane, float* __restrict__ seg, int nseg, int maxSeg,
+                                                int qcap = LSD_QCAP) {
+  // pass 1: x = sum x*w, y = sum y*w, sum = sum w, in list order
+  double acc = 0.0;                                   // lanes 0,1,2 hold x, y, sum
+  for (int c0 = 0; c0 < cnt; c0 += 64) {
+    const int k = c0 + lane;
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0;              // lanes past the end add +0.0 (the sums are never -0.0)
+    if (k < cnt) {
+      const uint2 e = lsd_qget(qs, qg, k, qcap);
+      const double w = sqrt((double)(int)e.y / 4.0);
+      v0 = (double)(int)(e.x & 0xFFFFu) * w;
+      v1 = (double)(int)(e.x >> 16) * w;
+      v2 = w;
+    }
+    st[0][lane] = v0; st[1][lane] = v1; st[2][lane] = v2;
+    lsd_wave_sync();
+    if (lane < 3) {
+      // list-order sum, eight terms per trip: the LDS reads of a trip are issued together, the adds stay in order
+      const int m = (min(64, cnt - c0) + 7) & ~7;
+      for (int t = 0; t < m; t += 8) {
+        double a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = st[lane][t + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += a[u];
+      }
+    }
+    lsd_wave_sync();
+  }
+  // (wave-uniform f64 arithmetic costs a full wave instruction per operation: the two centroid divisions are one
+  // division in lanes 0 and 1, the four end-point divisions below one division in lanes 0..3)
+  const double cq = acc / __shfl(acc, 2, 64);
+  const double x = __shfl(cq, 0, 64), y = __shfl(cq, 1, 64);
+  // pass 2: inertia
+  acc = 0.0;                                          // lanes 0,1,2 hold Ixx, Iyy, Ixy
+  for (int c0 = 0; c0 < cnt; c0 += 64) {
+    const int k = c0 + lane;
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0;              // past the end: acc + 0.0 and acc - 0.0 leave acc as it is
+    if (k < cnt) {
+      const uint2 e = lsd_qget(qs, qg, k, qcap);
+      const double w = sqrt((double)(int)e.y / 4.0);
+      const double dx = (double)(int)(e.x & 0xFFFFu) - x, dy = (double)(int)(e.x >> 16) - y;
+      v0 = dy * dy * w;
+      v1 = dx * dx * w;
+      v2 = dx * dy * w;
+    }
+    st[0][lane] = v0; st[1][lane] = v1; st[2][lane] = v2;
+    lsd_wave_sync();
+    if (lane < 3) {
+      const int m = (min(64, cnt - c0) + 7) & ~7;
+      for (int t = 0; t < m; t += 8) {
+        double a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = st[lane][t + u];
+        if (lane < 2) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc += a[u];
+        } else {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc -= a[u];
+        }
+      }
+    }
+    lsd_wave_sync();
+  }
+  const double Ixx = __shfl(acc, 0, 64), Iyy = __shfl(acc, 1, 64), Ixy = __shfl(acc, 2, 64);
+  const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
+  const bool wide = fabs(Ixx) > fabs(Iyy);
+  double theta = (double)fast_atan2_deg(wide ? (float)(lambda - Ixx) : (float)Ixy, wide ? (float)Ixy : (float)(lambda - Iyy));
+  theta *= D_DEG2RAD;
+  if (lsd_angle_diff(theta, reg_angle) > prec) theta += D_PI;
+  double dxr, dyr;
+  sincos(theta, &dyr, &dxr);
+  // pass 3: extent along the main axis (min/max are order independent)
+  double l_min = 0, l_max = 0;
+  for (int k = lane; k < cnt; k += 64) {
+    const uint2 e = lsd_qget(qs, qg, k, qcap);
+    const double l = ((double)(int)(e.x & 0xFFFFu) - x) * dxr + ((double)(int)(e.x >> 16) - y) * dyr;
+    l_max = fmax(l_max, l);
+    l_min = fmin(l_min, l);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    l_max = fmax(l_max, __shfl_xor(l_max, o, 64));
+    l_min = fmin(l_min, __shfl_xor(l_min, o, 64));
+  }
+  // lanes 0..3: x1, y1, x2, y2
+  double e = ((lane & 1) ? y : x) + ((lane & 2) ? l_max : l_min) * ((lane & 1) ? dyr : dxr);
+  e += 0.5;
+  if (scale != 1) e /= scale;
+  if (nseg < maxSeg && lane < 4) seg[4 * nseg + lane] = (float)e;
 }
 
 // ---------------------------------------------------------------------------
@@ -471,98 +567,434 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
       LSTAT(4, 1);
       LSTAT(2, cnt);
       const unsigned long long tRect = LCLOCK();
-      // ---- region2rect ----------------------------------------------------
-      // pass 1: x = sum x*w, y = sum y*w, sum = sum w, in list order
-      double acc = 0.0;                                   // lanes 0,1,2 hold x, y, sum
-      for (int c0 = 0; c0 < cnt; c0 += 64) {
-        const int k = c0 + lane;
-        double v0 = 0.0, v1 = 0.0, v2 = 0.0;              // lanes past the end add +0.0 (the sums are never -0.0)
-        if (k < cnt) {
-          const uint2 e = lsd_qget(qs, qg, k);
-          const double w = sqrt((double)(int)e.y / 4.0);
-          v0 = (double)(int)(e.x & 0xFFFFu) * w;
-          v1 = (double)(int)(e.x >> 16) * w;
-          v2 = w;
-        }
-        st[0][lane] = v0; st[1][lane] = v1; st[2][lane] = v2;
-        lsd_wave_sync();
-        if (lane < 3) {
-          // list-order sum, eight terms per trip: the LDS reads of a trip are issued together, the adds stay in order
-          const int m = (min(64, cnt - c0) + 7) & ~7;
-          for (int t = 0; t < m; t += 8) {
-            double a[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) a[u] = st[lane][t + u];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc += a[u];
-          }
-        }
-        lsd_wave_sync();
-      }
-      // (wave-uniform f64 arithmetic costs a full wave instruction per operation: the two centroid divisions are one
-      // division in lanes 0 and 1, the four end-point divisions below one division in lanes 0..3)
-      const double cq = acc / __shfl(acc, 2, 64);
-      const double x = __shfl(cq, 0, 64), y = __shfl(cq, 1, 64);
-      // pass 2: inertia
-      acc = 0.0;                                          // lanes 0,1,2 hold Ixx, Iyy, Ixy
-      for (int c0 = 0; c0 < cnt; c0 += 64) {
-        const int k = c0 + lane;
-        double v0 = 0.0, v1 = 0.0, v2 = 0.0;              // past the end: acc + 0.0 and acc - 0.0 leave acc as it is
-        if (k < cnt) {
-          const uint2 e = lsd_qget(qs, qg, k);
-          const double w = sqrt((double)(int)e.y / 4.0);
-          const double dx = (double)(int)(e.x & 0xFFFFu) - x, dy = (double)(int)(e.x >> 16) - y;
-          v0 = dy * dy * w;
-          v1 = dx * dx * w;
-          v2 = dx * dy * w;
-        }
-        st[0][lane] = v0; st[1][lane] = v1; st[2][lane] = v2;
-        lsd_wave_sync();
-        if (lane < 3) {
-          const int m = (min(64, cnt - c0) + 7) & ~7;
-          for (int t = 0; t < m; t += 8) {
-            double a[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) a[u] = st[lane][t + u];
-            if (lane < 2) {
-#pragma unroll
-              for (int u = 0; u < 8; ++u) acc += a[u];
-            } else {
-#pragma unroll
-              for (int u = 0; u < 8; ++u) acc -= a[u];
-            }
-          }
-        }
-        lsd_wave_sync();
-      }
-      const double Ixx = __shfl(acc, 0, 64), Iyy = __shfl(acc, 1, 64), Ixy = __shfl(acc, 2, 64);
-      const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
-      const bool wide = fabs(Ixx) > fabs(Iyy);
-      double theta = (double)fast_atan2_deg(wide ? (float)(lambda - Ixx) : (float)Ixy, wide ? (float)Ixy : (float)(lambda - Iyy));
-      theta *= D_DEG2RAD;
-      if (lsd_angle_diff(theta, reg_angle) > prec) theta += D_PI;
-      double dxr, dyr;
-      sincos(theta, &dyr, &dxr);
-      // pass 3: extent along the main axis (min/max are order independent)
-      double l_min = 0, l_max = 0;
-      for (int k = lane; k < cnt; k += 64) {
-        const uint2 e = lsd_qget(qs, qg, k);
-        const double l = ((double)(int)(e.x & 0xFFFFu) - x) * dxr + ((double)(int)(e.x >> 16) - y) * dyr;
-        l_max = fmax(l_max, l);
-        l_min = fmin(l_min, l);
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        l_max = fmax(l_max, __shfl_xor(l_max, o, 64));
-        l_min = fmin(l_min, __shfl_xor(l_min, o, 64));
-      }
-      // lanes 0..3: x1, y1, x2, y2
-      double e = ((lane & 1) ? y : x) + ((lane & 2) ? l_max : l_min) * ((lane & 1) ? dyr : dxr);
-      e += 0.5;
-      if (scale != 1) e /= scale;
-      if (nseg < maxSeg && lane < 4) seg[4 * nseg + lane] = (float)e;
+      lsd_region2rect(qs, qg, st, cnt, reg_angle, prec, scale, lane, seg, nseg, maxSeg);
       ++nseg;
       LTIME(12, tRect);
+    }
+  }
+  if (lane == 0) nSeg[img] = nseg < maxSeg ? nseg : maxSeg;
+#ifdef LSD_STATS
+  LTIME(8, tKernel);
+  if (lane == 0) for (int i = 0; i < 16; ++i) atomicAdd(&g_lsdStats[i], stt[i]);
+  if (lane == 0) atomicMax(&g_lsdStatsMax, stt[8]);
+#endif
+}
+
+
+// ---------------------------------------------------------------------------
+// Speculative form of the sequential grower (lsd_grow_image_spec).  The sequential loop spends most of its round trips
+// on regions of a few pixels (on the EuRoC-shaped stream 34 000 of the 46 000 regions of an image stay below 9 pixels)
+// that a whole wave grows one after the other.  Here the wave first collects 64 LIVE seeds of the ordered list
+// (a "super-row"), and every lane grows the region of its own seed ALONE, against the committed state only (USED marks
+// of everything before the super-row), up to SPEC_CAP pixels; the pixels a lane takes are tagged with its lane number
+// (spare bits of rec.w, plain stores: where two lanes take the same pixel one tag survives).  Then, in lane = seed order:
+//   * a lane that still owns the tag of every pixel it took is CLEAN: no lower lane's speculative region touches its
+//     pixels.  Its region is final as soon as every lower lane is final, and is committed (USED marks) without any
+//     wave-wide work;
+//   * a lane that hit the cap, or lost a tag, is regrown by the whole wave with the batched steps of the sequential
+//     grower, in its turn (all lower lanes are final then).  Whenever that regrowth accepts a pixel that carries the tag
+//     of a higher clean lane, that lane is no longer clean and will be regrown in its turn as well.
+// A clean lane's speculative run equals its sequential run: the pixels it tested and rejected are rejected again
+// whether or not somebody else has taken them meanwhile, and the pixels it accepted are still unused when its turn
+// comes (nobody lower holds them: it owns their tags, and a regrowth that takes one of them un-cleans the lane).
+// tools/sim/sim_tile_relax.cpp replays this protocol on the CPU ("lane speculation": wrong 0 for every cap).
+// Tags never outlive a super-row: clean lanes' pixels are USED, every other lane clears the tags of its speculative
+// pixels before the next super-row.
+// ---------------------------------------------------------------------------
+constexpr int SPEC_CAP = 8;                 // pixels a lane may take before its region is handed to the whole wave
+constexpr int SPEC_Q = LSD_QCAP - SPEC_CAP * 64;   // wave-wide queue entries left in LDS beside the lanes' lists (2 x SPEC_CAP x 64 ints)
+constexpr unsigned SPEC_G2MASK = 0x7FFFFu;  // g2 <= 2 * 510^2 < 2^19: rec.w bits 19.. hold the tag (lane + 1)
+
+template <int WPB>
+__device__ __forceinline__ void lsd_grow_image_spec(const DevParams* __restrict__ Pp, float4* __restrict__ recAll,
+                                                    const int* __restrict__ orderAll, const int* __restrict__ nDefined,
+                                                    uint2* __restrict__ regOverflow, float* __restrict__ segAll,
+                                                    int* __restrict__ nSeg, int maxSeg, int img0, int nimg) {
+  __shared__ uint2 qsAll[WPB][LSD_QCAP];
+  __shared__ double stAll[WPB][3][64];
+  const DevParams& P = *Pp;
+  const int wv = threadIdx.x >> 6;
+  if ((int)blockIdx.x * WPB + wv >= nimg) return;       // (no block-wide barrier below: the waves are independent)
+  const int img = blockIdx.x * WPB + wv + img0;
+  const int lane = threadIdx.x & 63;
+  uint2* qs = qsAll[wv];
+  double (*st)[64] = stAll[wv];
+  // the lanes' pixel lists [SPEC_CAP][64] (y << 16 | x) and the g2 of those pixels live in the upper half of the queue area
+  // until the super-row is resolved: the wave-wide queue keeps SPEC_Q entries in LDS, longer regions spill to global memory
+  int* sq = reinterpret_cast<int*>(qs + SPEC_Q);
+  int* sq2 = sq + SPEC_CAP * 64;
+  int* stageSp = reinterpret_cast<int*>(&st[0][0]);     // staged seeds of the super-row: pixel, angle, g2 (64 entries each)
+  float* stageA = reinterpret_cast<float*>(stageSp + 64);
+  int* stageG = stageSp + 128;
+  const int W = P.LW, H = P.LH;
+  const int64_t npix = (int64_t)W * H;
+  float4* rec = recAll + img * npix;
+  const int* order = orderAll + img * npix;
+  uint2* qg = regOverflow + img * npix;
+  float* seg = segAll + (int64_t)img * maxSeg * 4;
+  const int nOrder = nDefined[img];
+  const int minReg = P.minRegSize;
+  const double prec = P.prec, scale = P.lsdScale;
+  const float alignLo = P.alignLo, alignHi = P.alignHi;
+  const bool useFilter = P.alignFilter != 0;
+  const unsigned tag = (unsigned)(lane + 1);
+  int cap = min(SPEC_CAP, minReg - 1);                  // a region that may yield a segment is never finished by a lane
+  if (P.alignPad >> 4) cap = min(cap, P.alignPad >> 4);  // (dev switch PLI_LSD_SPEC_CAP)
+  int nseg = 0;
+  int pos = 0;
+  int avgLive = 8;                                      // running estimate of live seeds per row of 64 list entries
+#ifdef LSD_STATS
+  unsigned long long stt[16] = {};
+  const unsigned long long tKernel = LCLOCK();
+#endif
+
+  while (pos < nOrder) {
+    // ---- fill: up to 64 live seeds, in list order ------------------------------------------------------------
+    const unsigned long long tFill = LCLOCK();
+    int nst = 0;
+    bool full = false;
+    while (!full && nst < 64 && pos < nOrder) {
+      const int want = (64 - nst + avgLive - 1) / max(avgLive, 1);
+      const int R = min(8, max(1, want));
+      int sp[8];
+      float4 sr[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = pos + 64 * u + lane;
+        sp[u] = (u < R && idx < nOrder) ? order[idx] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        sr[u] = make_float4(LSD_NOTDEF, 0.f, 0.f, 0.f);
+        if (sp[u] >= 0) sr[u] = rec[sp[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (u >= R || full || pos >= nOrder) continue;
+        const bool live = sr[u].x != LSD_NOTDEF;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(live);
+        const int c = __popcll(bal);
+        if (nst + c > 64) { full = true; continue; }      // this row does not fit: it starts the next super-row
+        if (live) {
+          const int at = nst + __popcll(bal & ((1ull << lane) - 1ull));
+          stageSp[at] = sp[u];
+          stageA[at] = sr[u].x;
+          stageG[at] = (int)((unsigned)__float_as_int(sr[u].w) & SPEC_G2MASK);
+        }
+        nst += c;
+        pos += 64;
+        avgLive = max(1, (3 * avgLive + c + 2) >> 2);
+      }
+    }
+    LTIME(9, tFill);
+    if (nst == 0) continue;
+    LSTAT(0, 1);
+    const unsigned long long tSpec = LCLOCK();
+    lsd_wave_sync();
+    // ---- speculation: lane l < nst grows the region of staged seed l alone -------------------------------------
+    const bool has = lane < nst;
+    const int sp_l = has ? stageSp[lane] : -1;
+    const float sa_l = has ? stageA[lane] : 0.f;
+    const int sg_l = has ? stageG[lane] : 0;
+    lsd_wave_sync();                                     // the staging area is the region2rect scratch: read before anything writes it
+    float scos = 0.f, ssin = 0.f;
+    double ang_l = 0.0;
+    int spx = 0, spy = 0;
+    if (has) {
+      ang_l = (double)sa_l * D_DEG2RAD;
+      double sn, cn;
+      sincos(ang_l, &sn, &cn);
+      scos = (float)cn;
+      ssin = (float)sn;
+      spy = sp_l / W;
+      spx = sp_l - spy * W;
+    }
+    int scnt = has ? 1 : 0;       // pixels of the lane's region (for a lane that hit the cap: up to the last completed step)
+    int tcnt = scnt;              // pixels that carry the lane's tag (scnt + those of an abandoned step)
+    int hk = 0;                   // queue entry the whole wave continues with when it takes the region over
+    float hsx = scos, hsy = ssin; // float sums at that point
+    bool big = false;
+    {
+      float sumdx = scos, sumdy = ssin;
+      double reg_angle = ang_l;
+      int k = 0;
+      bool active = has;
+      if (has) {
+        sq[lane] = (spy << 16) | spx;
+        sq2[lane] = sg_l;
+        rec[sp_l].w = __int_as_float((int)((tag << 19) | (unsigned)sg_l));     // (through the float member: the float4 loads below must alias it)
+      }
+      while (__builtin_amdgcn_ballot_w64(active)) {
+        LSTAT(14, 1);
+        if (active) {
+          const int xy = sq[k * 64 + lane];
+          const int px = xy & 0xFFFF, py = xy >> 16;
+          const int cnt0 = scnt;                         // state at the start of the step: a step that hits the cap is abandoned
+          const float sdx0 = sumdx, sdy0 = sumdy;
+          float4 nr[8];
+#pragma unroll
+          for (int n = 0; n < 8; ++n) {
+            const int m = n < 4 ? n : n + 1;             // skip the centre of the 3x3 block
+            const int nx = px + m % 3 - 1, ny = py + m / 3 - 1;
+            nr[n] = make_float4(LSD_NOTDEF, 0.f, 0.f, 0.f);
+            if (nx >= 0 && ny >= 0 && nx < W && ny < H) nr[n] = rec[ny * W + nx];
+          }
+#pragma unroll
+          for (int n = 0; n < 8; ++n) {
+            if (big || nr[n].x == LSD_NOTDEF) continue;
+            const unsigned wbits = (unsigned)__float_as_int(nr[n].w);
+            if ((wbits >> 19) == tag) continue;          // already in my region
+            double n_theta = fabs(reg_angle - (double)nr[n].x * D_DEG2RAD);
+            if (n_theta > D_3_2_PI) {
+              n_theta = fabs(n_theta - D_2PI);
+            }
+            if (!(n_theta <= prec)) continue;
+            const int m = n < 4 ? n : n + 1;
+            const int nx = px + m % 3 - 1, ny = py + m / 3 - 1;
+            // "already mine" must not depend on the tag alone: another lane may have overwritten it since (that lane and this
+            // one cannot both stay clean, but a pixel taken twice would corrupt this lane's own run)
+            bool mine = false;
+            if (wbits >> 19)                             // (a pixel of this lane always carries SOME tag)
+              for (int i = 0; i < scnt; ++i) mine = mine || sq[i * 64 + lane] == ((ny << 16) | nx);
+            if (mine) continue;
+            if (scnt == cap) { big = true; continue; }
+            sq[scnt * 64 + lane] = (ny << 16) | nx;
+            sq2[scnt * 64 + lane] = (int)(wbits & SPEC_G2MASK);
+            ++scnt;
+            rec[ny * W + nx].w = __int_as_float((int)((tag << 19) | (wbits & SPEC_G2MASK)));
+            sumdx = __fadd_rn(sumdx, nr[n].y);
+            sumdy = __fadd_rn(sumdy, nr[n].z);
+            reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * D_DEG2RAD;
+          }
+          tcnt = scnt;
+          if (big) { hk = k; scnt = cnt0; hsx = sdx0; hsy = sdy0; active = false; }
+          else {
+            ++k;
+            hsx = sumdx; hsy = sumdy;
+            if (k >= scnt) active = false;
+          }
+        }
+      }
+    }
+    auto lin = [&](int xy) -> int { return (xy >> 16) * W + (xy & 0xFFFF); };
+    lsd_wave_sync();
+    LTIME(10, tSpec);
+    const unsigned long long tVal = LCLOCK();
+    // ---- validation: who still owns the tags of its pixels ------------------------------------------------------
+    bool own = has, seedLost = false;                  // own: every pixel of the (prefix of the) region still carries this lane's tag
+    {
+      unsigned tg[SPEC_CAP];
+#pragma unroll
+      for (int i = 0; i < SPEC_CAP; ++i) {
+        tg[i] = tag << 19;
+        if (i < scnt) tg[i] = (unsigned)__float_as_int(const_cast<const volatile float4*>(rec)[lin(sq[i * 64 + lane])].w);
+      }
+#pragma unroll
+      for (int i = 0; i < SPEC_CAP; ++i)
+        if (i < scnt && (tg[i] >> 19) != tag) { own = false; if (i == 0) seedLost = true; }
+    }
+    const bool clean = own && !big;
+    unsigned long long cleanMask = __builtin_amdgcn_ballot_w64(clean);
+    unsigned long long handMask = __builtin_amdgcn_ballot_w64(own && big);   // capped regions whose prefix the wave can take over
+    if (P.alignPad & 1) handMask = 0ull;                 // (dev switch PLI_LSD_SPEC=3: every capped region restarts from its seed)
+    unsigned long long todoMask = __builtin_amdgcn_ballot_w64(has && !clean);
+    if ((P.alignPad & 2) && todoMask) {                  // (dev switch PLI_LSD_SPEC=4: no lane above the first todo lane stays clean)
+      const unsigned long long above = ~((todoMask & (0ull - todoMask)) - 1ull);
+      todoMask |= cleanMask & above;
+      cleanMask &= ~above;
+      handMask = 0ull;
+    }
+    const unsigned long long everTodo0 = todoMask;
+    unsigned long long committed = 0ull, killed = 0ull, everTodo = everTodo0;
+    const unsigned long long seedLostMask = __builtin_amdgcn_ballot_w64(seedLost);
+    auto commit = [&](unsigned long long m) {
+      if ((m >> lane) & 1ull) {
+#pragma unroll
+        for (int i = 0; i < SPEC_CAP; ++i)
+          if (i < scnt) rec[lin(sq[i * 64 + lane])].x = LSD_NOTDEF;
+      }
+    };
+    LTIME(11, tVal);
+    LSTAT(3, __popcll(cleanMask)); LSTAT(5, __popcll(__builtin_amdgcn_ballot_w64(big))); LSTAT(4, __popcll(todoMask) - __popcll(__builtin_amdgcn_ballot_w64(big)));
+    const unsigned long long tRes = LCLOCK();
+    // ---- ordered resolution -----------------------------------------------------------------------------------------
+    while (todoMask) {
+      const int i = __ffsll((long long)todoMask) - 1;
+      todoMask &= todoMask - 1ull;
+      const unsigned long long below = cleanMask & ((1ull << i) - 1ull) & ~committed;
+      if (below) { commit(below); committed |= below; }
+      if ((killed >> i) & 1ull) { LSTAT(6, 1); continue; }
+      const int sp = rl_i(sp_l, i);
+      const bool hand = (handMask >> i) & 1ull;         // the lane's run up to its last completed step is the sequential run
+      // an accepted pixel that carries the tag of a higher lane: that lane is not clean any more; if it is its seed, the lane is dead
+      auto tagged = [&](unsigned tg, int qj) {
+        const int L = (int)(tg >> 19) - 1;
+        if (L > i) {
+          const unsigned long long b = 1ull << L;
+          if (cleanMask & b & ~committed) { cleanMask &= ~b; todoMask |= b; everTodo |= b; }
+          handMask &= ~b;                               // (a capped lane restarts from its seed)
+          if (rl_i(sp_l, L) == qj) killed |= b;
+        }
+      };
+      if (!hand && ((seedLostMask >> i) & 1ull)) {
+        // the tag on this lane's seed belongs to somebody else: look whether the seed is still unused — and if it is, taking it
+        // takes it away from the lane whose tag it carries
+        float sx = LSD_NOTDEF, sw = 0.f;
+        const int fl = __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1;
+        if (lane == fl) { sx = const_cast<const volatile float4*>(rec)[sp].x; sw = const_cast<const volatile float4*>(rec)[sp].w; }
+        sx = rl_f(sx, fl);
+        if (sx == LSD_NOTDEF) continue;
+        const unsigned tw = (unsigned)__float_as_int(rl_f(sw, fl));
+        if (tw >> 19) tagged(tw, sp);
+      }
+      const float sa = rl_f(sa_l, i);
+      float sumdx = hand ? rl_f(hsx, i) : rl_f(scos, i), sumdy = hand ? rl_f(hsy, i) : rl_f(ssin, i);
+      const int sg2 = rl_i(sg_l, i);
+      double reg_angle = (double)sa * D_DEG2RAD;
+      const int ry = rl_i(spy, i), rx = rl_i(spx, i);
+      int cnt = 1, k0 = 0;
+      if (hand) {
+        // take the region over where the lane left it: its pixels become USED, its queue becomes the wave's queue
+        cnt = rl_i(scnt, i);
+        k0 = rl_i(hk, i);
+        if (lane == i) {
+#pragma unroll
+          for (int t = 0; t < SPEC_CAP; ++t)
+            if (t < scnt) { const int e = sq[t * 64 + lane]; rec[lin(e)].x = LSD_NOTDEF; qs[t] = make_uint2((unsigned)e, (unsigned)sq2[t * 64 + lane]); }
+        }
+        lsd_wave_sync();
+      } else {
+        if (lane == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1) rec[sp].x = LSD_NOTDEF;
+        qs[0] = make_uint2(((unsigned)ry << 16) | (unsigned)rx, (unsigned)sg2);
+      }
+      bool angValid = cnt == 1;                          // (after the first accepted pixel the angle is a function of the sums)
+      LSTAT(1, 1); if (hand) LSTAT(2, 1);
+      const int cntStart = cnt;
+      auto step = [&](int k, auto spillTag) {
+        constexpr bool SPILL = decltype(spillTag)::value;
+        const int ndx = lane % 3 - 1, ndy = (lane / 3) % 3 - 1;   // lanes 0..8: raster order of the 3x3 block
+        uint2 e = lsd_lds_read2(&qs[SPILL ? min(k, SPEC_Q - 1) : k]);
+        if (SPILL && k >= SPEC_Q) e = qg[k - SPEC_Q];
+        e.x = __builtin_amdgcn_readfirstlane(e.x);
+        e.y = __builtin_amdgcn_readfirstlane(e.y);
+        const int px = (int)(e.x & 0xFFFFu), py = (int)(e.x >> 16);
+        const int nx = px + ndx, ny = py + ndy;
+        const bool inb = lane < 9 && nx >= 0 && ny >= 0 && nx < W && ny < H;
+        const int qi = ny * W + nx;
+        float4 r = make_float4(LSD_NOTDEF, 0.f, 0.f, 0.f);
+        if (inb) r = rec[qi];
+        const bool cand = r.x != LSD_NOTDEF;
+        const double ad = (double)r.x * D_DEG2RAD;
+        unsigned long long remaining = __builtin_amdgcn_ballot_w64(cand);
+        if (!angValid) {
+          reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * D_DEG2RAD;
+          angValid = true;
+        }
+        while (remaining) {
+          double n_theta = fabs(reg_angle - ad);
+          if (n_theta > D_3_2_PI) {
+            n_theta = fabs(n_theta - D_2PI);
+          }
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(cand && n_theta <= prec) & remaining;
+          if (!m) break;
+          const int j2 = __ffsll((long long)m) - 1;
+          remaining &= ~((2ull << j2) - 1ull);
+          const int qj = rl_i(qi, j2);
+          const float cj = rl_f(r.y, j2), sj = rl_f(r.z, j2);
+          const unsigned wj = (unsigned)__float_as_int(rl_f(r.w, j2));
+          const unsigned xyj = ((unsigned)(py + j2 / 3 - 1) << 16) | (unsigned)(px + j2 % 3 - 1);
+          if (lane == j2) rec[qi].x = LSD_NOTDEF;
+          if (!SPILL || cnt < SPEC_Q) qs[cnt] = make_uint2(xyj, wj & SPEC_G2MASK);           // same value from every active lane
+          else if (lane == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1) qg[cnt - SPEC_Q] = make_uint2(xyj, wj & SPEC_G2MASK);
+          ++cnt;
+          sumdx = __fadd_rn(sumdx, cj);
+          sumdy = __fadd_rn(sumdy, sj);
+          reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * D_DEG2RAD;
+          if (wj >> 19) tagged(wj, qj);
+        }
+        if (SPILL && cnt > SPEC_Q) __threadfence_block();   // overflow entries are read back through global memory
+      };
+      auto batch = [&](int k, int nb) {
+        const int pi = lane >> 3, ni = (lane & 7) < 4 ? (lane & 7) : (lane & 7) + 1;   // 8 neighbours, raster order, centre skipped
+        const bool act = pi < nb;
+        const unsigned ex = lsd_lds_read2(&qs[k + (act ? pi : 0)]).x;
+        const int nx = (int)(ex & 0xFFFFu) + ni % 3 - 1, ny = (int)(ex >> 16) + ni / 3 - 1;
+        const bool inb = act && nx >= 0 && ny >= 0 && nx < W && ny < H;
+        const int qi = inb ? ny * W + nx : -1;
+        float4 r = make_float4(LSD_NOTDEF, 0.f, 0.f, 0.f);
+        if (inb) r = rec[qi];
+        const bool cand = r.x != LSD_NOTDEF;
+        const unsigned myxy = ((unsigned)ny << 16) | (unsigned)nx;
+        const unsigned wbits = (unsigned)__float_as_int(r.w);
+        unsigned long long remaining = __builtin_amdgcn_ballot_w64(cand);
+        while (remaining) {
+          const float n2 = __builtin_fmaf(sumdx, sumdx, sumdy * sumdy);
+          const float dot = __builtin_fmaf(sumdx, r.y, sumdy * r.z);
+          const float sd2 = dot * __builtin_fabsf(dot);
+          unsigned long long mm = __builtin_amdgcn_ballot_w64(sd2 >= alignLo * n2);
+          if (!useFilter) mm = ~0ull;
+          const unsigned long long m = mm & remaining;
+          if (!m) break;
+          const int j2 = __ffsll((long long)m) - 1;
+          remaining &= ~((2ull << j2) - 1ull);
+          unsigned long long sure = __builtin_amdgcn_ballot_w64(sd2 >= alignHi * n2);
+          if (!useFilter) sure = 0ull;
+          if (!((sure >> j2) & 1ull)) {
+            if (!angValid) {
+              reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * D_DEG2RAD;
+              angValid = true;
+            }
+            double n_theta = fabs(reg_angle - (double)rl_f(r.x, j2) * D_DEG2RAD);
+            if (n_theta > D_3_2_PI) {
+              n_theta = fabs(n_theta - D_2PI);
+            }
+            if (!(n_theta <= prec)) continue;
+          }
+          const int qj = rl_i(qi, j2);
+          const float cj = rl_f(r.y, j2), sj = rl_f(r.z, j2);
+          const unsigned wj = (unsigned)rl_i((int)wbits, j2);
+          if (lane == j2) {                            // lane j2 is in the exec mask: it is a set bit of a ballot
+            rec[qi].x = LSD_NOTDEF;
+            qs[cnt] = make_uint2(myxy, wbits & SPEC_G2MASK);
+          }
+          remaining &= ~__builtin_amdgcn_ballot_w64(qi == qj);            // the other copies of the accepted pixel
+          ++cnt;
+          sumdx = __fadd_rn(sumdx, cj);
+          sumdy = __fadd_rn(sumdy, sj);
+          angValid = false;
+          if (wj >> 19) tagged(wj, qj);
+        }
+      };
+      for (int k = k0; k < cnt;) {
+        if (cnt + 65 <= SPEC_Q) {                    // a batch can append up to 8 x 8 entries
+          const int nb = min(8, cnt - k);
+          LSTAT(15, 1);
+          batch(k, nb);
+          k += nb;
+        } else {
+          if (cnt + 9 > SPEC_Q) step(k, std::true_type{});
+          else step(k, std::false_type{});
+          ++k;
+        }
+      }
+      LSTAT(7, cnt - cntStart);
+      if (cnt < minReg) continue;
+      if (!angValid) reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * D_DEG2RAD;
+      const unsigned long long tRect = LCLOCK();
+      lsd_region2rect(qs, qg, st, cnt, reg_angle, prec, scale, lane, seg, nseg, maxSeg, SPEC_Q);
+      LTIME(13, tRect);
+      ++nseg;
+    }
+    LTIME(12, tRes);
+    // ---- the lanes that are still clean are final: commit them; everybody else clears its tags -------------------
+    {
+      const unsigned long long rest = cleanMask & ~committed;
+      if (rest) commit(rest);
+      if ((everTodo >> lane) & 1ull) {
+#pragma unroll
+        for (int i = 0; i < SPEC_CAP; ++i)
+          if (i < tcnt) rec[lin(sq[i * 64 + lane])].w = __int_as_float(sq2[i * 64 + lane]);
+      }
     }
   }
   if (lane == 0) nSeg[img] = nseg < maxSeg ? nseg : maxSeg;
@@ -586,6 +1018,19 @@ __global__ __launch_bounds__(128) void k_lsd_grow2(const DevParams* __restrict__
                                                    uint2* __restrict__ regOverflow, float* __restrict__ segAll,
                                                    int* __restrict__ nSeg, int maxSeg, int img0, int nimg) {
   lsd_grow_image<2>(Pp, recAll, orderAll, nDefined, regOverflow, segAll, nSeg, maxSeg, img0, nimg);
+}
+
+__global__ __launch_bounds__(64, 4) void k_lsd_grow_spec(const DevParams* __restrict__ Pp, float4* __restrict__ recAll,
+                                                      const int* __restrict__ orderAll, const int* __restrict__ nDefined,
+                                                      uint2* __restrict__ regOverflow, float* __restrict__ segAll,
+                                                      int* __restrict__ nSeg, int maxSeg, int img0, int nimg) {
+  lsd_grow_image_spec<1>(Pp, recAll, orderAll, nDefined, regOverflow, segAll, nSeg, maxSeg, img0, nimg);
+}
+__global__ __launch_bounds__(128, 4) void k_lsd_grow2_spec(const DevParams* __restrict__ Pp, float4* __restrict__ recAll,
+                                                        const int* __restrict__ orderAll, const int* __restrict__ nDefined,
+                                                        uint2* __restrict__ regOverflow, float* __restrict__ segAll,
+                                                        int* __restrict__ nSeg, int maxSeg, int img0, int nimg) {
+  lsd_grow_image_spec<2>(Pp, recAll, orderAll, nDefined, regOverflow, segAll, nSeg, maxSeg, img0, nimg);
 }
 
 // ---------------------------------------------------------------------------

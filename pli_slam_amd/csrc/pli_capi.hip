@@ -80,7 +80,8 @@ struct pli_ctx {
   RxCtl* jrCtl = nullptr;
   int2* txList = nullptr; int* txTileCnt = nullptr; int txTs = 64, txNtx = 0, txNty = 0;   // tile-sequential relaxation (lsd_tile.hip)
   std::vector<RxCtl> jrHost;
-  int lsdMode = 0;     // 0 auto, 1 relaxation, 2 sequential (cfg.lsd_mode, or PLI_LSD_MODE)
+  int lsdMode = 0;     // 0 auto, 1 relaxation, 2 sequential, 3 tile-sequential relaxation (cfg.lsd_mode, or PLI_LSD_MODE)
+  bool lsdSpec = !(getenv("PLI_LSD_SPEC") != nullptr && atoi(getenv("PLI_LSD_SPEC")) == 0);  // speculative sequential grower (PLI_LSD_SPEC=0: the plain one)
   int rxLastRounds = 0; // rounds the relaxation ran in the previous call (where the host starts looking at the state)
   unsigned short* chunkHist = nullptr; int* chunkBase = nullptr; int* nDefined = nullptr;
   int* order = nullptr; uint2* regScratch = nullptr; float* seg = nullptr; int* nSeg = nullptr;
@@ -310,7 +311,9 @@ pli_status buildGeometry(pli_ctx* c) {
     const double cl = std::cos(P.prec + margin), ch = std::cos(P.prec - margin);
     P.alignLo = P.alignFilter ? (float)(cl * cl * (1 - 1e-5)) : 0.f;
     P.alignHi = P.alignFilter ? (float)(ch * ch * (1 + 1e-5)) : 0.f;
-    P.alignPad = 0;
+    P.alignPad = 0;                                       // dev switches of the speculative grower
+    if (const char* e = getenv("PLI_LSD_SPEC")) P.alignPad = atoi(e) == 3 ? 1 : atoi(e) == 4 ? 3 : 0;
+    if (const char* e = getenv("PLI_LSD_SPEC_CAP")) P.alignPad |= std::max(0, std::min(8, atoi(e))) << 4;
   }
   {
     const double rho = cfg.lsd_quant / std::sin(P.prec);
@@ -603,8 +606,17 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   LAUNCH(c, "k_lsd_scatter", k_lsd_scatter, dim3((unsigned)(8 * ((nimg + 7) / 8) * c->nChunks)), dim3(64), scatterOccupancyPad, c->g2, npix, P.g2Thresh,
          P.nBins, c->maxG2, c->chunkBase, c->nChunks, c->order, img0, nimg);
   if (sequential) {
-    if (nimg >= 64 && !getenv("PLI_GROW_WPB1"))
+    // speculative form (line_kernels.hip: lsd_grow_image_spec): the small regions of 64 seeds at a time, one per lane
+    const bool spec = c->lsdSpec && P.minRegSize >= 2;
+    const bool two = nimg >= 64 && !getenv("PLI_GROW_WPB1");
+    if (two && spec)
+      LAUNCH(c, "k_lsd_grow2", k_lsd_grow2_spec, dim3((nimg + 1) / 2), dim3(128), 0, c->dP, c->rec, c->order, c->nDefined,
+             c->regScratch, c->seg, c->nSeg, c->maxSeg, img0, nimg);
+    else if (two)
       LAUNCH(c, "k_lsd_grow2", k_lsd_grow2, dim3((nimg + 1) / 2), dim3(128), 0, c->dP, c->rec, c->order, c->nDefined,
+             c->regScratch, c->seg, c->nSeg, c->maxSeg, img0, nimg);
+    else if (spec)
+      LAUNCH(c, "k_lsd_grow", k_lsd_grow_spec, dim3(nimg), dim3(64), 0, c->dP, c->rec, c->order, c->nDefined,
              c->regScratch, c->seg, c->nSeg, c->maxSeg, img0, nimg);
     else
       LAUNCH(c, "k_lsd_grow", k_lsd_grow, dim3(nimg), dim3(64), 0, c->dP, c->rec, c->order, c->nDefined,

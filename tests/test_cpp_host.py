@@ -39,3 +39,75 @@ def test_cpp_host_layer_builds_and_links():
                                "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
         r = subprocess.run([exe], capture_output=True, text=True)
         assert r.returncode == 0, r.stdout + r.stderr
+
+
+ADAPTER_SRC = r'''
+#define PLI_ADAPTER_NO_KEYLINE_HEADER
+#define PLI_ADAPTER_KEYLINE_TYPE StubKeyLine
+#include <opencv2/core/core.hpp>
+struct StubKeyLine {      // cv::line_descriptor::KeyLine, field names as in descriptor_custom.hpp:105-144
+  float angle; int class_id; int octave; cv::Point2f pt; float response; float size;
+  float startPointX, startPointY, endPointX, endPointY, sPointInOctaveX, sPointInOctaveY, ePointInOctaveX, ePointInOctaveY;
+  float lineLength; int numOfPixels;
+};
+#include "pli_slam_amd/adapters/orbslam_adapters.hpp"
+#include <map>
+// the members of Frame / MapPoint that SearchByProjection(CurrentFrame, LastFrame, ...) reads (include/Frame.h, MapPoint.h)
+struct StubMapPoint { cv::Mat GetWorldPos(); cv::Mat GetDescriptor(); int Observations(); };
+struct StubFrame {
+  cv::Mat mTcw, mDescriptors; float mb, mbf, fx, fy, cx, cy, mnMinX, mnMaxX, mnMinY, mnMaxY; int N;
+  std::vector<StubMapPoint*> mvpMapPoints; std::vector<bool> mvbOutlier; std::vector<cv::KeyPoint> mvKeys, mvKeysUn;
+  std::vector<float> mvScaleFactors, mvuRight;
+};
+int use(StubFrame& cur, const StubFrame& last, cv::Mat& im, cv::Mat& mask, std::vector<cv::KeyPoint>& kps, cv::Mat& desc,
+        std::vector<StubKeyLine>& kl, cv::Mat& ldesc) {
+  // the constructor lists of include/ORBextractor.h:53-54 and include/LineExtractor.h:44-46, as Tracking.cc:87-98,743-749 calls them
+  ORB_SLAM3::ORBextractor* l = new ORB_SLAM3::ORBextractor(1200, 1.2f, 8, 20, 7);
+  ORB_SLAM3::ORBextractor* r = new ORB_SLAM3::ORBextractor(1200, 1.2f, 8, 20, 7);
+  ORB_SLAM3::Lineextractor* ll = new ORB_SLAM3::Lineextractor(500, 0.025, 0, 1.2, 0.6, 2.0, 22.5, 1.0, 0.6, 1024, false);
+  ORB_SLAM3::Lineextractor* l2 = new ORB_SLAM3::Lineextractor(500, 0.025);
+  std::vector<int> lap = {0, 0};
+  int n = (*l)(im, mask, kps, desc, lap) + (*r)(im, mask, kps, desc, lap);
+  (*ll)(im, mask, kl, ldesc);
+  (*l2)(im, mask, kl, ldesc);
+  std::vector<int> m12;
+  n += ORB_SLAM3::match(ldesc, ldesc, 0.9f, m12);
+  typedef ORB_SLAM3::PliORBmatcher<StubFrame, StubMapPoint> ORBmatcher;
+  ORBmatcher matcher(0.9f, true);
+  std::map<int, int> match12;
+  n += matcher.SearchByProjection(cur, last, 15.f, false, match12) + matcher.SearchByProjection(cur, last, 7.f, true);
+  n += ORBmatcher::DescriptorDistance(desc, desc) + l->GetLevels() + (int)l->GetScaleFactors().size() + (int)l->mvImagePyramid.size();
+  return n;
+}
+'''
+
+
+def test_orbslam_adapter_header_is_valid_cpp_against_a_stub_cv():
+    """Syntax check only (g++ -fsyntax-only against tests/stubs/opencv2: declarations, no OpenCV): the adapter offers the
+    reference's constructor lists, functors, match(), DescriptorDistance and SearchByProjection signatures.  Pins nothing."""
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "a.cpp")
+        open(src, "w").write(ADAPTER_SRC)
+        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", ROOT, "-I", os.path.join(ROOT, "tests", "stubs"), src],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-4000:]
+
+
+def test_host_descriptor_distance():
+    src = r'''
+#include "pli_slam_amd/adapters/pli_cpp.hpp"
+int main() {
+  uint8_t a[32] = {0}, b[32];
+  for (int i = 0; i < 32; ++i) b[i] = 0xFF;
+  if (pli::descriptorDistance(a, a) != 0 || pli::descriptorDistance(a, b) != 256) return 1;
+  b[5] = 0xFE; a[31] = 0x80;
+  return pli::descriptorDistance(a, b) == 254 ? 0 : 2;
+}
+'''
+    lib = os.path.join(ROOT, "pli_slam_amd", "csrc", "libpli_frontend.so")
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "t.cpp")
+        open(p, "w").write(src)
+        exe = os.path.join(d, "t")
+        subprocess.check_call(["g++", "-std=c++17", "-I", ROOT, p, lib, "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+        assert subprocess.run([exe]).returncode == 0
