@@ -112,10 +112,30 @@ typedef struct pli_frontend_config {
      2 = sequential, one wave per image (line_kernels.hip: k_lsd_grow),
      3 = tile-sequential relaxation, one wave per 64x64 tile (lsd_tile.hip) */
   int32_t lsd_mode;
-  int32_t reserved0;
+  /* Arithmetic the reference leaves to its toolchain (PLI_PARITY_*, below): which libm function an unqualified
+     cos(float) resolves to, and which OpenCV generation's LineSegmentDetector is linked.  Oracle and kernels honour the
+     same flags; DESIGN.md "Oracle" says what is known about each. */
+  int32_t parity_flags;
 } pli_frontend_config;
 
-/* Fill `cfg` with the values of Examples/Stereo/Config/EuRoC.yaml for a w x h image. */
+enum {
+  /* cos/sin of the FLOAT angle in computeOrbDescriptor (ORBextractor.cc:110-111; the file says `using namespace std;`,
+     so the float overload std::cos(float) = cosf is selected): 1 = cosf/sinf as glibc >= 2.28 computes them,
+     0 = correctly rounded ((float)cos((double)x)).  Default 1. */
+  PLI_PARITY_TRIG_F32_ORB = 1,
+  /* the same choice for `cos(float(angle))` in OpenCV's lsd.cpp region_grow (inside namespace cv, no using-directive:
+     the overload depends on whether the C++ <math.h> wrapper is in scope).  Default 0. */
+  PLI_PARITY_TRIG_F32_LSD = 2,
+  /* ... and for `cos(direction)` in BinaryDescriptor::computeLBD (binary_descriptor_custom.cpp:1130).  Default 0. */
+  PLI_PARITY_TRIG_F32_LBD = 4,
+  /* LineSegmentDetector on the CV_64FC1 copy of the image (OpenCV 3.0 .. 3.4: double Gaussian blur, double bilinear
+     resize, double gradient) instead of the CV_8UC1 pipeline of the detector re-added in 4.5.x.  Default 1: the reference
+     pins OpenCV 3.3.1 (README.md:18-20). */
+  PLI_PARITY_LSD_F64 = 8
+};
+
+/* Fill `cfg` with the values of Examples/Stereo/Config/EuRoC.yaml for a w x h image
+ * (parity_flags = PLI_PARITY_TRIG_F32_ORB | PLI_PARITY_LSD_F64). */
 void pli_config_default(pli_frontend_config* cfg, int32_t width, int32_t height);
 
 /* Capacities derived from a config (sizes of the per-eye tables). */

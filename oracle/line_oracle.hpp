@@ -10,9 +10,10 @@
 // PARITY UNPINNED (no reference tests/golden vectors for this path, OpenCV not
 // runnable here).  Choices the reference leaves open, fixed here and mirrored
 // by the HIP kernels:
-//   * LSD works on the CV_8UC1 image (u8 fixed-point 7x7 sigma-0.6 blur and x1.2
-//     bilinear resize, integer 2x2 gradient), as OpenCV's lsd.cpp does once it
-//     asserts image.type()==CV_8UC1.
+//   * LSD input: OpenCV 3.0-3.4 convert the image to CV_64FC1 first (double blur, double
+//     resize, double gradient: LsdParams::input_f64, the default — the reference pins
+//     3.3.1); the detector re-added in 4.5.x works on CV_8UC1 (u8 fixed-point 7x7
+//     sigma-0.6 blur and x1.2 bilinear resize, integer 2x2 gradient): input_f64 = false.
 //   * seeds of equal gradient bin are visited in raster order (OpenCV sorts the
 //     bins with an unstable std::sort; the earlier linked-list version of the
 //     same file visits them in raster order).
@@ -25,7 +26,8 @@
 namespace orc {
 
 struct LsdDebug {
-  Img8 scaled;                       // blurred + resized image
+  Img8 scaled;                       // blurred + resized image (CV_8UC1 pipeline)
+  std::vector<double> scaled64;      // ... (CV_64FC1 pipeline)
   std::vector<float> angleDeg;       // fastAtan2 degrees, -1024 = NOTDEF
   std::vector<int> order;            // pixel index (y*W'+x) of every list entry, visiting order
   std::vector<float> segments;       // x1,y1,x2,y2 per detected segment (Vec4f), detection order
@@ -42,6 +44,8 @@ struct LsdParams {
   int refine = 0;
   double scale = 1.2, sigma_scale = 0.6, quant = 2.0, ang_th = 22.5, log_eps = 1.0, density_th = 0.6;
   int n_bins = 1024;
+  bool input_f64 = true;          // PLI_PARITY_LSD_F64: the CV_64FC1 pipeline of OpenCV 3.x
+  bool trig_f32 = false;          // PLI_PARITY_TRIG_F32_LSD: cos(float(angle)) is cosf
 };
 
 // cv::LineSegmentDetectorImpl::detect -> flsd (refine == LSD_REFINE_NONE).
@@ -49,38 +53,64 @@ static inline void lsdDetect(const Img8& image, const LsdParams& P, LsdDebug& D)
   const double prec = kPI * P.ang_th / 180;
   const double rho = P.quant / std::sin(prec);
   Img8 scaled;
+  Img64 scaled64;
   if (P.scale != 1) {
     const double sigma = (P.scale < 1) ? (P.sigma_scale / P.scale) : (P.sigma_scale);
     const double sprec = 3;
     const unsigned int h = (unsigned int)(std::ceil(sigma * std::sqrt(2 * sprec * std::log(10.0))));
-    Img8 g;
-    gaussianBlur8u(image, g, 1 + 2 * (int)h, sigma);
     int dw = cvRound(image.w * P.scale), dh = cvRound(image.h * P.scale);
-    resizeLinear8u(g, scaled, dw, dh, 1. / P.scale, 1. / P.scale);
+    if (P.input_f64) {
+      Img64 g;
+      gaussianBlur64f(image, g, 1 + 2 * (int)h, sigma);
+      resizeLinear64f(g, scaled64, dw, dh, 1. / P.scale, 1. / P.scale);
+    } else {
+      Img8 g;
+      gaussianBlur8u(image, g, 1 + 2 * (int)h, sigma);
+      resizeLinear8u(g, scaled, dw, dh, 1. / P.scale, 1. / P.scale);
+    }
   } else {
     scaled = image;
+    if (P.input_f64) {
+      scaled64 = Img64(image.w, image.h);
+      for (size_t i = 0; i < image.d.size(); ++i) scaled64.d[i] = (double)image.d[i];
+    }
   }
-  const int W = scaled.w, H = scaled.h;
+  const int W = P.input_f64 ? scaled64.w : scaled.w, H = P.input_f64 ? scaled64.h : scaled.h;
   D.W = W; D.H = H;
   D.scaled = scaled;
+  D.scaled64 = scaled64.d;
   // ll_angle
   std::vector<double> angles((size_t)W * H, kNOTDEF), modgrad((size_t)W * H, 0.0);
   std::vector<float> adeg((size_t)W * H, -1024.f);
   double max_grad = -1;
   for (int y = 0; y < H - 1; ++y) {
-    const uint8_t* r0 = scaled.row(y);
-    const uint8_t* r1 = scaled.row(y + 1);
     for (int x = 0; x < W - 1; ++x) {
-      int DA = r1[x + 1] - r0[x];
-      int BC = r0[x + 1] - r1[x];
-      int gx = DA + BC;
-      int gy = DA - BC;
-      double norm = std::sqrt((gx * gx + gy * gy) / 4.0);
+      double norm;
+      float gxf, gyf;
+      if (P.input_f64) {
+        const double* r0 = scaled64.row(y);
+        const double* r1 = scaled64.row(y + 1);
+        const double DA = r1[x + 1] - r0[x];
+        const double BC = r0[x + 1] - r1[x];
+        const double gx = DA + BC;
+        const double gy = DA - BC;
+        norm = std::sqrt((gx * gx + gy * gy) / 4);
+        gxf = float(gx); gyf = float(-gy);
+      } else {
+        const uint8_t* r0 = scaled.row(y);
+        const uint8_t* r1 = scaled.row(y + 1);
+        int DA = r1[x + 1] - r0[x];
+        int BC = r0[x + 1] - r1[x];
+        int gx = DA + BC;
+        int gy = DA - BC;
+        norm = std::sqrt((gx * gx + gy * gy) / 4.0);
+        gxf = float(gx); gyf = float(-gy);
+      }
       modgrad[(size_t)y * W + x] = norm;
       if (norm <= rho) {
         angles[(size_t)y * W + x] = kNOTDEF;
       } else {
-        float deg = fastAtan2(float(gx), float(-gy));
+        float deg = fastAtan2(gxf, gyf);
         adeg[(size_t)y * W + x] = deg;
         angles[(size_t)y * W + x] = deg * kDEG_TO_RADS;
         if (norm > max_grad) max_grad = norm;
@@ -152,8 +182,8 @@ static inline void lsdDetect(const Img8& image, const LsdParams& P, LsdDebug& D)
             const double angle = angles[q];
             used[q] = 1;
             reg.push_back({xx, yy, modgrad[q]});
-            sumdx += (float)std::cos((double)float(angle));
-            sumdy += (float)std::sin((double)float(angle));
+            sumdx += cosOfFloat(float(angle), P.trig_f32);
+            sumdy += sinOfFloat(float(angle), P.trig_f32);
             reg_angle = fastAtan2(sumdy, sumdx) * kDEG_TO_RADS;
           }
         }
@@ -278,7 +308,7 @@ static const int kLbdCombinations[32][2] = {
 
 // computeLBD for one line, binary_descriptor_custom.cpp:1026-1340 (useDetectionData=false).
 static inline void computeLBDLine(const pli_keyline& kl, const int16_t* pdxImg, const int16_t* pdyImg,
-                                  int imgW, int imgH, const LbdWeights& Wt, float desVec[72]) {
+                                  int imgW, int imgH, const LbdWeights& Wt, float desVec[72], bool trigF32 = false) {
   const int NUM_OF_BANDS = 9, widthOfBand = 7;
   float dL[2], dO[2];
   short heightOfLSP = (short)(widthOfBand * NUM_OF_BANDS);
@@ -292,8 +322,8 @@ static inline void computeLBDLine(const pli_keyline& kl, const int16_t* pdxImg, 
   short halfWidth = (lengthOfLSP - 1) / 2;
   float lineMiddlePointX = (float)(0.5 * (kl.sPointInOctaveX + kl.ePointInOctaveX));
   float lineMiddlePointY = (float)(0.5 * (kl.sPointInOctaveY + kl.ePointInOctaveY));
-  dL[0] = (float)std::cos((double)kl.angle);
-  dL[1] = (float)std::sin((double)kl.angle);
+  dL[0] = cosOfFloat(kl.angle, trigF32);      // cos( pSingleLine->direction ), binary_descriptor_custom.cpp:1130 (PLI_PARITY_TRIG_F32_LBD)
+  dL[1] = sinOfFloat(kl.angle, trigF32);
   dO[0] = -dL[1];
   dO[1] = dL[0];
   float sCorX0 = -dL[0] * halfWidth + dL[1] * halfHeight + lineMiddlePointX;
@@ -414,6 +444,7 @@ struct LineExtractorCfg {
   int lsd_nfeatures = 500;
   double min_line_length = 0.025;
   LsdParams lsd;
+  bool lbd_trig_f32 = false;      // PLI_PARITY_TRIG_F32_LBD
 };
 
 // Lineextractor::operator(), LineExtractor.cc:31-70
@@ -441,7 +472,7 @@ static inline void lineExtract(const Img8& img, const LineExtractorCfg& C, std::
   D.lbdFloat.resize(keylines.size() * 72);
   for (size_t i = 0; i < keylines.size(); ++i) {
     float* des = &D.lbdFloat[i * 72];
-    computeLBDLine(keylines[i], D.dx.data(), D.dy.data(), img.w, img.h, Wt, des);
+    computeLBDLine(keylines[i], D.dx.data(), D.dy.data(), img.w, img.h, Wt, des, C.lbd_trig_f32);
     lbdBinarise(des, &descriptors[i * 32]);
   }
 }

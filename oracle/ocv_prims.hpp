@@ -294,4 +294,157 @@ static inline void remapLinear8u(const Img8& src, const float* mapx, const float
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// CV_64F variants for OpenCV 3.3.x's LineSegmentDetector, which converts its input to CV_64FC1 before anything else
+// (lsd.cpp, LineSegmentDetectorImpl::detect: `Mat_<double> img = _image.getMat(); img.convertTo(image, CV_64FC1);`;
+// the CV_8UC1 form belongs to the detector that was re-added in 4.5.x).  OpenCV-3.3.1-compatible by intent, parity unpinned.
+// ---------------------------------------------------------------------------------------------------------------
+struct Img64 {
+  int w = 0, h = 0;
+  std::vector<double> d;
+  Img64() {}
+  Img64(int w_, int h_) : w(w_), h(h_), d((size_t)w_ * h_) {}
+  double* row(int y) { return d.data() + (size_t)y * w; }
+  const double* row(int y) const { return d.data() + (size_t)y * w; }
+};
+
+// cv::getGaussianKernel(n, sigma, CV_64F) (ktype = max(depth, CV_32F) = CV_64F for a CV_64F image)
+static inline std::vector<double> gaussKernel64(int n, double sigma) {
+  std::vector<double> cd(n);
+  const double scale2X = -0.5 / (sigma * sigma);
+  double sum = 0;
+  for (int i = 0; i < n; ++i) {
+    const double x = i - (n - 1) * 0.5;
+    cd[i] = std::exp(scale2X * x * x);
+    sum += cd[i];
+  }
+  sum = 1. / sum;
+  for (int i = 0; i < n; ++i) cd[i] *= sum;
+  return cd;
+}
+
+// cv::GaussianBlur on CV_64FC1 = sepFilter2D with the filter engine's generic double filters:
+//   RowFilter<double,double>: s = kx[0]*S[0]; s += kx[k]*S[k] for k = 1..n-1 (left to right);
+//   SymmColumnFilter<Cast<double,double>> (symmetric kernel): s = ky[c]*S[c]; s += ky[c+k]*(S[c+k] + S[c-k]) for k = 1..r.
+// BORDER_REFLECT_101.  Input: the u8 image converted to double.
+static inline void gaussianBlur64f(const Img8& src, Img64& dst, int n, double sigma) {
+  const std::vector<double> k = gaussKernel64(n, sigma);
+  const int r = n / 2, w = src.w, h = src.h;
+  Img64 tmp(w, h);
+  for (int y = 0; y < h; ++y) {
+    const uint8_t* S = src.row(y);
+    double* T = tmp.row(y);
+    for (int x = 0; x < w; ++x) {
+      double s = k[0] * (double)S[reflect101(x - r, w)];
+      for (int i = 1; i < n; ++i) s += k[i] * (double)S[reflect101(x - r + i, w)];
+      T[x] = s;
+    }
+  }
+  dst = Img64(w, h);
+  for (int y = 0; y < h; ++y) {
+    double* D = dst.row(y);
+    for (int x = 0; x < w; ++x) {
+      double s = k[r] * tmp.row(y)[x];
+      for (int i = 1; i <= r; ++i) s += k[r + i] * (tmp.row(reflect101(y + i, h))[x] + tmp.row(reflect101(y - i, h))[x]);
+      D[x] = s;
+    }
+  }
+}
+
+// cv::resize INTER_LINEAR on CV_64FC1: HResizeLinear<double,double,float> / VResizeLinear<double,double,float,Cast>: float
+// coefficients (1-f, f), double arithmetic: t = S[sx]*a0 + S[sx+1]*a1, dst = T0*b0 + T1*b1.  Index / weight tables as for
+// the 8-bit path (resizeLinearCoeffs), without the fixed-point conversion.
+static inline void resizeLinear64f(const Img64& src, Img64& dst, int dw, int dh, double scale_x, double scale_y) {
+  dst = Img64(dw, dh);
+  std::vector<int> xofs(dw), yofs(dh);
+  std::vector<float> alpha(2 * (size_t)dw), beta(2 * (size_t)dh);
+  for (int d = 0; d < dw; ++d) {
+    float f = (float)((d + 0.5) * scale_x - 0.5);
+    int s = cvFloor(f);
+    f -= s;
+    if (s < 0) { f = 0; s = 0; }
+    if (s >= src.w - 1) { f = 0; s = src.w - 1; }
+    xofs[d] = s; alpha[2 * d] = 1.f - f; alpha[2 * d + 1] = f;
+  }
+  for (int d = 0; d < dh; ++d) {
+    float f = (float)((d + 0.5) * scale_y - 0.5);
+    int s = cvFloor(f);
+    f -= s;
+    yofs[d] = s; beta[2 * d] = 1.f - f; beta[2 * d + 1] = f;
+  }
+  for (int dy = 0; dy < dh; ++dy) {
+    const double* S0 = src.row(clipi(yofs[dy], 0, src.h));
+    const double* S1 = src.row(clipi(yofs[dy] + 1, 0, src.h));
+    const double b0 = beta[2 * dy], b1 = beta[2 * dy + 1];
+    double* D = dst.row(dy);
+    for (int dx = 0; dx < dw; ++dx) {
+      const int sx = xofs[dx], sx1 = std::min(sx + 1, src.w - 1);
+      const double a0 = alpha[2 * dx], a1 = alpha[2 * dx + 1];
+      const double t0 = S0[sx] * a0 + S0[sx1] * a1;
+      const double t1 = S1[sx] * a0 + S1[sx1] * a1;
+      D[dx] = t0 * b0 + t1 * b1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// cosf / sinf as glibc >= 2.28 computes them (sysdeps/ieee754/flt-32/s_sincosf.h, the ARM optimized-routines algorithm:
+// reduction and a degree-7/8 polynomial in double, one rounding to float) — what `cos(float)` gives where the float
+// overload is selected (e.g. `using namespace std;` in ORBextractor.cc:65 with the float `angle` of :110-111).
+// Checked bit for bit against this image's glibc 2.35 on every third float of [2^-13, 2 pi) by tests/test_oracle_kat.py.
+// Valid for |x| < 120 (the angles here are in [0, 2 pi)).
+// ---------------------------------------------------------------------------------------------------------------
+struct SinCosfTab { double sign[4]; double hpi_inv, hpi, c0, c1, c2, c3, c4, s1, s2, s3; };
+static const SinCosfTab kSinCosf[2] = {
+    {{1.0, -1.0, -1.0, 1.0}, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, 0x1p0, -0x1.ffffffd0c621cp-2, 0x1.55553e1068f19p-5,
+     -0x1.6c087e89a359dp-10, 0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13},
+    {{1.0, -1.0, -1.0, 1.0}, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, -0x1p0, 0x1.ffffffd0c621cp-2, -0x1.55553e1068f19p-5,
+     0x1.6c087e89a359dp-10, -0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13}};
+static inline uint32_t f32bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+static inline uint32_t abstop12(float x) { return (f32bits(x) >> 20) & 0x7ff; }
+static inline float sinfPoly(double x, double x2, const SinCosfTab* p, int n) {
+  if ((n & 1) == 0) {
+    const double x3 = x * x2, s1 = p->s2 + x2 * p->s3, x7 = x3 * x2, s = x + x3 * p->s1;
+    return (float)(s + x7 * s1);
+  }
+  const double x4 = x2 * x2, c2 = p->c3 + x2 * p->c4, c1 = p->c0 + x2 * p->c1, x6 = x4 * x2, c = c1 + x4 * p->c2;
+  return (float)(c + x6 * c2);
+}
+static inline double sincosfReduce(double x, const SinCosfTab* p, int* np) {
+  const double r = x * p->hpi_inv;
+  const int n = ((int32_t)r + 0x800000) >> 24;
+  *np = n;
+  return x - n * p->hpi;
+}
+static inline float glibcSinf(float y) {
+  double x = y;
+  int n;
+  const SinCosfTab* p = &kSinCosf[0];
+  if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
+    if (abstop12(y) < abstop12(0x1p-12f)) return y;
+    return sinfPoly(x, x * x, p, 0);
+  }
+  x = sincosfReduce(x, p, &n);
+  const double s = p->sign[n & 3];
+  if (n & 2) p = &kSinCosf[1];
+  return sinfPoly(x * s, x * x, p, n);
+}
+static inline float glibcCosf(float y) {
+  double x = y;
+  int n;
+  const SinCosfTab* p = &kSinCosf[0];
+  if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
+    if (abstop12(y) < abstop12(0x1p-12f)) return 1.0f;
+    return sinfPoly(x, x * x, p, 1);
+  }
+  x = sincosfReduce(x, p, &n);
+  const double s = p->sign[(n + 1) & 3];
+  if ((n + 1) & 2) p = &kSinCosf[1];
+  return sinfPoly(x * s, x * x, p, n ^ 1);
+}
+// cos / sin of a float as the call site selects them: f32 = the float overload (glibc >= 2.28), else double libm + cast
+static inline float cosOfFloat(float a, bool f32) { return f32 ? glibcCosf(a) : (float)std::cos((double)a); }
+static inline float sinOfFloat(float a, bool f32) { return f32 ? glibcSinf(a) : (float)std::sin((double)a); }
+
 }  // namespace orc

@@ -50,6 +50,9 @@ LineExtractorCfg lineCfg(const pli_frontend_config& c) {
   L.lsd.log_eps = c.lsd_log_eps;
   L.lsd.density_th = c.lsd_density_th;
   L.lsd.n_bins = c.lsd_n_bins;
+  L.lsd.input_f64 = (c.parity_flags & PLI_PARITY_LSD_F64) != 0;
+  L.lsd.trig_f32 = (c.parity_flags & PLI_PARITY_TRIG_F32_LSD) != 0;
+  L.lbd_trig_f32 = (c.parity_flags & PLI_PARITY_TRIG_F32_LBD) != 0;
   return L;
 }
 
@@ -76,6 +79,7 @@ void* orc_frame_create(const pli_frontend_config* cfg) {
   for (int e = 0; e < 2; ++e)
     f->eye[e].orb.reset(new OrbExtractor(cfg->orb_nfeatures, cfg->orb_scale_factor, cfg->orb_nlevels,
                                          cfg->orb_ini_th_fast, cfg->orb_min_th_fast));
+  for (int e = 0; e < 2; ++e) f->eye[e].orb->trigF32 = (cfg->parity_flags & PLI_PARITY_TRIG_F32_ORB) != 0;
   return f;
 }
 void orc_frame_destroy(void* h) { delete (Frame*)h; }
@@ -143,6 +147,11 @@ int orc_get_lsd_dims(void* h, int eye, int* w, int* hgt) {
 int orc_get_lsd_scaled(void* h, int eye, uint8_t* dst) {
   Eye& E = ((Frame*)h)->eye[eye];
   std::memcpy(dst, E.ld.lsd.scaled.d.data(), E.ld.lsd.scaled.d.size());
+  return 0;
+}
+int orc_get_lsd_scaled64(void* h, int eye, double* dst) {
+  Eye& E = ((Frame*)h)->eye[eye];
+  std::memcpy(dst, E.ld.lsd.scaled64.data(), E.ld.lsd.scaled64.size() * 8);
   return 0;
 }
 int orc_get_lsd_angle(void* h, int eye, float* dst) {
@@ -373,10 +382,24 @@ int orc_lbd_weights(float* L21, float* G63) {
   std::memcpy(G63, W.gaussCoefG, sizeof(W.gaussCoefG));
   return 0;
 }
-int orc_orb_descriptor(const uint8_t* img, int w, int h, int x, int y, float angle, uint8_t* desc) {
+int orc_orb_descriptor(const uint8_t* img, int w, int h, int x, int y, float angle, uint8_t* desc, int trigF32) {
   Img8 I = wrap(img, w, h, w);
-  OrbExtractor::computeOrbDescriptor(angle, x, y, I, desc);
+  OrbExtractor::computeOrbDescriptor(angle, x, y, I, desc, trigF32 != 0);
   return 0;
+}
+
+float orc_glibc_cosf(float x) { return glibcCosf(x); }
+float orc_glibc_sinf(float x) { return glibcSinf(x); }
+// dense check of the sincosf restatement against the libm of this machine: returns the number of floats that differ
+long orc_sincosf_selfcheck(uint32_t first, uint32_t last, uint32_t step) {
+  long bad = 0;
+  for (uint64_t b = first; b < last; b += step) {
+    float x;
+    const uint32_t u = (uint32_t)b;
+    std::memcpy(&x, &u, 4);
+    if (cosf(x) != glibcCosf(x) || sinf(x) != glibcSinf(x)) ++bad;
+  }
+  return bad;
 }
 
 }  // extern "C"

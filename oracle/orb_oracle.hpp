@@ -30,6 +30,7 @@ struct OrbLevelDebug {
 };
 
 struct OrbExtractor {
+  bool trigF32 = true;            // PLI_PARITY_TRIG_F32_ORB
   int nfeatures, nlevels, iniThFAST, minThFAST;
   float scaleFactor;
   std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
@@ -120,10 +121,12 @@ struct OrbExtractor {
   }
 
   // computeOrbDescriptor, ORBextractor.cc:106-145
-  static void computeOrbDescriptor(float kpAngle, int px, int py, const Img8& img, uint8_t* desc) {
+  // trigF32: `cos(angle)` with a float argument under `using namespace std;` (ORBextractor.cc:65) is std::cos(float) = cosf
+  // (PLI_PARITY_TRIG_F32_ORB); false = the correctly rounded value
+  static void computeOrbDescriptor(float kpAngle, int px, int py, const Img8& img, uint8_t* desc, bool trigF32) {
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     float angle = (float)kpAngle * factorPI;
-    float a = (float)std::cos((double)angle), b = (float)std::sin((double)angle);
+    float a = cosOfFloat(angle, trigF32), b = sinOfFloat(angle, trigF32);
     const uint8_t* center = img.row(py) + px;
     const int step = img.w;
     const signed char* pattern = kOrbPattern;
@@ -394,7 +397,7 @@ struct OrbExtractor {
       float scale = mvScaleFactor[level];
       for (KP& kp : kps) {
         uint8_t d[32];
-        computeOrbDescriptor(kp.angle, kp.lx, kp.ly, mvBlurred[level], d);
+        computeOrbDescriptor(kp.angle, kp.lx, kp.ly, mvBlurred[level], d, trigF32);
         pli_keypoint o;
         o.x = kp.x; o.y = kp.y;
         if (level != 0) { o.x = kp.x * scale; o.y = kp.y * scale; }

@@ -26,6 +26,9 @@ PROJ_QUERY_DT = np.dtype([("u", "<f4"), ("v", "<f4"), ("radius", "<f4"), ("ur", 
 assert KEYPOINT_DT.itemsize == 24 and KEYLINE_DT.itemsize == 68 and PROJ_QUERY_DT.itemsize == 32
 
 
+PARITY_TRIG_F32_ORB, PARITY_TRIG_F32_LSD, PARITY_TRIG_F32_LBD, PARITY_LSD_F64 = 1, 2, 4, 8
+
+
 class Config(C.Structure):
     """Mirror of pli_frontend_config (include/pli_frontend.h)."""
     _fields_ = [
@@ -41,7 +44,7 @@ class Config(C.Structure):
         ("matching_s_ws", C.c_int32), ("best_lr_matches", C.c_int32),
         ("line_sim_th", C.c_double), ("stereo_overlap_th", C.c_double), ("min_ratio_12_l", C.c_double),
         ("ls_min_disp_ratio", C.c_double), ("min_disp", C.c_double), ("line_horiz_th", C.c_double),
-        ("lsd_mode", C.c_int32), ("reserved0", C.c_int32),
+        ("lsd_mode", C.c_int32), ("parity_flags", C.c_int32),
     ]
 
 
@@ -58,7 +61,7 @@ def default_config(width, height, **over):
     c.matching_s_ws, c.best_lr_matches = 10, 1
     c.line_sim_th, c.stereo_overlap_th, c.min_ratio_12_l = 0.75, 0.75, 0.9
     c.ls_min_disp_ratio, c.min_disp, c.line_horiz_th = 0.7, 1.0, 0.1
-    c.lsd_mode, c.reserved0 = 0, 0
+    c.lsd_mode, c.parity_flags = 0, PARITY_TRIG_F32_ORB | PARITY_LSD_F64
     for k, v in over.items():
         setattr(c, k, v)
     return c
@@ -179,6 +182,13 @@ class Frame:
         w, h = self.lsd_dims(eye)
         out = np.zeros((h, w), np.uint8)
         self.L.orc_get_lsd_scaled(self.h, eye, _p(out))
+        return out
+
+    def lsd_scaled64(self, eye):
+        """The scaled image of the CV_64FC1 pipeline (PARITY_LSD_F64), float64 (h, w)."""
+        w, h = self.lsd_dims(eye)
+        out = np.zeros((h, w), np.float64)
+        self.L.orc_get_lsd_scaled64(self.h, eye, _p(out))
         return out
 
     def lsd_angle(self, eye):
@@ -398,6 +408,22 @@ def ref_grid_query(segs, rows, cols, qx, qy, win):
     return _gridq(ref().ref_grid_query, segs, rows, cols, qx, qy, win)
 
 
+def glibc_cosf(x):
+    L_ = lib(); L_.orc_glibc_cosf.restype = C.c_float; L_.orc_glibc_cosf.argtypes = [C.c_float]
+    return float(L_.orc_glibc_cosf(C.c_float(x)))
+
+
+def glibc_sinf(x):
+    L_ = lib(); L_.orc_glibc_sinf.restype = C.c_float; L_.orc_glibc_sinf.argtypes = [C.c_float]
+    return float(L_.orc_glibc_sinf(C.c_float(x)))
+
+
+def sincosf_selfcheck(first, last, step):
+    """Floats (by bit pattern) in [first, last) on which the sincosf restatement differs from this machine's cosf/sinf."""
+    L_ = lib(); L_.orc_sincosf_selfcheck.restype = C.c_long; L_.orc_sincosf_selfcheck.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+    return int(L_.orc_sincosf_selfcheck(first, last, step))
+
+
 def fast_atan2(y, x):
     return float(lib().orc_fast_atan2(C.c_float(y), C.c_float(x)))
 
@@ -444,8 +470,8 @@ def lbd_weights():
     return L, G
 
 
-def orb_descriptor(img, x, y, angle):
+def orb_descriptor(img, x, y, angle, trig_f32=True):
     img = _u8(img)
     d = np.zeros(32, np.uint8)
-    lib().orc_orb_descriptor(_p(img), img.shape[1], img.shape[0], x, y, C.c_float(angle), _p(d))
+    lib().orc_orb_descriptor(_p(img), img.shape[1], img.shape[0], x, y, C.c_float(angle), _p(d), int(trig_f32))
     return d

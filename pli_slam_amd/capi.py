@@ -27,6 +27,7 @@ PROJ_QUERY_DT = np.dtype([("u", "<f4"), ("v", "<f4"), ("radius", "<f4"), ("ur", 
 PLI_OK = 0
 ERRORS = {-1: "PLI_ERR_INVALID", -2: "PLI_ERR_EMPTY_IMAGE", -3: "PLI_ERR_CAPACITY", -4: "PLI_ERR_HIP",
           -5: "PLI_ERR_NO_DEVICE", -6: "PLI_ERR_STATE"}
+PARITY_TRIG_F32_ORB, PARITY_TRIG_F32_LSD, PARITY_TRIG_F32_LBD, PARITY_LSD_F64 = 1, 2, 4, 8
 RUN_ORB, RUN_LINES, RUN_STEREO_POINTS, RUN_STEREO_LINES, RUN_ALL = 1, 2, 4, 8, 15
 (DBG_PYRAMID_LEVEL, DBG_BLUR_LEVEL, DBG_FAST_CANDIDATES, DBG_LEVEL_KEYPOINTS, DBG_LSD_SCALED, DBG_LSD_ANGLE,
  DBG_LSD_SEGMENTS, DBG_LBD_DXDY, DBG_LSD_ORDER, DBG_LBD_FLOAT, DBG_STEREO_SAD, DBG_LSD_OWNER, DBG_LSD_SIZES) = range(1, 14)
@@ -47,7 +48,7 @@ class Config(C.Structure):
         ("matching_s_ws", C.c_int32), ("best_lr_matches", C.c_int32),
         ("line_sim_th", C.c_double), ("stereo_overlap_th", C.c_double), ("min_ratio_12_l", C.c_double),
         ("ls_min_disp_ratio", C.c_double), ("min_disp", C.c_double), ("line_horiz_th", C.c_double),
-        ("lsd_mode", C.c_int32), ("reserved0", C.c_int32),
+        ("lsd_mode", C.c_int32), ("parity_flags", C.c_int32),
     ]
 
 

@@ -54,6 +54,8 @@ struct DevParams {
   double prec, lsdScale;
   float alignLo, alignHi;     // cos^2(prec + margin), cos^2(prec - margin): bounds of the vector form of the alignment test
   int alignFilter, alignPad;  // 0: prec too wide for the vector form, every test takes the exact path
+  int parityFlags, parityPad; // pli_frontend_config::parity_flags (PLI_PARITY_*)
+  double rho;                 // LSD gradient threshold quant / sin(prec) (the CV_64F pipeline compares the double norm with it)
   int maxLines;
   int lsdNFeatures;
   double minLength;

@@ -67,4 +67,53 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
   return v;
 }
 
+
+// cosf / sinf as glibc >= 2.28 computes them (the algorithm of ARM's optimized routines: reduction and polynomial in
+// double, one rounding to float; tests/test_oracle_kat.py checks the same restatement against the host libm).
+// Used where the reference's unqualified cos(float) selects the float overload (PLI_PARITY_TRIG_F32_*).  |x| < 120.
+struct SinCosfTab { double c0, c1, c2, c3, c4, s1, s2, s3; };
+__device__ __forceinline__ float glibc_sinf_poly(double x, double x2, bool neg, int n) {
+  // table 0 / table 1 of glibc's __sincosf_table differ in the sign of the cosine coefficients
+  const double sg = neg ? -1.0 : 1.0;
+  if ((n & 1) == 0) {
+    const double s1c = -0x1.555545995a603p-3, s2c = 0x1.1107605230bc4p-7, s3c = -0x1.994eb3774cf24p-13;
+    const double x3 = x * x2, s1 = s2c + x2 * s3c, x7 = x3 * x2, s = x + x3 * s1c;
+    return (float)(s + x7 * s1);
+  }
+  const double c0 = sg * 0x1p0, c1c = sg * -0x1.ffffffd0c621cp-2, c2c = sg * 0x1.55553e1068f19p-5, c3c = sg * -0x1.6c087e89a359dp-10,
+               c4c = sg * 0x1.99343027bf8c3p-16;
+  const double x4 = x2 * x2, c2 = c3c + x2 * c4c, c1 = c0 + x2 * c1c, x6 = x4 * x2, c = c1 + x4 * c2c;
+  return (float)(c + x6 * c2);
+}
+__device__ __forceinline__ unsigned glibc_abstop12(float x) { return ((unsigned)__float_as_int(x) >> 20) & 0x7ffu; }
+__device__ __forceinline__ void glibc_sincosf(float y, float* sn, float* cs) {
+  const double x = (double)y;
+  if (glibc_abstop12(y) < glibc_abstop12(0x1.921FB6p-1f)) {
+    if (glibc_abstop12(y) < glibc_abstop12(0x1p-12f)) { *sn = y; *cs = 1.0f; return; }
+    const double x2 = x * x;
+    *sn = glibc_sinf_poly(x, x2, false, 0);
+    *cs = glibc_sinf_poly(x, x2, false, 1);
+    return;
+  }
+  const double r = x * 0x1.45F306DC9C883p+23;
+  const int n = ((int)r + 0x800000) >> 24;
+  const double xr = x - (double)n * 0x1.921FB54442D18p0;
+  const double x2 = xr * xr;
+  // sine: sign[n & 3], table by (n & 2);  cosine: sign[(n + 1) & 3], table by ((n + 1) & 2), polynomial n ^ 1
+  const double ss = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+  const double sc = (((n + 1) & 3) == 1 || ((n + 1) & 3) == 2) ? -1.0 : 1.0;
+  *sn = glibc_sinf_poly(xr * ss, x2, (n & 2) != 0, n);
+  *cs = glibc_sinf_poly(xr * sc, x2, ((n + 1) & 2) != 0, n ^ 1);
+}
+// cos / sin of a float as the call site selects them (see include/pli_frontend.h, PLI_PARITY_TRIG_F32_*)
+__device__ __forceinline__ void sincos_of_float(float a, bool f32, float* sn, float* cs) {
+  if (f32) glibc_sincosf(a, sn, cs);
+  else {
+    double s, c;
+    sincos((double)a, &s, &c);
+    *sn = (float)s;
+    *cs = (float)c;
+  }
+}
+
 }  // namespace pli

@@ -35,7 +35,7 @@ constexpr int LSD_GRAD_ROWS = 16;   // rows per block: one atomicMax per block (
 __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ scaled, int64_t imgStride, int W, int H,
                                                   int pitch, int g2Thresh, float4* __restrict__ rec,
                                                   int* __restrict__ g2o, int2* __restrict__ own,
-                                                  int* __restrict__ maxG2, float* __restrict__ angDbg, int img0) {
+                                                  int* __restrict__ maxG2, float* __restrict__ angDbg, int img0, int trigF32) {
   __shared__ int wmax[4];
   const int img = blockIdx.z + img0;
   const int x = blockIdx.x * 256 + threadIdx.x;
@@ -56,12 +56,8 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ sc
         if (g2 > g2Thresh) {
           m = max(m, g2);
           a = fast_atan2_deg((float)gx, (float)(-gy));
-          double ad = (double)a * D_DEG2RAD;
-          double af = (double)(float)ad;
-          double sn, cn;
-          sincos(af, &sn, &cn);
-          cx = (float)cn;
-          sy = (float)sn;
+          // cos(float(angle)), sin(float(angle)) of lsd.cpp region_grow (PLI_PARITY_TRIG_F32_LSD: which overload)
+          sincos_of_float((float)((double)a * D_DEG2RAD), trigF32 != 0, &sy, &cx);
         }
       }
       const int64_t o = (int64_t)img * W * H + (int64_t)y * W + x;
@@ -89,6 +85,12 @@ __device__ __forceinline__ double lsd_bin_coef(int maxG2, int nBins) {
   double maxGrad = sqrt((double)maxG2 / 4.0);
   return maxG2 > 0 ? (double)(nBins - 1) / maxGrad : 0.0;
 }
+// CV_64F pipeline (lsd_f64.hip): the gradient norm is a double plane, its maximum is kept as the bits of a double
+__device__ __forceinline__ double lsd_bin_coef64(unsigned long long maxBits, int nBins) {
+  const double maxGrad = __longlong_as_double((long long)maxBits);
+  return maxBits ? (double)(nBins - 1) / maxGrad : 0.0;
+}
+__device__ __forceinline__ int lsd_bin64(double norm, double binCoef, int nBins) { return min((int)(norm * binCoef), nBins - 1); }
 
 // LDS traffic of ONE wave is executed in order: a write by some lanes followed by a read by others needs no s_barrier,
 // only the compiler must keep the order
@@ -102,18 +104,31 @@ __device__ __forceinline__ void lsd_wave_sync() {
 // per-chunk histogram of the bins of the defined pixels
 __global__ __launch_bounds__(256) void k_lsd_hist(const int* __restrict__ g2a, int npix, int g2Thresh, int nBins,
                                                   const int* __restrict__ maxG2, unsigned short* __restrict__ chunkHist,
-                                                  int nChunks, int img0) {
+                                                  int nChunks, int img0, const double* __restrict__ mgAll,
+                                                  const unsigned long long* __restrict__ maxMg, double rho) {
   __shared__ int h[1024];
   const int img = blockIdx.y + img0, chunk = blockIdx.x, tid = threadIdx.x;
   for (int i = tid; i < nBins; i += 256) h[i] = 0;
   __syncthreads();
-  const double bc = lsd_bin_coef(maxG2[img], nBins);
-  const int* g = g2a + (int64_t)img * npix;
-  for (int k = 0; k < LSD_CHUNK / 256; ++k) {
-    int i = chunk * LSD_CHUNK + k * 256 + tid;
-    if (i < npix) {
-      int v = g[i];
-      if (v > g2Thresh) atomicAdd(&h[lsd_bin(v, bc)], 1);
+  if (mgAll) {                                          // CV_64F pipeline
+    const double bc = lsd_bin_coef64(maxMg[img], nBins);
+    const double* g = mgAll + (int64_t)img * npix;
+    for (int k = 0; k < LSD_CHUNK / 256; ++k) {
+      int i = chunk * LSD_CHUNK + k * 256 + tid;
+      if (i < npix) {
+        const double v = g[i];
+        if (!(v <= rho)) atomicAdd(&h[lsd_bin64(v, bc, nBins)], 1);
+      }
+    }
+  } else {
+    const double bc = lsd_bin_coef(maxG2[img], nBins);
+    const int* g = g2a + (int64_t)img * npix;
+    for (int k = 0; k < LSD_CHUNK / 256; ++k) {
+      int i = chunk * LSD_CHUNK + k * 256 + tid;
+      if (i < npix) {
+        int v = g[i];
+        if (v > g2Thresh) atomicAdd(&h[lsd_bin(v, bc)], 1);
+      }
     }
   }
   __syncthreads();
@@ -156,7 +171,9 @@ __global__ __launch_bounds__(1024) void k_lsd_scan(const unsigned short* __restr
 // stable scatter: one wave per chunk walks its 1024 pixels in raster order
 __global__ __launch_bounds__(64) void k_lsd_scatter(const int* __restrict__ g2a, int npix, int g2Thresh, int nBins,
                                                     const int* __restrict__ maxG2, const int* __restrict__ chunkBase,
-                                                    int nChunks, int* __restrict__ order, int img0, int nimg) {
+                                                    int nChunks, int* __restrict__ order, int img0, int nimg,
+                                                    const double* __restrict__ mgAll, const unsigned long long* __restrict__ maxMg,
+                                                    double rho) {
   __shared__ int base[1024];
   // XCD-aware order: workgroup L runs on XCD L % 8, so all chunks of an image are dealt to ONE XCD (consecutive slots of
   // that XCD, i.e. close in time): the 4-byte stores of different chunks into the same lines of the ordered list then
@@ -168,25 +185,31 @@ __global__ __launch_bounds__(64) void k_lsd_scatter(const int* __restrict__ g2a,
   const int* cb = chunkBase + ((int64_t)img * nChunks + chunk) * nBins;
   for (int i = lane; i < nBins; i += 64) base[i] = cb[i];
   __syncthreads();
-  const double bc = lsd_bin_coef(maxG2[img], nBins);
+  const bool f64 = mgAll != nullptr;
+  const double bc = f64 ? lsd_bin_coef64(maxMg[img], nBins) : lsd_bin_coef(maxG2[img], nBins);
   const int* g = g2a + (int64_t)img * npix;
+  const double* gd = mgAll + (int64_t)img * npix;
   int* ord = order + (int64_t)img * npix;
   const int nbits = 32 - __clz(max(nBins - 1, 1));
   constexpr int GRP = 16;                        // rows of 64 pixels whose loads are in flight together
   for (int it0 = 0; it0 < LSD_CHUNK / 64; it0 += GRP) {
     if (chunk * LSD_CHUNK + it0 * 64 >= npix) break;
-    int vals[GRP];
+    int vals[GRP];                               // the bin of the pixel, -1 = not defined
 #pragma unroll
     for (int u = 0; u < GRP; ++u) {
       const int i = chunk * LSD_CHUNK + (it0 + u) * 64 + lane;
-      vals[u] = i < npix ? g[i] : 0;             // (g2Thresh >= 0: a zero is never "defined")
+      int b = -1;
+      if (i < npix) {
+        if (f64) { const double v = gd[i]; if (!(v <= rho)) b = lsd_bin64(v, bc, nBins); }
+        else { const int v = g[i]; if (v > g2Thresh) b = lsd_bin(v, bc); }
+      }
+      vals[u] = b;
     }
 #pragma unroll
     for (int u = 0; u < GRP; ++u) {
       const int i = chunk * LSD_CHUNK + (it0 + u) * 64 + lane;
-      const int v = vals[u];
-      const bool def = i < npix && v > g2Thresh;
-      const int bin = def ? lsd_bin(v, bc) : -1;
+      const int bin = vals[u];
+      const bool def = bin >= 0;
       // lanes with the same bin (match-any by bits: one ballot per bin bit instead of one round per distinct bin)
       unsigned long long peers = __builtin_amdgcn_ballot_w64(def);
       if (!peers) continue;
@@ -257,7 +280,11 @@ __device__ __forceinline__ uint2 lsd_qget(const uint2* qs, const uint2* qg, int 
 // accumulated in list order by three lanes (bit-exact with the sequential loop), the products 64 at a time.
 __device__ __forceinline__ void lsd_region2rect(const uint2* qs, const uint2* qg, double (*st)[64], int cnt, double reg_angle,
                                                 double prec, double scale, int lane, float* __restrict__ seg, int nseg, int maxSeg,
-                                                int qcap = LSD_QCAP) {
+                                                int qcap = LSD_QCAP, const double* __restrict__ mg = nullptr, int W = 0) {
+  // weight of a region pixel = its gradient norm: sqrt(g2 / 4) from the queue entry, or (CV_64F pipeline) the double plane
+  auto weight = [&](const uint2 e) -> double {
+    return mg ? mg[(int)(e.x >> 16) * W + (int)(e.x & 0xFFFFu)] : sqrt((double)(int)e.y / 4.0);
+  };
   // pass 1: x = sum x*w, y = sum y*w, sum = sum w, in list order
   double acc = 0.0;                                   // lanes 0,1,2 hold x, y, sum
   for (int c0 = 0; c0 < cnt; c0 += 64) {
@@ -265,7 +292,7 @@ __device__ __forceinline__ void lsd_region2rect(const uint2* qs, const uint2* qg
     double v0 = 0.0, v1 = 0.0, v2 = 0.0;              // lanes past the end add +0.0 (the sums are never -0.0)
     if (k < cnt) {
       const uint2 e = lsd_qget(qs, qg, k, qcap);
-      const double w = sqrt((double)(int)e.y / 4.0);
+      const double w = weight(e);
       v0 = (double)(int)(e.x & 0xFFFFu) * w;
       v1 = (double)(int)(e.x >> 16) * w;
       v2 = w;
@@ -296,7 +323,7 @@ __device__ __forceinline__ void lsd_region2rect(const uint2* qs, const uint2* qg
     double v0 = 0.0, v1 = 0.0, v2 = 0.0;              // past the end: acc + 0.0 and acc - 0.0 leave acc as it is
     if (k < cnt) {
       const uint2 e = lsd_qget(qs, qg, k, qcap);
-      const double w = sqrt((double)(int)e.y / 4.0);
+      const double w = weight(e);
       const double dx = (double)(int)(e.x & 0xFFFFu) - x, dy = (double)(int)(e.x >> 16) - y;
       v0 = dy * dy * w;
       v1 = dx * dx * w;
@@ -364,7 +391,7 @@ __device__ __forceinline__ void lsd_region2rect(const uint2* qs, const uint2* qg
 // Claimed pixels are marked by overwriting rec.x with NOTDEF.
 // ---------------------------------------------------------------------------
 template <int WPB>   // waves (= images) per block
-__device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp, float4* __restrict__ recAll,
+__device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp, float4* __restrict__ recAll, const double* __restrict__ mgAll,
                                                const int* __restrict__ orderAll, const int* __restrict__ nDefined,
                                                uint2* __restrict__ regOverflow, float* __restrict__ segAll,
                                                int* __restrict__ nSeg, int maxSeg, int img0, int nimg) {
@@ -567,7 +594,7 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
       LSTAT(4, 1);
       LSTAT(2, cnt);
       const unsigned long long tRect = LCLOCK();
-      lsd_region2rect(qs, qg, st, cnt, reg_angle, prec, scale, lane, seg, nseg, maxSeg);
+      lsd_region2rect(qs, qg, st, cnt, reg_angle, prec, scale, lane, seg, nseg, maxSeg, LSD_QCAP, mgAll ? mgAll + img * npix : nullptr, W);
       ++nseg;
       LTIME(12, tRect);
     }
@@ -606,7 +633,7 @@ constexpr int SPEC_Q = LSD_QCAP - SPEC_CAP * 64;   // wave-wide queue entries le
 constexpr unsigned SPEC_G2MASK = 0x7FFFFu;  // g2 <= 2 * 510^2 < 2^19: rec.w bits 19.. hold the tag (lane + 1)
 
 template <int WPB>
-__device__ __forceinline__ void lsd_grow_image_spec(const DevParams* __restrict__ Pp, float4* __restrict__ recAll,
+__device__ __forceinline__ void lsd_grow_image_spec(const DevParams* __restrict__ Pp, float4* __restrict__ recAll, const double* __restrict__ mgAll,
                                                     const int* __restrict__ orderAll, const int* __restrict__ nDefined,
                                                     uint2* __restrict__ regOverflow, float* __restrict__ segAll,
                                                     int* __restrict__ nSeg, int maxSeg, int img0, int nimg) {
@@ -981,7 +1008,7 @@ __device__ __forceinline__ void lsd_grow_image_spec(const DevParams* __restrict_
       if (cnt < minReg) continue;
       if (!angValid) reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * D_DEG2RAD;
       const unsigned long long tRect = LCLOCK();
-      lsd_region2rect(qs, qg, st, cnt, reg_angle, prec, scale, lane, seg, nseg, maxSeg, SPEC_Q);
+      lsd_region2rect(qs, qg, st, cnt, reg_angle, prec, scale, lane, seg, nseg, maxSeg, SPEC_Q, mgAll ? mgAll + img * npix : nullptr, W);
       LTIME(13, tRect);
       ++nseg;
     }
@@ -1007,30 +1034,30 @@ __device__ __forceinline__ void lsd_grow_image_spec(const DevParams* __restrict_
 
 // one image per wave; the 2-waves-per-block form keeps the two waves of a block on one CU, which spreads a large
 // batch evenly (2 per SIMD at 1024 frames) however the dispatcher deals the blocks
-__global__ __launch_bounds__(64) void k_lsd_grow(const DevParams* __restrict__ Pp, float4* __restrict__ recAll,
+__global__ __launch_bounds__(64) void k_lsd_grow(const DevParams* __restrict__ Pp, float4* __restrict__ recAll, const double* __restrict__ mgAll,
                                                  const int* __restrict__ orderAll, const int* __restrict__ nDefined,
                                                  uint2* __restrict__ regOverflow, float* __restrict__ segAll,
                                                  int* __restrict__ nSeg, int maxSeg, int img0, int nimg) {
-  lsd_grow_image<1>(Pp, recAll, orderAll, nDefined, regOverflow, segAll, nSeg, maxSeg, img0, nimg);
+  lsd_grow_image<1>(Pp, recAll, mgAll, orderAll, nDefined, regOverflow, segAll, nSeg, maxSeg, img0, nimg);
 }
-__global__ __launch_bounds__(128) void k_lsd_grow2(const DevParams* __restrict__ Pp, float4* __restrict__ recAll,
+__global__ __launch_bounds__(128) void k_lsd_grow2(const DevParams* __restrict__ Pp, float4* __restrict__ recAll, const double* __restrict__ mgAll,
                                                    const int* __restrict__ orderAll, const int* __restrict__ nDefined,
                                                    uint2* __restrict__ regOverflow, float* __restrict__ segAll,
                                                    int* __restrict__ nSeg, int maxSeg, int img0, int nimg) {
-  lsd_grow_image<2>(Pp, recAll, orderAll, nDefined, regOverflow, segAll, nSeg, maxSeg, img0, nimg);
+  lsd_grow_image<2>(Pp, recAll, mgAll, orderAll, nDefined, regOverflow, segAll, nSeg, maxSeg, img0, nimg);
 }
 
-__global__ __launch_bounds__(64, 4) void k_lsd_grow_spec(const DevParams* __restrict__ Pp, float4* __restrict__ recAll,
+__global__ __launch_bounds__(64, 4) void k_lsd_grow_spec(const DevParams* __restrict__ Pp, float4* __restrict__ recAll, const double* __restrict__ mgAll,
                                                       const int* __restrict__ orderAll, const int* __restrict__ nDefined,
                                                       uint2* __restrict__ regOverflow, float* __restrict__ segAll,
                                                       int* __restrict__ nSeg, int maxSeg, int img0, int nimg) {
-  lsd_grow_image_spec<1>(Pp, recAll, orderAll, nDefined, regOverflow, segAll, nSeg, maxSeg, img0, nimg);
+  lsd_grow_image_spec<1>(Pp, recAll, mgAll, orderAll, nDefined, regOverflow, segAll, nSeg, maxSeg, img0, nimg);
 }
-__global__ __launch_bounds__(128, 4) void k_lsd_grow2_spec(const DevParams* __restrict__ Pp, float4* __restrict__ recAll,
+__global__ __launch_bounds__(128, 4) void k_lsd_grow2_spec(const DevParams* __restrict__ Pp, float4* __restrict__ recAll, const double* __restrict__ mgAll,
                                                         const int* __restrict__ orderAll, const int* __restrict__ nDefined,
                                                         uint2* __restrict__ regOverflow, float* __restrict__ segAll,
                                                         int* __restrict__ nSeg, int maxSeg, int img0, int nimg) {
-  lsd_grow_image_spec<2>(Pp, recAll, orderAll, nDefined, regOverflow, segAll, nSeg, maxSeg, img0, nimg);
+  lsd_grow_image_spec<2>(Pp, recAll, mgAll, orderAll, nDefined, regOverflow, segAll, nSeg, maxSeg, img0, nimg);
 }
 
 // ---------------------------------------------------------------------------
@@ -1204,7 +1231,8 @@ __global__ __launch_bounds__(64) void k_lbd(const DevParams* __restrict__ Pp, co
   const short halfWidth = (short)((lengthOfLSP - 1) / 2);
   const float midX = (float)(0.5 * ((double)__fadd_rn(kl.sPointInOctaveX, kl.ePointInOctaveX)));
   const float midY = (float)(0.5 * ((double)__fadd_rn(kl.sPointInOctaveY, kl.ePointInOctaveY)));
-  const float dL0 = (float)cos((double)kl.angle), dL1 = (float)sin((double)kl.angle);
+  float dL0, dL1;                                      // cos( direction ), sin( direction ), binary_descriptor_custom.cpp:1130-1131
+  sincos_of_float(kl.angle, (P.parityFlags & PLI_PARITY_TRIG_F32_LBD) != 0, &dL1, &dL0);
   const float dO0 = -dL1, dO1 = dL0;
   if (lane < heightOfLSP) {
     float sCorX0 = __fadd_rn(__fadd_rn(__fmul_rn(-dL0, (float)halfWidth), __fmul_rn(dL1, (float)halfHeight)), midX);

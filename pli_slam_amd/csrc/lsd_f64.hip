@@ -1,0 +1,115 @@
+// The front of OpenCV 3.x's LineSegmentDetector on the CV_64FC1 copy of the image (PLI_PARITY_LSD_F64, the default: the
+// reference pins OpenCV 3.3.1, whose lsd.cpp starts with `img.convertTo(image, CV_64FC1)`):
+//   k_lsd_blur64    GaussianBlur(image, gaussian_img, ksize, sigma) on doubles — sepFilter2D with the filter engine's
+//                   generic double filters: RowFilter (left to right), SymmColumnFilter (centre, then the +-k pairs)
+//   k_lsd_resize64  resize(gaussian_img, scaled_image, Size(), SCALE, SCALE): INTER_LINEAR on doubles, float coefficients
+//   k_lsd_grad64    ll_angle: 2x2 gradient in double, modgrad (double plane), level-line angle, max gradient
+// (OpenCV-3.3.1-compatible by intent: see DESIGN.md "Oracle" for what is known about each primitive.)
+#include "kernels.hpp"
+#include "device_prims.hpp"
+
+namespace pli {
+
+constexpr float F64_NOTDEF = -1024.f;
+constexpr double F64_DEG2RAD = 3.14159265358979323846 / 180;
+
+// one 64 x 16 output tile per workgroup; u8 tile with halo and the row-filtered doubles staged in LDS
+__global__ __launch_bounds__(256) void k_lsd_blur64(const uint8_t* __restrict__ pyr, int64_t pyrBlock, int W, int H, int pitch,
+                                                    const double* __restrict__ kern, int radius, double* __restrict__ out,
+                                                    int img0) {
+  __shared__ uint8_t tile[22][72];
+  __shared__ double rows[22][64];
+  const int img = blockIdx.z + img0, tid = threadIdx.x;
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 16;
+  const uint8_t* src = pyr + (int64_t)img * pyrBlock;
+  const int r = radius, n = 2 * r + 1;
+  const int tw = 64 + 2 * r, th = 16 + 2 * r;
+  for (int i = tid; i < tw * th; i += 256) {
+    const int ty = i / tw, tx = i - ty * tw;
+    const int sx = reflect101(min(x0 + tx - r, W + r), W), sy = reflect101(min(y0 + ty - r, H + r), H);
+    tile[ty][tx] = src[(int64_t)sy * pitch + sx];
+  }
+  __syncthreads();
+  double k[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) k[i] = i < n ? kern[i] : 0.0;
+  for (int i = tid; i < 64 * th; i += 256) {
+    const int ty = i >> 6, tx = i & 63;
+    double s = k[0] * (double)tile[ty][tx];
+    for (int j = 1; j < n; ++j) s += k[j] * (double)tile[ty][tx + j];
+    rows[ty][tx] = s;
+  }
+  __syncthreads();
+  for (int i = tid; i < 64 * 16; i += 256) {
+    const int ty = i >> 6, tx = i & 63;
+    const int x = x0 + tx, y = y0 + ty;
+    if (x >= W || y >= H) continue;
+    double s = k[r] * rows[ty + r][tx];
+    for (int j = 1; j <= r; ++j) s += k[r + j] * (rows[ty + r + j][tx] + rows[ty + r - j][tx]);
+    out[(int64_t)img * W * H + (int64_t)y * W + x] = s;
+  }
+}
+
+// tab: xofs[dw] | alpha[2*dw] (float bits) | yofs[dh] | beta[2*dh] (float bits)
+__global__ __launch_bounds__(256) void k_lsd_resize64(const double* __restrict__ src, int sw, int sh, double* __restrict__ dst,
+                                                      int dw, int dh, const int* __restrict__ tab, int img0) {
+  const int img = blockIdx.z + img0, dy = blockIdx.y, dx = blockIdx.x * 256 + threadIdx.x;
+  if (dx >= dw) return;
+  const int sx = tab[dx], sx1 = min(sx + 1, sw - 1);
+  const double a0 = (double)__int_as_float(tab[dw + 2 * dx]), a1 = (double)__int_as_float(tab[dw + 2 * dx + 1]);
+  const int sy = tab[3 * dw + dy];
+  const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
+  const double b0 = (double)__int_as_float(tab[3 * dw + dh + 2 * dy]), b1 = (double)__int_as_float(tab[3 * dw + dh + 2 * dy + 1]);
+  const double* S0 = src + (int64_t)img * sw * sh + (int64_t)sy0 * sw;
+  const double* S1 = src + (int64_t)img * sw * sh + (int64_t)sy1 * sw;
+  const double t0 = S0[sx] * a0 + S0[sx1] * a1;
+  const double t1 = S1[sx] * a0 + S1[sx1] * a1;
+  dst[(int64_t)img * dw * dh + (int64_t)dy * dw + dx] = t0 * b0 + t1 * b1;
+}
+
+// rec = { ang, c, s, 0 } (rec.w only carries the speculative grower's tags here), mg = modgrad (double)
+__global__ __launch_bounds__(256) void k_lsd_grad64(const double* __restrict__ scaled, int W, int H, double rho,
+                                                    float4* __restrict__ rec, double* __restrict__ mg, int2* __restrict__ own,
+                                                    unsigned long long* __restrict__ maxMg, float* __restrict__ angDbg, int img0,
+                                                    int trigF32) {
+  __shared__ unsigned long long wmax[4];
+  const int img = blockIdx.z + img0;
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  unsigned long long m = 0ull;                            // bits of the largest norm (non-negative doubles order like their bits)
+  if (x < W) {
+    const int yEnd = min((int)(blockIdx.y + 1) * 16, H);
+    const double* S = scaled + (int64_t)img * W * H;
+    for (int y = blockIdx.y * 16; y < yEnd; ++y) {
+      double norm = 0.0;
+      float a = F64_NOTDEF, cx = 0.f, sy = 0.f;
+      if (x < W - 1 && y < H - 1) {
+        const double* r0 = S + (int64_t)y * W;
+        const double* r1 = r0 + W;
+        const double DA = r1[x + 1] - r0[x];
+        const double BC = r0[x + 1] - r1[x];
+        const double gx = DA + BC, gy = DA - BC;
+        norm = sqrt((gx * gx + gy * gy) / 4);
+        if (!(norm <= rho)) {
+          m = max(m, (unsigned long long)__double_as_longlong(norm));
+          a = fast_atan2_deg((float)gx, (float)(-gy));
+          sincos_of_float((float)((double)a * F64_DEG2RAD), trigF32 != 0, &sy, &cx);
+        }
+      }
+      const int64_t o = (int64_t)img * W * H + (int64_t)y * W + x;
+      rec[o] = make_float4(a, cx, sy, 0.f);
+      mg[o] = norm;
+      if (own) own[o] = make_int2(0x7FFFFFFF, 0x7FFFFFFF);
+      if (angDbg) angDbg[o] = a;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+    if (m) atomicMax(&maxMg[img], m);
+  }
+}
+
+}  // namespace pli

@@ -768,7 +768,7 @@ __global__ __launch_bounds__(64) void k_rx_grow_wave(const DevParams* __restrict
 __global__ __launch_bounds__(64) void k_rx_rect(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
                                                 const float4* __restrict__ recAll, const int* __restrict__ arenaAll,
                                                 int arenaCap, const RxRect* __restrict__ rectAll, int rectCap,
-                                                float4* __restrict__ rgSegAll, int img0) {
+                                                float4* __restrict__ rgSegAll, int img0, const double* __restrict__ mgAll) {
   __shared__ double st[3][64];
   const DevParams& P = *Pp;
   const int img = blockIdx.y + img0;
@@ -778,6 +778,7 @@ __global__ __launch_bounds__(64) void k_rx_rect(const DevParams* __restrict__ Pp
   const int W = P.LW;
   const int64_t npix = (int64_t)W * P.LH;
   const float4* rec = recAll + img * npix;
+  const double* mg = mgAll ? mgAll + img * npix : nullptr;       // CV_64F pipeline: the gradient norm as a double plane
   const int* arena = arenaAll + (int64_t)img * arenaCap;
   const RxRect* rects = rectAll + (int64_t)img * rectCap;
   float4* rgSeg = rgSegAll + img * npix;
@@ -796,7 +797,7 @@ __global__ __launch_bounds__(64) void k_rx_rect(const DevParams* __restrict__ Pp
       if (kk < cnt) {
         const int e = lst[kk];
         const int ex = e & 0xFFFF, ey = e >> 16;
-        const double w = sqrt((double)__float_as_int(rec[ey * W + ex].w) / 4.0);
+        const double w = mg ? mg[ey * W + ex] : sqrt((double)__float_as_int(rec[ey * W + ex].w) / 4.0);
         v0 = (double)ex * w;
         v1 = (double)ey * w;
         v2 = w;
@@ -826,7 +827,7 @@ __global__ __launch_bounds__(64) void k_rx_rect(const DevParams* __restrict__ Pp
       if (kk < cnt) {
         const int e = lst[kk];
         const int ex = e & 0xFFFF, ey = e >> 16;
-        const double w = sqrt((double)__float_as_int(rec[ey * W + ex].w) / 4.0);
+        const double w = mg ? mg[ey * W + ex] : sqrt((double)__float_as_int(rec[ey * W + ex].w) / 4.0);
         const double dx = (double)ex - x, dy = (double)ey - y;
         v0 = dy * dy * w;
         v1 = dx * dx * w;

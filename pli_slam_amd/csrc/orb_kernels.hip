@@ -882,9 +882,8 @@ __global__ __launch_bounds__(64) void k_describe(const DevParams* __restrict__ P
   // steered rBRIEF
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
   const float ang = __fmul_rn(angle, factorPI);
-  double sn, cs;
-  sincos((double)ang, &sn, &cs);
-  const float a = (float)cs, b = (float)sn;
+  float a, b;                                          // a = cos, b = sin (ORBextractor.cc:111)
+  sincos_of_float(ang, (P.parityFlags & PLI_PARITY_TRIG_F32_ORB) != 0, &b, &a);
   const uint8_t* bl = blur + (int64_t)img * P.pyrBlock + G.offset;
   const uint8_t* center = bl + (int64_t)ky * G.pitch + kx;
   unsigned long long words[4];

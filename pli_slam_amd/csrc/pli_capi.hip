@@ -73,6 +73,9 @@ struct pli_ctx {
   int tmpPitch = 0;
   int* lsdTab = nullptr;
   float4* rec = nullptr; int* g2 = nullptr; int* maxG2 = nullptr;
+  // CV_64F pipeline of the LSD front (PLI_PARITY_LSD_F64, lsd_f64.hip)
+  bool lsdF64 = false; double* mg = nullptr; unsigned long long* maxMg = nullptr; double* tmp64 = nullptr; double* kern64 = nullptr;
+  int* lsdTab64 = nullptr; int lsdRadius = 0;
   int2* own = nullptr; RxSeed* smallSeeds = nullptr; RxSeed* bigSeeds = nullptr; int bigCap = 0;
   RxHand* hand = nullptr; int handCap = 0; RxRect* rects = nullptr; int rectCap = 0; int* rankOf = nullptr; int2* rgBox = nullptr; float4* rgSeg = nullptr; uint8_t* rgClean = nullptr;
   int* tileMin = nullptr; int* tileAct = nullptr; int* rgDirty = nullptr; int tilesW = 0, tilesH = 0; int* rxChunkCnt = nullptr; int rxChunks = 0;
@@ -207,6 +210,7 @@ pli_status validate(const pli_frontend_config& c) {
   if (c.lsd_refine != 0) { g_err = "only lsd_refine = 0 (LSD_REFINE_NONE) is on the reference path"; return PLI_ERR_INVALID; }
   if (c.lsd_n_bins < 1 || c.lsd_n_bins > 1024) { g_err = "lsd_n_bins must be in [1,1024]"; return PLI_ERR_INVALID; }
   if (c.max_lines < 1 || c.max_lines > (1 << 20)) { g_err = "max_lines must be in [1,2^20]"; return PLI_ERR_INVALID; }
+  if (c.parity_flags < 0 || c.parity_flags > 15) { g_err = "parity_flags: unknown bits"; return PLI_ERR_INVALID; }
   if (c.lsd_mode < 0 || c.lsd_mode > 3) { g_err = "lsd_mode must be 0, 1, 2 or 3"; return PLI_ERR_INVALID; }
   if (c.lsd_nfeatures < 0 || c.lsd_nfeatures > c.max_lines) { g_err = "lsd_nfeatures must be in [0,max_lines]"; return PLI_ERR_INVALID; }
   if (!(c.lsd_scale > 0) || !(c.lsd_ang_th > 0 && c.lsd_ang_th < 180)) { g_err = "lsd_scale/ang_th invalid"; return PLI_ERR_INVALID; }
@@ -322,6 +326,8 @@ pli_status buildGeometry(pli_ctx* c) {
     P.g2Thresh = g - 1;
   }
   P.nBins = cfg.lsd_n_bins;
+  P.parityFlags = cfg.parity_flags; P.parityPad = 0;
+  P.rho = cfg.lsd_quant / std::sin(P.prec);
   {
     const double p = cfg.lsd_ang_th / 180;
     const double LOG_NT = 5 * (std::log10(double(P.LW)) + std::log10(double(P.LH))) / 2 + std::log10(11.0);
@@ -434,7 +440,53 @@ pli_status allocAll(pli_ctx* c) {
   }
   const size_t npix = (size_t)P.LW * P.LH;
   A(c->rec, npix * NI);
-  A(c->g2, npix * NI);
+  c->lsdF64 = (c->cfg.parity_flags & PLI_PARITY_LSD_F64) != 0;
+  if (c->lsdF64) {
+    A(c->mg, npix * NI);
+    A(c->maxMg, NI);
+    // Gaussian kernel in double (cv::getGaussianKernel(n, sigma, CV_64F)); radius 0 / kernel {1} converts u8 -> double (lsd_scale 1)
+    const double sigma = (c->cfg.lsd_scale < 1) ? (c->cfg.lsd_sigma_scale / c->cfg.lsd_scale) : c->cfg.lsd_sigma_scale;
+    const unsigned h = c->cfg.lsd_scale != 1 ? (unsigned)std::ceil(sigma * std::sqrt(2 * 3.0 * std::log(10.0))) : 0u;
+    if (h > 3) { g_err = "LSD pre-filter radius > 3 not supported"; return PLI_ERR_INVALID; }
+    c->lsdRadius = (int)h;
+    double k[7] = {0, 0, 0, 0, 0, 0, 0};
+    const int n = 1 + 2 * (int)h;
+    if (h == 0) k[0] = 1.0;
+    else {
+      const double scale2X = -0.5 / (sigma * sigma);
+      double sum = 0;
+      for (int i = 0; i < n; ++i) { const double x = i - (n - 1) * 0.5; k[i] = std::exp(scale2X * x * x); sum += k[i]; }
+      sum = 1. / sum;
+      for (int i = 0; i < n; ++i) k[i] *= sum;
+    }
+    A(c->kern64, 7);
+    HIPCHK(hipMemcpy(c->kern64, k, sizeof(k), hipMemcpyHostToDevice));
+    if (c->cfg.lsd_scale != 1) {
+      A(c->tmp64, (size_t)P.W * P.H * NI);
+      // cv::resize coefficient tables for CV_64F (imgwarp.cpp): float weights (1 - f, f), x clamped at the borders, y not
+      std::vector<int> t((size_t)3 * P.LW + 3 * P.LH);
+      const double sc = 1. / c->cfg.lsd_scale;
+      auto fbits = [](float f) { int b; std::memcpy(&b, &f, 4); return b; };
+      for (int d = 0; d < P.LW; ++d) {
+        float f = (float)((d + 0.5) * sc - 0.5);
+        int sidx = cvFloorf(f);
+        f -= sidx;
+        if (sidx < 0) { f = 0; sidx = 0; }
+        if (sidx >= P.W - 1) { f = 0; sidx = P.W - 1; }
+        t[d] = sidx; t[P.LW + 2 * d] = fbits(1.f - f); t[P.LW + 2 * d + 1] = fbits(f);
+      }
+      for (int d = 0; d < P.LH; ++d) {
+        float f = (float)((d + 0.5) * sc - 0.5);
+        int sidx = cvFloorf(f);
+        f -= sidx;
+        t[3 * P.LW + d] = sidx; t[3 * P.LW + P.LH + 2 * d] = fbits(1.f - f); t[3 * P.LW + P.LH + 2 * d + 1] = fbits(f);
+      }
+      A(c->lsdTab64, t.size());
+      HIPCHK(hipMemcpy(c->lsdTab64, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+    }
+  } else {
+    A(c->g2, npix * NI);
+  }
   c->lsdMode = c->cfg.lsd_mode;
   if (const char* e = getenv("PLI_LSD_MODE")) {
     const int m = atoi(e);
@@ -576,50 +628,68 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   const DevParams& P = c->hp;
   const pli_table_layout& Y = c->lay;
   const int npix = P.LW * P.LH;
-  const uint8_t* scaled;
-  int64_t sStride;
-  int sPitch;
-  if (c->cfg.lsd_scale != 1) {
-    LAUNCH(c, "k_blur_lsd", k_blur, dim3(c->l0Tiles, nimg), dim3(256), 0, c->jobLsd, c->pyr, P.pyrBlock, c->tmp8, c->tmp8Stride, img0);
-    dim3 g((P.LW + 255) / 256, (P.LH + 15) / 16, nimg);
-    LAUNCH(c, "k_resize_lsd", k_resize_level, g, dim3(256), 0, c->tmp8, c->tmp8Stride, P.W, P.H, c->tmpPitch, c->lsdScaled,
-           c->lsdStride, P.LW, P.LH, P.lpitch, c->lsdTab, img0);
-    scaled = c->lsdScaled; sStride = c->lsdStride; sPitch = P.lpitch;
-  } else {
-    scaled = c->pyr + P.lv[0].offset; sStride = P.pyrBlock; sPitch = P.lv[0].pitch;
-  }
-  HIPCHK(hipMemsetAsync(c->maxG2 + img0, 0, sizeof(int) * nimg, c->stream));
   const bool sequential = c->lsdMode == 2 || (c->lsdMode == 0 && nimg >= RX_AUTO_IMAGES);
   int2* ownPlane = sequential ? (int2*)nullptr : c->own;
-  {
+  const int trigF32 = (c->cfg.parity_flags & PLI_PARITY_TRIG_F32_LSD) ? 1 : 0;
+  if (c->lsdF64) {
+    // OpenCV 3.x: the detector works on the CV_64FC1 copy of the image (lsd_f64.hip).  The scaled double image lives in
+    // the grower's overflow area (same size, not in use before the growers run).
+    double* scaled64 = reinterpret_cast<double*>(c->regScratch);
+    const dim3 gb((P.W + 63) / 64, (P.H + 15) / 16, nimg);
+    if (c->cfg.lsd_scale != 1) {
+      LAUNCH(c, "k_blur_lsd", k_lsd_blur64, gb, dim3(256), 0, c->pyr + P.lv[0].offset, P.pyrBlock, P.W, P.H, P.lv[0].pitch,
+             c->kern64, c->lsdRadius, c->tmp64, img0);
+      LAUNCH(c, "k_resize_lsd", k_lsd_resize64, dim3((P.LW + 255) / 256, P.LH, nimg), dim3(256), 0, c->tmp64, P.W, P.H, scaled64, P.LW,
+             P.LH, c->lsdTab64, img0);
+    } else {
+      LAUNCH(c, "k_blur_lsd", k_lsd_blur64, gb, dim3(256), 0, c->pyr + P.lv[0].offset, P.pyrBlock, P.W, P.H, P.lv[0].pitch,
+             c->kern64, 0, scaled64, img0);
+    }
+    HIPCHK(hipMemsetAsync(c->maxMg + img0, 0, sizeof(unsigned long long) * nimg, c->stream));
+    LAUNCH(c, "k_lsd_grad", k_lsd_grad64, dim3((P.LW + 255) / 256, (P.LH + 15) / 16, nimg), dim3(256), 0, scaled64, P.LW, P.LH, P.rho,
+           c->rec, c->mg, ownPlane, c->maxMg, c->debug ? c->angDbg : (float*)nullptr, img0, trigF32);
+  } else {
+    const uint8_t* scaled;
+    int64_t sStride;
+    int sPitch;
+    if (c->cfg.lsd_scale != 1) {
+      LAUNCH(c, "k_blur_lsd", k_blur, dim3(c->l0Tiles, nimg), dim3(256), 0, c->jobLsd, c->pyr, P.pyrBlock, c->tmp8, c->tmp8Stride, img0);
+      dim3 g((P.LW + 255) / 256, (P.LH + 15) / 16, nimg);
+      LAUNCH(c, "k_resize_lsd", k_resize_level, g, dim3(256), 0, c->tmp8, c->tmp8Stride, P.W, P.H, c->tmpPitch, c->lsdScaled,
+             c->lsdStride, P.LW, P.LH, P.lpitch, c->lsdTab, img0);
+      scaled = c->lsdScaled; sStride = c->lsdStride; sPitch = P.lpitch;
+    } else {
+      scaled = c->pyr + P.lv[0].offset; sStride = P.pyrBlock; sPitch = P.lv[0].pitch;
+    }
+    HIPCHK(hipMemsetAsync(c->maxG2 + img0, 0, sizeof(int) * nimg, c->stream));
     dim3 g((P.LW + 255) / 256, (P.LH + 15) / 16, nimg);   // 16 = LSD_GRAD_ROWS
     LAUNCH(c, "k_lsd_grad", k_lsd_grad, g, dim3(256), 0, scaled, sStride, P.LW, P.LH, sPitch, P.g2Thresh, c->rec, c->g2, ownPlane,
-           c->maxG2, c->debug ? c->angDbg : (float*)nullptr, img0);
+           c->maxG2, c->debug ? c->angDbg : (float*)nullptr, img0, trigF32);
   }
   LAUNCH(c, "k_lsd_hist", k_lsd_hist, dim3(c->nChunks, nimg), dim3(256), 0, c->g2, npix, P.g2Thresh, P.nBins, c->maxG2,
-         c->chunkHist, c->nChunks, img0);
+         c->chunkHist, c->nChunks, img0, c->mg, c->maxMg, P.rho);
   LAUNCH(c, "k_lsd_scan", k_lsd_scan, dim3(nimg), dim3(1024), 0, c->chunkHist, c->nChunks, P.nBins, c->chunkBase, c->nDefined, img0);
   // 16 KB of unused dynamic LDS per single-wave workgroup caps the scatter at 8 waves per CU: with all chunks of an image on
   // one XCD (see the kernel) that keeps the ordered lists "open" in an XCD's 4 MB L2 to ~2 images, so the 4-byte stores of
   // different chunks merge into whole lines before they are evicted (2048 frames: 21.8 -> 15.3 ms; 32 KB starves the CUs)
   constexpr size_t scatterOccupancyPad = 16384;
   LAUNCH(c, "k_lsd_scatter", k_lsd_scatter, dim3((unsigned)(8 * ((nimg + 7) / 8) * c->nChunks)), dim3(64), scatterOccupancyPad, c->g2, npix, P.g2Thresh,
-         P.nBins, c->maxG2, c->chunkBase, c->nChunks, c->order, img0, nimg);
+         P.nBins, c->maxG2, c->chunkBase, c->nChunks, c->order, img0, nimg, c->mg, c->maxMg, P.rho);
   if (sequential) {
     // speculative form (line_kernels.hip: lsd_grow_image_spec): the small regions of 64 seeds at a time, one per lane
     const bool spec = c->lsdSpec && P.minRegSize >= 2;
     const bool two = nimg >= 64 && !getenv("PLI_GROW_WPB1");
     if (two && spec)
-      LAUNCH(c, "k_lsd_grow2", k_lsd_grow2_spec, dim3((nimg + 1) / 2), dim3(128), 0, c->dP, c->rec, c->order, c->nDefined,
+      LAUNCH(c, "k_lsd_grow2", k_lsd_grow2_spec, dim3((nimg + 1) / 2), dim3(128), 0, c->dP, c->rec, c->mg, c->order, c->nDefined,
              c->regScratch, c->seg, c->nSeg, c->maxSeg, img0, nimg);
     else if (two)
-      LAUNCH(c, "k_lsd_grow2", k_lsd_grow2, dim3((nimg + 1) / 2), dim3(128), 0, c->dP, c->rec, c->order, c->nDefined,
+      LAUNCH(c, "k_lsd_grow2", k_lsd_grow2, dim3((nimg + 1) / 2), dim3(128), 0, c->dP, c->rec, c->mg, c->order, c->nDefined,
              c->regScratch, c->seg, c->nSeg, c->maxSeg, img0, nimg);
     else if (spec)
-      LAUNCH(c, "k_lsd_grow", k_lsd_grow_spec, dim3(nimg), dim3(64), 0, c->dP, c->rec, c->order, c->nDefined,
+      LAUNCH(c, "k_lsd_grow", k_lsd_grow_spec, dim3(nimg), dim3(64), 0, c->dP, c->rec, c->mg, c->order, c->nDefined,
              c->regScratch, c->seg, c->nSeg, c->maxSeg, img0, nimg);
     else
-      LAUNCH(c, "k_lsd_grow", k_lsd_grow, dim3(nimg), dim3(64), 0, c->dP, c->rec, c->order, c->nDefined,
+      LAUNCH(c, "k_lsd_grow", k_lsd_grow, dim3(nimg), dim3(64), 0, c->dP, c->rec, c->mg, c->order, c->nDefined,
              c->regScratch, c->seg, c->nSeg, c->maxSeg, img0, nimg);
   } else {
     const bool trace = getenv("PLI_RX_TRACE") != nullptr;
@@ -699,7 +769,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
               c->arenaCap, c->rects, c->rectCap, img0, t);
         }
         TRL(c, "k_rx_rect", k_rx_rect, dim3(rectBlocks, nimg), dim3(64), 0, c->dP, c->jrCtl, c->rec, c->arena, c->arenaCap, c->rects,
-            c->rectCap, c->rgSeg, img0);
+            c->rectCap, c->rgSeg, img0, c->mg);
         if (trace) {
           HIPCHK(hipMemcpyAsync(c->jrHost.data(), c->jrCtl + img0, sizeof(RxCtl) * nimg, hipMemcpyDeviceToHost, c->stream));
           HIPCHK(hipStreamSynchronize(c->stream));
@@ -739,7 +809,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
         TRL(c, "k_rx_grow_big", k_rx_grow_big, dim3(bigBlocks, nimg), dim3(64), 0, c->dP, c->jrCtl, c->rec, c->own, c->bigSeeds,
             c->bigCap, c->hand, c->handCap, c->lastSize, c->rgBox, c->arena, c->arenaCap, c->rects, c->rectCap, img0, t);
       TRL(c, "k_rx_rect", k_rx_rect, dim3(rectBlocks, nimg), dim3(64), 0, c->dP, c->jrCtl, c->rec, c->arena, c->arenaCap, c->rects,
-          c->rectCap, c->rgSeg, img0);
+          c->rectCap, c->rgSeg, img0, c->mg);
       if (trace) {
         HIPCHK(hipMemcpyAsync(c->jrHost.data(), c->jrCtl + img0, sizeof(RxCtl) * nimg, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -758,7 +828,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     // images that ran out of a capacity (or did not settle) take the sequential grower
     for (int i = 0; i < nimg; ++i) {
       if (c->jrHost[i].overflow || c->jrHost[i].state != 2) {
-        LAUNCH(c, "k_lsd_grow", k_lsd_grow, dim3(1), dim3(64), 0, c->dP, c->rec, c->order, c->nDefined,
+        LAUNCH(c, "k_lsd_grow", k_lsd_grow, dim3(1), dim3(64), 0, c->dP, c->rec, c->mg, c->order, c->nDefined,
                c->regScratch, c->seg, c->nSeg, c->maxSeg, img0 + i, 1);
       }
     }
@@ -835,6 +905,7 @@ void pli_config_default(pli_frontend_config* c, int32_t width, int32_t height) {
   c->line_sim_th = 0.75; c->stereo_overlap_th = 0.75; c->min_ratio_12_l = 0.9;
   c->ls_min_disp_ratio = 0.7; c->min_disp = 1.0; c->line_horiz_th = 0.1;
   c->lsd_mode = 0;
+  c->parity_flags = PLI_PARITY_TRIG_F32_ORB | PLI_PARITY_LSD_F64;
 }
 
 int32_t pli_kp_capacity(const pli_frontend_config* c) {
@@ -1584,6 +1655,11 @@ pli_status pli_debug_fetch(pli_ctx* c, int32_t image, int32_t what, int32_t arg,
       return PLI_OK;
     }
     case PLI_DBG_LSD_SCALED: {
+      if (c->lsdF64) {     // CV_64F pipeline: doubles (the plane lives in the grower's overflow area: fetch before anything overwrites it)
+        if (!need((int64_t)P.LW * P.LH * 8)) return dst ? PLI_ERR_CAPACITY : PLI_OK;
+        HIPCHK(hipMemcpy(dst, reinterpret_cast<double*>(c->regScratch) + (int64_t)image * P.LW * P.LH, (size_t)P.LW * P.LH * 8, hipMemcpyDeviceToHost));
+        return PLI_OK;
+      }
       if (!need((int64_t)P.LW * P.LH)) return dst ? PLI_ERR_CAPACITY : PLI_OK;
       if (c->cfg.lsd_scale != 1)
         HIPCHK(hipMemcpy2D(dst, P.LW, c->lsdScaled + (int64_t)image * c->lsdStride, P.lpitch, P.LW, P.LH, hipMemcpyDeviceToHost));

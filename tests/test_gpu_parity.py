@@ -96,7 +96,10 @@ def test_config2_line_stages(cfg2):
     for eye, img in ((0, L), (1, R)):
         n, kl, ld = fe.line_extract(eye, img)
         on, okl, old = fr.line_extract(eye, img)
-        assert np.array_equal(fe.debug_fetch(eye, capi.DBG_LSD_SCALED), fr.lsd_scaled(eye).ravel())
+        if cfg.parity_flags & capi.PARITY_LSD_F64:         # OpenCV 3.x: the scaled image is a CV_64FC1 plane
+            assert np.array_equal(fe.debug_fetch(eye, capi.DBG_LSD_SCALED).view(np.float64), fr.lsd_scaled64(eye).ravel())
+        else:
+            assert np.array_equal(fe.debug_fetch(eye, capi.DBG_LSD_SCALED), fr.lsd_scaled(eye).ravel())
         oang = fr.lsd_angle(eye).ravel()
         assert np.array_equal(fe.debug_fetch(eye, capi.DBG_LSD_ANGLE).view(np.float32), oang)
         raw = fe.debug_fetch(eye, capi.DBG_LSD_ORDER).view(np.int32)
@@ -149,11 +152,13 @@ def test_batch_equals_per_call_and_oracle(cfg2):
     assert kl.tobytes() == recs[1]["klR"].tobytes() and np.array_equal(ld, recs[1]["ldescR"])
 
 
-def test_golden_vectors_small(gpu):
+@pytest.mark.parametrize("name,flags", [("oracle_small.npz", 0), ("oracle_small_default.npz", 9), ("oracle_small_all.npz", 15)])
+def test_golden_vectors_small(gpu, name, flags):
+    """The committed fixtures (one per set of parity flags; oracle_small.npz is round 1's file, flags 0)."""
     g = gpu
-    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_small.npz"))
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", name))
     L, R = gold["left"], gold["right"]
-    cfg = g.capi.default_config(L.shape[1], L.shape[0], orb_nfeatures=300, lsd_nfeatures=40)
+    cfg = g.capi.default_config(L.shape[1], L.shape[0], orb_nfeatures=300, lsd_nfeatures=40, parity_flags=flags)
     rec = g.Frontend(cfg).batch_run_host(np.stack([L, R])[None])[0]
     for s in ("L", "R"):
         assert rec["kp" + s].tobytes() == gold["kp" + s].tobytes() and np.array_equal(rec["desc" + s], gold["d" + s])
@@ -796,3 +801,40 @@ def test_batch_track_config3(gpu):
         assert tr["counts"][2] == len(last["ldescL"]) and tr["counts"][3] == ln and np.array_equal(tr["lines"], lm), "frame %d lines" % f
         assert on > 50 and ln > 10
     assert seen == {"neutral", "forward", "backward"}, seen
+
+
+@pytest.mark.parametrize("flags", [0, 1, 2, 4, 8, 6, 15])
+def test_parity_flags_every_variant(gpu, flags):
+    """The arithmetic the reference leaves to its toolchain (PLI_PARITY_*: cosf vs correctly rounded cos per call site, CV_8UC1 vs
+    CV_64FC1 LineSegmentDetector): oracle and kernels take the same flags and agree bit for bit in every variant, in all three
+    LSD schedules; the scaled image / angle map are compared stage by stage for the LSD pipelines."""
+    g = gpu
+    W, H = 376, 240
+    L, R = g.synth.make_stereo_pair(21, W, H)
+    for mode in (2, 3, 1):
+        cfg = g.capi.default_config(W, H, orb_nfeatures=500, lsd_nfeatures=0, max_frames=1, lsd_mode=mode, parity_flags=flags)
+        fe = g.Frontend(cfg)
+        fe.debug_enable(True)
+        rec = fe.batch_run_host(np.stack([L, R])[None])[0]
+        fr = g.po.Frame(ocfg(g, cfg))
+        assert_frame_equal(g, rec, fr, L, R, "flags %d mode %d" % (flags, mode))
+        if mode == 2:
+            n, kl, ld = fe.line_extract(0, L)
+            if flags & g.capi.PARITY_LSD_F64:
+                assert np.array_equal(fe.debug_fetch(0, g.capi.DBG_LSD_SCALED).view(np.float64), fr.lsd_scaled64(0).ravel())
+            else:
+                assert np.array_equal(fe.debug_fetch(0, g.capi.DBG_LSD_SCALED), fr.lsd_scaled(0).ravel())
+            assert np.array_equal(fe.debug_fetch(0, g.capi.DBG_LSD_ANGLE).view(np.float32), fr.lsd_angle(0).ravel())
+    assert len(rec["klL"]) > 100 and len(rec["kpL"]) > 300
+
+
+def test_parity_flags_change_results(gpu):
+    """The switches are not no-ops: the two LSD pipelines give different segments on the same image."""
+    g = gpu
+    W, H = 376, 240
+    L, R = g.synth.make_stereo_pair(21, W, H)
+    out = {}
+    for flags in (0, 8):
+        cfg = g.capi.default_config(W, H, orb_nfeatures=300, lsd_nfeatures=0, max_frames=1, parity_flags=flags)
+        out[flags] = g.Frontend(cfg).batch_run_host(np.stack([L, R])[None])[0]["klL"]
+    assert out[0].tobytes() != out[8].tobytes()

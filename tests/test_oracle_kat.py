@@ -330,3 +330,35 @@ def test_bow_vocabulary_descent_and_vector(oracle):
     words, vals = v.bow_vector(f, levelsup=1)
     assert words.tolist() == [0, 2, 3]                                    # the stopped word does not appear
     assert vals.tolist() == [4.0 / 17.0, 3.0 / 17.0, 10.0 / 17.0]
+
+
+def test_sincosf_restatement_equals_this_machines_libm(oracle):
+    """PLI_PARITY_TRIG_F32_*: the restated cosf / sinf (glibc >= 2.28 algorithm) against the libm of this machine, bit for bit, on
+    every 5th float of [2^-13, 2 pi) — the range of the angles on the path — and on a few hand values."""
+    import ctypes
+    ver = ctypes.CDLL("libc.so.6").gnu_get_libc_version
+    ver.restype = ctypes.c_char_p
+    major, minor = (int(v) for v in ver().decode().split(".")[:2])
+    if (major, minor) < (2, 28):
+        import pytest
+        pytest.skip("glibc %d.%d has the older cosf" % (major, minor))
+    assert oracle.sincosf_selfcheck(0x39000000, 0x40C90FDB, 5) == 0
+    assert oracle.glibc_cosf(0.0) == 1.0 and oracle.glibc_sinf(0.0) == 0.0
+    assert abs(oracle.glibc_cosf(1.0) - 0.5403023) < 1e-7 and abs(oracle.glibc_sinf(2.5) - 0.5984721) < 1e-7
+
+
+def test_lsd_f64_pipeline_primitives(oracle):
+    """CV_64F Gaussian blur of a constant image is the constant (kernel sums to 1 within rounding); bilinear resize of a linear
+    ramp stays linear in the interior with slope 1 / scale."""
+    W, H = 40, 30
+    cfg = oracle.default_config(W, H, parity_flags=oracle.PARITY_LSD_F64, lsd_nfeatures=0)
+    f = oracle.Frame(cfg)
+    flat = np.full((H, W), 77, np.uint8)
+    f.line_extract(0, flat)
+    s = f.lsd_scaled64(0)
+    assert s.shape == (36, 48) and np.abs(s - 77.0).max() < 1e-9
+    ramp = np.tile((np.arange(W) * 5).astype(np.uint8), (H, 1))
+    f.line_extract(0, ramp)
+    s = f.lsd_scaled64(0)
+    d = np.diff(s[10, 8:40])
+    assert np.abs(d - d.mean()).max() < 1e-2 and abs(d.mean() - 5 / 1.2) < 1e-6

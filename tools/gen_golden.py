@@ -50,14 +50,18 @@ else:
 
 W, H = 240, 160
 L, R = synth.make_stereo_pair(11, W, H)
-cfg = po.default_config(W, H, orb_nfeatures=300, lsd_nfeatures=40)
-f = po.Frame(cfg)
-nL, kpL, dL = f.orb_extract(0, L)
-nR, kpR, dR = f.orb_extract(1, R)
-mL, klL, ldL = f.line_extract(0, L)
-mR, klR, ldR = f.line_extract(1, R)
-ur, dp, bi, sad = f.stereo_points()
-disp, le, lm = f.stereo_lines()
-np.savez_compressed(os.path.join(out, "oracle_small.npz"), left=L, right=R, kpL=kpL, dL=dL, kpR=kpR, dR=dR, klL=klL, ldL=ldL,
-                    klR=klR, ldR=ldR, uright=ur, depth=dp, disp=disp, le=le, segL=f.lsd_segments(0))
-print("oracle_small.npz: %d/%d kp, %d/%d lines, %d stereo pts" % (nL, nR, mL, mR, int((ur >= 0).sum())))
+# one fixture per set of parity flags (include/pli_frontend.h PLI_PARITY_*): 0 = the CV_8UC1 LSD pipeline with correctly
+# rounded cos/sin everywhere (round 1's oracle), default = OpenCV 3.x's CV_64FC1 LSD + cosf in computeOrbDescriptor, 15 = all
+for name, flags in (("oracle_small.npz", 0), ("oracle_small_default.npz", po.PARITY_TRIG_F32_ORB | po.PARITY_LSD_F64),
+                    ("oracle_small_all.npz", 15)):
+    cfg = po.default_config(W, H, orb_nfeatures=300, lsd_nfeatures=40, parity_flags=flags)
+    f = po.Frame(cfg)
+    nL, kpL, dL = f.orb_extract(0, L)
+    nR, kpR, dR = f.orb_extract(1, R)
+    mL, klL, ldL = f.line_extract(0, L)
+    mR, klR, ldR = f.line_extract(1, R)
+    ur, dp, bi, sad = f.stereo_points()
+    disp, le, lm = f.stereo_lines()
+    np.savez_compressed(os.path.join(out, name), left=L, right=R, kpL=kpL, dL=dL, kpR=kpR, dR=dR, klL=klL, ldL=ldL,
+                        klR=klR, ldR=ldR, uright=ur, depth=dp, disp=disp, le=le, segL=f.lsd_segments(0), parity_flags=np.int32(flags))
+    print("%s: %d/%d kp, %d/%d lines, %d stereo pts" % (name, nL, nR, mL, mR, int((ur >= 0).sum())))
