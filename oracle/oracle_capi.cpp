@@ -388,6 +388,18 @@ int orc_orb_descriptor(const uint8_t* img, int w, int h, int x, int y, float ang
   return 0;
 }
 
+// cv::FAST(img, kps, th, true) on a whole image (the extractor calls it per cell, ORBextractor.cc:803-815): x, y, response triples
+int orc_fast_image(const uint8_t* img, int w, int h, int th, float* out, int cap) {
+  Img8 I = wrap(img, w, h, w);
+  std::vector<OrbCand> c;
+  OrbExtractor::fastCell(I, 0, 0, w, h, th, th, c);
+  int n = 0;
+  for (const OrbCand& k : c) {
+    if (n < cap) { out[3 * n] = (float)k.x; out[3 * n + 1] = (float)k.y; out[3 * n + 2] = (float)k.score; }
+    ++n;
+  }
+  return n;
+}
 float orc_glibc_cosf(float x) { return glibcCosf(x); }
 float orc_glibc_sinf(float x) { return glibcSinf(x); }
 // dense check of the sincosf restatement against the libm of this machine: returns the number of floats that differ

@@ -408,6 +408,15 @@ def ref_grid_query(segs, rows, cols, qx, qy, win):
     return _gridq(ref().ref_grid_query, segs, rows, cols, qx, qy, win)
 
 
+def fast_image(img, th):
+    """cv::FAST(img, kps, th, nonmaxSuppression=true) on the whole image: (n, 3) float32 x, y, response, raster order."""
+    img = _u8(img)
+    cap = img.size // 4
+    out = np.zeros((cap, 3), np.float32)
+    n = lib().orc_fast_image(_p(img), img.shape[1], img.shape[0], int(th), _p(out), cap)
+    return out[:n].copy()
+
+
 def glibc_cosf(x):
     L_ = lib(); L_.orc_glibc_cosf.restype = C.c_float; L_.orc_glibc_cosf.argtypes = [C.c_float]
     return float(L_.orc_glibc_cosf(C.c_float(x)))

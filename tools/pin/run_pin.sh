@@ -1,0 +1,12 @@
+#!/bin/sh
+# One command to pin the oracle against a real OpenCV (3.3.1 is what the reference names):  tools/pin/run_pin.sh [opencv prefix]
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"; ROOT="$(cd "$HERE/../.." && pwd)"
+OUT="$ROOT/tests/golden/opencv_pin"; IN="$OUT/inputs"
+mkdir -p "$OUT"
+python3 "$HERE/dump_inputs.py" "$IN"
+if [ -n "$1" ]; then export PKG_CONFIG_PATH="$1/lib/pkgconfig:$PKG_CONFIG_PATH"; fi
+PC=opencv; pkg-config --exists opencv4 2>/dev/null && PC=opencv4
+g++ -std=c++11 -O2 "$HERE/pin_against_opencv.cpp" -o "$OUT/pin_against_opencv" $(pkg-config --cflags --libs $PC)
+"$OUT/pin_against_opencv" "$IN" "$OUT"
+python3 "$HERE/pin_compare.py" "$OUT"
