@@ -345,6 +345,42 @@ pli_status pli_set_rectify_maps(pli_ctx* ctx, int32_t eye, const float* mapx, co
 pli_status pli_stereo_from_depth(pli_ctx* ctx, const float* depth, int64_t stride_floats, float* uright, float* depth_out,
                                  int32_t cap);
 
+/* --- SURVEY.md §8(f) row 4 (fisheye stereo front-end, Frame.cc:1484-1576) ---
+ * ORBextractor::operator()(image, mask, keypoints, descriptors, vLappingArea) with a real lapping area
+ * (ORBextractor.cc:1135-1144; Frame::ExtractORB passes mpCamera->mvLappingArea, Frame.cc:488,490): keypoints whose
+ * level-0 x lies in [lap0, lap1] fill the table from the back in visiting order, all others from the front.
+ * *n = keypoints, *n_mono = the reference's return value (index of the first lapping-area keypoint = monoLeft /
+ * monoRight, Frame.cc:1521-1522).  The device table of that eye keeps this order for pli_stereo_fisheye. */
+pli_status pli_orb_extract_lapping(pli_ctx* ctx, int32_t eye,
+                                   const uint8_t* img, int32_t w, int32_t h, int64_t stride,
+                                   int32_t lap0, int32_t lap1,
+                                   pli_keypoint* kp, int32_t cap, uint8_t* desc /* cap x 32 */,
+                                   int32_t* n, int32_t* n_mono);
+
+/* KannalaBrandt8::mvParameters (include/CameraModels/KannalaBrandt8.h): fx, fy, cx, cy, k0..k3. */
+typedef struct pli_kb8_camera { float fx, fy, cx, cy, k0, k1, k2, k3; } pli_kb8_camera;
+
+/* Frame::ComputeStereoFishEyeMatches() Frame.cc:1577-1618 on the tables left on the device by the last
+ * pli_orb_extract_lapping(eye 0) / (eye 1): BFMatcher(NORM_HAMMING).knnMatch(k = 2) of the lapping-area descriptors,
+ * Lowe ratio 0.7, KannalaBrandt8::TriangulateMatches (src/CameraModels/KannalaBrandt8.cpp:334-402: parallax
+ * cos <= 0.9998, SVD triangulation, positive depth in both cameras, reprojection error <= 5.991 mvLevelSigma2[octave]
+ * in both), depth > 0.0001.  Rlr: 3x3 row major (mRlr), tlr: 3 (mtlr) = mTlr of Frame.cc:1539-1540.
+ * l2r: mvLeftToRightMatch (Nleft ints, -1 = none), r2l: mvRightToLeftMatch (Nright), depth: mvDepth (Nleft, -1),
+ * p3d: mvStereo3Dpoints (Nleft x 3 floats, camera-1 coordinates, zeros where unset); *nmatches = nMatches. */
+pli_status pli_stereo_fisheye(pli_ctx* ctx, const pli_kb8_camera* cam1, const pli_kb8_camera* cam2,
+                              const float* Rlr, const float* tlr,
+                              int32_t* l2r, int32_t cap_left, int32_t* r2l, int32_t cap_right,
+                              float* depth, float* p3d, int32_t* nmatches);
+
+/* The same on caller tables: kp_left / desc_left = mvKeys / mDescriptors (Nleft rows, lapping-area keypoints from row
+ * mono_left on), kp_right / desc_right = mvKeysRight / mDescriptorsRight; octaves index the context's mvLevelSigma2. */
+pli_status pli_stereo_fisheye_tables(pli_ctx* ctx, const pli_keypoint* kp_left, const uint8_t* desc_left, int32_t nleft,
+                                     int32_t mono_left, const pli_keypoint* kp_right, const uint8_t* desc_right,
+                                     int32_t nright, int32_t mono_right,
+                                     const pli_kb8_camera* cam1, const pli_kb8_camera* cam2,
+                                     const float* Rlr, const float* tlr,
+                                     int32_t* l2r, int32_t* r2l, float* depth, float* p3d, int32_t* nmatches);
+
 /* --- local-map tracking (Tracking::SearchLocalPointsAndLines, Tracking.cc:3854,3882) --- */
 
 /* Core of ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, th, ...)

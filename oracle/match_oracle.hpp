@@ -689,4 +689,212 @@ static inline void trackQueries(const pli_keypoint* lastKp, const float* lastDep
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// SURVEY §8(f) row 4, fisheye stereo: Frame::ComputeStereoFishEyeMatches (Frame.cc:1577-1618) with
+// KannalaBrandt8::unproject / project / TriangulateMatches / Triangulate (src/CameraModels/KannalaBrandt8.cpp:28-42,
+// 103-130, 334-402, 422-435), and the lapping-area ordering of ORBextractor::operator() (ORBextractor.cc:1135-1144).
+// Third-party arithmetic restated (OpenCV 3.3.1, parity unpinned like everything OpenCV-backed):
+//   * cv::Mat products (CV_32F gemm): double accumulation, one rounding (as trackQueries above);
+//   * Mat::dot / cv::norm(NORM_L2): sequential double accumulation;
+//   * a*row - row (MatExpr -> addWeighted, float work type); Mat / scalar = convertTo with the float factor (float)(1/s);
+//   * cv::SVD::compute(A 4x4 CV_32F, MODIFY_A | FULL_UV): one-sided Jacobi of lapack.cpp (JacobiSVDImpl_<float>, eps =
+//     2*FLT_EPSILON, at most 30 sweeps, rotations in float, norms/dot products in double, rows sorted by singular value),
+//     with hypot(p, beta) taken as sqrt(p*p + beta*beta) in double;
+//   * libm: tan / atan2 / cos / sin of a float are evaluated in double and rounded (std::tan(float), atan2f of glibc are
+//     not correctly rounded; the difference is at most the last bit of the float result).
+// ---------------------------------------------------------------------------------------------------------------
+struct Kb8Camera { float fx, fy, cx, cy, k0, k1, k2, k3; };
+static constexpr double CV_PI_D = 3.1415926535897932384626433832795;   // CV_PI
+
+static inline void kb8Unproject(const Kb8Camera& c, float u, float v, float r[3]) {
+  const float pwx = (u - c.cx) / c.fx, pwy = (v - c.cy) / c.fy;
+  float scale = 1.f;
+  float theta_d = sqrtf(pwx * pwx + pwy * pwy);
+  theta_d = fminf(fmaxf((float)(-CV_PI_D / 2.0), theta_d), (float)(CV_PI_D / 2.0));
+  if ((double)theta_d > 1e-8) {
+    float theta = theta_d;
+    for (int j = 0; j < 10; j++) {
+      float theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta4 * theta4;
+      float k0_theta2 = c.k0 * theta2, k1_theta4 = c.k1 * theta4;
+      float k2_theta6 = c.k2 * theta6, k3_theta8 = c.k3 * theta8;
+      float theta_fix = (theta * (1 + k0_theta2 + k1_theta4 + k2_theta6 + k3_theta8) - theta_d) /
+                        (1 + 3 * k0_theta2 + 5 * k1_theta4 + 7 * k2_theta6 + 9 * k3_theta8);
+      theta = theta - theta_fix;
+      if (fabsf(theta_fix) < 1e-6f) break;          // KannalaBrandt8::precision
+    }
+    scale = (float)tan((double)theta) / theta_d;
+  }
+  r[0] = pwx * scale; r[1] = pwy * scale; r[2] = 1.f;
+}
+
+static inline void kb8Project(const Kb8Camera& c, const float p[3], float& u, float& v) {
+  const float x2_plus_y2 = p[0] * p[0] + p[1] * p[1];
+  const float theta = (float)atan2((double)sqrtf(x2_plus_y2), (double)p[2]);
+  const float psi = (float)atan2((double)p[1], (double)p[0]);
+  const float theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2,
+              theta9 = theta7 * theta2;
+  const float r = theta + c.k0 * theta3 + c.k1 * theta5 + c.k2 * theta7 + c.k3 * theta9;
+  u = (float)((double)(c.fx * r) * cos((double)psi) + (double)c.cx);
+  v = (float)((double)(c.fy * r) * sin((double)psi) + (double)c.cy);
+}
+
+// cv::SVD::compute on a 4x4 CV_32F matrix: the last row of vt.  At = A transposed (row i of At = column i of A).
+static inline void jacobiSvdLastVt4(float At[4][4], float out[4]) {
+  const int n = 4, m = 4;
+  double W[4];
+  float Vt[4][4];
+  const float eps = FLT_EPSILON * 2;
+  for (int i = 0; i < n; i++) {
+    double sd = 0;
+    for (int k = 0; k < m; k++) { const float t = At[i][k]; sd += (double)t * t; }
+    W[i] = sd;
+    for (int k = 0; k < n; k++) Vt[i][k] = 0;
+    Vt[i][i] = 1;
+  }
+  for (int iter = 0; iter < 30; iter++) {
+    bool changed = false;
+    for (int i = 0; i < n - 1; i++)
+      for (int j = i + 1; j < n; j++) {
+        float *Ai = At[i], *Aj = At[j];
+        double a = W[i], p = 0, b = W[j];
+        for (int k = 0; k < m; k++) p += (double)Ai[k] * Aj[k];
+        if (fabs(p) <= (double)eps * sqrt(a * b)) continue;
+        p *= 2;
+        const double beta = a - b, gamma = sqrt(p * p + beta * beta);
+        float c, s;
+        if (beta < 0) {
+          const double delta = (gamma - beta) * 0.5;
+          s = (float)sqrt(delta / gamma);
+          c = (float)(p / (gamma * s * 2));
+        } else {
+          c = (float)sqrt((gamma + beta) / (gamma * 2));
+          s = (float)(p / (gamma * c * 2));
+        }
+        a = b = 0;
+        for (int k = 0; k < m; k++) {
+          const float t0 = c * Ai[k] + s * Aj[k];
+          const float t1 = -s * Ai[k] + c * Aj[k];
+          Ai[k] = t0; Aj[k] = t1;
+          a += (double)t0 * t0; b += (double)t1 * t1;
+        }
+        W[i] = a; W[j] = b;
+        changed = true;
+        float *Vi = Vt[i], *Vj = Vt[j];
+        for (int k = 0; k < n; k++) {
+          const float t0 = c * Vi[k] + s * Vj[k];
+          const float t1 = -s * Vi[k] + c * Vj[k];
+          Vi[k] = t0; Vj[k] = t1;
+        }
+      }
+    if (!changed) break;
+  }
+  for (int i = 0; i < n; i++) {
+    double sd = 0;
+    for (int k = 0; k < m; k++) { const float t = At[i][k]; sd += (double)t * t; }
+    W[i] = sqrt(sd);
+  }
+  for (int i = 0; i < n - 1; i++) {
+    int j = i;
+    for (int k = i + 1; k < n; k++)
+      if (W[j] < W[k]) j = k;
+    if (i != j) {
+      std::swap(W[i], W[j]);
+      for (int k = 0; k < m; k++) std::swap(At[i][k], At[j][k]);
+      for (int k = 0; k < n; k++) std::swap(Vt[i][k], Vt[j][k]);
+    }
+  }
+  for (int k = 0; k < 4; k++) out[k] = Vt[3][k];
+}
+
+// KannalaBrandt8::TriangulateMatches: depth in the first camera (or -1), p3D filled on success.  R12: 3x3 row major.
+static inline float kb8TriangulateMatches(const Kb8Camera& c1, const Kb8Camera& c2, const pli_keypoint& kp1, const pli_keypoint& kp2,
+                                          const float* R12, const float* t12, float sigmaLevel, float unc, float p3D[3]) {
+  float r1[3], r2[3], r21[3];
+  kb8Unproject(c1, kp1.x, kp1.y, r1);
+  kb8Unproject(c2, kp2.x, kp2.y, r2);
+  for (int a = 0; a < 3; ++a) r21[a] = cvmatDot3(R12 + 3 * a, 1, r2, 1.0, 0.0);
+  const double dot = (double)r1[0] * r21[0] + (double)r1[1] * r21[1] + (double)r1[2] * r21[2];
+  const double n1 = sqrt((double)r1[0] * r1[0] + (double)r1[1] * r1[1] + (double)r1[2] * r1[2]);
+  const double n2 = sqrt((double)r21[0] * r21[0] + (double)r21[1] * r21[1] + (double)r21[2] * r21[2]);
+  const float cosParallaxRays = (float)(dot / (n1 * n2));
+  if ((double)cosParallaxRays > 0.9998) return -1;
+  float R21[9], t21[3];
+  for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) R21[3 * a + b] = R12[3 * b + a];
+  for (int a = 0; a < 3; ++a) t21[a] = cvmatDot3(R21 + 3 * a, 1, t12, -1.0, 0.0);
+  const float T1[3][4] = {{1.f, 0.f, 0.f, 0.f}, {0.f, 1.f, 0.f, 0.f}, {0.f, 0.f, 1.f, 0.f}};
+  float T2[3][4];
+  for (int a = 0; a < 3; ++a) { T2[a][0] = R21[3 * a]; T2[a][1] = R21[3 * a + 1]; T2[a][2] = R21[3 * a + 2]; T2[a][3] = t21[a]; }
+  float At[4][4];                                    // At[col][row] of A
+  for (int b = 0; b < 4; ++b) {
+    At[b][0] = r1[0] * T1[2][b] - T1[0][b];
+    At[b][1] = r1[1] * T1[2][b] - T1[1][b];
+    At[b][2] = r2[0] * T2[2][b] - T2[0][b];
+    At[b][3] = r2[1] * T2[2][b] - T2[1][b];
+  }
+  float vh[4];
+  jacobiSvdLastVt4(At, vh);
+  const float inv = (float)(1.0 / (double)vh[3]);
+  float x3D[3] = {vh[0] * inv + 0.f, vh[1] * inv + 0.f, vh[2] * inv + 0.f};
+  const float z1 = x3D[2];
+  if (z1 <= 0) return -1;
+  const float z2 = (float)(((double)R21[6] * x3D[0] + (double)R21[7] * x3D[1] + (double)R21[8] * x3D[2]) + (double)t21[2]);
+  if (z2 <= 0) return -1;
+  float u1, v1;
+  kb8Project(c1, x3D, u1, v1);
+  const float errX1 = u1 - kp1.x, errY1 = v1 - kp1.y;
+  if ((double)(errX1 * errX1 + errY1 * errY1) > 5.991 * (double)sigmaLevel) return -1;
+  float x3D2[3];
+  for (int a = 0; a < 3; ++a) x3D2[a] = cvmatDot3(R21 + 3 * a, 1, x3D, 1.0, (double)t21[a]);
+  float u2, v2;
+  kb8Project(c2, x3D2, u2, v2);
+  const float errX2 = u2 - kp2.x, errY2 = v2 - kp2.y;
+  if ((double)(errX2 * errX2 + errY2 * errY2) > 5.991 * (double)unc) return -1;
+  p3D[0] = x3D[0]; p3D[1] = x3D[1]; p3D[2] = x3D[2];
+  return z1;
+}
+
+// Frame::ComputeStereoFishEyeMatches.  kpL / descL: the left table in lapping order (mono first), monoLeft = first lapping
+// keypoint; same on the right.  Outputs sized Nleft / Nright: mvLeftToRightMatch, mvRightToLeftMatch, mvDepth (-1),
+// mvStereo3Dpoints (zeros where unset).  Returns nMatches.
+static inline int computeStereoFishEyeMatches(const pli_keypoint* kpL, const uint8_t* descL, int Nleft, int monoLeft,
+                                              const pli_keypoint* kpR, const uint8_t* descR, int Nright, int monoRight,
+                                              const Kb8Camera& c1, const Kb8Camera& c2, const float* Rlr, const float* tlr,
+                                              const float* levelSigma2, int* l2r, int* r2l, float* depth, float* p3d) {
+  for (int i = 0; i < Nleft; ++i) { l2r[i] = -1; depth[i] = -1.0f; p3d[3 * i] = p3d[3 * i + 1] = p3d[3 * i + 2] = 0.f; }
+  for (int i = 0; i < Nright; ++i) r2l[i] = -1;
+  const int nq = Nleft - monoLeft, nt = Nright - monoRight;
+  std::vector<int> idx, dist;
+  knn2(descL + (size_t)monoLeft * 32, nq, descR + (size_t)monoRight * 32, nt, idx, dist);
+  int nMatches = 0;
+  for (int i = 0; i < nq; ++i) {
+    if (nt < 2) break;                                   // (*it).size() >= 2
+    if (!((double)(float)dist[2 * i] < (double)(float)dist[2 * i + 1] * 0.7)) continue;
+    const int li = i + monoLeft, ri = idx[2 * i] + monoRight;
+    float p3D[3];
+    const float d = kb8TriangulateMatches(c1, c2, kpL[li], kpR[ri], Rlr, tlr, levelSigma2[kpL[li].octave],
+                                          levelSigma2[kpR[ri].octave], p3D);
+    if (d > 0.0001f) {
+      l2r[li] = ri;
+      r2l[ri] = li;
+      p3d[3 * li] = p3D[0]; p3d[3 * li + 1] = p3D[1]; p3d[3 * li + 2] = p3D[2];
+      depth[li] = d;
+      nMatches++;
+    }
+  }
+  return nMatches;
+}
+
+// The keypoint order ORBextractor::operator() leaves with a lapping area (ORBextractor.cc:1135-1144): keypoints (already
+// scaled to level-0 coordinates) with lap0 <= x <= lap1 fill the table from the back, the others from the front.
+// order[dst] = src; returns monoIndex.
+static inline int lappingOrder(const pli_keypoint* kp, int n, int lap0, int lap1, std::vector<int>& order) {
+  order.assign(n, -1);
+  int monoIndex = 0, stereoIndex = n - 1;
+  for (int i = 0; i < n; ++i) {
+    if (kp[i].x >= (float)lap0 && kp[i].x <= (float)lap1) order[stereoIndex--] = i;
+    else order[monoIndex++] = i;
+  }
+  return monoIndex;
+}
+
 }  // namespace orc

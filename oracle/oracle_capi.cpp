@@ -345,6 +345,29 @@ int orc_grid_query(const double* segs, int nseg, int rows, int cols, int qx, int
   return n;
 }
 // OpenCV-primitive restatements, exposed for known-answer tests.
+int orc_stereo_fisheye(const pli_keypoint* kpL, const uint8_t* descL, int nleft, int monoLeft, const pli_keypoint* kpR,
+                       const uint8_t* descR, int nright, int monoRight, const float* cam1, const float* cam2, const float* Rlr,
+                       const float* tlr, const float* sigma2, int* l2r, int* r2l, float* depth, float* p3d) {
+  Kb8Camera c1, c2;
+  memcpy(&c1, cam1, sizeof(c1));
+  memcpy(&c2, cam2, sizeof(c2));
+  return computeStereoFishEyeMatches(kpL, descL, nleft, monoLeft, kpR, descR, nright, monoRight, c1, c2, Rlr, tlr, sigma2, l2r, r2l,
+                                     depth, p3d);
+}
+int orc_lapping_order(const pli_keypoint* kp, int n, int lap0, int lap1, int* order) {
+  std::vector<int> o;
+  const int mono = lappingOrder(kp, n, lap0, lap1, o);
+  for (int i = 0; i < n; ++i) order[i] = o[i];
+  return mono;
+}
+int orc_kb8_unproject(const float* cam, float u, float v, float* r) { Kb8Camera c; memcpy(&c, cam, sizeof(c)); kb8Unproject(c, u, v, r); return 0; }
+int orc_kb8_project(const float* cam, const float* p, float* uv) { Kb8Camera c; memcpy(&c, cam, sizeof(c)); kb8Project(c, p, uv[0], uv[1]); return 0; }
+int orc_level_sigma2(void* h, float* out) {
+  Frame* f = (Frame*)h;
+  const auto& v = f->eye[0].orb->mvLevelSigma2;
+  for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+  return (int)v.size();
+}
 float orc_fast_atan2(float y, float x) { return fastAtan2(y, x); }
 int orc_cv_round(double v) { return cvRound(v); }
 int orc_gauss_kernel(int n, double sigma, int* out) {

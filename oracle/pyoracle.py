@@ -136,6 +136,11 @@ class Frame:
         self.L.orc_umax(self.h, _p(out))
         return out
 
+    def level_sigma2(self):
+        out = np.zeros(self.cfg.orb_nlevels, np.float32)
+        self.L.orc_level_sigma2(self.h, _p(out))
+        return out
+
     # ---- ORB ----
     def orb_extract(self, eye, img):
         if img is None or img.size == 0:
@@ -367,6 +372,43 @@ def match_nnr(d1, d2, nnr):
     m = np.full(d1.shape[0], -1, np.int32)
     n = lib().orc_match_nnr(_p(d1), d1.shape[0], _p(d2), d2.shape[0], C.c_float(nnr), _p(m))
     return n, m
+
+
+def lapping_order(kp, lap0, lap1):
+    """ORBextractor.cc:1135-1144: (order with order[dst] = src, mono count)."""
+    kp = np.ascontiguousarray(kp, KEYPOINT_DT)
+    order = np.zeros(kp.shape[0], np.int32)
+    mono = lib().orc_lapping_order(_p(kp), kp.shape[0], int(lap0), int(lap1), _p(order))
+    return order, mono
+
+
+def stereo_fisheye(kpL, descL, mono_left, kpR, descR, mono_right, cam1, cam2, Rlr, tlr, sigma2):
+    """Frame::ComputeStereoFishEyeMatches (Frame.cc:1577-1618) on tables in lapping order."""
+    kpL, kpR = np.ascontiguousarray(kpL, KEYPOINT_DT), np.ascontiguousarray(kpR, KEYPOINT_DT)
+    descL, descR = np.ascontiguousarray(descL, np.uint8), np.ascontiguousarray(descR, np.uint8)
+    c1, c2 = np.ascontiguousarray(cam1, np.float32), np.ascontiguousarray(cam2, np.float32)
+    R, t = np.ascontiguousarray(Rlr, np.float32).reshape(9), np.ascontiguousarray(tlr, np.float32).reshape(3)
+    s2 = np.ascontiguousarray(sigma2, np.float32)
+    nl, nr = kpL.shape[0], kpR.shape[0]
+    l2r, r2l = np.zeros(nl, np.int32), np.zeros(nr, np.int32)
+    depth, p3d = np.zeros(nl, np.float32), np.zeros((nl, 3), np.float32)
+    n = lib().orc_stereo_fisheye(_p(kpL), _p(descL), nl, int(mono_left), _p(kpR), _p(descR), nr, int(mono_right), _p(c1), _p(c2),
+                                 _p(R), _p(t), _p(s2), _p(l2r), _p(r2l), _p(depth), _p(p3d))
+    return n, l2r, r2l, depth, p3d
+
+
+def kb8_unproject(cam, u, v):
+    c = np.ascontiguousarray(cam, np.float32)
+    r = np.zeros(3, np.float32)
+    lib().orc_kb8_unproject(_p(c), C.c_float(u), C.c_float(v), _p(r))
+    return r
+
+
+def kb8_project(cam, p):
+    c, p = np.ascontiguousarray(cam, np.float32), np.ascontiguousarray(p, np.float32)
+    uv = np.zeros(2, np.float32)
+    lib().orc_kb8_project(_p(c), _p(p), _p(uv))
+    return uv
 
 
 def stereo_lines_tables(cfg, kl, dl, kr, dr, w, h):

@@ -135,6 +135,22 @@ class Frontend {
     check(pli_match_nnr(ctx_, desc1, n1, desc2, n2, nnr, matches12.data(), &n));
     return n;
   }
+  // Frame::ComputeStereoFishEyeMatches Frame.cc:1577-1618 on the Frame's own tables (mvKeys / mDescriptors / monoLeft, ...);
+  // fills mvLeftToRightMatch, mvRightToLeftMatch, mvDepth, mvStereo3Dpoints (x, y, z per left keypoint) and returns nMatches
+  int stereoFishEye(const std::vector<pli_keypoint>& kpLeft, const uint8_t* descLeft, int monoLeft,
+                    const std::vector<pli_keypoint>& kpRight, const uint8_t* descRight, int monoRight, const pli_kb8_camera& cam1,
+                    const pli_kb8_camera& cam2, const float* Rlr, const float* tlr, std::vector<int>& leftToRight,
+                    std::vector<int>& rightToLeft, std::vector<float>& depth, std::vector<float>& points3d) {
+    leftToRight.assign(kpLeft.size(), -1);
+    rightToLeft.assign(kpRight.size(), -1);
+    depth.assign(kpLeft.size(), -1.0f);
+    points3d.assign(kpLeft.size() * 3, 0.0f);
+    int32_t n = 0;
+    check(pli_stereo_fisheye_tables(ctx_, kpLeft.data(), descLeft, (int)kpLeft.size(), monoLeft, kpRight.data(), descRight,
+                                    (int)kpRight.size(), monoRight, &cam1, &cam2, Rlr, tlr, leftToRight.data(), rightToLeft.data(),
+                                    depth.data(), points3d.data(), &n));
+    return n;
+  }
 
  private:
   pli_frontend_config cfg_;

@@ -112,6 +112,13 @@ _PROTOS = {
     "pli_line_extract": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p,
                                      C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]),
     "pli_stereo_match_points": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "pli_orb_extract_lapping": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
+                                            C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pli_stereo_fisheye": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                       C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pli_stereo_fisheye_tables": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                              C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p]),
     "pli_stereo_from_depth": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32]),
     "pli_stereo_match_lines": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "pli_descriptor_distance": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),

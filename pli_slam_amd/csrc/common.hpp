@@ -121,4 +121,7 @@ struct TrackParams {
   int64_t trackBytes, toffCounts, toffBest, toffLines;
 };
 
+// KannalaBrandt8 parameters (pli_kb8_camera), by value (match_kernels.hip: k_fisheye_triangulate)
+struct Kb8 { float fx, fy, cx, cy, k0, k1, k2, k3; };
+
 }  // namespace pli

@@ -236,16 +236,18 @@ __global__ __launch_bounds__(64) void k_lsd_scatter(const int* __restrict__ g2a,
 
 // -DLSD_STATS (make EXTRA=-DLSD_STATS): per-image counts of the sequential grower, read by tools/lsd_stats.py
 #ifdef LSD_STATS
-__device__ unsigned long long g_lsdStats[16];
+__device__ unsigned long long g_lsdStats[24];
 __device__ unsigned long long g_lsdStatsMax;
 extern "C" unsigned long long pli_lsd_stats_max() { unsigned long long v = 0, z = 0; (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_lsdStatsMax), 8); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lsdStatsMax), &z, 8); return v; }
-extern "C" void pli_lsd_stats(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lsdStats), 128); unsigned long long z[16] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lsdStats), z, 128); }
+extern "C" void pli_lsd_stats(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lsdStats), 192); unsigned long long z[24] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lsdStats), z, 192); }
 #define LSTAT(i, v) do { if (lane == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1) stt[i] += (v); } while (0)
 #define LCLOCK() __builtin_readcyclecounter()
+#define LWAIT() __builtin_amdgcn_s_waitcnt(0)
 #define LTIME(i, t0) do { stt[i] += __builtin_readcyclecounter() - (t0); } while (0)
 #else
 #define LSTAT(i, v) do {} while (0)
 #define LCLOCK() 0ull
+#define LWAIT() do {} while (0)
 #define LTIME(i, t0) do {} while (0)
 #endif
 constexpr int LSD_QCAP = 1024;      // region queue entries kept in LDS (8 KB/wave): longer regions spill to global memory
@@ -420,7 +422,7 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
   const int ndx = lane % 3 - 1, ndy = (lane / 3) % 3 - 1;   // lanes 0..8: raster order of the 3x3 block
   int nseg = 0;
 #ifdef LSD_STATS
-  unsigned long long stt[16] = {};
+  unsigned long long stt[24] = {};
   const unsigned long long tKernel = LCLOCK();
 #endif
   LSTAT(7, nOrder);
@@ -602,7 +604,7 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
   if (lane == 0) nSeg[img] = nseg < maxSeg ? nseg : maxSeg;
 #ifdef LSD_STATS
   LTIME(8, tKernel);
-  if (lane == 0) for (int i = 0; i < 16; ++i) atomicAdd(&g_lsdStats[i], stt[i]);
+  if (lane == 0) for (int i = 0; i < 24; ++i) atomicAdd(&g_lsdStats[i], stt[i]);
   if (lane == 0) atomicMax(&g_lsdStatsMax, stt[8]);
 #endif
 }
@@ -671,7 +673,7 @@ __device__ __forceinline__ void lsd_grow_image_spec(const DevParams* __restrict_
   int pos = 0;
   int avgLive = 8;                                      // running estimate of live seeds per row of 64 list entries
 #ifdef LSD_STATS
-  unsigned long long stt[16] = {};
+  unsigned long long stt[24] = {};
   const unsigned long long tKernel = LCLOCK();
 #endif
 
@@ -949,12 +951,18 @@ __device__ __forceinline__ void lsd_grow_image_spec(const DevParams* __restrict_
         const bool inb = act && nx >= 0 && ny >= 0 && nx < W && ny < H;
         const int qi = inb ? ny * W + nx : -1;
         float4 r = make_float4(LSD_NOTDEF, 0.f, 0.f, 0.f);
+        const unsigned long long tF = LCLOCK();
         if (inb) r = rec[qi];
+        LWAIT();
+        LTIME(16, tF);
+        const unsigned long long tA = LCLOCK();
         const bool cand = r.x != LSD_NOTDEF;
         const unsigned myxy = ((unsigned)ny << 16) | (unsigned)nx;
         const unsigned wbits = (unsigned)__float_as_int(r.w);
         unsigned long long remaining = __builtin_amdgcn_ballot_w64(cand);
+        LSTAT(18, nb);
         while (remaining) {
+          LSTAT(19, 1);
           const float n2 = __builtin_fmaf(sumdx, sumdx, sumdy * sumdy);
           const float dot = __builtin_fmaf(sumdx, r.y, sumdy * r.z);
           const float sd2 = dot * __builtin_fabsf(dot);
@@ -991,6 +999,7 @@ __device__ __forceinline__ void lsd_grow_image_spec(const DevParams* __restrict_
           angValid = false;
           if (wj >> 19) tagged(wj, qj);
         }
+        LTIME(17, tA);
       };
       for (int k = k0; k < cnt;) {
         if (cnt + 65 <= SPEC_Q) {                    // a batch can append up to 8 x 8 entries
@@ -1027,7 +1036,7 @@ __device__ __forceinline__ void lsd_grow_image_spec(const DevParams* __restrict_
   if (lane == 0) nSeg[img] = nseg < maxSeg ? nseg : maxSeg;
 #ifdef LSD_STATS
   LTIME(8, tKernel);
-  if (lane == 0) for (int i = 0; i < 16; ++i) atomicAdd(&g_lsdStats[i], stt[i]);
+  if (lane == 0) for (int i = 0; i < 24; ++i) atomicAdd(&g_lsdStats[i], stt[i]);
   if (lane == 0) atomicMax(&g_lsdStatsMax, stt[8]);
 #endif
 }

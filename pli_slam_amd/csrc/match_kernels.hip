@@ -1099,3 +1099,230 @@ __global__ __launch_bounds__(64) void k_bow_descend(const uint8_t* __restrict__ 
 }
 
 }  // namespace pli
+
+namespace pli {
+
+// ---------------------------------------------------------------------------
+// SURVEY §8(f) row 4, fisheye stereo.
+// Frame::ComputeStereoFishEyeMatches (Frame.cc:1577-1618): after knnMatch(k = 2) of the lapping-area descriptors (k_knn2),
+// Lowe's ratio 0.7 and KannalaBrandt8::TriangulateMatches (src/CameraModels/KannalaBrandt8.cpp:334-402) per surviving pair:
+// unproject both keypoints (Newton on the distortion polynomial, :103-130), parallax test, linear triangulation (:422-435),
+// positive depths, reprojection errors against 5.991 * sigma^2 (project, :28-42).
+// One thread per left lapping-area keypoint; cv::Mat arithmetic as OpenCV 3.3.1 evaluates it: gemm = double accumulation and
+// one rounding, Mat::dot / norm in double, cv::SVD::compute = the one-sided float Jacobi of lapack.cpp (4x4, <= 30 sweeps,
+// hypot as sqrt(p*p + beta*beta)), libm calls on floats in double and rounded.  Same statement as the checker's
+// (match_oracle.hpp kb8TriangulateMatches), operation for operation.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float mat_dot3(const float* a, int sa, const float* b, double alpha, double c) {
+  const double d = (double)a[0] * (double)b[0] + (double)a[sa] * (double)b[1] + (double)a[2 * sa] * (double)b[2];
+  return (float)(alpha * d + c);
+}
+
+__device__ __forceinline__ void kb8_unproject(const Kb8& c, float u, float v, float r[3]) {
+  const float pwx = (u - c.cx) / c.fx, pwy = (v - c.cy) / c.fy;
+  float scale = 1.f;
+  float theta_d = sqrtf(pwx * pwx + pwy * pwy);
+  theta_d = fminf(fmaxf((float)(-3.1415926535897932384626433832795 / 2.0), theta_d), (float)(3.1415926535897932384626433832795 / 2.0));
+  if ((double)theta_d > 1e-8) {
+    float theta = theta_d;
+    for (int j = 0; j < 10; j++) {
+      const float theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta4 * theta4;
+      const float k0t2 = c.k0 * theta2, k1t4 = c.k1 * theta4, k2t6 = c.k2 * theta6, k3t8 = c.k3 * theta8;
+      const float fix = (theta * (1 + k0t2 + k1t4 + k2t6 + k3t8) - theta_d) / (1 + 3 * k0t2 + 5 * k1t4 + 7 * k2t6 + 9 * k3t8);
+      theta = theta - fix;
+      if (fabsf(fix) < 1e-6f) break;                  // KannalaBrandt8::precision
+    }
+    scale = (float)tan((double)theta) / theta_d;
+  }
+  r[0] = pwx * scale; r[1] = pwy * scale; r[2] = 1.f;
+}
+
+__device__ __forceinline__ void kb8_project(const Kb8& c, const float p[3], float& u, float& v) {
+  const float x2y2 = p[0] * p[0] + p[1] * p[1];
+  const float theta = (float)atan2((double)sqrtf(x2y2), (double)p[2]);
+  const float psi = (float)atan2((double)p[1], (double)p[0]);
+  const float t2 = theta * theta, t3 = theta * t2, t5 = t3 * t2, t7 = t5 * t2, t9 = t7 * t2;
+  const float r = theta + c.k0 * t3 + c.k1 * t5 + c.k2 * t7 + c.k3 * t9;
+  u = (float)((double)(c.fx * r) * cos((double)psi) + (double)c.cx);
+  v = (float)((double)(c.fy * r) * sin((double)psi) + (double)c.cy);
+}
+
+// last row of vt of cv::SVD::compute(A) for a 4x4 CV_32F matrix; At = A transposed
+__device__ __forceinline__ void jacobi_svd_last_vt4(float At[4][4], float out[4]) {
+  double W[4];
+  float Vt[4][4];
+  const float eps = 2.384185791015625e-07f;             // FLT_EPSILON * 2
+  for (int i = 0; i < 4; i++) {
+    double sd = 0;
+    for (int k = 0; k < 4; k++) { const float t = At[i][k]; sd += (double)t * t; }
+    W[i] = sd;
+    for (int k = 0; k < 4; k++) Vt[i][k] = 0;
+    Vt[i][i] = 1;
+  }
+  for (int iter = 0; iter < 30; iter++) {
+    bool changed = false;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = i + 1; j < 4; j++) {
+        double a = W[i], p = 0, b = W[j];
+        for (int k = 0; k < 4; k++) p += (double)At[i][k] * At[j][k];
+        if (fabs(p) <= (double)eps * sqrt(a * b)) continue;
+        p *= 2;
+        const double beta = a - b, gamma = sqrt(p * p + beta * beta);
+        float c, s;
+        if (beta < 0) {
+          const double delta = (gamma - beta) * 0.5;
+          s = (float)sqrt(delta / gamma);
+          c = (float)(p / (gamma * s * 2));
+        } else {
+          c = (float)sqrt((gamma + beta) / (gamma * 2));
+          s = (float)(p / (gamma * c * 2));
+        }
+        a = b = 0;
+        for (int k = 0; k < 4; k++) {
+          const float t0 = c * At[i][k] + s * At[j][k];
+          const float t1 = -s * At[i][k] + c * At[j][k];
+          At[i][k] = t0; At[j][k] = t1;
+          a += (double)t0 * t0; b += (double)t1 * t1;
+        }
+        W[i] = a; W[j] = b;
+        changed = true;
+        for (int k = 0; k < 4; k++) {
+          const float t0 = c * Vt[i][k] + s * Vt[j][k];
+          const float t1 = -s * Vt[i][k] + c * Vt[j][k];
+          Vt[i][k] = t0; Vt[j][k] = t1;
+        }
+      }
+    if (!changed) break;
+  }
+  for (int i = 0; i < 4; i++) {
+    double sd = 0;
+    for (int k = 0; k < 4; k++) { const float t = At[i][k]; sd += (double)t * t; }
+    W[i] = sqrt(sd);
+  }
+  // the descending selection sort of lapack.cpp only matters for where the smallest singular value ends up: row 3 takes
+  // part in a swap at step i iff it holds the maximum of W[i..3] (the first maximum wins: W[j] < W[k] is strict)
+  int idx[4] = {0, 1, 2, 3};
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    int j = i;
+#pragma unroll
+    for (int k = i + 1; k < 4; k++)
+      if (W[j] < W[k]) j = k;
+    if (i != j) {
+      const double tw = W[i]; W[i] = W[j]; W[j] = tw;
+      const int ti = idx[i]; idx[i] = idx[j]; idx[j] = ti;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+    if (idx[3] == r)
+      for (int k = 0; k < 4; k++) out[k] = Vt[r][k];
+}
+
+__global__ __launch_bounds__(64) void k_fisheye_triangulate(const pli_keypoint* __restrict__ kpL, const pli_keypoint* __restrict__ kpR,
+                                                            const int* __restrict__ knnIdx, const int* __restrict__ knnDist, int nl, int nr,
+                                                            int monoL, int monoR, Kb8 c1, Kb8 c2, const float* __restrict__ R12t12,
+                                                            const float* __restrict__ sigma2, int* __restrict__ l2r, int* __restrict__ r2l,
+                                                            float* __restrict__ depth, float* __restrict__ p3d, int* __restrict__ nmatches) {
+  const int i = blockIdx.x * 64 + threadIdx.x;          // index into the lapping-area (stereo) part of the left table
+  if (i >= nl || nr < 2) return;                        // (*it).size() >= 2
+  const int d0 = knnDist[2 * i], d1 = knnDist[2 * i + 1], j = knnIdx[2 * i];
+  if (!((double)(float)d0 < (double)(float)d1 * 0.7)) return;
+  const pli_keypoint k1 = kpL[monoL + i], k2 = kpR[monoR + j];
+  const float* R12 = R12t12;
+  const float* t12 = R12t12 + 9;
+  float r1[3], r2[3], r21[3];
+  kb8_unproject(c1, k1.x, k1.y, r1);
+  kb8_unproject(c2, k2.x, k2.y, r2);
+  for (int a = 0; a < 3; ++a) r21[a] = mat_dot3(R12 + 3 * a, 1, r2, 1.0, 0.0);
+  const double dot = (double)r1[0] * r21[0] + (double)r1[1] * r21[1] + (double)r1[2] * r21[2];
+  const double n1 = sqrt((double)r1[0] * r1[0] + (double)r1[1] * r1[1] + (double)r1[2] * r1[2]);
+  const double n2 = sqrt((double)r21[0] * r21[0] + (double)r21[1] * r21[1] + (double)r21[2] * r21[2]);
+  const float cosPar = (float)(dot / (n1 * n2));
+  if ((double)cosPar > 0.9998) return;
+  // Tcw1 = [I | 0], Tcw2 = [R21 | t21] with R21 = R12^T, t21 = -R21 t12
+  float R21[9], t21[3];
+  for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) R21[3 * a + b] = R12[3 * b + a];
+  for (int a = 0; a < 3; ++a) t21[a] = mat_dot3(R21 + 3 * a, 1, t12, -1.0, 0.0);
+  const float T1[3][4] = {{1.f, 0.f, 0.f, 0.f}, {0.f, 1.f, 0.f, 0.f}, {0.f, 0.f, 1.f, 0.f}};
+  float T2[3][4];
+  for (int a = 0; a < 3; ++a) { T2[a][0] = R21[3 * a]; T2[a][1] = R21[3 * a + 1]; T2[a][2] = R21[3 * a + 2]; T2[a][3] = t21[a]; }
+  float At[4][4];
+  for (int b = 0; b < 4; ++b) {
+    At[b][0] = r1[0] * T1[2][b] - T1[0][b];
+    At[b][1] = r1[1] * T1[2][b] - T1[1][b];
+    At[b][2] = r2[0] * T2[2][b] - T2[0][b];
+    At[b][3] = r2[1] * T2[2][b] - T2[1][b];
+  }
+  float vh[4];
+  jacobi_svd_last_vt4(At, vh);
+  const float inv = (float)(1.0 / (double)vh[3]);
+  const float x3[3] = {vh[0] * inv + 0.f, vh[1] * inv + 0.f, vh[2] * inv + 0.f};
+  const float z1 = x3[2];
+  if (!(z1 > 0)) return;                                // z1 <= 0 (or NaN: `depth > 0.0001f` fails for it below in the reference)
+  const float z2 = (float)(((double)R21[6] * x3[0] + (double)R21[7] * x3[1] + (double)R21[8] * x3[2]) + (double)t21[2]);
+  if (z2 <= 0) return;
+  float u1, v1;
+  kb8_project(c1, x3, u1, v1);
+  const float ex1 = u1 - k1.x, ey1 = v1 - k1.y;
+  if ((double)(ex1 * ex1 + ey1 * ey1) > 5.991 * (double)sigma2[k1.octave]) return;
+  float x32[3];
+  for (int a = 0; a < 3; ++a) x32[a] = mat_dot3(R21 + 3 * a, 1, x3, 1.0, (double)t21[a]);
+  float u2, v2;
+  kb8_project(c2, x32, u2, v2);
+  const float ex2 = u2 - k2.x, ey2 = v2 - k2.y;
+  if ((double)(ex2 * ex2 + ey2 * ey2) > 5.991 * (double)sigma2[k2.octave]) return;
+  if (!(z1 > 0.0001f)) return;
+  l2r[monoL + i] = monoR + j;
+  atomicMax(&r2l[monoR + j], monoL + i);        // the reference's loop overwrites: the LAST left keypoint that takes a right one stays
+  depth[monoL + i] = z1;
+  p3d[3 * (monoL + i)] = x3[0]; p3d[3 * (monoL + i) + 1] = x3[1]; p3d[3 * (monoL + i) + 2] = x3[2];
+  atomicAdd(nmatches, 1);
+}
+
+__global__ void k_fill_f32(float* __restrict__ dst, int n, float v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = v;
+}
+
+// ---------------------------------------------------------------------------
+// The keypoint order ORBextractor::operator() leaves when a lapping area is given (ORBextractor.cc:1135-1144): keypoints
+// with lap0 <= x <= lap1 (level-0 coordinates) fill the table from the back in visiting order, the others from the front.
+// One workgroup per image: ordered counts by block scans over chunks of 1024 keypoints; src = snapshot of the table.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_lapping_order(const pli_keypoint* __restrict__ srcKp, const uint8_t* __restrict__ srcDesc,
+                                                        int n, float lap0, float lap1, pli_keypoint* __restrict__ dstKp,
+                                                        uint8_t* __restrict__ dstDesc, int* __restrict__ monoCount) {
+  __shared__ int waveCnt[16];
+  __shared__ int base;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < n; c0 += 1024) {
+    const int i = c0 + tid;
+    pli_keypoint k;
+    bool mono = false;
+    if (i < n) { k = srcKp[i]; mono = !(k.x >= lap0 && k.x <= lap1); }
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(mono);
+    if (lane == 0) waveCnt[wv] = __popcll(bal);
+    __syncthreads();
+    int before = base;
+    for (int w = 0; w < wv; ++w) before += waveCnt[w];
+    before += __popcll(bal & ((1ull << lane) - 1ull));       // mono keypoints before i
+    if (i < n) {
+      const int dst = mono ? before : n - 1 - (i - before);
+      dstKp[dst] = k;
+      const uint4* s4 = reinterpret_cast<const uint4*>(srcDesc + (int64_t)i * 32);
+      uint4* d4 = reinterpret_cast<uint4*>(dstDesc + (int64_t)dst * 32);
+      d4[0] = s4[0]; d4[1] = s4[1];
+    }
+    __syncthreads();
+    if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += waveCnt[w]; base += t; }
+    __syncthreads();
+  }
+  if (tid == 0) *monoCount = base;
+}
+
+}  // namespace pli

@@ -101,6 +101,7 @@ struct pli_ctx {
   uint8_t* ownTable = nullptr;
   std::vector<uint8_t> hostRec;
   bool orbDone[2] = {false, false}, lineDone[2] = {false, false};
+  int monoCount[2] = {0, 0};                 // pli_orb_extract_lapping: first lapping-area keypoint of each eye's table
   // pipelined host entry point: two slots of device staging (images + table), H2D and D2H copy streams
   struct HostSlot { uint8_t* dimg = nullptr; uint8_t* dtab = nullptr; size_t imgBytes = 0, tabBytes = 0;
                     hipEvent_t h2d = nullptr, kern = nullptr, d2h = nullptr; bool busy = false; };
@@ -1168,6 +1169,7 @@ pli_status pli_orb_extract(pli_ctx* c, int32_t eye, const uint8_t* img, int32_t 
   HIPCHK(hipStreamSynchronize(c->stream));
   const int N = counts[eye];
   c->orbDone[eye] = true;
+  c->monoCount[eye] = N;
   *n = N;
   if (N > cap) { g_err = "keypoint buffer too small"; return PLI_ERR_CAPACITY; }
   if (N > 0) {
@@ -1254,6 +1256,143 @@ pli_status pli_stereo_from_depth(pli_ctx* c, const float* depth, int64_t strideF
     if (depthOut) HIPCHK(hipMemcpy(depthOut, c->ownTable + Y.off_depth, (size_t)N * 4, hipMemcpyDeviceToHost));
   }
   return PLI_OK;
+}
+
+// ORBextractor::operator() with a lapping area (ORBextractor.cc:1135-1144): pli_orb_extract, then the device table of that eye
+// is put into the reference's mono-first / lapping-from-the-back order (k_lapping_order), which is the order
+// pli_stereo_fisheye expects; *n_mono = the reference's return value (monoIndex).
+pli_status pli_orb_extract_lapping(pli_ctx* c, int32_t eye, const uint8_t* img, int32_t w, int32_t h, int64_t stride,
+                                   int32_t lap0, int32_t lap1, pli_keypoint* kp, int32_t cap, uint8_t* desc, int32_t* n,
+                                   int32_t* n_mono) {
+  if (!n_mono) { g_err = "bad argument"; return PLI_ERR_INVALID; }
+  *n_mono = 0;
+  pli_status st = pli_orb_extract(c, eye, img, w, h, stride, nullptr, INT_MAX, nullptr, n);
+  if (st != PLI_OK) return st;
+  const int N = *n;
+  if (N > cap) { g_err = "keypoint buffer too small"; return PLI_ERR_CAPACITY; }
+  if (N == 0) return PLI_OK;
+  const pli_table_layout& Y = c->lay;
+  const size_t bk = alignUp((size_t)N * sizeof(pli_keypoint), 256), bd = alignUp((size_t)N * 32, 256);
+  if ((st = ensureScratch(c, bk + bd + 256)) != PLI_OK) return st;
+  uint8_t* p = (uint8_t*)c->scratch;
+  pli_keypoint* sk = (pli_keypoint*)p;
+  uint8_t* sd = p + bk;
+  int* dmono = (int*)(p + bk + bd);
+  pli_keypoint* tk = (pli_keypoint*)(c->ownTable + Y.off_kp[eye]);
+  uint8_t* td = c->ownTable + Y.off_desc[eye];
+  HIPCHK(hipMemcpyAsync(sk, tk, (size_t)N * sizeof(pli_keypoint), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(sd, td, (size_t)N * 32, hipMemcpyDeviceToDevice, c->stream));
+  LAUNCH(c, "k_lapping_order", k_lapping_order, dim3(1), dim3(1024), 0, (const pli_keypoint*)sk, (const uint8_t*)sd, N, (float)lap0,
+         (float)lap1, tk, td, dmono);
+  int mono = 0;
+  HIPCHK(hipMemcpyAsync(&mono, dmono, 4, hipMemcpyDeviceToHost, c->stream));
+  if (kp) HIPCHK(hipMemcpyAsync(kp, tk, (size_t)N * sizeof(pli_keypoint), hipMemcpyDeviceToHost, c->stream));
+  if (desc) HIPCHK(hipMemcpyAsync(desc, td, (size_t)N * 32, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *n_mono = mono;
+  c->monoCount[eye] = mono;
+  return PLI_OK;
+}
+
+// Frame::ComputeStereoFishEyeMatches (Frame.cc:1577-1618): tables on the device (kL/dL/kR/dR), results to host buffers.
+// `scratchOff`: bytes of c->scratch already in use by the caller.
+static pli_status fisheyeCore(pli_ctx* c, const pli_keypoint* kL, const uint8_t* dL, int NL, int monoL, const pli_keypoint* kR,
+                              const uint8_t* dR, int NR, int monoR, size_t scratchOff, const pli_kb8_camera* cam1,
+                              const pli_kb8_camera* cam2, const float* Rlr, const float* tlr, int32_t* l2r, int32_t* r2l, float* depth,
+                              float* p3d, int32_t* nmatches) {
+  monoL = std::min(std::max(monoL, 0), NL);
+  monoR = std::min(std::max(monoR, 0), NR);
+  const int nq = NL - monoL, nt = NR - monoR;
+  const size_t bi = alignUp((size_t)std::max(nq, 1) * 16, 256), bl = alignUp((size_t)std::max(NL, 1) * 4, 256),
+               br = alignUp((size_t)std::max(NR, 1) * 4, 256), bp = alignUp((size_t)std::max(NL, 1) * 12, 256);
+  uint8_t* p = (uint8_t*)c->scratch + scratchOff;
+  int* kidx = (int*)p; int* kdst = kidx + 2 * std::max(nq, 1); p += bi;
+  int* dl2r = (int*)p; p += bl;
+  float* ddepth = (float*)p; p += bl;
+  int* dr2l = (int*)p; p += br;
+  float* dp3 = (float*)p; p += bp;
+  float* dRt = (float*)p; p += 128;
+  float* dsig = (float*)p; p += 128;
+  int* dcnt = (int*)p;
+  float hRt[12], hsig[MAX_LEVELS];
+  for (int i = 0; i < 9; ++i) hRt[i] = Rlr[i];
+  for (int i = 0; i < 3; ++i) hRt[9 + i] = tlr[i];
+  for (int l = 0; l < c->hp.nlevels; ++l) hsig[l] = c->hp.lv[l].scale * c->hp.lv[l].scale;      // mvLevelSigma2, ORBextractor.cc:424
+  HIPCHK(hipMemcpyAsync(dRt, hRt, sizeof(hRt), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(dsig, hsig, sizeof(float) * c->hp.nlevels, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemsetAsync(dl2r, 0xFF, (size_t)std::max(NL, 1) * 4, c->stream));
+  HIPCHK(hipMemsetAsync(dr2l, 0xFF, (size_t)std::max(NR, 1) * 4, c->stream));
+  HIPCHK(hipMemsetAsync(dp3, 0, (size_t)std::max(NL, 1) * 12, c->stream));
+  HIPCHK(hipMemsetAsync(dcnt, 0, 4, c->stream));
+  LAUNCH(c, "k_fill_f32", k_fill_f32, dim3((std::max(NL, 1) + 255) / 256), dim3(256), 0, ddepth, std::max(NL, 1), -1.0f);
+  if (nq > 0) {
+    LAUNCH(c, "k_knn2", k_knn2, dim3(nq), dim3(64), 0, dL + (size_t)monoL * 32, nq, dR + (size_t)monoR * 32, nt, kidx, kdst);
+    Kb8 c1, c2;
+    memcpy(&c1, cam1, sizeof(c1));
+    memcpy(&c2, cam2, sizeof(c2));
+    LAUNCH(c, "k_fisheye_triangulate", k_fisheye_triangulate, dim3((nq + 63) / 64), dim3(64), 0, kL, kR, (const int*)kidx,
+           (const int*)kdst, nq, nt, monoL, monoR, c1, c2, (const float*)dRt, (const float*)dsig, dl2r, dr2l, ddepth, dp3, dcnt);
+  }
+  int cnt = 0;
+  if (l2r && NL) HIPCHK(hipMemcpyAsync(l2r, dl2r, (size_t)NL * 4, hipMemcpyDeviceToHost, c->stream));
+  if (r2l && NR) HIPCHK(hipMemcpyAsync(r2l, dr2l, (size_t)NR * 4, hipMemcpyDeviceToHost, c->stream));
+  if (depth && NL) HIPCHK(hipMemcpyAsync(depth, ddepth, (size_t)NL * 4, hipMemcpyDeviceToHost, c->stream));
+  if (p3d && NL) HIPCHK(hipMemcpyAsync(p3d, dp3, (size_t)NL * 12, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(&cnt, dcnt, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (nmatches) *nmatches = cnt;
+  return PLI_OK;
+}
+static size_t fisheyeScratch(int NL, int NR) {
+  return alignUp((size_t)std::max(NL, 1) * 16, 256) + 2 * alignUp((size_t)std::max(NL, 1) * 4, 256) +
+         alignUp((size_t)std::max(NR, 1) * 4, 256) + alignUp((size_t)std::max(NL, 1) * 12, 256) + 512;
+}
+
+// ... on the device tables of the last pli_orb_extract_lapping of both eyes
+pli_status pli_stereo_fisheye(pli_ctx* c, const pli_kb8_camera* cam1, const pli_kb8_camera* cam2, const float* Rlr, const float* tlr,
+                              int32_t* l2r, int32_t capL, int32_t* r2l, int32_t capR, float* depth, float* p3d, int32_t* nmatches) {
+  if (!c || !cam1 || !cam2 || !Rlr || !tlr) { g_err = "bad argument"; return PLI_ERR_INVALID; }
+  if (nmatches) *nmatches = 0;
+  if (!c->orbDone[0] || !c->orbDone[1]) { g_err = "pli_orb_extract_lapping must run for both eyes first"; return PLI_ERR_STATE; }
+  HIPCHK(hipSetDevice(c->device));
+  const pli_table_layout& Y = c->lay;
+  int counts[8];
+  HIPCHK(hipMemcpyAsync(counts, c->ownTable + Y.off_counts, sizeof(counts), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const int NL = counts[0], NR = counts[1];
+  if (NL > capL || NR > capR) { g_err = "output buffer too small"; return PLI_ERR_CAPACITY; }
+  pli_status st = ensureScratch(c, fisheyeScratch(NL, NR));
+  if (st != PLI_OK) return st;
+  return fisheyeCore(c, (const pli_keypoint*)(c->ownTable + Y.off_kp[0]), c->ownTable + Y.off_desc[0], NL, c->monoCount[0],
+                     (const pli_keypoint*)(c->ownTable + Y.off_kp[1]), c->ownTable + Y.off_desc[1], NR, c->monoCount[1], 0, cam1, cam2,
+                     Rlr, tlr, l2r, r2l, depth, p3d, nmatches);
+}
+
+// ... on caller tables (the Frame members mvKeys / mDescriptors / mvKeysRight / mDescriptorsRight, monoLeft / monoRight)
+pli_status pli_stereo_fisheye_tables(pli_ctx* c, const pli_keypoint* kpL, const uint8_t* descL, int32_t nleft, int32_t monoLeft,
+                                     const pli_keypoint* kpR, const uint8_t* descR, int32_t nright, int32_t monoRight,
+                                     const pli_kb8_camera* cam1, const pli_kb8_camera* cam2, const float* Rlr, const float* tlr,
+                                     int32_t* l2r, int32_t* r2l, float* depth, float* p3d, int32_t* nmatches) {
+  if (!c || !cam1 || !cam2 || !Rlr || !tlr || nleft < 0 || nright < 0 || (nleft > 0 && (!kpL || !descL)) ||
+      (nright > 0 && (!kpR || !descR))) { g_err = "bad argument"; return PLI_ERR_INVALID; }
+  if (nmatches) *nmatches = 0;
+  HIPCHK(hipSetDevice(c->device));
+  const size_t bkl = alignUp((size_t)std::max(nleft, 1) * sizeof(pli_keypoint), 256), bdl = alignUp((size_t)std::max(nleft, 1) * 32, 256);
+  const size_t bkr = alignUp((size_t)std::max(nright, 1) * sizeof(pli_keypoint), 256), bdr = alignUp((size_t)std::max(nright, 1) * 32, 256);
+  pli_status st = ensureScratch(c, bkl + bdl + bkr + bdr + fisheyeScratch(nleft, nright));
+  if (st != PLI_OK) return st;
+  uint8_t* p = (uint8_t*)c->scratch;
+  pli_keypoint* kL = (pli_keypoint*)p; uint8_t* dL = p + bkl; pli_keypoint* kR = (pli_keypoint*)(p + bkl + bdl); uint8_t* dR = p + bkl + bdl + bkr;
+  if (nleft) {
+    HIPCHK(hipMemcpyAsync(kL, kpL, (size_t)nleft * sizeof(pli_keypoint), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dL, descL, (size_t)nleft * 32, hipMemcpyHostToDevice, c->stream));
+  }
+  if (nright) {
+    HIPCHK(hipMemcpyAsync(kR, kpR, (size_t)nright * sizeof(pli_keypoint), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dR, descR, (size_t)nright * 32, hipMemcpyHostToDevice, c->stream));
+  }
+  return fisheyeCore(c, kL, dL, nleft, monoLeft, kR, dR, nright, monoRight, bkl + bdl + bkr + bdr, cam1, cam2, Rlr, tlr, l2r, r2l, depth,
+                     p3d, nmatches);
 }
 
 pli_status pli_stereo_match_lines(pli_ctx* c, float* disp, double* le, int32_t cap) {

@@ -158,6 +158,44 @@ class Frontend:
         check(self.L.pli_bow_transform(self.h, vocab, ptr(d), n, levelsup, ptr(word), ptr(weight), ptr(node)))
         return word, weight, node
 
+    def orb_extract_lapping(self, eye, image, lapping):
+        """ORBextractor::operator() with vLappingArea = lapping (ORBextractor.cc:1135-1144): (n, mono count, keypoints, descriptors);
+        the table keeps the mono-first / lapping-from-the-back order for stereo_fisheye()."""
+        image = _u8(image)
+        kp = np.zeros(self.kp_cap, KEYPOINT_DT)
+        desc = np.zeros((self.kp_cap, 32), np.uint8)
+        n, mono = C.c_int32(), C.c_int32()
+        check(self.L.pli_orb_extract_lapping(self.h, eye, ptr(image), image.shape[1], image.shape[0], image.strides[0],
+                                             int(lapping[0]), int(lapping[1]), ptr(kp), self.kp_cap, ptr(desc), C.byref(n),
+                                             C.byref(mono)))
+        return n.value, mono.value, kp[:n.value].copy(), desc[:n.value].copy()
+
+    def stereo_fisheye(self, cam1, cam2, Rlr, tlr, nleft, nright):
+        """Frame::ComputeStereoFishEyeMatches (Frame.cc:1577-1618): (nMatches, mvLeftToRightMatch, mvRightToLeftMatch, mvDepth,
+        mvStereo3Dpoints) on the tables of the last orb_extract_lapping of both eyes.  cam: the 8 KannalaBrandt8 parameters."""
+        c1, c2 = np.ascontiguousarray(cam1, np.float32), np.ascontiguousarray(cam2, np.float32)
+        R, t = np.ascontiguousarray(Rlr, np.float32).reshape(9), np.ascontiguousarray(tlr, np.float32).reshape(3)
+        l2r, r2l = np.zeros(self.kp_cap, np.int32), np.zeros(self.kp_cap, np.int32)
+        depth, p3d = np.zeros(self.kp_cap, np.float32), np.zeros((self.kp_cap, 3), np.float32)
+        nm = C.c_int32()
+        check(self.L.pli_stereo_fisheye(self.h, ptr(c1), ptr(c2), ptr(R), ptr(t), ptr(l2r), self.kp_cap, ptr(r2l), self.kp_cap,
+                                        ptr(depth), ptr(p3d), C.byref(nm)))
+        return nm.value, l2r[:nleft].copy(), r2l[:nright].copy(), depth[:nleft].copy(), p3d[:nleft].copy()
+
+    def stereo_fisheye_tables(self, kpL, descL, mono_left, kpR, descR, mono_right, cam1, cam2, Rlr, tlr):
+        """Frame::ComputeStereoFishEyeMatches on caller tables (mvKeys / mDescriptors / monoLeft, ... of the Frame)."""
+        kpL, kpR = np.ascontiguousarray(kpL, KEYPOINT_DT), np.ascontiguousarray(kpR, KEYPOINT_DT)
+        descL, descR = np.ascontiguousarray(descL, np.uint8), np.ascontiguousarray(descR, np.uint8)
+        c1, c2 = np.ascontiguousarray(cam1, np.float32), np.ascontiguousarray(cam2, np.float32)
+        R, t = np.ascontiguousarray(Rlr, np.float32).reshape(9), np.ascontiguousarray(tlr, np.float32).reshape(3)
+        nl, nr = kpL.shape[0], kpR.shape[0]
+        l2r, r2l = np.zeros(max(nl, 1), np.int32), np.zeros(max(nr, 1), np.int32)
+        depth, p3d = np.zeros(max(nl, 1), np.float32), np.zeros((max(nl, 1), 3), np.float32)
+        nm = C.c_int32()
+        check(self.L.pli_stereo_fisheye_tables(self.h, ptr(kpL), ptr(descL), nl, int(mono_left), ptr(kpR), ptr(descR), nr, int(mono_right),
+                                               ptr(c1), ptr(c2), ptr(R), ptr(t), ptr(l2r), ptr(r2l), ptr(depth), ptr(p3d), C.byref(nm)))
+        return nm.value, l2r[:nl], r2l[:nr], depth[:nl], p3d[:nl]
+
     def stereo_from_depth(self, depth):
         """Frame::ComputeStereoFromRGBD (Frame.cc:1309): (mvuRight, mvDepth) of the left keypoints from a float depth image."""
         d = np.ascontiguousarray(depth, np.float32)

@@ -705,9 +705,14 @@ def test_config5_4k(gpu):
     n2, kp2, desc2 = fe.orb_extract(1, R)
     assert kp2.tobytes() == kp.tobytes() and np.array_equal(desc2, desc)
     # LSD/LBD at 4K (4608 x 2592 scaled image, ~10 M seeds) against the oracle
-    m, kl, ld = fe.line_extract(0, L)
-    om, okl, old = fr.line_extract(0, L)
-    assert m == om == 500 and kl.tobytes() == okl.tobytes() and np.array_equal(ld, old)
+    for eye, img in ((0, L), (1, R)):
+        m, kl, ld = fe.line_extract(eye, img)
+        om, okl, old = fr.line_extract(eye, img)
+        assert m == om == 500 and kl.tobytes() == okl.tobytes() and np.array_equal(ld, old)
+    disp, le = fe.compute_stereo_matches_lines()
+    odisp, ole, _ = fr.stereo_lines()
+    assert disp[:len(odisp)].tobytes() == odisp.tobytes() and le[:len(ole)].tobytes() == ole.tobytes()
+    assert (odisp[:, 0] >= 0).sum() > 20
 
 
 def test_pipelined_host_entry_point(gpu):
@@ -838,3 +843,76 @@ def test_parity_flags_change_results(gpu):
         cfg = g.capi.default_config(W, H, orb_nfeatures=300, lsd_nfeatures=0, max_frames=1, parity_flags=flags)
         out[flags] = g.Frontend(cfg).batch_run_host(np.stack([L, R])[None])[0]["klL"]
     assert out[0].tobytes() != out[8].tobytes()
+
+
+# ---------------------------------------------------------------------------------------------
+# fisheye stereo — lapping-area ordering of the extractor + ComputeStereoFishEyeMatches
+# ---------------------------------------------------------------------------------------------
+# a KannalaBrandt8 camera whose r(theta) is the Taylor polynomial of tan(theta): pinhole-like, so that the synthetic
+# stream's horizontal disparities are consistent with the epipolar geometry of a pure x-baseline
+PINHOLE_KB8 = [435.2, 435.2, 367.2, 252.2, 1 / 3, 2 / 15, 17 / 315, 62 / 2835]
+TUMVI_KB8 = ([190.978477, 190.973307, 254.931706, 256.897442, 0.00348238940, 0.000715034845, -0.00205323614, 0.000202936736],
+             [190.442369, 190.434438, 252.597254, 254.917230, 0.00340031805, 0.00176627874, -0.00266312161, 0.000329951911])
+
+
+def test_fisheye_lapping_order_and_stereo(gpu):
+    """ORBextractor.cc:1135-1144 + Frame.cc:1577-1618 through pli_orb_extract_lapping / pli_stereo_fisheye: table order, mono
+    counts, mvLeftToRightMatch / mvRightToLeftMatch / mvDepth / mvStereo3Dpoints equal to the oracle's, bit for bit."""
+    g = gpu
+    W, H = 752, 480
+    cfg = g.capi.default_config(W, H, orb_nfeatures=1200, lsd_nfeatures=0)
+    fe = g.Frontend(cfg)
+    fr = g.po.Frame(ocfg(g, cfg))
+    sigma2 = fr.level_sigma2()
+    a = np.deg2rad(0.05)
+    Rlr = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)
+    tlr = np.array([0.11, 0.0004, -0.0003], np.float32)
+    total = 0
+    for seed, lapL, lapR in ((5, (90, 700), (30, 640)), (6, (0, 751), (0, 751)), (7, (300, 420), (280, 400)), (8, (0, 0), (0, 0))):
+        L, R = g.synth.make_stereo_pair(seed, W, H)
+        tabs = []
+        for eye, img, lap in ((0, L, lapL), (1, R, lapR)):
+            n, mono, kp, desc = fe.orb_extract_lapping(eye, img, lap)
+            on, okp, odesc = fr.orb_extract(eye, img)
+            order, omono = g.po.lapping_order(okp, lap[0], lap[1])
+            assert n == on and mono == omono
+            assert kp.tobytes() == okp[order].tobytes() and np.array_equal(desc, odesc[order])
+            tabs.append((kp, desc, mono))
+        (kpL, dL, mL), (kpR, dR, mR) = tabs
+        for cams in ((PINHOLE_KB8, PINHOLE_KB8), TUMVI_KB8):
+            nm, l2r, r2l, depth, p3d = fe.stereo_fisheye(cams[0], cams[1], Rlr, tlr, len(kpL), len(kpR))
+            onm, ol2r, or2l, odepth, op3d = g.po.stereo_fisheye(kpL, dL, mL, kpR, dR, mR, cams[0], cams[1], Rlr, tlr, sigma2)
+            assert nm == onm and np.array_equal(l2r, ol2r) and np.array_equal(r2l, or2l)
+            assert depth.tobytes() == odepth.tobytes() and p3d.tobytes() == op3d.tobytes()
+            assert (l2r[:mL] == -1).all() and (depth[l2r < 0] == -1).all() and (depth[l2r >= 0] > 0.0001).all()
+            if cams[0] is PINHOLE_KB8:
+                total += nm
+    assert total > 100                                  # the pinhole-like pair triangulates a real share of the lapping area
+
+
+def test_fisheye_stereo_on_constructed_tables(gpu):
+    """pli_stereo_fisheye_tables against the oracle on constructed two-view tables (known 3-D points through two TUM-VI-like
+    fisheye cameras, pixel noise, shuffled right table, a right keypoint wanted by two left ones), several seeds."""
+    g = gpu
+    from helpers_fisheye import fisheye_tables as _fisheye_tables
+    cfg = g.capi.default_config(512, 512, orb_nfeatures=500, lsd_nfeatures=0)
+    fe = g.Frontend(cfg)
+    sigma2 = g.po.Frame(ocfg(g, cfg)).level_sigma2()
+    a = np.deg2rad(2.0)
+    R = [[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]
+    t = [0.101, 0.002, -0.001]
+    for seed, noise, n in ((1, 0.0, 300), (2, 0.7, 300), (3, 1.5, 1000), (4, 3.0, 64)):
+        P1, kpL, dL, kpR, dR, mono, perm = _fisheye_tables(g.po, TUMVI_KB8[0], TUMVI_KB8[1], R, t, n=n, seed=seed, noise=noise)
+        # two left keypoints with the same descriptor: both take the same right keypoint, the later one keeps mvRightToLeftMatch
+        kpL = np.concatenate([kpL, kpL[mono + 3:mono + 4]]); dL = np.concatenate([dL, dL[mono + 3:mono + 4]])
+        got = fe.stereo_fisheye_tables(kpL, dL, mono, kpR, dR, mono, TUMVI_KB8[0], TUMVI_KB8[1], R, t)
+        exp = g.po.stereo_fisheye(kpL, dL, mono, kpR, dR, mono, TUMVI_KB8[0], TUMVI_KB8[1], R, t, sigma2)
+        assert got[0] == exp[0] and np.array_equal(got[1], exp[1]) and np.array_equal(got[2], exp[2])
+        assert got[3].tobytes() == exp[3].tobytes() and got[4].tobytes() == exp[4].tobytes()
+        if noise == 0.0:
+            assert got[0] == n + 1 and got[2][got[1][mono + 3]] == len(kpL) - 1
+    # empty lapping areas and a single right candidate
+    got = fe.stereo_fisheye_tables(kpL, dL, len(kpL), kpR, dR, mono, TUMVI_KB8[0], TUMVI_KB8[1], R, t)
+    assert got[0] == 0 and (got[1] == -1).all() and (got[3] == -1).all()
+    got = fe.stereo_fisheye_tables(kpL, dL, mono, kpR, dR, len(kpR) - 1, TUMVI_KB8[0], TUMVI_KB8[1], R, t)
+    assert got[0] == 0

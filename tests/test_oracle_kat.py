@@ -362,3 +362,65 @@ def test_lsd_f64_pipeline_primitives(oracle):
     s = f.lsd_scaled64(0)
     d = np.diff(s[10, 8:40])
     assert np.abs(d - d.mean()).max() < 1e-2 and abs(d.mean() - 5 / 1.2) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------
+# fisheye stereo (KannalaBrandt8 + ComputeStereoFishEyeMatches), lapping order
+# ---------------------------------------------------------------------------------------------
+TUMVI_CAM1 = [190.978477, 190.973307, 254.931706, 256.897442, 0.00348238940, 0.000715034845, -0.00205323614, 0.000202936736]
+TUMVI_CAM2 = [190.442369, 190.434438, 252.597254, 254.917230, 0.00340031805, 0.00176627874, -0.00266312161, 0.000329951911]
+
+
+def test_kb8_unproject_project_round_trip(oracle):
+    """unproject (Newton, KannalaBrandt8.cpp:103-130) then project (:28-42) returns the pixel; with k = 0 the model is the
+    equidistant fisheye r = f * theta."""
+    rng = np.random.default_rng(4)
+    for rad, phi in zip(rng.uniform(1, 230, 50), rng.uniform(0, 2 * np.pi, 50)):     # (beyond ~290 px the ray is past 90 degrees)
+        u, v = TUMVI_CAM1[2] + rad * np.cos(phi), TUMVI_CAM1[3] + rad * np.sin(phi)
+        r = oracle.kb8_unproject(TUMVI_CAM1, u, v)
+        assert r[2] == 1.0
+        uv = oracle.kb8_project(TUMVI_CAM1, r * np.float32(3.0))
+        assert np.abs(uv - np.array([u, v], np.float32)).max() < 2e-3
+    eq = [100.0, 100.0, 0.0, 0.0, 0, 0, 0, 0]
+    uv = oracle.kb8_project(eq, [np.tan(0.5), 0.0, 1.0])
+    assert abs(uv[0] - 50.0) < 1e-4 and abs(uv[1]) < 1e-6
+    assert oracle.kb8_unproject(eq, 0.0, 0.0).tolist() == [0.0, 0.0, 1.0]              # theta_d <= 1e-8: scale stays 1
+
+
+from helpers_fisheye import fisheye_tables as _fisheye_tables  # noqa: E402
+
+
+def test_fisheye_stereo_triangulation(oracle):
+    """ComputeStereoFishEyeMatches (Frame.cc:1577-1618): every constructed pair is found, its depth is the z of the 3-D point
+    (noise-free: 1e-3 relative), mvRightToLeftMatch is the inverse; a pair without parallax and a point behind the
+    camera are refused."""
+    a = np.deg2rad(2.0)
+    R = [[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]
+    t = [0.101, 0.002, -0.001]
+    sigma2 = np.array([1.0, 1.44, 2.0736], np.float32)
+    P1, kpL, dL, kpR, dR, mono, perm = _fisheye_tables(oracle, TUMVI_CAM1, TUMVI_CAM2, R, t, noise=0.0)
+    n, l2r, r2l, depth, p3d = oracle.stereo_fisheye(kpL, dL, mono, kpR, dR, mono, TUMVI_CAM1, TUMVI_CAM2, R, t, sigma2)
+    assert n == len(P1) and (l2r[:mono] == -1).all() and (depth[:mono] == -1).all()
+    inv = np.empty(len(perm), np.int64); inv[perm - mono] = np.arange(len(perm))        # left i -> right row
+    assert np.array_equal(l2r[mono:], mono + inv)
+    assert np.array_equal(r2l[l2r[mono:]], np.arange(mono, mono + len(P1)))
+    assert np.abs(depth[mono:] / P1[:, 2] - 1).max() < 1e-3 and np.abs(p3d[mono:] - P1).max() < 5e-3
+    # with pixel noise most pairs survive the 5.991 sigma^2 gate, not all
+    P1, kpL, dL, kpR, dR, mono, perm = _fisheye_tables(oracle, TUMVI_CAM1, TUMVI_CAM2, R, t, noise=1.2, seed=5)
+    n2 = oracle.stereo_fisheye(kpL, dL, mono, kpR, dR, mono, TUMVI_CAM1, TUMVI_CAM2, R, t, sigma2)[0]
+    assert 0.3 * len(P1) < n2 < len(P1)
+    # no parallax (zero baseline): cosParallaxRays > 0.9998 for every pair
+    P1, kpL, dL, kpR, dR, mono, perm = _fisheye_tables(oracle, TUMVI_CAM1, TUMVI_CAM1, np.eye(3), [0, 0, 0], noise=0.0)
+    assert oracle.stereo_fisheye(kpL, dL, mono, kpR, dR, mono, TUMVI_CAM1, TUMVI_CAM1, np.eye(3), [0, 0, 0], sigma2)[0] == 0
+    # fewer than two right candidates: knnMatch returns rows of size < 2 -> nothing
+    assert oracle.stereo_fisheye(kpL, dL, mono, kpR[:mono + 1], dR[:mono + 1], mono, TUMVI_CAM1, TUMVI_CAM1, R, t, sigma2)[0] == 0
+
+
+def test_lapping_order_hand_case(oracle):
+    """ORBextractor.cc:1135-1144: lapping keypoints fill the table from the back in visiting order."""
+    kp = np.zeros(6, oracle.KEYPOINT_DT)
+    kp["x"] = [5, 100, 7, 300, 250, 9]
+    order, mono = oracle.lapping_order(kp, 100, 300)
+    assert mono == 3 and order.tolist() == [0, 2, 5, 4, 3, 1]
+    order, mono = oracle.lapping_order(kp, 0, 0)                      # the rectified pipeline: nothing in [0, 0]
+    assert mono == 6 and order.tolist() == [0, 1, 2, 3, 4, 5]

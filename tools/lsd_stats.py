@@ -11,7 +11,7 @@ fe = Frontend(cfg)
 uniq = np.stack([np.stack(synth.make_stereo_pair(s_, 752, 480)) for s_ in range(min(F, 32))])
 frames = uniq[np.arange(F) % len(uniq)]
 fe.batch_run_host(frames)
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 24)()
 fe.L.pli_lsd_stats(out)
 fe.L.pli_lsd_stats_max.restype = C.c_ulonglong
 fe.L.pli_lsd_stats_max()

@@ -12,7 +12,7 @@ fe = Frontend(cfg)
 uniq = np.stack([np.stack(synth.make_stereo_pair(s_, 752, 480)) for s_ in range(min(F, 32))])
 frames = uniq[np.arange(F) % len(uniq)]
 fe.batch_run_host(frames)
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 24)()
 fe.L.pli_lsd_stats(out)
 fe.L.pli_lsd_stats_max.restype = C.c_ulonglong
 fe.L.pli_lsd_stats_max()
@@ -27,3 +27,7 @@ for k in sorted(names):
 print("%-36s %10.3f Mcycles (mean %.3f)" % ("slowest image wave", mx / 1e6, out[8] / n / 1e6))
 for k, nme in ((9, "fill"), (10, "speculation"), (11, "validation"), (12, "resolution (incl. region2rect)"), (13, "region2rect")):
     print("%-36s %10.3f Mcycles per image (%.1f %%)" % (nme, out[k] / n / 1e6, 100.0 * out[k] / max(out[8], 1)))
+for k, nme in ((16, "batch fetch (issue -> data)"), (17, "batch accept loop")):
+    print("%-36s %10.3f Mcycles per image (%.1f %%)" % (nme, out[k] / n / 1e6, 100.0 * out[k] / max(out[8], 1)))
+print("%-36s %10.1f per image" % ("entries popped by batches", out[18] / n))
+print("%-36s %10.1f per image" % ("accept-loop iterations", out[19] / n))
