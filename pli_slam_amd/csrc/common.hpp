@@ -121,6 +121,9 @@ struct TrackParams {
   int64_t trackBytes, toffCounts, toffBest, toffLines;
 };
 
+// a region handed from the sequential LSD grower to k_lsd_rect: its pixel list in the image's arena and its angle
+struct LsdRectItem { int off, cnt; double reg_angle; };
+
 // KannalaBrandt8 parameters (pli_kb8_camera), by value (match_kernels.hip: k_fisheye_triangulate)
 struct Kb8 { float fx, fy, cx, cy, k0, k1, k2, k3; };
 

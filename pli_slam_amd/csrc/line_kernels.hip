@@ -273,6 +273,7 @@ __device__ __forceinline__ uint2 lsd_lds_read2(const uint2* p) {
 
 // (the LDS read is unconditional so that it stays a ds_read instead of a flat load)
 __device__ __forceinline__ uint2 lsd_qget(const uint2* qs, const uint2* qg, int k, int qcap = LSD_QCAP) {
+  if (qcap == 0) return qg[k];                          // (k_lsd_rect: the whole list is in global memory)
   uint2 e = lsd_lds_read2(&qs[min(k, qcap - 1)]);
   if (k >= qcap) e = qg[k - qcap];
   return e;
@@ -611,6 +612,76 @@ __device__ __forceinline__ void lsd_grow_image(const DevParams* __restrict__ Pp,
 
 
 // ---------------------------------------------------------------------------
+// The accept loop of a batched step, hand-scheduled (the compiler's rendering of the same loop carries ~48 instructions and
+// seven branches per accepted pixel; this one 15 VALU + 13 SALU and three not-taken branches).  State: the float sums
+// (replicated in every lane), `remaining` (candidates not yet decided, lane order = test order), `acc` (lanes accepted so far
+// in this batch: they are accepted in increasing lane order, so a lane's queue slot is cnt0 + its rank in acc), cnt.
+// Per iteration: vector filter of every candidate against the current sums (lo: "maybe aligned", hi: "surely aligned", see
+// lsd_grow_image), first maybe-lane j; if it is not sure the loop hands over to the exact test (return 1, `remaining` already
+// without the lanes up to j); else lane j is accepted: sums += (cos, sin)(j), the other copies of its pixel leave
+// `remaining`; if the pixel carries a speculation tag the caller must see it (return 2, pixel index in qj).
+// Return 0: no candidate left.  Wait states (gfx940 rules): a v_readlane result is used by a VALU instruction at least two
+// instructions later; VALU-written VCC is only read by SALU instructions (interlocked).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int lsd_accept_fast(float& sumdx, float& sumdy, float cosv, float sinv, int qi, unsigned long long& remaining,
+                                               unsigned long long& acc, int& cnt, unsigned long long tagMask, float lo, float hi,
+                                               int& j2, int& qj) {
+  int code, sc, ss;
+  float t0, t1, t2, t3;
+  unsigned long long m, sh;
+  // (wave-uniform values the register allocator may be holding in vector registers)
+  cnt = __builtin_amdgcn_readfirstlane(cnt);
+  lo = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(lo)));
+  hi = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hi)));
+  asm volatile(
+      "1:\n\t"
+      "v_mul_f32_e32 %[t0], %[sy], %[sy]\n\t"
+      "v_mul_f32_e32 %[t1], %[sy], %[sn]\n\t"
+      "v_fmac_f32_e32 %[t0], %[sx], %[sx]\n\t"
+      "v_fmac_f32_e32 %[t1], %[sx], %[cs]\n\t"
+      "v_mul_f32_e32 %[t2], %[lo], %[t0]\n\t"
+      "v_mul_f32_e64 %[t3], %[t1], |%[t1]|\n\t"
+      "v_mul_f32_e32 %[t0], %[hi], %[t0]\n\t"
+      "v_cmp_ge_f32_e32 vcc, %[t3], %[t2]\n\t"
+      "s_and_b64 %[m], vcc, %[rem]\n\t"
+      "s_cbranch_scc0 4f\n\t"
+      "v_cmp_ge_f32_e32 vcc, %[t3], %[t0]\n\t"
+      "s_ff1_i32_b64 %[j], %[m]\n\t"
+      "s_lshl_b64 %[sh], -2, %[j]\n\t"
+      "s_and_b64 %[rem], %[rem], %[sh]\n\t"
+      "s_bitcmp1_b64 vcc, %[j]\n\t"
+      "s_cbranch_scc0 5f\n\t"
+      "v_readlane_b32 %[sc], %[cs], %[j]\n\t"
+      "v_readlane_b32 %[ss], %[sn], %[j]\n\t"
+      "v_readlane_b32 %[q], %[qi], %[j]\n\t"
+      "s_bitset1_b64 %[acc], %[j]\n\t"
+      "s_add_i32 %[cnt], %[cnt], 1\n\t"
+      "v_add_f32_e32 %[sx], %[sc], %[sx]\n\t"
+      "v_add_f32_e32 %[sy], %[ss], %[sy]\n\t"
+      "v_cmp_eq_u32_e32 vcc, %[q], %[qi]\n\t"
+      "s_bitcmp1_b64 %[tag], %[j]\n\t"
+      "s_cbranch_scc1 6f\n\t"
+      "s_andn2_b64 %[rem], %[rem], vcc\n\t"
+      "s_cbranch_scc1 1b\n"
+      "4:\n\t"
+      "s_mov_b32 %[code], 0\n\t"
+      "s_branch 9f\n"
+      "5:\n\t"
+      "s_mov_b32 %[code], 1\n\t"
+      "s_branch 9f\n"
+      "6:\n\t"
+      "s_andn2_b64 %[rem], %[rem], vcc\n\t"
+      "s_mov_b32 %[code], 2\n"
+      "9:\n\t"
+      : [sx] "+v"(sumdx), [sy] "+v"(sumdy), [rem] "+s"(remaining), [acc] "+s"(acc), [cnt] "+s"(cnt), [code] "=&s"(code), [j] "=&s"(j2),
+        [q] "=&s"(qj), [sc] "=&s"(sc), [ss] "=&s"(ss), [m] "=&s"(m), [sh] "=&s"(sh), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+        [t3] "=&v"(t3)
+      : [cs] "v"(cosv), [sn] "v"(sinv), [qi] "v"(qi), [tag] "s"(tagMask), [lo] "s"(lo), [hi] "s"(hi)
+      : "vcc", "scc");
+  return code;
+}
+
+// ---------------------------------------------------------------------------
 // Speculative form of the sequential grower (lsd_grow_image_spec).  The sequential loop spends most of its round trips
 // on regions of a few pixels (on the EuRoC-shaped stream 34 000 of the 46 000 regions of an image stay below 9 pixels)
 // that a whole wave grows one after the other.  Here the wave first collects 64 LIVE seeds of the ordered list
@@ -638,7 +709,8 @@ template <int WPB>
 __device__ __forceinline__ void lsd_grow_image_spec(const DevParams* __restrict__ Pp, float4* __restrict__ recAll, const double* __restrict__ mgAll,
                                                     const int* __restrict__ orderAll, const int* __restrict__ nDefined,
                                                     uint2* __restrict__ regOverflow, float* __restrict__ segAll,
-                                                    int* __restrict__ nSeg, int maxSeg, int img0, int nimg) {
+                                                    int* __restrict__ nSeg, int maxSeg, int img0, int nimg,
+                                                    LsdRectItem* __restrict__ rectAll, double* __restrict__ rectWAll) {
   __shared__ uint2 qsAll[WPB][LSD_QCAP];
   __shared__ double stAll[WPB][3][64];
   const DevParams& P = *Pp;
@@ -665,13 +737,23 @@ __device__ __forceinline__ void lsd_grow_image_spec(const DevParams* __restrict_
   const int minReg = P.minRegSize;
   const double prec = P.prec, scale = P.lsdScale;
   const float alignLo = P.alignLo, alignHi = P.alignHi;
-  const bool useFilter = P.alignFilter != 0;
   const unsigned tag = (unsigned)(lane + 1);
   int cap = min(SPEC_CAP, minReg - 1);                  // a region that may yield a segment is never finished by a lane
   if (P.alignPad >> 4) cap = min(cap, P.alignPad >> 4);  // (dev switch PLI_LSD_SPEC_CAP)
   int nseg = 0;
   int pos = 0;
   int avgLive = 8;                                      // running estimate of live seeds per row of 64 list entries
+  // region2rect off the serial wave (rectAll != null): the pixel list of every region that yields a segment is left in the
+  // image's arena (= the overflow area: the lists of disjoint regions never exceed npix entries), entry apos.., and k_lsd_rect
+  // computes the segments afterwards, many regions at a time.  The overflow of the region being grown is written where its list
+  // will stay.
+  LsdRectItem* items = rectAll ? rectAll + (int64_t)img * maxSeg : nullptr;
+  // CV_64F pipeline: the weight of a pixel (its gradient norm) is a double in its own plane; the wave gathers the weights of
+  // a finished region (consecutive list entries are neighbours: few sectors per load) and leaves them beside the list, so that
+  // k_lsd_rect streams them instead of gathering one sector per pixel and lane
+  double* rectW = (rectAll && rectWAll && mgAll) ? rectWAll + img * npix : nullptr;
+  const double* mgImg = mgAll ? mgAll + img * npix : nullptr;
+  int apos = 0;
 #ifdef LSD_STATS
   unsigned long long stt[24] = {};
   const unsigned long long tKernel = LCLOCK();
@@ -896,14 +978,15 @@ __device__ __forceinline__ void lsd_grow_image_spec(const DevParams* __restrict_
         if (lane == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1) rec[sp].x = LSD_NOTDEF;
         qs[0] = make_uint2(((unsigned)ry << 16) | (unsigned)rx, (unsigned)sg2);
       }
-      bool angValid = cnt == 1;                          // (after the first accepted pixel the angle is a function of the sums)
+      int angCnt = cnt == 1 ? 1 : -1;                    // reg_angle is the angle of the sums at this pixel count (the seed angle at 1)
       LSTAT(1, 1); if (hand) LSTAT(2, 1);
       const int cntStart = cnt;
+      const int qoff = items ? apos : -SPEC_Q;           // queue entry k >= SPEC_Q lives at qg[qoff + k]
       auto step = [&](int k, auto spillTag) {
         constexpr bool SPILL = decltype(spillTag)::value;
         const int ndx = lane % 3 - 1, ndy = (lane / 3) % 3 - 1;   // lanes 0..8: raster order of the 3x3 block
         uint2 e = lsd_lds_read2(&qs[SPILL ? min(k, SPEC_Q - 1) : k]);
-        if (SPILL && k >= SPEC_Q) e = qg[k - SPEC_Q];
+        if (SPILL && k >= SPEC_Q) e = qg[qoff + k];
         e.x = __builtin_amdgcn_readfirstlane(e.x);
         e.y = __builtin_amdgcn_readfirstlane(e.y);
         const int px = (int)(e.x & 0xFFFFu), py = (int)(e.x >> 16);
@@ -915,10 +998,7 @@ __device__ __forceinline__ void lsd_grow_image_spec(const DevParams* __restrict_
         const bool cand = r.x != LSD_NOTDEF;
         const double ad = (double)r.x * D_DEG2RAD;
         unsigned long long remaining = __builtin_amdgcn_ballot_w64(cand);
-        if (!angValid) {
-          reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * D_DEG2RAD;
-          angValid = true;
-        }
+        if (angCnt != cnt) reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * D_DEG2RAD;
         while (remaining) {
           double n_theta = fabs(reg_angle - ad);
           if (n_theta > D_3_2_PI) {
@@ -934,15 +1014,21 @@ __device__ __forceinline__ void lsd_grow_image_spec(const DevParams* __restrict_
           const unsigned xyj = ((unsigned)(py + j2 / 3 - 1) << 16) | (unsigned)(px + j2 % 3 - 1);
           if (lane == j2) rec[qi].x = LSD_NOTDEF;
           if (!SPILL || cnt < SPEC_Q) qs[cnt] = make_uint2(xyj, wj & SPEC_G2MASK);           // same value from every active lane
-          else if (lane == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1) qg[cnt - SPEC_Q] = make_uint2(xyj, wj & SPEC_G2MASK);
+          else if (lane == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1) qg[qoff + cnt] = make_uint2(xyj, wj & SPEC_G2MASK);
           ++cnt;
           sumdx = __fadd_rn(sumdx, cj);
           sumdy = __fadd_rn(sumdy, sj);
           reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * D_DEG2RAD;
           if (wj >> 19) tagged(wj, qj);
         }
+        angCnt = cnt;                                       // (this form keeps the angle current)
         if (SPILL && cnt > SPEC_Q) __threadfence_block();   // overflow entries are read back through global memory
       };
+      // One round trip for up to 8 queue entries x 8 neighbours; the accept loop (lsd_accept_fast) walks the candidates in lane
+      // order = the order of the sequential tests.  The loop is what the wave spends its issue slots on (300 000 iterations per
+      // image), so it carries nothing that can wait: accepted lanes are only noted in a mask and write their USED mark and
+      // their queue entry after the loop; the tag of an accepted pixel is looked at only where a tag is known to sit (ballot
+      // before the loop); without the vector filter alignLo / alignHi are -inf / +inf (never sure, always maybe).
       auto batch = [&](int k, int nb) {
         const int pi = lane >> 3, ni = (lane & 7) < 4 ? (lane & 7) : (lane & 7) + 1;   // 8 neighbours, raster order, centre skipped
         const bool act = pi < nb;
@@ -960,44 +1046,42 @@ __device__ __forceinline__ void lsd_grow_image_spec(const DevParams* __restrict_
         const unsigned myxy = ((unsigned)ny << 16) | (unsigned)nx;
         const unsigned wbits = (unsigned)__float_as_int(r.w);
         unsigned long long remaining = __builtin_amdgcn_ballot_w64(cand);
+        const unsigned long long tagMask = __builtin_amdgcn_ballot_w64(cand && (wbits >> 19) != 0u);
+        unsigned long long acc = 0ull;                 // lanes accepted in this batch (in increasing lane order)
+        const int cnt0 = cnt;
         LSTAT(18, nb);
         while (remaining) {
-          LSTAT(19, 1);
-          const float n2 = __builtin_fmaf(sumdx, sumdx, sumdy * sumdy);
-          const float dot = __builtin_fmaf(sumdx, r.y, sumdy * r.z);
-          const float sd2 = dot * __builtin_fabsf(dot);
-          unsigned long long mm = __builtin_amdgcn_ballot_w64(sd2 >= alignLo * n2);
-          if (!useFilter) mm = ~0ull;
-          const unsigned long long m = mm & remaining;
-          if (!m) break;
-          const int j2 = __ffsll((long long)m) - 1;
-          remaining &= ~((2ull << j2) - 1ull);
-          unsigned long long sure = __builtin_amdgcn_ballot_w64(sd2 >= alignHi * n2);
-          if (!useFilter) sure = 0ull;
-          if (!((sure >> j2) & 1ull)) {
-            if (!angValid) {
+          int j2, qj;
+          const int code = lsd_accept_fast(sumdx, sumdy, r.y, r.z, qi, remaining, acc, cnt, tagMask, alignLo, alignHi, j2, qj);
+          if (code == 0) break;
+          if (code == 1) {
+            // lane j2 lies inside the margin of the vector filter: the reference's own expression decides
+            if (angCnt != cnt) {
               reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * D_DEG2RAD;
-              angValid = true;
+              angCnt = cnt;
             }
             double n_theta = fabs(reg_angle - (double)rl_f(r.x, j2) * D_DEG2RAD);
             if (n_theta > D_3_2_PI) {
               n_theta = fabs(n_theta - D_2PI);
             }
-            if (!(n_theta <= prec)) continue;
+            // (the sums live in vector registers: the compiler takes everything derived from them for lane-dependent; say that
+            // this decision is the same in every lane, or the loop state ends up in vector registers)
+            if (!__builtin_amdgcn_readfirstlane((int)(n_theta <= prec))) continue;
+            qj = rl_i(qi, j2);
+            const float cj = rl_f(r.y, j2), sj = rl_f(r.z, j2);
+            acc |= 1ull << j2;
+            remaining &= ~__builtin_amdgcn_ballot_w64(qi == qj);          // the other copies of the accepted pixel
+            ++cnt;
+            sumdx = __fadd_rn(sumdx, cj);
+            sumdy = __fadd_rn(sumdy, sj);
+            if (!((tagMask >> j2) & 1ull)) continue;
           }
-          const int qj = rl_i(qi, j2);
-          const float cj = rl_f(r.y, j2), sj = rl_f(r.z, j2);
-          const unsigned wj = (unsigned)rl_i((int)wbits, j2);
-          if (lane == j2) {                            // lane j2 is in the exec mask: it is a set bit of a ballot
-            rec[qi].x = LSD_NOTDEF;
-            qs[cnt] = make_uint2(myxy, wbits & SPEC_G2MASK);
-          }
-          remaining &= ~__builtin_amdgcn_ballot_w64(qi == qj);            // the other copies of the accepted pixel
-          ++cnt;
-          sumdx = __fadd_rn(sumdx, cj);
-          sumdy = __fadd_rn(sumdy, sj);
-          angValid = false;
-          if (wj >> 19) tagged(wj, qj);
+          tagged((unsigned)rl_i((int)wbits, j2), qj);
+        }
+        LSTAT(19, cnt - cnt0);
+        if ((acc >> lane) & 1ull) {
+          rec[qi].x = LSD_NOTDEF;
+          qs[cnt0 + __popcll(acc & ((1ull << lane) - 1ull))] = make_uint2(myxy, wbits & SPEC_G2MASK);
         }
         LTIME(17, tA);
       };
@@ -1015,9 +1099,27 @@ __device__ __forceinline__ void lsd_grow_image_spec(const DevParams* __restrict_
       }
       LSTAT(7, cnt - cntStart);
       if (cnt < minReg) continue;
-      if (!angValid) reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * D_DEG2RAD;
+      if (angCnt != cnt) reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * D_DEG2RAD;
       const unsigned long long tRect = LCLOCK();
-      lsd_region2rect(qs, qg, st, cnt, reg_angle, prec, scale, lane, seg, nseg, maxSeg, SPEC_Q, mgAll ? mgAll + img * npix : nullptr, W);
+      if (items) {
+        const int nl = min(cnt, SPEC_Q);
+        for (int i2 = lane; i2 < nl; i2 += 64) qg[apos + i2] = lsd_lds_read2(&qs[i2]);
+        if (rectW) {
+          if (cnt > SPEC_Q) __threadfence_block();
+          for (int i2 = lane; i2 < cnt; i2 += 64) {
+            const unsigned exy = i2 < SPEC_Q ? lsd_lds_read2(&qs[min(i2, SPEC_Q - 1)]).x : qg[apos + i2].x;
+            rectW[apos + i2] = mgImg[(int)(exy >> 16) * W + (int)(exy & 0xFFFFu)];
+          }
+        }
+        if (nseg < maxSeg && lane == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1) {
+          LsdRectItem it;
+          it.off = apos; it.cnt = cnt; it.reg_angle = reg_angle;
+          items[nseg] = it;
+        }
+        apos += cnt;
+      } else {
+        lsd_region2rect(qs, qg, st, cnt, reg_angle, prec, scale, lane, seg, nseg, maxSeg, SPEC_Q, mgAll ? mgAll + img * npix : nullptr, W);
+      }
       LTIME(13, tRect);
       ++nseg;
     }
@@ -1059,14 +1161,109 @@ __global__ __launch_bounds__(128) void k_lsd_grow2(const DevParams* __restrict__
 __global__ __launch_bounds__(64, 4) void k_lsd_grow_spec(const DevParams* __restrict__ Pp, float4* __restrict__ recAll, const double* __restrict__ mgAll,
                                                       const int* __restrict__ orderAll, const int* __restrict__ nDefined,
                                                       uint2* __restrict__ regOverflow, float* __restrict__ segAll,
-                                                      int* __restrict__ nSeg, int maxSeg, int img0, int nimg) {
-  lsd_grow_image_spec<1>(Pp, recAll, mgAll, orderAll, nDefined, regOverflow, segAll, nSeg, maxSeg, img0, nimg);
+                                                      int* __restrict__ nSeg, int maxSeg, int img0, int nimg, LsdRectItem* __restrict__ rectAll,
+    double* __restrict__ rectWAll) {
+  lsd_grow_image_spec<1>(Pp, recAll, mgAll, orderAll, nDefined, regOverflow, segAll, nSeg, maxSeg, img0, nimg, rectAll, rectWAll);
 }
 __global__ __launch_bounds__(128, 4) void k_lsd_grow2_spec(const DevParams* __restrict__ Pp, float4* __restrict__ recAll, const double* __restrict__ mgAll,
                                                         const int* __restrict__ orderAll, const int* __restrict__ nDefined,
                                                         uint2* __restrict__ regOverflow, float* __restrict__ segAll,
-                                                        int* __restrict__ nSeg, int maxSeg, int img0, int nimg) {
-  lsd_grow_image_spec<2>(Pp, recAll, mgAll, orderAll, nDefined, regOverflow, segAll, nSeg, maxSeg, img0, nimg);
+                                                        int* __restrict__ nSeg, int maxSeg, int img0, int nimg, LsdRectItem* __restrict__ rectAll,
+    double* __restrict__ rectWAll) {
+  lsd_grow_image_spec<2>(Pp, recAll, mgAll, orderAll, nDefined, regOverflow, segAll, nSeg, maxSeg, img0, nimg, rectAll, rectWAll);
+}
+
+// ---------------------------------------------------------------------------
+// k_lsd_rect: region2rect + segment end points (lsd.cpp region2rect / get_theta, refine = NONE) of the regions the sequential
+// grower left in the arena, off the grower's serial chain.  RECT_WPI waves per image; a wave takes 64 regions at a time, ONE
+// REGION PER LANE: the weighted sums are accumulated in list order by the lane (the same adds in the same order as the
+// sequential loop; three independent chains), the inertia pass likewise, the extent pass is order independent.  A region
+// longer than RECT_LANE_MAX pixels would hold its wave back: those are done afterwards by the whole wave
+// (lsd_region2rect, list-order sums by three lanes, products 64 at a time).
+// ---------------------------------------------------------------------------
+constexpr int RECT_WPI = 16;
+constexpr int RECT_LANE_MAX = 160;
+
+__global__ __launch_bounds__(64) void k_lsd_rect(const DevParams* __restrict__ Pp, const LsdRectItem* __restrict__ rectAll,
+                                                 const uint2* __restrict__ arenaAll, const double* __restrict__ mgAll,
+                                                 const double* __restrict__ rectWAll, const int* __restrict__ nSeg,
+                                                 float* __restrict__ segAll, int maxSeg, int img0) {
+  __shared__ double st[3][64];
+  const DevParams& P = *Pp;
+  const int img = blockIdx.y + img0, lane = threadIdx.x;
+  const int W = P.LW;
+  const int64_t npix = (int64_t)W * P.LH;
+  const int n = min(nSeg[img], maxSeg);
+  const LsdRectItem* items = rectAll + (int64_t)img * maxSeg;
+  const uint2* arena = arenaAll + img * npix;
+  const double* mg = mgAll ? mgAll + img * npix : nullptr;
+  const double* wlist = (mgAll && rectWAll) ? rectWAll + img * npix : nullptr;     // CV_64F pipeline: weights beside the lists
+  float* seg = segAll + (int64_t)img * maxSeg * 4;
+  const double prec = P.prec, scale = P.lsdScale;
+  for (int t0 = blockIdx.x * 64; t0 < n; t0 += RECT_WPI * 64) {
+    const int t = t0 + lane;
+    LsdRectItem it;
+    it.off = 0; it.cnt = 0; it.reg_angle = 0.0;
+    if (t < n) it = items[t];
+    const bool small = t < n && it.cnt <= RECT_LANE_MAX;
+    if (small) {
+      const uint2* lst = arena + it.off;
+      const double* wl = wlist ? wlist + it.off : nullptr;
+      auto weight = [&](const uint2 e, int k) -> double {
+        return wl ? wl[k] : mg ? mg[(int)(e.x >> 16) * W + (int)(e.x & 0xFFFFu)] : sqrt((double)(int)e.y / 4.0);
+      };
+      const int cnt = it.cnt;
+      double sx = 0.0, sy = 0.0, sw = 0.0;
+      for (int k = 0; k < cnt; ++k) {
+        const uint2 e = lst[k];
+        const double w = weight(e, k);
+        sx += (double)(int)(e.x & 0xFFFFu) * w;
+        sy += (double)(int)(e.x >> 16) * w;
+        sw += w;
+      }
+      const double x = sx / sw, y = sy / sw;
+      double Ixx = 0.0, Iyy = 0.0, Ixy = 0.0;
+      for (int k = 0; k < cnt; ++k) {
+        const uint2 e = lst[k];
+        const double w = weight(e, k);
+        const double dx = (double)(int)(e.x & 0xFFFFu) - x, dy = (double)(int)(e.x >> 16) - y;
+        Ixx += dy * dy * w;
+        Iyy += dx * dx * w;
+        Ixy -= dx * dy * w;
+      }
+      const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
+      const bool wide = fabs(Ixx) > fabs(Iyy);
+      double theta = (double)fast_atan2_deg(wide ? (float)(lambda - Ixx) : (float)Ixy, wide ? (float)Ixy : (float)(lambda - Iyy));
+      theta *= D_DEG2RAD;
+      if (lsd_angle_diff(theta, it.reg_angle) > prec) theta += D_PI;
+      double dxr, dyr;
+      sincos(theta, &dyr, &dxr);
+      double l_min = 0, l_max = 0;
+      for (int k = 0; k < cnt; ++k) {
+        const uint2 e = lst[k];
+        const double l = ((double)(int)(e.x & 0xFFFFu) - x) * dxr + ((double)(int)(e.x >> 16) - y) * dyr;
+        l_max = fmax(l_max, l);
+        l_min = fmin(l_min, l);
+      }
+      float4 o;
+      double e0 = x + l_min * dxr, e1 = y + l_min * dyr, e2 = x + l_max * dxr, e3 = y + l_max * dyr;
+      e0 += 0.5; e1 += 0.5; e2 += 0.5; e3 += 0.5;
+      if (scale != 1) { e0 /= scale; e1 /= scale; e2 /= scale; e3 /= scale; }
+      o.x = (float)e0; o.y = (float)e1; o.z = (float)e2; o.w = (float)e3;
+      reinterpret_cast<float4*>(seg)[t] = o;
+    }
+    // the long ones of this group of 64, one after the other, by the whole wave
+    unsigned long long big = __builtin_amdgcn_ballot_w64(t < n && !small);
+    while (big) {
+      const int j = __ffsll((long long)big) - 1;
+      big &= big - 1ull;
+      const int off = rl_i(it.off, j), cnt = rl_i(it.cnt, j);
+      const double ra = __longlong_as_double(((long long)rl_i(__double2hiint(it.reg_angle), j) << 32) |
+                                             (unsigned long long)(unsigned)rl_i(__double2loint(it.reg_angle), j));
+      lsd_wave_sync();
+      lsd_region2rect(nullptr, arena + off, st, cnt, ra, prec, scale, lane, seg, t0 + j, maxSeg, 0, mg, W);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------

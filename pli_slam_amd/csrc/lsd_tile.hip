@@ -252,7 +252,6 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
   const double prec = P.prec;
   const int minReg = P.minRegSize;
   const float alignLo = P.alignLo, alignHi = P.alignHi;
-  const bool useFilter = P.alignFilter != 0;
   const int pi = lane >> 3;
   const int nm = (lane & 7) < 4 ? (lane & 7) : (lane & 7) + 1;      // 8 neighbours, raster order, centre skipped
   const int ndx = nm % 3 - 1, ndy = nm / 3 - 1;
@@ -335,15 +334,13 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
             const float n2 = __builtin_fmaf(sumdx, sumdx, sumdy * sumdy);
             const float dot = __builtin_fmaf(sumdx, rr.y, sumdy * rr.z);
             const float sd2 = dot * __builtin_fabsf(dot);
-            unsigned long long mm = __builtin_amdgcn_ballot_w64(sd2 >= alignLo * n2);
-            if (!useFilter) mm = ~0ull;
-            const unsigned long long m = mm & remaining;
+            // (without the vector filter alignLo / alignHi are -inf / +inf: always maybe, never sure)
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(sd2 >= alignLo * n2) & remaining;
             if (!m) break;
             const int j2 = __ffsll((long long)m) - 1;
-            remaining &= ~((2ull << j2) - 1ull);
-            unsigned long long sure = __builtin_amdgcn_ballot_w64(sd2 >= alignHi * n2);
-            if (!useFilter) sure = 0ull;
-            if (!((sure >> j2) & 1ull)) {
+            remaining &= ~1ull << j2;
+            const unsigned long long sure = __builtin_amdgcn_ballot_w64(sd2 >= alignHi * n2);
+            if (__builtin_expect(!((sure >> j2) & 1ull), 0)) {
               if (!angValid) {
                 reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * TX_DEG2RAD;
                 angValid = true;
@@ -352,7 +349,8 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
               if (n_theta > TX_3_2_PI) {
                 n_theta = fabs(n_theta - TX_2PI);
               }
-              if (!(n_theta <= prec)) continue;
+              // (the sums live in vector registers, so the compiler takes this decision for lane-dependent: say it is not)
+              if (!__builtin_amdgcn_readfirstlane((int)(n_theta <= prec))) continue;
             }
             const int qj = tx_rl(qi, j2);
             const int xyj = tx_rl(myxy, j2);

@@ -88,6 +88,9 @@ struct pli_ctx {
   int rxLastRounds = 0; // rounds the relaxation ran in the previous call (where the host starts looking at the state)
   unsigned short* chunkHist = nullptr; int* chunkBase = nullptr; int* nDefined = nullptr;
   int* order = nullptr; uint2* regScratch = nullptr; float* seg = nullptr; int* nSeg = nullptr;
+  LsdRectItem* rectItems = nullptr;          // sequential grower -> k_lsd_rect (maxSeg per image)
+  double* rectW = nullptr;                   // CV_64F pipeline: the weights of the listed pixels, beside the lists
+  double* scaled64Dbg = nullptr;             // debug copy of the CV_64F scaled image (its plane is reused as the growers' arena)
   int nChunks = 0, maxSeg = 0;
   pli_keyline* tmpKL = nullptr;
   short2* dxy = nullptr;           // Sobel (dx, dy) of level 0, interleaved
@@ -314,8 +317,9 @@ pli_status buildGeometry(pli_ctx* c) {
     const double margin = 0.05 * 3.14159265358979323846 / 180;
     P.alignFilter = (P.prec + margin < 1.5) && (P.prec - margin > 0.01);
     const double cl = std::cos(P.prec + margin), ch = std::cos(P.prec - margin);
-    P.alignLo = P.alignFilter ? (float)(cl * cl * (1 - 1e-5)) : 0.f;
-    P.alignHi = P.alignFilter ? (float)(ch * ch * (1 + 1e-5)) : 0.f;
+    // (without the filter: every candidate is a "maybe", none is "sure")
+    P.alignLo = P.alignFilter ? (float)(cl * cl * (1 - 1e-5)) : -INFINITY;
+    P.alignHi = P.alignFilter ? (float)(ch * ch * (1 + 1e-5)) : INFINITY;
     P.alignPad = 0;                                       // dev switches of the speculative grower
     if (const char* e = getenv("PLI_LSD_SPEC")) P.alignPad = atoi(e) == 3 ? 1 : atoi(e) == 4 ? 3 : 0;
     if (const char* e = getenv("PLI_LSD_SPEC_CAP")) P.alignPad |= std::max(0, std::min(8, atoi(e))) << 4;
@@ -541,6 +545,8 @@ pli_status allocAll(pli_ctx* c) {
   A(c->regScratch, npix * NI);
   c->maxSeg = (int)(npix / std::max(P.minRegSize, 1)) + 64;   // a region needs minRegSize pixels: no image can yield more segments
   A(c->seg, (size_t)NI * c->maxSeg * 4);
+  A(c->rectItems, (size_t)NI * c->maxSeg);
+  if (c->lsdF64) A(c->rectW, npix * NI);
   A(c->nSeg, NI);
   A(c->tmpKL, (size_t)NI * P.maxLines);
   A(c->dxy, (size_t)P.W * P.H * NI);
@@ -646,6 +652,9 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       LAUNCH(c, "k_blur_lsd", k_lsd_blur64, gb, dim3(256), 0, c->pyr + P.lv[0].offset, P.pyrBlock, P.W, P.H, P.lv[0].pitch,
              c->kern64, 0, scaled64, img0);
     }
+    if (c->debug && c->scaled64Dbg)                    // the plane becomes the growers' arena: keep a copy for PLI_DBG_LSD_SCALED
+      HIPCHK(hipMemcpyAsync(c->scaled64Dbg + (int64_t)img0 * npix, scaled64 + (int64_t)img0 * npix, (size_t)nimg * npix * 8,
+                            hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipMemsetAsync(c->maxMg + img0, 0, sizeof(unsigned long long) * nimg, c->stream));
     LAUNCH(c, "k_lsd_grad", k_lsd_grad64, dim3((P.LW + 255) / 256, (P.LH + 15) / 16, nimg), dim3(256), 0, scaled64, P.LW, P.LH, P.rho,
            c->rec, c->mg, ownPlane, c->maxMg, c->debug ? c->angDbg : (float*)nullptr, img0, trigF32);
@@ -680,18 +689,23 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     // speculative form (line_kernels.hip: lsd_grow_image_spec): the small regions of 64 seeds at a time, one per lane
     const bool spec = c->lsdSpec && P.minRegSize >= 2;
     const bool two = nimg >= 64 && !getenv("PLI_GROW_WPB1");
+    // region2rect off the grower's serial chain: the spec grower leaves the pixel lists in the arena, k_lsd_rect does the segments
+    LsdRectItem* items = (spec && getenv("PLI_LSD_RECT_OFFLOAD")) ? c->rectItems : (LsdRectItem*)nullptr;      // dev switch: measured, not a gain
     if (two && spec)
       LAUNCH(c, "k_lsd_grow2", k_lsd_grow2_spec, dim3((nimg + 1) / 2), dim3(128), 0, c->dP, c->rec, c->mg, c->order, c->nDefined,
-             c->regScratch, c->seg, c->nSeg, c->maxSeg, img0, nimg);
+             c->regScratch, c->seg, c->nSeg, c->maxSeg, img0, nimg, items, c->rectW);
     else if (two)
       LAUNCH(c, "k_lsd_grow2", k_lsd_grow2, dim3((nimg + 1) / 2), dim3(128), 0, c->dP, c->rec, c->mg, c->order, c->nDefined,
              c->regScratch, c->seg, c->nSeg, c->maxSeg, img0, nimg);
     else if (spec)
       LAUNCH(c, "k_lsd_grow", k_lsd_grow_spec, dim3(nimg), dim3(64), 0, c->dP, c->rec, c->mg, c->order, c->nDefined,
-             c->regScratch, c->seg, c->nSeg, c->maxSeg, img0, nimg);
+             c->regScratch, c->seg, c->nSeg, c->maxSeg, img0, nimg, items, c->rectW);
     else
       LAUNCH(c, "k_lsd_grow", k_lsd_grow, dim3(nimg), dim3(64), 0, c->dP, c->rec, c->mg, c->order, c->nDefined,
              c->regScratch, c->seg, c->nSeg, c->maxSeg, img0, nimg);
+    if (items)
+      LAUNCH(c, "k_lsd_rect", k_lsd_rect, dim3(16, nimg), dim3(64), 0, c->dP, (const LsdRectItem*)items, (const uint2*)c->regScratch,
+             (const double*)c->mg, (const double*)c->rectW, (const int*)c->nSeg, c->seg, c->maxSeg, img0);     // 16 = RECT_WPI
   } else {
     const bool trace = getenv("PLI_RX_TRACE") != nullptr;
     const bool fullPasses = getenv("PLI_RX_FULL") != nullptr;      // dev: full-image bookkeeping in every round
@@ -1755,6 +1769,7 @@ pli_status pli_debug_enable(pli_ctx* c, int32_t on) {
     pli_status st;
     if ((st = c->dalloc(&c->angDbg, (size_t)c->hp.LW * c->hp.LH * c->NI)) != PLI_OK) return st;
     if ((st = c->dalloc(&c->lbdFloat, (size_t)c->NI * c->hp.klCap * 72)) != PLI_OK) return st;
+    if (c->lsdF64 && (st = c->dalloc(&c->scaled64Dbg, (size_t)c->hp.LW * c->hp.LH * c->NI)) != PLI_OK) return st;
   }
   c->debug = on != 0;
   return PLI_OK;
@@ -1794,9 +1809,11 @@ pli_status pli_debug_fetch(pli_ctx* c, int32_t image, int32_t what, int32_t arg,
       return PLI_OK;
     }
     case PLI_DBG_LSD_SCALED: {
-      if (c->lsdF64) {     // CV_64F pipeline: doubles (the plane lives in the grower's overflow area: fetch before anything overwrites it)
+      if (c->lsdF64) {     // CV_64F pipeline: doubles (the debug copy: the plane itself is the growers' arena)
         if (!need((int64_t)P.LW * P.LH * 8)) return dst ? PLI_ERR_CAPACITY : PLI_OK;
-        HIPCHK(hipMemcpy(dst, reinterpret_cast<double*>(c->regScratch) + (int64_t)image * P.LW * P.LH, (size_t)P.LW * P.LH * 8, hipMemcpyDeviceToHost));
+        if (!c->scaled64Dbg) { g_err = "pli_debug_enable was not on during the run"; return PLI_ERR_STATE; }
+        const double* src64 = c->scaled64Dbg;
+        HIPCHK(hipMemcpy(dst, src64 + (int64_t)image * P.LW * P.LH, (size_t)P.LW * P.LH * 8, hipMemcpyDeviceToHost));
         return PLI_OK;
       }
       if (!need((int64_t)P.LW * P.LH)) return dst ? PLI_ERR_CAPACITY : PLI_OK;
