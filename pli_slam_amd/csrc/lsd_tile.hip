@@ -32,6 +32,13 @@ constexpr double TX_PI = 3.14159265358979323846;
 constexpr double TX_DEG2RAD = TX_PI / 180;
 constexpr double TX_3_2_PI = (3 * TX_PI) / 2;
 constexpr double TX_2PI = 2 * TX_PI;
+// 1: the claims of a step (returning atomicMin on the owner word) are waited for before the owner loads of the next step.
+// 0 (tried): non-returning claims, not waited for — the loads are issued by the same wave in program order and meet the
+// claims in the same L2 channel, so they still see them (all parity tests and fuzzers green), but with 32 tile waves per CU it
+// is slower (k_tx_grow 24.4 -> 26.8 ms at 256 frames; a hair faster at 32 frames): kept as a build switch.
+#ifndef TX_WAIT_CLAIMS
+#define TX_WAIT_CLAIMS 1
+#endif
 constexpr int TX_GQ = 1024;       // queue entries of a region kept in LDS
 constexpr int TX_BBLK = 256;      // arena block for the overflow of a large region's queue
 constexpr int TX_BMAXBLK = 128;   // => regions of up to TX_GQ + 32768 pixels
@@ -212,6 +219,78 @@ __global__ __launch_bounds__(1024) void k_tx_prep(RxCtl* __restrict__ ctl, int2*
 // ---------------------------------------------------------------------------
 // k_tx_grow: one wave per tile walks the tile's seeds in rank order.
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// The accept loop of a batched step, hand-scheduled like lsd_accept_fast (line_kernels.hip): the tile growers are bound by
+// the scalar unit (SQ counters at 256 frames: 188 000 SALU against 120 000 VALU instructions per tile wave, and one scalar
+// instruction per cycle and CU makes 73 % of the kernel's time), so the loop keeps 12 scalar instructions per accepted pixel.
+// State: the float sums, `remaining` (candidates not yet decided; lane order = test order), `acc` (lanes accepted in this
+// batch, in increasing lane order: a lane's queue slot is cnt0 + its rank in acc), `seeds` (live seeds of the current list
+// row: a seed whose pixel is taken leaves it), cnt, and the bounding box as packed 16-bit (y, x) minima / maxima.
+// Return 0: no candidate left; 1: lane j2 lies inside the margin of the vector filter and needs the exact test (`remaining`
+// already without the lanes up to j2).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int tx_accept_fast(float& sumdx, float& sumdy, float cosv, float sinv, int qi, int myxy, int seedPix,
+                                              unsigned long long& remaining, unsigned long long& acc, unsigned long long& seeds,
+                                              int& cnt, int& bmin, int& bmax, float lo, float hi, int& j2) {
+  int code, sc, ss, sq, sxy;
+  float t0, t1, t2, t3;
+  unsigned long long m, sh;
+  cnt = __builtin_amdgcn_readfirstlane(cnt);            // (wave-uniform values the register allocator may hold in vector registers)
+  lo = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(lo)));
+  hi = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hi)));
+  asm volatile(
+      "1:\n\t"
+      "v_mul_f32_e32 %[t0], %[sy], %[sy]\n\t"
+      "v_mul_f32_e32 %[t1], %[sy], %[sn]\n\t"
+      "v_fmac_f32_e32 %[t0], %[sx], %[sx]\n\t"
+      "v_fmac_f32_e32 %[t1], %[sx], %[cs]\n\t"
+      "v_mul_f32_e32 %[t2], %[lo], %[t0]\n\t"
+      "v_mul_f32_e64 %[t3], %[t1], |%[t1]|\n\t"
+      "v_mul_f32_e32 %[t0], %[hi], %[t0]\n\t"
+      "v_cmp_ge_f32_e32 vcc, %[t3], %[t2]\n\t"
+      "s_and_b64 %[m], vcc, %[rem]\n\t"
+      "s_cbranch_scc0 4f\n\t"
+      "v_cmp_ge_f32_e32 vcc, %[t3], %[t0]\n\t"
+      "s_ff1_i32_b64 %[j], %[m]\n\t"
+      "s_lshl_b64 %[sh], -2, %[j]\n\t"
+      "s_and_b64 %[rem], %[rem], %[sh]\n\t"
+      "s_bitcmp1_b64 vcc, %[j]\n\t"
+      "s_cbranch_scc0 5f\n\t"
+      "v_readlane_b32 %[sc], %[cs], %[j]\n\t"
+      "v_readlane_b32 %[ss], %[sn], %[j]\n\t"
+      "v_readlane_b32 %[q], %[qi], %[j]\n\t"
+      "v_readlane_b32 %[xy], %[mxy], %[j]\n\t"
+      "s_bitset1_b64 %[acc], %[j]\n\t"
+      "s_add_i32 %[cnt], %[cnt], 1\n\t"
+      "v_add_f32_e32 %[sx], %[sc], %[sx]\n\t"
+      "v_add_f32_e32 %[sy], %[ss], %[sy]\n\t"
+      "v_cmp_eq_u32_e32 vcc, %[q], %[sp]\n\t"
+      "v_pk_min_u16 %[bmin], %[bmin], %[xy]\n\t"
+      "s_andn2_b64 %[seeds], %[seeds], vcc\n\t"
+      "v_cmp_eq_u32_e32 vcc, %[q], %[qi]\n\t"
+      "v_pk_max_u16 %[bmax], %[bmax], %[xy]\n\t"
+      "s_andn2_b64 %[rem], %[rem], vcc\n\t"
+      "s_cbranch_scc1 1b\n"
+      "4:\n\t"
+      "s_mov_b32 %[code], 0\n\t"
+      "s_branch 9f\n"
+      "5:\n\t"
+      "s_mov_b32 %[code], 1\n"
+      "9:\n\t"
+      : [sx] "+v"(sumdx), [sy] "+v"(sumdy), [bmin] "+v"(bmin), [bmax] "+v"(bmax), [rem] "+s"(remaining), [acc] "+s"(acc),
+        [seeds] "+s"(seeds), [cnt] "+s"(cnt), [code] "=&s"(code), [j] "=&s"(j2), [q] "=&s"(sq), [xy] "=&s"(sxy), [sc] "=&s"(sc),
+        [ss] "=&s"(ss), [m] "=&s"(m), [sh] "=&s"(sh), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+      : [cs] "v"(cosv), [sn] "v"(sinv), [qi] "v"(qi), [mxy] "v"(myxy), [sp] "v"(seedPix), [lo] "s"(lo), [hi] "s"(hi)
+      : "vcc", "scc");
+  return code;
+}
+__device__ __forceinline__ int tx_pk_min_u16(int a, int b) {
+  return (int)((min((unsigned)a >> 16, (unsigned)b >> 16) << 16) | min((unsigned)a & 0xFFFFu, (unsigned)b & 0xFFFFu));
+}
+__device__ __forceinline__ int tx_pk_max_u16(int a, int b) {
+  return (int)((max((unsigned)a >> 16, (unsigned)b >> 16) << 16) | max((unsigned)a & 0xFFFFu, (unsigned)b & 0xFFFFu));
+}
+
 template <bool SPARSE>
 __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
                                              const float4* __restrict__ recAll, int2* __restrict__ ownAll,
@@ -294,11 +373,11 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
       const float sa = tx_rlf(srec.x, j);
       float sumdx = tx_rlf(scos, j), sumdy = tx_rlf(ssin, j);
       double reg_angle = (double)sa * TX_DEG2RAD;
-      bool angValid = true;
+      int angCnt = 1;                                     // reg_angle is the angle of the sums at this pixel count (the seed angle at 1)
       const int spy = sp / W, spx = sp - spy * W;
       q[0] = (spy << 16) | spx;                           // every lane stores the same value
       int cnt = 1, k = 0;
-      int bx0 = spx, bx1 = spx, by0 = spy, by1 = spy;
+      int bmin = (spy << 16) | spx, bmax = bmin;          // bounding box: packed 16-bit (y, x) minima / maxima
       int pendOld = 0x7FFFFFFF;
       bool dead = false;
       while (k < cnt && !dead) {
@@ -306,7 +385,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         // The claims of the previous step are returning atomics: their results are consumed here, before the owner
         // loads of this step are issued, so those loads see the region's own claims.
-        asm volatile("" ::"v"(pendOld) : "memory");
+        if (TX_WAIT_CLAIMS) asm volatile("" ::"v"(pendOld) : "memory");
         pendOld = 0x7FFFFFFF;
         bool accepted = false;
         int qi = -1, nb = 0;
@@ -329,6 +408,43 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
           const int prevv = ci ? oo.x : oo.y, curv = ci ? oo.y : oo.x;
           const bool cand = rr.x != TX_NOTDEF && !(prevv < r || curv <= r);
           unsigned long long remaining = __builtin_amdgcn_ballot_w64(cand);
+          if (!SPILL) {
+            // the usual case (the queue entries of this batch fit the LDS queue): tx_accept_fast; accepted lanes write their queue
+            // entries after the loop (they are accepted in increasing lane order)
+            unsigned long long acc = 0ull;
+            const int cnt0 = cnt;
+            while (remaining) {
+              int j2;
+              const int code = tx_accept_fast(sumdx, sumdy, rr.y, rr.z, qi, myxy, se.y, remaining, acc, unusedMask, cnt, bmin, bmax,
+                                              alignLo, alignHi, j2);
+              if (code == 0) break;
+              // lane j2 lies inside the margin of the vector filter: the reference's own expression decides
+              if (angCnt != cnt) {
+                reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * TX_DEG2RAD;
+                angCnt = cnt;
+              }
+              double n_theta = fabs(reg_angle - (double)tx_rlf(rr.x, j2) * TX_DEG2RAD);
+              if (n_theta > TX_3_2_PI) {
+                n_theta = fabs(n_theta - TX_2PI);
+              }
+              // (the sums live in vector registers, so the compiler takes this decision for lane-dependent: say it is not)
+              if (!__builtin_amdgcn_readfirstlane((int)(n_theta <= prec))) continue;
+              const int qj = tx_rl(qi, j2);
+              const int xyj = tx_rl(myxy, j2);
+              const float cj = tx_rlf(rr.y, j2), sj = tx_rlf(rr.z, j2);
+              acc |= 1ull << j2;
+              remaining &= ~__builtin_amdgcn_ballot_w64(qi == qj);          // the other copies of the accepted pixel
+              unusedMask &= ~__builtin_amdgcn_ballot_w64(se.y == qj);       // a seed of this row that was just taken
+              ++cnt;
+              bmin = tx_pk_min_u16(bmin, xyj);
+              bmax = tx_pk_max_u16(bmax, xyj);
+              sumdx = __fadd_rn(sumdx, cj);
+              sumdy = __fadd_rn(sumdy, sj);
+            }
+            accepted = (acc >> lane) & 1ull;
+            if (accepted) q[cnt0 + __popcll(acc & ((1ull << lane) - 1ull))] = myxy;
+            return;
+          }
           while (remaining) {
             // the alignment test in vector form with the exact expression inside the margin (see k_lsd_grow)
             const float n2 = __builtin_fmaf(sumdx, sumdx, sumdy * sumdy);
@@ -341,15 +457,14 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
             remaining &= ~1ull << j2;
             const unsigned long long sure = __builtin_amdgcn_ballot_w64(sd2 >= alignHi * n2);
             if (__builtin_expect(!((sure >> j2) & 1ull), 0)) {
-              if (!angValid) {
+              if (angCnt != cnt) {
                 reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * TX_DEG2RAD;
-                angValid = true;
+                angCnt = cnt;
               }
               double n_theta = fabs(reg_angle - (double)tx_rlf(rr.x, j2) * TX_DEG2RAD);
               if (n_theta > TX_3_2_PI) {
                 n_theta = fabs(n_theta - TX_2PI);
               }
-              // (the sums live in vector registers, so the compiler takes this decision for lane-dependent: say it is not)
               if (!__builtin_amdgcn_readfirstlane((int)(n_theta <= prec))) continue;
             }
             const int qj = tx_rl(qi, j2);
@@ -357,7 +472,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
             const float cj = tx_rlf(rr.y, j2), sj = tx_rlf(rr.z, j2);
             accepted = accepted || lane == j2;          // the claims are issued together after the loop
             remaining &= ~__builtin_amdgcn_ballot_w64(qi == qj);          // the other copies of the accepted pixel
-            if (!SPILL || cnt < TX_GQ) {
+            if (cnt < TX_GQ) {
               q[cnt] = xyj;                              // every active lane stores the same value
             } else {
               const int o = cnt - TX_GQ;
@@ -376,17 +491,19 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
               __threadfence_block();
             }
             ++cnt;
-            const int ax = xyj & 0xFFFF, ay = xyj >> 16;
-            bx0 = min(bx0, ax); bx1 = max(bx1, ax); by0 = min(by0, ay); by1 = max(by1, ay);
+            bmin = tx_pk_min_u16(bmin, xyj);
+            bmax = tx_pk_max_u16(bmax, xyj);
             sumdx = __fadd_rn(sumdx, cj);
             sumdy = __fadd_rn(sumdy, sj);
-            angValid = false;
             unusedMask &= ~__builtin_amdgcn_ballot_w64(se.y == qj);   // a seed of this row that was just taken
           }
         };
         if (cnt + 8 * 8 + 1 > TX_GQ) step(std::true_type{});
         else step(std::false_type{});
-        if (accepted) pendOld = __hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (accepted) {
+          if (TX_WAIT_CLAIMS) pendOld = __hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else (void)__hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         k += nb;
       }
       asm volatile("" ::"v"(pendOld) : "memory");
@@ -395,7 +512,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
       const bool first = lane == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1;   // the first ACTIVE lane
       if (first) {
         rgSize[r] = cnt;
-        rgBox[r] = make_int2((by0 << 16) | bx0, (by1 << 16) | bx1);
+        rgBox[r] = make_int2(bmin, bmax);
       }
       if (cnt >= minReg) {                              // the pixel list goes to k_rx_rect (region2rect)
         int off = 0, slot = 0;

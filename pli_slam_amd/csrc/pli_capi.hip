@@ -762,6 +762,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       TRL(c, "k_tx_sort", k_tx_sort, dim3(ntile, nimg), dim3(256), (size_t)ts * ts * 4, c->rankOf, c->order, c->own, c->txList,
           c->txTileCnt, P.LW, P.LH, ts, c->txNtx, c->txNty, img0);
       const bool fullRound2 = getenv("PLI_TX_FULL2") != nullptr;       // dev: regrow everything in round 2
+      const size_t txPad = getenv("PLI_TX_LDSPAD") ? (size_t)atoi(getenv("PLI_TX_LDSPAD")) : 0;   // dev: occupancy cap of the tile growers
       for (int t = 1; t <= maxRounds && !allDone; ++t) {
         curT = t;
         if (t == 2 && !fullRound2)
@@ -775,11 +776,11 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
               c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, t >= 3 ? 1 : 0);
           TRL(c, "k_tx_prep", k_tx_prep, dim3((P.LW + 31) / 32, (P.LH + 31) / 32, nimg), dim3(1024), 0, c->jrCtl, c->own, c->rankOf,
               c->rgDirty, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, t == 2 ? 1 : 0);
-          TRL(c, "k_tx_grow_sparse", k_tx_grow_sparse, dim3(ntile, nimg), dim3(64), 0, c->dP, c->jrCtl, c->rec, c->own, c->txList,
+          TRL(c, "k_tx_grow_sparse", k_tx_grow_sparse, dim3(ntile, nimg), dim3(64), txPad, c->dP, c->jrCtl, c->rec, c->own, c->txList,
               c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty, c->tileAct, c->tilesW, c->tilesH, c->arena,
               c->arenaCap, c->rects, c->rectCap, img0, t);
         } else {
-          TRL(c, "k_tx_grow", k_tx_grow, dim3(ntile, nimg), dim3(64), 0, c->dP, c->jrCtl, c->rec, c->own, c->txList,
+          TRL(c, "k_tx_grow", k_tx_grow, dim3(ntile, nimg), dim3(64), txPad, c->dP, c->jrCtl, c->rec, c->own, c->txList,
               c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty, c->tileAct, c->tilesW, c->tilesH, c->arena,
               c->arenaCap, c->rects, c->rectCap, img0, t);
         }
