@@ -81,6 +81,7 @@ def kernel_bytes_per_image(name, g, n_kp, n_l, W, H):
         "k_blur_lsd": 2 * P0,
         "k_resize_lsd": P0 + Pp,
         "k_lsd_grad": Pp + 16 * Pp,                   # scaled u8 read; angle/modgrad/cos/sin write
+        "k_lsd_front": P0 + 16 * Pp,                  # fused blur -> resize -> gradient of the CV_64F pipeline: u8 read; record write
         "k_lsd_hist": 4 * Pp,
         "k_lsd_scan": 0,
         "k_lsd_scatter": 8 * Pp,

@@ -112,4 +112,111 @@ __global__ __launch_bounds__(256) void k_lsd_grad64(const double* __restrict__ s
   }
 }
 
+// ---------------------------------------------------------------------------
+// k_lsd_front64: the three kernels above in one pass per 64 x 16 tile of the SCALED image (lsd_scale != 1): the u8 source
+// window of the tile (plus the blur radius) is staged in LDS, blurred there (rows, then columns: the same sums in the same
+// order as k_lsd_blur64), resized from LDS (the expressions of k_lsd_resize64) into a 65 x 17 tile of the scaled image, and
+// the gradient / level-line angle of the 64 x 16 pixels is written (k_lsd_grad64).  Neither the blurred nor the scaled
+// double plane goes to HBM: per scaled pixel the pass writes 24 B (record + norm) and reads ~0.8 B, where the three
+// kernels moved 8·(2·P0/P' + 2) + 24 = 51 B.  The host uses it when the source window of every tile fits FS_W x FS_H
+// (any scale >= 1; otherwise the separate kernels run) and debugging is off (PLI_DBG_LSD_SCALED wants the plane).
+// ---------------------------------------------------------------------------
+constexpr int FT_W = 64, FT_H = 16;        // scaled pixels per tile
+constexpr int FS_W = 64, FS_H = 20;        // blurred source window (columns, rows) a tile may need
+constexpr int FR = 3;                      // largest blur radius
+
+__global__ __launch_bounds__(256) void k_lsd_front64(const uint8_t* __restrict__ pyr, int64_t pyrBlock, int sw, int sh, int pitch,
+                                                     const double* __restrict__ kern, int radius, const int* __restrict__ tab,
+                                                     int dw, int dh, double rho, float4* __restrict__ rec, double* __restrict__ mg,
+                                                     int2* __restrict__ own, unsigned long long* __restrict__ maxMg, int img0,
+                                                     int trigF32) {
+  __shared__ uint8_t tile[FS_H + 2 * FR][FS_W + 2 * FR + 2];
+  __shared__ double rows[FS_H + 2 * FR][FS_W];               // row-filtered window; afterwards the scaled tile (scl)
+  __shared__ double blur[FS_H][FS_W];
+  static_assert((FT_H + 1) * (FT_W + 1) <= (FS_H + 2 * FR) * FS_W, "the scaled tile reuses the row buffer");
+  double (*scl)[FT_W + 1] = reinterpret_cast<double (*)[FT_W + 1]>(&rows[0][0]);
+  __shared__ unsigned long long wmax[4];
+  const int img = blockIdx.z + img0, tid = threadIdx.x;
+  const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
+  const uint8_t* src = pyr + (int64_t)img * pyrBlock;
+  const int r = radius, n = 2 * r + 1;
+  // scaled pixels of this tile (with the +1 halo of the 2x2 gradient), and the source window they read
+  const int x1 = min(x0 + FT_W, dw - 1), y1 = min(y0 + FT_H, dh - 1);          // last scaled column / row needed
+  const int sx0 = tab[x0], sx1 = min(tab[x1] + 1, sw - 1);
+  const int sy0 = min(max(tab[3 * dw + y0], 0), sh - 1), sy1 = min(max(tab[3 * dw + y1] + 1, 0), sh - 1);
+  const int cw = sx1 - sx0 + 1, ch = sy1 - sy0 + 1;                             // <= FS_W, FS_H (checked by the host)
+  const int tw = cw + 2 * r, th = ch + 2 * r;
+  // (thread = (column lx, row group ly): no division by the window width anywhere)
+  const int lx = tid & 63, ly = tid >> 6;
+  for (int ty = ly; ty < th; ty += 4) {
+    const int sy = reflect101(sy0 + ty - r, sh);
+    for (int tx = lx; tx < tw; tx += 64) tile[ty][tx] = src[(int64_t)sy * pitch + reflect101(sx0 + tx - r, sw)];
+  }
+  __syncthreads();
+  double k[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) k[i] = i < n ? kern[i] : 0.0;
+  if (lx < cw)
+    for (int ty = ly; ty < th; ty += 4) {
+      double s = k[0] * (double)tile[ty][lx];
+      for (int j = 1; j < n; ++j) s += k[j] * (double)tile[ty][lx + j];
+      rows[ty][lx] = s;
+    }
+  __syncthreads();
+  if (lx < cw)
+    for (int ty = ly; ty < ch; ty += 4) {
+      double s = k[r] * rows[ty + r][lx];
+      for (int j = 1; j <= r; ++j) s += k[r + j] * (rows[ty + r + j][lx] + rows[ty + r - j][lx]);
+      blur[ty][lx] = s;
+    }
+  __syncthreads();
+  const int nx = x1 - x0 + 1, ny = y1 - y0 + 1;
+  for (int tx = lx; tx < nx; tx += 64) {
+    const int dx = x0 + tx;
+    const int sx = tab[dx] - sx0, sxn = min(sx + sx0 + 1, sw - 1) - sx0;
+    const double a0 = (double)__int_as_float(tab[dw + 2 * dx]), a1 = (double)__int_as_float(tab[dw + 2 * dx + 1]);
+    for (int ty = ly; ty < ny; ty += 4) {
+      const int dy = y0 + ty;
+      const int sy = tab[3 * dw + dy];
+      const int sya = min(max(sy, 0), sh - 1) - sy0, syb = min(max(sy + 1, 0), sh - 1) - sy0;
+      const double b0 = (double)__int_as_float(tab[3 * dw + dh + 2 * dy]), b1 = (double)__int_as_float(tab[3 * dw + dh + 2 * dy + 1]);
+      const double t0 = blur[sya][sx] * a0 + blur[sya][sxn] * a1;
+      const double t1 = blur[syb][sx] * a0 + blur[syb][sxn] * a1;
+      scl[ty][tx] = t0 * b0 + t1 * b1;
+    }
+  }
+  __syncthreads();
+  unsigned long long m = 0ull;
+  for (int i = tid; i < FT_W * FT_H; i += 256) {
+    const int ty = i >> 6, tx = i & 63;
+    const int x = x0 + tx, y = y0 + ty;
+    if (x >= dw || y >= dh) continue;
+    double norm = 0.0;
+    float a = F64_NOTDEF, cx = 0.f, sy = 0.f;
+    if (x < dw - 1 && y < dh - 1) {
+      const double DA = scl[ty + 1][tx + 1] - scl[ty][tx];
+      const double BC = scl[ty][tx + 1] - scl[ty + 1][tx];
+      const double gx = DA + BC, gy = DA - BC;
+      norm = sqrt((gx * gx + gy * gy) / 4);
+      if (!(norm <= rho)) {
+        m = max(m, (unsigned long long)__double_as_longlong(norm));
+        a = fast_atan2_deg((float)gx, (float)(-gy));
+        sincos_of_float((float)((double)a * F64_DEG2RAD), trigF32 != 0, &sy, &cx);
+      }
+    }
+    const int64_t o = (int64_t)img * dw * dh + (int64_t)y * dw + x;
+    rec[o] = make_float4(a, cx, sy, 0.f);
+    mg[o] = norm;
+    if (own) own[o] = make_int2(0x7FFFFFFF, 0x7FFFFFFF);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+    if (m) atomicMax(&maxMg[img], m);
+  }
+}
+
 }  // namespace pli

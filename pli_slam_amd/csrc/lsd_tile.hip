@@ -33,9 +33,10 @@ constexpr double TX_DEG2RAD = TX_PI / 180;
 constexpr double TX_3_2_PI = (3 * TX_PI) / 2;
 constexpr double TX_2PI = 2 * TX_PI;
 // 1: the claims of a step (returning atomicMin on the owner word) are waited for before the owner loads of the next step.
-// 0 (tried): non-returning claims, not waited for — the loads are issued by the same wave in program order and meet the
-// claims in the same L2 channel, so they still see them (all parity tests and fuzzers green), but with 32 tile waves per CU it
-// is slower (k_tx_grow 24.4 -> 26.8 ms at 256 frames; a hair faster at 32 frames): kept as a build switch.
+// Tried: 0 = non-returning claims, not waited for, and 2 = returning claims consumed after the next step's loads are issued.
+// In both the loads are issued by the same wave in program order and meet the claims in the same L2 channel, so they still see
+// them (all parity tests and fuzzers green), but with 32 tile waves per CU both are slower (k_tx_grow 24.4 -> 26.8 / 26.7 ms
+// at 256 frames; a hair faster at 32 frames): kept as a build switch.
 #ifndef TX_WAIT_CLAIMS
 #define TX_WAIT_CLAIMS 1
 #endif
@@ -385,7 +386,8 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         // The claims of the previous step are returning atomics: their results are consumed here, before the owner
         // loads of this step are issued, so those loads see the region's own claims.
-        if (TX_WAIT_CLAIMS) asm volatile("" ::"v"(pendOld) : "memory");
+        if (TX_WAIT_CLAIMS == 1) asm volatile("" ::"v"(pendOld) : "memory");
+        const int pendPrev = pendOld;
         pendOld = 0x7FFFFFFF;
         bool accepted = false;
         int qi = -1, nb = 0;
@@ -405,6 +407,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
               oo = tx_load_own(&own[qi]);
             }
           }
+          if (TX_WAIT_CLAIMS == 2) asm volatile("" ::"v"(pendPrev) : "memory");   // (the claims return before the loads issued after them)
           const int prevv = ci ? oo.x : oo.y, curv = ci ? oo.y : oo.x;
           const bool cand = rr.x != TX_NOTDEF && !(prevv < r || curv <= r);
           unsigned long long remaining = __builtin_amdgcn_ballot_w64(cand);

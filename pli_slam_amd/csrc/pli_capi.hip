@@ -76,6 +76,7 @@ struct pli_ctx {
   // CV_64F pipeline of the LSD front (PLI_PARITY_LSD_F64, lsd_f64.hip)
   bool lsdF64 = false; double* mg = nullptr; unsigned long long* maxMg = nullptr; double* tmp64 = nullptr; double* kern64 = nullptr;
   int* lsdTab64 = nullptr; int lsdRadius = 0;
+  bool lsdFront64 = false;                   // the fused blur -> resize -> gradient pass applies (lsd_f64.hip: k_lsd_front64)
   int2* own = nullptr; RxSeed* smallSeeds = nullptr; RxSeed* bigSeeds = nullptr; int bigCap = 0;
   RxHand* hand = nullptr; int handCap = 0; RxRect* rects = nullptr; int rectCap = 0; int* rankOf = nullptr; int2* rgBox = nullptr; float4* rgSeg = nullptr; uint8_t* rgClean = nullptr;
   int* tileMin = nullptr; int* tileAct = nullptr; int* rgDirty = nullptr; int tilesW = 0, tilesH = 0; int* rxChunkCnt = nullptr; int rxChunks = 0;
@@ -488,6 +489,18 @@ pli_status allocAll(pli_ctx* c) {
       }
       A(c->lsdTab64, t.size());
       HIPCHK(hipMemcpy(c->lsdTab64, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+      // the fused front (k_lsd_front64) stages the source window of a 64 x 16 tile of the scaled image in LDS: 64 x 20 at most
+      bool fits = (int)h <= 3;
+      for (int x0 = 0; x0 < P.LW && fits; x0 += 64) {
+        const int x1 = std::min(x0 + 64, P.LW - 1);
+        fits = std::min(t[x1] + 1, P.W - 1) - t[x0] + 1 <= 64;
+      }
+      for (int y0 = 0; y0 < P.LH && fits; y0 += 16) {
+        const int y1 = std::min(y0 + 16, P.LH - 1);
+        const int a = std::min(std::max(t[3 * P.LW + y0], 0), P.H - 1), b = std::min(std::max(t[3 * P.LW + y1] + 1, 0), P.H - 1);
+        fits = b - a + 1 <= 20;
+      }
+      c->lsdFront64 = fits && !getenv("PLI_LSD_NOFUSE");
     }
   } else {
     A(c->g2, npix * NI);
@@ -643,6 +656,13 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     // the grower's overflow area (same size, not in use before the growers run).
     double* scaled64 = reinterpret_cast<double*>(c->regScratch);
     const dim3 gb((P.W + 63) / 64, (P.H + 15) / 16, nimg);
+    if (c->lsdFront64 && !c->debug) {
+      // blur -> resize -> gradient in one pass over LDS tiles: neither double plane goes to HBM
+      HIPCHK(hipMemsetAsync(c->maxMg + img0, 0, sizeof(unsigned long long) * nimg, c->stream));
+      LAUNCH(c, "k_lsd_front", k_lsd_front64, dim3((P.LW + 63) / 64, (P.LH + 15) / 16, nimg), dim3(256), 0, c->pyr + P.lv[0].offset,
+             P.pyrBlock, P.W, P.H, P.lv[0].pitch, c->kern64, c->lsdRadius, c->lsdTab64, P.LW, P.LH, P.rho, c->rec, c->mg, ownPlane,
+             c->maxMg, img0, trigF32);
+    } else {
     if (c->cfg.lsd_scale != 1) {
       LAUNCH(c, "k_blur_lsd", k_lsd_blur64, gb, dim3(256), 0, c->pyr + P.lv[0].offset, P.pyrBlock, P.W, P.H, P.lv[0].pitch,
              c->kern64, c->lsdRadius, c->tmp64, img0);
@@ -658,6 +678,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     HIPCHK(hipMemsetAsync(c->maxMg + img0, 0, sizeof(unsigned long long) * nimg, c->stream));
     LAUNCH(c, "k_lsd_grad", k_lsd_grad64, dim3((P.LW + 255) / 256, (P.LH + 15) / 16, nimg), dim3(256), 0, scaled64, P.LW, P.LH, P.rho,
            c->rec, c->mg, ownPlane, c->maxMg, c->debug ? c->angDbg : (float*)nullptr, img0, trigF32);
+    }
   } else {
     const uint8_t* scaled;
     int64_t sStride;
