@@ -407,6 +407,10 @@ def main():
         dom = max(prof.items(), key=lambda kv: kv[1][1]) if prof else (None, (0, 0.0))
         name, (calls, total_ms) = dom
         per_img = kernel_bytes_per_image(name, g, nfeat, nlines, W, H) if name else None
+        # a relaxation grower is launched once per round; ideally the rounds of a step together touch the angle / modgrad planes
+        # once, so the algorithmic bytes of ONE launch are that pass divided by the launches of the step
+        if per_img is not None and name in ("k_tx_grow_sparse", "k_rx_grow", "k_rx_grow_big", "k_rx_grow_wave"):
+            per_img = per_img / max(calls / max(args.steps, 1), 1.0)
         avg_s = (total_ms / max(calls, 1)) * 1e-3
         peak = 8000.0
         achieved = per_img * 2 * F / avg_s / 1e9 if (per_img is not None and avg_s > 0) else None

@@ -58,22 +58,34 @@ __device__ __forceinline__ int tx_rl(int v, int l) { return __builtin_amdgcn_rea
 __device__ __forceinline__ float tx_rlf(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
 // ---------------------------------------------------------------------------
-// k_tx_sort: the seeds of every tile in rank order.  One workgroup per tile: the ranks of the tile's pixels are
-// sorted in LDS (bitonic, ts*ts keys); list entry = (rank, pixel).  Also writes owner_0 = (rank, rank).
+// k_tx_sort: the seeds of every tile in rank order.  One workgroup of 256 threads per tile sorts the ranks of the tile's
+// pixels (bitonic network over ts*ts keys); list entry = (rank, pixel).  Also writes owner_0 = (rank, rank).
+// Thread t holds the KPT = ts*ts/256 consecutive keys t*KPT .. t*KPT+KPT-1 in registers: a compare distance j < KPT stays
+// inside the thread, j < 64*KPT pairs lanes of one wave (ds_bpermute, no LDS memory, no barrier), and only the 3 of the 78
+// stages (ts = 64) whose partner sits in another wave go through LDS — the earlier form did every stage there (6.6 ms at 256
+// frames).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tx_sort(const int* __restrict__ rankAll, const int* __restrict__ orderAll,
-                                                 int2* __restrict__ ownAll, int2* __restrict__ listAll,
-                                                 int* __restrict__ tileCntAll, int W, int H, int ts, int ntx, int nty, int img0) {
-  extern __shared__ unsigned keys[];
+template <int KPT>
+__device__ __forceinline__ void tx_sort_tile(const int* __restrict__ rankAll, const int* __restrict__ orderAll,
+                                             int2* __restrict__ ownAll, int2* __restrict__ listAll,
+                                             int* __restrict__ tileCntAll, int W, int H, int ts, int ntx, int nty, int img0,
+                                             unsigned* xch) {
   __shared__ int s_cnt;
   const int img = blockIdx.y + img0, tile = blockIdx.x, tid = threadIdx.x;
-  const int n2 = ts * ts;
+  constexpr int n2 = KPT * 256;
   const int tx0 = (tile % ntx) * ts, ty0 = (tile / ntx) * ts;
   const int64_t npix = (int64_t)W * H;
   const int* rank = rankAll + img * npix;
   int2* own = ownAll + img * npix;
   if (tid == 0) s_cnt = 0;
-  for (int i = tid; i < n2; i += 256) {
+  __syncthreads();
+  // coalesced read of the tile (element i = m*256 + tid), transposed to "KPT consecutive keys per thread" through LDS
+  // (padded by one word per 16: the strided side of the transposition is bank-conflict free)
+  auto pad = [](int i) -> int { return i + (i >> 4); };
+  int valid = 0;
+#pragma unroll
+  for (int m = 0; m < KPT; ++m) {
+    const int i = m * 256 + tid;
     const int x = tx0 + i % ts, y = ty0 + i / ts;
     unsigned k = 0xFFFFFFFFu;
     if (x < W && y < H) {
@@ -81,34 +93,78 @@ __global__ __launch_bounds__(256) void k_tx_sort(const int* __restrict__ rankAll
       if (r != TX_INF) {
         k = (unsigned)r;
         own[y * W + x] = make_int2(r, r);
+        ++valid;
       }
     }
-    keys[i] = k;
+    xch[pad(i)] = k;
   }
+  valid = wave_sum_i32(valid);
+  if ((tid & 63) == 0 && valid) atomicAdd(&s_cnt, valid);
   __syncthreads();
-  for (int k = 2; k <= n2; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < n2; i += 256) {
-        const int p = i ^ j;
-        if (p > i) {
-          const unsigned a = keys[i], b = keys[p];
-          const bool asc = (i & k) == 0;
-          if ((a > b) == asc) { keys[i] = b; keys[p] = a; }
+  unsigned key[KPT];
+#pragma unroll
+  for (int u = 0; u < KPT; ++u) key[u] = xch[pad(tid * KPT + u)];
+#pragma unroll
+  for (int k = 2; k <= n2; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {             // (fully unrolled: the register array needs constant indices)
+      if (j >= KPT) {
+        const int pt = j / KPT;                           // partner thread = tid ^ pt
+        const bool asc = ((tid * KPT) & k) == 0;           // (k > j >= KPT: the direction depends on the thread only)
+        const bool lower = (tid & pt) == 0;
+        const bool keepMin = lower == asc;
+        if (pt < 64) {
+#pragma unroll
+          for (int u = 0; u < KPT; ++u) {
+            const unsigned o = (unsigned)__shfl_xor((int)key[u], pt, 64);
+            key[u] = keepMin ? min(key[u], o) : max(key[u], o);
+          }
+        } else {
+          __syncthreads();
+#pragma unroll
+          for (int u = 0; u < KPT; ++u) xch[u * 256 + tid] = key[u];
+          __syncthreads();
+#pragma unroll
+          for (int u = 0; u < KPT; ++u) {
+            const unsigned o = xch[u * 256 + (tid ^ pt)];
+            key[u] = keepMin ? min(key[u], o) : max(key[u], o);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < KPT; ++u) {
+          if ((u & j) == 0) {
+            const bool asc = ((tid * KPT + u) & k) == 0;
+            const unsigned a = key[u], b = key[u | j];
+            const bool sw = (a > b) == asc;
+            key[u] = sw ? b : a;
+            key[u | j] = sw ? a : b;
+          }
         }
       }
-      __syncthreads();
-    }
-  int2* list = listAll + ((int64_t)img * ntx * nty + tile) * n2;
-  const int* order = orderAll + img * npix;
-  for (int i = tid; i < n2; i += 256) {
-    const unsigned k = keys[i];
-    if (k != 0xFFFFFFFFu) {
-      list[i] = make_int2((int)k, order[k]);
-      if (i + 1 == n2 || keys[i + 1] == 0xFFFFFFFFu) s_cnt = i + 1;
     }
   }
+  int2* list = listAll + ((int64_t)img * ntx * nty + tile) * n2;
+  const int* order = orderAll + img * npix;
   __syncthreads();
+#pragma unroll
+  for (int u = 0; u < KPT; ++u) xch[pad(tid * KPT + u)] = key[u];
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < KPT; ++m) {
+    const int i = m * 256 + tid;
+    const unsigned k = xch[pad(i)];
+    if (k != 0xFFFFFFFFu) list[i] = make_int2((int)k, order[k]);
+  }
   if (tid == 0) tileCntAll[(int64_t)img * ntx * nty + tile] = s_cnt;
+}
+
+__global__ __launch_bounds__(256) void k_tx_sort(const int* __restrict__ rankAll, const int* __restrict__ orderAll,
+                                                 int2* __restrict__ ownAll, int2* __restrict__ listAll,
+                                                 int* __restrict__ tileCntAll, int W, int H, int ts, int ntx, int nty, int img0) {
+  __shared__ unsigned xch[16 * 256 + 256];
+  if (ts == 64) tx_sort_tile<16>(rankAll, orderAll, ownAll, listAll, tileCntAll, W, H, ts, ntx, nty, img0, xch);
+  else tx_sort_tile<4>(rankAll, orderAll, ownAll, listAll, tileCntAll, W, H, ts, ntx, nty, img0, xch);
 }
 
 // ---------------------------------------------------------------------------

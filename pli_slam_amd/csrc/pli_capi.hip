@@ -780,7 +780,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     if (tile) {
       // tile-sequential relaxation (lsd_tile.hip): per-tile seed lists once, then rounds of one wave per tile
       const int ts = c->txTs, ntile = c->txNtx * c->txNty;
-      TRL(c, "k_tx_sort", k_tx_sort, dim3(ntile, nimg), dim3(256), (size_t)ts * ts * 4, c->rankOf, c->order, c->own, c->txList,
+      TRL(c, "k_tx_sort", k_tx_sort, dim3(ntile, nimg), dim3(256), 0, c->rankOf, c->order, c->own, c->txList,
           c->txTileCnt, P.LW, P.LH, ts, c->txNtx, c->txNty, img0);
       const bool fullRound2 = getenv("PLI_TX_FULL2") != nullptr;       // dev: regrow everything in round 2
       const size_t txPad = getenv("PLI_TX_LDSPAD") ? (size_t)atoi(getenv("PLI_TX_LDSPAD")) : 0;   // dev: occupancy cap of the tile growers
