@@ -1066,7 +1066,8 @@ pli_status pli_batch_run(pli_ctx* c, int32_t nframes, const uint8_t* dl, const u
   pli_status st;
   const int nimg = 2 * nframes;
   if ((st = runIngest(c, dl, dr, stride, frameStride, 0, nimg)) != PLI_OK) return st;
-  if (nimg < 256 && (stages & PLI_RUN_ORB) && (stages & PLI_RUN_LINES) && !c->syncDebug) {
+  static const int sideMax = getenv("PLI_SIDE_MAX") ? atoi(getenv("PLI_SIDE_MAX")) : 256;      // (dev: images below which the ORB chain runs beside the line chain)
+  if (nimg < sideMax && (stages & PLI_RUN_ORB) && (stages & PLI_RUN_LINES) && !c->syncDebug) {
     if (!c->aux) {
       HIPCHK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
       HIPCHK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));

@@ -916,3 +916,29 @@ def test_fisheye_stereo_on_constructed_tables(gpu):
     assert got[0] == 0 and (got[1] == -1).all() and (got[3] == -1).all()
     got = fe.stereo_fisheye_tables(kpL, dL, mono, kpR, dR, len(kpR) - 1, TUMVI_KB8[0], TUMVI_KB8[1], R, t)
     assert got[0] == 0
+
+
+@pytest.mark.parametrize("flags", [None, 0])
+def test_sequential_grower_dev_switches(gpu, flags, monkeypatch):
+    """The measured-and-shelved variants of the sequential LSD grower stay exact: region2rect off the wave (k_lsd_rect,
+    PLI_LSD_RECT_OFFLOAD), the plain (non-speculative) grower (PLI_LSD_SPEC=0) and the unfused CV_64F front (PLI_LSD_NOFUSE) —
+    in both detector pipelines (flags None = default CV_64F, 0 = CV_8U)."""
+    g = gpu
+    W, H = 752, 480
+    over = {} if flags is None else {"parity_flags": flags}
+    L, R = g.synth.make_stereo_pair(41, W, H)
+    ocfg_ = None
+    want = None
+    for env in ({}, {"PLI_LSD_RECT_OFFLOAD": "1"}, {"PLI_LSD_SPEC": "0"}, {"PLI_LSD_NOFUSE": "1"}):
+        for k in ("PLI_LSD_RECT_OFFLOAD", "PLI_LSD_SPEC", "PLI_LSD_NOFUSE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        cfg = g.capi.default_config(W, H, orb_nfeatures=300, lsd_nfeatures=0, max_frames=1, lsd_mode=2, **over)
+        fe = g.Frontend(cfg)
+        m, kl, ld = fe.line_extract(0, L)
+        if want is None:
+            fr = g.po.Frame(ocfg(g, cfg))
+            want = fr.line_extract(0, L)
+            assert want[0] > 500
+        assert m == want[0] and kl.tobytes() == want[1].tobytes() and np.array_equal(ld, want[2]), env
