@@ -120,29 +120,37 @@ __global__ __launch_bounds__(256) void k_rx_guess(const float4* __restrict__ rec
 
 // ---- round bookkeeping -------------------------------------------------------------------------
 // owner_{t-1} against owner_{t-2}: per 8x8 tile the lowest rank that takes part in a change
+// (RX_DIFF_ROWS rows of 8x8 cells per workgroup: with one row the grid is a million blocks of a few instructions at 256 frames
+// and the kernel is bound by the rate at which workgroups are dispatched)
+constexpr int RX_DIFF_ROWS = 4;
 __global__ __launch_bounds__(256) void k_rx_diff(RxCtl* __restrict__ ctl, const int2* __restrict__ ownAll,
                                                  int* __restrict__ tileMinAll, int* __restrict__ tileActAll, int W, int H,
                                                  int TW, int TH, int t, int img0) {
-  __shared__ int tmin[4];
+  __shared__ int tmin[RX_DIFF_ROWS][4];
   const int img = blockIdx.z + img0;
   RxCtl& c = ctl[img];
   if (c.state == 2) return;
   const int tid = threadIdx.x;
   if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { c.nSmall = 0; c.nBig = 0; c.nHand = 0; c.nextBig = 0; c.rectArena = 0ull; }
-  if (tid < 4) tmin[tid] = INT_MAX;
+  if (tid < 4 * RX_DIFF_ROWS) tmin[tid >> 2][tid & 3] = INT_MAX;
   __syncthreads();
-  const int x = blockIdx.x * 32 + (tid & 31), y = blockIdx.y * 8 + (tid >> 5);
+  const int x = blockIdx.x * 32 + (tid & 31);
   bool ch = false;
-  if (x < W && y < H) {
-    const int2 o = ownAll[(int64_t)img * W * H + y * W + x];
-    if (o.x != o.y) { ch = true; atomicMin(&tmin[(tid & 31) >> 3], min(o.x, o.y)); }
+#pragma unroll
+  for (int rr = 0; rr < RX_DIFF_ROWS; ++rr) {
+    const int y = (blockIdx.y * RX_DIFF_ROWS + rr) * 8 + (tid >> 5);
+    if (x < W && y < H) {
+      const int2 o = ownAll[(int64_t)img * W * H + y * W + x];
+      if (o.x != o.y) { ch = true; atomicMin(&tmin[rr][(tid & 31) >> 3], min(o.x, o.y)); }
+    }
   }
   const int any = __syncthreads_or(ch ? 1 : 0);
-  if (tid < 4) {
-    const int tx = blockIdx.x * 4 + tid;
-    if (tx < TW) {
-      tileMinAll[(int64_t)img * TW * TH + blockIdx.y * TW + tx] = tmin[tid];
-      if (tmin[tid] != INT_MAX) tileActAll[(int64_t)img * TW * TH + blockIdx.y * TW + tx] = t;   // a changed tile is active
+  if (tid < 4 * RX_DIFF_ROWS) {
+    const int tx = blockIdx.x * 4 + (tid & 3), ty = blockIdx.y * RX_DIFF_ROWS + (tid >> 2);
+    if (tx < TW && ty < TH) {
+      const int v = tmin[tid >> 2][tid & 3];
+      tileMinAll[(int64_t)img * TW * TH + ty * TW + tx] = v;
+      if (v != INT_MAX) tileActAll[(int64_t)img * TW * TH + ty * TW + tx] = t;   // a changed tile is active
     }
   }
   if (any && tid == 0) atomicOr(&c.changed, 1);
@@ -260,8 +268,9 @@ __global__ __launch_bounds__(256) void k_rx_mark(RxCtl* __restrict__ ctl, const 
                                                  int* __restrict__ rgDirtyAll, const int* __restrict__ tileMinAll,
                                                  int* __restrict__ tileActAll, int W, int H, int TW, int TH, int t, int img0,
                                                  int seedRule) {
-  __shared__ int nt[3][6];
-  __shared__ int s_any;
+  // (RX_DIFF_ROWS rows of cells per workgroup, like k_rx_diff: the grid of one-row blocks is bound by the dispatch rate)
+  __shared__ int nt[RX_DIFF_ROWS + 2][6];
+  __shared__ int s_any[RX_DIFF_ROWS];
   const int img = blockIdx.z + img0;
   RxCtl& c = ctl[img];
   if (c.state == 2) return;
@@ -271,37 +280,44 @@ __global__ __launch_bounds__(256) void k_rx_mark(RxCtl* __restrict__ ctl, const 
   }
   const int tid = threadIdx.x;
   const int* tm = tileMinAll + (int64_t)img * TW * TH;
-  if (tid == 0) s_any = 0;
+  if (tid < RX_DIFF_ROWS) s_any[tid] = 0;
   __syncthreads();
-  if (tid < 18) {
-    const int ty = (int)blockIdx.y + tid / 6 - 1, tx = (int)blockIdx.x * 4 + tid % 6 - 1;
+  if (tid < 6 * (RX_DIFF_ROWS + 2)) {
+    const int ty = (int)blockIdx.y * RX_DIFF_ROWS + tid / 6 - 1, tx = (int)blockIdx.x * 4 + tid % 6 - 1;
     const int v = (ty >= 0 && ty < TH && tx >= 0 && tx < TW) ? tm[ty * TW + tx] : INT_MAX;
     nt[tid / 6][tid % 6] = v;
-    if (v != INT_MAX) s_any = 1;
+    if (v != INT_MAX) {                              // a change in row tid/6 concerns the cell rows tid/6 - 1 .. tid/6 + 1 (block-local: -2 .. 0)
+      for (int d = -2; d <= 0; ++d) {
+        const int rr = tid / 6 + d;
+        if (rr >= 0 && rr < RX_DIFF_ROWS) s_any[rr] = 1;
+      }
+    }
   }
   __syncthreads();
-  if (!s_any) return;                                // nothing changed in or next to these four tiles
-  const int x = blockIdx.x * 32 + (tid & 31), y = blockIdx.y * 8 + (tid >> 5);
-  if (x >= W || y >= H) return;
   const int64_t base = (int64_t)img * W * H;
-  const int r = rankAll[base + y * W + x];
-  if (r == RX_INF) return;
-  const int2 o = ownAll[base + y * W + x];
-  const int ci = t & 1;
-  const int prevv = ci ? o.x : o.y, prev2 = ci ? o.y : o.x;
-  // lowest rank of a change in the tiles within one pixel of (x, y)
-  const int lx = tid & 31, ly = tid >> 5;
-  const int cx0 = (lx + 7) >> 3, cx1 = (lx + 9) >> 3;        // nt column of x-1 and x+1 (nt column 1 = first own tile)
-  const int cy0 = (ly + 7) >> 3, cy1 = (ly + 9) >> 3;
-  const int m = min(min(nt[cy0][cx0], nt[cy0][cx1]), min(nt[cy1][cx0], nt[cy1][cx1]));
   int* rgDirty = rgDirtyAll + base;
   const int2* rgBox = rgBoxAll + base;
   int* tileAct = tileActAll + (int64_t)img * TW * TH;
-  if (m < prevv) rx_mark_dirty(prevv, true, t, rgDirty, rgBox, tileAct, TW, TH);
-  const bool a1 = prevv == r, a2 = prev2 == r;
-  // (seedRule 0: round 2 of the tile-sequential relaxation, where owner_{t-2} is the trivial map and the seeds that died in
-  // round 1 never ran)
-  if (seedRule && a1 != a2) rx_mark_dirty(r, a2, t, rgDirty, rgBox, tileAct, TW, TH);   // died: its last box; newly alive: only this pixel
+  const int ci = t & 1;
+  for (int rr = 0; rr < RX_DIFF_ROWS; ++rr) {
+    if (!s_any[rr]) continue;                        // nothing changed in or next to these four tiles
+    const int x = blockIdx.x * 32 + (tid & 31), y = (blockIdx.y * RX_DIFF_ROWS + rr) * 8 + (tid >> 5);
+    if (x >= W || y >= H) continue;
+    const int r = rankAll[base + y * W + x];
+    if (r == RX_INF) continue;
+    const int2 o = ownAll[base + y * W + x];
+    const int prevv = ci ? o.x : o.y, prev2 = ci ? o.y : o.x;
+    // lowest rank of a change in the tiles within one pixel of (x, y)
+    const int lx = tid & 31, ly = tid >> 5;
+    const int cx0 = (lx + 7) >> 3, cx1 = (lx + 9) >> 3;        // nt column of x-1 and x+1 (nt column 1 = first own tile)
+    const int cy0 = rr + ((ly + 7) >> 3), cy1 = rr + ((ly + 9) >> 3);
+    const int m = min(min(nt[cy0][cx0], nt[cy0][cx1]), min(nt[cy1][cx0], nt[cy1][cx1]));
+    if (m < prevv) rx_mark_dirty(prevv, true, t, rgDirty, rgBox, tileAct, TW, TH);
+    const bool a1 = prevv == r, a2 = prev2 == r;
+    // (seedRule 0: round 2 of the tile-sequential relaxation, where owner_{t-2} is the trivial map and the seeds that died in
+    // round 1 never ran)
+    if (seedRule && a1 != a2) rx_mark_dirty(r, a2, t, rgDirty, rgBox, tileAct, TW, TH);   // died: its last box; newly alive: only this pixel
+  }
 }
 
 // (32 x 32 pixels = 16 tiles per block: one list atomic per 1024 pixels)

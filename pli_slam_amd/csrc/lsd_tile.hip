@@ -239,7 +239,9 @@ __global__ __launch_bounds__(256) void k_tx_diff2(RxCtl* __restrict__ ctl, const
 // a pixel whose previous owner is carried (not stamped dirty) stays with it, any other falls back to its own
 // rank.  Elsewhere owner_{t-2} == owner_{t-1} and the owner is carried: the word that is there is right.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_tx_prep(RxCtl* __restrict__ ctl, int2* __restrict__ ownAll,
+// (256 threads walk the 32 x 32 pixels of a block in four steps: most blocks leave after the activity test, and the cost of
+// that is per wave)
+__global__ __launch_bounds__(256) void k_tx_prep(RxCtl* __restrict__ ctl, int2* __restrict__ ownAll,
                                                  const int* __restrict__ rankAll, const int* __restrict__ rgDirtyAll,
                                                  const int* __restrict__ tileActAll, int W, int H, int TW, int TH, int t, int img0,
                                                  int full) {
@@ -257,19 +259,23 @@ __global__ __launch_bounds__(1024) void k_tx_prep(RxCtl* __restrict__ ctl, int2*
   }
   __syncthreads();
   if (!s_act) return;
-  const int x = blockIdx.x * 32 + (tid & 31), y = blockIdx.y * 32 + (tid >> 5);
-  if (x >= W || y >= H) return;
   const int64_t base = (int64_t)img * W * H;
-  const int p = y * W + x;
-  const int r = rankAll[base + p];
-  if (r == TX_INF) return;
   const int ci = t & 1;
-  int2 o = ownAll[base + p];
-  const int prevv = ci ? o.x : o.y;
-  const int cur = rgDirtyAll[base + prevv] != t ? prevv : r;
-  if (cur != (ci ? o.y : o.x)) {
-    if (ci) o.y = cur; else o.x = cur;
-    ownAll[base + p] = o;
+  const int x = blockIdx.x * 32 + (tid & 31);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int y = blockIdx.y * 32 + i * 8 + (tid >> 5);
+    if (x >= W || y >= H) continue;
+    const int p = y * W + x;
+    const int r = rankAll[base + p];
+    if (r == TX_INF) continue;
+    int2 o = ownAll[base + p];
+    const int prevv = ci ? o.x : o.y;
+    const int cur = rgDirtyAll[base + prevv] != t ? prevv : r;
+    if (cur != (ci ? o.y : o.x)) {
+      if (ci) o.y = cur; else o.x = cur;
+      ownAll[base + p] = o;
+    }
   }
 }
 
