@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void k_rx_guess(const float4* __restrict__ rec
 // owner_{t-1} against owner_{t-2}: per 8x8 tile the lowest rank that takes part in a change
 // (RX_DIFF_ROWS rows of 8x8 cells per workgroup: with one row the grid is a million blocks of a few instructions at 256 frames
 // and the kernel is bound by the rate at which workgroups are dispatched)
-constexpr int RX_DIFF_ROWS = 4;
+constexpr int RX_DIFF_ROWS = 8;
 __global__ __launch_bounds__(256) void k_rx_diff(RxCtl* __restrict__ ctl, const int2* __restrict__ ownAll,
                                                  int* __restrict__ tileMinAll, int* __restrict__ tileActAll, int W, int H,
                                                  int TW, int TH, int t, int img0) {

@@ -790,10 +790,10 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
           TRL(c, "k_tx_diff2", k_tx_diff2, dim3((P.LW + 31) / 32, c->tilesH, nimg), dim3(256), 0, c->jrCtl, c->own, c->order, c->rgBox,
               c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, ts, t, img0);
         else
-          TRL(c, "k_rx_diff", k_rx_diff, dim3((P.LW + 31) / 32, (c->tilesH + 3) / 4, nimg), dim3(256), 0, c->jrCtl, c->own, c->tileMin, c->tileAct,
+          TRL(c, "k_rx_diff", k_rx_diff, dim3((P.LW + 31) / 32, (c->tilesH + 7) / 8, nimg), dim3(256), 0, c->jrCtl, c->own, c->tileMin, c->tileAct,
               P.LW, P.LH, c->tilesW, c->tilesH, t, img0);
         if (t >= 3 || (t == 2 && !fullRound2)) {
-          TRL(c, "k_rx_mark", k_rx_mark, dim3((P.LW + 31) / 32, (c->tilesH + 3) / 4, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->rgBox,
+          TRL(c, "k_rx_mark", k_rx_mark, dim3((P.LW + 31) / 32, (c->tilesH + 7) / 8, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->rgBox,
               c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, t >= 3 ? 1 : 0);
           TRL(c, "k_tx_prep", k_tx_prep, dim3((P.LW + 31) / 32, (P.LH + 31) / 32, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf,
               c->rgDirty, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, t == 2 ? 1 : 0);
@@ -821,11 +821,11 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     TRL(c, "k_rx_guess", k_rx_guess, raster, dim3(256), 0, c->rec, c->rankOf, c->own, P.LW, P.LH, precDeg, img0);
     for (int t = 1; t <= maxRounds && !allDone; ++t) {
       curT = t;
-      TRL(c, "k_rx_diff", k_rx_diff, dim3((P.LW + 31) / 32, (c->tilesH + 3) / 4, nimg), dim3(256), 0, c->jrCtl, c->own, c->tileMin, c->tileAct,
+      TRL(c, "k_rx_diff", k_rx_diff, dim3((P.LW + 31) / 32, (c->tilesH + 7) / 8, nimg), dim3(256), 0, c->jrCtl, c->own, c->tileMin, c->tileAct,
              P.LW, P.LH, c->tilesW, c->tilesH, t, img0);
       if (t >= 3 && !fullPasses) {
         // bookkeeping only where something happened (lsd_relax.hip)
-        TRL(c, "k_rx_mark", k_rx_mark, dim3((P.LW + 31) / 32, (c->tilesH + 3) / 4, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->rgBox,
+        TRL(c, "k_rx_mark", k_rx_mark, dim3((P.LW + 31) / 32, (c->tilesH + 7) / 8, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->rgBox,
             c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, 1);
         TRL(c, "k_rx_seed_sparse", k_rx_seed_sparse, dim3((P.LW + 31) / 32, (P.LH + 31) / 32, nimg), dim3(1024), 0, c->jrCtl, c->own, c->rankOf,
             c->rec, c->lastSize, c->rgDirty, c->tileAct, c->smallSeeds, c->bigSeeds, c->bigCap, P.LW, P.LH, c->tilesW, c->tilesH,
