@@ -151,7 +151,10 @@ int32_t pli_kl_capacity(const pli_frontend_config* cfg);   /* lsd_nfeatures or m
 typedef struct pli_table_layout {
   int64_t record_bytes;       /* stride between consecutive frames                         */
   int32_t kp_cap, kl_cap;
-  int64_t off_counts;         /* int32[8]: n_kp[2], n_kl[2], n_stereo_pts, n_stereo_lines, 2 reserved */
+  int64_t off_counts;         /* int32[8]: n_kp[2], n_kl[2], n_stereo_pts, n_stereo_lines, truncation flags, 1 reserved.
+                                 Flags = 4 bytes: [0],[1] lines of eye 0 / 1: more segments passed the length cut than
+                                 max_lines holds (the top-N selection did not see all of them); [2],[3] keypoints of eye
+                                 0 / 1 cut at kp_cap.  The per-call entry points return PLI_ERR_CAPACITY for them. */
   int64_t off_kp[2];          /* pli_keypoint[kp_cap]                                       */
   int64_t off_desc[2];        /* uint8[kp_cap][32]   (mDescriptors / mDescriptorsRight)     */
   int64_t off_uright;         /* float[kp_cap]       (mvuRight)                             */

@@ -1333,6 +1333,9 @@ __global__ __launch_bounds__(256) void k_keylines(const DevParams* __restrict__ 
   const int M = min(s_base, P.maxLines);
   uint8_t* rec = table + (int64_t)(img >> 1) * recordBytes;
   const int eye = img & 1;
+  // truncation flag (counts[6], one byte per eye): more segments passed the length cut than max_lines holds, i.e. the top-N
+  // selection did not see all of them (the reference keeps every segment: raise pli_frontend_config.max_lines)
+  if (tid == 0) rec[offCounts + 24 + eye] = s_base > P.maxLines ? 1 : 0;
   pli_keyline* out = reinterpret_cast<pli_keyline*>(rec + (eye ? offKl1 : offKl0));
   const int nf = P.lsdNFeatures;
   __threadfence_block();

@@ -922,8 +922,10 @@ __global__ void k_kp_counts(const DevParams* __restrict__ Pp, const int* __restr
   img += img0;
   int total = 0;
   for (int l = 0; l < P.nlevels; ++l) total += kpSelCount[img * P.nlevels + l];
+  uint8_t* rec = table + (int64_t)(img >> 1) * recordBytes;
+  rec[offCounts + 26 + (img & 1)] = total > P.kpCap ? 1 : 0;       // truncation flag (counts[6], bytes 2 and 3)
   if (total > P.kpCap) total = P.kpCap;
-  reinterpret_cast<int*>(table + (int64_t)(img >> 1) * recordBytes + offCounts)[img & 1] = total;
+  reinterpret_cast<int*>(rec + offCounts)[img & 1] = total;
 }
 
 }  // namespace pli

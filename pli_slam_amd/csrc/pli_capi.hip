@@ -1208,6 +1208,7 @@ pli_status pli_orb_extract(pli_ctx* c, int32_t eye, const uint8_t* img, int32_t 
   c->orbDone[eye] = true;
   c->monoCount[eye] = N;
   *n = N;
+  if (reinterpret_cast<const uint8_t*>(counts + 6)[2 + eye]) { g_err = "more keypoints than kp_cap holds"; return PLI_ERR_CAPACITY; }
   if (N > cap) { g_err = "keypoint buffer too small"; return PLI_ERR_CAPACITY; }
   if (N > 0) {
     if (kp) HIPCHK(hipMemcpy(kp, c->ownTable + Y.off_kp[eye], (size_t)N * sizeof(pli_keypoint), hipMemcpyDeviceToHost));
@@ -1245,6 +1246,10 @@ pli_status pli_line_extract(pli_ctx* c, int32_t eye, const uint8_t* img, int32_t
   const int N = counts[2 + eye];
   c->lineDone[eye] = true;
   *n = N;
+  if (reinterpret_cast<const uint8_t*>(counts + 6)[eye]) {
+    g_err = "more segments pass the length cut than max_lines holds: raise pli_frontend_config.max_lines";
+    return PLI_ERR_CAPACITY;
+  }
   if (N > cap) { g_err = "keyline buffer too small"; return PLI_ERR_CAPACITY; }
   if (N > 0) {
     if (kl) HIPCHK(hipMemcpy(kl, c->ownTable + Y.off_kl[eye], (size_t)N * sizeof(pli_keyline), hipMemcpyDeviceToHost));

@@ -342,7 +342,7 @@ class Frontend:
         Y = self.layout
         rec = table[frame * Y.record_bytes:(frame + 1) * Y.record_bytes]
         counts = rec[Y.off_counts:Y.off_counts + 32].view(np.int32)
-        out = {"counts": counts.copy()}
+        out = {"counts": counts.copy(), "truncated": rec[Y.off_counts + 24:Y.off_counts + 28].copy()}   # lines L/R, keypoints L/R
         for e, name in ((0, "L"), (1, "R")):
             n = int(counts[e])
             out["kp" + name] = rec[Y.off_kp[e]:Y.off_kp[e] + 24 * n].view(KEYPOINT_DT).copy()

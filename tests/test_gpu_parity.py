@@ -942,3 +942,25 @@ def test_sequential_grower_dev_switches(gpu, flags, monkeypatch):
             want = fr.line_extract(0, L)
             assert want[0] > 500
         assert m == want[0] and kl.tobytes() == want[1].tobytes() and np.array_equal(ld, want[2]), env
+
+
+def test_truncation_is_flagged_not_silent(gpu):
+    """A max_lines smaller than the number of segments that pass the length cut: the record carries the truncation flag and
+    the per-call entry point returns PLI_ERR_CAPACITY; with room enough the flag is clear and the result is the oracle's."""
+    g = gpu
+    W, H = 752, 480
+    L, R = g.synth.make_stereo_pair(9, W, H)
+    cfg = g.capi.default_config(W, H, orb_nfeatures=300, lsd_nfeatures=50, max_lines=64)
+    fe = g.Frontend(cfg)
+    rec = fe.batch_run_host(np.stack([L, R])[None])[0]
+    assert rec["truncated"][:2].tolist() == [1, 1] and rec["truncated"][2:].tolist() == [0, 0]
+    with pytest.raises(g.capi.PliError) as ei:
+        fe.line_extract(0, L)
+    assert ei.value.status == -3                          # PLI_ERR_CAPACITY
+    cfg = g.capi.default_config(W, H, orb_nfeatures=300, lsd_nfeatures=50)
+    fe = g.Frontend(cfg)
+    rec = fe.batch_run_host(np.stack([L, R])[None])[0]
+    assert rec["truncated"].tolist() == [0, 0, 0, 0]
+    m, kl, ld = fe.line_extract(0, L)
+    om, okl, old = g.po.Frame(ocfg(g, cfg)).line_extract(0, L)
+    assert m == om == 50 and kl.tobytes() == okl.tobytes()
