@@ -81,27 +81,27 @@ __device__ __forceinline__ float tx_rlf(float v, int l) { return __int_as_float(
 // stages (ts = 64) whose partner sits in another wave go through LDS — the earlier form did every stage there (6.6 ms at 256
 // frames).
 // ---------------------------------------------------------------------------
-template <int KPT>
+template <int KPT, int NT>
 __device__ __forceinline__ void tx_sort_tile(const int* __restrict__ rankAll, const int* __restrict__ orderAll,
                                              int2* __restrict__ ownAll, int2* __restrict__ listAll,
                                              int* __restrict__ tileCntAll, int W, int H, int ts, int ntx, int nty, int img0,
                                              unsigned* xch) {
   __shared__ int s_cnt;
   const int img = blockIdx.y + img0, tile = blockIdx.x, tid = threadIdx.x;
-  constexpr int n2 = KPT * 256;
+  constexpr int n2 = KPT * NT;
   const int tx0 = (tile % ntx) * ts, ty0 = (tile / ntx) * ts;
   const int64_t npix = (int64_t)W * H;
   const int* rank = rankAll + img * npix;
   int2* own = ownAll + img * npix;
   if (tid == 0) s_cnt = 0;
   __syncthreads();
-  // coalesced read of the tile (element i = m*256 + tid), transposed to "KPT consecutive keys per thread" through LDS
+  // coalesced read of the tile (element i = m*NT + tid), transposed to "KPT consecutive keys per thread" through LDS
   // (padded by one word per 16: the strided side of the transposition is bank-conflict free)
   auto pad = [](int i) -> int { return i + (i >> 4); };
   int valid = 0;
 #pragma unroll
   for (int m = 0; m < KPT; ++m) {
-    const int i = m * 256 + tid;
+    const int i = m * NT + tid;
     const int x = tx0 + i % ts, y = ty0 + i / ts;
     unsigned k = 0xFFFFFFFFu;
     if (x < W && y < H) {
@@ -138,11 +138,11 @@ __device__ __forceinline__ void tx_sort_tile(const int* __restrict__ rankAll, co
         } else {
           __syncthreads();
 #pragma unroll
-          for (int u = 0; u < KPT; ++u) xch[u * 256 + tid] = key[u];
+          for (int u = 0; u < KPT; ++u) xch[u * NT + tid] = key[u];
           __syncthreads();
 #pragma unroll
           for (int u = 0; u < KPT; ++u) {
-            const unsigned o = xch[u * 256 + (tid ^ pt)];
+            const unsigned o = xch[u * NT + (tid ^ pt)];
             key[u] = keepMin ? min(key[u], o) : max(key[u], o);
           }
         }
@@ -168,7 +168,7 @@ __device__ __forceinline__ void tx_sort_tile(const int* __restrict__ rankAll, co
   __syncthreads();
 #pragma unroll
   for (int m = 0; m < KPT; ++m) {
-    const int i = m * 256 + tid;
+    const int i = m * NT + tid;
     const unsigned k = xch[pad(i)];
     if (k != 0xFFFFFFFFu) list[i] = make_int2((int)k, order[k]);
   }
@@ -179,8 +179,15 @@ __global__ __launch_bounds__(256) void k_tx_sort(const int* __restrict__ rankAll
                                                  int2* __restrict__ ownAll, int2* __restrict__ listAll,
                                                  int* __restrict__ tileCntAll, int W, int H, int ts, int ntx, int nty, int img0) {
   __shared__ unsigned xch[16 * 256 + 256];
-  if (ts == 64) tx_sort_tile<16>(rankAll, orderAll, ownAll, listAll, tileCntAll, W, H, ts, ntx, nty, img0, xch);
-  else tx_sort_tile<4>(rankAll, orderAll, ownAll, listAll, tileCntAll, W, H, ts, ntx, nty, img0, xch);
+  if (ts == 64) tx_sort_tile<16, 256>(rankAll, orderAll, ownAll, listAll, tileCntAll, W, H, ts, ntx, nty, img0, xch);
+  else tx_sort_tile<4, 256>(rankAll, orderAll, ownAll, listAll, tileCntAll, W, H, ts, ntx, nty, img0, xch);
+}
+// tiles of 128 x 128 (large batches): 1024 threads x 16 keys, 10 of the 105 stages through LDS
+__global__ __launch_bounds__(1024) void k_tx_sort128(const int* __restrict__ rankAll, const int* __restrict__ orderAll,
+                                                     int2* __restrict__ ownAll, int2* __restrict__ listAll,
+                                                     int* __restrict__ tileCntAll, int W, int H, int ts, int ntx, int nty, int img0) {
+  __shared__ unsigned xch[16 * 1024 + 1024];
+  tx_sort_tile<16, 1024>(rankAll, orderAll, ownAll, listAll, tileCntAll, W, H, ts, ntx, nty, img0, xch);
 }
 
 // ---------------------------------------------------------------------------
@@ -394,9 +401,12 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
   const int64_t npix = (int64_t)W * H;
   if (SPARSE) {
     // a dirty region activates the cells under its bounding box, its seed's cell among them: no active cell, nothing to do
-    const int cpt = ts >> 3;                              // 8x8 cells per tile side (ts = 32 or 64: up to 64 cells)
-    const int cx = (tile % ntx) * cpt + lane % cpt, cy = (tile / ntx) * cpt + lane / cpt;
-    const bool act = lane < cpt * cpt && cx < TW && cy < TH && tileActAll[(int64_t)img * TW * TH + cy * TW + cx] == t;
+    const int cpt = ts >> 3;                              // 8x8 cells per tile side (ts = 32, 64 or 128: up to 256 cells)
+    bool act = false;
+    for (int cidx = lane; cidx < cpt * cpt; cidx += 64) {
+      const int cx = (tile % ntx) * cpt + cidx % cpt, cy = (tile / ntx) * cpt + cidx / cpt;
+      act = act || (cx < TW && cy < TH && tileActAll[(int64_t)img * TW * TH + cy * TW + cx] == t);
+    }
     if (!__builtin_amdgcn_ballot_w64(act)) return;
   }
   const float4* rec = recAll + img * npix;

@@ -540,7 +540,7 @@ pli_status allocAll(pli_ctx* c) {
     A(c->arena, (size_t)c->arenaCap * NR);
     if (tiles) {
       c->txTs = NI <= TX_SMALL_TILE_IMAGES ? 32 : 64;
-      if (const char* e = getenv("PLI_TX_TS")) c->txTs = atoi(e) == 32 ? 32 : 64;
+      if (const char* e = getenv("PLI_TX_TS")) c->txTs = atoi(e) == 32 ? 32 : atoi(e) == 128 ? 128 : 64;
       c->txNtx = (P.LW + c->txTs - 1) / c->txTs; c->txNty = (P.LH + c->txTs - 1) / c->txTs;
       A(c->txList, (size_t)c->txNtx * c->txNty * c->txTs * c->txTs * NR);
       A(c->txTileCnt, (size_t)c->txNtx * c->txNty * NR);
@@ -780,8 +780,12 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     if (tile) {
       // tile-sequential relaxation (lsd_tile.hip): per-tile seed lists once, then rounds of one wave per tile
       const int ts = c->txTs, ntile = c->txNtx * c->txNty;
-      TRL(c, "k_tx_sort", k_tx_sort, dim3(ntile, nimg), dim3(256), 0, c->rankOf, c->order, c->own, c->txList,
-          c->txTileCnt, P.LW, P.LH, ts, c->txNtx, c->txNty, img0);
+      if (ts == 128)
+        TRL(c, "k_tx_sort", k_tx_sort128, dim3(ntile, nimg), dim3(1024), 0, c->rankOf, c->order, c->own, c->txList,
+            c->txTileCnt, P.LW, P.LH, ts, c->txNtx, c->txNty, img0);
+      else
+        TRL(c, "k_tx_sort", k_tx_sort, dim3(ntile, nimg), dim3(256), 0, c->rankOf, c->order, c->own, c->txList,
+            c->txTileCnt, P.LW, P.LH, ts, c->txNtx, c->txNty, img0);
       const bool fullRound2 = getenv("PLI_TX_FULL2") != nullptr;       // dev: regrow everything in round 2
       const size_t txPad = getenv("PLI_TX_LDSPAD") ? (size_t)atoi(getenv("PLI_TX_LDSPAD")) : 0;   // dev: occupancy cap of the tile growers
       for (int t = 1; t <= maxRounds && !allDone; ++t) {
