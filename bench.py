@@ -417,15 +417,20 @@ def main():
         peak = 8000.0
         achieved = per_img * 2 * F / avg_s / 1e9 if (per_img is not None and avg_s > 0) else None
         traffic = None     # HBM bytes per launch from the committed PMC passes of the same workload, if any
-        try:
+        sector = None      # the growers are gather kernels: their ceiling is the rate of random 64-byte sector requests the chip
+        try:               # sustains (tools/probes/gather_rate.hip, profiles/r02_gather_rate_probe.txt: 49 G/s), not the stream peak
             tr = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
             k = tr["workloads"].get("%dx%d_F%d" % (W, H, F), {}).get(name)
             if k:
                 traffic = (2 * k["fetch_kb"] + k["write_kb"]) * 1024
+                if name.startswith(("k_tx_grow", "k_lsd_grow", "k_rx_grow")) and avg_s > 0:
+                    rate = k["fetch_kb"] * 1024 / 64 / avg_s / 1e9      # FETCH_SIZE counts 64 B per request of these kernels
+                    sector = {"achieved": rate, "peak": 49.0, "unit": "G 64-byte sector requests/s (L2 misses)", "frac": rate / 49.0,
+                              "note": "peak measured by tools/probes/gather_rate.hip; requests per launch from the committed FETCH_SIZE pass"}
         except Exception:
             pass
         roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": peak, "unit": "GB/s",
-                "frac": (achieved / peak) if achieved is not None else None, "traffic": traffic,
+                "frac": (achieved / peak) if achieved is not None else None, "traffic": traffic, "sector_requests": sector,
                 "avg_launch_ms": avg_s * 1e3, "launches": calls,
                 "path_achieved": fps / world * b_frame / 1e9, "path_frac": fps / world * b_frame / 1e9 / peak,
                 "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in
