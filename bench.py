@@ -332,7 +332,9 @@ def main():
         t = torch.tensor([F], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         Fmax = int(t.item())
-    cfg = capi.default_config(W, H, orb_nfeatures=nfeat, lsd_nfeatures=nlines, max_frames=Fmax, lsd_mode=args.lsd_mode)
+    # (config 3 on several ranks: the frame-to-frame matcher also sees the halo frame of the previous shard)
+    cfg = capi.default_config(W, H, orb_nfeatures=nfeat, lsd_nfeatures=nlines, max_frames=Fmax + (1 if (args.config == 3 and world > 1) else 0),
+                              lsd_mode=args.lsd_mode)
     fe = Frontend(cfg, device=local_rank)
     # synthetic stream: up to --unique-frames distinct seeded stereo pairs per rank (seeds disjoint across ranks), cycled to F
     # frames; config 3: consecutive frames t = 0..nuniq-1 of ONE scene (the motion of synth.make_stereo_pair)
@@ -340,7 +342,8 @@ def main():
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as ex:
         if args.config == 3:
-            pairs = list(ex.map(lambda t_: synth.make_stereo_pair(100 + rank, W, H, t=t_), range(nuniq)))
+            # one scene for all ranks, rank r holds the time slice [r * nuniq, r * nuniq + nuniq): consecutive shards of ONE stream
+            pairs = list(ex.map(lambda t_: synth.make_stereo_pair(100, W, H, t=rank * nuniq + t_), range(nuniq)))
         else:
             pairs = list(ex.map(lambda s_: synth.make_stereo_pair(s_, W, H), range(rank * nuniq, rank * nuniq + nuniq)))
     images = np.stack([np.stack(p) for p in pairs])                    # (nuniq, 2, H, W) u8
@@ -361,15 +364,32 @@ def main():
             a_ = np.deg2rad(0.5 * t_)
             return np.array([[np.cos(a_), -np.sin(a_), 0, -0.02 * t_], [np.sin(a_), np.cos(a_), 0, -0.007 * t_], [0, 0, 1, 0.01 * t_]],
                             np.float32)
-        d_poses = torch.from_numpy(np.stack([pose(t_ % nuniq) for t_ in range(F)]).reshape(-1)).to(dev)
         tl = fe.track_layout()
-        track = (d_poses, fe.track_params(th=15.0), torch.zeros(F * int(tl.record_bytes), dtype=torch.uint8, device=dev))
+        if world > 1:
+            # f2f matching across shard borders: the record of the frame before this shard's first one arrives from
+            # the previous rank (1-frame halo, point-to-point) and the matcher runs over [halo | own frames]
+            from pli_slam_amd.sharding import exchange_halo
+            halo_pose = pose((rank * nuniq - 1) % (world * nuniq))
+            d_poses = torch.from_numpy(np.stack([halo_pose] + [pose(rank * nuniq + t_ % nuniq) for t_ in range(F)]).reshape(-1)).to(dev)
+            d_halo_table = torch.zeros((F + 1) * rec_bytes, dtype=torch.uint8, device=dev)
+            track = (d_poses, fe.track_params(th=15.0), torch.zeros((F + 1) * int(tl.record_bytes), dtype=torch.uint8, device=dev))
+        else:
+            d_poses = torch.from_numpy(np.stack([pose(t_ % nuniq) for t_ in range(F)]).reshape(-1)).to(dev)
+            track = (d_poses, fe.track_params(th=15.0), torch.zeros(F * int(tl.record_bytes), dtype=torch.uint8, device=dev))
 
     def step():
         slot = gath.acquire() if gath else 0
         tbl = gath.table(slot) if gath else d_table
         fe.batch_run_device(F, d_left.data_ptr(), d_right.data_ptr(), W, W * H, tbl.data_ptr())
-        if track is not None:
+        if track is not None and world > 1:
+            d_halo_table[rec_bytes:(F + 1) * rec_bytes].copy_(tbl[:F * rec_bytes])
+            got = exchange_halo(d_halo_table, rec_bytes, F, counts=[F] * world)
+            if got:       # [halo | frames]: F + 1 consecutive records
+                fe.batch_track_device(F + 1, d_halo_table.data_ptr(), track[0].data_ptr(), track[1], track[2].data_ptr())
+            else:         # the first shard of the stream: nothing in front of its frame 0
+                fe.batch_track_device(F, d_halo_table.data_ptr() + rec_bytes, track[0].data_ptr() + 48, track[1],
+                                      track[2].data_ptr() + int(tl.record_bytes))
+        elif track is not None:
             fe.batch_track_device(F, tbl.data_ptr(), track[0].data_ptr(), track[1], track[2].data_ptr())
         if gath:
             gath.submit(slot)

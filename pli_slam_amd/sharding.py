@@ -48,6 +48,40 @@ def gather_tables(table, record_bytes, nframes_local, dst=0, group=None, counts=
     return [b[: n * record_bytes] for b, n in zip(bufs, all_counts)]
 
 
+def exchange_halo(table, record_bytes, nframes_local, group=None, counts=None):
+    """1-frame halo for frame-to-frame matching across shard borders: every rank sends the record of its LAST
+    frame to the next rank and receives the record of the frame before its first one.
+
+    `table`: 1-D uint8 tensor with ONE FREE RECORD IN FRONT of the `nframes_local` records of this rank
+    (layout [halo | frame 0 | frame 1 | ...]).  The halo slot is filled in place; returns True when it holds a frame
+    (every rank but the first; a rank whose predecessor has no frames gets none either), so that the caller runs the
+    frame-to-frame matcher over nframes_local + 1 consecutive records starting at the halo, or over nframes_local
+    records starting at frame 0.  Point-to-point only (isend / irecv): no collective on the data path.
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return False
+    rank = dist.get_rank(group)
+    if counts is not None:                               # the frame count of every rank, known to the caller: no exchange of counts
+        all_counts = [int(c) for c in counts]
+    else:
+        mine = torch.tensor([nframes_local], dtype=torch.int64, device=table.device)
+        all_counts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(all_counts, mine, group=group)
+        all_counts = [int(c.item()) for c in all_counts]
+    reqs = []
+    last = table[nframes_local * record_bytes:(nframes_local + 1) * record_bytes]          # record of the last local frame
+    if rank + 1 < world and nframes_local > 0:
+        reqs.append(dist.isend(last.contiguous(), dst=rank + 1, group=group))
+    got = rank > 0 and all_counts[rank - 1] > 0
+    if got:
+        halo = table[:record_bytes]
+        reqs.append(dist.irecv(halo, src=rank - 1, group=group))
+    for r in reqs:
+        r.wait()
+    return got
+
+
 class TableGatherer:
     """Double-buffered, asynchronous gather of equal-sized shards to rank `dst`: the gather of step i travels over
     xGMI while the kernels of step i+1 run (a result table is only waited for when its buffer is reused).

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from pli_slam_amd.sharding import TableGatherer, gather_tables, shard_range
+from pli_slam_amd.sharding import TableGatherer, exchange_halo, gather_tables, shard_range
 
 
 def test_shard_range_partitions_the_batch():
@@ -77,3 +77,27 @@ def _worker_async(rank, world, path, steps, nbytes):
 def test_async_double_buffered_gather_gloo_world2():
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker_async, args=(2, os.path.join(d, "rdv"), 5, 4096), nprocs=2, join=True)
+
+
+def _worker_halo(rank, world, path, nframes, rec):
+    dist.init_process_group("gloo", init_method="file://" + path, rank=rank, world_size=world)
+    start, count = shard_range(nframes, rank, world)
+    t = torch.zeros((count + 1) * rec, dtype=torch.uint8)                    # [halo | local frames]
+    for f in range(count):
+        t[(f + 1) * rec:(f + 2) * rec] = (start + f) % 251
+    got = exchange_halo(t, rec, count)
+    if rank == 0 or shard_range(nframes, rank - 1, world)[1] == 0:
+        assert not got and int(t[:rec].max()) == 0                           # nothing in front of the stream's first frame
+    else:
+        assert got and bool((t[:rec] == (start - 1) % 251).all())            # the frame before this shard's first one
+    for f in range(count):                                                   # the local records are untouched
+        assert bool((t[(f + 1) * rec:(f + 2) * rec] == (start + f) % 251).all())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nframes", [(2, 8), (3, 7), (3, 2)])
+def test_one_frame_halo_across_shard_borders_gloo(world, nframes):
+    """rank r receives the table record of frame start_r - 1 (f2f matching across shard borders)."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_halo, args=(world, os.path.join(d, "rdv"), nframes, 128), nprocs=world, join=True)

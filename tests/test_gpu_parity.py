@@ -806,6 +806,19 @@ def test_batch_track_config3(gpu):
         assert tr["counts"][2] == len(last["ldescL"]) and tr["counts"][3] == ln and np.array_equal(tr["lines"], lm), "frame %d lines" % f
         assert on > 50 and ln > 10
     assert seen == {"neutral", "forward", "backward"}, seen
+    # a shard of the stream with its 1-frame halo (frame-to-frame matching across shard borders): the table
+    # [record of frame 1 | records of frames 2, 3] with the poses of frames 1..3 gives frames 2 and 3 the tracks of the full run
+    rb = int(fe.layout.record_bytes)
+    d_halo = torch.from_numpy(np.concatenate([table[1 * rb:2 * rb], table[2 * rb:4 * rb]])).cuda()
+    d_poses_h = torch.from_numpy(poses[1:4].reshape(-1)).cuda()
+    d_track_h = torch.zeros(3 * tl.record_bytes, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    fe.batch_track_device(3, d_halo.data_ptr(), d_poses_h.data_ptr(), tp, d_track_h.data_ptr())
+    fe.sync()
+    th = d_track_h.cpu().numpy()
+    for f in (2, 3):
+        a, b = fe.parse_track(track, f), fe.parse_track(th, f - 1)
+        assert np.array_equal(a["counts"], b["counts"]) and np.array_equal(a["best"], b["best"]) and np.array_equal(a["lines"], b["lines"])
 
 
 @pytest.mark.parametrize("flags", [0, 1, 2, 4, 8, 6, 15])
