@@ -32,31 +32,18 @@ constexpr double TX_PI = 3.14159265358979323846;
 constexpr double TX_DEG2RAD = TX_PI / 180;
 constexpr double TX_3_2_PI = (3 * TX_PI) / 2;
 constexpr double TX_2PI = 2 * TX_PI;
-// 1: the claims of a step (returning atomicMin on the owner word) are waited for before the owner loads of the next step.
-// Tried: 0 = non-returning claims, not waited for, and 2 = returning claims consumed after the next step's loads are issued.
-// In both the loads are issued by the same wave in program order and meet the claims in the same L2 channel, so they still see
-// them (all parity tests and fuzzers green), but with 32 tile waves per CU both are slower (k_tx_grow 24.4 -> 26.8 / 26.7 ms
-// at 256 frames; a hair faster at 32 frames): kept as a build switch.
-#ifndef TX_WAIT_CLAIMS
-#define TX_WAIT_CLAIMS 1
-#endif
-// TX_LOCAL_CLAIMS = 1: a tile wave keeps the pixels IT claimed in this round as a bitmap in LDS (a 128 x 128 window around the
-// tile) instead of reading them back from the owner map.  What a step has to know about a neighbour q is (a) owner_{t-1}[q] — the
-// other component of the owner word, which nobody writes in round t: a plain, cacheable load — and (b) whether a lower rank claimed
-// q in this round.  The wave walks its seeds in rank order, so every claim it made before the current region IS a lower rank, and
-// a claim of the current region is "already mine": one bit answers both.  Claims of OTHER tiles' waves made in the same round are
-// not seen any more (they were seen only when the timing happened to allow it; the relaxation is exact for any interleaving, the
-// next round's diff / mark stamp the regions that lost a pixel).  The step then is ONE round trip of plain loads: the claims are
-// fire-and-forget atomics.  Pixels outside the window (long regions) still go through the owner map (L1-bypassing load of the
-// current component, returning claim that is waited for).
-// Measured (256 frames): exact (all parity tests and fuzzers green) but slower — k_tx_grow 24.4 -> 28.2 ms, the later rounds
-// 24.3 -> 31.0 ms (unseen foreign claims are regrown a round later; and the growers move 2 TB/s of 64-byte sectors, close to what
-// HBM gives random gathers: cacheable owner loads fetch whole lines where the L1-bypassing ones fetched sectors).  Off.
-#ifndef TX_LOCAL_CLAIMS
-#define TX_LOCAL_CLAIMS 0
-#endif
-constexpr int TX_WIN = 128;                               // side of the claim window (bits)
-constexpr int TX_GQ = TX_LOCAL_CLAIMS ? 512 : 1024;       // queue entries of a region kept in LDS
+// Variants of the step that were built, measured at 256 frames and shelved — all exact (parity tests and fuzzers green); the code is
+// in the history (commits 04f13dc .. 1fb47bd):
+//   * claims not waited for (non-returning atomicMin, or returning ones consumed after the next step's loads are issued): the loads
+//     are issued by the same wave in program order and meet the claims in the same L2 channel, so they still see them; slower with
+//     32 tile waves per CU (k_tx_grow 24.4 -> 26.8 / 26.7 ms), a hair faster at 32 frames;
+//   * the wave's own claims of the round as an LDS bitmap, the owner map read only for owner_{t-1} (one round trip per step, claims
+//     fire-and-forget): k_tx_grow 24.4 -> 28.2 ms, later rounds 24.3 -> 31.0 ms — the claims of OTHER tiles' waves made in the same
+//     round are no longer seen and are regrown a round later;
+//   * the same bitmap only to skip the loads of seeds the wave itself has taken: a third of the L2 misses gone (854 M -> 577 M),
+//     time unchanged — the growers are bound by instruction issue (4 cycles x (VALU + SALU instructions) per SIMD matches the
+//     kernel time within 10 % in every variant), not by the miss rate (65 % of the 49 G/s ceiling of tools/probes/gather_rate.hip).
+constexpr int TX_GQ = 1024;       // queue entries of a region kept in LDS
 constexpr int TX_BBLK = 256;      // arena block for the overflow of a large region's queue
 constexpr int TX_BMAXBLK = 128;   // => regions of up to TX_GQ + 32768 pixels
 
@@ -388,7 +375,6 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
                                              int rectCap, int img0, int t) {
   __shared__ int q[TX_GQ];
   __shared__ int gb[TX_BMAXBLK];
-  __shared__ unsigned claimed[TX_LOCAL_CLAIMS ? TX_WIN * TX_WIN / 32 : 1];
   const DevParams& P = *Pp;
   const int img = blockIdx.y + img0, tile = blockIdx.x;
   RxCtl& c = ctl[img];
@@ -411,18 +397,6 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
   }
   const float4* rec = recAll + img * npix;
   int2* own = ownAll + img * npix;
-  // the claim window: TX_WIN x TX_WIN pixels centred on the tile
-  const int wx0 = (tile % ntx) * ts - (TX_WIN - ts) / 2, wy0 = (tile / ntx) * ts - (TX_WIN - ts) / 2;
-  if (TX_LOCAL_CLAIMS) {
-    for (int i = threadIdx.x; i < TX_WIN * TX_WIN / 32; i += 64) claimed[i] = 0u;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  }
-  auto winBit = [&](int x, int y, int& word, unsigned& bit) -> bool {
-    const int wx = x - wx0, wy = y - wy0;
-    word = (wy * TX_WIN + wx) >> 5;
-    bit = 1u << (wx & 31);
-    return (unsigned)wx < (unsigned)TX_WIN && (unsigned)wy < (unsigned)TX_WIN;
-  };
   const int2* list = listAll + ((int64_t)img * ntile + tile) * ts * ts;
   int* rgSize = rgSizeAll + img * npix;
   int2* rgBox = rgBoxAll + img * npix;
@@ -458,12 +432,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
       srec = rec[se.y];
       so = tx_load_own(&own[se.y]);
     }
-    bool alive = d && (ci ? so.x : so.y) == se.x && (ci ? so.y : so.x) == se.x;
-    if (TX_LOCAL_CLAIMS && alive) {                       // (the seeds of a tile lie inside its window)
-      int wd; unsigned bt;
-      const int sy_ = se.y / W;
-      if (winBit(se.y - sy_ * W, sy_, wd, bt) && (claimed[wd] & bt)) alive = false;
-    }
+    const bool alive = d && (ci ? so.x : so.y) == se.x && (ci ? so.y : so.x) == se.x;
     // region_grow seeds its sums with cos/sin of the unrounded double angle
     float scos = 0.f, ssin = 0.f;
     if (alive) {
@@ -483,96 +452,74 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
       int angCnt = 1;                                     // reg_angle is the angle of the sums at this pixel count (the seed angle at 1)
       const int spy = sp / W, spx = sp - spy * W;
       q[0] = (spy << 16) | spx;                           // every lane stores the same value
-      if (TX_LOCAL_CLAIMS) {
-        int wd; unsigned bt;
-        if (winBit(spx, spy, wd, bt) && lane == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1) claimed[wd] |= bt;
-      }
       int cnt = 1, k = 0;
       int bmin = (spy << 16) | spx, bmax = bmin;          // bounding box: packed 16-bit (y, x) minima / maxima
       int pendOld = 0x7FFFFFFF;
       bool dead = false;
-      while (k < cnt && !dead) {
+      // One step = up to 8 queue entries x 8 neighbours in one round trip (record + owner pair per lane), the accept loop, the
+      // claims.  Two loops, the usual one first (the queue entries of the step fit the LDS queue) and the overflow form after
+      // it: as two instances inside ONE loop they shared their loop-carried state and the compiler moved ~20 registers per step.
+      auto oneStep = [&](auto spillTag) {
+        constexpr bool SPILL = decltype(spillTag)::value;
         // single-wave block: the LDS operations of a wave execute in order (the compiler only has to keep the order)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         // The claims of the previous step are returning atomics: their results are consumed here, before the owner
         // loads of this step are issued, so those loads see the region's own claims.
-        if (TX_WAIT_CLAIMS == 1 && !TX_LOCAL_CLAIMS) asm volatile("" ::"v"(pendOld) : "memory");
-        const int pendPrev = pendOld;
+        asm volatile("" ::"v"(pendOld) : "memory");
         pendOld = 0x7FFFFFFF;
         bool accepted = false;
-        int qi = -1, nb = 0, myxyOut = 0;
-        bool inWin = false;
-        auto step = [&](auto spillTag) {
-          constexpr bool SPILL = decltype(spillTag)::value;
-          int myxy = -1;
-          float4 rr = make_float4(TX_NOTDEF, 0.f, 0.f, 0.f);
-          int2 oo = make_int2(0, 0);
-          nb = min(8, cnt - k);
-          bool mineOrLower = false;                       // TX_LOCAL_CLAIMS: claimed by this wave in this round (window bit)
-          if (pi < nb) {
-            const int e = SPILL ? qget(k + pi) : tx_lds_read(&q[k + pi]);
-            const int nx = (e & 0xFFFF) + ndx, ny = (e >> 16) + ndy;
-            if (nx >= 0 && ny >= 0 && nx < W && ny < H) {
-              qi = ny * W + nx;
-              myxy = (ny << 16) | nx;
-              myxyOut = myxy;
-              rr = rec[qi];
-              if (TX_LOCAL_CLAIMS) {
-                int wd; unsigned bt;
-                inWin = winBit(nx, ny, wd, bt);
-                if (inWin) {
-                  oo = own[qi];                           // owner_{t-1} is all that is read of it: static in this round
-                  mineOrLower = (claimed[wd] & bt) != 0u;
-                  if (ci) oo.y = 0x7FFFFFFF; else oo.x = 0x7FFFFFFF;     // (the current component is not looked at)
-                } else {
-                  oo = tx_load_own(&own[qi]);
-                }
-              } else {
-                oo = tx_load_own(&own[qi]);
-              }
-            }
+        int qi = -1, myxy = -1;
+        float4 rr = make_float4(TX_NOTDEF, 0.f, 0.f, 0.f);
+        int2 oo = make_int2(0, 0);
+        const int nb = min(8, cnt - k);
+        if (pi < nb) {
+          const int e = SPILL ? qget(k + pi) : tx_lds_read(&q[k + pi]);
+          const int nx = (e & 0xFFFF) + ndx, ny = (e >> 16) + ndy;
+          if (nx >= 0 && ny >= 0 && nx < W && ny < H) {
+            qi = ny * W + nx;
+            myxy = (ny << 16) | nx;
+            rr = rec[qi];
+            oo = tx_load_own(&own[qi]);
           }
-          if (TX_WAIT_CLAIMS == 2) asm volatile("" ::"v"(pendPrev) : "memory");   // (the claims return before the loads issued after them)
-          const int prevv = ci ? oo.x : oo.y, curv = ci ? oo.y : oo.x;
-          const bool cand = rr.x != TX_NOTDEF && !(prevv < r || curv <= r) && !mineOrLower;
-          unsigned long long remaining = __builtin_amdgcn_ballot_w64(cand);
-          if (!SPILL) {
-            // the usual case (the queue entries of this batch fit the LDS queue): tx_accept_fast; accepted lanes write their queue
-            // entries after the loop (they are accepted in increasing lane order)
-            unsigned long long acc = 0ull;
-            const int cnt0 = cnt;
-            while (remaining) {
-              int j2;
-              const int code = tx_accept_fast(sumdx, sumdy, rr.y, rr.z, qi, myxy, se.y, remaining, acc, unusedMask, cnt, bmin, bmax,
-                                              alignLo, alignHi, j2);
-              if (code == 0) break;
-              // lane j2 lies inside the margin of the vector filter: the reference's own expression decides
-              if (angCnt != cnt) {
-                reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * TX_DEG2RAD;
-                angCnt = cnt;
-              }
-              double n_theta = fabs(reg_angle - (double)tx_rlf(rr.x, j2) * TX_DEG2RAD);
-              if (n_theta > TX_3_2_PI) {
-                n_theta = fabs(n_theta - TX_2PI);
-              }
-              // (the sums live in vector registers, so the compiler takes this decision for lane-dependent: say it is not)
-              if (!__builtin_amdgcn_readfirstlane((int)(n_theta <= prec))) continue;
-              const int qj = tx_rl(qi, j2);
-              const int xyj = tx_rl(myxy, j2);
-              const float cj = tx_rlf(rr.y, j2), sj = tx_rlf(rr.z, j2);
-              acc |= 1ull << j2;
-              remaining &= ~__builtin_amdgcn_ballot_w64(qi == qj);          // the other copies of the accepted pixel
-              unusedMask &= ~__builtin_amdgcn_ballot_w64(se.y == qj);       // a seed of this row that was just taken
-              ++cnt;
-              bmin = tx_pk_min_u16(bmin, xyj);
-              bmax = tx_pk_max_u16(bmax, xyj);
-              sumdx = __fadd_rn(sumdx, cj);
-              sumdy = __fadd_rn(sumdy, sj);
+        }
+        const int prevv = ci ? oo.x : oo.y, curv = ci ? oo.y : oo.x;
+        const bool cand = rr.x != TX_NOTDEF && !(prevv < r || curv <= r);
+        unsigned long long remaining = __builtin_amdgcn_ballot_w64(cand);
+        if (!SPILL) {
+          // tx_accept_fast; accepted lanes write their queue entries after the loop (they are accepted in increasing lane order)
+          unsigned long long acc = 0ull;
+          const int cnt0 = cnt;
+          while (remaining) {
+            int j2;
+            const int code = tx_accept_fast(sumdx, sumdy, rr.y, rr.z, qi, myxy, se.y, remaining, acc, unusedMask, cnt, bmin, bmax,
+                                            alignLo, alignHi, j2);
+            if (code == 0) break;
+            // lane j2 lies inside the margin of the vector filter: the reference's own expression decides
+            if (angCnt != cnt) {
+              reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * TX_DEG2RAD;
+              angCnt = cnt;
             }
-            accepted = (acc >> lane) & 1ull;
-            if (accepted) q[cnt0 + __popcll(acc & ((1ull << lane) - 1ull))] = myxy;
-            return;
+            double n_theta = fabs(reg_angle - (double)tx_rlf(rr.x, j2) * TX_DEG2RAD);
+            if (n_theta > TX_3_2_PI) {
+              n_theta = fabs(n_theta - TX_2PI);
+            }
+            // (the sums live in vector registers, so the compiler takes this decision for lane-dependent: say it is not)
+            if (!__builtin_amdgcn_readfirstlane((int)(n_theta <= prec))) continue;
+            const int qj = tx_rl(qi, j2);
+            const int xyj = tx_rl(myxy, j2);
+            const float cj = tx_rlf(rr.y, j2), sj = tx_rlf(rr.z, j2);
+            acc |= 1ull << j2;
+            remaining &= ~__builtin_amdgcn_ballot_w64(qi == qj);          // the other copies of the accepted pixel
+            unusedMask &= ~__builtin_amdgcn_ballot_w64(se.y == qj);       // a seed of this row that was just taken
+            ++cnt;
+            bmin = tx_pk_min_u16(bmin, xyj);
+            bmax = tx_pk_max_u16(bmax, xyj);
+            sumdx = __fadd_rn(sumdx, cj);
+            sumdy = __fadd_rn(sumdy, sj);
           }
+          accepted = (acc >> lane) & 1ull;
+          if (accepted) q[cnt0 + __popcll(acc & ((1ull << lane) - 1ull))] = myxy;
+        } else {
           while (remaining) {
             // the alignment test in vector form with the exact expression inside the margin (see k_lsd_grow)
             const float n2 = __builtin_fmaf(sumdx, sumdx, sumdy * sumdy);
@@ -625,30 +572,12 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
             sumdy = __fadd_rn(sumdy, sj);
             unusedMask &= ~__builtin_amdgcn_ballot_w64(se.y == qj);   // a seed of this row that was just taken
           }
-        };
-        if (cnt + 8 * 8 + 1 > TX_GQ) step(std::true_type{});
-        else step(std::false_type{});
-        if (TX_LOCAL_CLAIMS) {
-          // claims inside the window: the bit, and a fire-and-forget atomicMin; a claim outside it is read back from the owner
-          // map by later steps, so it is a returning atomic that the next step waits for (wave-uniform choice: the wait must
-          // not be there when nobody needs it)
-          if (accepted && inWin) {
-            const int wx = (myxyOut & 0xFFFF) - wx0, wy = (myxyOut >> 16) - wy0;
-            atomicOr(&claimed[(wy * TX_WIN + wx) >> 5], 1u << (wx & 31));
-          }
-          if (__builtin_amdgcn_ballot_w64(accepted && !inWin)) {
-            if (accepted) pendOld = __hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("" ::"v"(pendOld) : "memory");
-            pendOld = 0x7FFFFFFF;
-          } else if (accepted) {
-            (void)__hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        } else if (accepted) {
-          if (TX_WAIT_CLAIMS) pendOld = __hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else (void)__hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (accepted) pendOld = __hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         k += nb;
-      }
+      };
+      while (k < cnt && cnt + 8 * 8 + 1 <= TX_GQ) oneStep(std::false_type{});
+      while (k < cnt && !dead) oneStep(std::true_type{});
       asm volatile("" ::"v"(pendOld) : "memory");
       if (dead) { c.overflow = 5; return; }
       // ---- the region is complete ----
