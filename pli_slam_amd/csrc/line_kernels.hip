@@ -1085,17 +1085,19 @@ __device__ __forceinline__ void lsd_grow_image_spec(const DevParams* __restrict_
         }
         LTIME(17, tA);
       };
-      for (int k = k0; k < cnt;) {
-        if (cnt + 65 <= SPEC_Q) {                    // a batch can append up to 8 x 8 entries
-          const int nb = min(8, cnt - k);
-          LSTAT(15, 1);
-          batch(k, nb);
-          k += nb;
-        } else {
-          if (cnt + 9 > SPEC_Q) step(k, std::true_type{});
-          else step(k, std::false_type{});
-          ++k;
-        }
+      // (two loops, not one with a branch: as alternatives inside one loop the two forms share their loop-carried state and
+      // the compiler moves a dozen registers per step between them)
+      int k = k0;
+      while (k < cnt && cnt + 65 <= SPEC_Q) {        // a batch can append up to 8 x 8 entries
+        const int nb = min(8, cnt - k);
+        LSTAT(15, 1);
+        batch(k, nb);
+        k += nb;
+      }
+      while (k < cnt) {
+        if (cnt + 9 > SPEC_Q) step(k, std::true_type{});
+        else step(k, std::false_type{});
+        ++k;
       }
       LSTAT(7, cnt - cntStart);
       if (cnt < minReg) continue;
