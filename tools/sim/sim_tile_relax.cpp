@@ -196,7 +196,19 @@ int main(int argc, char** argv) {
       std::vector<char> dirty(R, (t <= 1 || (t == 2 && full2)) ? 1 : 0);
       std::vector<int> cellMin(CW * CH, INT32_MAX);
       long changed = 0;
-      if (t == 2) {
+      if (t == 2 && getenv("SIM_LOST")) {
+        // candidate rule: a region is regrown in round 2 iff it LOST a pixel it claimed in round 1 (to a lower rank), or died
+        for (int r = 0; r < R; ++r) {
+          if (lastRound[r] != 1) continue;
+          for (int q : lastRun[r]) if (prev[q] != r) { dirty[r] = 1; break; }
+        }
+        for (int q = 0; q < N; ++q) {
+          const int o = prev[q];
+          if (o == INT32_MAX) continue;
+          if (prev[F.order[o]] != o) dirty[o] = 1;
+        }
+        changed = 1;
+      } else if (t == 2) {
         for (int q = 0; q < N; ++q) {
           const int o = prev[q];
           if (o == INT32_MAX) continue;
