@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void k_tx_diff2(RxCtl* __restrict__ ctl, const
                                                   const int* __restrict__ orderAll, const int2* __restrict__ rgBoxAll,
                                                   int* __restrict__ rgDirtyAll, int* __restrict__ tileMinAll,
                                                   int* __restrict__ tileActAll, int W, int H, int TW, int TH, int ts, int t,
-                                                  int img0) {
+                                                  int img0, const int* __restrict__ rgLostAll) {
   __shared__ int tmin[4];
   const int img = blockIdx.z + img0;
   RxCtl& c = ctl[img];
@@ -220,13 +220,22 @@ __global__ __launch_bounds__(256) void k_tx_diff2(RxCtl* __restrict__ ctl, const
     if (o != INT_MAX) {
       const int sp = orderAll[base + o];
       const int sx = sp % W, sy = sp / W;
-      if (sx / ts != x / ts || sy / ts != y / ts) atomicMin(&tmin[(tid & 31) >> 3], o);
+      if (!rgLostAll && (sx / ts != x / ts || sy / ts != y / ts)) atomicMin(&tmin[(tid & 31) >> 3], o);
       if (sp != y * W + x) {
         // the owner ran in round 1 and lost its seed afterwards (to a lower rank of another tile): it is dead in owner_1, its
         // remaining pixels must be released (the later rounds do this with k_rx_mark's "seed changed hands" rule)
         const int2 so = ownAll[base + sp];
         if (((t & 1) ? so.x : so.y) != o) tx_mark_dirty(o, t, rgDirtyAll + base, rgBoxAll + base, tileActAll + (int64_t)img * TW * TH, TW, TH);
-      } else {                                          // the seed of an alive region: does its box (+1) leave the tile?
+      } else if (rgLostAll) {
+        // the seed of an alive region.  Exact rule (rgLostAll): its round-1 run stands unless it LOST a pixel it claimed — a lower
+        // rank claimed the pixel too; the growers note the loser of every such claim.  (Why nothing else: take the lowest-ranked
+        // region whose run differs from the sequential one; everything below it is final, so a pixel it wrongly took is claimed
+        // by its rightful lower owner as well, and a pixel it was wrongly refused would have to be held by a lower region that
+        // does not hold it in the end — which is then a change of the later rounds' kind.  tools/sim/sim_tile_relax.cpp replays
+        // the rule: SIM_CARRY=1 SIM_LOST=1.)
+        if (rgLostAll[base + o] != 0)
+          tx_mark_dirty(o, t, rgDirtyAll + base, rgBoxAll + base, tileActAll + (int64_t)img * TW * TH, TW, TH);
+      } else {                                          // conservative rule: does its box (+1) leave the tile?
         const int2 b = rgBoxAll[base + o];
         const int tx0 = (x / ts) * ts, ty0 = (y / ts) * ts;
         if ((b.x & 0xFFFF) - 1 < tx0 || (b.x >> 16) - 1 < ty0 || (b.y & 0xFFFF) + 1 >= tx0 + ts || (b.y >> 16) + 1 >= ty0 + ts)
@@ -372,7 +381,8 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
                                              int2* __restrict__ rgBoxAll, const int* __restrict__ rgDirtyAll,
                                              const int* __restrict__ tileActAll, int TW, int TH,
                                              int* __restrict__ arenaAll, int arenaCap, RxRect* __restrict__ rectAll,
-                                             int rectCap, int img0, int t) {
+                                             int rectCap, int img0, int t, const int* __restrict__ rankAll,
+                                             int* __restrict__ rgLostAll) {
   __shared__ int q[TX_GQ];
   __shared__ int gb[TX_BMAXBLK];
   const DevParams& P = *Pp;
@@ -402,6 +412,10 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
   int2* rgBox = rgBoxAll + img * npix;
   const int* rgDirty = rgDirtyAll + img * npix;
   int* arena = arenaAll + (int64_t)img * arenaCap;
+  // round 1: the loser of every contested claim is noted for k_tx_diff2 (a region that lost a pixel it claimed is regrown)
+  const bool noteLost = rgLostAll != nullptr && t == 1;
+  int* rgLost = rgLostAll ? rgLostAll + img * npix : nullptr;
+  const int* rankOfPix = rankAll + img * npix;
   RxRect* rects = rectAll + (int64_t)img * rectCap;
   const int ci = t & 1;                                   // owner_t lives in component ci, owner_{t-1} in the other
   const double prec = P.prec;
@@ -454,7 +468,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
       q[0] = (spy << 16) | spx;                           // every lane stores the same value
       int cnt = 1, k = 0;
       int bmin = (spy << 16) | spx, bmax = bmin;          // bounding box: packed 16-bit (y, x) minima / maxima
-      int pendOld = 0x7FFFFFFF;
+      int pendOld = 0x7FFFFFFF, pendRank = 0;
       bool dead = false;
       // One step = up to 8 queue entries x 8 neighbours in one round trip (record + owner pair per lane), the accept loop, the
       // claims.  Two loops, the usual one first (the queue entries of the step fit the LDS queue) and the overflow form after
@@ -466,6 +480,12 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
         // The claims of the previous step are returning atomics: their results are consumed here, before the owner
         // loads of this step are issued, so those loads see the region's own claims.
         asm volatile("" ::"v"(pendOld) : "memory");
+        if (noteLost && pendOld != 0x7FFFFFFF) {          // (0x7FFFFFFF: this lane claimed nothing in the last step)
+          // pendOld = what stood in the owner word when this region's claim arrived: a lower rank -> this region does not hold the
+          // pixel it took; a higher rank that is not the pixel's own (initial) rank -> that region just lost the pixel
+          if (pendOld < r) rgLost[r] = 1;
+          else if (pendOld != r && pendOld != pendRank) rgLost[pendOld] = 1;
+        }
         pendOld = 0x7FFFFFFF;
         bool accepted = false;
         int qi = -1, myxy = -1;
@@ -573,11 +593,22 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
             unusedMask &= ~__builtin_amdgcn_ballot_w64(se.y == qj);   // a seed of this row that was just taken
           }
         }
-        if (accepted) pendOld = __hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (accepted) {
+          pendOld = __hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (noteLost) pendRank = rankOfPix[qi];
+        }
         k += nb;
       };
       while (k < cnt && cnt + 8 * 8 + 1 <= TX_GQ) oneStep(std::false_type{});
       while (k < cnt && !dead) oneStep(std::true_type{});
+      if (noteLost) {                                     // the claims of the region's last step
+        asm volatile("" ::"v"(pendOld) : "memory");
+        if (pendOld != 0x7FFFFFFF) {
+          if (pendOld < r) rgLost[r] = 1;
+          else if (pendOld != r && pendOld != pendRank) rgLost[pendOld] = 1;
+        }
+        pendOld = 0x7FFFFFFF;
+      }
       asm volatile("" ::"v"(pendOld) : "memory");
       if (dead) { c.overflow = 5; return; }
       // ---- the region is complete ----
@@ -614,9 +645,10 @@ __global__ __launch_bounds__(64) void k_tx_grow(const DevParams* __restrict__ Pp
                                                 int2* __restrict__ rgBoxAll, const int* __restrict__ rgDirtyAll,
                                                 const int* __restrict__ tileActAll, int TW, int TH,
                                                 int* __restrict__ arenaAll, int arenaCap, RxRect* __restrict__ rectAll,
-                                                int rectCap, int img0, int t) {
+                                                int rectCap, int img0, int t, const int* __restrict__ rankAll,
+                                                int* __restrict__ rgLostAll) {
   tx_grow_tile<false>(Pp, ctl, recAll, ownAll, listAll, tileCntAll, ts, ntx, nty, rgSizeAll, rgBoxAll, rgDirtyAll, tileActAll,
-                      TW, TH, arenaAll, arenaCap, rectAll, rectCap, img0, t);
+                      TW, TH, arenaAll, arenaCap, rectAll, rectCap, img0, t, rankAll, rgLostAll);
 }
 __global__ __launch_bounds__(64) void k_tx_grow_sparse(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
                                                        const float4* __restrict__ recAll, int2* __restrict__ ownAll,
@@ -625,9 +657,10 @@ __global__ __launch_bounds__(64) void k_tx_grow_sparse(const DevParams* __restri
                                                        int2* __restrict__ rgBoxAll, const int* __restrict__ rgDirtyAll,
                                                        const int* __restrict__ tileActAll, int TW, int TH,
                                                        int* __restrict__ arenaAll, int arenaCap, RxRect* __restrict__ rectAll,
-                                                       int rectCap, int img0, int t) {
+                                                       int rectCap, int img0, int t, const int* __restrict__ rankAll,
+                                                       int* __restrict__ rgLostAll) {
   tx_grow_tile<true>(Pp, ctl, recAll, ownAll, listAll, tileCntAll, ts, ntx, nty, rgSizeAll, rgBoxAll, rgDirtyAll, tileActAll,
-                     TW, TH, arenaAll, arenaCap, rectAll, rectCap, img0, t);
+                     TW, TH, arenaAll, arenaCap, rectAll, rectCap, img0, t, rankAll, rgLostAll);
 }
 
 }  // namespace pli
