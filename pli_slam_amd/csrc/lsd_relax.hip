@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void k_rx_mark(RxCtl* __restrict__ ctl, const 
                                                  const int* __restrict__ rankAll, const int2* __restrict__ rgBoxAll,
                                                  int* __restrict__ rgDirtyAll, const int* __restrict__ tileMinAll,
                                                  int* __restrict__ tileActAll, int W, int H, int TW, int TH, int t, int img0,
-                                                 int seedRule) {
+                                                 int seedRule, const int* __restrict__ rgLostAll) {
   // (RX_DIFF_ROWS rows of cells per workgroup, like k_rx_diff: the grid of one-row blocks is bound by the dispatch rate)
   __shared__ int nt[RX_DIFF_ROWS + 2][6];
   __shared__ int s_any[RX_DIFF_ROWS];
@@ -312,7 +312,28 @@ __global__ __launch_bounds__(256) void k_rx_mark(RxCtl* __restrict__ ctl, const 
     const int cx0 = (lx + 7) >> 3, cx1 = (lx + 9) >> 3;        // nt column of x-1 and x+1 (nt column 1 = first own tile)
     const int cy0 = rr + ((ly + 7) >> 3), cy1 = rr + ((ly + 9) >> 3);
     const int m = min(min(nt[cy0][cx0], nt[cy0][cx1]), min(nt[cy1][cx0], nt[cy1][cx1]));
-    if (m < prevv) rx_mark_dirty(prevv, true, t, rgDirty, rgBox, tileAct, TW, TH);
+    if (rgLostAll) {
+      // Exact rule (tile-sequential relaxation): the region that holds (x, y) in owner_{t-1} is regrown iff
+      //   * it lost a contested claim in round t-1 (the growers stamp the loser), or a neighbour q of this pixel was its own in
+      //     owner_{t-2} and belongs to a lower rank now (it lost q across the rounds), or
+      //   * a neighbour q was held by a lower rank in owner_{t-2} and is not any more (released, or passed to a higher rank):
+      //     the region may take it now.
+      // (The 8x8-cell rule below — any change that involves a lower rank within a pixel — regrew ten times as many regions;
+      // tools/sim/sim_tile_relax.cpp replays both: SIM_CARRY=1 SIM_LOST=1 SIM_EXACT=1 SIM_GPURULE=1.)
+      bool hit = m != INT_MAX && rgLostAll[base + prevv] == t - 1;
+      if (m != INT_MAX && !hit) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          if (k == 4) continue;
+          const int qx = x + k % 3 - 1, qy = y + k / 3 - 1;
+          if (qx < 0 || qy < 0 || qx >= W || qy >= H) continue;
+          const int2 oq = ownAll[base + qy * W + qx];
+          const int pq = ci ? oq.x : oq.y, p2q = ci ? oq.y : oq.x;
+          hit = hit || (p2q < prevv && pq > prevv && pq != INT_MAX) || (p2q == prevv && pq < prevv);
+        }
+      }
+      if (hit) rx_mark_dirty(prevv, true, t, rgDirty, rgBox, tileAct, TW, TH);
+    } else if (m < prevv) rx_mark_dirty(prevv, true, t, rgDirty, rgBox, tileAct, TW, TH);
     const bool a1 = prevv == r, a2 = prev2 == r;
     // (seedRule 0: round 2 of the tile-sequential relaxation, where owner_{t-2} is the trivial map and the seeds that died in
     // round 1 never ran)

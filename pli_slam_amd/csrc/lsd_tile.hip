@@ -412,8 +412,8 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
   int2* rgBox = rgBoxAll + img * npix;
   const int* rgDirty = rgDirtyAll + img * npix;
   int* arena = arenaAll + (int64_t)img * arenaCap;
-  // round 1: the loser of every contested claim is noted for k_tx_diff2 (a region that lost a pixel it claimed is regrown)
-  const bool noteLost = rgLostAll != nullptr && t == 1;
+  // the loser of every contested claim is noted (a region that lost a pixel it claimed is regrown in the next round)
+  const bool noteLost = rgLostAll != nullptr;             // (stamped with the round: k_tx_diff2 reads round 1's, k_rx_mark the last round's)
   int* rgLost = rgLostAll ? rgLostAll + img * npix : nullptr;
   const int* rankOfPix = rankAll + img * npix;
   RxRect* rects = rectAll + (int64_t)img * rectCap;
@@ -483,8 +483,8 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
         if (noteLost && pendOld != 0x7FFFFFFF) {          // (0x7FFFFFFF: this lane claimed nothing in the last step)
           // pendOld = what stood in the owner word when this region's claim arrived: a lower rank -> this region does not hold the
           // pixel it took; a higher rank that is not the pixel's own (initial) rank -> that region just lost the pixel
-          if (pendOld < r) rgLost[r] = 1;
-          else if (pendOld != r && pendOld != pendRank) rgLost[pendOld] = 1;
+          if (pendOld < r) rgLost[r] = t;
+          else if (pendOld != r && pendOld != pendRank) rgLost[pendOld] = t;
         }
         pendOld = 0x7FFFFFFF;
         bool accepted = false;
@@ -604,8 +604,8 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
       if (noteLost) {                                     // the claims of the region's last step
         asm volatile("" ::"v"(pendOld) : "memory");
         if (pendOld != 0x7FFFFFFF) {
-          if (pendOld < r) rgLost[r] = 1;
-          else if (pendOld != r && pendOld != pendRank) rgLost[pendOld] = 1;
+          if (pendOld < r) rgLost[r] = t;
+          else if (pendOld != r && pendOld != pendRank) rgLost[pendOld] = t;
         }
         pendOld = 0x7FFFFFFF;
       }

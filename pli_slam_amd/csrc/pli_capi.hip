@@ -802,7 +802,8 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
               P.LW, P.LH, c->tilesW, c->tilesH, t, img0);
         if (t >= 3 || (t == 2 && !fullRound2)) {
           TRL(c, "k_rx_mark", k_rx_mark, dim3((P.LW + 31) / 32, (c->tilesH + 7) / 8, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->rgBox,
-              c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, t >= 3 ? 1 : 0);
+              c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, t >= 3 ? 1 : 0,
+              (lostRule && t >= 3 && !getenv("PLI_TX_CELLRULE")) ? (const int*)c->rgLost : (const int*)nullptr);
           TRL(c, "k_tx_prep", k_tx_prep, dim3((P.LW + 31) / 32, (P.LH + 31) / 32, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf,
               c->rgDirty, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, t == 2 ? 1 : 0);
           TRL(c, "k_tx_grow_sparse", k_tx_grow_sparse, dim3(ntile, nimg), dim3(64), txPad, c->dP, c->jrCtl, c->rec, c->own, c->txList,
@@ -834,7 +835,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       if (t >= 3 && !fullPasses) {
         // bookkeeping only where something happened (lsd_relax.hip)
         TRL(c, "k_rx_mark", k_rx_mark, dim3((P.LW + 31) / 32, (c->tilesH + 7) / 8, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->rgBox,
-            c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, 1);
+            c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, 1, (const int*)nullptr);
         TRL(c, "k_rx_seed_sparse", k_rx_seed_sparse, dim3((P.LW + 31) / 32, (P.LH + 31) / 32, nimg), dim3(1024), 0, c->jrCtl, c->own, c->rankOf,
             c->rec, c->lastSize, c->rgDirty, c->tileAct, c->smallSeeds, c->bigSeeds, c->bigCap, P.LW, P.LH, c->tilesW, c->tilesH,
             bigThresh, t, img0);

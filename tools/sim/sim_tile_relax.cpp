@@ -178,6 +178,8 @@ int main(int argc, char** argv) {
     for (int q = 0; q < N; ++q) prev[q] = F.rankOf[q];          // trivial owner_0 (INT_MAX for undefined)
     std::vector<std::vector<int>> lastRun(R);                    // pixel list of the last run of every region
     std::vector<int> lastRound(R, 0);
+    std::vector<int> lostStamp(R, 0);                            // GPU form: round in which the region last lost a contested claim
+    const bool gpuRule = getenv("SIM_GPURULE") != nullptr;       // flags + map comparison instead of the pixel lists
     const bool full2 = getenv("SIM_FULL2") != nullptr;
     std::vector<int> boxes(4 * (size_t)R, 0);
     // truth lists
@@ -200,7 +202,8 @@ int main(int argc, char** argv) {
         // candidate rule: a region is regrown in round 2 iff it LOST a pixel it claimed in round 1 (to a lower rank), or died
         for (int r = 0; r < R; ++r) {
           if (lastRound[r] != 1) continue;
-          for (int q : lastRun[r]) if (prev[q] != r) { dirty[r] = 1; break; }
+          if (gpuRule) { if (lostStamp[r] == 1) dirty[r] = 1; }
+          else for (int q : lastRun[r]) if (prev[q] != r) { dirty[r] = 1; break; }
         }
         for (int q = 0; q < N; ++q) {
           const int o = prev[q];
@@ -253,7 +256,32 @@ int main(int argc, char** argv) {
           break;
         }
       }
-      if (t >= 2) {
+      if (t >= 3 && getenv("SIM_EXACT")) {
+        // candidate rule for the later rounds: region o (alive in owner_{t-1}) is regrown iff
+        //  (a) it lost a pixel of its last run (owner_{t-1}[q] != o for a q of the list), or
+        //  (b) a neighbour q of one of its pixels was held by a lower rank in owner_{t-2} and is not any more (released or passed
+        //      to a higher rank): o may take it now;  plus the "seed changed hands" rule.
+        if (!gpuRule)
+          for (int r = 0; r < R; ++r) {
+            if (prev[F.order[r]] != r || lastRound[r] == 0) continue;
+            for (int q : lastRun[r]) if (prev[q] != r) { dirty[r] = 1; break; }
+          }
+        for (int p = 0; p < N; ++p) {
+          const int o = prev[p];
+          if (o == INT32_MAX) continue;
+          if (gpuRule && lostStamp[o] == t - 1) dirty[o] = 1;       // lost a contested claim in the last round
+          const int x = p % W, y = p / W;
+          for (int yy = std::max(y - 1, 0); yy <= std::min(y + 1, H - 1); ++yy)
+            for (int xx = std::max(x - 1, 0); xx <= std::min(x + 1, W - 1); ++xx) {
+              const int q = yy * W + xx;
+              if (prev2[q] < o && prev[q] > o && prev[q] != INT32_MAX) dirty[o] = 1;
+              if (gpuRule && prev2[q] == o && prev[q] < o) dirty[o] = 1;      // lost q across the rounds
+            }
+          const int r = F.rankOf[p];
+          const bool a1 = prev[p] == r, a2 = prev2[p] == r;
+          if (a1 != a2) dirty[r] = 1;
+        }
+      } else if (t >= 2) {
         for (int q = 0; q < N; ++q) {
           const int o = prev[q];
           if (o == INT32_MAX) continue;
@@ -301,7 +329,13 @@ int main(int argc, char** argv) {
         static std::vector<std::pair<int, int>> all;
         if (T == 0) all.clear();
         all.insert(all.end(), claims.begin(), claims.end());
-        if (T == NT - 1) for (auto& c : all) cur[c.first] = std::min(cur[c.first], c.second);
+        if (T == NT - 1)
+          for (auto& c : all) {
+            const int old = cur[c.first];
+            if (old < c.second) lostStamp[c.second] = t;
+            else if (old > c.second && old != F.rankOf[c.first] && old != INT32_MAX) lostStamp[old] = t;
+            cur[c.first] = std::min(old, c.second);
+          }
       }
       long wrong = 0, wrongRuns = 0;
       for (int q = 0; q < N; ++q) if (cur[q] != truth[q]) ++wrong;
