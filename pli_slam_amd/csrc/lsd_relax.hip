@@ -313,26 +313,28 @@ __global__ __launch_bounds__(256) void k_rx_mark(RxCtl* __restrict__ ctl, const 
     const int cy0 = rr + ((ly + 7) >> 3), cy1 = rr + ((ly + 9) >> 3);
     const int m = min(min(nt[cy0][cx0], nt[cy0][cx1]), min(nt[cy1][cx0], nt[cy1][cx1]));
     if (rgLostAll) {
-      // Exact rule (tile-sequential relaxation): the region that holds (x, y) in owner_{t-1} is regrown iff
-      //   * it lost a contested claim in round t-1 (the growers stamp the loser), or a neighbour q of this pixel was its own in
-      //     owner_{t-2} and belongs to a lower rank now (it lost q across the rounds), or
-      //   * a neighbour q was held by a lower rank in owner_{t-2} and is not any more (released, or passed to a higher rank):
-      //     the region may take it now.
+      // Exact rule (tile-sequential relaxation).  A region is regrown iff
+      //   * it lost a contested claim in round t-1 (the growers stamp the loser), or a pixel next to one of its own was its own in
+      //     owner_{t-2} and belongs to a lower rank now (it lost that pixel across the rounds), or
+      //   * a pixel next to one of its own was held by a lower rank in owner_{t-2} and is not any more (released, or passed to a
+      //     higher rank): the region may take it now.
+      // All three start from a pixel whose owner CHANGED, so they are evaluated from that pixel's side: a changed (x, y) looks at
+      // its eight neighbours and stamps their owners (a few thousand pixels per image and round do so).
       // (The 8x8-cell rule below — any change that involves a lower rank within a pixel — regrew ten times as many regions;
       // tools/sim/sim_tile_relax.cpp replays both: SIM_CARRY=1 SIM_LOST=1 SIM_EXACT=1 SIM_GPURULE=1.)
-      bool hit = m != INT_MAX && rgLostAll[base + prevv] == t - 1;
-      if (m != INT_MAX && !hit) {
+      if (prevv != prev2) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
           if (k == 4) continue;
-          const int qx = x + k % 3 - 1, qy = y + k / 3 - 1;
-          if (qx < 0 || qy < 0 || qx >= W || qy >= H) continue;
-          const int2 oq = ownAll[base + qy * W + qx];
-          const int pq = ci ? oq.x : oq.y, p2q = ci ? oq.y : oq.x;
-          hit = hit || (p2q < prevv && pq > prevv && pq != INT_MAX) || (p2q == prevv && pq < prevv);
+          const int px = x + k % 3 - 1, py = y + k / 3 - 1;
+          if (px < 0 || py < 0 || px >= W || py >= H) continue;
+          const int2 op2 = ownAll[base + py * W + px];
+          const int op = ci ? op2.x : op2.y;           // owner_{t-1} of the neighbour
+          if (op == INT_MAX) continue;
+          if ((prev2 < op && prevv > op) || (prev2 == op && prevv < op) || rgLostAll[base + op] == t - 1)
+            rx_mark_dirty(op, true, t, rgDirty, rgBox, tileAct, TW, TH);
         }
       }
-      if (hit) rx_mark_dirty(prevv, true, t, rgDirty, rgBox, tileAct, TW, TH);
     } else if (m < prevv) rx_mark_dirty(prevv, true, t, rgDirty, rgBox, tileAct, TW, TH);
     const bool a1 = prevv == r, a2 = prev2 == r;
     // (seedRule 0: round 2 of the tile-sequential relaxation, where owner_{t-2} is the trivial map and the seeds that died in
