@@ -125,13 +125,36 @@ __global__ __launch_bounds__(256) void k_rx_guess(const float4* __restrict__ rec
 constexpr int RX_DIFF_ROWS = 8;
 __global__ __launch_bounds__(256) void k_rx_diff(RxCtl* __restrict__ ctl, const int2* __restrict__ ownAll,
                                                  int* __restrict__ tileMinAll, int* __restrict__ tileActAll, int W, int H,
-                                                 int TW, int TH, int t, int img0) {
+                                                 int TW, int TH, int t, int img0, const int* __restrict__ tileTouchAll) {
   __shared__ int tmin[RX_DIFF_ROWS][4];
+  __shared__ int s_rel;
   const int img = blockIdx.z + img0;
   RxCtl& c = ctl[img];
   if (c.state == 2) return;
   const int tid = threadIdx.x;
   if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { c.nSmall = 0; c.nBig = 0; c.nHand = 0; c.nextBig = 0; c.rectArena = 0ull; }
+  if (tileTouchAll) {
+    // tile-sequential relaxation, later rounds: the two owner components of a cell can only differ where round t-1 wrote one of
+    // them — k_tx_prep rewrites the cells with tileAct == t-1, the growers note the cells of their claims in tileTouch —
+    // everywhere else the carried owner stands in both: the block leaves without reading the 16 KB of owner pairs under it
+    if (tid == 0) s_rel = 0;
+    __syncthreads();
+    if (tid < 4 * RX_DIFF_ROWS) {
+      const int tx = blockIdx.x * 4 + (tid & 3), ty = blockIdx.y * RX_DIFF_ROWS + (tid >> 2);
+      if (tx < TW && ty < TH) {
+        const int64_t cell = (int64_t)img * TW * TH + ty * TW + tx;
+        if (tileActAll[cell] == t - 1 || tileTouchAll[cell] == t - 1) s_rel = 1;
+      }
+    }
+    __syncthreads();
+    if (!s_rel) {
+      if (tid < 4 * RX_DIFF_ROWS) {
+        const int tx = blockIdx.x * 4 + (tid & 3), ty = blockIdx.y * RX_DIFF_ROWS + (tid >> 2);
+        if (tx < TW && ty < TH) tileMinAll[(int64_t)img * TW * TH + ty * TW + tx] = INT_MAX;
+      }
+      return;
+    }
+  }
   if (tid < 4 * RX_DIFF_ROWS) tmin[tid >> 2][tid & 3] = INT_MAX;
   __syncthreads();
   const int x = blockIdx.x * 32 + (tid & 31);

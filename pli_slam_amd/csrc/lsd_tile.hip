@@ -382,7 +382,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
                                              const int* __restrict__ tileActAll, int TW, int TH,
                                              int* __restrict__ arenaAll, int arenaCap, RxRect* __restrict__ rectAll,
                                              int rectCap, int img0, int t, const int* __restrict__ rankAll,
-                                             int* __restrict__ rgLostAll) {
+                                             int* __restrict__ rgLostAll, int* __restrict__ tileTouchAll) {
   __shared__ int q[TX_GQ];
   __shared__ int gb[TX_BMAXBLK];
   const DevParams& P = *Pp;
@@ -416,6 +416,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
   const bool noteLost = rgLostAll != nullptr;             // (stamped with the round: k_tx_diff2 reads round 1's, k_rx_mark the last round's)
   int* rgLost = rgLostAll ? rgLostAll + img * npix : nullptr;
   const int* rankOfPix = rankAll + img * npix;
+  int* tileTouch = tileTouchAll ? tileTouchAll + (int64_t)img * TW * TH : nullptr;
   RxRect* rects = rectAll + (int64_t)img * rectCap;
   const int ci = t & 1;                                   // owner_t lives in component ci, owner_{t-1} in the other
   const double prec = P.prec;
@@ -596,6 +597,9 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
         if (accepted) {
           pendOld = __hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (noteLost) pendRank = rankOfPix[qi];
+          // (later rounds) the 8x8 cell of every claimed pixel is noted: the next round's k_rx_diff only looks where a claim or the
+          // round's k_tx_prep wrote
+          if (SPARSE && tileTouch) tileTouch[(myxy >> 19) * TW + ((myxy & 0xFFFF) >> 3)] = t;
         }
         k += nb;
       };
@@ -646,9 +650,9 @@ __global__ __launch_bounds__(64) void k_tx_grow(const DevParams* __restrict__ Pp
                                                 const int* __restrict__ tileActAll, int TW, int TH,
                                                 int* __restrict__ arenaAll, int arenaCap, RxRect* __restrict__ rectAll,
                                                 int rectCap, int img0, int t, const int* __restrict__ rankAll,
-                                                int* __restrict__ rgLostAll) {
+                                                int* __restrict__ rgLostAll, int* __restrict__ tileTouchAll) {
   tx_grow_tile<false>(Pp, ctl, recAll, ownAll, listAll, tileCntAll, ts, ntx, nty, rgSizeAll, rgBoxAll, rgDirtyAll, tileActAll,
-                      TW, TH, arenaAll, arenaCap, rectAll, rectCap, img0, t, rankAll, rgLostAll);
+                      TW, TH, arenaAll, arenaCap, rectAll, rectCap, img0, t, rankAll, rgLostAll, tileTouchAll);
 }
 __global__ __launch_bounds__(64) void k_tx_grow_sparse(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
                                                        const float4* __restrict__ recAll, int2* __restrict__ ownAll,
@@ -658,9 +662,9 @@ __global__ __launch_bounds__(64) void k_tx_grow_sparse(const DevParams* __restri
                                                        const int* __restrict__ tileActAll, int TW, int TH,
                                                        int* __restrict__ arenaAll, int arenaCap, RxRect* __restrict__ rectAll,
                                                        int rectCap, int img0, int t, const int* __restrict__ rankAll,
-                                                       int* __restrict__ rgLostAll) {
+                                                       int* __restrict__ rgLostAll, int* __restrict__ tileTouchAll) {
   tx_grow_tile<true>(Pp, ctl, recAll, ownAll, listAll, tileCntAll, ts, ntx, nty, rgSizeAll, rgBoxAll, rgDirtyAll, tileActAll,
-                     TW, TH, arenaAll, arenaCap, rectAll, rectCap, img0, t, rankAll, rgLostAll);
+                     TW, TH, arenaAll, arenaCap, rectAll, rectCap, img0, t, rankAll, rgLostAll, tileTouchAll);
 }
 
 }  // namespace pli

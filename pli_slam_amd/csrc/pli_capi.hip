@@ -79,7 +79,8 @@ struct pli_ctx {
   bool lsdFront64 = false;                   // the fused blur -> resize -> gradient pass applies (lsd_f64.hip: k_lsd_front64)
   int2* own = nullptr; RxSeed* smallSeeds = nullptr; RxSeed* bigSeeds = nullptr; int bigCap = 0;
   RxHand* hand = nullptr; int handCap = 0; RxRect* rects = nullptr; int rectCap = 0; int* rankOf = nullptr; int2* rgBox = nullptr; float4* rgSeg = nullptr; uint8_t* rgClean = nullptr;
-  int* rgLost = nullptr;                     // tile relaxation, round 1: regions that lost a pixel they claimed (per rank)
+  int* rgLost = nullptr;                     // tile relaxation: round in which a region last lost a contested claim (per rank)
+  int* tileTouch = nullptr;                  // tile relaxation: round in which a grower last claimed a pixel of the 8x8 cell
   int* tileMin = nullptr; int* tileAct = nullptr; int* rgDirty = nullptr; int tilesW = 0, tilesH = 0; int* rxChunkCnt = nullptr; int rxChunks = 0;
   int* lastSize = nullptr; int* arena = nullptr; int arenaCap = 0;
   RxCtl* jrCtl = nullptr;
@@ -533,6 +534,7 @@ pli_status allocAll(pli_ctx* c) {
     c->tilesW = (P.LW + 7) / 8; c->tilesH = (P.LH + 7) / 8;
     A(c->tileMin, (size_t)c->tilesW * c->tilesH * NR);
     A(c->tileAct, (size_t)c->tilesW * c->tilesH * NR);
+    A(c->tileTouch, (size_t)c->tilesW * c->tilesH * NR);
     A(c->rgDirty, npix * NR);
     A(c->rgLost, npix * NR);
     c->rxChunks = (int)((npix + 2047) / 2048);
@@ -759,6 +761,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     HIPCHK(hipMemsetAsync(c->rgDirty + (int64_t)img0 * npix, 0, sizeof(int) * npix64 * nimg, c->stream));
     const bool lostRule = c->lsdMode != 1 && getenv("PLI_TX_BOXRULE") == nullptr;     // dev switch: the conservative round-2 rule
     if (lostRule) HIPCHK(hipMemsetAsync(c->rgLost + (int64_t)img0 * npix, 0, sizeof(int) * npix64 * nimg, c->stream));
+    HIPCHK(hipMemsetAsync(c->tileTouch + (int64_t)img0 * c->tilesW * c->tilesH, 0, sizeof(int) * (size_t)c->tilesW * c->tilesH * nimg, c->stream));
     HIPCHK(hipMemsetAsync(c->tileAct + (int64_t)img0 * c->tilesW * c->tilesH, 0, sizeof(int) * (size_t)c->tilesW * c->tilesH * nimg, c->stream));
     TRL(c, "k_rx_rank", k_rx_rank, dim3((npix + 255) / 256, nimg), dim3(256), 0, c->order, c->nDefined, c->rankOf, npix64, img0);
     const dim3 raster((P.LW + 255) / 256, P.LH, nimg);
@@ -799,7 +802,8 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
               c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, ts, t, img0, lostRule ? (const int*)c->rgLost : (const int*)nullptr);
         else
           TRL(c, "k_rx_diff", k_rx_diff, dim3((P.LW + 31) / 32, (c->tilesH + 7) / 8, nimg), dim3(256), 0, c->jrCtl, c->own, c->tileMin, c->tileAct,
-              P.LW, P.LH, c->tilesW, c->tilesH, t, img0);
+              P.LW, P.LH, c->tilesW, c->tilesH, t, img0,
+              (t >= 3 && !fullRound2 && !getenv("PLI_TX_FULLDIFF")) ? (const int*)c->tileTouch : (const int*)nullptr);
         if (t >= 3 || (t == 2 && !fullRound2)) {
           TRL(c, "k_rx_mark", k_rx_mark, dim3((P.LW + 31) / 32, (c->tilesH + 7) / 8, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->rgBox,
               c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, t >= 3 ? 1 : 0,
@@ -808,11 +812,11 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
               c->rgDirty, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, t == 2 ? 1 : 0);
           TRL(c, "k_tx_grow_sparse", k_tx_grow_sparse, dim3(ntile, nimg), dim3(64), txPad, c->dP, c->jrCtl, c->rec, c->own, c->txList,
               c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty, c->tileAct, c->tilesW, c->tilesH, c->arena,
-              c->arenaCap, c->rects, c->rectCap, img0, t, (const int*)c->rankOf, lostRule ? c->rgLost : (int*)nullptr);
+              c->arenaCap, c->rects, c->rectCap, img0, t, (const int*)c->rankOf, lostRule ? c->rgLost : (int*)nullptr, c->tileTouch);
         } else {
           TRL(c, "k_tx_grow", k_tx_grow, dim3(ntile, nimg), dim3(64), txPad, c->dP, c->jrCtl, c->rec, c->own, c->txList,
               c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty, c->tileAct, c->tilesW, c->tilesH, c->arena,
-              c->arenaCap, c->rects, c->rectCap, img0, t, (const int*)c->rankOf, lostRule ? c->rgLost : (int*)nullptr);
+              c->arenaCap, c->rects, c->rectCap, img0, t, (const int*)c->rankOf, lostRule ? c->rgLost : (int*)nullptr, c->tileTouch);
         }
         TRL(c, "k_rx_rect", k_rx_rect, dim3(rectBlocks, nimg), dim3(64), 0, c->dP, c->jrCtl, c->rec, c->arena, c->arenaCap, c->rects,
             c->rectCap, c->rgSeg, img0, c->mg);
@@ -831,7 +835,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     for (int t = 1; t <= maxRounds && !allDone; ++t) {
       curT = t;
       TRL(c, "k_rx_diff", k_rx_diff, dim3((P.LW + 31) / 32, (c->tilesH + 7) / 8, nimg), dim3(256), 0, c->jrCtl, c->own, c->tileMin, c->tileAct,
-             P.LW, P.LH, c->tilesW, c->tilesH, t, img0);
+             P.LW, P.LH, c->tilesW, c->tilesH, t, img0, (const int*)nullptr);
       if (t >= 3 && !fullPasses) {
         // bookkeeping only where something happened (lsd_relax.hip)
         TRL(c, "k_rx_mark", k_rx_mark, dim3((P.LW + 31) / 32, (c->tilesH + 7) / 8, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->rgBox,
