@@ -36,7 +36,7 @@ inline int cvFloorf(float v) { int i = (int)v; return i - (i > v); }
 // per image: work-efficient, its throughput keeps growing with the batch); below it the tile-sequential relaxation
 // (lsd_tile.hip: parallel inside an image, ~3x the sequential work).  Measured, 752x480, stereo frames/s: 256 frames
 // 2072 (tile) vs 1168 (sequential), 512 frames 2141 vs 2005, 1024 frames 2177 vs 3630.
-constexpr int RX_AUTO_IMAGES = 1280;
+constexpr int RX_AUTO_IMAGES = 1536;     // images (2 per stereo frame): measured crossover of the tile relaxation and the sequential waves (768 frames)
 // tiles of 32 for a handful of images (more waves: a single stereo pair takes 4.6 instead of 7.3 ms), 64 otherwise
 constexpr int TX_SMALL_TILE_IMAGES = 16;
 
