@@ -103,6 +103,17 @@ struct RxRect {
   float sumdx, sumdy;
 };
 
+// tile-sequential relaxation, rounds >= 2: the seeds stamped dirty in a round, per tile of their seed pixel (appended by whoever
+// stamps the region first; the tile's wave sorts its few entries by rank instead of walking its whole seed list).
+// list == nullptr: no lists (the rank-ordered relaxation shares k_rx_mark).
+struct TxDirtyLists {
+  int2* list;          // [image][tile][ts * ts] (rank, seed pixel)
+  int* cnt;            // [image][tile]
+  const int* order;    // [image][npix] seed pixel of a rank
+  int ts, ntx, nty, W;
+  int64_t npix;
+};
+
 // a region in mid-growth, handed from the lane grower to the wave grower
 struct RxHand {
   int rank, k, cnt;

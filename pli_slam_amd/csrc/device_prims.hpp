@@ -11,6 +11,7 @@
 #pragma clang fp contract(off)
 #include <cfloat>
 #include <cstdint>
+#include "common.hpp"
 
 namespace pli {
 
@@ -114,6 +115,17 @@ __device__ __forceinline__ void sincos_of_float(float a, bool f32, float* sn, fl
     *sn = (float)s;
     *cs = (float)c;
   }
+}
+
+// (tile-sequential relaxation) the region of rank o was just stamped dirty for this round — the caller won the stamp, so this
+// runs once per region and round: its seed goes on the list of the seed's tile (at most ts * ts seeds per tile: no overflow)
+__device__ __forceinline__ void tx_dirty_append(const TxDirtyLists& DL, int img, int o) {
+  if (!DL.list) return;
+  const int sp = DL.order[(int64_t)img * DL.npix + o];
+  const int sy = sp / DL.W, sx = sp - sy * DL.W;
+  const int64_t tile = (int64_t)img * DL.ntx * DL.nty + (sy / DL.ts) * DL.ntx + sx / DL.ts;
+  const int slot = atomicAdd(&DL.cnt[tile], 1);
+  DL.list[tile * DL.ts * DL.ts + slot] = make_int2(o, sp);
 }
 
 }  // namespace pli

@@ -127,24 +127,29 @@ __global__ __launch_bounds__(256) void k_rx_diff(RxCtl* __restrict__ ctl, const 
                                                  int* __restrict__ tileMinAll, int* __restrict__ tileActAll, int W, int H,
                                                  int TW, int TH, int t, int img0, const int* __restrict__ tileTouchAll) {
   __shared__ int tmin[RX_DIFF_ROWS][4];
+  __shared__ int s_cell[RX_DIFF_ROWS][4];
   __shared__ int s_rel;
   const int img = blockIdx.z + img0;
   RxCtl& c = ctl[img];
   if (c.state == 2) return;
   const int tid = threadIdx.x;
   if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { c.nSmall = 0; c.nBig = 0; c.nHand = 0; c.nextBig = 0; c.rectArena = 0ull; }
+  if (tid < 4 * RX_DIFF_ROWS) s_cell[tid >> 2][tid & 3] = 1;
   if (tileTouchAll) {
     // tile-sequential relaxation, later rounds: the two owner components of a cell can only differ where round t-1 wrote one of
     // them — k_tx_prep rewrites the cells with tileAct == t-1, the growers note the cells of their claims in tileTouch —
-    // everywhere else the carried owner stands in both: the block leaves without reading the 16 KB of owner pairs under it
+    // everywhere else the carried owner stands in both: only those cells are read (a block without one leaves at once)
     if (tid == 0) s_rel = 0;
     __syncthreads();
     if (tid < 4 * RX_DIFF_ROWS) {
       const int tx = blockIdx.x * 4 + (tid & 3), ty = blockIdx.y * RX_DIFF_ROWS + (tid >> 2);
+      int rel = 0;
       if (tx < TW && ty < TH) {
         const int64_t cell = (int64_t)img * TW * TH + ty * TW + tx;
-        if (tileActAll[cell] == t - 1 || tileTouchAll[cell] == t - 1) s_rel = 1;
+        rel = tileActAll[cell] == t - 1 || tileTouchAll[cell] == t - 1;
       }
+      s_cell[tid >> 2][tid & 3] = rel;
+      if (rel) s_rel = 1;
     }
     __syncthreads();
     if (!s_rel) {
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(256) void k_rx_diff(RxCtl* __restrict__ ctl, const 
 #pragma unroll
   for (int rr = 0; rr < RX_DIFF_ROWS; ++rr) {
     const int y = (blockIdx.y * RX_DIFF_ROWS + rr) * 8 + (tid >> 5);
-    if (x < W && y < H) {
+    if (x < W && y < H && s_cell[rr][(tid & 31) >> 3]) {
       const int2 o = ownAll[(int64_t)img * W * H + y * W + x];
       if (o.x != o.y) { ch = true; atomicMin(&tmin[rr][(tid & 31) >> 3], min(o.x, o.y)); }
     }
@@ -275,9 +280,11 @@ __global__ __launch_bounds__(1024) void k_rx_seed(RxCtl* __restrict__ ctl, int2*
 // k_rx_seed_sparse then rewrites owner_t only in active tiles: everywhere else owner_{t-2} == owner_{t-1} and the
 // owner is carried, i.e. the word that is already there is the right start value.
 __device__ __forceinline__ void rx_mark_dirty(int o, bool withBox, int t, int* __restrict__ rgDirty,
-                                              const int2* __restrict__ rgBox, int* __restrict__ tileAct, int TW, int TH) {
+                                              const int2* __restrict__ rgBox, int* __restrict__ tileAct, int TW, int TH,
+                                              const TxDirtyLists& DL, int img) {
   if (rgDirty[o] == t) return;
   if (atomicExch(&rgDirty[o], t) == t) return;      // one marker per region activates the tiles
+  tx_dirty_append(DL, img, o);
   if (!withBox) return;
   const int2 b = rgBox[o];
   const int tx0 = min(max((b.x & 0xFFFF) >> 3, 0), TW - 1), ty0 = min(max((b.x >> 16) >> 3, 0), TH - 1);
@@ -290,7 +297,7 @@ __global__ __launch_bounds__(256) void k_rx_mark(RxCtl* __restrict__ ctl, const 
                                                  const int* __restrict__ rankAll, const int2* __restrict__ rgBoxAll,
                                                  int* __restrict__ rgDirtyAll, const int* __restrict__ tileMinAll,
                                                  int* __restrict__ tileActAll, int W, int H, int TW, int TH, int t, int img0,
-                                                 int seedRule, const int* __restrict__ rgLostAll) {
+                                                 int seedRule, const int* __restrict__ rgLostAll, TxDirtyLists DL) {
   // (RX_DIFF_ROWS rows of cells per workgroup, like k_rx_diff: the grid of one-row blocks is bound by the dispatch rate)
   __shared__ int nt[RX_DIFF_ROWS + 2][6];
   __shared__ int s_any[RX_DIFF_ROWS];
@@ -309,10 +316,15 @@ __global__ __launch_bounds__(256) void k_rx_mark(RxCtl* __restrict__ ctl, const 
     const int ty = (int)blockIdx.y * RX_DIFF_ROWS + tid / 6 - 1, tx = (int)blockIdx.x * 4 + tid % 6 - 1;
     const int v = (ty >= 0 && ty < TH && tx >= 0 && tx < TW) ? tm[ty * TW + tx] : INT_MAX;
     nt[tid / 6][tid % 6] = v;
-    if (v != INT_MAX) {                              // a change in row tid/6 concerns the cell rows tid/6 - 1 .. tid/6 + 1 (block-local: -2 .. 0)
-      for (int d = -2; d <= 0; ++d) {
-        const int rr = tid / 6 + d;
-        if (rr >= 0 && rr < RX_DIFF_ROWS) s_any[rr] = 1;
+    if (v != INT_MAX) {
+      if (rgLostAll) {                               // exact rule: evaluated from the changed pixels, i.e. inside the changed cells only
+        const int rr = tid / 6 - 1, cc = tid % 6;
+        if (rr >= 0 && rr < RX_DIFF_ROWS && cc >= 1 && cc <= 4) s_any[rr] = 1;
+      } else {                                       // a change in row tid/6 concerns the cell rows tid/6 - 1 .. tid/6 + 1 (block-local: -2 .. 0)
+        for (int d = -2; d <= 0; ++d) {
+          const int rr = tid / 6 + d;
+          if (rr >= 0 && rr < RX_DIFF_ROWS) s_any[rr] = 1;
+        }
       }
     }
   }
@@ -326,12 +338,14 @@ __global__ __launch_bounds__(256) void k_rx_mark(RxCtl* __restrict__ ctl, const 
     if (!s_any[rr]) continue;                        // nothing changed in or next to these four tiles
     const int x = blockIdx.x * 32 + (tid & 31), y = (blockIdx.y * RX_DIFF_ROWS + rr) * 8 + (tid >> 5);
     if (x >= W || y >= H) continue;
-    const int r = rankAll[base + y * W + x];
-    if (r == RX_INF) continue;
+    const int lx = tid & 31, ly = tid >> 5;
+    if (rgLostAll && nt[rr + 1][1 + (lx >> 3)] == INT_MAX) continue;      // (exact rule) no pixel of this cell changed
     const int2 o = ownAll[base + y * W + x];
     const int prevv = ci ? o.x : o.y, prev2 = ci ? o.y : o.x;
+    if (rgLostAll && prevv == prev2) continue;       // (exact rule) everything below starts from a changed pixel
+    const int r = rankAll[base + y * W + x];
+    if (r == RX_INF) continue;
     // lowest rank of a change in the tiles within one pixel of (x, y)
-    const int lx = tid & 31, ly = tid >> 5;
     const int cx0 = (lx + 7) >> 3, cx1 = (lx + 9) >> 3;        // nt column of x-1 and x+1 (nt column 1 = first own tile)
     const int cy0 = rr + ((ly + 7) >> 3), cy1 = rr + ((ly + 9) >> 3);
     const int m = min(min(nt[cy0][cx0], nt[cy0][cx1]), min(nt[cy1][cx0], nt[cy1][cx1]));
@@ -346,6 +360,7 @@ __global__ __launch_bounds__(256) void k_rx_mark(RxCtl* __restrict__ ctl, const 
       // (The 8x8-cell rule below — any change that involves a lower rank within a pixel — regrew ten times as many regions;
       // tools/sim/sim_tile_relax.cpp replays both: SIM_CARRY=1 SIM_LOST=1 SIM_EXACT=1 SIM_GPURULE=1.)
       if (prevv != prev2) {
+        int lastOp = INT_MAX;                          // (neighbours mostly share their owner: a rank is looked at once in a row)
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
           if (k == 4) continue;
@@ -353,16 +368,17 @@ __global__ __launch_bounds__(256) void k_rx_mark(RxCtl* __restrict__ ctl, const 
           if (px < 0 || py < 0 || px >= W || py >= H) continue;
           const int2 op2 = ownAll[base + py * W + px];
           const int op = ci ? op2.x : op2.y;           // owner_{t-1} of the neighbour
-          if (op == INT_MAX) continue;
+          if (op == INT_MAX || op == lastOp) continue;
+          lastOp = op;
           if ((prev2 < op && prevv > op) || (prev2 == op && prevv < op) || rgLostAll[base + op] == t - 1)
-            rx_mark_dirty(op, true, t, rgDirty, rgBox, tileAct, TW, TH);
+            rx_mark_dirty(op, true, t, rgDirty, rgBox, tileAct, TW, TH, DL, img);
         }
       }
-    } else if (m < prevv) rx_mark_dirty(prevv, true, t, rgDirty, rgBox, tileAct, TW, TH);
+    } else if (m < prevv) rx_mark_dirty(prevv, true, t, rgDirty, rgBox, tileAct, TW, TH, DL, img);
     const bool a1 = prevv == r, a2 = prev2 == r;
     // (seedRule 0: round 2 of the tile-sequential relaxation, where owner_{t-2} is the trivial map and the seeds that died in
     // round 1 never ran)
-    if (seedRule && a1 != a2) rx_mark_dirty(r, a2, t, rgDirty, rgBox, tileAct, TW, TH);   // died: its last box; newly alive: only this pixel
+    if (seedRule && a1 != a2) rx_mark_dirty(r, a2, t, rgDirty, rgBox, tileAct, TW, TH, DL, img);   // died: its last box; newly alive: only this pixel
   }
 }
 

@@ -189,9 +189,12 @@ __global__ __launch_bounds__(1024) void k_tx_sort128(const int* __restrict__ ran
 // (SIM_CARRY=1), which replays these rules on the CPU.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void tx_mark_dirty(int o, int t, int* __restrict__ rgDirty, const int2* __restrict__ rgBox,
-                                              int* __restrict__ tileAct, int TW, int TH) {
+                                              int* __restrict__ tileAct, int TW, int TH, const TxDirtyLists& DL, int img,
+                                              bool withBox = true) {
   if (rgDirty[o] == t) return;
   if (atomicExch(&rgDirty[o], t) == t) return;
+  tx_dirty_append(DL, img, o);
+  if (!withBox) return;
   const int2 b = rgBox[o];
   const int tx0 = min(max((b.x & 0xFFFF) >> 3, 0), TW - 1), ty0 = min(max((b.x >> 16) >> 3, 0), TH - 1);
   const int tx1 = min(max((b.y & 0xFFFF) >> 3, 0), TW - 1), ty1 = min(max((b.y >> 16) >> 3, 0), TH - 1);
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(256) void k_tx_diff2(RxCtl* __restrict__ ctl, const
                                                   const int* __restrict__ orderAll, const int2* __restrict__ rgBoxAll,
                                                   int* __restrict__ rgDirtyAll, int* __restrict__ tileMinAll,
                                                   int* __restrict__ tileActAll, int W, int H, int TW, int TH, int ts, int t,
-                                                  int img0, const int* __restrict__ rgLostAll) {
+                                                  int img0, const int* __restrict__ rgLostAll, TxDirtyLists DL) {
   __shared__ int tmin[4];
   const int img = blockIdx.z + img0;
   RxCtl& c = ctl[img];
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(256) void k_tx_diff2(RxCtl* __restrict__ ctl, const
         // the owner ran in round 1 and lost its seed afterwards (to a lower rank of another tile): it is dead in owner_1, its
         // remaining pixels must be released (the later rounds do this with k_rx_mark's "seed changed hands" rule)
         const int2 so = ownAll[base + sp];
-        if (((t & 1) ? so.x : so.y) != o) tx_mark_dirty(o, t, rgDirtyAll + base, rgBoxAll + base, tileActAll + (int64_t)img * TW * TH, TW, TH);
+        if (((t & 1) ? so.x : so.y) != o) tx_mark_dirty(o, t, rgDirtyAll + base, rgBoxAll + base, tileActAll + (int64_t)img * TW * TH, TW, TH, DL, img);
       } else if (rgLostAll) {
         // the seed of an alive region.  Exact rule (rgLostAll): its round-1 run stands unless it LOST a pixel it claimed — a lower
         // rank claimed the pixel too; the growers note the loser of every such claim.  (Why nothing else: take the lowest-ranked
@@ -234,12 +237,12 @@ __global__ __launch_bounds__(256) void k_tx_diff2(RxCtl* __restrict__ ctl, const
         // does not hold it in the end — which is then a change of the later rounds' kind.  tools/sim/sim_tile_relax.cpp replays
         // the rule: SIM_CARRY=1 SIM_LOST=1.)
         if (rgLostAll[base + o] != 0)
-          tx_mark_dirty(o, t, rgDirtyAll + base, rgBoxAll + base, tileActAll + (int64_t)img * TW * TH, TW, TH);
+          tx_mark_dirty(o, t, rgDirtyAll + base, rgBoxAll + base, tileActAll + (int64_t)img * TW * TH, TW, TH, DL, img);
       } else {                                          // conservative rule: does its box (+1) leave the tile?
         const int2 b = rgBoxAll[base + o];
         const int tx0 = (x / ts) * ts, ty0 = (y / ts) * ts;
         if ((b.x & 0xFFFF) - 1 < tx0 || (b.x >> 16) - 1 < ty0 || (b.y & 0xFFFF) + 1 >= tx0 + ts || (b.y >> 16) + 1 >= ty0 + ts)
-          tx_mark_dirty(o, t, rgDirtyAll + base, rgBoxAll + base, tileActAll + (int64_t)img * TW * TH, TW, TH);
+          tx_mark_dirty(o, t, rgDirtyAll + base, rgBoxAll + base, tileActAll + (int64_t)img * TW * TH, TW, TH, DL, img);
       }
     }
   }
@@ -249,6 +252,79 @@ __global__ __launch_bounds__(256) void k_tx_diff2(RxCtl* __restrict__ ctl, const
     if (tx < TW) {
       tileMinAll[(int64_t)img * TW * TH + blockIdx.y * TW + tx] = tmin[tid];
       if (tmin[tid] != INT_MAX) tileActAll[(int64_t)img * TW * TH + blockIdx.y * TW + tx] = t;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_tx_mark (rounds >= 3, exact rule; takes the place of k_rx_mark, whose comment states the rule).  Everything the rule does
+// starts from a pixel whose owner changed between owner_{t-2} and owner_{t-1}, and those are few: a block (4 x 8 cells) first
+// lists the changed pixels of its changed cells in LDS, then spreads (changed pixel, neighbour) pairs over its threads, so the
+// dependent chain neighbour owner -> rgLost -> stamp runs once per block, not once per row of cells.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tx_mark(RxCtl* __restrict__ ctl, const int2* __restrict__ ownAll,
+                                                 const int* __restrict__ rankAll, const int2* __restrict__ rgBoxAll,
+                                                 int* __restrict__ rgDirtyAll, const int* __restrict__ tileMinAll,
+                                                 int* __restrict__ tileActAll, int W, int H, int TW, int TH, int t, int img0,
+                                                 const int* __restrict__ rgLostAll, TxDirtyLists DL) {
+  __shared__ int s_chg[8][4];
+  __shared__ int s_n;
+  __shared__ unsigned short lst[2048];
+  const int img = blockIdx.z + img0;
+  RxCtl& c = ctl[img];
+  if (c.state == 2) return;
+  if (c.changed == 0) {                              // owner_{t-1} == owner_{t-2}: exact (every block sees the same flag)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { c.state = 2; c.rounds = t; }
+    return;
+  }
+  const int tid = threadIdx.x;
+  if (tid == 0) s_n = 0;
+  if (tid < 32) {
+    const int ty = (int)blockIdx.y * 8 + (tid >> 2), tx = (int)blockIdx.x * 4 + (tid & 3);
+    s_chg[tid >> 2][tid & 3] = (ty < TH && tx < TW) ? tileMinAll[(int64_t)img * TW * TH + ty * TW + tx] != INT_MAX : 0;
+  }
+  __syncthreads();
+  const int64_t base = (int64_t)img * W * H;
+  const int lx = tid & 31, ly = tid >> 5;
+  const int x = blockIdx.x * 32 + lx;
+  int2 o[8];
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr) {
+    const int y = (blockIdx.y * 8 + rr) * 8 + ly;
+    o[rr] = make_int2(0, 0);
+    if (s_chg[rr][lx >> 3] && x < W && y < H) o[rr] = ownAll[base + y * W + x];
+  }
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr)
+    if (o[rr].x != o[rr].y) lst[atomicAdd(&s_n, 1)] = (unsigned short)(((rr * 8 + ly) << 5) | lx);
+  __syncthreads();
+  const int n = s_n;
+  if (n == 0) return;
+  int* rgDirty = rgDirtyAll + base;
+  const int2* rgBox = rgBoxAll + base;
+  int* tileAct = tileActAll + (int64_t)img * TW * TH;
+  const int ci = t & 1;
+  for (int i = tid; i < n * 9; i += 256) {
+    const int e = (int)(((unsigned)i * 7282u) >> 16);   // i / 9 for i < 2048 * 9
+    const int k = i - 9 * e;
+    const int li = lst[e];
+    const int px0 = blockIdx.x * 32 + (li & 31), py0 = blockIdx.y * 64 + (li >> 5);
+    const int2 oc = ownAll[base + py0 * W + px0];
+    const int prevv = ci ? oc.x : oc.y, prev2 = ci ? oc.y : oc.x;
+    if (k == 4) {
+      // the seed of a region changed hands: it died (its last box is released) or is newly alive (only this pixel)
+      const int r = rankAll[base + py0 * W + px0];
+      if (r == TX_INF) continue;
+      const bool a1 = prevv == r, a2 = prev2 == r;
+      if (a1 != a2) tx_mark_dirty(r, t, rgDirty, rgBox, tileAct, TW, TH, DL, img, a2);
+    } else {
+      const int px = px0 + k % 3 - 1, py = py0 + k / 3 - 1;
+      if (px < 0 || py < 0 || px >= W || py >= H) continue;
+      const int2 op2 = ownAll[base + py * W + px];
+      const int op = ci ? op2.x : op2.y;               // owner_{t-1} of the neighbour
+      if (op == INT_MAX) continue;
+      if ((prev2 < op && prevv > op) || (prev2 == op && prevv < op) || rgLostAll[base + op] == t - 1)
+        tx_mark_dirty(op, t, rgDirty, rgBox, tileAct, TW, TH, DL, img);
     }
   }
 }
@@ -265,6 +341,7 @@ __global__ __launch_bounds__(256) void k_tx_prep(RxCtl* __restrict__ ctl, int2* 
                                                  const int* __restrict__ tileActAll, int W, int H, int TW, int TH, int t, int img0,
                                                  int full) {
   __shared__ int s_act;
+  __shared__ int s_cell[4][4];
   const int img = blockIdx.z + img0;
   RxCtl& c = ctl[img];
   if (c.state == 2) return;
@@ -274,26 +351,40 @@ __global__ __launch_bounds__(256) void k_tx_prep(RxCtl* __restrict__ ctl, int2* 
   __syncthreads();
   if (tid < 16) {
     const int tx = blockIdx.x * 4 + (tid & 3), ty = blockIdx.y * 4 + (tid >> 2);
-    if (tx < TW && ty < TH && tileActAll[(int64_t)img * TW * TH + ty * TW + tx] == t) s_act = 1;
+    const int a = full || (tx < TW && ty < TH && tileActAll[(int64_t)img * TW * TH + ty * TW + tx] == t);
+    s_cell[tid >> 2][tid & 3] = a;
+    if (a) s_act = 1;
   }
   __syncthreads();
   if (!s_act) return;
   const int64_t base = (int64_t)img * W * H;
   const int ci = t & 1;
   const int x = blockIdx.x * 32 + (tid & 31);
+  // (the loads of the four rows first, then the dependent stamps, then the stores: a store between them would order them)
+  int r[4], dirtyAt[4];
+  int2 o[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int y = blockIdx.y * 32 + i * 8 + (tid >> 5);
-    if (x >= W || y >= H) continue;
-    const int p = y * W + x;
-    const int r = rankAll[base + p];
-    if (r == TX_INF) continue;
-    int2 o = ownAll[base + p];
-    const int prevv = ci ? o.x : o.y;
-    const int cur = rgDirtyAll[base + prevv] != t ? prevv : r;
-    if (cur != (ci ? o.y : o.x)) {
-      if (ci) o.y = cur; else o.x = cur;
-      ownAll[base + p] = o;
+    r[i] = TX_INF;
+    o[i] = make_int2(0, 0);
+    // (a cell that is not active keeps its words: they are right)
+    if (x < W && y < H && s_cell[i][(tid & 31) >> 3]) {
+      r[i] = rankAll[base + y * W + x];
+      o[i] = ownAll[base + y * W + x];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dirtyAt[i] = r[i] != TX_INF ? rgDirtyAll[base + (ci ? o[i].x : o[i].y)] : 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (r[i] == TX_INF) continue;
+    const int y = blockIdx.y * 32 + i * 8 + (tid >> 5);
+    const int prevv = ci ? o[i].x : o[i].y;
+    const int cur = dirtyAt[i] != t ? prevv : r[i];
+    if (cur != (ci ? o[i].y : o[i].x)) {
+      if (ci) o[i].y = cur; else o[i].x = cur;
+      ownAll[base + y * W + x] = o[i];
     }
   }
 }
@@ -382,7 +473,8 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
                                              const int* __restrict__ tileActAll, int TW, int TH,
                                              int* __restrict__ arenaAll, int arenaCap, RxRect* __restrict__ rectAll,
                                              int rectCap, int img0, int t, const int* __restrict__ rankAll,
-                                             int* __restrict__ rgLostAll, int* __restrict__ tileTouchAll) {
+                                             int* __restrict__ rgLostAll, int* __restrict__ tileTouchAll,
+                                             const TxDirtyLists& DL) {
   __shared__ int q[TX_GQ];
   __shared__ int gb[TX_BMAXBLK];
   const DevParams& P = *Pp;
@@ -390,12 +482,37 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
   RxCtl& c = ctl[img];
   if (c.state == 2 || c.overflow) return;
   const int ntile = ntx * nty;
-  const int n = tileCntAll[(int64_t)img * ntile + tile];
+  int n = tileCntAll[(int64_t)img * ntile + tile];
   if (n == 0) return;
   const int lane = threadIdx.x;
   const int W = P.LW, H = P.LH;
   const int64_t npix = (int64_t)W * H;
-  if (SPARSE) {
+  // (later rounds) the seeds stamped dirty for this round were listed per tile by whoever stamped them: up to 64 of them are
+  // sorted by rank in registers and taken as the tile's only row; a longer list falls back to the walk over all the seeds
+  int2 dse = make_int2(TX_INF, -1);
+  bool useDirty = false;
+  if (SPARSE && DL.list) {
+    const int nd = DL.cnt[(int64_t)img * ntile + tile];
+    if (nd == 0) return;
+    if (nd <= 64) {
+      useDirty = true;
+      if (lane < nd) dse = DL.list[((int64_t)img * ntile + tile) * ts * ts + lane];
+      // bitonic sort of the 64 (rank, seed pixel) pairs, ascending by rank (ranks are distinct; the padding is TX_INF)
+#pragma unroll
+      for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+          const int ox = __shfl_xor(dse.x, j2, 64), oy = __shfl_xor(dse.y, j2, 64);
+          const bool up = (lane & k2) == 0, lowHalf = (lane & j2) == 0;
+          const bool takeMin = lowHalf == up;
+          const bool swap = takeMin ? ox < dse.x : ox > dse.x;
+          if (swap) { dse.x = ox; dse.y = oy; }
+        }
+      }
+      n = nd;
+    }
+  }
+  if (SPARSE && !useDirty) {
     // a dirty region activates the cells under its bounding box, its seed's cell among them: no active cell, nothing to do
     const int cpt = ts >> 3;                              // 8x8 cells per tile side (ts = 32, 64 or 128: up to 256 cells)
     bool act = false;
@@ -438,9 +555,10 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
   for (int base = 0; base < n; base += 64) {
     const bool valid = base + lane < n;
     int2 se = make_int2(TX_INF, -1);
-    if (valid) se = list[base + lane];
+    if (useDirty) se = dse;                               // (n <= 64: one row)
+    else if (valid) se = list[base + lane];
     bool d = valid;
-    if (SPARSE) d = valid && rgDirty[se.x] == t;
+    if (SPARSE && !useDirty) d = valid && rgDirty[se.x] == t;
     float4 srec = make_float4(TX_NOTDEF, 0.f, 0.f, 0.f);
     int2 so = make_int2(0, 0);
     if (d) {
@@ -650,9 +768,9 @@ __global__ __launch_bounds__(64) void k_tx_grow(const DevParams* __restrict__ Pp
                                                 const int* __restrict__ tileActAll, int TW, int TH,
                                                 int* __restrict__ arenaAll, int arenaCap, RxRect* __restrict__ rectAll,
                                                 int rectCap, int img0, int t, const int* __restrict__ rankAll,
-                                                int* __restrict__ rgLostAll, int* __restrict__ tileTouchAll) {
+                                                int* __restrict__ rgLostAll, int* __restrict__ tileTouchAll, TxDirtyLists DL) {
   tx_grow_tile<false>(Pp, ctl, recAll, ownAll, listAll, tileCntAll, ts, ntx, nty, rgSizeAll, rgBoxAll, rgDirtyAll, tileActAll,
-                      TW, TH, arenaAll, arenaCap, rectAll, rectCap, img0, t, rankAll, rgLostAll, tileTouchAll);
+                      TW, TH, arenaAll, arenaCap, rectAll, rectCap, img0, t, rankAll, rgLostAll, tileTouchAll, DL);
 }
 __global__ __launch_bounds__(64) void k_tx_grow_sparse(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
                                                        const float4* __restrict__ recAll, int2* __restrict__ ownAll,
@@ -662,9 +780,9 @@ __global__ __launch_bounds__(64) void k_tx_grow_sparse(const DevParams* __restri
                                                        const int* __restrict__ tileActAll, int TW, int TH,
                                                        int* __restrict__ arenaAll, int arenaCap, RxRect* __restrict__ rectAll,
                                                        int rectCap, int img0, int t, const int* __restrict__ rankAll,
-                                                       int* __restrict__ rgLostAll, int* __restrict__ tileTouchAll) {
+                                                       int* __restrict__ rgLostAll, int* __restrict__ tileTouchAll, TxDirtyLists DL) {
   tx_grow_tile<true>(Pp, ctl, recAll, ownAll, listAll, tileCntAll, ts, ntx, nty, rgSizeAll, rgBoxAll, rgDirtyAll, tileActAll,
-                     TW, TH, arenaAll, arenaCap, rectAll, rectCap, img0, t, rankAll, rgLostAll, tileTouchAll);
+                     TW, TH, arenaAll, arenaCap, rectAll, rectCap, img0, t, rankAll, rgLostAll, tileTouchAll, DL);
 }
 
 }  // namespace pli

@@ -85,6 +85,7 @@ struct pli_ctx {
   int* lastSize = nullptr; int* arena = nullptr; int arenaCap = 0;
   RxCtl* jrCtl = nullptr;
   int2* txList = nullptr; int* txTileCnt = nullptr; int txTs = 64, txNtx = 0, txNty = 0;   // tile-sequential relaxation (lsd_tile.hip)
+  int2* txDirtyList = nullptr; int* txDirtyCnt = nullptr;                                  // per tile: the seeds stamped dirty in a round
   std::vector<RxCtl> jrHost;
   int lsdMode = 0;     // 0 auto, 1 relaxation, 2 sequential, 3 tile-sequential relaxation (cfg.lsd_mode, or PLI_LSD_MODE)
   bool lsdSpec = !(getenv("PLI_LSD_SPEC") != nullptr && atoi(getenv("PLI_LSD_SPEC")) == 0);  // speculative sequential grower (PLI_LSD_SPEC=0: the plain one)
@@ -548,6 +549,8 @@ pli_status allocAll(pli_ctx* c) {
       c->txNtx = (P.LW + c->txTs - 1) / c->txTs; c->txNty = (P.LH + c->txTs - 1) / c->txTs;
       A(c->txList, (size_t)c->txNtx * c->txNty * c->txTs * c->txTs * NR);
       A(c->txTileCnt, (size_t)c->txNtx * c->txNty * NR);
+      A(c->txDirtyList, (size_t)c->txNtx * c->txNty * c->txTs * c->txTs * NR);
+      A(c->txDirtyCnt, (size_t)c->txNtx * c->txNty * NR);
     }
   }
   A(c->jrCtl, NI);
@@ -795,28 +798,39 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
             c->txTileCnt, P.LW, P.LH, ts, c->txNtx, c->txNty, img0);
       const bool fullRound2 = getenv("PLI_TX_FULL2") != nullptr;       // dev: regrow everything in round 2
       const size_t txPad = getenv("PLI_TX_LDSPAD") ? (size_t)atoi(getenv("PLI_TX_LDSPAD")) : 0;   // dev: occupancy cap of the tile growers
+      TxDirtyLists DL{c->txDirtyList, c->txDirtyCnt, c->order, ts, c->txNtx, c->txNty, P.LW, npix64};
+      if (getenv("PLI_TX_NODIRTYLIST")) DL.list = nullptr;             // dev: every active tile walks its whole seed list
+      TxDirtyLists noDL = DL; noDL.list = nullptr;
       for (int t = 1; t <= maxRounds && !allDone; ++t) {
         curT = t;
+        if (t >= 2 && DL.list)
+          HIPCHK(hipMemsetAsync(c->txDirtyCnt + (int64_t)img0 * ntile, 0, sizeof(int) * (size_t)ntile * nimg, c->stream));
         if (t == 2 && !fullRound2)
           TRL(c, "k_tx_diff2", k_tx_diff2, dim3((P.LW + 31) / 32, c->tilesH, nimg), dim3(256), 0, c->jrCtl, c->own, c->order, c->rgBox,
-              c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, ts, t, img0, lostRule ? (const int*)c->rgLost : (const int*)nullptr);
+              c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, ts, t, img0, lostRule ? (const int*)c->rgLost : (const int*)nullptr, DL);
         else
           TRL(c, "k_rx_diff", k_rx_diff, dim3((P.LW + 31) / 32, (c->tilesH + 7) / 8, nimg), dim3(256), 0, c->jrCtl, c->own, c->tileMin, c->tileAct,
               P.LW, P.LH, c->tilesW, c->tilesH, t, img0,
               (t >= 3 && !fullRound2 && !getenv("PLI_TX_FULLDIFF")) ? (const int*)c->tileTouch : (const int*)nullptr);
         if (t >= 3 || (t == 2 && !fullRound2)) {
+          // (round 2 under the lost-pixel rule: k_tx_diff2 has stamped the regions itself, k_rx_mark would find nothing)
+          if (lostRule && t >= 3 && !getenv("PLI_TX_CELLRULE") && !getenv("PLI_TX_OLDMARK"))
+          TRL(c, "k_rx_mark", k_tx_mark, dim3((P.LW + 31) / 32, (c->tilesH + 7) / 8, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->rgBox,
+              c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, (const int*)c->rgLost, DL);
+          else if (t >= 3 || !lostRule)
           TRL(c, "k_rx_mark", k_rx_mark, dim3((P.LW + 31) / 32, (c->tilesH + 7) / 8, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->rgBox,
               c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, t >= 3 ? 1 : 0,
-              (lostRule && t >= 3 && !getenv("PLI_TX_CELLRULE")) ? (const int*)c->rgLost : (const int*)nullptr);
+              (lostRule && t >= 3 && !getenv("PLI_TX_CELLRULE")) ? (const int*)c->rgLost : (const int*)nullptr, DL);
           TRL(c, "k_tx_prep", k_tx_prep, dim3((P.LW + 31) / 32, (P.LH + 31) / 32, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf,
               c->rgDirty, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, t == 2 ? 1 : 0);
           TRL(c, "k_tx_grow_sparse", k_tx_grow_sparse, dim3(ntile, nimg), dim3(64), txPad, c->dP, c->jrCtl, c->rec, c->own, c->txList,
               c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty, c->tileAct, c->tilesW, c->tilesH, c->arena,
-              c->arenaCap, c->rects, c->rectCap, img0, t, (const int*)c->rankOf, lostRule ? c->rgLost : (int*)nullptr, c->tileTouch);
+              c->arenaCap, c->rects, c->rectCap, img0, t, (const int*)c->rankOf, lostRule ? c->rgLost : (int*)nullptr, c->tileTouch,
+              fullRound2 && t == 2 ? noDL : DL);
         } else {
           TRL(c, "k_tx_grow", k_tx_grow, dim3(ntile, nimg), dim3(64), txPad, c->dP, c->jrCtl, c->rec, c->own, c->txList,
               c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty, c->tileAct, c->tilesW, c->tilesH, c->arena,
-              c->arenaCap, c->rects, c->rectCap, img0, t, (const int*)c->rankOf, lostRule ? c->rgLost : (int*)nullptr, c->tileTouch);
+              c->arenaCap, c->rects, c->rectCap, img0, t, (const int*)c->rankOf, lostRule ? c->rgLost : (int*)nullptr, c->tileTouch, noDL);
         }
         TRL(c, "k_rx_rect", k_rx_rect, dim3(rectBlocks, nimg), dim3(64), 0, c->dP, c->jrCtl, c->rec, c->arena, c->arenaCap, c->rects,
             c->rectCap, c->rgSeg, img0, c->mg);
@@ -839,7 +853,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       if (t >= 3 && !fullPasses) {
         // bookkeeping only where something happened (lsd_relax.hip)
         TRL(c, "k_rx_mark", k_rx_mark, dim3((P.LW + 31) / 32, (c->tilesH + 7) / 8, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->rgBox,
-            c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, 1, (const int*)nullptr);
+            c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, 1, (const int*)nullptr, TxDirtyLists{});
         TRL(c, "k_rx_seed_sparse", k_rx_seed_sparse, dim3((P.LW + 31) / 32, (P.LH + 31) / 32, nimg), dim3(1024), 0, c->jrCtl, c->own, c->rankOf,
             c->rec, c->lastSize, c->rgDirty, c->tileAct, c->smallSeeds, c->bigSeeds, c->bigCap, P.LW, P.LH, c->tilesW, c->tilesH,
             bigThresh, t, img0);

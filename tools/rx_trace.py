@@ -13,7 +13,7 @@ W = int(sys.argv[1]) if len(sys.argv) > 1 else 752
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 480
 SEED = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 L, R = synth.make_stereo_pair(SEED, W, H)
-cfg = capi.default_config(W, H, lsd_nfeatures=0, max_frames=1, lsd_mode=1)
+cfg = capi.default_config(W, H, lsd_nfeatures=0, max_frames=1, lsd_mode=int(os.environ.get("RX_MODE", "1")))
 fe = Frontend(cfg)
 fr = po.Frame(po.Config.from_buffer_copy(bytes(cfg)))
 t0 = time.time()
