@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64) void k_lsd_scatter(const int* __restrict__ g2a,
                                                     const int* __restrict__ maxG2, const int* __restrict__ chunkBase,
                                                     int nChunks, int* __restrict__ order, int img0, int nimg,
                                                     const double* __restrict__ mgAll, const unsigned long long* __restrict__ maxMg,
-                                                    double rho) {
+                                                    double rho, int* __restrict__ rankAll) {
   __shared__ int base[1024];
   // XCD-aware order: workgroup L runs on XCD L % 8, so all chunks of an image are dealt to ONE XCD (consecutive slots of
   // that XCD, i.e. close in time): the 4-byte stores of different chunks into the same lines of the ordered list then
@@ -190,6 +190,9 @@ __global__ __launch_bounds__(64) void k_lsd_scatter(const int* __restrict__ g2a,
   const int* g = g2a + (int64_t)img * npix;
   const double* gd = mgAll + (int64_t)img * npix;
   int* ord = order + (int64_t)img * npix;
+  // (relaxations) the rank of every pixel — its slot in the ordered list, 0x7F7F7F7F for an undefined pixel — is written here,
+  // in raster order, instead of being scattered from the list afterwards
+  int* rk = rankAll ? rankAll + (int64_t)img * npix : nullptr;
   const int nbits = 32 - __clz(max(nBins - 1, 1));
   constexpr int GRP = 16;                        // rows of 64 pixels whose loads are in flight together
   for (int it0 = 0; it0 < LSD_CHUNK / 64; it0 += GRP) {
@@ -212,7 +215,10 @@ __global__ __launch_bounds__(64) void k_lsd_scatter(const int* __restrict__ g2a,
       const bool def = bin >= 0;
       // lanes with the same bin (match-any by bits: one ballot per bin bit instead of one round per distinct bin)
       unsigned long long peers = __builtin_amdgcn_ballot_w64(def);
-      if (!peers) continue;
+      if (!peers) {
+        if (rk && i < npix) rk[i] = 0x7F7F7F7F;
+        continue;
+      }
       for (int b = 0; b < nbits; ++b) {
         const bool bit = (bin >> b) & 1;
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(def && bit);
@@ -225,7 +231,9 @@ __global__ __launch_bounds__(64) void k_lsd_scatter(const int* __restrict__ g2a,
         cnt = __popcll(peers);
         last = (peers >> lane) == 1ull;
       }
-      if (def) ord[base[bin] + rank] = i;
+      const int slot = def ? base[bin] + rank : 0x7F7F7F7F;
+      if (def) ord[slot] = i;
+      if (rk && i < npix) rk[i] = slot;
       // single-wave block: the LDS operations of a wave execute in order (a block barrier would also wait for the stores)
       lsd_wave_sync();
       if (def && last) base[bin] += cnt;

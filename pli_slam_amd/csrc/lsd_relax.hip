@@ -84,12 +84,7 @@ __device__ __forceinline__ int rx_block_append(bool flag, int* counter, int* lds
 }
 
 // ---- setup -------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rx_rank(const int* __restrict__ orderAll, const int* __restrict__ nDefined,
-                                                 int* __restrict__ rankAll, int64_t npix, int img0) {
-  const int img = blockIdx.y + img0;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < nDefined[img]) rankAll[img * npix + orderAll[img * npix + i]] = i;
-}
+// (the rank plane — rank of every pixel, 0x7F7F7F7F where undefined — is written by k_lsd_scatter, line_kernels.hip)
 
 // owner_0: the lowest-ranked 3x3 neighbour whose own angle accepts the pixel (a heuristic: any owner_0 is valid)
 __global__ __launch_bounds__(256) void k_rx_guess(const float4* __restrict__ recAll, const int* __restrict__ rankAll,

@@ -712,7 +712,8 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   // different chunks merge into whole lines before they are evicted (2048 frames: 21.8 -> 15.3 ms; 32 KB starves the CUs)
   constexpr size_t scatterOccupancyPad = 16384;
   LAUNCH(c, "k_lsd_scatter", k_lsd_scatter, dim3((unsigned)(8 * ((nimg + 7) / 8) * c->nChunks)), dim3(64), scatterOccupancyPad, c->g2, npix, P.g2Thresh,
-         P.nBins, c->maxG2, c->chunkBase, c->nChunks, c->order, img0, nimg, c->mg, c->maxMg, P.rho);
+         P.nBins, c->maxG2, c->chunkBase, c->nChunks, c->order, img0, nimg, c->mg, c->maxMg, P.rho,
+         sequential ? (int*)nullptr : c->rankOf);
   if (sequential) {
     // speculative form (line_kernels.hip: lsd_grow_image_spec): the small regions of 64 seeds at a time, one per lane
     const bool spec = c->lsdSpec && P.minRegSize >= 2;
@@ -759,14 +760,13 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     if (const char* e = getenv("PLI_RX_MAXROUNDS")) maxRounds = std::max(1, atoi(e));
     const float precDeg = (float)(P.prec * 180.0 / 3.14159265358979323846);
     HIPCHK(hipMemsetAsync(c->jrCtl + img0, 0, sizeof(RxCtl) * nimg, c->stream));
-    HIPCHK(hipMemsetAsync(c->rankOf + (int64_t)img0 * npix, 0x7F, sizeof(int) * npix64 * nimg, c->stream));
     if (c->rgClean) HIPCHK(hipMemsetAsync(c->rgClean + (int64_t)img0 * npix, 0, npix64 * nimg, c->stream));   // round stamps
     HIPCHK(hipMemsetAsync(c->rgDirty + (int64_t)img0 * npix, 0, sizeof(int) * npix64 * nimg, c->stream));
     const bool lostRule = c->lsdMode != 1 && getenv("PLI_TX_BOXRULE") == nullptr;     // dev switch: the conservative round-2 rule
     if (lostRule) HIPCHK(hipMemsetAsync(c->rgLost + (int64_t)img0 * npix, 0, sizeof(int) * npix64 * nimg, c->stream));
     HIPCHK(hipMemsetAsync(c->tileTouch + (int64_t)img0 * c->tilesW * c->tilesH, 0, sizeof(int) * (size_t)c->tilesW * c->tilesH * nimg, c->stream));
     HIPCHK(hipMemsetAsync(c->tileAct + (int64_t)img0 * c->tilesW * c->tilesH, 0, sizeof(int) * (size_t)c->tilesW * c->tilesH * nimg, c->stream));
-    TRL(c, "k_rx_rank", k_rx_rank, dim3((npix + 255) / 256, nimg), dim3(256), 0, c->order, c->nDefined, c->rankOf, npix64, img0);
+    // (the rank plane was written by k_lsd_scatter)
     const dim3 raster((P.LW + 255) / 256, P.LH, nimg);
     const bool tile = c->lsdMode != 1;      // auto below RX_AUTO_IMAGES and mode 3: the tile-sequential relaxation
     bool allDone = false;
@@ -808,7 +808,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
         if (t == 2 && !fullRound2)
           TRL(c, "k_tx_diff2", k_tx_diff2, dim3((P.LW + 31) / 32, c->tilesH, nimg), dim3(256), 0, c->jrCtl, c->own, c->order, c->rgBox,
               c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, ts, t, img0, lostRule ? (const int*)c->rgLost : (const int*)nullptr, DL);
-        else
+        else if (t >= 2)                     // (round 1 starts from the trivial map: nothing to compare, the control block is zeroed)
           TRL(c, "k_rx_diff", k_rx_diff, dim3((P.LW + 31) / 32, (c->tilesH + 7) / 8, nimg), dim3(256), 0, c->jrCtl, c->own, c->tileMin, c->tileAct,
               P.LW, P.LH, c->tilesW, c->tilesH, t, img0,
               (t >= 3 && !fullRound2 && !getenv("PLI_TX_FULLDIFF")) ? (const int*)c->tileTouch : (const int*)nullptr);
