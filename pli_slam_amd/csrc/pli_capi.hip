@@ -34,9 +34,10 @@ inline int cvFloorf(float v) { int i = (int)v; return i - (i > v); }
 
 // lsd_mode auto: batches of at least this many images (2 per stereo frame) take the sequential wave grower (one wave
 // per image: work-efficient, its throughput keeps growing with the batch); below it the tile-sequential relaxation
-// (lsd_tile.hip: parallel inside an image, ~3x the sequential work).  Measured, 752x480, stereo frames/s: 256 frames
-// 2072 (tile) vs 1168 (sequential), 512 frames 2141 vs 2005, 1024 frames 2177 vs 3630.
-constexpr int RX_AUTO_IMAGES = 1536;     // images (2 per stereo frame): measured crossover of the tile relaxation and the sequential waves (768 frames)
+// (lsd_tile.hip: parallel inside an image, ~1.5x the sequential work per frame at large batches).  Measured, 752x480,
+// stereo frames/s: 256 frames 3908 (tile), 768 frames ~4200 (tile) vs 3474 (sequential), 1024 frames 4211 vs 4177,
+// 2048 frames 6057 (sequential).
+constexpr int RX_AUTO_IMAGES = 2048;     // images (2 per stereo frame): measured crossover of the tile relaxation and the sequential waves (1024 frames)
 // tiles of 32 for a handful of images (more waves: a single stereo pair takes 4.6 instead of 7.3 ms), 64 otherwise
 constexpr int TX_SMALL_TILE_IMAGES = 16;
 
