@@ -574,6 +574,9 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
       scos = (float)cn;
       ssin = (float)sn;
     }
+    // (the packed (y, x) of the row's seeds, 64 at a time: a scalar division per region costs more than this one per row)
+    const unsigned spyv = (unsigned)max(se.y, 0) / (unsigned)W;
+    const int sxyv = (int)((spyv << 16) | ((unsigned)max(se.y, 0) - spyv * (unsigned)W));
     unsigned long long unusedMask = __builtin_amdgcn_ballot_w64(alive);
     while (unusedMask) {
       const int j = __ffsll((long long)unusedMask) - 1;
@@ -583,11 +586,23 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
       float sumdx = tx_rlf(scos, j), sumdy = tx_rlf(ssin, j);
       double reg_angle = (double)sa * TX_DEG2RAD;
       int angCnt = 1;                                     // reg_angle is the angle of the sums at this pixel count (the seed angle at 1)
-      const int spy = sp / W, spx = sp - spy * W;
-      q[0] = (spy << 16) | spx;                           // every lane stores the same value
+      const int sxy = tx_rl(sxyv, j);
+      q[0] = sxy;                                         // every lane stores the same value
       int cnt = 1, k = 0;
-      int bmin = (spy << 16) | spx, bmax = bmin;          // bounding box: packed 16-bit (y, x) minima / maxima
-      int pendOld = 0x7FFFFFFF, pendRank = 0;
+      int bmin = sxy, bmax = bmin;                        // bounding box: packed 16-bit (y, x) minima / maxima
+      // pendOld = what stood in the owner word when this lane's claim of the last step arrived (r: it claimed nothing): a lower
+      // rank -> this region does not hold the pixel it took; a higher rank that is not the pixel's own (initial) rank -> that
+      // region just lost the pixel.  Contested claims are rare: one ballot decides for the wave.
+      int pendOld = r, pendRank = 0;
+      auto stampLosers = [&]() {
+        if (noteLost) {
+          const bool contested = pendOld < r || (pendOld != r && pendOld != pendRank);
+          if (__builtin_amdgcn_ballot_w64(contested) != 0ull) {
+            if (contested) rgLost[pendOld < r ? r : pendOld] = t;
+          }
+        }
+        pendOld = r;
+      };
       bool dead = false;
       // One step = up to 8 queue entries x 8 neighbours in one round trip (record + owner pair per lane), the accept loop, the
       // claims.  Two loops, the usual one first (the queue entries of the step fit the LDS queue) and the overflow form after
@@ -599,30 +614,25 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
         // The claims of the previous step are returning atomics: their results are consumed here, before the owner
         // loads of this step are issued, so those loads see the region's own claims.
         asm volatile("" ::"v"(pendOld) : "memory");
-        if (noteLost && pendOld != 0x7FFFFFFF) {          // (0x7FFFFFFF: this lane claimed nothing in the last step)
-          // pendOld = what stood in the owner word when this region's claim arrived: a lower rank -> this region does not hold the
-          // pixel it took; a higher rank that is not the pixel's own (initial) rank -> that region just lost the pixel
-          if (pendOld < r) rgLost[r] = t;
-          else if (pendOld != r && pendOld != pendRank) rgLost[pendOld] = t;
-        }
-        pendOld = 0x7FFFFFFF;
+        stampLosers();
         bool accepted = false;
-        int qi = -1, myxy = -1;
-        float4 rr = make_float4(TX_NOTDEF, 0.f, 0.f, 0.f);
-        int2 oo = make_int2(0, 0);
         const int nb = min(8, cnt - k);
-        if (pi < nb) {
-          const int e = SPILL ? qget(k + pi) : tx_lds_read(&q[k + pi]);
-          const int nx = (e & 0xFFFF) + ndx, ny = (e >> 16) + ndy;
-          if (nx >= 0 && ny >= 0 && nx < W && ny < H) {
-            qi = ny * W + nx;
-            myxy = (ny << 16) | nx;
-            rr = rec[qi];
-            oo = tx_load_own(&own[qi]);
-          }
+        // (one predicate for the whole fetch: the lanes outside it keep whatever their registers hold, and stay out of `cand`)
+        const int e = SPILL ? qget(min(k + pi, cnt - 1)) : tx_lds_read(&q[min(k + pi, cnt - 1)]);
+        const int nx = (e & 0xFFFF) + ndx, ny = (e >> 16) + ndy;
+        const bool ok = pi < nb && nx >= 0 && ny >= 0 && nx < W && ny < H;
+        const int qi = ok ? ny * W + nx : -1;
+        const int myxy = (ny << 16) | nx;
+        float4 rr;
+        int2 oo;
+        asm volatile("" : "=v"(rr.x), "=v"(rr.y), "=v"(rr.z), "=v"(oo.x), "=v"(oo.y));
+        rr.w = 0.f;
+        if (ok) {
+          rr = rec[qi];
+          oo = tx_load_own(&own[qi]);
         }
         const int prevv = ci ? oo.x : oo.y, curv = ci ? oo.y : oo.x;
-        const bool cand = rr.x != TX_NOTDEF && !(prevv < r || curv <= r);
+        const bool cand = ok && rr.x != TX_NOTDEF && !(prevv < r || curv <= r);
         unsigned long long remaining = __builtin_amdgcn_ballot_w64(cand);
         if (!SPILL) {
           // tx_accept_fast; accepted lanes write their queue entries after the loop (they are accepted in increasing lane order)
@@ -723,14 +733,8 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
       };
       while (k < cnt && cnt + 8 * 8 + 1 <= TX_GQ) oneStep(std::false_type{});
       while (k < cnt && !dead) oneStep(std::true_type{});
-      if (noteLost) {                                     // the claims of the region's last step
-        asm volatile("" ::"v"(pendOld) : "memory");
-        if (pendOld != 0x7FFFFFFF) {
-          if (pendOld < r) rgLost[r] = t;
-          else if (pendOld != r && pendOld != pendRank) rgLost[pendOld] = t;
-        }
-        pendOld = 0x7FFFFFFF;
-      }
+      asm volatile("" ::"v"(pendOld) : "memory");       // the claims of the region's last step
+      stampLosers();
       asm volatile("" ::"v"(pendOld) : "memory");
       if (dead) { c.overflow = 5; return; }
       // ---- the region is complete ----
