@@ -257,6 +257,70 @@ __global__ __launch_bounds__(256) void k_tx_diff2(RxCtl* __restrict__ ctl, const
 }
 
 // ---------------------------------------------------------------------------
+// k_tx_round2 (round 2, lost-pixel rule): k_tx_diff2 and the round's k_tx_prep in one pass over the owner map.  Whether the
+// owner o of a pixel is regrown is decided where the pixel is — o is dead in owner_1 (its seed belongs to another region), or
+// it lost a contested claim in round 1 (rgLost) — so the pixel can take its start value for owner_2 at once: o when o is
+// carried, its own rank otherwise.  The first pixel that finds o stamps it (rgDirty, the cells under its box, the dirty list
+// of its tile).  32 x 32 pixels per block, the four rows of a thread in flight together.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tx_round2(RxCtl* __restrict__ ctl, int2* __restrict__ ownAll,
+                                                   const int* __restrict__ rankAll, const int* __restrict__ orderAll,
+                                                   const int2* __restrict__ rgBoxAll, int* __restrict__ rgDirtyAll,
+                                                   int* __restrict__ tileActAll, int W, int H, int TW, int TH, int t, int img0,
+                                                   const int* __restrict__ rgLostAll, TxDirtyLists DL) {
+  const int img = blockIdx.z + img0;
+  RxCtl& c = ctl[img];
+  if (c.state == 2) return;
+  const int tid = threadIdx.x;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { c.nSmall = 0; c.nBig = 0; c.nHand = 0; c.nextBig = 0; c.rectArena = 0ull; c.changed = 0; }
+  const int64_t base = (int64_t)img * W * H;
+  const int ci = t & 1;
+  const int x = blockIdx.x * 32 + (tid & 31);
+  int2 ow[4];
+  int o[4], r[4], sp[4], lost[4];
+  int2 so[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int y = blockIdx.y * 32 + i * 8 + (tid >> 5);
+    ow[i] = make_int2(INT_MAX, INT_MAX);
+    r[i] = TX_INF;
+    if (x < W && y < H) {
+      ow[i] = ownAll[base + y * W + x];
+      r[i] = rankAll[base + y * W + x];
+    }
+    o[i] = ci ? ow[i].x : ow[i].y;                     // owner_{t-1}
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    sp[i] = -1; lost[i] = 0;
+    if (o[i] != INT_MAX) {
+      sp[i] = orderAll[base + o[i]];
+      lost[i] = rgLostAll[base + o[i]];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    so[i] = make_int2(0, 0);
+    if (sp[i] >= 0) so[i] = ownAll[base + sp[i]];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (o[i] == INT_MAX) continue;
+    const int y = blockIdx.y * 32 + i * 8 + (tid >> 5);
+    const int p = y * W + x;
+    // (p is o's seed: o holds it, so o is alive)
+    const bool dead = sp[i] != p && (ci ? so[i].x : so[i].y) != o[i];
+    const bool dirty = dead || lost[i] != 0;
+    if (dirty) tx_mark_dirty(o[i], t, rgDirtyAll + base, rgBoxAll + base, tileActAll + (int64_t)img * TW * TH, TW, TH, DL, img);
+    const int cur = dirty ? r[i] : o[i];
+    if (cur != (ci ? ow[i].y : ow[i].x)) {
+      if (ci) ow[i].y = cur; else ow[i].x = cur;
+      ownAll[base + p] = ow[i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // k_tx_mark (rounds >= 3, exact rule; takes the place of k_rx_mark, whose comment states the rule).  Everything the rule does
 // starts from a pixel whose owner changed between owner_{t-2} and owner_{t-1}, and those are few: a block (4 x 8 cells) first
 // lists the changed pixels of its changed cells in LDS, then spreads (changed pixel, neighbour) pairs over its threads, so the

@@ -806,7 +806,11 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
         curT = t;
         if (t >= 2 && DL.list)
           HIPCHK(hipMemsetAsync(c->txDirtyCnt + (int64_t)img0 * ntile, 0, sizeof(int) * (size_t)ntile * nimg, c->stream));
-        if (t == 2 && !fullRound2)
+        const bool fused2 = t == 2 && !fullRound2 && lostRule && !getenv("PLI_TX_NOFUSE2");    // (dev switch: the two passes)
+        if (fused2)
+          TRL(c, "k_tx_round2", k_tx_round2, dim3((P.LW + 31) / 32, (P.LH + 31) / 32, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->order,
+              c->rgBox, c->rgDirty, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, (const int*)c->rgLost, DL);
+        else if (t == 2 && !fullRound2)
           TRL(c, "k_tx_diff2", k_tx_diff2, dim3((P.LW + 31) / 32, c->tilesH, nimg), dim3(256), 0, c->jrCtl, c->own, c->order, c->rgBox,
               c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, ts, t, img0, lostRule ? (const int*)c->rgLost : (const int*)nullptr, DL);
         else if (t >= 2)                     // (round 1 starts from the trivial map: nothing to compare, the control block is zeroed)
@@ -822,6 +826,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
           TRL(c, "k_rx_mark", k_rx_mark, dim3((P.LW + 31) / 32, (c->tilesH + 7) / 8, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->rgBox,
               c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, t >= 3 ? 1 : 0,
               (lostRule && t >= 3 && !getenv("PLI_TX_CELLRULE")) ? (const int*)c->rgLost : (const int*)nullptr, DL);
+          if (!fused2)
           TRL(c, "k_tx_prep", k_tx_prep, dim3((P.LW + 31) / 32, (P.LH + 31) / 32, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf,
               c->rgDirty, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, t == 2 ? 1 : 0);
           TRL(c, "k_tx_grow_sparse", k_tx_grow_sparse, dim3(ntile, nimg), dim3(64), txPad, c->dP, c->jrCtl, c->rec, c->own, c->txList,
