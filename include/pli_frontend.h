@@ -107,7 +107,7 @@ typedef struct pli_frontend_config {
   double  min_disp;           /* 1.0                                                       */
   double  line_horiz_th;      /* 0.1                                                       */
   /* execution strategy of the LSD region grower (results are identical):
-     0 = auto (picked by batch size, see pli_capi.hip: chooseLsdMode),
+     0 = auto (by batch size: 3 below 1024 frames per call, 2 from there on — pli_capi.hip: RX_AUTO_IMAGES, a measured crossover),
      1 = rank-ordered relaxation, one region per lane / lane group (lsd_relax.hip),
      2 = sequential, one wave per image (line_kernels.hip: k_lsd_grow),
      3 = tile-sequential relaxation, one wave per 64x64 tile (lsd_tile.hip) */
