@@ -168,12 +168,60 @@ __global__ __launch_bounds__(1024) void k_lsd_scan(const unsigned short* __restr
   }
 }
 
+// The same for large images (thousands of chunks: one block per image is a long serial walk), in two kernels: a block per
+// (image, group of chunks) makes the group-local prefix and the group's bin totals; a block per image then scans the groups
+// per bin and writes, per (group, bin), the offset k_lsd_scatter adds to the group-local value when it loads a chunk's bases.
+__global__ __launch_bounds__(1024) void k_lsd_scan_part(const unsigned short* __restrict__ chunkHist, int nChunks, int nBins,
+                                                        int chunksPerGroup, int* __restrict__ chunkBase,
+                                                        int* __restrict__ groupOff, int img0) {
+  const int img = blockIdx.x + img0, g = blockIdx.y, b = threadIdx.x;
+  if (b >= nBins) return;
+  const int c0 = g * chunksPerGroup, c1 = min(c0 + chunksPerGroup, nChunks);
+  const unsigned short* hin = chunkHist + (int64_t)img * nChunks * nBins;
+  int* cb = chunkBase + (int64_t)img * nChunks * nBins;
+  int run = 0;
+#pragma unroll 8
+  for (int c = c0; c < c1; ++c) {
+    const int v = hin[(int64_t)c * nBins + b];
+    cb[(int64_t)c * nBins + b] = run;
+    run += v;
+  }
+  groupOff[((int64_t)img * gridDim.y + g) * nBins + b] = run;
+}
+__global__ __launch_bounds__(1024) void k_lsd_scan_groups(int nGroups, int nBins, int* __restrict__ groupOff,
+                                                          int* __restrict__ nDefined, int img0) {
+  __shared__ int tot[1024];
+  __shared__ int start[1024];
+  const int img = blockIdx.x + img0, b = threadIdx.x;
+  int* go = groupOff + (int64_t)img * nGroups * nBins;
+  int run = 0;
+  if (b < nBins)
+    for (int g = 0; g < nGroups; ++g) {
+      const int v = go[g * nBins + b];
+      go[g * nBins + b] = run;
+      run += v;
+    }
+  tot[b] = b < nBins ? run : 0;
+  __syncthreads();
+  if (b == 0) {
+    int acc = 0;
+    for (int k = nBins - 1; k >= 0; --k) { start[k] = acc; acc += tot[k]; }   // bins in descending order
+    nDefined[img] = acc;
+  }
+  __syncthreads();
+  if (b < nBins) {
+    const int s0 = start[b];
+    for (int g = 0; g < nGroups; ++g) go[g * nBins + b] += s0;
+  }
+}
+
 // stable scatter: one wave per chunk walks its 1024 pixels in raster order
 __global__ __launch_bounds__(64) void k_lsd_scatter(const int* __restrict__ g2a, int npix, int g2Thresh, int nBins,
                                                     const int* __restrict__ maxG2, const int* __restrict__ chunkBase,
                                                     int nChunks, int* __restrict__ order, int img0, int nimg,
                                                     const double* __restrict__ mgAll, const unsigned long long* __restrict__ maxMg,
-                                                    double rho, int* __restrict__ rankAll) {
+                                                    double rho, int* __restrict__ rankAll,
+                                                    const int* __restrict__ groupOff, int chunksPerGroup, int nGroups) {
   __shared__ int base[1024];
   // XCD-aware order: workgroup L runs on XCD L % 8, so all chunks of an image are dealt to ONE XCD (consecutive slots of
   // that XCD, i.e. close in time): the 4-byte stores of different chunks into the same lines of the ordered list then
@@ -183,7 +231,12 @@ __global__ __launch_bounds__(64) void k_lsd_scatter(const int* __restrict__ g2a,
   if (li >= nimg) return;
   const int img = li + img0;
   const int* cb = chunkBase + ((int64_t)img * nChunks + chunk) * nBins;
-  for (int i = lane; i < nBins; i += 64) base[i] = cb[i];
+  if (groupOff) {                                        // (large images: k_lsd_scan_part / k_lsd_scan_groups)
+    const int* go = groupOff + ((int64_t)img * nGroups + chunk / chunksPerGroup) * nBins;
+    for (int i = lane; i < nBins; i += 64) base[i] = cb[i] + go[i];
+  } else {
+    for (int i = lane; i < nBins; i += 64) base[i] = cb[i];
+  }
   __syncthreads();
   const bool f64 = mgAll != nullptr;
   const double bc = f64 ? lsd_bin_coef64(maxMg[img], nBins) : lsd_bin_coef(maxG2[img], nBins);

@@ -97,6 +97,7 @@ struct pli_ctx {
   double* rectW = nullptr;                   // CV_64F pipeline: the weights of the listed pixels, beside the lists
   double* scaled64Dbg = nullptr;             // debug copy of the CV_64F scaled image (its plane is reused as the growers' arena)
   int nChunks = 0, maxSeg = 0;
+  int scanGroups = 0, scanChunksPerGroup = 0; int* scanGroupOff = nullptr;     // ordered-list scan of large images, in groups of chunks
   pli_keyline* tmpKL = nullptr;
   short2* dxy = nullptr;           // Sobel (dx, dy) of level 0, interleaved
   LbdCoef* lbdCoef = nullptr;
@@ -561,6 +562,11 @@ pli_status allocAll(pli_ctx* c) {
   c->nChunks = (int)((npix + LSD_CHUNK - 1) / LSD_CHUNK);
   A(c->chunkHist, (size_t)NI * c->nChunks * P.nBins);
   A(c->chunkBase, (size_t)NI * c->nChunks * P.nBins);
+  if (c->nChunks > 256 && !getenv("PLI_LSD_SCAN1")) {     // (dev switch: the one-block scan)
+    c->scanChunksPerGroup = 64;
+    c->scanGroups = (c->nChunks + c->scanChunksPerGroup - 1) / c->scanChunksPerGroup;
+    A(c->scanGroupOff, (size_t)NI * c->scanGroups * P.nBins);
+  }
   A(c->nDefined, NI);
   A(c->order, npix * NI);
   A(c->regScratch, npix * NI);
@@ -707,6 +713,12 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   }
   LAUNCH(c, "k_lsd_hist", k_lsd_hist, dim3(c->nChunks, nimg), dim3(256), 0, c->g2, npix, P.g2Thresh, P.nBins, c->maxG2,
          c->chunkHist, c->nChunks, img0, c->mg, c->maxMg, P.rho);
+  // (thousands of chunks per image — 4K —: the scan over the chunks in groups, lsd_scanGroups > 0)
+  if (c->scanGroups > 0) {
+    LAUNCH(c, "k_lsd_scan", k_lsd_scan_part, dim3(nimg, c->scanGroups), dim3(1024), 0, c->chunkHist, c->nChunks, P.nBins,
+           c->scanChunksPerGroup, c->chunkBase, c->scanGroupOff, img0);
+    LAUNCH(c, "k_lsd_scan", k_lsd_scan_groups, dim3(nimg), dim3(1024), 0, c->scanGroups, P.nBins, c->scanGroupOff, c->nDefined, img0);
+  } else
   LAUNCH(c, "k_lsd_scan", k_lsd_scan, dim3(nimg), dim3(1024), 0, c->chunkHist, c->nChunks, P.nBins, c->chunkBase, c->nDefined, img0);
   // 16 KB of unused dynamic LDS per single-wave workgroup caps the scatter at 8 waves per CU: with all chunks of an image on
   // one XCD (see the kernel) that keeps the ordered lists "open" in an XCD's 4 MB L2 to ~2 images, so the 4-byte stores of
@@ -714,7 +726,8 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   constexpr size_t scatterOccupancyPad = 16384;
   LAUNCH(c, "k_lsd_scatter", k_lsd_scatter, dim3((unsigned)(8 * ((nimg + 7) / 8) * c->nChunks)), dim3(64), scatterOccupancyPad, c->g2, npix, P.g2Thresh,
          P.nBins, c->maxG2, c->chunkBase, c->nChunks, c->order, img0, nimg, c->mg, c->maxMg, P.rho,
-         sequential ? (int*)nullptr : c->rankOf);
+         sequential ? (int*)nullptr : c->rankOf, (const int*)(c->scanGroups > 0 ? c->scanGroupOff : nullptr), c->scanChunksPerGroup,
+         c->scanGroups);
   if (sequential) {
     // speculative form (line_kernels.hip: lsd_grow_image_spec): the small regions of 64 seeds at a time, one per lane
     const bool spec = c->lsdSpec && P.minRegSize >= 2;
@@ -1102,7 +1115,11 @@ pli_status pli_batch_run(pli_ctx* c, int32_t nframes, const uint8_t* dl, const u
   static const int sideMax = getenv("PLI_SIDE_MAX") ? atoi(getenv("PLI_SIDE_MAX")) : 256;      // (dev: images below which the ORB chain runs beside the line chain)
   if (nimg < sideMax && (stages & PLI_RUN_ORB) && (stages & PLI_RUN_LINES) && !c->syncDebug) {
     if (!c->aux) {
-      HIPCHK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+      // (the line chain is the longer one: the ORB chain beside it takes what the line kernels leave free)
+      int prLow = 0, prHigh = 0;
+      HIPCHK(hipDeviceGetStreamPriorityRange(&prLow, &prHigh));
+      if (getenv("PLI_SIDE_NOPRIO")) prLow = 0;            // dev switch: default priority
+      HIPCHK(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prLow));
       HIPCHK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
     }
