@@ -957,6 +957,33 @@ def test_sequential_grower_dev_switches(gpu, flags, monkeypatch):
         assert m == want[0] and kl.tobytes() == want[1].tobytes() and np.array_equal(ld, want[2]), env
 
 
+@pytest.mark.parametrize("W,H", [(752, 480), (1600, 1200)])
+def test_tile_relaxation_dev_switches(gpu, W, H, monkeypatch):
+    """The tile-sequential relaxation with each of its round-2 shortcuts switched off gives the same lines as with them:
+    the walk over all seeds instead of the per-tile dirty lists (PLI_TX_NODIRTYLIST), k_tx_diff2 + k_tx_prep instead of the
+    fused round 2 (PLI_TX_NOFUSE2), k_rx_mark instead of k_tx_mark (PLI_TX_OLDMARK), the conservative regrowth rules
+    (PLI_TX_BOXRULE, PLI_TX_CELLRULE), every cell compared every round (PLI_TX_FULLDIFF), and the one-block ordered-list scan
+    (PLI_LSD_SCAN1; the larger shape has enough chunks for the grouped scan)."""
+    g = gpu
+    L, R = g.synth.make_stereo_pair(77, W, H)
+    switches = ("PLI_TX_NODIRTYLIST", "PLI_TX_NOFUSE2", "PLI_TX_OLDMARK", "PLI_TX_BOXRULE", "PLI_TX_CELLRULE", "PLI_TX_FULLDIFF",
+                "PLI_LSD_SCAN1")
+    want = None
+    for on in (None,) + switches:
+        for k in switches:
+            monkeypatch.delenv(k, raising=False)
+        if on:
+            monkeypatch.setenv(on, "1")
+        cfg = g.capi.default_config(W, H, orb_nfeatures=300, lsd_nfeatures=0, max_frames=1, lsd_mode=3)
+        fe = g.Frontend(cfg)
+        m, kl, ld = fe.line_extract(0, L)
+        if want is None:
+            fr = g.po.Frame(ocfg(g, cfg))
+            want = fr.line_extract(0, L)
+            assert want[0] > 500
+        assert m == want[0] and kl.tobytes() == want[1].tobytes() and np.array_equal(ld, want[2]), on
+
+
 def test_truncation_is_flagged_not_silent(gpu):
     """A max_lines smaller than the number of segments that pass the length cut: the record carries the truncation flag and
     the per-call entry point returns PLI_ERR_CAPACITY; with room enough the flag is clear and the result is the oracle's."""
