@@ -400,6 +400,24 @@ pli_status pli_search_local_map(pli_ctx* ctx, const pli_proj_query* q, const uin
                                 float min_x, float max_x, float min_y, float max_y, float nnratio,
                                 int32_t* best_idx2, int32_t* nmatches);
 
+/* The same function for a frame of two fisheye cameras (F.Nleft != -1), ORBmatcher.cc:44-214 in full.  Per map point i:
+ * q_left[i] as above (valid = mbTrackInView etc.; no mvuRight gate in this branch), then — unless the left ratio test failed,
+ * whose `continue` leaves the map point (:126) — q_right[i]: (u,v) = mTrackProjXR/YR, radius = RadiusByViewingCos(
+ * mTrackViewCosR)*mvScaleFactors[mnTrackScaleLevelR] (no th, :148-151), levels mnTrackScaleLevelR-1..mnTrackScaleLevelR,
+ * valid = mbTrackInViewR && mnTrackScaleLevelR != -1, searched in mGridRight / mvKeysRight.  F.mvpMapPoints is one array
+ * of Nleft + Nright slots: occ_left / occ_right (may be NULL) mark the slots that hold a map point with observations,
+ * left_to_right / right_to_left are mvLeftToRightMatch / mvRightToLeftMatch (-1 = none) — a match is also written to the
+ * keypoint's stereo partner (:133-137, :201-205).  mp_left[k] / mp_right[k] = index of the map point this call left in the
+ * slot, or -1; *nmatches = return value.  nleft + nright <= 15360. */
+pli_status pli_search_local_map_fisheye(pli_ctx* ctx, const pli_proj_query* q_left, const pli_proj_query* q_right,
+                                        const uint8_t* qdesc, int32_t nq,
+                                        const pli_keypoint* kp_left, const uint8_t* desc_left, const uint8_t* occ_left,
+                                        const int32_t* left_to_right, int32_t nleft,
+                                        const pli_keypoint* kp_right, const uint8_t* desc_right, const uint8_t* occ_right,
+                                        const int32_t* right_to_left, int32_t nright,
+                                        float min_x, float max_x, float min_y, float max_y, float nnratio,
+                                        int32_t* mp_left, int32_t* mp_right, int32_t* nmatches);
+
 /* int match(const vector<MapLine*>&, Frame&, nnr, matches_12) LineMatcher.cpp:161-171: one-directional matchNNR
  * of the local map lines' descriptors against the frame's (the reference returns before its mutual check). */
 pli_status pli_match_nnr(pli_ctx* ctx, const uint8_t* desc1, int32_t n1, const uint8_t* desc2, int32_t n2, float nnr,

@@ -560,6 +560,102 @@ static inline int searchLocalMap(const pli_proj_query* q, const uint8_t* qdesc, 
   return nmatches;
 }
 
+// ---------------------------------------------------------------------------
+// The same function for a frame of two fisheye cameras (F.Nleft != -1), ORBmatcher.cc:44-214 in full: per map point first
+// the left camera (:62-143; no mvuRight gate; a match is also written to the keypoint's stereo partner in the right camera,
+// mvLeftToRightMatch, :133-137), then — unless the left ratio test just failed, whose `continue` leaves the map point —
+// the right camera (:145-211: GetFeaturesInArea(..., bRight = true), radius WITHOUT th, keypoints idx + Nleft, partner
+// mvRightToLeftMatch).  F.mvpMapPoints is one array of Nleft + Nright slots: mpLeft / mpRight receive the index of the map
+// point this call left in each slot (-1: none).  A slot counts as taken — "mvpMapPoints[idx] && Observations() > 0" — when
+// the caller says so (occupied*) or once this call has written it: the local map's points have observations (they come from
+// keyframes), the same reduction of the SLAM state as in searchLocalMap above.  Returns nmatches.
+// ---------------------------------------------------------------------------
+static inline int searchLocalMapFisheye(const pli_proj_query* qL, const pli_proj_query* qR, const uint8_t* qdesc, int nq,
+                                        const pli_keypoint* kpL, const uint8_t* descL, const uint8_t* occL, const int* l2r, int nL,
+                                        const pli_keypoint* kpR, const uint8_t* descR, const uint8_t* occR, const int* r2l, int nR,
+                                        float mnMinX, float mnMaxX, float mnMinY, float mnMaxY, float mfNNratio,
+                                        std::vector<int>& mpLeft, std::vector<int>& mpRight) {
+  const int COLS = 64, ROWS = 48, TH_HIGH = 100;
+  mpLeft.assign(nL, -1);
+  mpRight.assign(nR, -1);
+  const float gwInv = static_cast<float>(COLS) / (mnMaxX - mnMinX);
+  const float ghInv = static_cast<float>(ROWS) / (mnMaxY - mnMinY);
+  // Frame::AssignFeaturesToGrid (Frame.cc:451-482): mGrid for the left keypoints, mGridRight for the right ones
+  auto makeGrid = [&](const pli_keypoint* kp, int n) {
+    std::vector<std::vector<int>> grid((size_t)COLS * ROWS);
+    for (int i = 0; i < n; ++i) {
+      int px = (int)std::round((kp[i].x - mnMinX) * gwInv);
+      int py = (int)std::round((kp[i].y - mnMinY) * ghInv);
+      if (px < 0 || px >= COLS || py < 0 || py >= ROWS) continue;
+      grid[(size_t)px * ROWS + py].push_back(i);
+    }
+    return grid;
+  };
+  const auto gridL = makeGrid(kpL, nL), gridR = makeGrid(kpR, nR);
+  std::vector<char> takenL(nL, 0), takenR(nR, 0);
+  if (occL) for (int i = 0; i < nL; ++i) takenL[i] = occL[i] != 0;
+  if (occR) for (int i = 0; i < nR; ++i) takenR[i] = occR[i] != 0;
+  // best / second best of one camera (GetFeaturesInArea order); false: the window holds no keypoint at all
+  auto best2 = [&](const pli_proj_query& Q, const uint8_t* d, const pli_keypoint* kp, const uint8_t* desc,
+                   const std::vector<std::vector<int>>& grid, const std::vector<char>& taken, int& bestDist, int& bestLevel,
+                   int& bestDist2, int& bestLevel2, int& bestIdx) -> bool {
+    bestDist = 256; bestLevel = -1; bestDist2 = 256; bestLevel2 = -1; bestIdx = -1;
+    const float x = Q.u, y = Q.v, r = Q.radius;
+    const int minLevel = Q.min_level, maxLevel = Q.max_level;
+    const int nMinCellX = std::max(0, (int)std::floor((x - mnMinX - r) * gwInv));
+    if (nMinCellX >= COLS) return false;
+    const int nMaxCellX = std::min(COLS - 1, (int)std::ceil((x - mnMinX + r) * gwInv));
+    if (nMaxCellX < 0) return false;
+    const int nMinCellY = std::max(0, (int)std::floor((y - mnMinY - r) * ghInv));
+    if (nMinCellY >= ROWS) return false;
+    const int nMaxCellY = std::min(ROWS - 1, (int)std::ceil((y - mnMinY + r) * ghInv));
+    if (nMaxCellY < 0) return false;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    bool any = false;
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+      for (int iy = nMinCellY; iy <= nMaxCellY; iy++)
+        for (int idx : grid[(size_t)ix * ROWS + iy]) {
+          const pli_keypoint& k = kp[idx];
+          if (bCheckLevels) {
+            if (k.octave < minLevel) continue;
+            if (maxLevel >= 0 && k.octave > maxLevel) continue;
+          }
+          if (!(std::fabs(k.x - x) < r && std::fabs(k.y - y) < r)) continue;
+          any = true;
+          if (taken[idx]) continue;
+          const int dist = descriptorDistance(d, desc + (size_t)idx * 32);
+          if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = k.octave; bestIdx = idx; }
+          else if (dist < bestDist2) { bestLevel2 = k.octave; bestDist2 = dist; }
+        }
+    return any;
+  };
+  int nmatches = 0;
+  for (int i = 0; i < nq; ++i) {
+    const uint8_t* d = qdesc + (size_t)i * 32;
+    int bestDist, bestLevel, bestDist2, bestLevel2, bestIdx;
+    if (qL[i].valid) {                                   // pMP->mbTrackInView
+      if (best2(qL[i], d, kpL, descL, gridL, takenL, bestDist, bestLevel, bestDist2, bestLevel2, bestIdx)) {
+        if (bestDist <= TH_HIGH) {
+          if (bestLevel == bestLevel2 && (float)bestDist > mfNNratio * (float)bestDist2) continue;   // (leaves the map point: :126)
+          mpLeft[bestIdx] = i; takenL[bestIdx] = 1;
+          if (l2r[bestIdx] != -1) { mpRight[l2r[bestIdx]] = i; takenR[l2r[bestIdx]] = 1; nmatches++; }
+          nmatches++;
+        }
+      }
+    }
+    if (qR[i].valid) {                                   // pMP->mbTrackInViewR && mnTrackScaleLevelR != -1
+      if (!best2(qR[i], d, kpR, descR, gridR, takenR, bestDist, bestLevel, bestDist2, bestLevel2, bestIdx)) continue;
+      if (bestDist <= TH_HIGH) {
+        if (bestLevel == bestLevel2 && (float)bestDist > mfNNratio * (float)bestDist2) continue;
+        if (r2l[bestIdx] != -1) { mpLeft[r2l[bestIdx]] = i; takenL[r2l[bestIdx]] = 1; nmatches++; }
+        mpRight[bestIdx] = i; takenR[bestIdx] = 1;
+        nmatches++;
+      }
+    }
+  }
+  return nmatches;
+}
+
 // Frame::ComputeStereoFromRGBD, Frame.cc:1309-1331 (rectified: mvKeysUn == mvKeys)
 static inline void stereoFromDepth(const pli_keypoint* kp, int n, const float* depth, int64_t stride, int W, int H, float mbf,
                                    std::vector<float>& mvuRight, std::vector<float>& mvDepth) {

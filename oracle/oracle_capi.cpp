@@ -301,6 +301,16 @@ int orc_search_local_map(const pli_proj_query* q, const uint8_t* qdesc, int nq, 
   std::memcpy(best_idx2, B.data(), B.size() * 4);
   return r;
 }
+int orc_search_local_map_fisheye(const pli_proj_query* ql, const pli_proj_query* qr, const uint8_t* qdesc, int nq,
+                                 const pli_keypoint* kpl, const uint8_t* dl, const uint8_t* occl, const int* l2r, int nl,
+                                 const pli_keypoint* kpr, const uint8_t* dr, const uint8_t* occr, const int* r2l, int nr, float minx,
+                                 float maxx, float miny, float maxy, float nnratio, int* mpl, int* mpr) {
+  std::vector<int> ML, MR;
+  int r = searchLocalMapFisheye(ql, qr, qdesc, nq, kpl, dl, occl, l2r, nl, kpr, dr, occr, r2l, nr, minx, maxx, miny, maxy, nnratio, ML, MR);
+  if (nl) std::memcpy(mpl, ML.data(), ML.size() * 4);
+  if (nr) std::memcpy(mpr, MR.data(), MR.size() * 4);
+  return r;
+}
 int orc_match_nnr(const uint8_t* d1, int n1, const uint8_t* d2, int n2, float nnr, int* m12) {
   std::vector<int> M;
   int r = matchNNR(d1, n1, d2, n2, nnr, M);

@@ -367,6 +367,24 @@ def search_local_map(q, qdesc, kp, desc, uright, occupied, bounds, nnratio):
     return n, best
 
 
+def search_local_map_fisheye(ql, qr, qdesc, kpl, dl, occl, l2r, kpr, dr, occr, r2l, bounds, nnratio):
+    ql = np.ascontiguousarray(ql, PROJ_QUERY_DT)
+    qr = np.ascontiguousarray(qr, PROJ_QUERY_DT)
+    qdesc = np.ascontiguousarray(qdesc, np.uint8)
+    kpl, kpr = np.ascontiguousarray(kpl, KEYPOINT_DT), np.ascontiguousarray(kpr, KEYPOINT_DT)
+    dl, dr = np.ascontiguousarray(dl, np.uint8), np.ascontiguousarray(dr, np.uint8)
+    ol = None if occl is None else np.ascontiguousarray(occl, np.uint8)
+    orr = None if occr is None else np.ascontiguousarray(occr, np.uint8)
+    l2r, r2l = np.ascontiguousarray(l2r, np.int32), np.ascontiguousarray(r2l, np.int32)
+    mpl = np.full(kpl.shape[0], -1, np.int32)
+    mpr = np.full(kpr.shape[0], -1, np.int32)
+    n = lib().orc_search_local_map_fisheye(_p(ql), _p(qr), _p(qdesc), ql.shape[0], _p(kpl), _p(dl), _p(ol), _p(l2r), kpl.shape[0],
+                                           _p(kpr), _p(dr), _p(orr), _p(r2l), kpr.shape[0],
+                                           C.c_float(bounds[0]), C.c_float(bounds[1]), C.c_float(bounds[2]), C.c_float(bounds[3]),
+                                           C.c_float(nnratio), _p(mpl), _p(mpr))
+    return n, mpl, mpr
+
+
 def match_nnr(d1, d2, nnr):
     d1, d2 = np.ascontiguousarray(d1, np.uint8), np.ascontiguousarray(d2, np.uint8)
     m = np.full(d1.shape[0], -1, np.int32)

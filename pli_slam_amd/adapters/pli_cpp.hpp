@@ -128,6 +128,21 @@ class Frontend {
                                (int)cur.size(), minX, maxX, minY, maxY, nnratio, bestIdx2.data(), &n));
     return n;
   }
+  // the same for a frame of two fisheye cameras (F.Nleft != -1), ORBmatcher.cc:44-214: both halves of F.mvpMapPoints
+  // (mpLeft[k] / mpRight[k] = index into vpMapPoints of the point the call left in slot k / k + Nleft, or -1)
+  int searchLocalMapFishEye(const std::vector<pli_proj_query>& qLeft, const std::vector<pli_proj_query>& qRight, const uint8_t* qdesc,
+                            const std::vector<pli_keypoint>& kpLeft, const uint8_t* descLeft, const uint8_t* occLeft,
+                            const std::vector<int>& leftToRight, const std::vector<pli_keypoint>& kpRight,
+                            const uint8_t* descRight, const uint8_t* occRight, const std::vector<int>& rightToLeft, float minX,
+                            float maxX, float minY, float maxY, float nnratio, std::vector<int>& mpLeft, std::vector<int>& mpRight) {
+    mpLeft.assign(kpLeft.size(), -1); mpRight.assign(kpRight.size(), -1);
+    int32_t n = 0;
+    check(pli_search_local_map_fisheye(ctx_, qLeft.data(), qRight.data(), qdesc, (int)qLeft.size(), kpLeft.data(), descLeft, occLeft,
+                                       leftToRight.data(), (int)kpLeft.size(), kpRight.data(), descRight, occRight,
+                                       rightToLeft.data(), (int)kpRight.size(), minX, maxX, minY, maxY, nnratio, mpLeft.data(),
+                                       mpRight.data(), &n));
+    return n;
+  }
   // int match(const vector<MapLine*>&, Frame&, nnr, matches_12) LineMatcher.cpp:161 on the descriptor tables
   int matchNNR(const uint8_t* desc1, int n1, const uint8_t* desc2, int n2, float nnr, std::vector<int>& matches12) {
     matches12.assign(n1, -1);

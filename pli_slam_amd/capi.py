@@ -132,6 +132,11 @@ _PROTOS = {
     "pli_search_local_map": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
                                          C.c_float, C.c_void_p, C.POINTER(C.c_int32)]),
+    "pli_search_local_map_fisheye": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                                 C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "pli_match_nnr": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_void_p,
                                   C.POINTER(C.c_int32)]),
     "pli_vocab_create": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -913,6 +913,98 @@ __global__ __launch_bounds__(64) void k_proj_assign(const pli_proj_query* __rest
 }
 
 // ---------------------------------------------------------------------------
+// ORBmatcher::SearchByProjection(Frame&, vpMapPoints, th) for a frame of two fisheye cameras (ORBmatcher.cc:44-214 with
+// F.Nleft != -1).  The candidates of every (map point, camera)
+// come from k_proj_candidates, all in parallel; this wave walks the map points in order — left camera, then right unless
+// the left ratio test sent the map point away — with the two halves of F.mvpMapPoints as owner tables in LDS (-1 free,
+// INT_MAX taken before the call, else the map point that wrote the slot last), and writes a match to the stereo partner
+// of the keypoint as the reference does (mvLeftToRightMatch / mvRightToLeftMatch; the partner's slot is overwritten, taken
+// or not).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_proj_assign_fisheye(
+    const pli_proj_query* __restrict__ qL, const pli_proj_query* __restrict__ qR, const uint8_t* __restrict__ qdesc, int nq,
+    const pli_keypoint* __restrict__ kpL, const uint8_t* __restrict__ descL, const uint8_t* __restrict__ occL,
+    const int* __restrict__ l2r, int nL, const pli_keypoint* __restrict__ kpR, const uint8_t* __restrict__ descR,
+    const uint8_t* __restrict__ occR, const int* __restrict__ r2l, int nR, const float* __restrict__ noUright, float minX,
+    float maxX, float minY, float maxY, float nnratio, const unsigned long long* __restrict__ keysL,
+    const int* __restrict__ cntL, const unsigned long long* __restrict__ keysR, const int* __restrict__ cntR,
+    int* __restrict__ mpL, int* __restrict__ mpR, int* __restrict__ nmatchesOut) {
+  extern __shared__ int owner[];                         // [nL] left slots, [nR] right slots
+  int* ownL = owner;
+  int* ownR = owner + nL;
+  const int lane = threadIdx.x;
+  const float gwInv = __fdiv_rn((float)GRID_COLS, __fsub_rn(maxX, minX));
+  const float ghInv = __fdiv_rn((float)GRID_ROWS, __fsub_rn(maxY, minY));
+  for (int i = lane; i < nL; i += 64) ownL[i] = (occL && occL[i]) ? INT_MAX : -1;
+  for (int i = lane; i < nR; i += 64) ownR[i] = (occR && occR[i]) ? INT_MAX : -1;
+  __syncthreads();
+  int nmatches = 0;
+  // best and second best of one camera among the free keypoints; returns 0 nothing within TH_HIGH, 1 accepted (b1), 2 the
+  // ratio test failed (ORBmatcher.cc:124-126 / :197-199)
+  auto search = [&](int i, const pli_proj_query* q, const pli_keypoint* kp, const uint8_t* desc, int ncur, const int* own,
+                    const unsigned long long* keys, const int* cnts, int& b1) -> int {
+    const int cnt = cnts[i];
+    unsigned long long k1 = ~0ull, k2 = ~0ull;
+    if (cnt >= 0) {
+      unsigned long long key = lane < cnt ? keys[(int64_t)i * PROJ_K + lane] : ~0ull;
+      if (key != ~0ull && own[(int)(key & 0xFFFFFFFull)] >= 0) key = ~0ull;
+      k1 = key;
+    } else {                                             // more than PROJ_K candidates: scan the camera for this query
+      const pli_proj_query Q = q[i];
+      int c0, c1, r0, r1;
+      if (proj_window(Q, minX, maxX, minY, maxY, gwInv, ghInv, false, c0, c1, r0, r1)) {
+        uint64_t dq[4];
+        load_desc(qdesc + (int64_t)i * 32, dq);
+        for (int i2 = lane; i2 < ncur; i2 += 64) {
+          if (own[i2] >= 0) continue;
+          const unsigned long long kk = proj_key(Q, dq, i2, kp, desc, noUright, minX, minY, gwInv, ghInv, c0, c1, r0, r1);
+          if (kk < k1) { k2 = k1; k1 = kk; }
+          else if (kk < k2) k2 = kk;
+        }
+      }
+    }
+    const unsigned long long m1 = wave_min_u64(k1);
+    if (m1 == ~0ull || (int)(m1 >> 40) > 100) return 0;
+    b1 = (int)(m1 & 0xFFFFFFFull);
+    const unsigned long long c2 = (k1 == m1) ? k2 : k1;
+    const unsigned long long m2 = wave_min_u64(c2);
+    const int bestDist = (int)(m1 >> 40), bestLevel = kp[b1].octave;
+    int bestDist2 = 256, bestLevel2 = -1;
+    if (m2 != ~0ull) { bestDist2 = (int)(m2 >> 40); bestLevel2 = kp[(int)(m2 & 0xFFFFFFFull)].octave; }
+    return (bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2)) ? 2 : 1;
+  };
+  for (int i = 0; i < nq; ++i) {
+    int b1 = -1;
+    bool leave = false;
+    if (qL[i].valid) {
+      const int r = search(i, qL, kpL, descL, nL, ownL, keysL, cntL, b1);
+      if (r == 2) leave = true;
+      if (r == 1) {
+        ownL[b1] = i;                                     // every lane stores the same value
+        const int p = l2r[b1];
+        if (p != -1) { ownR[p] = i; ++nmatches; }
+        ++nmatches;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // single wave: LDS is executed in order
+    }
+    if (!leave && qR[i].valid) {
+      const int r = search(i, qR, kpR, descR, nR, ownR, keysR, cntR, b1);
+      if (r == 1) {
+        const int p = r2l[b1];
+        if (p != -1) { ownL[p] = i; ++nmatches; }
+        ownR[b1] = i;
+        ++nmatches;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+  }
+  __syncthreads();
+  for (int i = lane; i < nL; i += 64) { const int o = ownL[i]; mpL[i] = (o >= 0 && o != INT_MAX) ? o : -1; }
+  for (int i = lane; i < nR; i += 64) { const int o = ownR[i]; mpR[i] = (o >= 0 && o != INT_MAX) ? o : -1; }
+  if (lane == 0) *nmatchesOut = nmatches;
+}
+
+// ---------------------------------------------------------------------------
 // Frame-to-frame track matching of a whole batch on the device tables (pli_batch_track): frame i against frame i-1.
 //   k_track_queries     the projection part of ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono)
 //                       (ORBmatcher.cc:2190-2244) with LastFrame's stereo points standing for its map points

@@ -1681,6 +1681,77 @@ pli_status pli_search_local_map(pli_ctx* c, const pli_proj_query* q, const uint8
   return projectionSearch(c, 1, q, qdesc, nq, kp, desc, uright, occupied, ncur, minX, maxX, minY, maxY, 0, nnratio, best, nmatches);
 }
 
+pli_status pli_search_local_map_fisheye(pli_ctx* c, const pli_proj_query* qL, const pli_proj_query* qR, const uint8_t* qdesc,
+                                        int32_t nq, const pli_keypoint* kpL, const uint8_t* descL, const uint8_t* occL,
+                                        const int32_t* l2r, int32_t nL, const pli_keypoint* kpR, const uint8_t* descR,
+                                        const uint8_t* occR, const int32_t* r2l, int32_t nR, float minX, float maxX, float minY,
+                                        float maxY, float nnratio, int32_t* mpL, int32_t* mpR, int32_t* nmatches) {
+  if (!c || nq < 0 || nL < 0 || nR < 0 || (nq > 0 && (!qL || !qR || !qdesc)) || (nL > 0 && (!kpL || !descL || !l2r || !mpL)) ||
+      (nR > 0 && (!kpR || !descR || !r2l || !mpR))) { g_err = "bad argument"; return PLI_ERR_INVALID; }
+  if (nmatches) *nmatches = 0;
+  for (int i = 0; i < nL; ++i) {
+    mpL[i] = -1;
+    if (l2r[i] < -1 || l2r[i] >= nR) { g_err = "left_to_right out of range"; return PLI_ERR_INVALID; }
+  }
+  for (int i = 0; i < nR; ++i) {
+    mpR[i] = -1;
+    if (r2l[i] < -1 || r2l[i] >= nL) { g_err = "right_to_left out of range"; return PLI_ERR_INVALID; }
+  }
+  if (nq == 0 || nL + nR == 0) return PLI_OK;
+  if (nL + nR > PROJ_LDS_KEYPOINTS) { g_err = "too many keypoints for the LDS slot tables of the fisheye local-map search"; return PLI_ERR_CAPACITY; }
+  HIPCHK(hipSetDevice(c->device));
+  const int ncL = std::max(nL, 1), ncR = std::max(nR, 1), ncM = std::max(ncL, ncR);
+  const size_t bq = alignUp((size_t)nq * sizeof(pli_proj_query), 256), bqd = alignUp((size_t)nq * 32, 256);
+  const size_t bkL = alignUp((size_t)ncL * sizeof(pli_keypoint), 256), bdL = alignUp((size_t)ncL * 32, 256), boL = alignUp((size_t)ncL, 256), biL = alignUp((size_t)ncL * 4, 256);
+  const size_t bkR = alignUp((size_t)ncR * sizeof(pli_keypoint), 256), bdR = alignUp((size_t)ncR * 32, 256), boR = alignUp((size_t)ncR, 256), biR = alignUp((size_t)ncR * 4, 256);
+  const size_t bu = alignUp((size_t)ncM * 4, 256), bkeys = alignUp((size_t)nq * PROJ_CAND * 8, 256), bcc = alignUp((size_t)nq * 4, 256);
+  pli_status st = ensureScratch(c, 2 * bq + bqd + bkL + bdL + boL + 2 * biL + bkR + bdR + boR + 2 * biR + bu + 2 * bkeys + 2 * bcc + 256);
+  if (st != PLI_OK) return st;
+  uint8_t* p = (uint8_t*)c->scratch;
+  auto take = [&](size_t b) { uint8_t* r = p; p += b; return r; };
+  pli_proj_query* dqL = (pli_proj_query*)take(bq); pli_proj_query* dqR = (pli_proj_query*)take(bq);
+  uint8_t* dqd = take(bqd);
+  pli_keypoint* dkL = (pli_keypoint*)take(bkL); uint8_t* ddL = take(bdL); uint8_t* doL = take(boL); int* dl2r = (int*)take(biL); int* dmpL = (int*)take(biL);
+  pli_keypoint* dkR = (pli_keypoint*)take(bkR); uint8_t* ddR = take(bdR); uint8_t* doR = take(boR); int* dr2l = (int*)take(biR); int* dmpR = (int*)take(biR);
+  float* du = (float*)take(bu);
+  unsigned long long* dkeysL = (unsigned long long*)take(bkeys); unsigned long long* dkeysR = (unsigned long long*)take(bkeys);
+  int* dccL = (int*)take(bcc); int* dccR = (int*)take(bcc);
+  int* dcnt = (int*)p;
+  HIPCHK(hipMemcpyAsync(dqL, qL, (size_t)nq * sizeof(pli_proj_query), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(dqR, qR, (size_t)nq * sizeof(pli_proj_query), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(dqd, qdesc, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
+  if (nL > 0) {
+    HIPCHK(hipMemcpyAsync(dkL, kpL, (size_t)nL * sizeof(pli_keypoint), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(ddL, descL, (size_t)nL * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dl2r, l2r, (size_t)nL * 4, hipMemcpyHostToDevice, c->stream));
+    if (occL) HIPCHK(hipMemcpyAsync(doL, occL, (size_t)nL, hipMemcpyHostToDevice, c->stream));
+  }
+  if (nR > 0) {
+    HIPCHK(hipMemcpyAsync(dkR, kpR, (size_t)nR * sizeof(pli_keypoint), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(ddR, descR, (size_t)nR * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dr2l, r2l, (size_t)nR * 4, hipMemcpyHostToDevice, c->stream));
+    if (occR) HIPCHK(hipMemcpyAsync(doR, occR, (size_t)nR, hipMemcpyHostToDevice, c->stream));
+  }
+  // (the fisheye branch has no mvuRight gate: a plane of -1 switches it off in the shared candidate kernel)
+  LAUNCH(c, "k_fill_f32", k_fill_f32, dim3((ncM + 255) / 256), dim3(256), 0, du, ncM, -1.0f);
+  const int limit = (nnratio > 0.4f) ? std::min(255, (int)(100.0f / nnratio) + 2) : 255;
+  LAUNCH(c, "k_proj_candidates", k_proj_candidates, dim3(nq), dim3(64), 0, dqL, dqd, nq, dkL, ddL, du, nL, minX, maxX, minY, maxY, 0, limit,
+         dkeysL, dccL);
+  LAUNCH(c, "k_proj_candidates", k_proj_candidates, dim3(nq), dim3(64), 0, dqR, dqd, nq, dkR, ddR, du, nR, minX, maxX, minY, maxY, 0, limit,
+         dkeysR, dccR);
+  LAUNCH(c, "k_proj_assign_fisheye", k_proj_assign_fisheye, dim3(1), dim3(64), (size_t)(nL + nR) * 4, dqL, dqR, dqd, nq, dkL, ddL,
+         (occL && nL > 0) ? (const uint8_t*)doL : (const uint8_t*)nullptr, dl2r, nL, dkR, ddR,
+         (occR && nR > 0) ? (const uint8_t*)doR : (const uint8_t*)nullptr, dr2l, nR, du, minX, maxX, minY, maxY, nnratio, dkeysL, dccL,
+         dkeysR, dccR, dmpL, dmpR, dcnt);
+  int cnt = 0;
+  if (nL > 0) HIPCHK(hipMemcpyAsync(mpL, dmpL, (size_t)nL * 4, hipMemcpyDeviceToHost, c->stream));
+  if (nR > 0) HIPCHK(hipMemcpyAsync(mpR, dmpR, (size_t)nR * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(&cnt, dcnt, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (nmatches) *nmatches = cnt;
+  return PLI_OK;
+}
+
 // ---- frame-to-frame track matching of a batch (match_kernels.hip: k_track_*) ------------------------
 static void trackLayout(const pli_ctx* c, pli_track_layout& L) {
   int64_t o = 0;

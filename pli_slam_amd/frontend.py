@@ -231,6 +231,26 @@ class Frontend:
                                           C.byref(n)))
         return n.value, best
 
+    def search_local_map_fisheye(self, q_left, q_right, qdesc, kp_left, desc_left, left_to_right, kp_right, desc_right,
+                                 right_to_left, bounds, nnratio=0.8, occ_left=None, occ_right=None):
+        """ORBmatcher::SearchByProjection(F, vpMapPoints, th) for two fisheye cameras, ORBmatcher.cc:44-214 — see
+        pli_search_local_map_fisheye.  Returns (nmatches, mp_left, mp_right)."""
+        ql = np.ascontiguousarray(q_left, PROJ_QUERY_DT)
+        qr = np.ascontiguousarray(q_right, PROJ_QUERY_DT)
+        qd = np.ascontiguousarray(qdesc, np.uint8)
+        kl, kr = np.ascontiguousarray(kp_left, KEYPOINT_DT), np.ascontiguousarray(kp_right, KEYPOINT_DT)
+        dl, dr = np.ascontiguousarray(desc_left, np.uint8), np.ascontiguousarray(desc_right, np.uint8)
+        l2r, r2l = np.ascontiguousarray(left_to_right, np.int32), np.ascontiguousarray(right_to_left, np.int32)
+        ol = None if occ_left is None else np.ascontiguousarray(occ_left, np.uint8)
+        orr = None if occ_right is None else np.ascontiguousarray(occ_right, np.uint8)
+        mpl = np.full(kl.shape[0], -1, np.int32)
+        mpr = np.full(kr.shape[0], -1, np.int32)
+        n = C.c_int32()
+        check(self.L.pli_search_local_map_fisheye(self.h, ptr(ql), ptr(qr), ptr(qd), ql.shape[0], ptr(kl), ptr(dl), ptr(ol), ptr(l2r),
+                                                  kl.shape[0], ptr(kr), ptr(dr), ptr(orr), ptr(r2l), kr.shape[0], bounds[0], bounds[1],
+                                                  bounds[2], bounds[3], nnratio, ptr(mpl), ptr(mpr), C.byref(n)))
+        return n.value, mpl, mpr
+
     def match_nnr(self, desc1, desc2, nnr):
         """match(vpLocalMapLines, CurrentFrame, nnr, matches_12) LineMatcher.cpp:161 (one-way matchNNR)."""
         d1, d2 = np.ascontiguousarray(desc1, np.uint8), np.ascontiguousarray(desc2, np.uint8)

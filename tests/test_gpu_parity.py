@@ -349,6 +349,66 @@ def test_projection_searches_dense_windows(gpu, ncur, nq):
     assert on > nq // 20
 
 
+@pytest.mark.parametrize("nl,nr,nq", [(1500, 1400, 900), (300, 5000, 2500), (0, 40, 30)])
+def test_local_map_search_two_fisheye_cameras(gpu, nl, nr, nq):
+    """ORBmatcher::SearchByProjection(F, vpMapPoints, th) with F.Nleft != -1 (ORBmatcher.cc:44-214) on random tables: both
+    cameras, stereo partners both ways, slots taken before the call, windows with more candidates than the candidate list
+    keeps, map points seen by one camera only."""
+    g = gpu
+    fe = g.Frontend(g.capi.default_config(128, 128))
+    rng = np.random.default_rng(nl + 7 * nr)
+
+    def table(n):
+        kp = np.zeros(n, g.capi.KEYPOINT_DT)
+        kp["x"] = rng.uniform(0, 640, n).astype(np.float32); kp["y"] = rng.uniform(0, 480, n).astype(np.float32)
+        kp["octave"] = rng.integers(0, 8, n)
+        d = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        if n:
+            d[:, 8:] = 0x5A                                              # close descriptors: most candidates pass the limit
+        return kp, d
+    kpl, dl = table(nl)
+    kpr, dr = table(nr)
+    l2r = np.full(nl, -1, np.int32); r2l = np.full(nr, -1, np.int32)
+    npair = min(nl, nr) // 3
+    if npair:
+        a = rng.choice(nl, npair, replace=False); b = rng.choice(nr, npair, replace=False)
+        l2r[a] = b; r2l[b] = a
+    occl = (rng.random(nl) < 0.2).astype(np.uint8); occr = (rng.random(nr) < 0.2).astype(np.uint8)
+
+    def queries(kp, n):
+        q = np.zeros(nq, g.capi.PROJ_QUERY_DT)
+        if n == 0:
+            q["u"] = rng.uniform(0, 640, nq); q["v"] = rng.uniform(0, 480, nq); q["radius"] = 10; q["valid"] = 1
+            return q, None
+        src = rng.integers(0, n, nq)
+        q["u"] = kp["x"][src] + rng.uniform(-4, 4, nq).astype(np.float32); q["v"] = kp["y"][src] + rng.uniform(-4, 4, nq).astype(np.float32)
+        q["radius"] = np.where(rng.random(nq) < 0.6, rng.uniform(5, 30, nq), rng.uniform(60, 200, nq)).astype(np.float32)
+        q["min_level"] = rng.integers(-1, 3, nq); q["max_level"] = np.where(rng.random(nq) < 0.3, -1, q["min_level"] + rng.integers(0, 6, nq))
+        q["valid"] = rng.random(nq) < 0.8
+        return q, src
+    ql, srcl = queries(kpl, nl)
+    qr, srcr = queries(kpr, nr)
+    qd = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    qd[:, 8:] = 0x5A
+    if srcr is not None:
+        qd[:, :8] = dr[srcr][:, :8]
+    qd[:, :2] ^= rng.integers(0, 256, (nq, 2), dtype=np.uint8)
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    for nnratio in (0.8, 0.3):
+        for ol, orr in ((occl, occr), (None, None)):
+            n, mpl, mpr = fe.search_local_map_fisheye(ql, qr, qd, kpl, dl, l2r, kpr, dr, r2l, bounds, nnratio, ol, orr)
+            on, ompl, ompr = g.po.search_local_map_fisheye(ql, qr, qd, kpl, dl, ol, l2r, kpr, dr, orr, r2l, bounds, nnratio)
+            assert n == on and np.array_equal(mpl, ompl) and np.array_equal(mpr, ompr)
+    assert on > nq // 20
+    # nothing to search, and partner indices out of range
+    n, mpl, mpr = fe.search_local_map_fisheye(ql[:0], qr[:0], qd[:0], kpl, dl, l2r, kpr, dr, r2l, bounds)
+    assert n == 0 and (mpl == -1).all() and (mpr == -1).all()
+    if nr:
+        bad = r2l.copy(); bad[0] = nl
+        with pytest.raises(g.capi.PliError):
+            fe.search_local_map_fisheye(ql, qr, qd, kpl, dl, l2r, kpr, dr, bad, bounds)
+
+
 # ---------------------------------------------------------------------------------------------
 # matchers on engineered descriptor tables (ties, empties)
 # ---------------------------------------------------------------------------------------------

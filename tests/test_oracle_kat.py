@@ -424,3 +424,35 @@ def test_lapping_order_hand_case(oracle):
     assert mono == 3 and order.tolist() == [0, 2, 5, 4, 3, 1]
     order, mono = oracle.lapping_order(kp, 0, 0)                      # the rectified pipeline: nothing in [0, 0]
     assert mono == 6 and order.tolist() == [0, 1, 2, 3, 4, 5]
+
+
+def test_search_local_map_fisheye_partners_and_order(oracle):
+    """ORBmatcher.cc:44-214 with F.Nleft != -1, by hand: a left match is also written to the keypoint's right partner, a left
+    ratio failure leaves the map point before its right camera is searched, a slot written through a partner is taken for
+    the map points that follow, and the partner's slot is overwritten even when it was taken."""
+    KP, Q = oracle.KEYPOINT_DT, oracle.PROJ_QUERY_DT
+    b = (0, 752, 0, 480)
+    kpl = np.zeros(3, KP); kpl["x"] = [100.0, 103.0, 300.0]; kpl["y"] = 100.0; kpl["octave"] = 1
+    kpr = np.zeros(2, KP); kpr["x"] = [200.0, 400.0]; kpr["y"] = 100.0; kpr["octave"] = 1
+    dl = np.zeros((3, 32), np.uint8); dl[0, 0] = 0b1111; dl[1, 0] = 0b11111; dl[2, :] = 255
+    dr = np.zeros((2, 32), np.uint8); dr[1, 0] = 0b1
+    l2r = np.array([0, -1, -1], np.int32); r2l = np.array([0, -1], np.int32)
+
+    def query(u, v, valid=1):
+        q = np.zeros(1, Q); q["u"] = u; q["v"] = v; q["radius"] = 7.0; q["min_level"] = 0; q["max_level"] = 1; q["valid"] = valid
+        return q
+    qd = np.zeros((1, 32), np.uint8)
+    # left: 4 <= 0.8*5 -> keypoint 0 and its partner right 0; right camera: right 0 is taken now, nothing else near (200,100)
+    n, mpl, mpr = oracle.search_local_map_fisheye(query(101, 100), query(200, 100), qd, kpl, dl, None, l2r, kpr, dr, None, r2l, b, 0.8)
+    assert n == 2 and mpl.tolist() == [0, -1, -1] and mpr.tolist() == [0, -1]
+    # ratio 0.7: the left test fails (4 > 0.7*5, same level) and the map point is left: its right camera is not searched
+    n, mpl, mpr = oracle.search_local_map_fisheye(query(101, 100), query(200, 100), qd, kpl, dl, None, l2r, kpr, dr, None, r2l, b, 0.7)
+    assert n == 0 and (mpl == -1).all() and (mpr == -1).all()
+    # not in view on the left: the right camera takes right 0 and writes its partner left 0 — although left 0 was taken
+    n, mpl, mpr = oracle.search_local_map_fisheye(query(101, 100, 0), query(200, 100), qd, kpl, dl, np.array([1, 0, 0], np.uint8), l2r,
+                                                  kpr, dr, None, r2l, b, 0.8)
+    assert n == 2 and mpl.tolist() == [0, -1, -1] and mpr.tolist() == [0, -1]
+    # two map points: the first takes left 0 (+ right 0); the second, same place, finds left 1 only (5 <= 100, second best gone)
+    q2l = np.concatenate([query(101, 100), query(101, 100)]); q2r = np.concatenate([query(200, 100, 0), query(200, 100)])
+    n, mpl, mpr = oracle.search_local_map_fisheye(q2l, q2r, np.zeros((2, 32), np.uint8), kpl, dl, None, l2r, kpr, dr, None, r2l, b, 0.8)
+    assert n == 3 and mpl.tolist() == [0, 1, -1] and mpr.tolist() == [0, -1]
