@@ -38,8 +38,10 @@ inline int cvFloorf(float v) { int i = (int)v; return i - (i > v); }
 // stereo frames/s: 256 frames 3908 (tile), 768 frames ~4200 (tile) vs 3474 (sequential), 1024 frames 4211 vs 4177,
 // 2048 frames 6057 (sequential).
 constexpr int RX_AUTO_IMAGES = 2048;     // images (2 per stereo frame): measured crossover of the tile relaxation and the sequential waves (1024 frames)
-// tiles of 32 for a handful of images (more waves: a single stereo pair takes 4.6 instead of 7.3 ms), 64 otherwise
-constexpr int TX_SMALL_TILE_IMAGES = 16;
+// tiles of 32 for contexts of up to 32 frames (four times the waves where 64-pixel tiles leave the chip under-occupied: a
+// single stereo pair takes 4.6 instead of 7.3 ms with the round-1 code; now, frames/s with 32 vs 64: 16 frames 2228 vs 2066,
+// 32 frames 2930 vs 2777; from 64 frames on the extra border conflicts cost more: 3343 vs 3445, 128 frames 3568 vs 3782)
+constexpr int TX_SMALL_TILE_IMAGES = 64;
 
 struct ProfEntry { const char* name; hipEvent_t a, b; };
 
