@@ -1114,16 +1114,15 @@ pli_status pli_batch_run(pli_ctx* c, int32_t nframes, const uint8_t* dl, const u
   pli_status st;
   const int nimg = 2 * nframes;
   if ((st = runIngest(c, dl, dr, stride, frameStride, 0, nimg)) != PLI_OK) return st;
-  // The ORB chain runs beside the line chain where the line chain leaves the chip room: small batches (both chains are
-  // launch / latency bound), and the sequential grower's one wave per image up to 2560 images (measured, 752x480: 1024 frames
-  // 4213 -> 4544 frames/s, 1280 frames 4830 -> 5266; from 1536 frames on the grower's blocks fill the CUs' LDS, the ORB
-  // kernels wait for it and stretch the grower: 5170 -> 4287, 2048 frames 6067 -> 4942).  The tile relaxation in between
-  // saturates the issue slots by itself (256 frames: no gain).
-  static const int sideMax = getenv("PLI_SIDE_MAX") ? atoi(getenv("PLI_SIDE_MAX")) : 256;      // (dev: images below which the ORB chain runs beside the line chain)
+  // The ORB chain runs beside the line chain (fork after the ingest, join before the stereo matchers) except under the
+  // sequential grower above 2560 images.  Measured, 752x480, frames/s without -> with: tile relaxation 32 frames 2688 -> 2847,
+  // 128 frames 3711 -> 3947, 256 frames 4054 -> 4245, 512 frames 4268 -> 4379, 768 frames 4303 -> 4420; sequential grower
+  // 1024 frames 4213 -> 4544, 1280 frames 4830 -> 5266; from 1536 frames on the grower's blocks fill the CUs' LDS, the ORB
+  // kernels wait for it and stretch the grower: 5170 -> 4287, 2048 frames 6067 -> 4942.
+  static const int sideMax = getenv("PLI_SIDE_MAX") ? atoi(getenv("PLI_SIDE_MAX")) : INT_MAX;    // (dev: images below which the tile relaxation has the ORB chain beside it)
   static const int sideSeqMax = getenv("PLI_SIDE_SEQ_MAX") ? atoi(getenv("PLI_SIDE_SEQ_MAX")) : 2560;
   const bool seqGrower = c->lsdMode == 2 || (c->lsdMode == 0 && nimg >= RX_AUTO_IMAGES);
-  if ((nimg < sideMax || (seqGrower && nimg >= 1024 && nimg <= sideSeqMax)) && (stages & PLI_RUN_ORB) && (stages & PLI_RUN_LINES) &&
-      !c->syncDebug) {
+  if ((seqGrower ? nimg <= sideSeqMax : nimg < sideMax) && (stages & PLI_RUN_ORB) && (stages & PLI_RUN_LINES) && !c->syncDebug) {
     if (!c->aux) {
       // (the line chain is the longer one: the ORB chain beside it takes what the line kernels leave free)
       int prLow = 0, prHigh = 0;
