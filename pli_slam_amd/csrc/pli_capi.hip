@@ -38,10 +38,11 @@ inline int cvFloorf(float v) { int i = (int)v; return i - (i > v); }
 // stereo frames/s: 256 frames 3908 (tile), 768 frames ~4200 (tile) vs 3474 (sequential), 1024 frames 4211 vs 4177,
 // 2048 frames 6057 (sequential).
 constexpr int RX_AUTO_IMAGES = 2048;     // images (2 per stereo frame): measured crossover of the tile relaxation and the sequential waves (1024 frames)
-// tiles of 32 for contexts of up to 32 frames (four times the waves where 64-pixel tiles leave the chip under-occupied: a
+// tiles of 32 for contexts of up to 32 frames of 752x480 (four times the waves where 64-pixel tiles leave the chip under-occupied: a
 // single stereo pair takes 4.6 instead of 7.3 ms with the round-1 code; now, frames/s with 32 vs 64: 16 frames 2228 vs 2066,
 // 32 frames 2930 vs 2777; from 64 frames on the extra border conflicts cost more: 3343 vs 3445, 128 frames 3568 vs 3782)
-constexpr int TX_SMALL_TILE_IMAGES = 64;
+// — in tile waves: 32 frames of 752x480 are 64 x 135 = 8640 waves of 64-pixel tiles, about what the chip holds at once (7168)
+constexpr int TX_SMALL_TILE_WAVES = 12000;
 
 struct ProfEntry { const char* name; hipEvent_t a, b; };
 
@@ -548,7 +549,8 @@ pli_status allocAll(pli_ctx* c) {
     c->arenaCap = (int)std::min<size_t>((lane ? 8 : 3) * npix + 65536, (size_t)1 << 30);
     A(c->arena, (size_t)c->arenaCap * NR);
     if (tiles) {
-      c->txTs = NI <= TX_SMALL_TILE_IMAGES ? 32 : 64;
+      // (the measure is the number of 64-pixel tile waves the context can put on the chip, not the number of images)
+      c->txTs = (int64_t)NI * ((P.LW + 63) / 64) * ((P.LH + 63) / 64) <= TX_SMALL_TILE_WAVES ? 32 : 64;
       if (const char* e = getenv("PLI_TX_TS")) c->txTs = atoi(e) == 32 ? 32 : atoi(e) == 128 ? 128 : 64;
       c->txNtx = (P.LW + c->txTs - 1) / c->txTs; c->txNty = (P.LH + c->txTs - 1) / c->txTs;
       A(c->txList, (size_t)c->txNtx * c->txNty * c->txTs * c->txTs * NR);
