@@ -1116,6 +1116,7 @@ pli_status pli_batch_run(pli_ctx* c, int32_t nframes, const uint8_t* dl, const u
   pli_status st;
   const int nimg = 2 * nframes;
   if ((st = runIngest(c, dl, dr, stride, frameStride, 0, nimg)) != PLI_OK) return st;
+  bool stereoPointsDone = false;
   // The ORB chain runs beside the line chain (fork after the ingest, join before the stereo matchers) except under the
   // sequential grower above 2560 images.  Measured, 752x480, frames/s without -> with: tile relaxation 32 frames 2688 -> 2847,
   // 128 frames 3711 -> 3947, 256 frames 4054 -> 4245, 512 frames 4268 -> 4379, 768 frames 4303 -> 4420; sequential grower
@@ -1139,6 +1140,9 @@ pli_status pli_batch_run(pli_ctx* c, int32_t nframes, const uint8_t* dl, const u
     HIPCHK(hipStreamWaitEvent(c->aux, c->evFork, 0));
     c->stream = c->aux;
     st = runOrb(c, 0, nimg, T);
+    // (the stereo point matcher needs the ORB tables only: it stays on the side stream, off the line chain's path)
+    static const bool sideStereo = getenv("PLI_SIDE_NOSTEREO") == nullptr;      // (dev switch)
+    if (st == PLI_OK && (stages & PLI_RUN_STEREO_POINTS) && sideStereo) { st = runStereoPoints(c, nframes, T); stereoPointsDone = true; }
     c->stream = main;
     if (st != PLI_OK) return st;
     HIPCHK(hipEventRecord(c->evJoin, c->aux));
@@ -1149,7 +1153,7 @@ pli_status pli_batch_run(pli_ctx* c, int32_t nframes, const uint8_t* dl, const u
     if (stages & PLI_RUN_LINES) if ((st = runLines(c, 0, nimg, T)) != PLI_OK) return st;
   }
   if (stages & PLI_RUN_STEREO_LINES) if ((st = runStereoLines(c, nframes, T)) != PLI_OK) return st;
-  if (stages & PLI_RUN_STEREO_POINTS) if ((st = runStereoPoints(c, nframes, T)) != PLI_OK) return st;
+  if ((stages & PLI_RUN_STEREO_POINTS) && !stereoPointsDone) if ((st = runStereoPoints(c, nframes, T)) != PLI_OK) return st;
   return PLI_OK;
 }
 
