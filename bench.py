@@ -274,6 +274,7 @@ def main():
     ap.add_argument("--unique-frames", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true")
+    ap.add_argument("--no-large-batch-leg", action="store_true")
     ap.add_argument("--lsd-mode", type=int, default=0, help="0 auto, 1 relaxation, 2 sequential waves, 3 tile-sequential relaxation")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--dry-tables", action="store_true", help="CPU exercise of sharding + gather (needs --backend gloo)")
@@ -501,11 +502,44 @@ def main():
             if not out["parity"]["ok"]:
                 out["value"] = None                   # a fast path whose results differ from the reference's is not a result
                 rc = 3
+            if not args.no_large_batch_leg and not args.config and (W, H) == (752, 480) and F < LARGE_BATCH:
+                # the same path at the batch size where the throughput of one GPU levels off (the sequential LSD schedule takes
+                # over above 1024 frames per call; 158 GB of the 288 GB HBM): informational, never the headline value
+                try:
+                    del fe
+                    out["large_batch"] = large_batch_leg(capi, Frontend, nfeat, nlines, args.lsd_mode, local_rank, d_uniq, nuniq, W, H)
+                except Exception as e:                # (the headline line must not depend on this leg)
+                    out["large_batch"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     sys.exit(rc)
+
+
+LARGE_BATCH = 2048
+
+
+def large_batch_leg(capi, Frontend, nfeat, nlines, lsd_mode, device, d_uniq, nuniq, W, H, steps=3):
+    """One GPU, LARGE_BATCH stereo frames per step (images resident in HBM, cycled from the same distinct pairs)."""
+    import torch
+    dev = d_uniq.device
+    F = LARGE_BATCH
+    fe = Frontend(capi.default_config(W, H, orb_nfeatures=nfeat, lsd_nfeatures=nlines, max_frames=F, lsd_mode=lsd_mode), device=device)
+    fe.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_img = d_uniq[torch.arange(F, device=dev) % nuniq].contiguous()
+    d_left, d_right = d_img[:, 0].contiguous(), d_img[:, 1].contiguous()
+    del d_img
+    table = torch.zeros(F * int(fe.layout.record_bytes), dtype=torch.uint8, device=dev)
+    fe.batch_run_device(F, d_left.data_ptr(), d_right.data_ptr(), W, W * H, table.data_ptr())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fe.batch_run_device(F, d_left.data_ptr(), d_right.data_ptr(), W, W * H, table.data_ptr())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"frames_per_gpu": F, "value": F * steps / dt, "unit": "stereo frames/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "note": "same path and shapes, %d stereo frames per step on one GPU (sequential LSD schedule)" % F}
 
 
 def host_inclusive_leg(fe, images, F, nuniq, W, H, rec_bytes, steps):
