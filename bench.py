@@ -102,6 +102,7 @@ def kernel_bytes_per_image(name, g, n_kp, n_l, W, H):
         "k_rx_mark": 12 * Pp,
         "k_tx_diff2": 8 * Pp,
         "k_tx_round2": 20 * Pp,
+        "k_tx_diffmark": 12 * Pp,
         "k_rx_guess": 8 * Pp + 8 * Pp,
         "k_rx_rect": 0,
         "k_rx_count": 0,

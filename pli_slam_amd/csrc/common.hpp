@@ -75,7 +75,8 @@ struct alignas(128) RxCtl {
   int overflow;    // a capacity was exhausted (code): the image falls back to the sequential grower
   int rounds;      // round in which the fixed point was detected
   int nSmall, nBig;   // work lists of this round: lane grower, wave grower
-  int pad0[26];
+  int changedOdd;     // (tile relaxation, fused diff + mark: the flag of the odd rounds; `changed` serves the even ones)
+  int pad0[25];
   int nHand;       // regions handed from the lane grower to the wave grower in this round
   int pad1[31];
   int nextBig;     // work counter of the wave grower

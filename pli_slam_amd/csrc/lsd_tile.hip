@@ -267,12 +267,13 @@ __global__ __launch_bounds__(256) void k_tx_round2(RxCtl* __restrict__ ctl, int2
                                                    const int* __restrict__ rankAll, const int* __restrict__ orderAll,
                                                    const int2* __restrict__ rgBoxAll, int* __restrict__ rgDirtyAll,
                                                    int* __restrict__ tileActAll, int W, int H, int TW, int TH, int t, int img0,
-                                                   const int* __restrict__ rgLostAll, TxDirtyLists DL) {
+                                                   const int* __restrict__ rgLostAll, TxDirtyLists DL,
+                                                   int* __restrict__ tileTouchAll) {
   const int img = blockIdx.z + img0;
   RxCtl& c = ctl[img];
   if (c.state == 2) return;
   const int tid = threadIdx.x;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { c.nSmall = 0; c.nBig = 0; c.nHand = 0; c.nextBig = 0; c.rectArena = 0ull; c.changed = 0; }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { c.nSmall = 0; c.nBig = 0; c.nHand = 0; c.nextBig = 0; c.rectArena = 0ull; c.changed = 0; c.changedOdd = 0; }
   const int64_t base = (int64_t)img * W * H;
   const int ci = t & 1;
   const int x = blockIdx.x * 32 + (tid & 31);
@@ -312,6 +313,8 @@ __global__ __launch_bounds__(256) void k_tx_round2(RxCtl* __restrict__ ctl, int2
     const bool dead = sp[i] != p && (ci ? so[i].x : so[i].y) != o[i];
     const bool dirty = dead || lost[i] != 0;
     if (dirty) tx_mark_dirty(o[i], t, rgDirtyAll + base, rgBoxAll + base, tileActAll + (int64_t)img * TW * TH, TW, TH, DL, img);
+    // (a pixel that falls back to its own rank makes its cell differ between owner_1 and owner_2: noted for round 3's diff)
+    if (dirty && tileTouchAll) tileTouchAll[(int64_t)img * TW * TH + (y >> 3) * TW + (x >> 3)] = t;
     const int cur = dirty ? r[i] : o[i];
     if (cur != (ci ? ow[i].y : ow[i].x)) {
       if (ci) ow[i].y = cur; else ow[i].x = cur;
@@ -394,6 +397,86 @@ __global__ __launch_bounds__(256) void k_tx_mark(RxCtl* __restrict__ ctl, const 
 }
 
 // ---------------------------------------------------------------------------
+// k_tx_diffmark (rounds >= 3): k_rx_diff and k_tx_mark in one pass.  The cells whose two owner components can differ are the
+// ones tileTouch stamps with t-1 — the growers' claims of round t-1 and the cells k_tx_prep rewrote in round t-1 (it stamps
+// them too in this mode) — so a block reads its touched cells once, lists their changed pixels and goes on to the rule.
+// "Nothing changed anywhere" is known only when the kernel ends: the round's k_tx_prep tests the flag (one flag per round
+// parity: it clears the other one for the next round) and declares the fixed point.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tx_diffmark(RxCtl* __restrict__ ctl, const int2* __restrict__ ownAll,
+                                                     const int* __restrict__ rankAll, const int2* __restrict__ rgBoxAll,
+                                                     int* __restrict__ rgDirtyAll, int* __restrict__ tileActAll,
+                                                     const int* __restrict__ tileTouchAll, int W, int H, int TW, int TH, int t,
+                                                     int img0, const int* __restrict__ rgLostAll, TxDirtyLists DL) {
+  __shared__ int s_rel[8][4];
+  __shared__ int s_chg[8][4];
+  __shared__ int s_n;
+  __shared__ unsigned short lst[2048];
+  const int img = blockIdx.z + img0;
+  RxCtl& c = ctl[img];
+  if (c.state == 2) return;
+  const int tid = threadIdx.x;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { c.nSmall = 0; c.nBig = 0; c.nHand = 0; c.nextBig = 0; c.rectArena = 0ull; }
+  if (tid == 0) s_n = 0;
+  if (tid < 32) {
+    const int ty = (int)blockIdx.y * 8 + (tid >> 2), tx = (int)blockIdx.x * 4 + (tid & 3);
+    s_rel[tid >> 2][tid & 3] = (ty < TH && tx < TW) ? tileTouchAll[(int64_t)img * TW * TH + ty * TW + tx] == t - 1 : 0;
+    s_chg[tid >> 2][tid & 3] = 0;
+  }
+  __syncthreads();
+  const int64_t base = (int64_t)img * W * H;
+  const int lx = tid & 31, ly = tid >> 5;
+  const int x = blockIdx.x * 32 + lx;
+  int2 o[8];
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr) {
+    const int y = (blockIdx.y * 8 + rr) * 8 + ly;
+    o[rr] = make_int2(0, 0);
+    if (s_rel[rr][lx >> 3] && x < W && y < H) o[rr] = ownAll[base + y * W + x];
+  }
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr)
+    if (o[rr].x != o[rr].y) {
+      lst[atomicAdd(&s_n, 1)] = (unsigned short)(((rr * 8 + ly) << 5) | lx);
+      s_chg[rr][lx >> 3] = 1;                           // (benign race: every writer stores 1)
+    }
+  __syncthreads();
+  const int n = s_n;
+  if (n == 0) return;
+  int* tileAct = tileActAll + (int64_t)img * TW * TH;
+  if (tid < 32 && s_chg[tid >> 2][tid & 3]) {
+    const int ty = (int)blockIdx.y * 8 + (tid >> 2), tx = (int)blockIdx.x * 4 + (tid & 3);
+    tileAct[ty * TW + tx] = t;                          // a changed cell is active
+  }
+  if (tid == 0) atomicOr((t & 1) ? &c.changedOdd : &c.changed, 1);
+  int* rgDirty = rgDirtyAll + base;
+  const int2* rgBox = rgBoxAll + base;
+  const int ci = t & 1;
+  for (int i = tid; i < n * 9; i += 256) {
+    const int e = (int)(((unsigned)i * 7282u) >> 16);   // i / 9 for i < 2048 * 9
+    const int k = i - 9 * e;
+    const int li = lst[e];
+    const int px0 = blockIdx.x * 32 + (li & 31), py0 = blockIdx.y * 64 + (li >> 5);
+    const int2 oc = ownAll[base + py0 * W + px0];
+    const int prevv = ci ? oc.x : oc.y, prev2 = ci ? oc.y : oc.x;
+    if (k == 4) {
+      const int r = rankAll[base + py0 * W + px0];
+      if (r == TX_INF) continue;
+      const bool a1 = prevv == r, a2 = prev2 == r;
+      if (a1 != a2) tx_mark_dirty(r, t, rgDirty, rgBox, tileAct, TW, TH, DL, img, a2);
+    } else {
+      const int px = px0 + k % 3 - 1, py = py0 + k / 3 - 1;
+      if (px < 0 || py < 0 || px >= W || py >= H) continue;
+      const int2 op2 = ownAll[base + py * W + px];
+      const int op = ci ? op2.x : op2.y;               // owner_{t-1} of the neighbour
+      if (op == INT_MAX) continue;
+      if ((prev2 < op && prevv > op) || (prev2 == op && prevv < op) || rgLostAll[base + op] == t - 1)
+        tx_mark_dirty(op, t, rgDirty, rgBox, tileAct, TW, TH, DL, img);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // k_tx_prep (rounds >= 2, after the diff and k_rx_mark): owner_t is rewritten in the active 8x8 cells only:
 // a pixel whose previous owner is carried (not stamped dirty) stays with it, any other falls back to its own
 // rank.  Elsewhere owner_{t-2} == owner_{t-1} and the owner is carried: the word that is there is right.
@@ -403,14 +486,21 @@ __global__ __launch_bounds__(256) void k_tx_mark(RxCtl* __restrict__ ctl, const 
 __global__ __launch_bounds__(256) void k_tx_prep(RxCtl* __restrict__ ctl, int2* __restrict__ ownAll,
                                                  const int* __restrict__ rankAll, const int* __restrict__ rgDirtyAll,
                                                  const int* __restrict__ tileActAll, int W, int H, int TW, int TH, int t, int img0,
-                                                 int full) {
+                                                 int full, int* __restrict__ tileTouchAll) {
   __shared__ int s_act;
   __shared__ int s_cell[4][4];
   const int img = blockIdx.z + img0;
   RxCtl& c = ctl[img];
   if (c.state == 2) return;
   const int tid = threadIdx.x;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) c.changed = 0;
+  if (tileTouchAll) {
+    // after k_tx_diffmark: the round's flag decides (every block reads the same value: nobody writes it in this kernel)
+    if (((t & 1) ? c.changedOdd : c.changed) == 0) {
+      if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { c.state = 2; c.rounds = t; }
+      return;
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { if (t & 1) c.changed = 0; else c.changedOdd = 0; }
+  } else if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) c.changed = 0;
   if (tid == 0) s_act = full;                          // round 2: owner_t still holds the trivial map, every cell is rewritten
   __syncthreads();
   if (tid < 16) {
@@ -418,6 +508,7 @@ __global__ __launch_bounds__(256) void k_tx_prep(RxCtl* __restrict__ ctl, int2* 
     const int a = full || (tx < TW && ty < TH && tileActAll[(int64_t)img * TW * TH + ty * TW + tx] == t);
     s_cell[tid >> 2][tid & 3] = a;
     if (a) s_act = 1;
+    if (a && tileTouchAll && tx < TW && ty < TH) tileTouchAll[(int64_t)img * TW * TH + ty * TW + tx] = t;   // (this cell is rewritten)
   }
   __syncthreads();
   if (!s_act) return;

@@ -819,6 +819,9 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       TxDirtyLists DL{c->txDirtyList, c->txDirtyCnt, c->order, ts, c->txNtx, c->txNty, P.LW, npix64};
       if (getenv("PLI_TX_NODIRTYLIST")) DL.list = nullptr;             // dev: every active tile walks its whole seed list
       TxDirtyLists noDL = DL; noDL.list = nullptr;
+      // rounds >= 3: k_rx_diff + k_tx_mark as one kernel (k_tx_diffmark; the dev rules keep the separate passes)
+      const bool fusedDM = lostRule && !fullRound2 && !getenv("PLI_TX_CELLRULE") && !getenv("PLI_TX_OLDMARK") && !getenv("PLI_TX_FULLDIFF") &&
+                           !getenv("PLI_TX_NOFUSEDM");
       for (int t = 1; t <= maxRounds && !allDone; ++t) {
         curT = t;
         if (t >= 2 && DL.list)
@@ -826,7 +829,10 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
         const bool fused2 = t == 2 && !fullRound2 && lostRule && !getenv("PLI_TX_NOFUSE2");    // (dev switch: the two passes)
         if (fused2)
           TRL(c, "k_tx_round2", k_tx_round2, dim3((P.LW + 31) / 32, (P.LH + 31) / 32, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->order,
-              c->rgBox, c->rgDirty, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, (const int*)c->rgLost, DL);
+              c->rgBox, c->rgDirty, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, (const int*)c->rgLost, DL, c->tileTouch);
+        else if (t >= 3 && fusedDM)
+          TRL(c, "k_tx_diffmark", k_tx_diffmark, dim3((P.LW + 31) / 32, (c->tilesH + 7) / 8, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf,
+              c->rgBox, c->rgDirty, c->tileAct, (const int*)c->tileTouch, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, (const int*)c->rgLost, DL);
         else if (t == 2 && !fullRound2)
           TRL(c, "k_tx_diff2", k_tx_diff2, dim3((P.LW + 31) / 32, c->tilesH, nimg), dim3(256), 0, c->jrCtl, c->own, c->order, c->rgBox,
               c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, ts, t, img0, lostRule ? (const int*)c->rgLost : (const int*)nullptr, DL);
@@ -836,7 +842,9 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
               (t >= 3 && !fullRound2 && !getenv("PLI_TX_FULLDIFF")) ? (const int*)c->tileTouch : (const int*)nullptr);
         if (t >= 3 || (t == 2 && !fullRound2)) {
           // (round 2 under the lost-pixel rule: k_tx_diff2 has stamped the regions itself, k_rx_mark would find nothing)
-          if (lostRule && t >= 3 && !getenv("PLI_TX_CELLRULE") && !getenv("PLI_TX_OLDMARK"))
+          if (t >= 3 && fusedDM) {
+            // (k_tx_diffmark has done it)
+          } else if (lostRule && t >= 3 && !getenv("PLI_TX_CELLRULE") && !getenv("PLI_TX_OLDMARK"))
           TRL(c, "k_rx_mark", k_tx_mark, dim3((P.LW + 31) / 32, (c->tilesH + 7) / 8, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->rgBox,
               c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, (const int*)c->rgLost, DL);
           else if (t >= 3 || !lostRule)
@@ -845,7 +853,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
               (lostRule && t >= 3 && !getenv("PLI_TX_CELLRULE")) ? (const int*)c->rgLost : (const int*)nullptr, DL);
           if (!fused2)
           TRL(c, "k_tx_prep", k_tx_prep, dim3((P.LW + 31) / 32, (P.LH + 31) / 32, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf,
-              c->rgDirty, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, t == 2 ? 1 : 0);
+              c->rgDirty, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, t == 2 ? 1 : 0, fusedDM ? c->tileTouch : (int*)nullptr);
           TRL(c, "k_tx_grow_sparse", k_tx_grow_sparse, dim3(ntile, nimg), dim3(64), txPad, c->dP, c->jrCtl, c->rec, c->own, c->txList,
               c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty, c->tileAct, c->tilesW, c->tilesH, c->arena,
               c->arenaCap, c->rects, c->rectCap, img0, t, (const int*)c->rankOf, lostRule ? c->rgLost : (int*)nullptr, c->tileTouch,

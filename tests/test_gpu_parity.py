@@ -1021,13 +1021,14 @@ def test_sequential_grower_dev_switches(gpu, flags, monkeypatch):
 def test_tile_relaxation_dev_switches(gpu, W, H, monkeypatch):
     """The tile-sequential relaxation with each of its round-2 shortcuts switched off gives the same lines as with them:
     the walk over all seeds instead of the per-tile dirty lists (PLI_TX_NODIRTYLIST), k_tx_diff2 + k_tx_prep instead of the
-    fused round 2 (PLI_TX_NOFUSE2), k_rx_mark instead of k_tx_mark (PLI_TX_OLDMARK), the conservative regrowth rules
+    fused round 2 (PLI_TX_NOFUSE2), k_rx_diff + k_tx_mark instead of k_tx_diffmark (PLI_TX_NOFUSEDM), k_rx_mark instead of k_tx_mark
+    (PLI_TX_OLDMARK), the conservative regrowth rules
     (PLI_TX_BOXRULE, PLI_TX_CELLRULE), every cell compared every round (PLI_TX_FULLDIFF), and the one-block ordered-list scan
     (PLI_LSD_SCAN1; the larger shape has enough chunks for the grouped scan)."""
     g = gpu
     L, R = g.synth.make_stereo_pair(77, W, H)
-    switches = ("PLI_TX_NODIRTYLIST", "PLI_TX_NOFUSE2", "PLI_TX_OLDMARK", "PLI_TX_BOXRULE", "PLI_TX_CELLRULE", "PLI_TX_FULLDIFF",
-                "PLI_LSD_SCAN1")
+    switches = ("PLI_TX_NODIRTYLIST", "PLI_TX_NOFUSE2", "PLI_TX_NOFUSEDM", "PLI_TX_OLDMARK", "PLI_TX_BOXRULE", "PLI_TX_CELLRULE",
+                "PLI_TX_FULLDIFF", "PLI_LSD_SCAN1")
     want = None
     for on in (None,) + switches:
         for k in switches:
