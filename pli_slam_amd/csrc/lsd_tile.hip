@@ -919,7 +919,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
   }
 }
 
-__global__ __launch_bounds__(64) void k_tx_grow(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tx_grow(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
                                                 const float4* __restrict__ recAll, int2* __restrict__ ownAll,
                                                 const int2* __restrict__ listAll, const int* __restrict__ tileCntAll,
                                                 int ts, int ntx, int nty, int* __restrict__ rgSizeAll,
@@ -931,7 +931,7 @@ __global__ __launch_bounds__(64) void k_tx_grow(const DevParams* __restrict__ Pp
   tx_grow_tile<false>(Pp, ctl, recAll, ownAll, listAll, tileCntAll, ts, ntx, nty, rgSizeAll, rgBoxAll, rgDirtyAll, tileActAll,
                       TW, TH, arenaAll, arenaCap, rectAll, rectCap, img0, t, rankAll, rgLostAll, tileTouchAll, DL);
 }
-__global__ __launch_bounds__(64) void k_tx_grow_sparse(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tx_grow_sparse(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
                                                        const float4* __restrict__ recAll, int2* __restrict__ ownAll,
                                                        const int2* __restrict__ listAll, const int* __restrict__ tileCntAll,
                                                        int ts, int ntx, int nty, int* __restrict__ rgSizeAll,
