@@ -58,7 +58,8 @@ struct pli_ctx {
   // side stream: for small batches the ORB chain runs beside the line chain (fork after the ingest, join before the stereo
   // stage); both chains are launch/latency bound there (+4 % on a single pair, +2.5 % at 32 frames, nothing from 256 frames on)
   hipStream_t aux = nullptr;
-  hipEvent_t evFork = nullptr, evJoin = nullptr;
+  hipEvent_t evFork = nullptr, evJoin = nullptr, evLbdPre = nullptr;
+  bool lbdPreOnSide = false;                 // the LBD's blur + Sobel of this call ran on the side stream (pli_batch_run)
   bool syncDebug = getenv("PLI_SYNC_DEBUG") != nullptr;
   int NI = 0;
   pli_table_layout lay;
@@ -662,6 +663,17 @@ pli_status runOrb(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     }                                                                          \
   } while (0)
 
+// BinaryDescriptor::compute's image work (binary_descriptor_custom.cpp:350-398): GaussianBlur 5x5 + Sobel of level 0.  It
+// needs the image only, not the lines: pli_batch_run puts it on the side stream (after the ORB chain) when the LSD front does
+// not use the u8 scratch plane itself (CV_64F detector).
+pli_status runLbdPre(pli_ctx* c, int img0, int nimg) {
+  const DevParams& P = c->hp;
+  LAUNCH(c, "k_blur_lbd", k_blur, dim3(c->l0Tiles, nimg), dim3(256), 0, c->jobLbd, c->pyr, P.pyrBlock, c->tmp8, c->tmp8Stride, img0);
+  dim3 g((P.W + 1023) / 1024, P.H, nimg);
+  LAUNCH(c, "k_sobel", k_sobel, g, dim3(256), 0, c->tmp8, c->tmp8Stride, P.W, P.H, c->tmpPitch, c->dxy, img0);
+  return PLI_OK;
+}
+
 pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   const DevParams& P = c->hp;
   const pli_table_layout& Y = c->lay;
@@ -930,10 +942,11 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   }
   LAUNCH(c, "k_keylines", k_keylines, dim3(nimg), dim3(256), 0, c->dP, c->seg, c->nSeg, c->maxSeg, c->tmpKL, table,
          Y.record_bytes, Y.off_counts, Y.off_kl[0], Y.off_kl[1], img0);
-  LAUNCH(c, "k_blur_lbd", k_blur, dim3(c->l0Tiles, nimg), dim3(256), 0, c->jobLbd, c->pyr, P.pyrBlock, c->tmp8, c->tmp8Stride, img0);
-  {
-    dim3 g((P.W + 1023) / 1024, P.H, nimg);
-    LAUNCH(c, "k_sobel", k_sobel, g, dim3(256), 0, c->tmp8, c->tmp8Stride, P.W, P.H, c->tmpPitch, c->dxy, img0);
+  if (c->lbdPreOnSide) {
+    HIPCHK(hipStreamWaitEvent(c->stream, c->evLbdPre, 0));   // (the blur + Sobel of the LBD ran on the side stream, see pli_batch_run)
+  } else {
+    pli_status ls = runLbdPre(c, img0, nimg);
+    if (ls != PLI_OK) return ls;
   }
   LAUNCH(c, "k_lbd", k_lbd, dim3(P.klCap, nimg), dim3(64), 0, c->dP, c->lbdCoef, c->dxy, table, Y.record_bytes,
          Y.off_counts, Y.off_kl[0], Y.off_kl[1], Y.off_ldesc[0], Y.off_ldesc[1], c->debug ? c->lbdFloat : (float*)nullptr, img0);
@@ -1059,7 +1072,7 @@ void pli_ctx_destroy(pli_ctx* c) {
   if (c->scratch) hipFree(c->scratch);
   for (hipEvent_t e : c->evPool) hipEventDestroy(e);
   if (c->ownStream && c->stream) hipStreamDestroy(c->stream);
-  if (c->aux) { hipStreamSynchronize(c->aux); hipStreamDestroy(c->aux); hipEventDestroy(c->evFork); hipEventDestroy(c->evJoin); }
+  if (c->aux) { hipStreamSynchronize(c->aux); hipStreamDestroy(c->aux); hipEventDestroy(c->evFork); hipEventDestroy(c->evJoin); hipEventDestroy(c->evLbdPre); }
   for (int e = 0; e < 2; ++e) if (c->rectMap[e]) hipFree(c->rectMap[e]);
   for (int s = 0; s < 2; ++s) {
     if (c->hs[s].busy) hipEventSynchronize(c->hs[s].d2h);
@@ -1142,6 +1155,7 @@ pli_status pli_batch_run(pli_ctx* c, int32_t nframes, const uint8_t* dl, const u
       HIPCHK(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prLow));
       HIPCHK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&c->evLbdPre, hipEventDisableTiming));
     }
     hipStream_t main = c->stream;
     HIPCHK(hipEventRecord(c->evFork, main));
@@ -1151,10 +1165,17 @@ pli_status pli_batch_run(pli_ctx* c, int32_t nframes, const uint8_t* dl, const u
     // (the stereo point matcher needs the ORB tables only: it stays on the side stream, off the line chain's path)
     static const bool sideStereo = getenv("PLI_SIDE_NOSTEREO") == nullptr;      // (dev switch)
     if (st == PLI_OK && (stages & PLI_RUN_STEREO_POINTS) && sideStereo) { st = runStereoPoints(c, nframes, T); stereoPointsDone = true; }
+    static const bool sideLbd = getenv("PLI_SIDE_NOLBD") == nullptr;            // (dev switch)
+    if (st == PLI_OK && c->lsdF64 && sideLbd) {
+      st = runLbdPre(c, 0, nimg);
+      if (st == PLI_OK) { HIPCHK(hipEventRecord(c->evLbdPre, c->aux)); c->lbdPreOnSide = true; }
+    }
     c->stream = main;
     if (st != PLI_OK) return st;
     HIPCHK(hipEventRecord(c->evJoin, c->aux));
-    if ((st = runLines(c, 0, nimg, T)) != PLI_OK) return st;
+    st = runLines(c, 0, nimg, T);
+    c->lbdPreOnSide = false;
+    if (st != PLI_OK) return st;
     HIPCHK(hipStreamWaitEvent(main, c->evJoin, 0));
   } else {
     if (stages & PLI_RUN_ORB) if ((st = runOrb(c, 0, nimg, T)) != PLI_OK) return st;
