@@ -251,7 +251,11 @@ __global__ __launch_bounds__(256) void k_stereo_lines(const DevParams* __restric
                                                       int64_t offKl1, int64_t offLd0, int64_t offLd1, int64_t offDisp,
                                                       int64_t offLe, unsigned long long* __restrict__ maskAll,
                                                       double* __restrict__ dirAll, short* __restrict__ dmatAll,
-                                                      int* __restrict__ m12All, int* __restrict__ m21All) {
+                                                      int* __restrict__ m12All, int* __restrict__ m21All, int phase) {
+  // phase 0: the whole matcher, one workgroup per frame.  With many lines (4K: 500 x 500 pairs per frame) the pair distances are
+  // the bulk and one workgroup per frame leaves the chip idle: the host then launches phase 1 (tables of the right lines),
+  // phase 2 (the pair distances, gridDim.y workgroups per frame) and phase 3 (the selection) — the phases already talk through
+  // global memory.
   const DevParams& P = *Pp;
   const int frame = blockIdx.x, tid = threadIdx.x;
   uint8_t* rec = table + (int64_t)frame * recordBytes;
@@ -269,18 +273,20 @@ __global__ __launch_bounds__(256) void k_stereo_lines(const DevParams* __restric
   short* dmat = dmatAll + (int64_t)frame * cap * cap;
   int* m12 = m12All + (int64_t)frame * cap;
   int* m21 = m21All + (int64_t)frame * cap;
+  if (phase <= 1)
   for (int i = tid; i < n1; i += 256) {
     disp[2 * i] = -1.f; disp[2 * i + 1] = -1.f;
     le[3 * i] = 0.0; le[3 * i + 1] = 0.0; le[3 * i + 2] = 0.0;
     m12[i] = -1;
   }
   if (n1 == 0 || n2 == 0) {
-    if (tid == 0) counts[5] = 0;
+    if (tid == 0 && phase != 2) counts[5] = 0;
     return;
   }
   const double inv_width = (double)GRID_COLS / (double)P.W;
   const double inv_height = (double)GRID_ROWS / (double)P.H;
   // right lines: direction + Bresenham cell masks (getLineCoords / LineIterator)
+  if (phase <= 1)
   for (int i2 = tid; i2 < n2; i2 += 256) {
     const pli_keyline kl = KR[i2];
     double vx = (double)__fsub_rn(kl.endPointX, kl.startPointX) * inv_width;
@@ -307,11 +313,13 @@ __global__ __launch_bounds__(256) void k_stereo_lines(const DevParams* __restric
       x++;
     }
   }
+  if (phase == 1) return;
   __threadfence_block();
   __syncthreads();
   // pair distances for candidate pairs passing the direction gate, else -1
   const int ws = P.sWs;
-  for (int pidx = tid; pidx < n1 * n2; pidx += 256) {
+  if (phase == 0 || phase == 2)
+  for (int pidx = tid + 256 * (int)blockIdx.y; pidx < n1 * n2; pidx += 256 * (int)gridDim.y) {
     const int i1 = pidx / n2, i2 = pidx - i1 * n2;
     const pli_keyline kl = KL[i1];
     const int sx = (int)((double)kl.startPointX * inv_width), sy = (int)((double)kl.startPointY * inv_height);
@@ -342,6 +350,7 @@ __global__ __launch_bounds__(256) void k_stereo_lines(const DevParams* __restric
     }
     dmat[(int64_t)i1 * cap + i2] = d;
   }
+  if (phase == 2) return;
   __threadfence_block();
   __syncthreads();
   // bestLRMatches: a pair only counts if it lowers the running minimum of its column

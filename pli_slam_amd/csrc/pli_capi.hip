@@ -966,8 +966,13 @@ pli_status runStereoPoints(pli_ctx* c, int nframes, uint8_t* table) {
 
 pli_status runStereoLines(pli_ctx* c, int nframes, uint8_t* table) {
   const pli_table_layout& Y = c->lay;
-  LAUNCH(c, "k_stereo_lines", k_stereo_lines, dim3(nframes), dim3(256), 0, c->dP, table, Y.record_bytes, Y.off_counts,
-         Y.off_kl[0], Y.off_kl[1], Y.off_ldesc[0], Y.off_ldesc[1], Y.off_disp, Y.off_le, c->lmask, c->ldir, c->dmat, c->m12, c->m21);
+  // (many lines per frame: the pair distances by several workgroups per frame, see the kernel)
+  const int cap = c->hp.klCap;
+  const int slices = (cap >= 192 && !getenv("PLI_STEREO_LINES_1")) ? std::max(1, std::min(64, (cap * cap) / 8192)) : 1;
+  for (int phase = slices > 1 ? 1 : 0; phase <= (slices > 1 ? 3 : 0); ++phase)
+    LAUNCH(c, "k_stereo_lines", k_stereo_lines, dim3(nframes, phase == 2 ? slices : 1), dim3(256), 0, c->dP, table, Y.record_bytes,
+           Y.off_counts, Y.off_kl[0], Y.off_kl[1], Y.off_ldesc[0], Y.off_ldesc[1], Y.off_disp, Y.off_le, c->lmask, c->ldir, c->dmat,
+           c->m12, c->m21, phase);
   return PLI_OK;
 }
 
