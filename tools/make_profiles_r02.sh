@@ -50,4 +50,9 @@ if [[ $WHAT == *sq* ]]; then
 fi
 cd $R && timeout 900 python3 bench.py --steps 5 --warmup 1 > $O/bench_default.log 2>&1
 grep '^{"metric"' $O/bench_default.log | tail -1 > $O/bench_default.json
+# the other workloads without the profiler attached (the bench_<name>.json beside the kernel stats are runs under rocprofv3)
+for w in "config5_4k --config 5" "config3_720p --config 3" "f32 --frames-per-gpu 32" "f2048_sequential --frames-per-gpu 2048"; do
+  set -- $w; name=$1; shift
+  timeout 900 python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline "$@" 2>/dev/null | grep '^{"metric"' | tail -1 > $O/bench_${name}_plain.json
+done
 ls -la $O
