@@ -16,11 +16,18 @@
  *     the function returns the produced count.
  *   - "host" pointers are ordinary memory; "dev" pointers are HIP device
  *     memory of the context's device.
- *   - a context owns one HIP stream and all scratch for `max_frames` stereo
- *     frames of `width x height`; calls on one context are serialised by the
- *     caller, different contexts are independent (the reference runs its four
- *     extractors on four threads, Frame.cc:128-135: use one context per thread
- *     or the batch API, which covers both eyes at once).
+ *   - a context owns its HIP streams and all scratch for `max_frames` stereo
+ *     frames of `width x height`.  Every entry point that takes a context is
+ *     THREAD-SAFE: it holds the context's own lock for the whole call, so
+ *     concurrent calls on ONE context are legal and run one after the other
+ *     (the reference drives its four extractors from four std::threads,
+ *     Frame.cc:128-135, and the adapters put the four on one context — the
+ *     stereo matchers need both eyes' tables on the device).  Calls on
+ *     DIFFERENT contexts run concurrently.  What the lock does not order is
+ *     the caller's own protocol: pli_stereo_match_* read the tables of the LAST
+ *     extract calls, so a second Frame must not start extracting on a context
+ *     while the first Frame's stereo matchers have not run yet.
+ *     pli_ctx_destroy must not race with other calls on that context.
  */
 #ifndef PLI_FRONTEND_H
 #define PLI_FRONTEND_H
@@ -244,6 +251,17 @@ pli_status pli_line_extract(pli_ctx* ctx, int32_t eye,
                             const uint8_t* img, int32_t w, int32_t h, int64_t stride,
                             pli_keyline* kl, int32_t cap, uint8_t* desc /* cap x 32 */,
                             int32_t* n);
+
+/* The stereo rig of Frame::ComputeStereoMatches (Frame.cc:1005-1008: minZ = mb, maxD = mbf / minZ, depth = mbf / disparity):
+ * replaces pli_frontend_config.bf / .fx of an existing context (the extractors' constructors, which create the context in
+ * the adapters, do not know the camera; the Frame does: mbf and mK(0,0)).  A no-op when the values are the ones in use. */
+pli_status pli_set_stereo_camera(pli_ctx* ctx, float bf, float fx);
+
+/* Sizes of the tables the context holds from the last per-call extractions: counts[0], [1] = keypoints of eye 0 / 1
+ * (mvKeys.size(), mvKeysRight.size()), counts[2], [3] = keylines of eye 0 / 1 (mvKeys_Line.size(),
+ * mvKeysRight_Line.size()); -1 where that extractor has not run on this context.  The Frame-level stereo matchers of
+ * the adapters check their vectors against these before they read the device tables (Frame.cc:976, :1156). */
+pli_status pli_last_counts(pli_ctx* ctx, int32_t counts[4]);
 
 /* Frame::ComputeStereoMatches() Frame.cc:976-1154 on the tables + pyramids left
  * on the device by the last pli_orb_extract(eye 0) / (eye 1).

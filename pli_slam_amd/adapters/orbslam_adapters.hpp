@@ -57,11 +57,12 @@ struct LineParams {
 };
 
 // One group = the extractors of one Frame constructor: ORB left/right + LSD left/right on one device context per image size.
+// orbMask / lineMask: which eye slots (bit 0 = left, bit 1 = right) are held by a living extractor.
 struct Group {
   bool hasOrb = false, hasLine = false;
   OrbParams orb{};
   LineParams line{};
-  int orbEyes = 0, lineEyes = 0;
+  int orbMask = 0, lineMask = 0;
   std::mutex mu;
   std::map<std::pair<int, int>, std::shared_ptr<pli::Frontend>> ctx;     // by image size
 
@@ -88,32 +89,50 @@ struct Group {
   }
 };
 
+inline int freeEye(int mask) { return (mask & 1) ? 1 : 0; }
+
 struct Registry {
   std::mutex mu;
   std::vector<std::shared_ptr<Group>> groups;
   static Registry& get() { static Registry r; return r; }
-  // the group of the k-th distinct parameter set of its kind; eye = how many extractors of that kind joined it before
+  // the group of the k-th distinct parameter set of its kind; eye = the free slot taken (left first)
   std::shared_ptr<Group> joinOrb(const OrbParams& p, int& eye) {
     std::lock_guard<std::mutex> lk(mu);
     for (auto& g : groups)
-      if (g->hasOrb && g->orb == p && g->orbEyes < 2) { eye = g->orbEyes++; return g; }
+      if (g->hasOrb && g->orb == p && g->orbMask != 3) { eye = freeEye(g->orbMask); g->orbMask |= 1 << eye; return g; }
     for (auto& g : groups)
-      if (!g->hasOrb) { g->hasOrb = true; g->orb = p; eye = g->orbEyes++; return g; }
+      if (!g->hasOrb) { g->hasOrb = true; g->orb = p; eye = 0; g->orbMask = 1; return g; }
     groups.push_back(std::make_shared<Group>());
     auto& g = groups.back();
-    g->hasOrb = true; g->orb = p; eye = g->orbEyes++;
+    g->hasOrb = true; g->orb = p; eye = 0; g->orbMask = 1;
     return g;
   }
   std::shared_ptr<Group> joinLine(const LineParams& p, int& eye) {
     std::lock_guard<std::mutex> lk(mu);
     for (auto& g : groups)
-      if (g->hasLine && g->line == p && g->lineEyes < 2) { eye = g->lineEyes++; return g; }
+      if (g->hasLine && g->line == p && g->lineMask != 3) { eye = freeEye(g->lineMask); g->lineMask |= 1 << eye; return g; }
     for (auto& g : groups)
-      if (!g->hasLine) { g->hasLine = true; g->line = p; eye = g->lineEyes++; return g; }
+      if (!g->hasLine) { g->hasLine = true; g->line = p; eye = 0; g->lineMask = 1; return g; }
     groups.push_back(std::make_shared<Group>());
     auto& g = groups.back();
-    g->hasLine = true; g->line = p; eye = g->lineEyes++;
+    g->hasLine = true; g->line = p; eye = 0; g->lineMask = 1;
     return g;
+  }
+  // an extractor dies (or is re-bound): its eye slot is free again; a kind without extractors forgets its parameters, and a
+  // group without extractors leaves the registry — its device contexts go with the last shared_ptr (a Frame-level matcher
+  // still running on one keeps it alive until it returns).
+  void leave(const std::shared_ptr<Group>& g, bool isOrb, int eye) {
+    if (!g) return;
+    std::lock_guard<std::mutex> lk(mu);
+    if (isOrb) { g->orbMask &= ~(1 << eye); if (!g->orbMask) g->hasOrb = false; }
+    else { g->lineMask &= ~(1 << eye); if (!g->lineMask) g->hasLine = false; }
+    if (!g->orbMask && !g->lineMask)
+      for (size_t i = 0; i < groups.size(); ++i)
+        if (groups[i] == g) { groups.erase(groups.begin() + i); break; }
+  }
+  void adopt(const std::shared_ptr<Group>& g) {
+    std::lock_guard<std::mutex> lk(mu);
+    groups.push_back(g);
   }
   // a context for the stateless matchers (any group will do)
   std::shared_ptr<pli::Frontend> any() {
@@ -132,7 +151,16 @@ inline void checkGray(const cv::Mat& m, const char* who) {
 
 }  // namespace pli_detail
 
+class ORBextractor;
+class Lineextractor;
+// (not in the reference) Explicit pairing instead of the construction-order rule above: the four extractors of a stereo
+// Tracking (Tracking.cc:87-98,743-749) — or the two of a monocular one (right = nullptr) — move onto ONE fresh group /
+// device context.  Call it once after construction when the order or the parameters make the implicit rule ambiguous
+// (e.g. initial extractors built with the same parameters as the main ones).
+inline void pliBind(ORBextractor* orbLeft, ORBextractor* orbRight, Lineextractor* lineLeft, Lineextractor* lineRight);
+
 class ORBextractor {
+  friend void pliBind(ORBextractor*, ORBextractor*, Lineextractor*, Lineextractor*);
  public:
   enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
 
@@ -145,7 +173,9 @@ class ORBextractor {
     for (int i = 0; i < nlevels; i++) { mvInvScaleFactor[i] = 1.0f / mvScaleFactor[i]; mvInvLevelSigma2[i] = 1.0f / mvLevelSigma2[i]; }
     group_ = pli_detail::Registry::get().joinOrb({nfeatures, nlevels, iniThFAST, minThFAST, scaleFactor}, eye_);
   }
-  ~ORBextractor() {}
+  ~ORBextractor() { pli_detail::Registry::get().leave(group_, true, eye_); }
+  ORBextractor(const ORBextractor&) = delete;
+  ORBextractor& operator=(const ORBextractor&) = delete;
 
   // Compute the ORB features and descriptors on an image (mask ignored like the reference; vLappingArea: see below).
   int operator()(cv::InputArray _image, cv::InputArray /*_mask*/, std::vector<cv::KeyPoint>& _keypoints, cv::OutputArray _descriptors,
@@ -216,6 +246,7 @@ typedef cv::line_descriptor::KeyLine PliKeyLine;
 #endif
 
 class Lineextractor {
+  friend void pliBind(ORBextractor*, ORBextractor*, Lineextractor*, Lineextractor*);
  public:
   Lineextractor(int _lsd_nfeatures, double _llength_th, bool _bFLD = false)
       : Lineextractor(_lsd_nfeatures, _llength_th, 0, 0.8, 0.6, 2.0, 22.5, 1.0, 0.7, 1024, _bFLD) {}   // LSDOptions defaults, LineExtractor.cc:31-48
@@ -228,7 +259,9 @@ class Lineextractor {
     group_ = pli_detail::Registry::get().joinLine({lsd_nfeatures, lsd_refine, lsd_n_bins, min_line_length, lsd_scale, lsd_sigma_scale,
                                                    lsd_quant, lsd_ang_th, lsd_log_eps, lsd_density_th, bFLD}, eye_);
   }
-  ~Lineextractor() {}
+  ~Lineextractor() { pli_detail::Registry::get().leave(group_, false, eye_); }
+  Lineextractor(const Lineextractor&) = delete;
+  Lineextractor& operator=(const Lineextractor&) = delete;
 
   void operator()(const cv::Mat& image, const cv::Mat& /*mask*/, std::vector<PliKeyLine>& keylines, cv::Mat& descriptors_line) {
     pli_detail::checkGray(image, "Lineextractor");
@@ -266,6 +299,34 @@ class Lineextractor {
   std::shared_ptr<pli_detail::Group> group_;
   int eye_ = 0;
 };
+
+inline void pliBind(ORBextractor* orbLeft, ORBextractor* orbRight, Lineextractor* lineLeft, Lineextractor* lineRight) {
+  using namespace pli_detail;
+  if (!orbLeft && !lineLeft) throw std::invalid_argument("pliBind: no left extractor");
+  if ((orbRight && !orbLeft) || (lineRight && !lineLeft)) throw std::invalid_argument("pliBind: a right extractor without its left one");
+  auto orbParams = [](ORBextractor* e) { return OrbParams{e->nfeatures, e->nlevels, e->iniThFAST, e->minThFAST, (float)e->scaleFactor}; };
+  auto lineParams = [](Lineextractor* e) {
+    return LineParams{e->lsd_nfeatures, e->lsd_refine, e->lsd_n_bins, e->min_line_length, e->lsd_scale, e->lsd_sigma_scale,
+                      e->lsd_quant, e->lsd_ang_th, e->lsd_log_eps, e->lsd_density_th, e->bFLD};
+  };
+  if (orbRight && !(orbParams(orbLeft) == orbParams(orbRight))) throw std::invalid_argument("pliBind: the two ORB extractors differ");
+  if (lineRight && !(lineParams(lineLeft) == lineParams(lineRight))) throw std::invalid_argument("pliBind: the two line extractors differ");
+  auto g = std::make_shared<Group>();
+  Registry& R = Registry::get();
+  if (orbLeft) {
+    g->hasOrb = true; g->orb = orbParams(orbLeft);
+    R.leave(orbLeft->group_, true, orbLeft->eye_);
+    orbLeft->group_ = g; orbLeft->eye_ = 0; g->orbMask |= 1;
+    if (orbRight) { R.leave(orbRight->group_, true, orbRight->eye_); orbRight->group_ = g; orbRight->eye_ = 1; g->orbMask |= 2; }
+  }
+  if (lineLeft) {
+    g->hasLine = true; g->line = lineParams(lineLeft);
+    R.leave(lineLeft->group_, false, lineLeft->eye_);
+    lineLeft->group_ = g; lineLeft->eye_ = 0; g->lineMask |= 1;
+    if (lineRight) { R.leave(lineRight->group_, false, lineRight->eye_); lineRight->group_ = g; lineRight->eye_ = 1; g->lineMask |= 2; }
+  }
+  R.adopt(g);
+}
 
 // int match(const cv::Mat& desc1, const cv::Mat& desc2, float nnr, std::vector<int>& matches_12), LineMatcher.h:63 /
 // LineMatcher.cpp:201-229 (uses the context of the extractors that produced the descriptors; they exist by then)

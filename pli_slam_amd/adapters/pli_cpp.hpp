@@ -38,6 +38,10 @@ inline int descriptorDistance(const uint8_t* a, const uint8_t* b) {
 
 // One context = the four extractors of Tracking (ORB left/right, LSD left/right) plus the stereo matchers,
 // sharing device-resident pyramids and tables (reference Tracking.cc:87-98,743-749 and Frame.cc:98-228).
+// Thread safety: every pli_* call on a context holds the context's own lock inside the library
+// (include/pli_frontend.h, "Conventions"), so the methods below may be called from several threads at once —
+// the four std::threads of Frame.cc:128-135 — and run one after the other; this class adds no state of its own
+// that would need a second lock.
 class Frontend {
  public:
   explicit Frontend(const pli_frontend_config& cfg, int device = 0) : cfg_(cfg) {
@@ -77,6 +81,10 @@ class Frontend {
     desc.resize((size_t)n * 32);
   }
 
+  // sizes of the device tables of the last per-call extractions: mvKeys, mvKeysRight, mvKeys_Line, mvKeysRight_Line (-1: not run)
+  void lastCounts(int32_t counts[4]) { check(pli_last_counts(ctx_, counts)); }
+  // the rig Frame::ComputeStereoMatches works with: mbf and fx = mK(0,0) (Frame.cc:1005-1008)
+  void setStereoCamera(float bf, float fx) { check(pli_set_stereo_camera(ctx_, bf, fx)); }
   // Frame::ComputeStereoMatches
   void computeStereoMatches(std::vector<float>& uRight, std::vector<float>& depth) {
     uRight.assign(layout_.kp_cap, -1.f);

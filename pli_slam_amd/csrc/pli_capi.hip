@@ -12,6 +12,7 @@
 #include <set>
 #include <string>
 #include <functional>
+#include <mutex>
 
 using namespace pli;
 
@@ -50,6 +51,10 @@ struct ProfEntry { const char* name; hipEvent_t a, b; };
 }  // namespace
 
 struct pli_ctx {
+  // Every entry point that takes a context holds this lock for the whole call: the reference drives its four extractors
+  // from four std::threads (Frame.cc:128-135) and the adapters put them on ONE context, so concurrent calls on a context
+  // are legal and are serialised here (recursive: entry points call each other).  Different contexts run concurrently.
+  mutable std::recursive_mutex mu;
   pli_frontend_config cfg;
   DevParams hp;
   DevParams* dP = nullptr;
@@ -116,6 +121,8 @@ struct pli_ctx {
   uint8_t* ownTable = nullptr;
   std::vector<uint8_t> hostRec;
   bool orbDone[2] = {false, false}, lineDone[2] = {false, false};
+  int orbCount[2] = {0, 0};                  // keypoints the last pli_orb_extract(_lapping) left in each eye's table
+  int lineCount[2] = {0, 0};                 // keylines the last pli_line_extract left in each eye's table
   int monoCount[2] = {0, 0};                 // pli_orb_extract_lapping: first lapping-area keypoint of each eye's table
   // pipelined host entry point: two slots of device staging (images + table), H2D and D2H copy streams
   struct HostSlot { uint8_t* dimg = nullptr; uint8_t* dtab = nullptr; size_t imgBytes = 0, tabBytes = 0;
@@ -160,6 +167,14 @@ struct pli_ctx {
     if (!prof) return;
     hipEventRecord(profLog.back().b, stream);
   }
+};
+
+struct CtxGuard {
+  const pli_ctx* c;
+  explicit CtxGuard(const pli_ctx* c_) : c(c_) { if (c) c->mu.lock(); }
+  ~CtxGuard() { if (c) c->mu.unlock(); }
+  CtxGuard(const CtxGuard&) = delete;
+  CtxGuard& operator=(const CtxGuard&) = delete;
 };
 
 #define LAUNCH(c, name, kern, grid, block, shmem, ...)                       \
@@ -1079,6 +1094,7 @@ pli_status pli_ctx_create(const pli_frontend_config* cfg, int32_t device, pli_ct
 
 void pli_ctx_destroy(pli_ctx* c) {
   if (!c) return;
+  { CtxGuard wait__(c); }       // a call still running on another thread finishes first (destroying under it is the caller's bug)
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   for (void* p : c->allocs) hipFree(p);
@@ -1098,12 +1114,14 @@ void pli_ctx_destroy(pli_ctx* c) {
 }
 
 pli_status pli_ctx_layout(const pli_ctx* c, pli_table_layout* out) {
+  CtxGuard guard__(c);
   if (!c || !out) return PLI_ERR_INVALID;
   *out = c->lay;
   return PLI_OK;
 }
 
 pli_status pli_ctx_set_stream(pli_ctx* c, void* s) {
+  CtxGuard guard__(c);
   if (!c) return PLI_ERR_INVALID;
   HIPCHK(hipStreamSynchronize(c->stream));
   if (s) {
@@ -1118,6 +1136,7 @@ pli_status pli_ctx_set_stream(pli_ctx* c, void* s) {
 }
 
 pli_status pli_set_rectify_maps(pli_ctx* c, int32_t eye, const float* mapx, const float* mapy) {
+  CtxGuard guard__(c);
   if (!c || eye < 0 || eye > 1 || ((mapx == nullptr) != (mapy == nullptr))) { g_err = "bad argument"; return PLI_ERR_INVALID; }
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -1134,6 +1153,7 @@ pli_status pli_set_rectify_maps(pli_ctx* c, int32_t eye, const float* mapx, cons
 }
 
 pli_status pli_ctx_sync(pli_ctx* c) {
+  CtxGuard guard__(c);
   if (!c) return PLI_ERR_INVALID;
   HIPCHK(hipStreamSynchronize(c->stream));
   return PLI_OK;
@@ -1141,6 +1161,7 @@ pli_status pli_ctx_sync(pli_ctx* c) {
 
 pli_status pli_batch_run(pli_ctx* c, int32_t nframes, const uint8_t* dl, const uint8_t* dr, int64_t stride,
                          int64_t frameStride, uint32_t stages, void* table) {
+  CtxGuard guard__(c);
   if (!c || !dl || !dr || !table) { g_err = "null argument"; return PLI_ERR_INVALID; }
   if (nframes < 1 || nframes > c->cfg.max_frames) { g_err = "nframes exceeds the context's max_frames"; return PLI_ERR_INVALID; }
   if (stride < c->cfg.width) { g_err = "stride < width"; return PLI_ERR_INVALID; }
@@ -1216,6 +1237,7 @@ pli_status pli_batch_run(pli_ctx* c, int32_t nframes, const uint8_t* dl, const u
 
 pli_status pli_batch_run_host(pli_ctx* c, int32_t nframes, const uint8_t* left, const uint8_t* right, int64_t stride,
                               int64_t frameStride, uint32_t stages, void* table) {
+  CtxGuard guard__(c);
   if (!c || !left || !right || !table) { g_err = "null argument"; return PLI_ERR_INVALID; }
   if (nframes < 1 || nframes > c->cfg.max_frames) { g_err = "nframes exceeds the context's max_frames"; return PLI_ERR_INVALID; }
   HIPCHK(hipSetDevice(c->device));
@@ -1254,6 +1276,7 @@ static pli_status waitSlot(pli_ctx* c, int s) {
 }
 
 pli_status pli_batch_wait(pli_ctx* c, int32_t all) {
+  CtxGuard guard__(c);
   if (!c) return PLI_ERR_INVALID;
   HIPCHK(hipSetDevice(c->device));
   pli_status st;
@@ -1266,6 +1289,7 @@ pli_status pli_batch_wait(pli_ctx* c, int32_t all) {
 
 pli_status pli_batch_submit_host(pli_ctx* c, int32_t nframes, const uint8_t* left, const uint8_t* right, int64_t stride,
                                  int64_t frameStride, uint32_t stages, void* table) {
+  CtxGuard guard__(c);
   if (!c || !left || !right || !table) { g_err = "null argument"; return PLI_ERR_INVALID; }
   if (nframes < 1 || nframes > c->cfg.max_frames) { g_err = "nframes exceeds the context's max_frames"; return PLI_ERR_INVALID; }
   if (stride < c->cfg.width) { g_err = "stride < width"; return PLI_ERR_INVALID; }
@@ -1315,6 +1339,7 @@ pli_status pli_batch_submit_host(pli_ctx* c, int32_t nframes, const uint8_t* lef
 
 pli_status pli_orb_extract(pli_ctx* c, int32_t eye, const uint8_t* img, int32_t w, int32_t h, int64_t stride,
                            pli_keypoint* kp, int32_t cap, uint8_t* desc, int32_t* n) {
+  CtxGuard guard__(c);
   if (!c || eye < 0 || eye > 1 || !n) { g_err = "bad argument"; return PLI_ERR_INVALID; }
   *n = 0;
   pli_status st = checkImage(c, img, w, h, stride);
@@ -1328,6 +1353,7 @@ pli_status pli_orb_extract(pli_ctx* c, int32_t eye, const uint8_t* img, int32_t 
   HIPCHK(hipStreamSynchronize(c->stream));
   const int N = counts[eye];
   c->orbDone[eye] = true;
+  c->orbCount[eye] = N;
   c->monoCount[eye] = N;
   *n = N;
   if (reinterpret_cast<const uint8_t*>(counts + 6)[2 + eye]) { g_err = "more keypoints than kp_cap holds"; return PLI_ERR_CAPACITY; }
@@ -1340,6 +1366,7 @@ pli_status pli_orb_extract(pli_ctx* c, int32_t eye, const uint8_t* img, int32_t 
 }
 
 pli_status pli_orb_pyramid_level(pli_ctx* c, int32_t eye, int32_t level, uint8_t* dst, int64_t dstBytes, int32_t* w, int32_t* h) {
+  CtxGuard guard__(c);
   if (!c || eye < 0 || eye > 1 || level < 0 || level >= c->hp.nlevels) { g_err = "bad argument"; return PLI_ERR_INVALID; }
   if (!c->orbDone[eye]) { g_err = "pli_orb_extract has not run for this eye"; return PLI_ERR_STATE; }
   const LevelGeom& G = c->hp.lv[level];
@@ -1354,6 +1381,7 @@ pli_status pli_orb_pyramid_level(pli_ctx* c, int32_t eye, int32_t level, uint8_t
 
 pli_status pli_line_extract(pli_ctx* c, int32_t eye, const uint8_t* img, int32_t w, int32_t h, int64_t stride,
                             pli_keyline* kl, int32_t cap, uint8_t* desc, int32_t* n) {
+  CtxGuard guard__(c);
   if (!c || eye < 0 || eye > 1 || !n) { g_err = "bad argument"; return PLI_ERR_INVALID; }
   *n = 0;
   pli_status st = checkImage(c, img, w, h, stride);
@@ -1367,6 +1395,7 @@ pli_status pli_line_extract(pli_ctx* c, int32_t eye, const uint8_t* img, int32_t
   HIPCHK(hipStreamSynchronize(c->stream));
   const int N = counts[2 + eye];
   c->lineDone[eye] = true;
+  c->lineCount[eye] = N;
   *n = N;
   if (reinterpret_cast<const uint8_t*>(counts + 6)[eye]) {
     g_err = "more segments pass the length cut than max_lines holds: raise pli_frontend_config.max_lines";
@@ -1380,7 +1409,32 @@ pli_status pli_line_extract(pli_ctx* c, int32_t eye, const uint8_t* img, int32_t
   return PLI_OK;
 }
 
+pli_status pli_set_stereo_camera(pli_ctx* c, float bf, float fx) {
+  CtxGuard guard__(c);
+  if (!c || !(bf > 0) || !(fx > 0)) { g_err = "bad argument"; return PLI_ERR_INVALID; }
+  if (bf == c->cfg.bf && fx == c->cfg.fx) return PLI_OK;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));           // kernels in flight read the old parameter block
+  if (c->aux) HIPCHK(hipStreamSynchronize(c->aux));
+  c->cfg.bf = bf; c->cfg.fx = fx;
+  c->hp.bf = bf;
+  c->hp.maxD = c->cfg.stereo_maxd_inf ? std::numeric_limits<float>::infinity() : bf / (bf / fx);
+  HIPCHK(hipMemcpy(c->dP, &c->hp, sizeof(DevParams), hipMemcpyHostToDevice));
+  return PLI_OK;
+}
+
+pli_status pli_last_counts(pli_ctx* c, int32_t counts[4]) {
+  CtxGuard guard__(c);
+  if (!c || !counts) { g_err = "bad argument"; return PLI_ERR_INVALID; }
+  for (int e = 0; e < 2; ++e) {
+    counts[e] = c->orbDone[e] ? c->orbCount[e] : -1;
+    counts[2 + e] = c->lineDone[e] ? c->lineCount[e] : -1;
+  }
+  return PLI_OK;
+}
+
 pli_status pli_stereo_match_points(pli_ctx* c, float* uright, float* depth, int32_t cap) {
+  CtxGuard guard__(c);
   if (!c) return PLI_ERR_INVALID;
   if (!c->orbDone[0] || !c->orbDone[1]) { g_err = "pli_orb_extract must run for both eyes first"; return PLI_ERR_STATE; }
   HIPCHK(hipSetDevice(c->device));
@@ -1400,6 +1454,7 @@ pli_status pli_stereo_match_points(pli_ctx* c, float* uright, float* depth, int3
 }
 
 pli_status pli_stereo_from_depth(pli_ctx* c, const float* depth, int64_t strideFloats, float* uright, float* depthOut, int32_t cap) {
+  CtxGuard guard__(c);
   if (!c || !depth || strideFloats < c->cfg.width) { g_err = "bad argument"; return PLI_ERR_INVALID; }
   if (!c->orbDone[0]) { g_err = "pli_orb_extract must run for the left eye first"; return PLI_ERR_STATE; }
   HIPCHK(hipSetDevice(c->device));
@@ -1428,6 +1483,7 @@ pli_status pli_stereo_from_depth(pli_ctx* c, const float* depth, int64_t strideF
 pli_status pli_orb_extract_lapping(pli_ctx* c, int32_t eye, const uint8_t* img, int32_t w, int32_t h, int64_t stride,
                                    int32_t lap0, int32_t lap1, pli_keypoint* kp, int32_t cap, uint8_t* desc, int32_t* n,
                                    int32_t* n_mono) {
+  CtxGuard guard__(c);
   if (!n_mono) { g_err = "bad argument"; return PLI_ERR_INVALID; }
   *n_mono = 0;
   pli_status st = pli_orb_extract(c, eye, img, w, h, stride, nullptr, INT_MAX, nullptr, n);
@@ -1515,6 +1571,7 @@ static size_t fisheyeScratch(int NL, int NR) {
 // ... on the device tables of the last pli_orb_extract_lapping of both eyes
 pli_status pli_stereo_fisheye(pli_ctx* c, const pli_kb8_camera* cam1, const pli_kb8_camera* cam2, const float* Rlr, const float* tlr,
                               int32_t* l2r, int32_t capL, int32_t* r2l, int32_t capR, float* depth, float* p3d, int32_t* nmatches) {
+  CtxGuard guard__(c);
   if (!c || !cam1 || !cam2 || !Rlr || !tlr) { g_err = "bad argument"; return PLI_ERR_INVALID; }
   if (nmatches) *nmatches = 0;
   if (!c->orbDone[0] || !c->orbDone[1]) { g_err = "pli_orb_extract_lapping must run for both eyes first"; return PLI_ERR_STATE; }
@@ -1537,6 +1594,7 @@ pli_status pli_stereo_fisheye_tables(pli_ctx* c, const pli_keypoint* kpL, const 
                                      const pli_keypoint* kpR, const uint8_t* descR, int32_t nright, int32_t monoRight,
                                      const pli_kb8_camera* cam1, const pli_kb8_camera* cam2, const float* Rlr, const float* tlr,
                                      int32_t* l2r, int32_t* r2l, float* depth, float* p3d, int32_t* nmatches) {
+  CtxGuard guard__(c);
   if (!c || !cam1 || !cam2 || !Rlr || !tlr || nleft < 0 || nright < 0 || (nleft > 0 && (!kpL || !descL)) ||
       (nright > 0 && (!kpR || !descR))) { g_err = "bad argument"; return PLI_ERR_INVALID; }
   if (nmatches) *nmatches = 0;
@@ -1560,6 +1618,7 @@ pli_status pli_stereo_fisheye_tables(pli_ctx* c, const pli_keypoint* kpL, const 
 }
 
 pli_status pli_stereo_match_lines(pli_ctx* c, float* disp, double* le, int32_t cap) {
+  CtxGuard guard__(c);
   if (!c) return PLI_ERR_INVALID;
   if (!c->lineDone[0] || !c->lineDone[1]) { g_err = "pli_line_extract must run for both eyes first"; return PLI_ERR_STATE; }
   HIPCHK(hipSetDevice(c->device));
@@ -1579,6 +1638,7 @@ pli_status pli_stereo_match_lines(pli_ctx* c, float* disp, double* le, int32_t c
 }
 
 pli_status pli_descriptor_distance(pli_ctx* c, const uint8_t* a, const uint8_t* b, int32_t n, int32_t* dist) {
+  CtxGuard guard__(c);
   if (!c || n < 0 || (n > 0 && (!a || !b || !dist))) { g_err = "bad argument"; return PLI_ERR_INVALID; }
   if (n == 0) return PLI_OK;
   HIPCHK(hipSetDevice(c->device));
@@ -1597,6 +1657,7 @@ pli_status pli_descriptor_distance(pli_ctx* c, const uint8_t* a, const uint8_t* 
 }
 
 pli_status pli_hamming_knn2(pli_ctx* c, const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt, int32_t* idx, int32_t* dist) {
+  CtxGuard guard__(c);
   if (!c || nq < 0 || nt < 0 || (nq > 0 && (!q || !idx || !dist)) || (nt > 0 && !t)) { g_err = "bad argument"; return PLI_ERR_INVALID; }
   if (nq == 0) return PLI_OK;
   HIPCHK(hipSetDevice(c->device));
@@ -1656,11 +1717,13 @@ static pli_status matchDescriptors(pli_ctx* c, const uint8_t* d1, int32_t n1, co
 
 pli_status pli_match_lines(pli_ctx* c, const uint8_t* d1, int32_t n1, const uint8_t* d2, int32_t n2, float nnr,
                            int32_t* m12, int32_t* nmatches) {
+  CtxGuard guard__(c);
   return matchDescriptors(c, d1, n1, d2, n2, nnr, c && c->cfg.best_lr_matches != 0, m12, nmatches);
 }
 
 pli_status pli_match_nnr(pli_ctx* c, const uint8_t* d1, int32_t n1, const uint8_t* d2, int32_t n2, float nnr,
                          int32_t* m12, int32_t* nmatches) {
+  CtxGuard guard__(c);
   return matchDescriptors(c, d1, n1, d2, n2, nnr, false, m12, nmatches);
 }
 
@@ -1735,6 +1798,7 @@ pli_status pli_search_by_projection(pli_ctx* c, const pli_proj_query* q, const u
                                     const pli_keypoint* kp, const uint8_t* desc, const float* uright, int32_t ncur,
                                     float minX, float maxX, float minY, float maxY, int32_t checkOri,
                                     int32_t* best, int32_t* nmatches) {
+  CtxGuard guard__(c);
   return projectionSearch(c, 0, q, qdesc, nq, kp, desc, uright, nullptr, ncur, minX, maxX, minY, maxY, checkOri, 0.0f, best, nmatches);
 }
 
@@ -1742,6 +1806,7 @@ pli_status pli_search_local_map(pli_ctx* c, const pli_proj_query* q, const uint8
                                 const pli_keypoint* kp, const uint8_t* desc, const float* uright,
                                 const uint8_t* occupied, int32_t ncur, float minX, float maxX, float minY, float maxY,
                                 float nnratio, int32_t* best, int32_t* nmatches) {
+  CtxGuard guard__(c);
   return projectionSearch(c, 1, q, qdesc, nq, kp, desc, uright, occupied, ncur, minX, maxX, minY, maxY, 0, nnratio, best, nmatches);
 }
 
@@ -1750,6 +1815,7 @@ pli_status pli_search_local_map_fisheye(pli_ctx* c, const pli_proj_query* qL, co
                                         const int32_t* l2r, int32_t nL, const pli_keypoint* kpR, const uint8_t* descR,
                                         const uint8_t* occR, const int32_t* r2l, int32_t nR, float minX, float maxX, float minY,
                                         float maxY, float nnratio, int32_t* mpL, int32_t* mpR, int32_t* nmatches) {
+  CtxGuard guard__(c);
   if (!c || nq < 0 || nL < 0 || nR < 0 || (nq > 0 && (!qL || !qR || !qdesc)) || (nL > 0 && (!kpL || !descL || !l2r || !mpL)) ||
       (nR > 0 && (!kpR || !descR || !r2l || !mpR))) { g_err = "bad argument"; return PLI_ERR_INVALID; }
   if (nmatches) *nmatches = 0;
@@ -1828,6 +1894,7 @@ static void trackLayout(const pli_ctx* c, pli_track_layout& L) {
 }
 
 pli_status pli_track_layout_get(const pli_ctx* c, pli_track_layout* out) {
+  CtxGuard guard__(c);
   if (!c || !out) return PLI_ERR_INVALID;
   trackLayout(c, *out);
   return PLI_OK;
@@ -1835,6 +1902,7 @@ pli_status pli_track_layout_get(const pli_ctx* c, pli_track_layout* out) {
 
 pli_status pli_batch_track(pli_ctx* c, int32_t nframes, const void* table, const float* poses, const pli_track_params* tpar,
                            void* track) {
+  CtxGuard guard__(c);
   if (!c || !table || !poses || !tpar || !track) { g_err = "null argument"; return PLI_ERR_INVALID; }
   if (nframes < 1 || nframes > c->cfg.max_frames) { g_err = "nframes exceeds the context's max_frames"; return PLI_ERR_INVALID; }
   if (!(tpar->max_x > tpar->min_x) || !(tpar->max_y > tpar->min_y) || !(tpar->fx > 0) || !(tpar->fy > 0)) { g_err = "bad track parameters"; return PLI_ERR_INVALID; }
@@ -1886,6 +1954,7 @@ void pli_vocab_destroy(pli_vocab* v) {
 
 pli_status pli_vocab_create(pli_ctx* c, int32_t k, int32_t L, int32_t n, const int32_t* parent, const uint8_t* isLeaf,
                             const uint8_t* desc, const double* weight, pli_vocab** out) {
+  CtxGuard guard__(c);
   if (!c || !out || n < 1 || !parent || !isLeaf || !desc || !weight || k < 1 || L < 1) { g_err = "bad argument"; return PLI_ERR_INVALID; }
   *out = nullptr;
   const int N = n + 1;                                      // + root (TemplatedVocabulary.h:1387)
@@ -1925,6 +1994,7 @@ pli_status pli_vocab_create(pli_ctx* c, int32_t k, int32_t L, int32_t n, const i
 
 pli_status pli_bow_transform(pli_ctx* c, const pli_vocab* v, const uint8_t* desc, int32_t n, int32_t levelsup, int32_t* wordId,
                              double* weight, int32_t* nodeId) {
+  CtxGuard guard__(c);
   if (!c || !v || n < 0 || (n > 0 && (!desc || !wordId || !weight || !nodeId))) { g_err = "bad argument"; return PLI_ERR_INVALID; }
   if (n == 0) return PLI_OK;
   HIPCHK(hipSetDevice(c->device));
@@ -1948,12 +2018,14 @@ pli_status pli_bow_transform(pli_ctx* c, const pli_vocab* v, const uint8_t* desc
 
 // ---- measurement -----------------------------------------------------------
 pli_status pli_prof_enable(pli_ctx* c, int32_t on) {
+  CtxGuard guard__(c);
   if (!c) return PLI_ERR_INVALID;
   HIPCHK(hipStreamSynchronize(c->stream));
   c->prof = on != 0;
   return PLI_OK;
 }
 pli_status pli_prof_reset(pli_ctx* c) {
+  CtxGuard guard__(c);
   if (!c) return PLI_ERR_INVALID;
   HIPCHK(hipStreamSynchronize(c->stream));
   c->profLog.clear();
@@ -1961,6 +2033,7 @@ pli_status pli_prof_reset(pli_ctx* c) {
   return PLI_OK;
 }
 pli_status pli_prof_report(pli_ctx* c, char* buf, int64_t bytes) {
+  CtxGuard guard__(c);
   if (!c || !buf || bytes <= 0) return PLI_ERR_INVALID;
   HIPCHK(hipStreamSynchronize(c->stream));
   std::map<std::string, std::pair<int, double>> acc;
@@ -1984,6 +2057,7 @@ pli_status pli_prof_report(pli_ctx* c, char* buf, int64_t bytes) {
 }
 
 pli_status pli_debug_enable(pli_ctx* c, int32_t on) {
+  CtxGuard guard__(c);
   if (!c) return PLI_ERR_INVALID;
   HIPCHK(hipStreamSynchronize(c->stream));
   if (on && !c->angDbg) {
@@ -1997,6 +2071,7 @@ pli_status pli_debug_enable(pli_ctx* c, int32_t on) {
 }
 
 pli_status pli_debug_fetch(pli_ctx* c, int32_t image, int32_t what, int32_t arg, void* dst, int64_t dstBytes, int64_t* outBytes) {
+  CtxGuard guard__(c);
   if (!c || image < 0 || image >= c->NI || !outBytes) { g_err = "bad argument"; return PLI_ERR_INVALID; }
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamSynchronize(c->stream));

@@ -83,8 +83,9 @@ int use(StubFrame& cur, const StubFrame& last, cv::Mat& im, cv::Mat& mask, std::
 
 
 def test_orbslam_adapter_header_is_valid_cpp_against_a_stub_cv():
-    """Syntax check only (g++ -fsyntax-only against tests/stubs/opencv2: declarations, no OpenCV): the adapter offers the
-    reference's constructor lists, functors, match(), DescriptorDistance and SearchByProjection signatures.  Pins nothing."""
+    """Syntax check (g++ -fsyntax-only against tests/stubs/opencv2, a functional stand-in for the cv:: types, no OpenCV): the
+    adapter offers the reference's constructor lists, functors, match(), DescriptorDistance and SearchByProjection signatures.
+    The adapters are EXECUTED by tests/test_cpp_dropin.py (-m gpu) and, without a device, by the test below."""
     with tempfile.TemporaryDirectory() as d:
         src = os.path.join(d, "a.cpp")
         open(src, "w").write(ADAPTER_SRC)
@@ -111,3 +112,23 @@ int main() {
         exe = os.path.join(d, "t")
         subprocess.check_call(["g++", "-std=c++17", "-I", ROOT, p, lib, "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
         assert subprocess.run([exe]).returncode == 0
+
+
+def test_dropin_harness_builds_and_fails_loudly_without_a_device(tmp_path):
+    """tests/cpp/dropin_harness.cpp (the -m gpu drop-in test's program) compiles against the adapters and links the library here
+    too; without a GPU the first operator() call throws pli::Error (PLI_ERR_NO_DEVICE) out of the extractor thread's caller —
+    no CPU fallback, no crash.  On the GPU box the same program runs one small frame."""
+    import numpy as np
+    from test_cpp_dropin import build_harness, write_input, read_dump
+    exe = build_harness(str(tmp_path))
+    rng = np.random.default_rng(0)
+    img = (rng.random((240, 376)) * 255).astype(np.uint8)
+    inp, outp = str(tmp_path / "in"), str(tmp_path / "out")
+    write_input(inp, [(img, img)], 1, 0, nfeatures=500, nlines=60)       # sequential calls: the exception surfaces in main
+    r = subprocess.run([exe, inp, outp], capture_output=True, text=True)
+    import torch
+    if torch.cuda.is_available():
+        assert r.returncode == 0, r.stderr
+        assert int(read_dump(outp)["groups_left"][0, 0]) == 0
+    else:
+        assert r.returncode == 1 and "no HIP device" in r.stderr, (r.returncode, r.stderr)
