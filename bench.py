@@ -206,6 +206,52 @@ def parity_check(fe, cfg, d_table, images, F, nuniq, rec_bytes, npairs=8):
             "pairs_checked_against_oracle": len(pick), "pairs_mismatching": bad}
 
 
+def gathered_parity_check(fe, cfg, gathered, counts, rec_bytes, pair_of, per_rank=2):
+    """N > 1, on the root: `per_rank` records of EVERY rank's gathered shard (first and last frame of the shard) against the
+    oracle's frame for the stereo pair that rank processed there; plus, per rank, that no record of the shard is empty."""
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = []
+    empty = 0
+    for r_, (tab, n) in enumerate(zip(gathered, counts)):
+        host = tab[: n * rec_bytes].cpu().numpy()
+        recs = host.reshape(n, rec_bytes) if n else host.reshape(0, rec_bytes)
+        empty += int((~recs.any(axis=1)).sum())
+        for i_ in sorted({0, n - 1} if per_rank >= 2 else {0}):
+            if 0 <= i_ < n:
+                jobs.append((r_, i_, host))
+    with ThreadPoolExecutor(min(len(jobs), os.cpu_count() or 1) or 1) as ex:
+        oks = list(ex.map(lambda j: oracle_frame_equal(fe, fe.parse_record(j[2], j[1]), pair_of(j[0], j[1]), cfg), jobs))
+    bad = [(j[0], j[1]) for j, o in zip(jobs, oks) if not o]
+    return {"ok": not bad and empty == 0, "ranks_checked": len(counts), "records_gathered": int(sum(counts)), "empty_records": empty,
+            "pairs_checked_against_oracle": len(jobs), "pairs_mismatching": len(bad), "mismatching_rank_frame": bad[:8]}
+
+
+def halo_track_check(fe, cfg, track, d_halo_table, rec_bytes, prev_pair, prev_pose, own_pose, W, H):
+    """Config 3 on several ranks: the track of this rank's FIRST frame was matched against the record that arrived through the
+    1-frame halo.  The oracle computes the same track from scratch — the previous shard's last frame from its image pair, the
+    projection of ORBmatcher.cc:2190-2244, the window search, match() of the line descriptors — and the two must be equal."""
+    import torch
+    from oracle import pyoracle as po
+    torch.cuda.synchronize()
+    tl = fe.track_layout()
+    tr = fe.parse_track(track[2].cpu().numpy(), 1)                    # [halo | frame 0 | ...]: record 1 = own frame 0 against the halo
+    own = fe.parse_record(d_halo_table[rec_bytes:2 * rec_bytes].cpu().numpy(), 0)
+    fr = po.Frame(po.Config.from_buffer_copy(bytes(cfg)))
+    n, kp, desc = fr.orb_extract(0, prev_pair[0])
+    fr.orb_extract(1, prev_pair[1])
+    m, kl, ld = fr.line_extract(0, prev_pair[0])
+    fr.line_extract(1, prev_pair[1])
+    ur, dp, _, _ = fr.stereo_points()
+    tp = track[1]
+    sf = np.cumprod(np.concatenate([[np.float32(1.0)], np.full(cfg.orb_nlevels - 1, np.float32(cfg.orb_scale_factor), np.float32)])).astype(np.float32)
+    q = po.track_queries(kp, dp, prev_pose, own_pose, tp.fx, tp.fy, tp.cx, tp.cy, tp.bf, tp.th, bool(tp.mono), sf)
+    on, obest = po.search_by_projection(q, desc, own["kpL"], own["descL"], own["uright"], (0.0, float(W), 0.0, float(H)), bool(tp.check_orientation))
+    ln, lm = po.match_lines(ld, own["ldescL"], float(tp.nnr_lines), True)
+    ok = (tr["counts"][0] == n and tr["counts"][1] == on and np.array_equal(tr["best"], obest) and tr["counts"][2] == m
+          and tr["counts"][3] == ln and np.array_equal(tr["lines"], lm) and on > 0)
+    return {"checked": 1, "bad": 0 if ok else 1}
+
+
 # --------------------------------------------------------------------------------------------------------------
 def free_port():
     s = socket.socket()
@@ -279,6 +325,9 @@ def main():
     ap.add_argument("--lsd-mode", type=int, default=0, help="0 auto, 1 relaxation, 2 sequential waves, 3 tile-sequential relaxation")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--dry-tables", action="store_true", help="CPU exercise of sharding + gather (needs --backend gloo)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="all ranks run their kernels on GPU 0 (rehearsal of the multi-rank path on a one-GPU box; needs --backend gloo: "
+                         "the tables are staged through the host for the gather and the halo)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -305,11 +354,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the front-end has no CPU path")
+    if args.share_device:
+        if args.backend != "gloo":
+            sys.exit("--share-device puts several ranks on one GPU, which RCCL refuses: use --backend gloo")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    ctl = torch.device("cpu") if args.backend == "gloo" else dev        # where the small control tensors of the collectives live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(args.backend, rank=rank, world_size=world, device_id=dev)
+        if args.backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world, device_id=dev)
         assert dist.get_world_size() == args.gpus
 
     from pli_slam_amd import capi, synth
@@ -331,7 +388,7 @@ def main():
         F = args.frames_per_gpu or 256
     Fmax = F
     if world > 1:                                     # equal table sizes for the gather (config 4 shards may differ by one)
-        t = torch.tensor([F], device=dev)
+        t = torch.tensor([F], device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         Fmax = int(t.item())
     # (config 3 on several ranks: the frame-to-frame matcher also sees the halo frame of the previous shard)
@@ -379,8 +436,11 @@ def main():
             d_poses = torch.from_numpy(np.stack([pose(t_ % nuniq) for t_ in range(F)]).reshape(-1)).to(dev)
             track = (d_poses, fe.track_params(th=15.0), torch.zeros(F * int(tl.record_bytes), dtype=torch.uint8, device=dev))
 
+    last_slot = [0]
+
     def step():
         slot = gath.acquire() if gath else 0
+        last_slot[0] = slot
         tbl = gath.table(slot) if gath else d_table
         fe.batch_run_device(F, d_left.data_ptr(), d_right.data_ptr(), W, W * H, tbl.data_ptr())
         if track is not None and world > 1:
@@ -415,13 +475,37 @@ def main():
     dt = time.perf_counter() - t0
     fe.prof_enable(False)
     prof = fe.prof_report()
-    frames_done = torch.tensor([float(F * args.steps)], dtype=torch.float64, device=dev)
+    frames_done = torch.tensor([float(F * args.steps)], dtype=torch.float64, device=ctl)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         dist.all_reduce(frames_done, op=dist.ReduceOp.SUM)
     total_frames = float(frames_done.item())
+
+    # N > 1: parity of what the ranks produced and of what arrived at the root (outside the timed region).  Every rank checks the
+    # track of its first frame against the oracle's track over [last frame of the previous shard | own first frame] (config 3:
+    # that track exists only through the halo exchange); rank 0 checks records of EVERY rank's gathered shard against the oracle.
+    parity_multi = None
+    if world > 1 and not args.no_cpu_baseline:
+        counts_r = [shard_range(BATCH4, r_, world)[1] * max(1, args.inflight) if args.config == 4 else F for r_ in range(world)]
+
+        def pair_of(r_, i_):        # the stereo pair behind record i_ of rank r_ (the seeds / instants the ranks drew above)
+            nu = min(counts_r[r_], args.unique_frames)
+            if args.config == 3:
+                return synth.make_stereo_pair(100, W, H, t=r_ * nu + (i_ % nu))
+            return synth.make_stereo_pair(r_ * nu + (i_ % nu), W, H)
+        halo = {"checked": 0, "bad": 0}
+        if track is not None and rank > 0 and F > 0:
+            halo = halo_track_check(fe, cfg, track, d_halo_table, rec_bytes, pair_of(rank - 1, nuniq - 1),
+                                    pose((rank * nuniq - 1) % (world * nuniq)), pose(rank * nuniq), W, H)
+        hb = torch.tensor([halo["checked"], halo["bad"]], dtype=torch.int64, device=ctl)
+        dist.all_reduce(hb, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            parity_multi = gathered_parity_check(fe, cfg, gath.gathered(last_slot[0]), counts_r, rec_bytes, pair_of)
+            parity_multi["halo_tracks_checked_against_oracle"] = int(hb[0].item())
+            parity_multi["halo_tracks_mismatching"] = int(hb[1].item())
+            parity_multi["ok"] = bool(parity_multi["ok"] and hb[1].item() == 0)
 
     rc = 0
     if rank == 0:
@@ -478,7 +562,14 @@ def main():
         }
         if world > 1:
             out["gather"] = {"bytes_per_rank_per_step": Fmax * rec_bytes, "bytes_at_root_per_step": world * Fmax * rec_bytes,
-                             "backend": args.backend}
+                             "backend": args.backend, "staged_through_host": bool(gath.staged)}
+            if args.share_device:
+                out["config"]["parallelism"] += "; ALL ranks share GPU 0 (rehearsal, not a scaling measurement)"
+            if parity_multi is not None:
+                out["parity"] = parity_multi
+                if not parity_multi["ok"]:
+                    out["value"] = None
+                    rc = 3
         if args.config == 4:
             out["config"]["batch_frames"] = BATCH4
             out["config"]["batches_in_flight"] = max(1, args.inflight)
@@ -498,7 +589,7 @@ def main():
             if not args.no_host_leg:
                 out["host_inclusive"] = host_inclusive_leg(fe, images, F, nuniq, W, H, rec_bytes, args.steps)
             out["cpu_baseline"] = cpu_baseline(images, bytes(cfg))
-            # the timed steps left their last table in d_table: re-run one step so the checked table is a fresh one
+            # the table the last timed step left in d_table is the one that is checked
             out["parity"] = parity_check(fe, cfg, d_table, images, F, nuniq, rec_bytes)
             if not out["parity"]["ok"]:
                 out["value"] = None                   # a fast path whose results differ from the reference's is not a result

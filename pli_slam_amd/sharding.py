@@ -4,6 +4,9 @@ Extraction and stereo matching are independent per stereo frame, so a batch is
 cut into contiguous shards, one per rank, with no data-path collective; the only
 exchange is the gather of the fixed-stride result tables to one rank
 (torch.distributed: backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU).
+
+With the gloo backend and tables in HBM (several ranks sharing ONE GPU: the single-GPU rehearsal of the multi-GPU path,
+bench.py --share-device) the gather and the halo are staged through host memory: gloo moves CPU tensors only.
 """
 import torch
 import torch.distributed as dist
@@ -48,6 +51,11 @@ def gather_tables(table, record_bytes, nframes_local, dst=0, group=None, counts=
     return [b[: n * record_bytes] for b, n in zip(bufs, all_counts)]
 
 
+def _host_staged(t, group=None):
+    """gloo cannot move device tensors point to point / by gather: stage them through the host."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def exchange_halo(table, record_bytes, nframes_local, group=None, counts=None):
     """1-frame halo for frame-to-frame matching across shard borders: every rank sends the record of its LAST
     frame to the next rank and receives the record of the frame before its first one.
@@ -70,15 +78,23 @@ def exchange_halo(table, record_bytes, nframes_local, group=None, counts=None):
         dist.all_gather(all_counts, mine, group=group)
         all_counts = [int(c.item()) for c in all_counts]
     reqs = []
+    staged = _host_staged(table, group)
     last = table[nframes_local * record_bytes:(nframes_local + 1) * record_bytes]          # record of the last local frame
     if rank + 1 < world and nframes_local > 0:
-        reqs.append(dist.isend(last.contiguous(), dst=rank + 1, group=group))
+        reqs.append(dist.isend(last.cpu() if staged else last.contiguous(), dst=rank + 1, group=group))
     got = rank > 0 and all_counts[rank - 1] > 0
+    halo_host = None
     if got:
         halo = table[:record_bytes]
-        reqs.append(dist.irecv(halo, src=rank - 1, group=group))
+        if staged:
+            halo_host = torch.empty(record_bytes, dtype=torch.uint8)
+            reqs.append(dist.irecv(halo_host, src=rank - 1, group=group))
+        else:
+            reqs.append(dist.irecv(halo, src=rank - 1, group=group))
     for r in reqs:
         r.wait()
+    if halo_host is not None:
+        table[:record_bytes].copy_(halo_host)
     return got
 
 
@@ -100,8 +116,12 @@ class TableGatherer:
         self.dst, self.group, self.depth = dst, group, depth
         self.tables = [torch.zeros(table_bytes, dtype=torch.uint8, device=device) for _ in range(depth)]
         self.bufs = [None] * depth
+        # gloo + tables in HBM: the shard goes to a (pinned) host copy first and the root receives host buffers
+        self.staged = self.world > 1 and torch.device(device).type == "cuda" and dist.get_backend(group) == "gloo"
+        self.host = [torch.empty(table_bytes, dtype=torch.uint8).pin_memory() for _ in range(depth)] if self.staged else None
+        bdev = torch.device("cpu") if self.staged else device
         if self.world > 1 and self.rank == dst:
-            self.bufs = [[torch.empty(table_bytes, dtype=torch.uint8, device=device) for _ in range(self.world)]
+            self.bufs = [[torch.empty(table_bytes, dtype=torch.uint8, device=bdev) for _ in range(self.world)]
                          for _ in range(depth)]
         self.works = [None] * depth
         self.next = 0
@@ -119,7 +139,11 @@ class TableGatherer:
 
     def submit(self, slot):
         if self.world > 1:
-            self.works[slot] = dist.gather(self.tables[slot], self.bufs[slot], dst=self.dst, group=self.group, async_op=True)
+            src = self.tables[slot]
+            if self.staged:
+                self.host[slot].copy_(src)               # waits for the kernels on the current stream that fill the table
+                src = self.host[slot]
+            self.works[slot] = dist.gather(src, self.bufs[slot], dst=self.dst, group=self.group, async_op=True)
 
     def drain(self):
         for slot in range(self.depth):

@@ -1,0 +1,49 @@
+"""The multi-rank path on REAL kernels, rehearsed on the one GPU of the test box (-m gpu): `bench.py --gpus 2 --backend gloo
+--share-device` starts two rank processes that both run their shard on GPU 0 — real `step()`, real `TableGatherer` and
+`exchange_halo` (the tables staged through the host, gloo moves CPU tensors only) — and rank 0 checks records of EVERY rank's
+gathered shard against the oracle; with --config 3 every rank also checks the track that exists only through the halo
+exchange against the oracle's track over [last frame of the previous shard | own first frame].  The line a future 8-GPU run
+prints has the same keys (`n_gpus`, `gather`, `parity`)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(*extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "2", "--warmup", "1",
+                          *extra], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_config4_two_ranks_real_kernels_gather_and_parity():
+    d = run_bench("--config", "4")
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["frames_per_gpu"] == 128 and d["config"]["batch_frames"] == 256
+    assert d["gather"]["backend"] == "gloo" and d["gather"]["staged_through_host"] is True
+    assert d["gather"]["bytes_at_root_per_step"] == 2 * d["gather"]["bytes_per_rank_per_step"] > 2 * 128 * 100_000
+    p = d["parity"]
+    assert p["ok"] is True and p["ranks_checked"] == 2 and p["records_gathered"] == 256 and p["empty_records"] == 0
+    assert p["pairs_checked_against_oracle"] == 4 and p["pairs_mismatching"] == 0
+
+
+def test_config3_two_ranks_halo_tracks_equal_the_oracle():
+    d = run_bench("--config", "3", "--frames-per-gpu", "6")
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    p = d["parity"]
+    assert p["ok"] is True and p["ranks_checked"] == 2 and p["pairs_mismatching"] == 0 and p["pairs_checked_against_oracle"] == 4
+    assert p["halo_tracks_checked_against_oracle"] == 1 and p["halo_tracks_mismatching"] == 0      # rank 1's first frame
+
+
+def test_default_workload_two_ranks_weak_scaling_line():
+    d = run_bench("--frames-per-gpu", "16")
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["parity"]["ok"] is True
+    assert d["parity"]["records_gathered"] == 32
