@@ -560,6 +560,10 @@ def main():
                        "parallelism": "frame-batch data parallel, %d rank(s), gather of result tables to rank 0" % world},
             "roofline": roof,
         }
+        rs = fe.lsd_round_stats()
+        out["lsd_rounds"] = {"launched_without_host_look": rs[0], "needed_by_slowest_image": rs[1], "images_redone_by_device_fallback": rs[2],
+                             "note": "relaxation rounds per step; an image that has not settled after the launched rounds is redone on the "
+                                     "device by the sequential grower (exact, slow): needed = -1 would flag it"}
         if world > 1:
             out["gather"] = {"bytes_per_rank_per_step": Fmax * rec_bytes, "bytes_at_root_per_step": world * Fmax * rec_bytes,
                              "backend": args.backend, "staged_through_host": bool(gath.staged)}

@@ -252,6 +252,16 @@ pli_status pli_line_extract(pli_ctx* ctx, int32_t eye,
                             pli_keyline* kl, int32_t cap, uint8_t* desc /* cap x 32 */,
                             int32_t* n);
 
+/* Diagnostics of the LSD relaxation schedule (lsd_mode 1 / 3; results never depend on it).  After the first call on a context
+ * the relaxation rounds are launched WITHOUT a host look: as many as the slowest image of an earlier call needed plus a margin,
+ * an image that is not at its fixed point after them is redone on the device by the sequential grower (exact, slow), and no
+ * entry point drains the stream in the middle of a call.  Synchronises the context.
+ *   out[0] rounds the last call launched without looking (0: it looked at the state, as every first call does)
+ *   out[1] rounds the slowest image of that call needed (-1: at least one image did not settle and took the slow path)
+ *   out[2] images that took the slow path since the context was created
+ *   out[3] the round count the next call plans from */
+pli_status pli_lsd_round_stats(pli_ctx* ctx, int32_t out[4]);
+
 /* The stereo rig of Frame::ComputeStereoMatches (Frame.cc:1005-1008: minZ = mb, maxD = mbf / minZ, depth = mbf / disparity):
  * replaces pli_frontend_config.bf / .fx of an existing context (the extractors' constructors, which create the context in
  * the adapters, do not know the camera; the Frame does: mbf and mK(0,0)).  A no-op when the values are the ones in use. */

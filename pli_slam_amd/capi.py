@@ -111,6 +111,7 @@ _PROTOS = {
                                           C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "pli_line_extract": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p,
                                      C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]),
+    "pli_lsd_round_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
     "pli_set_stereo_camera": (C.c_int32, [C.c_void_p, C.c_float, C.c_float]),
     "pli_last_counts": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
     "pli_stereo_match_points": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),

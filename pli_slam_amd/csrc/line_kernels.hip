@@ -1214,6 +1214,18 @@ __global__ __launch_bounds__(64) void k_lsd_grow(const DevParams* __restrict__ P
                                                  int* __restrict__ nSeg, int maxSeg, int img0, int nimg) {
   lsd_grow_image<1>(Pp, recAll, mgAll, orderAll, nDefined, regOverflow, segAll, nSeg, maxSeg, img0, nimg);
 }
+// The relaxations' fallback without a host look: one wave per image, and only the images whose relaxation did not reach its fixed
+// point in the rounds that were launched (or ran out of a capacity) are grown again, sequentially; the others leave at once.
+__global__ __launch_bounds__(64) void k_lsd_grow_unsettled(const DevParams* __restrict__ Pp, float4* __restrict__ recAll, const double* __restrict__ mgAll,
+                                                           const int* __restrict__ orderAll, const int* __restrict__ nDefined,
+                                                           uint2* __restrict__ regOverflow, float* __restrict__ segAll,
+                                                           int* __restrict__ nSeg, int maxSeg, int img0, int nimg,
+                                                           RxCtl* __restrict__ ctl) {
+  RxCtl& c = ctl[blockIdx.x + img0];
+  if (c.state == 2 && !c.overflow) return;
+  if (threadIdx.x == 0) c.races = -1;                   // (noted for the host: this image took the slow path)
+  lsd_grow_image<1>(Pp, recAll, mgAll, orderAll, nDefined, regOverflow, segAll, nSeg, maxSeg, img0, nimg);
+}
 __global__ __launch_bounds__(128) void k_lsd_grow2(const DevParams* __restrict__ Pp, float4* __restrict__ recAll, const double* __restrict__ mgAll,
                                                    const int* __restrict__ orderAll, const int* __restrict__ nDefined,
                                                    uint2* __restrict__ regOverflow, float* __restrict__ segAll,

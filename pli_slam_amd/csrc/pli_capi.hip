@@ -101,7 +101,17 @@ struct pli_ctx {
   std::vector<RxCtl> jrHost;
   int lsdMode = 0;     // 0 auto, 1 relaxation, 2 sequential, 3 tile-sequential relaxation (cfg.lsd_mode, or PLI_LSD_MODE)
   bool lsdSpec = !(getenv("PLI_LSD_SPEC") != nullptr && atoi(getenv("PLI_LSD_SPEC")) == 0);  // speculative sequential grower (PLI_LSD_SPEC=0: the plain one)
-  int rxLastRounds = 0; // rounds the relaxation ran in the previous call (where the host starts looking at the state)
+  int rxLastRounds = 0; // rounds the relaxation needed in an earlier call (the last one whose control blocks the host has seen)
+  // Rounds without a host look (the default once rxLastRounds is known): the call launches rxLastRounds + rxMargin rounds — kernels
+  // of a settled image leave at once —, k_lsd_grow_unsettled redoes, on the device, whatever image did not settle in them, and the
+  // control blocks come back asynchronously (rxSeen / evRxSeen) to be read at the start of a later call.  The call never drains the
+  // stream, so copies and kernels of neighbouring calls overlap (pli_batch_submit_host, the multi-GPU gather).
+  int rxMargin = 3;
+  int rxPlanned = 0;                // rounds the last call launched without looking (0: it looked)
+  int* rxSeen = nullptr;            // pinned: {state, changed, overflow, rounds} per image of the last look-free call
+  hipEvent_t evRxSeen = nullptr;
+  int rxSeenImages = 0;             // images behind rxSeen while the copy is in flight (0: nothing pending)
+  int64_t rxSlowImages = 0;         // images that took the device-side fallback so far (pli_prof_report prints it)
   unsigned short* chunkHist = nullptr; int* chunkBase = nullptr; int* nDefined = nullptr;
   int* order = nullptr; uint2* regScratch = nullptr; float* seg = nullptr; int* nSeg = nullptr;
   LsdRectItem* rectItems = nullptr;          // sequential grower -> k_lsd_rect (maxSeg per image)
@@ -817,10 +827,27 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     const dim3 raster((P.LW + 255) / 256, P.LH, nimg);
     const bool tile = c->lsdMode != 1;      // auto below RX_AUTO_IMAGES and mode 3: the tile-sequential relaxation
     bool allDone = false;
+    // what the last look-free call left behind (if its copy has arrived): how many rounds its slowest image needed
+    if (c->rxSeenImages > 0 && hipEventQuery(c->evRxSeen) == hipSuccess) {
+      int settled = 0, slow = 0;
+      for (int i = 0; i < c->rxSeenImages; ++i) {
+        const int* h = c->rxSeen + 4 * i;
+        if (h[0] == 2 && !h[2]) settled = std::max(settled, h[3]); else ++slow;
+      }
+      c->rxSlowImages += slow;
+      if (slow) c->rxLastRounds = std::min(maxRounds, c->rxLastRounds + c->rxMargin);   // not enough rounds: plan more next time
+      else if (settled > 0) c->rxLastRounds = std::max(settled, c->rxLastRounds - 1);      // (follows a calmer stream down slowly)
+      c->rxSeenImages = 0;
+    }
+    const bool blocking = c->rxLastRounds == 0 || trace || getenv("PLI_RX_BLOCKING") != nullptr;
+    if (!blocking) maxRounds = std::min(maxRounds, c->rxLastRounds + c->rxMargin);
+    if (!blocking) if (const char* e = getenv("PLI_RX_PLAN")) maxRounds = std::max(1, atoi(e));   // dev / test: a plan that is too short
+    c->rxPlanned = blocking ? 0 : maxRounds;
     const int firstLook = c->rxLastRounds > 0 ? std::max(4, c->rxLastRounds) : 4;
     auto look = [&](int t) -> pli_status {
       // the host looks at the state every second round, starting where the previous call on this context ended (a
       // stream of similar frames settles after a similar number of rounds; each look drains the stream)
+      if (!blocking) return PLI_OK;
       if ((t >= firstLook && ((t - firstLook) % 2) == 0) || t == maxRounds) {
         HIPCHK(hipMemcpyAsync(c->jrHost.data(), c->jrCtl + img0, sizeof(RxCtl) * nimg, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -956,10 +983,25 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     TRL(c, "k_rx_emit", k_rx_emit, dim3(c->rxChunks, nimg), dim3(256), 0, c->jrCtl, c->order, c->nDefined, c->own, c->lastSize,
            c->rgSeg, c->rxChunkCnt, c->rxChunks, npix64, P.minRegSize, c->seg, c->nSeg, c->maxSeg, img0);
     // images that ran out of a capacity (or did not settle) take the sequential grower
-    for (int i = 0; i < nimg; ++i) {
-      if (c->jrHost[i].overflow || c->jrHost[i].state != 2) {
-        LAUNCH(c, "k_lsd_grow", k_lsd_grow, dim3(1), dim3(64), 0, c->dP, c->rec, c->mg, c->order, c->nDefined,
-               c->regScratch, c->seg, c->nSeg, c->maxSeg, img0 + i, 1);
+    if (blocking) {
+      for (int i = 0; i < nimg; ++i) {
+        if (c->jrHost[i].overflow || c->jrHost[i].state != 2) {
+          LAUNCH(c, "k_lsd_grow", k_lsd_grow, dim3(1), dim3(64), 0, c->dP, c->rec, c->mg, c->order, c->nDefined,
+                 c->regScratch, c->seg, c->nSeg, c->maxSeg, img0 + i, 1);
+        }
+      }
+    } else {
+      // ... decided on the device: the waves of the settled images leave at once
+      LAUNCH(c, "k_lsd_grow_unsettled", k_lsd_grow_unsettled, dim3(nimg), dim3(64), 0, c->dP, c->rec, c->mg, c->order, c->nDefined,
+             c->regScratch, c->seg, c->nSeg, c->maxSeg, img0, nimg, c->jrCtl);
+      if (!c->rxSeen) {
+        HIPCHK(hipHostMalloc((void**)&c->rxSeen, sizeof(int) * 4 * (size_t)c->NI, hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&c->evRxSeen, hipEventDisableTiming));
+      }
+      if (c->rxSeenImages == 0) {                       // (an earlier copy still in flight keeps the buffer: this call is not sampled)
+        HIPCHK(hipMemcpy2DAsync(c->rxSeen, 16, c->jrCtl + img0, sizeof(RxCtl), 16, nimg, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipEventRecord(c->evRxSeen, c->stream));
+        c->rxSeenImages = nimg;
       }
     }
   }
@@ -1110,6 +1152,7 @@ void pli_ctx_destroy(pli_ctx* c) {
     if (c->hs[s].h2d) { hipEventDestroy(c->hs[s].h2d); hipEventDestroy(c->hs[s].kern); hipEventDestroy(c->hs[s].d2h); }
   }
   if (c->sH2D) { hipStreamDestroy(c->sH2D); hipStreamDestroy(c->sD2H); }
+  if (c->rxSeen) { hipHostFree(c->rxSeen); hipEventDestroy(c->evRxSeen); }
   delete c;
 }
 
@@ -1406,6 +1449,31 @@ pli_status pli_line_extract(pli_ctx* c, int32_t eye, const uint8_t* img, int32_t
     if (kl) HIPCHK(hipMemcpy(kl, c->ownTable + Y.off_kl[eye], (size_t)N * sizeof(pli_keyline), hipMemcpyDeviceToHost));
     if (desc) HIPCHK(hipMemcpy(desc, c->ownTable + Y.off_ldesc[eye], (size_t)N * 32, hipMemcpyDeviceToHost));
   }
+  return PLI_OK;
+}
+
+pli_status pli_lsd_round_stats(pli_ctx* c, int32_t out[4]) {
+  CtxGuard guard__(c);
+  if (!c || !out) { g_err = "bad argument"; return PLI_ERR_INVALID; }
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->rxSeenImages > 0 && hipEventQuery(c->evRxSeen) == hipSuccess) {      // fold in the last look-free call (as the next call would)
+    int settled = 0, slow = 0;
+    for (int i = 0; i < c->rxSeenImages; ++i) {
+      const int* h = c->rxSeen + 4 * i;
+      if (h[0] == 2 && !h[2]) settled = std::max(settled, h[3]); else ++slow;
+    }
+    c->rxSlowImages += slow;
+    if (slow) c->rxLastRounds = std::min(96, c->rxLastRounds + c->rxMargin);
+    else if (settled > 0) c->rxLastRounds = std::max(settled, c->rxLastRounds - 1);
+    c->rxSeenImages = 0;
+    out[1] = slow ? -1 : settled;
+  } else {
+    out[1] = c->rxLastRounds;
+  }
+  out[0] = c->rxPlanned;
+  out[2] = (int32_t)std::min<int64_t>(c->rxSlowImages, INT32_MAX);
+  out[3] = c->rxLastRounds;
   return PLI_OK;
 }
 

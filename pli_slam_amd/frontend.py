@@ -298,6 +298,13 @@ class Frontend:
         check(self.L.pli_batch_run(self.h, nframes, C.c_void_p(dev_left), C.c_void_p(dev_right), stride, frame_stride,
                                    stages, C.c_void_p(dev_table)))
 
+    def lsd_round_stats(self):
+        """(rounds launched without a look by the last call, rounds its slowest image needed or -1, images that took the
+        device-side fallback so far, rounds the next call plans from) — pli_lsd_round_stats; synchronises."""
+        out = (C.c_int32 * 4)()
+        check(self.L.pli_lsd_round_stats(self.h, out))
+        return tuple(int(v) for v in out)
+
     def sync(self):
         check(self.L.pli_ctx_sync(self.h))
 

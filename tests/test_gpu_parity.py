@@ -1065,3 +1065,34 @@ def test_truncation_is_flagged_not_silent(gpu):
     m, kl, ld = fe.line_extract(0, L)
     om, okl, old = g.po.Frame(ocfg(g, cfg)).line_extract(0, L)
     assert m == om == 50 and kl.tobytes() == okl.tobytes()
+
+
+def test_look_free_rounds_and_device_side_fallback(gpu, monkeypatch):
+    """After its first call a context launches the relaxation rounds without a host look (pli_lsd_round_stats).  With a plan that
+    is deliberately too short (dev switch PLI_RX_PLAN) the images that have not settled are redone on the device by the sequential
+    grower: slow, and still the oracle's result, byte for byte."""
+    g = gpu
+    W, H = 752, 480
+    cfg = g.capi.default_config(W, H, orb_nfeatures=1200, lsd_nfeatures=100, max_frames=4)
+    fe = g.Frontend(cfg)
+    pairs = [g.synth.make_stereo_pair(60 + i, W, H) for i in range(4)]
+    imgs = np.stack([np.stack(p) for p in pairs])
+    first = fe.batch_run_host(imgs)                          # the first call looks (and learns the round count)
+    st = fe.lsd_round_stats()
+    assert st[0] == 0 and st[3] >= 4
+    again = fe.batch_run_host(imgs)                          # look-free
+    st = fe.lsd_round_stats()
+    assert st[0] >= st[1] > 0 and st[2] == 0, st             # planned >= needed, nobody took the slow path
+    monkeypatch.setenv("PLI_RX_PLAN", "3")
+    short = fe.batch_run_host(imgs)                          # three rounds are not enough: the device-side fallback
+    st = fe.lsd_round_stats()
+    assert st[0] == 3 and st[1] == -1 and st[2] >= 1, st
+    monkeypatch.delenv("PLI_RX_PLAN")
+    later = fe.batch_run_host(imgs)
+    for f, (L, R) in enumerate(pairs):
+        for recs, what in ((first, "look"), (again, "look-free"), (short, "fallback"), (later, "after the fallback")):
+            if f == 0 or recs is short:
+                assert_frame_equal(g, recs[f], g.po.Frame(ocfg(g, cfg)), L, R, "%s frame %d" % (what, f))
+            else:
+                for k in ("klL", "klR", "ldescL", "ldescR", "disp", "le"):
+                    assert recs[f][k].tobytes() == first[f][k].tobytes(), (what, f, k)
