@@ -255,8 +255,10 @@ pli_status pli_line_extract(pli_ctx* ctx, int32_t eye,
 /* Diagnostics of the LSD relaxation schedule (lsd_mode 1 / 3; results never depend on it).  After the first call on a context
  * the relaxation rounds are launched WITHOUT a host look: as many as the slowest image of an earlier call needed plus a margin,
  * an image that is not at its fixed point after them is redone on the device by the sequential grower (exact, slow), and no
- * entry point drains the stream in the middle of a call.  Synchronises the context.
- *   out[0] rounds the last call launched without looking (0: it looked at the state, as every first call does)
+ * entry point drains the stream in the middle of a call.  (The tile relaxation needs no plan: its rounds from the third or fourth on
+ * run in one persistent launch that ends when every image is at its fixed point.)  Synchronises the context.
+ *   out[0] rounds the last call launched without looking; -1: the tile relaxation's persistent tail kernel ran the late rounds and
+ *          stopped by itself at the fixed point (the default schedule of lsd_mode 3 / auto); 0: the host looked at the state
  *   out[1] rounds the slowest image of that call needed (-1: at least one image did not settle and took the slow path)
  *   out[2] images that took the slow path since the context was created
  *   out[3] the round count the next call plans from */

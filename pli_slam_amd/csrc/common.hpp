@@ -115,6 +115,34 @@ struct TxDirtyLists {
   int64_t npix;
 };
 
+// arguments of k_tx_tail (lsd_tile.hip): the rounds t >= t0 of the tile relaxation in one persistent launch
+struct TxTailArgs {
+  const DevParams* Pp;
+  RxCtl* ctl;
+  const float4* rec;
+  int2* own;
+  const int2* list;
+  const int* tileCnt;
+  int ts, ntx, nty;
+  int* rgSize;
+  int2* rgBox;
+  int* rgDirty;
+  int* tileAct;
+  int* tileTouch;
+  int TW, TH;
+  int* arena;
+  int arenaCap;
+  RxRect* rects;
+  int rectCap;
+  float4* rgSeg;
+  const double* mg;
+  const int* rank;
+  int* rgLost;
+  TxDirtyLists DL;
+  int img0, nimg, t0, maxRounds;
+  unsigned* bar;       // [0] arrivals (zeroed by the host before the launch), [32] abort word (its own line)
+};
+
 // a region in mid-growth, handed from the lane grower to the wave grower
 struct RxHand {
   int rank, k, cnt;

@@ -31,6 +31,7 @@
 // last run was that large.
 #include "kernels.hpp"
 #include "device_prims.hpp"
+#include "lsd_rect.hpp"
 #include <climits>
 #include <type_traits>
 
@@ -38,10 +39,6 @@ namespace pli {
 
 constexpr float RX_NOTDEF = -1024.f;
 constexpr int RX_INF = 0x7F7F7F7F;          // rank plane of undefined pixels (hipMemset 0x7F)
-constexpr double RX_PI = 3.14159265358979323846;
-constexpr double RX_DEG2RAD = RX_PI / 180;
-constexpr double RX_3_2_PI = (3 * RX_PI) / 2;
-constexpr double RX_2PI = 2 * RX_PI;
 
 __device__ __forceinline__ int2 rx_load_own(const int2* p) {
   // bypass the per-CU L1: claims of other workgroups (and our own atomics) are served from L2 / memory
@@ -57,12 +54,6 @@ __device__ __forceinline__ int rx_lds_read(const int* p) {
   return *(lds_cvint*)p;
 }
 
-__device__ __forceinline__ double rx_angle_diff(double a, double b) {
-  double diff = a - b;
-  while (diff <= -RX_PI) diff += RX_2PI;
-  while (diff > RX_PI) diff -= RX_2PI;
-  return fabs(diff);
-}
 
 // Block-wide stream compaction: position of this thread's element in a list whose counter gets ONE atomic per
 // block (same-address returning atomics serialise at their L2 channel, ~150 ns each).  lds: 17 ints, up to 1024 threads.
@@ -835,125 +826,6 @@ __global__ __launch_bounds__(64) void k_rx_grow_wave(const DevParams* __restrict
                            rectAll, rectCap, img0, t);
 }
 
-// ---- region2rect of the regions completed in this round (lsd.cpp region2rect / get_theta) --------------
-// The running sums are accumulated in list order by three lanes (bit-exact with the sequential loop), the products are
-// computed a row of lanes at a time.  Most regions are small (46 pixels on average at 752x480), so a wave takes FOUR list
-// entries at a time, 16 lanes each (the three serial sums of the four regions run side by side); a region of more than
-// RX_RECT_GROUP_MAX pixels is left to the whole wave (LANES = 64), which does it right after its group of four.
-constexpr int RX_RECT_GROUP_MAX = 192;
-
-__device__ __forceinline__ void rx_wave_sync() {
-  // single-wave workgroups: the LDS operations of a wave execute in order, the compiler only has to keep the order
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// LANES lanes (a whole wave, or an aligned group of 16) compute the segment of one region; `on` = this group has one
-template <int LANES>
-__device__ __forceinline__ void rx_rect_region(bool on, const RxRect& it, const DevParams& P, const float4* __restrict__ rec,
-                                               const double* __restrict__ mg, const int* __restrict__ arena,
-                                               float4* __restrict__ rgSeg, double (*st)[64]) {
-  const int lane = threadIdx.x, gl = lane & (LANES - 1), g0 = lane & ~(LANES - 1);
-  const int W = P.LW;
-  const double prec = P.prec;
-  const int cnt = on ? it.cnt : 0;
-  const int* lst = arena + it.off;
-  const double reg_angle = (double)fast_atan2_deg(it.sumdy, it.sumdx) * RX_DEG2RAD;
-  // (the trip count of the group with the longest list: the passes below run in step over the wave)
-  int cmax = cnt;
-#pragma unroll
-  for (int o = 32; o >= LANES; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o, 64));
-  double acc = 0.0;
-  for (int c0 = 0; c0 < cmax; c0 += LANES) {
-    const int kk = c0 + gl;
-    double v0 = 0.0, v1 = 0.0, v2 = 0.0;                  // lanes past the end add +0.0 (the sums are never -0.0)
-    if (kk < cnt) {
-      const int e = lst[kk];
-      const int ex = e & 0xFFFF, ey = e >> 16;
-      const double w = mg ? mg[ey * W + ex] : sqrt((double)__float_as_int(rec[ey * W + ex].w) / 4.0);
-      v0 = (double)ex * w;
-      v1 = (double)ey * w;
-      v2 = w;
-    }
-    rx_wave_sync();
-    st[0][lane] = v0; st[1][lane] = v1; st[2][lane] = v2;
-    rx_wave_sync();
-    if (gl < 3 && c0 < cnt) {
-      // list-order sum, eight terms per trip: the LDS reads of a trip are issued together, the adds stay in order
-      const int mm = (min(LANES, cnt - c0) + 7) & ~7;
-      for (int tt = 0; tt < mm; tt += 8) {
-        double a[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) a[u] = st[gl][g0 + tt + u];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc += a[u];
-      }
-    }
-  }
-  // (the two centroid divisions are one division in lanes 0 and 1, the four end-point divisions one in lanes 0..3)
-  const double cq = acc / __shfl(acc, g0 + 2, 64);
-  const double x = __shfl(cq, g0, 64), y = __shfl(cq, g0 + 1, 64);
-  acc = 0.0;
-  for (int c0 = 0; c0 < cmax; c0 += LANES) {
-    const int kk = c0 + gl;
-    double v0 = 0.0, v1 = 0.0, v2 = 0.0;                  // past the end: acc + 0.0 and acc - 0.0 leave acc as it is
-    if (kk < cnt) {
-      const int e = lst[kk];
-      const int ex = e & 0xFFFF, ey = e >> 16;
-      const double w = mg ? mg[ey * W + ex] : sqrt((double)__float_as_int(rec[ey * W + ex].w) / 4.0);
-      const double dx = (double)ex - x, dy = (double)ey - y;
-      v0 = dy * dy * w;
-      v1 = dx * dx * w;
-      v2 = dx * dy * w;
-    }
-    rx_wave_sync();
-    st[0][lane] = v0; st[1][lane] = v1; st[2][lane] = v2;
-    rx_wave_sync();
-    if (gl < 3 && c0 < cnt) {
-      const int mm = (min(LANES, cnt - c0) + 7) & ~7;
-      for (int tt = 0; tt < mm; tt += 8) {
-        double a[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) a[u] = st[gl][g0 + tt + u];
-        if (gl < 2) {
-#pragma unroll
-          for (int u = 0; u < 8; ++u) acc += a[u];
-        } else {
-#pragma unroll
-          for (int u = 0; u < 8; ++u) acc -= a[u];
-        }
-      }
-    }
-  }
-  const double Ixx = __shfl(acc, g0, 64), Iyy = __shfl(acc, g0 + 1, 64), Ixy = __shfl(acc, g0 + 2, 64);
-  const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
-  const bool wide = fabs(Ixx) > fabs(Iyy);
-  double theta = (double)fast_atan2_deg(wide ? (float)(lambda - Ixx) : (float)Ixy, wide ? (float)Ixy : (float)(lambda - Iyy));
-  theta *= RX_DEG2RAD;
-  if (rx_angle_diff(theta, reg_angle) > prec) theta += RX_PI;
-  double dxr, dyr;
-  sincos(theta, &dyr, &dxr);
-  double l_min = 0, l_max = 0;
-  for (int kk = gl; kk < cnt; kk += LANES) {
-    const int e = lst[kk];
-    const double l = ((double)(e & 0xFFFF) - x) * dxr + ((double)(e >> 16) - y) * dyr;
-    l_max = fmax(l_max, l);
-    l_min = fmin(l_min, l);
-  }
-#pragma unroll
-  for (int o = LANES / 2; o > 0; o >>= 1) {
-    l_max = fmax(l_max, __shfl_xor(l_max, o, 64));
-    l_min = fmin(l_min, __shfl_xor(l_min, o, 64));
-  }
-  // lanes 0..3: x1, y1, x2, y2
-  double e = ((gl & 1) ? y : x) + ((gl & 2) ? l_max : l_min) * ((gl & 1) ? dyr : dxr);
-  e += 0.5;
-  const double scale = P.lsdScale;
-  if (scale != 1) e /= scale;
-  if (on && gl < 4) reinterpret_cast<float*>(&rgSeg[it.rank])[gl] = (float)e;
-}
-
 __global__ __launch_bounds__(64) void k_rx_rect(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
                                                 const float4* __restrict__ recAll, const int* __restrict__ arenaAll,
                                                 int arenaCap, const RxRect* __restrict__ rectAll, int rectCap,
@@ -963,30 +835,9 @@ __global__ __launch_bounds__(64) void k_rx_rect(const DevParams* __restrict__ Pp
   const int img = blockIdx.y + img0;
   const RxCtl& c = ctl[img];
   if (c.state == 2 || c.overflow) return;
-  const int nrect = min((int)(c.rectArena >> RX_ARENA_BITS), rectCap);
   const int64_t npix = (int64_t)P.LW * P.LH;
-  const float4* rec = recAll + img * npix;
-  const double* mg = mgAll ? mgAll + img * npix : nullptr;       // CV_64F pipeline: the gradient norm as a double plane
-  const int* arena = arenaAll + (int64_t)img * arenaCap;
-  const RxRect* rects = rectAll + (int64_t)img * rectCap;
-  float4* rgSeg = rgSegAll + img * npix;
-  const int lane = threadIdx.x, g = lane >> 4;
-  for (int w0 = blockIdx.x * 4; w0 < nrect; w0 += gridDim.x * 4) {
-    RxRect it = {0, 0, 0, 1.f, 0.f};
-    const bool have = w0 + g < nrect;
-    if (have) it = rects[w0 + g];
-    const bool small = have && it.cnt <= RX_RECT_GROUP_MAX;
-    if (__builtin_amdgcn_ballot_w64(small)) rx_rect_region<16>(small, it, P, rec, mg, arena, rgSeg, st);
-    unsigned long long big = __builtin_amdgcn_ballot_w64(have && !small) & 0x0001000100010001ull;   // one bit per group
-    while (big) {
-      const int gl0 = __ffsll((long long)big) - 1;
-      big &= big - 1ull;
-      RxRect bt;
-      bt.rank = __shfl(it.rank, gl0, 64); bt.off = __shfl(it.off, gl0, 64); bt.cnt = __shfl(it.cnt, gl0, 64);
-      bt.sumdx = __shfl(it.sumdx, gl0, 64); bt.sumdy = __shfl(it.sumdy, gl0, 64);
-      rx_rect_region<64>(true, bt, P, rec, mg, arena, rgSeg, st);
-    }
-  }
+  rx_rect_wave(P, c, recAll + img * npix, mgAll ? mgAll + img * npix : nullptr /* CV_64F pipeline: the gradient norm as a double plane */,
+               arenaAll + (int64_t)img * arenaCap, rectAll + (int64_t)img * rectCap, rectCap, rgSegAll + img * npix, blockIdx.x, gridDim.x, st);
 }
 
 // ---- segments in seed-rank order (= detection order of the sequential algorithm) ------------------------

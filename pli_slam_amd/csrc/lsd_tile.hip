@@ -21,6 +21,7 @@
 // what k_rx_mark stamps dirty.
 #include "kernels.hpp"
 #include "device_prims.hpp"
+#include "lsd_rect.hpp"
 #include <climits>
 #include <type_traits>
 
@@ -167,7 +168,8 @@ __global__ __launch_bounds__(256) void k_tx_sort(const int* __restrict__ rankAll
                                                  int* __restrict__ tileCntAll, int W, int H, int ts, int ntx, int nty, int img0) {
   __shared__ unsigned xch[16 * 256 + 256];
   if (ts == 64) tx_sort_tile<16, 256>(rankAll, orderAll, ownAll, listAll, tileCntAll, W, H, ts, ntx, nty, img0, xch);
-  else tx_sort_tile<4, 256>(rankAll, orderAll, ownAll, listAll, tileCntAll, W, H, ts, ntx, nty, img0, xch);
+  else if (ts == 32) tx_sort_tile<4, 256>(rankAll, orderAll, ownAll, listAll, tileCntAll, W, H, ts, ntx, nty, img0, xch);
+  else tx_sort_tile<1, 256>(rankAll, orderAll, ownAll, listAll, tileCntAll, W, H, ts, ntx, nty, img0, xch);
 }
 // tiles of 128 x 128 (large batches): 1024 threads x 16 keys, 10 of the 105 stages through LDS
 __global__ __launch_bounds__(1024) void k_tx_sort128(const int* __restrict__ rankAll, const int* __restrict__ orderAll,
@@ -403,34 +405,33 @@ __global__ __launch_bounds__(256) void k_tx_mark(RxCtl* __restrict__ ctl, const 
 // "Nothing changed anywhere" is known only when the kernel ends: the round's k_tx_prep tests the flag (one flag per round
 // parity: it clears the other one for the next round) and declares the fixed point.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tx_diffmark(RxCtl* __restrict__ ctl, const int2* __restrict__ ownAll,
-                                                     const int* __restrict__ rankAll, const int2* __restrict__ rgBoxAll,
-                                                     int* __restrict__ rgDirtyAll, int* __restrict__ tileActAll,
-                                                     const int* __restrict__ tileTouchAll, int W, int H, int TW, int TH, int t,
-                                                     int img0, const int* __restrict__ rgLostAll, TxDirtyLists DL) {
+// (one block's share: the 4 x 8 cells at (bx, by) of image img; a kernel of its own — k_tx_diffmark — and a phase of k_tx_tail)
+__device__ __forceinline__ void tx_diffmark_block(RxCtl* ctl, const int2* ownAll, const int* rankAll, const int2* rgBoxAll,
+                                                  int* rgDirtyAll, int* tileActAll, const int* tileTouchAll, int W, int H, int TW,
+                                                  int TH, int t, int bx, int by, int img, const int* rgLostAll,
+                                                  const TxDirtyLists& DL) {
   __shared__ int s_rel[8][4];
   __shared__ int s_chg[8][4];
   __shared__ int s_n;
   __shared__ unsigned short lst[2048];
-  const int img = blockIdx.z + img0;
   RxCtl& c = ctl[img];
   if (c.state == 2) return;
   const int tid = threadIdx.x;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { c.nSmall = 0; c.nBig = 0; c.nHand = 0; c.nextBig = 0; c.rectArena = 0ull; }
+  if (bx == 0 && by == 0 && tid == 0) { c.nSmall = 0; c.nBig = 0; c.nHand = 0; c.nextBig = 0; c.rectArena = 0ull; }
   if (tid == 0) s_n = 0;
   if (tid < 32) {
-    const int ty = (int)blockIdx.y * 8 + (tid >> 2), tx = (int)blockIdx.x * 4 + (tid & 3);
+    const int ty = by * 8 + (tid >> 2), tx = bx * 4 + (tid & 3);
     s_rel[tid >> 2][tid & 3] = (ty < TH && tx < TW) ? tileTouchAll[(int64_t)img * TW * TH + ty * TW + tx] == t - 1 : 0;
     s_chg[tid >> 2][tid & 3] = 0;
   }
   __syncthreads();
   const int64_t base = (int64_t)img * W * H;
   const int lx = tid & 31, ly = tid >> 5;
-  const int x = blockIdx.x * 32 + lx;
+  const int x = bx * 32 + lx;
   int2 o[8];
 #pragma unroll
   for (int rr = 0; rr < 8; ++rr) {
-    const int y = (blockIdx.y * 8 + rr) * 8 + ly;
+    const int y = (by * 8 + rr) * 8 + ly;
     o[rr] = make_int2(0, 0);
     if (s_rel[rr][lx >> 3] && x < W && y < H) o[rr] = ownAll[base + y * W + x];
   }
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(256) void k_tx_diffmark(RxCtl* __restrict__ ctl, co
   if (n == 0) return;
   int* tileAct = tileActAll + (int64_t)img * TW * TH;
   if (tid < 32 && s_chg[tid >> 2][tid & 3]) {
-    const int ty = (int)blockIdx.y * 8 + (tid >> 2), tx = (int)blockIdx.x * 4 + (tid & 3);
+    const int ty = by * 8 + (tid >> 2), tx = bx * 4 + (tid & 3);
     tileAct[ty * TW + tx] = t;                          // a changed cell is active
   }
   if (tid == 0) atomicOr((t & 1) ? &c.changedOdd : &c.changed, 1);
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(256) void k_tx_diffmark(RxCtl* __restrict__ ctl, co
     const int e = (int)(((unsigned)i * 7282u) >> 16);   // i / 9 for i < 2048 * 9
     const int k = i - 9 * e;
     const int li = lst[e];
-    const int px0 = blockIdx.x * 32 + (li & 31), py0 = blockIdx.y * 64 + (li >> 5);
+    const int px0 = bx * 32 + (li & 31), py0 = by * 64 + (li >> 5);
     const int2 oc = ownAll[base + py0 * W + px0];
     const int prevv = ci ? oc.x : oc.y, prev2 = ci ? oc.y : oc.x;
     if (k == 4) {
@@ -476,6 +477,15 @@ __global__ __launch_bounds__(256) void k_tx_diffmark(RxCtl* __restrict__ ctl, co
   }
 }
 
+__global__ __launch_bounds__(256) void k_tx_diffmark(RxCtl* __restrict__ ctl, const int2* __restrict__ ownAll,
+                                                     const int* __restrict__ rankAll, const int2* __restrict__ rgBoxAll,
+                                                     int* __restrict__ rgDirtyAll, int* __restrict__ tileActAll,
+                                                     const int* __restrict__ tileTouchAll, int W, int H, int TW, int TH, int t,
+                                                     int img0, const int* __restrict__ rgLostAll, TxDirtyLists DL) {
+  tx_diffmark_block(ctl, ownAll, rankAll, rgBoxAll, rgDirtyAll, tileActAll, tileTouchAll, W, H, TW, TH, t, blockIdx.x, blockIdx.y,
+                    blockIdx.z + img0, rgLostAll, DL);
+}
+
 // ---------------------------------------------------------------------------
 // k_tx_prep (rounds >= 2, after the diff and k_rx_mark): owner_t is rewritten in the active 8x8 cells only:
 // a pixel whose previous owner is carried (not stamped dirty) stays with it, any other falls back to its own
@@ -483,28 +493,26 @@ __global__ __launch_bounds__(256) void k_tx_diffmark(RxCtl* __restrict__ ctl, co
 // ---------------------------------------------------------------------------
 // (256 threads walk the 32 x 32 pixels of a block in four steps: most blocks leave after the activity test, and the cost of
 // that is per wave)
-__global__ __launch_bounds__(256) void k_tx_prep(RxCtl* __restrict__ ctl, int2* __restrict__ ownAll,
-                                                 const int* __restrict__ rankAll, const int* __restrict__ rgDirtyAll,
-                                                 const int* __restrict__ tileActAll, int W, int H, int TW, int TH, int t, int img0,
-                                                 int full, int* __restrict__ tileTouchAll) {
+__device__ __forceinline__ void tx_prep_block(RxCtl* ctl, int2* ownAll, const int* rankAll, const int* rgDirtyAll,
+                                              const int* tileActAll, int W, int H, int TW, int TH, int t, int bx, int by, int img,
+                                              int full, int* tileTouchAll) {
   __shared__ int s_act;
   __shared__ int s_cell[4][4];
-  const int img = blockIdx.z + img0;
   RxCtl& c = ctl[img];
   if (c.state == 2) return;
   const int tid = threadIdx.x;
   if (tileTouchAll) {
     // after k_tx_diffmark: the round's flag decides (every block reads the same value: nobody writes it in this kernel)
     if (((t & 1) ? c.changedOdd : c.changed) == 0) {
-      if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { c.state = 2; c.rounds = t; }
+      if (bx == 0 && by == 0 && tid == 0) { c.state = 2; c.rounds = t; }
       return;
     }
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { if (t & 1) c.changed = 0; else c.changedOdd = 0; }
-  } else if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) c.changed = 0;
+    if (bx == 0 && by == 0 && tid == 0) { if (t & 1) c.changed = 0; else c.changedOdd = 0; }
+  } else if (bx == 0 && by == 0 && tid == 0) c.changed = 0;
   if (tid == 0) s_act = full;                          // round 2: owner_t still holds the trivial map, every cell is rewritten
   __syncthreads();
   if (tid < 16) {
-    const int tx = blockIdx.x * 4 + (tid & 3), ty = blockIdx.y * 4 + (tid >> 2);
+    const int tx = bx * 4 + (tid & 3), ty = by * 4 + (tid >> 2);
     const int a = full || (tx < TW && ty < TH && tileActAll[(int64_t)img * TW * TH + ty * TW + tx] == t);
     s_cell[tid >> 2][tid & 3] = a;
     if (a) s_act = 1;
@@ -514,13 +522,13 @@ __global__ __launch_bounds__(256) void k_tx_prep(RxCtl* __restrict__ ctl, int2* 
   if (!s_act) return;
   const int64_t base = (int64_t)img * W * H;
   const int ci = t & 1;
-  const int x = blockIdx.x * 32 + (tid & 31);
+  const int x = bx * 32 + (tid & 31);
   // (the loads of the four rows first, then the dependent stamps, then the stores: a store between them would order them)
   int r[4], dirtyAt[4];
   int2 o[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int y = blockIdx.y * 32 + i * 8 + (tid >> 5);
+    const int y = by * 32 + i * 8 + (tid >> 5);
     r[i] = TX_INF;
     o[i] = make_int2(0, 0);
     // (a cell that is not active keeps its words: they are right)
@@ -534,7 +542,7 @@ __global__ __launch_bounds__(256) void k_tx_prep(RxCtl* __restrict__ ctl, int2* 
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     if (r[i] == TX_INF) continue;
-    const int y = blockIdx.y * 32 + i * 8 + (tid >> 5);
+    const int y = by * 32 + i * 8 + (tid >> 5);
     const int prevv = ci ? o[i].x : o[i].y;
     const int cur = dirtyAt[i] != t ? prevv : r[i];
     if (cur != (ci ? o[i].y : o[i].x)) {
@@ -542,6 +550,13 @@ __global__ __launch_bounds__(256) void k_tx_prep(RxCtl* __restrict__ ctl, int2* 
       ownAll[base + y * W + x] = o[i];
     }
   }
+}
+
+__global__ __launch_bounds__(256) void k_tx_prep(RxCtl* __restrict__ ctl, int2* __restrict__ ownAll,
+                                                 const int* __restrict__ rankAll, const int* __restrict__ rgDirtyAll,
+                                                 const int* __restrict__ tileActAll, int W, int H, int TW, int TH, int t, int img0,
+                                                 int full, int* __restrict__ tileTouchAll) {
+  tx_prep_block(ctl, ownAll, rankAll, rgDirtyAll, tileActAll, W, H, TW, TH, t, blockIdx.x, blockIdx.y, blockIdx.z + img0, full, tileTouchAll);
 }
 
 // ---------------------------------------------------------------------------
@@ -627,19 +642,16 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
                                              int2* __restrict__ rgBoxAll, const int* __restrict__ rgDirtyAll,
                                              const int* __restrict__ tileActAll, int TW, int TH,
                                              int* __restrict__ arenaAll, int arenaCap, RxRect* __restrict__ rectAll,
-                                             int rectCap, int img0, int t, const int* __restrict__ rankAll,
+                                             int rectCap, int img, int tile, int t, const int* __restrict__ rankAll,
                                              int* __restrict__ rgLostAll, int* __restrict__ tileTouchAll,
-                                             const TxDirtyLists& DL) {
-  __shared__ int q[TX_GQ];
-  __shared__ int gb[TX_BMAXBLK];
+                                             const TxDirtyLists& DL, int* q /* LDS, TX_GQ */, int* gb /* LDS, TX_BMAXBLK */) {
   const DevParams& P = *Pp;
-  const int img = blockIdx.y + img0, tile = blockIdx.x;
   RxCtl& c = ctl[img];
   if (c.state == 2 || c.overflow) return;
   const int ntile = ntx * nty;
   int n = tileCntAll[(int64_t)img * ntile + tile];
   if (n == 0) return;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const int W = P.LW, H = P.LH;
   const int64_t npix = (int64_t)W * H;
   // (later rounds) the seeds stamped dirty for this round were listed per tile by whoever stamped them: up to 64 of them are
@@ -928,8 +940,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                                                 int* __restrict__ arenaAll, int arenaCap, RxRect* __restrict__ rectAll,
                                                 int rectCap, int img0, int t, const int* __restrict__ rankAll,
                                                 int* __restrict__ rgLostAll, int* __restrict__ tileTouchAll, TxDirtyLists DL) {
-  tx_grow_tile<false>(Pp, ctl, recAll, ownAll, listAll, tileCntAll, ts, ntx, nty, rgSizeAll, rgBoxAll, rgDirtyAll, tileActAll,
-                      TW, TH, arenaAll, arenaCap, rectAll, rectCap, img0, t, rankAll, rgLostAll, tileTouchAll, DL);
+  __shared__ int q[TX_GQ];
+  __shared__ int gb[TX_BMAXBLK];
+  tx_grow_tile<false>(Pp, ctl, recAll, ownAll, listAll, tileCntAll, ts, ntx, nty, rgSizeAll, rgBoxAll, rgDirtyAll, tileActAll, TW, TH,
+                   arenaAll, arenaCap, rectAll, rectCap, blockIdx.y + img0, blockIdx.x, t, rankAll, rgLostAll, tileTouchAll, DL, q, gb);
 }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tx_grow_sparse(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
                                                        const float4* __restrict__ recAll, int2* __restrict__ ownAll,
@@ -940,8 +954,181 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                                                        int* __restrict__ arenaAll, int arenaCap, RxRect* __restrict__ rectAll,
                                                        int rectCap, int img0, int t, const int* __restrict__ rankAll,
                                                        int* __restrict__ rgLostAll, int* __restrict__ tileTouchAll, TxDirtyLists DL) {
-  tx_grow_tile<true>(Pp, ctl, recAll, ownAll, listAll, tileCntAll, ts, ntx, nty, rgSizeAll, rgBoxAll, rgDirtyAll, tileActAll,
-                     TW, TH, arenaAll, arenaCap, rectAll, rectCap, img0, t, rankAll, rgLostAll, tileTouchAll, DL);
+  __shared__ int q[TX_GQ];
+  __shared__ int gb[TX_BMAXBLK];
+  tx_grow_tile<true>(Pp, ctl, recAll, ownAll, listAll, tileCntAll, ts, ntx, nty, rgSizeAll, rgBoxAll, rgDirtyAll, tileActAll, TW, TH,
+                   arenaAll, arenaCap, rectAll, rectCap, blockIdx.y + img0, blockIdx.x, t, rankAll, rgLostAll, tileTouchAll, DL, q, gb);
+}
+
+// ---------------------------------------------------------------------------
+// k_tx_tail: the rounds t >= t0 of the tile relaxation in ONE persistent launch.  From the fourth round on a round is four
+// kernels of almost no work (at 256 frames: 133 000 + 267 000 + 69 000 + 32 000 workgroups that look at a flag and leave;
+// a single stereo pair: four launches of a few microseconds of work each), ~10 rounds of them, and the host cannot know the
+// last round without looking.  Here a resident grid walks the same blocks — tx_diffmark_block, tx_prep_block, tx_grow_tile,
+// rx_rect_wave: the code of the four kernels, unchanged — as VIRTUAL blocks / waves, with a grid barrier where a kernel
+// boundary was, and stops by itself when every image is at its fixed point (or out of a capacity).
+// The grid must be co-resident: the host sizes it from the occupancy of this kernel (pli_capi.hip).  A barrier that is not
+// passed within seconds (it cannot happen on a healthy device) raises the abort word, every block leaves, and the images
+// that have not settled take the device-side fallback like any other unsettled image.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool tx_grid_barrier(unsigned* bar, unsigned target) {
+  // One release (L2 write-back towards the other XCDs) and one acquire (L1 / stale-L2 invalidation) per BLOCK, by its first wave:
+  // the agent-scope fences are the expensive part of a grid barrier on this chip (every wave fencing on both sides of every barrier
+  // cost ~140 us per barrier with 2048 waves; the polls are relaxed loads for the same reason).  Each wave first waits for its own
+  // stores to be acknowledged by the L2, so that the one write-back covers them; the per-CU L1 is shared by the waves of a block, so
+  // the one invalidation serves them all.
+  __shared__ int s_ok;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int ok = 1;
+    unsigned spins = 0;
+    while (__hip_atomic_load(&bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(4);
+      if ((++spins & 63u) == 0u &&
+          (__hip_atomic_load(&bar[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || spins > (1u << 23))) {
+        __hip_atomic_store(&bar[32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    s_ok = ok;
+  }
+  __syncthreads();
+  asm volatile("s_dcache_inv" ::: "memory");           // (the scalar cache: uniform loads of flags and counters)
+  return s_ok != 0;
+}
+
+__global__ __launch_bounds__(256) void k_tx_tail(TxTailArgs A) {
+  __shared__ int qs[4][TX_GQ];
+  __shared__ int gbs[4][TX_BMAXBLK];
+  __shared__ double sts[4][3][64];
+  __shared__ int s_live, s_n;
+  __shared__ int s_list[256];
+  const DevParams& P = *A.Pp;
+  const int W = P.LW, H = P.LH;
+  const int64_t npix = (int64_t)W * H;
+  const int tid = threadIdx.x, wv = tid >> 6;
+  const int G = gridDim.x;
+  const int nbx = (W + 31) / 32, nbyA = (A.TH + 7) / 8, nbyB = (H + 31) / 32, ntile = A.ntx * A.nty, ncell = A.TW * A.TH;
+  const int64_t nA = (int64_t)nbx * nbyA * A.nimg, nB = (int64_t)nbx * nbyB * A.nimg, nC = (int64_t)ntile * A.nimg;
+  const int nwaves = G * 4, gw = blockIdx.x * 4 + wv;
+  auto relaxing = [&](int il) -> bool {
+    const RxCtl& c = A.ctl[A.img0 + il];
+    return c.state != 2 && c.overflow == 0;
+  };
+  // A block's candidates are the virtual blocks blockIdx.x, blockIdx.x + G, ...: 256 of them are TESTED at a time, one per thread
+  // (is there anything to do there at all?), the few that pass are listed in LDS and then run, one after the other, by the whole
+  // block.  The tests cost a pass over the cell stamps; the virtual blocks that do something are spread evenly over the grid.
+  unsigned epoch = 0;
+  for (int t = A.t0; t <= A.maxRounds; ++t) {
+    // ---- k_tx_diffmark: the 4 x 8 cell blocks with a cell touched in round t - 1 ----
+    for (int il = blockIdx.x * 256 + tid; il < A.nimg; il += G * 256) {          // (what block (0, 0) of the kernel does for its image)
+      RxCtl& c = A.ctl[A.img0 + il];
+      if (c.state != 2) { c.nSmall = 0; c.nBig = 0; c.nHand = 0; c.nextBig = 0; c.rectArena = 0ull; }
+    }
+    for (int64_t base = blockIdx.x; base < nA; base += (int64_t)G * 256) {
+      if (tid == 0) s_n = 0;
+      __syncthreads();
+      const int64_t v = base + (int64_t)tid * G;
+      if (v < nA) {
+        const int il = (int)(v / (nbx * nbyA)), rem = (int)(v - (int64_t)il * (nbx * nbyA));
+        const int bx = rem % nbx, by = rem / nbx;
+        bool act = false;
+        if (relaxing(il)) {
+          const int* tt = A.tileTouch + (int64_t)(A.img0 + il) * ncell;
+          for (int cy = by * 8; cy < min(by * 8 + 8, A.TH); ++cy)
+            for (int cx = bx * 4; cx < min(bx * 4 + 4, A.TW); ++cx) act = act || tt[cy * A.TW + cx] == t - 1;
+        }
+        if (act) s_list[atomicAdd(&s_n, 1)] = (int)((v - base) / G);
+      }
+      __syncthreads();
+      const int n = s_n;
+      for (int i = 0; i < n; ++i) {
+        const int64_t va = base + (int64_t)s_list[i] * G;
+        const int il = (int)(va / (nbx * nbyA)), rem = (int)(va - (int64_t)il * (nbx * nbyA));
+        tx_diffmark_block(A.ctl, A.own, A.rank, A.rgBox, A.rgDirty, A.tileAct, A.tileTouch, W, H, A.TW, A.TH, t, rem % nbx, rem / nbx,
+                          A.img0 + il, A.rgLost, A.DL);
+        __syncthreads();                                 // (the block's LDS lists are reused by the next virtual block)
+      }
+    }
+    if (!tx_grid_barrier(A.bar, ++epoch * G)) return;
+    // ---- k_tx_prep: the fixed point of an image whose round-t flag stayed clear; the 32 x 32 blocks with an active cell ----
+    for (int il = blockIdx.x * 256 + tid; il < A.nimg; il += G * 256) {
+      RxCtl& c = A.ctl[A.img0 + il];
+      if (c.state == 2) continue;
+      if (((t & 1) ? c.changedOdd : c.changed) == 0) { c.state = 2; c.rounds = t; }
+      else if (t & 1) c.changed = 0;
+      else c.changedOdd = 0;
+    }
+    for (int64_t base = blockIdx.x; base < nB; base += (int64_t)G * 256) {
+      if (tid == 0) s_n = 0;
+      __syncthreads();
+      const int64_t v = base + (int64_t)tid * G;
+      if (v < nB) {
+        const int il = (int)(v / (nbx * nbyB)), rem = (int)(v - (int64_t)il * (nbx * nbyB));
+        const int bx = rem % nbx, by = rem / nbx;
+        bool act = false;
+        if (relaxing(il)) {
+          const int* ta = A.tileAct + (int64_t)(A.img0 + il) * ncell;
+          for (int cy = by * 4; cy < min(by * 4 + 4, A.TH); ++cy)
+            for (int cx = bx * 4; cx < min(bx * 4 + 4, A.TW); ++cx) act = act || ta[cy * A.TW + cx] == t;
+        }
+        if (act) s_list[atomicAdd(&s_n, 1)] = (int)((v - base) / G);
+      }
+      __syncthreads();
+      const int n = s_n;
+      for (int i = 0; i < n; ++i) {
+        const int64_t va = base + (int64_t)s_list[i] * G;
+        const int il = (int)(va / (nbx * nbyB)), rem = (int)(va - (int64_t)il * (nbx * nbyB));
+        tx_prep_block(A.ctl, A.own, A.rank, A.rgDirty, A.tileAct, W, H, A.TW, A.TH, t, rem % nbx, rem / nbx, A.img0 + il, 0, A.tileTouch);
+        __syncthreads();
+      }
+    }
+    if (!tx_grid_barrier(A.bar, ++epoch * G)) return;
+    // ---- is anybody still relaxing?  (every block counts the same control words: the answer is the same everywhere) ----
+    if (tid == 0) s_live = 0;
+    __syncthreads();
+    int live = 0;
+    for (int i = tid; i < A.nimg; i += 256) live += relaxing(i) ? 1 : 0;
+    if (live) atomicAdd(&s_live, live);
+    __syncthreads();
+    if (s_live == 0) return;
+    // ---- k_tx_grow_sparse: one wave per tile that has seeds to regrow ----
+    for (int64_t base = blockIdx.x; base < nC; base += (int64_t)G * 256) {
+      if (tid == 0) s_n = 0;
+      __syncthreads();
+      const int64_t v = base + (int64_t)tid * G;
+      if (v < nC && A.DL.cnt[(int64_t)A.img0 * ntile + v] > 0 && relaxing((int)(v / ntile))) s_list[atomicAdd(&s_n, 1)] = (int)((v - base) / G);
+      __syncthreads();
+      const int n = s_n;
+      for (int i = wv; i < n; i += 4) {
+        const int64_t va = base + (int64_t)s_list[i] * G;
+        const int il = (int)(va / ntile);
+        tx_grow_tile<true>(A.Pp, A.ctl, A.rec, A.own, A.list, A.tileCnt, A.ts, A.ntx, A.nty, A.rgSize, A.rgBox, A.rgDirty, A.tileAct, A.TW,
+                           A.TH, A.arena, A.arenaCap, A.rects, A.rectCap, A.img0 + il, (int)(va - (int64_t)il * ntile), t, A.rank, A.rgLost,
+                           A.tileTouch, A.DL, qs[wv], gbs[wv]);
+      }
+      __syncthreads();
+    }
+    if (!tx_grid_barrier(A.bar, ++epoch * G)) return;
+    // ---- k_rx_rect of the regions this round completed; the dirty lists are consumed: emptied for the next round ----
+    for (int64_t v = (int64_t)blockIdx.x * 256 + tid; v < nC; v += (int64_t)G * 256) A.DL.cnt[(int64_t)A.img0 * ntile + v] = 0;
+    {
+      const int per = max(1, nwaves / A.nimg);            // waves per image (few images), or images per wave (many)
+      for (int il = gw / per; il < A.nimg; il += max(1, nwaves / per)) {
+        const int img = A.img0 + il;
+        const RxCtl& c = A.ctl[img];
+        if (c.state == 2 || c.overflow) continue;
+        rx_rect_wave(P, c, A.rec + img * npix, A.mg ? A.mg + img * npix : nullptr, A.arena + (int64_t)img * A.arenaCap,
+                     A.rects + (int64_t)img * A.rectCap, A.rectCap, A.rgSeg + img * npix, gw % per, per, sts[wv]);
+      }
+    }
+    if (!tx_grid_barrier(A.bar, ++epoch * G)) return;
+  }
 }
 
 }  // namespace pli

@@ -377,13 +377,15 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams* __restrict_
 // first among equal sizes in the "careful" rounds) then child n1..n4.
 // Keys never move: node_of[key] holds the list position of the key's node.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int block_excl_scan_1024(int* a, int n, int* scratch /*>=5 ints*/) {
-  // in-place exclusive scan of a[0..n) (n <= 1024) by 256 threads; returns the total
+template <int NT>
+__device__ __forceinline__ int block_excl_scan_1024(int* a, int n, int* scratch /*>= NT / 64 ints*/) {
+  // in-place exclusive scan of a[0..n) (n <= 1024) by NT threads (256 or 1024); returns the total
+  constexpr int PER = 1024 / NT, NW = NT / 64;
   const int tid = threadIdx.x;
-  int v[4], s = 0;
+  int v[PER], s = 0;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    int i = tid * 4 + k;
+  for (int k = 0; k < PER; ++k) {
+    int i = tid * PER + k;
     v[k] = i < n ? a[i] : 0;
     s += v[k];
   }
@@ -397,13 +399,17 @@ __device__ __forceinline__ int block_excl_scan_1024(int* a, int n, int* scratch 
   }
   if (lane == 63) scratch[wv] = inc;
   __syncthreads();
-  int wbase = 0;
-  for (int k = 0; k < wv; ++k) wbase += scratch[k];
-  int total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+  int wbase = 0, total = 0;
+#pragma unroll
+  for (int k = 0; k < NW; ++k) {
+    const int w = scratch[k];
+    if (k < wv) wbase += w;
+    total += w;
+  }
   int run = wbase + inc - s;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    int i = tid * 4 + k;
+  for (int k = 0; k < PER; ++k) {
+    int i = tid * PER + k;
     if (i < n) a[i] = run;
     run += v[k];
   }
@@ -421,7 +427,9 @@ struct OtNodes {
 // MAXN: node capacity of the list = LDS footprint (the list ends at N..N+3 nodes, N = the level's quota; the host
 // picks the smallest instance that holds the largest quota: 70 KB of LDS at 1024 nodes allow 2 workgroups per CU,
 // 22 KB at 320 allow 7)
-template <int MAXN>
+// NT: threads of the workgroup.  The passes over the keys (quadrant counts, node_of updates, best response) and the rank-by-counting
+// of the careful rounds are spread over the threads; a batch whose (level, image) workgroups do not fill the chip takes 1024.
+template <int MAXN, int NT>
 __device__ __forceinline__ void octree_level(const DevParams* __restrict__ Pp, const uint32_t* __restrict__ cellCand,
                                              const int* __restrict__ cellCount, uint32_t* __restrict__ candAll,
                                              unsigned short* __restrict__ nodeOfAll, int* __restrict__ candCount,
@@ -435,7 +443,7 @@ __device__ __forceinline__ void octree_level(const DevParams* __restrict__ Pp, c
   __shared__ int unsplitRank[OT_MAXN];
   __shared__ int scanbuf[OT_MAXN];
   __shared__ unsigned long long best[OT_MAXN];
-  __shared__ int scratch[8];
+  __shared__ int scratch[16];
   __shared__ int s_n, s_S, s_T, s_mode, s_done, s_nExp;
 
   const DevParams& P = *Pp;
@@ -455,10 +463,10 @@ __device__ __forceinline__ void octree_level(const DevParams* __restrict__ Pp, c
   int n = 0;
   for (int base = 0; base < ncells; base += OT_MAXN) {
     int m = min(OT_MAXN, ncells - base);
-    for (int i = tid; i < m; i += 256) scanbuf[i] = cc[base + i];
+    for (int i = tid; i < m; i += NT) scanbuf[i] = cc[base + i];
     __syncthreads();
-    int tot = block_excl_scan_1024(scanbuf, m, scratch);
-    for (int i = tid; i < m; i += 256) {
+    int tot = block_excl_scan_1024<NT>(scanbuf, m, scratch);
+    for (int i = tid; i < m; i += NT) {
       int cnt = cc[base + i];
       int o = n + scanbuf[i];
       const uint32_t* src = cin + (int64_t)(base + i) * CELL_CAP;
@@ -480,9 +488,9 @@ __device__ __forceinline__ void octree_level(const DevParams* __restrict__ Pp, c
   // ---- root nodes (ORBextractor.cc:540-589) ----
   const int nIni = G.nIni;
   const float hX = G.hX;
-  for (int i = tid; i < OT_MAXN; i += 256) scanbuf[i] = 0;
+  for (int i = tid; i < OT_MAXN; i += NT) scanbuf[i] = 0;
   __syncthreads();
-  for (int k = tid; k < n; k += 256) {
+  for (int k = tid; k < n; k += NT) {
     int x = (cand[k] >> 8) & 0xFFF;
     int r = (int)__fdiv_rn((float)x, hX);
     if (r >= nIni) r = nIni - 1;
@@ -509,7 +517,7 @@ __device__ __forceinline__ void octree_level(const DevParams* __restrict__ Pp, c
     s_S = S; s_mode = 0; s_done = 0;
   }
   __syncthreads();
-  for (int k = tid; k < n; k += 256) nodeOf[k] = (unsigned short)procIdx[nodeOf[k]];
+  for (int k = tid; k < n; k += NT) nodeOf[k] = (unsigned short)procIdx[nodeOf[k]];
   __syncthreads();
 
   OtNodes<MAXN>* cur = &A;
@@ -519,14 +527,14 @@ __device__ __forceinline__ void octree_level(const DevParams* __restrict__ Pp, c
     const int S = s_S;
     const int mode = s_mode;
     // A. split candidates
-    for (int p = tid; p < S; p += 256) {
+    for (int p = tid; p < S; p += NT) {
       bool cd = cur->cnt[p] > 1 && (mode == 0 || cur->isNew[p]);
       isSplit[p] = cd ? 1 : 0;
       c4[4 * p] = c4[4 * p + 1] = c4[4 * p + 2] = c4[4 * p + 3] = 0;
     }
     __syncthreads();
     // B. keys per quadrant (ExtractorNode::DivideNode, :479-535)
-    for (int k = tid; k < n; k += 256) {
+    for (int k = tid; k < n; k += NT) {
       int p = nodeOf[k];
       if (!isSplit[p]) continue;
       uint32_t cv = cand[k];
@@ -541,20 +549,20 @@ __device__ __forceinline__ void octree_level(const DevParams* __restrict__ Pp, c
     // C/D. processing order and the set of nodes actually split
     int ncand;
     if (mode == 0) {
-      for (int p = tid; p < S; p += 256) scanbuf[p] = isSplit[p];
+      for (int p = tid; p < S; p += NT) scanbuf[p] = isSplit[p];
       __syncthreads();
-      ncand = block_excl_scan_1024(scanbuf, S, scratch);
-      for (int p = tid; p < S; p += 256)
+      ncand = block_excl_scan_1024<NT>(scanbuf, S, scratch);
+      for (int p = tid; p < S; p += NT)
         if (isSplit[p]) procIdx[scanbuf[p]] = p;
       if (tid == 0) s_T = ncand;
       __syncthreads();
     } else {
       // order by (size desc, list position asc): newest-created first among equals
-      for (int p = tid; p < S; p += 256) scanbuf[p] = isSplit[p];
+      for (int p = tid; p < S; p += NT) scanbuf[p] = isSplit[p];
       __syncthreads();
-      ncand = block_excl_scan_1024(scanbuf, S, scratch);
+      ncand = block_excl_scan_1024<NT>(scanbuf, S, scratch);
       // rank by counting
-      for (int p = tid; p < S; p += 256) {
+      for (int p = tid; p < S; p += NT) {
         if (!isSplit[p]) continue;
         int cp = cur->cnt[p], r = 0;
         for (int j = 0; j < S; ++j) {
@@ -566,16 +574,16 @@ __device__ __forceinline__ void octree_level(const DevParams* __restrict__ Pp, c
       }
       __syncthreads();
       // size after each split in processing order; stop at the first >= N
-      for (int r = tid; r < ncand; r += 256) {
+      for (int r = tid; r < ncand; r += NT) {
         int p = procIdx[r];
         int ne = (c4[4 * p] > 0) + (c4[4 * p + 1] > 0) + (c4[4 * p + 2] > 0) + (c4[4 * p + 3] > 0);
         scanbuf[r] = ne - 1;
       }
       __syncthreads();
-      block_excl_scan_1024(scanbuf, ncand, scratch);
+      block_excl_scan_1024<NT>(scanbuf, ncand, scratch);
       if (tid == 0) s_T = ncand;
       __syncthreads();
-      for (int r = tid; r < ncand; r += 256) {
+      for (int r = tid; r < ncand; r += NT) {
         int p = procIdx[r];
         int ne = (c4[4 * p] > 0) + (c4[4 * p + 1] > 0) + (c4[4 * p + 2] > 0) + (c4[4 * p + 3] > 0);
         int after = S + scanbuf[r] + ne - 1;       // list size once this node is split
@@ -583,29 +591,29 @@ __device__ __forceinline__ void octree_level(const DevParams* __restrict__ Pp, c
       }
       __syncthreads();
       const int T = s_T;
-      for (int r = T + tid; r < ncand; r += 256) isSplit[procIdx[r]] = 0;
+      for (int r = T + tid; r < ncand; r += NT) isSplit[procIdx[r]] = 0;
       __syncthreads();
     }
     const int T = s_T;
     // E. creation index of every split node's first child
-    for (int r = tid; r < T; r += 256) {
+    for (int r = tid; r < T; r += NT) {
       int p = procIdx[r];
       scanbuf[r] = (c4[4 * p] > 0) + (c4[4 * p + 1] > 0) + (c4[4 * p + 2] > 0) + (c4[4 * p + 3] > 0);
     }
     __syncthreads();
-    const int C = block_excl_scan_1024(scanbuf, T, scratch);
-    for (int r = tid; r < T; r += 256) cbase[procIdx[r]] = scanbuf[r];
+    const int C = block_excl_scan_1024<NT>(scanbuf, T, scratch);
+    for (int r = tid; r < T; r += NT) cbase[procIdx[r]] = scanbuf[r];
     __syncthreads();
     // F. positions of the unsplit nodes
-    for (int p = tid; p < S; p += 256) scanbuf[p] = isSplit[p] ? 0 : 1;
+    for (int p = tid; p < S; p += NT) scanbuf[p] = isSplit[p] ? 0 : 1;
     __syncthreads();
-    const int U = block_excl_scan_1024(scanbuf, S, scratch);
-    for (int p = tid; p < S; p += 256) unsplitRank[p] = scanbuf[p];
+    const int U = block_excl_scan_1024<NT>(scanbuf, S, scratch);
+    for (int p = tid; p < S; p += NT) unsplitRank[p] = scanbuf[p];
     __syncthreads();
     const int S2 = C + U;
     // G. build the new list
     if (S2 <= OT_MAXN) {
-      for (int p = tid; p < S; p += 256) {
+      for (int p = tid; p < S; p += NT) {
         if (isSplit[p]) {
           int halfX = (int)ceilf(__fdiv_rn((float)(cur->x1[p] - cur->x0[p]), 2.f));
           int halfY = (int)ceilf(__fdiv_rn((float)(cur->y1[p] - cur->y0[p]), 2.f));
@@ -633,7 +641,7 @@ __device__ __forceinline__ void octree_level(const DevParams* __restrict__ Pp, c
           nxt->isNew[pos] = 0;
         }
       }
-      for (int k = tid; k < n; k += 256) {
+      for (int k = tid; k < n; k += NT) {
         int p = nodeOf[k];
         int np;
         if (isSplit[p]) {
@@ -658,7 +666,7 @@ __device__ __forceinline__ void octree_level(const DevParams* __restrict__ Pp, c
     __syncthreads();
     if (S2 <= OT_MAXN) {
       int loc = 0;
-      for (int p = tid; p < C; p += 256) loc += nxt->cnt[p] > 1;
+      for (int p = tid; p < C; p += NT) loc += nxt->cnt[p] > 1;
       if (loc) atomicAdd(&s_nExp, loc);
     }
     __syncthreads();
@@ -675,39 +683,35 @@ __device__ __forceinline__ void octree_level(const DevParams* __restrict__ Pp, c
   }
   // ---- best response per node, first maximum wins (:741-757) ----
   const int S = s_S;
-  for (int p = tid; p < S; p += 256) best[p] = 0ull;
+  for (int p = tid; p < S; p += NT) best[p] = 0ull;
   __syncthreads();
-  for (int k = tid; k < n; k += 256) {
+  for (int k = tid; k < n; k += NT) {
     uint32_t cv = cand[k];
     unsigned long long key = ((unsigned long long)(cv & 0xFF) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)k);
     atomicMax(&best[nodeOf[k]], key);
   }
   __syncthreads();
-  for (int p = tid; p < S; p += 256) {
+  for (int p = tid; p < S; p += NT) {
     unsigned k = 0xFFFFFFFFu - (unsigned)(best[p] & 0xFFFFFFFFull);
     if (p < G.kpCap) sel[p] = cand[k];
   }
   if (tid == 0) kpSelCount[lc] = S < G.kpCap ? S : G.kpCap;
 }
 
-__global__ __launch_bounds__(256) void k_octree(const DevParams* __restrict__ Pp, const uint32_t* __restrict__ cellCand,
-                                                    const int* __restrict__ cellCount, uint32_t* __restrict__ candAll,
-                                                    unsigned short* __restrict__ nodeOfAll, int* __restrict__ candCount,
-                                                    uint32_t* __restrict__ kpSel, int* __restrict__ kpSelCount, int img0) {
-  octree_level<1024>(Pp, cellCand, cellCount, candAll, nodeOfAll, candCount, kpSel, kpSelCount, img0);
-}
-__global__ __launch_bounds__(256) void k_octree_512(const DevParams* __restrict__ Pp, const uint32_t* __restrict__ cellCand,
-                                                    const int* __restrict__ cellCount, uint32_t* __restrict__ candAll,
-                                                    unsigned short* __restrict__ nodeOfAll, int* __restrict__ candCount,
-                                                    uint32_t* __restrict__ kpSel, int* __restrict__ kpSelCount, int img0) {
-  octree_level<512>(Pp, cellCand, cellCount, candAll, nodeOfAll, candCount, kpSel, kpSelCount, img0);
-}
-__global__ __launch_bounds__(256) void k_octree_320(const DevParams* __restrict__ Pp, const uint32_t* __restrict__ cellCand,
-                                                    const int* __restrict__ cellCount, uint32_t* __restrict__ candAll,
-                                                    unsigned short* __restrict__ nodeOfAll, int* __restrict__ candCount,
-                                                    uint32_t* __restrict__ kpSel, int* __restrict__ kpSelCount, int img0) {
-  octree_level<320>(Pp, cellCand, cellCount, candAll, nodeOfAll, candCount, kpSel, kpSelCount, img0);
-}
+#define OCTREE_KERNEL(NAME, MAXN, NT)                                                                                             \
+  __global__ __launch_bounds__(NT) void NAME(const DevParams* __restrict__ Pp, const uint32_t* __restrict__ cellCand,             \
+                                             const int* __restrict__ cellCount, uint32_t* __restrict__ candAll,                    \
+                                             unsigned short* __restrict__ nodeOfAll, int* __restrict__ candCount,                  \
+                                             uint32_t* __restrict__ kpSel, int* __restrict__ kpSelCount, int img0) {               \
+    octree_level<MAXN, NT>(Pp, cellCand, cellCount, candAll, nodeOfAll, candCount, kpSel, kpSelCount, img0);                        \
+  }
+OCTREE_KERNEL(k_octree, 1024, 256)
+OCTREE_KERNEL(k_octree_512, 512, 256)
+OCTREE_KERNEL(k_octree_320, 320, 256)
+OCTREE_KERNEL(k_octree_w, 1024, 1024)
+OCTREE_KERNEL(k_octree_512_w, 512, 1024)
+OCTREE_KERNEL(k_octree_320_w, 320, 1024)
+#undef OCTREE_KERNEL
 
 // ---------------------------------------------------------------------------
 // k_blur: separable Gaussian, u8 -> u8, 8-bit fixed-point kernel (radius <= 3),

@@ -106,6 +106,9 @@ struct pli_ctx {
   // of a settled image leave at once —, k_lsd_grow_unsettled redoes, on the device, whatever image did not settle in them, and the
   // control blocks come back asynchronously (rxSeen / evRxSeen) to be read at the start of a later call.  The call never drains the
   // stream, so copies and kernels of neighbouring calls overlap (pli_batch_submit_host, the multi-GPU gather).
+  // the rounds t >= tail t0 of the tile relaxation run in one persistent launch (lsd_tile.hip: k_tx_tail)
+  unsigned* tailBar = nullptr;      // [0] barrier arrivals, [32] abort word
+  int tailBlocks = 0;               // resident grid: CUs x blocks per CU (from the kernel's occupancy)
   int rxMargin = 3;
   int rxPlanned = 0;                // rounds the last call launched without looking (0: it looked)
   int* rxSeen = nullptr;            // pinned: {state, changed, overflow, rounds} per image of the last look-free call
@@ -579,12 +582,13 @@ pli_status allocAll(pli_ctx* c) {
     if (tiles) {
       // (the measure is the number of 64-pixel tile waves the context can put on the chip, not the number of images)
       c->txTs = (int64_t)NI * ((P.LW + 63) / 64) * ((P.LH + 63) / 64) <= TX_SMALL_TILE_WAVES ? 32 : 64;
-      if (const char* e = getenv("PLI_TX_TS")) c->txTs = atoi(e) == 32 ? 32 : atoi(e) == 128 ? 128 : 64;
+      if (const char* e = getenv("PLI_TX_TS")) c->txTs = atoi(e) == 16 ? 16 : atoi(e) == 32 ? 32 : atoi(e) == 128 ? 128 : 64;
       c->txNtx = (P.LW + c->txTs - 1) / c->txTs; c->txNty = (P.LH + c->txTs - 1) / c->txTs;
       A(c->txList, (size_t)c->txNtx * c->txNty * c->txTs * c->txTs * NR);
       A(c->txTileCnt, (size_t)c->txNtx * c->txNty * NR);
       A(c->txDirtyList, (size_t)c->txNtx * c->txNty * c->txTs * c->txTs * NR);
       A(c->txDirtyCnt, (size_t)c->txNtx * c->txNty * NR);
+      A(c->tailBar, 64);
     }
   }
   A(c->jrCtl, NI);
@@ -642,6 +646,23 @@ pli_status allocAll(pli_ctx* c) {
 }
 
 // ---- stage scheduling -------------------------------------------------------
+// Folds the control blocks a look-free call sent back (rxSeen) into the plan of the next call.  Returns the rounds the slowest
+// settled image needed, or -1 when an image took the device-side fallback.
+int foldRoundStats(pli_ctx* c) {
+  int settled = 0, unsettled = 0, overflowed = 0;
+  for (int i = 0; i < c->rxSeenImages; ++i) {
+    const int* h = c->rxSeen + 4 * i;
+    if (h[2]) ++overflowed;                            // a capacity ran out (adversarial images): more rounds would not help
+    else if (h[0] != 2) ++unsettled;
+    else settled = std::max(settled, h[3]);
+  }
+  c->rxSlowImages += unsettled + overflowed;
+  if (unsettled) c->rxLastRounds = std::min(96, c->rxLastRounds + c->rxMargin);        // not enough rounds: plan more next time
+  else if (settled > 0) c->rxLastRounds = std::max(settled, c->rxLastRounds - 1);       // (follows a calmer stream down slowly)
+  c->rxSeenImages = 0;
+  return (unsettled || overflowed) ? -1 : settled;
+}
+
 pli_status runIngest(pli_ctx* c, const uint8_t* dl, const uint8_t* dr, int64_t stride, int64_t frameStride, int img0, int nimg) {
   const DevParams& P = c->hp;
   dim3 g((P.W + 1023) / 1024, P.H, nimg);
@@ -665,12 +686,16 @@ pli_status runOrb(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     // node capacity of the octree instance: the list ends at quota..quota+3 nodes (first pass: 4 per root)
     int need = 0;
     for (int l = 0; l < P.nlevels; ++l) need = std::max(need, std::max(P.lv[l].nfeatures + 8, 4 * P.lv[l].nIni + 8));
-    if (need <= 320) LAUNCH(c, "k_octree", k_octree_320, dim3(P.nlevels, nimg), dim3(256), 0, c->dP, c->cellCand, c->cellCount, c->candAll,
-         c->nodeOf, c->candCount, c->kpSel, c->kpSelCount, img0);
-    else if (need <= 512) LAUNCH(c, "k_octree", k_octree_512, dim3(P.nlevels, nimg), dim3(256), 0, c->dP, c->cellCand, c->cellCount, c->candAll,
-         c->nodeOf, c->candCount, c->kpSel, c->kpSelCount, img0);
-    else LAUNCH(c, "k_octree", k_octree, dim3(P.nlevels, nimg), dim3(256), 0, c->dP, c->cellCand, c->cellCount, c->candAll,
-         c->nodeOf, c->candCount, c->kpSel, c->kpSelCount, img0);
+    // workgroups of 1024 threads while the (level, image) workgroups do not fill the chip (4K: 32 images x 8 levels; a single pair:
+    // 16 workgroups): the passes over a level's keys are the long pole, 4x the threads on them (dev switch PLI_OCTREE_WIDE=0/1)
+    bool wide = P.nlevels * nimg <= 1024;
+    if (const char* e = getenv("PLI_OCTREE_WIDE")) wide = atoi(e) != 0;
+    const dim3 og(P.nlevels, nimg), ob(wide ? 1024 : 256);
+#define OCTREE_LAUNCH(K) LAUNCH(c, "k_octree", K, og, ob, 0, c->dP, c->cellCand, c->cellCount, c->candAll, c->nodeOf, c->candCount, c->kpSel, c->kpSelCount, img0)
+    if (need <= 320) { if (wide) OCTREE_LAUNCH(k_octree_320_w); else OCTREE_LAUNCH(k_octree_320); }
+    else if (need <= 512) { if (wide) OCTREE_LAUNCH(k_octree_512_w); else OCTREE_LAUNCH(k_octree_512); }
+    else { if (wide) OCTREE_LAUNCH(k_octree_w); else OCTREE_LAUNCH(k_octree); }
+#undef OCTREE_LAUNCH
   }
   LAUNCH(c, "k_blur_orb", k_blur, dim3(c->orbTiles, nimg), dim3(256), 0, c->jobOrb, c->pyr, P.pyrBlock, c->blur, P.pyrBlock, img0);
   LAUNCH(c, "k_kp_counts", k_kp_counts, dim3((nimg + 63) / 64), dim3(64), 0, c->dP, c->kpSelCount, table, Y.record_bytes,
@@ -828,21 +853,23 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     const bool tile = c->lsdMode != 1;      // auto below RX_AUTO_IMAGES and mode 3: the tile-sequential relaxation
     bool allDone = false;
     // what the last look-free call left behind (if its copy has arrived): how many rounds its slowest image needed
-    if (c->rxSeenImages > 0 && hipEventQuery(c->evRxSeen) == hipSuccess) {
-      int settled = 0, slow = 0;
-      for (int i = 0; i < c->rxSeenImages; ++i) {
-        const int* h = c->rxSeen + 4 * i;
-        if (h[0] == 2 && !h[2]) settled = std::max(settled, h[3]); else ++slow;
-      }
-      c->rxSlowImages += slow;
-      if (slow) c->rxLastRounds = std::min(maxRounds, c->rxLastRounds + c->rxMargin);   // not enough rounds: plan more next time
-      else if (settled > 0) c->rxLastRounds = std::max(settled, c->rxLastRounds - 1);      // (follows a calmer stream down slowly)
-      c->rxSeenImages = 0;
+    if (c->rxSeenImages > 0 && hipEventQuery(c->evRxSeen) == hipSuccess) foldRoundStats(c);
+    if (tile && c->tailBar && c->tailBlocks == 0) {       // the resident grid of k_tx_tail: CUs x blocks per CU (-1: it does not fit)
+      int perCu = 0, cus = 0;
+      HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_tx_tail, 256, 0));
+      HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+      int bpc = 1;
+      if (const char* e = getenv("PLI_TX_TAIL_BPC")) bpc = std::max(1, atoi(e));
+      c->tailBlocks = perCu < 1 ? -1 : std::min(perCu, bpc) * std::max(1, cus);
     }
-    const bool blocking = c->rxLastRounds == 0 || trace || getenv("PLI_RX_BLOCKING") != nullptr;
-    if (!blocking) maxRounds = std::min(maxRounds, c->rxLastRounds + c->rxMargin);
+    const bool tailPossible = tile && c->tailBar && c->tailBlocks > 0 && !getenv("PLI_RX_PLAN") && !trace && !perRound && !getenv("PLI_RX_BLOCKING") &&
+                              !(getenv("PLI_TX_TAIL") && atoi(getenv("PLI_TX_TAIL")) == 0) && lostRule && !getenv("PLI_TX_FULL2") &&
+                              !getenv("PLI_TX_CELLRULE") && !getenv("PLI_TX_OLDMARK") && !getenv("PLI_TX_FULLDIFF") &&
+                              !getenv("PLI_TX_NOFUSEDM") && !getenv("PLI_TX_NODIRTYLIST");
+    const bool blocking = !tailPossible && (c->rxLastRounds == 0 || trace || getenv("PLI_RX_BLOCKING") != nullptr);
+    if (!blocking && !tailPossible) maxRounds = std::min(maxRounds, c->rxLastRounds + c->rxMargin);
     if (!blocking) if (const char* e = getenv("PLI_RX_PLAN")) maxRounds = std::max(1, atoi(e));   // dev / test: a plan that is too short
-    c->rxPlanned = blocking ? 0 : maxRounds;
+    c->rxPlanned = blocking ? 0 : (tailPossible ? -1 : maxRounds);
     const int firstLook = c->rxLastRounds > 0 ? std::max(4, c->rxLastRounds) : 4;
     auto look = [&](int t) -> pli_status {
       // the host looks at the state every second round, starting where the previous call on this context ended (a
@@ -878,8 +905,22 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       // rounds >= 3: k_rx_diff + k_tx_mark as one kernel (k_tx_diffmark; the dev rules keep the separate passes)
       const bool fusedDM = lostRule && !fullRound2 && !getenv("PLI_TX_CELLRULE") && !getenv("PLI_TX_OLDMARK") && !getenv("PLI_TX_FULLDIFF") &&
                            !getenv("PLI_TX_NOFUSEDM");
+      // rounds >= tailT0 in one persistent launch that ends by itself when every image is at its fixed point (no host look, no
+      // planned round count; dev switches: PLI_TX_TAIL=0, PLI_TX_TAIL_T0, PLI_TX_TAIL_BPC)
+      const bool useTail = tailPossible && fusedDM && DL.list;
+      int tailT0 = 8;
+      if (const char* e = getenv("PLI_TX_TAIL_T0")) tailT0 = std::max(3, atoi(e));
       for (int t = 1; t <= maxRounds && !allDone; ++t) {
         curT = t;
+        if (useTail && t == tailT0) {
+          HIPCHK(hipMemsetAsync(c->txDirtyCnt + (int64_t)img0 * ntile, 0, sizeof(int) * (size_t)ntile * nimg, c->stream));
+          HIPCHK(hipMemsetAsync(c->tailBar, 0, 64 * sizeof(unsigned), c->stream));
+          TxTailArgs ta{c->dP, c->jrCtl, c->rec, c->own, c->txList, c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty,
+                        c->tileAct, c->tileTouch, c->tilesW, c->tilesH, c->arena, c->arenaCap, c->rects, c->rectCap, c->rgSeg, c->mg,
+                        c->rankOf, c->rgLost, DL, img0, nimg, t, 96, c->tailBar};
+          LAUNCH(c, "k_tx_tail", k_tx_tail, dim3(c->tailBlocks), dim3(256), 0, ta);
+          break;
+        }
         if (t >= 2 && DL.list)
           HIPCHK(hipMemsetAsync(c->txDirtyCnt + (int64_t)img0 * ntile, 0, sizeof(int) * (size_t)ntile * nimg, c->stream));
         const bool fused2 = t == 2 && !fullRound2 && lostRule && !getenv("PLI_TX_NOFUSE2");    // (dev switch: the two passes)
@@ -1457,20 +1498,8 @@ pli_status pli_lsd_round_stats(pli_ctx* c, int32_t out[4]) {
   if (!c || !out) { g_err = "bad argument"; return PLI_ERR_INVALID; }
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamSynchronize(c->stream));
-  if (c->rxSeenImages > 0 && hipEventQuery(c->evRxSeen) == hipSuccess) {      // fold in the last look-free call (as the next call would)
-    int settled = 0, slow = 0;
-    for (int i = 0; i < c->rxSeenImages; ++i) {
-      const int* h = c->rxSeen + 4 * i;
-      if (h[0] == 2 && !h[2]) settled = std::max(settled, h[3]); else ++slow;
-    }
-    c->rxSlowImages += slow;
-    if (slow) c->rxLastRounds = std::min(96, c->rxLastRounds + c->rxMargin);
-    else if (settled > 0) c->rxLastRounds = std::max(settled, c->rxLastRounds - 1);
-    c->rxSeenImages = 0;
-    out[1] = slow ? -1 : settled;
-  } else {
-    out[1] = c->rxLastRounds;
-  }
+  if (c->rxSeenImages > 0 && hipEventQuery(c->evRxSeen) == hipSuccess) out[1] = foldRoundStats(c);   // (as the next call would)
+  else out[1] = c->rxLastRounds;
   out[0] = c->rxPlanned;
   out[2] = (int32_t)std::min<int64_t>(c->rxSlowImages, INT32_MAX);
   out[3] = c->rxLastRounds;

@@ -1077,12 +1077,14 @@ def test_look_free_rounds_and_device_side_fallback(gpu, monkeypatch):
     fe = g.Frontend(cfg)
     pairs = [g.synth.make_stereo_pair(60 + i, W, H) for i in range(4)]
     imgs = np.stack([np.stack(p) for p in pairs])
-    first = fe.batch_run_host(imgs)                          # the first call looks (and learns the round count)
+    first = fe.batch_run_host(imgs)                          # the late rounds in the persistent tail kernel: no look, no plan
     st = fe.lsd_round_stats()
-    assert st[0] == 0 and st[3] >= 4
-    again = fe.batch_run_host(imgs)                          # look-free
+    assert st[0] == -1 and st[1] >= 4 and st[2] == 0, st
+    monkeypatch.setenv("PLI_TX_TAIL", "0")
+    again = fe.batch_run_host(imgs)                          # without the tail: planned rounds, look-free
     st = fe.lsd_round_stats()
     assert st[0] >= st[1] > 0 and st[2] == 0, st             # planned >= needed, nobody took the slow path
+    monkeypatch.delenv("PLI_TX_TAIL")
     monkeypatch.setenv("PLI_RX_PLAN", "3")
     short = fe.batch_run_host(imgs)                          # three rounds are not enough: the device-side fallback
     st = fe.lsd_round_stats()
@@ -1090,7 +1092,7 @@ def test_look_free_rounds_and_device_side_fallback(gpu, monkeypatch):
     monkeypatch.delenv("PLI_RX_PLAN")
     later = fe.batch_run_host(imgs)
     for f, (L, R) in enumerate(pairs):
-        for recs, what in ((first, "look"), (again, "look-free"), (short, "fallback"), (later, "after the fallback")):
+        for recs, what in ((first, "tail"), (again, "planned rounds"), (short, "fallback"), (later, "after the fallback")):
             if f == 0 or recs is short:
                 assert_frame_equal(g, recs[f], g.po.Frame(ocfg(g, cfg)), L, R, "%s frame %d" % (what, f))
             else:
