@@ -127,8 +127,9 @@ def cpu_baseline(images, cfg_bytes, budget_s=18.0):
     cores frame-parallel.  `value` is the all-cores rate."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import pyoracle as po
+    flags = po.use_native_build()
     cores = os.cpu_count() or 1
-    nthreads = max(1, min(cores, 128))
+    nthreads = max(1, cores)                      # every logical CPU of the box (one oracle frame pipeline per thread)
     nimg = images.shape[0]
     f0 = po.Frame(po.Config.from_buffer_copy(cfg_bytes))
     t0 = time.perf_counter()
@@ -163,8 +164,8 @@ def cpu_baseline(images, cfg_bytes, budget_s=18.0):
         done = sum(ex.map(work, range(nthreads)))
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "stereo frames/s", "cores": nthreads, "kind": "port",
-            "sample": "%d stereo frames (cycled over the GPU batch) on %d threads, one oracle frame pipeline per thread, %.1f s"
-                      % (done, nthreads, dt),
+            "sample": "%d stereo frames (cycled over the GPU batch) on %d threads = all %d logical CPUs of the box, one oracle frame "
+                      "pipeline per thread, oracle built %s, %.1f s" % (done, nthreads, cores, flags, dt),
             "single_thread": {"value": 1.0 / t1, "seconds_per_frame": t1, "cores": 1},
             "ref4": {"value": n4 / dt4, "cores": 4, "sample": "%d stereo frames, the four extractors of a frame on 4 threads "
                                                               "(Frame.cc:128-135), matching serial, %.1f s" % (n4, dt4)},
@@ -529,10 +530,15 @@ def main():
         traffic = None     # HBM bytes per launch from the committed PMC passes of the same workload, if any
         sector = None      # the growers are gather kernels: their ceiling is the rate of random 64-byte sector requests the chip
         try:               # sustains (tools/probes/gather_rate.hip, profiles/r02_gather_rate_probe.txt: 49 G/s), not the stream peak
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+            tpath = [p_ for p_ in (os.path.join(ROOT, "profiles", "r03_traffic.json"), os.path.join(ROOT, "profiles", "r02_traffic.json"))
+                     if os.path.exists(p_)][0]
+            tr = json.load(open(tpath))
             k = tr["workloads"].get("%dx%d_F%d" % (W, H, F), {}).get(name)
             if k:
-                traffic = (2 * k["fetch_kb"] + k["write_kb"]) * 1024
+                # FETCH_SIZE counts 32-byte units for streaming kernels on gfx950 (MI355X_MICROARCH.md: x2) but 64 bytes per request
+                # of the growers' 8-byte gathers (TCC_MISS x 64 B agrees with the undoubled figure, profiles/README.md)
+                gather = name.startswith(("k_tx_grow", "k_lsd_grow", "k_rx_grow"))
+                traffic = ((1 if gather else 2) * k["fetch_kb"] + k["write_kb"]) * 1024
                 if name.startswith(("k_tx_grow", "k_lsd_grow", "k_rx_grow")) and avg_s > 0:
                     rate = k["fetch_kb"] * 1024 / 64 / avg_s / 1e9      # FETCH_SIZE counts 64 B per request of these kernels
                     sector = {"achieved": rate, "peak": 49.0, "unit": "G 64-byte sector requests/s (L2 misses)", "frac": rate / 49.0,

@@ -78,6 +78,30 @@ _lib = None
 _ref = None
 
 
+def use_native_build():
+    """cpu_baseline leg of bench.py: rebuild the oracle ON THIS MACHINE with the reference's own flags (-O3 -march=native,
+    CMakeLists.txt:12-13) into oracle/_native/ and use that library from here on; the shipped liboracle.so is built -march=x86-64-v3
+    in the build container, whose CPU is not the GPU box's.  Returns the flags in use (the shipped library's when g++ is missing)."""
+    global _lib
+    d = os.path.join(_HERE, "_native")
+    so = os.path.join(d, "liboracle_native.so")
+    try:
+        os.makedirs(d, exist_ok=True)
+        subprocess.check_call(["g++", "-O3", "-march=native", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-shared",
+                               "-o", so, os.path.join(_HERE, "oracle_capi.cpp")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except Exception:
+        lib()
+        return "-O3 -march=x86-64-v3 (shipped build; no compiler on this machine)"
+    _lib = None
+    real_build = globals()["build"]
+    globals()["build"] = lambda force=False: so
+    try:
+        lib()
+    finally:
+        globals()["build"] = real_build
+    return "-O3 -march=native (built on this machine)"
+
+
 def lib():
     global _lib
     if _lib is None:

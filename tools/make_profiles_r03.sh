@@ -1,0 +1,58 @@
+#!/bin/bash
+# GPU box: regenerates the round-3 rocprofv3 summaries kept under profiles/ (written to gpurun_out/prof_r03/).
+# rocprofv3 is run from /tmp with the program directly after "--"; counters in their own passes (--kernel-trace --pmc only).
+#   tools/make_profiles_r03.sh [stats] [pmc] [sq]      (default: all three groups)
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/prof_r03
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+WHAT="${*:-stats pmc sq}"
+run_stats() {  # name, bench args
+  local name=$1; shift
+  rm -rf $R/gpurun_out/ps_$name
+  timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/ps_$name -o s -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $O/$name.log 2>&1
+  python3 $R/tools/rocprof_summary.py stats $(find $R/gpurun_out/ps_$name -name "*.db" | head -1) > $O/kernel_stats_$name.txt
+  grep '^{"metric"' $O/$name.log | tail -1 > $O/bench_$name.json
+  rm -rf $R/gpurun_out/ps_$name
+}
+run_pmc() {  # name, "counters", bench args -> appends to pmc_<name>.txt
+  local name=$1; local grp=$2; shift; shift
+  rm -rf $R/gpurun_out/pp
+  timeout 900 rocprofv3 --kernel-trace --pmc $grp -d $R/gpurun_out/pp -o s -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $O/pmc.log 2>&1
+  echo "## --pmc $grp   (bench.py --steps 1 --warmup 0 --no-cpu-baseline $*)" >> $O/pmc_$name.txt
+  python3 $R/tools/rocprof_summary.py pmc $(find $R/gpurun_out/pp -name "*.db" | head -1) >> $O/pmc_$name.txt
+  rm -rf $R/gpurun_out/pp
+}
+if [[ $WHAT == *stats* ]]; then
+  run_stats default_f256
+  run_stats f32 --frames-per-gpu 32
+  run_stats config2_single_pair --config 2
+  run_stats f2048_sequential --frames-per-gpu 2048
+  run_stats config3_720p --config 3
+  run_stats config5_4k --config 5
+fi
+if [[ $WHAT == *pmc* ]]; then
+  for w in "default_f256" "f2048_sequential --frames-per-gpu 2048" "config5_4k --config 5" "config3_720p --config 3"; do
+    set -- $w; name=$1; shift
+    : > $O/pmc_$name.txt
+    run_pmc $name FETCH_SIZE "$@"
+    run_pmc $name WRITE_SIZE "$@"
+  done
+fi
+if [[ $WHAT == *sq* ]]; then
+  for w in "default_f256" "f2048_sequential --frames-per-gpu 2048"; do
+    set -- $w; name=sq_$1; shift
+    : > $O/pmc_$name.txt
+    for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum"; do
+      run_pmc $name "$grp" "$@"
+    done
+  done
+fi
+cd $R && timeout 900 python3 bench.py --steps 5 --warmup 1 > $O/bench_default.log 2>&1
+grep '^{"metric"' $O/bench_default.log | tail -1 > $O/bench_default.json
+# the other workloads without the profiler attached (the bench_<name>.json beside the kernel stats are runs under rocprofv3)
+for w in "config5_4k --config 5" "config3_720p --config 3" "f32 --frames-per-gpu 32" "f2048_sequential --frames-per-gpu 2048"; do
+  set -- $w; name=$1; shift
+  timeout 900 python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline "$@" 2>/dev/null | grep '^{"metric"' | tail -1 > $O/bench_${name}_plain.json
+done
+ls -la $O

@@ -306,11 +306,95 @@ int main(int argc, char** argv) {
         cur[q] = o == INT32_MAX ? INT32_MAX : (dirty[o] ? F.rankOf[q] : o);
       }
       long grown = 0, acc = 0, tst = 0;
+      // SIM_LANESPEC=cap (round 1 only): the alive seeds of a row of 64 list entries grow at the same time, one per lane, alone
+      // against the state at the start of the row, up to `cap` pixels; the ones that stay below the cap claim their pixels together
+      // (lowest rank wins a pixel, the others are stamped losers and regrown in round 2 by the usual rule), the ones that hit the cap
+      // are grown afterwards by the whole wave, in rank order, like every region is without this switch.
+      const int laneCap = (t == 1 && getenv("SIM_LANESPEC")) ? atoi(getenv("SIM_LANESPEC")) : 0;
+      long specSmall = 0, specBig = 0, specLosers = 0, specKilledBig = 0, specRows = 0, specSteps = 0;
       for (int T = 0; T < NT; ++T) {
         std::vector<std::pair<int, int>> claims;
         std::vector<int> mineIdx;
         static std::vector<int> mine;
         if ((int)mine.size() != N) mine.assign(N, INT32_MAX);
+        if (laneCap > 0) {
+          const std::vector<int>& S = tileSeeds[T];
+          auto record = [&](int r, const std::vector<int>& rg) {
+            lastRun[r] = rg;
+            lastRound[r] = t;
+            int* b = &boxes[4 * (size_t)r];
+            b[0] = b[2] = rg[0] % W; b[1] = b[3] = rg[0] / W;
+            for (int q : rg) { b[0] = std::min(b[0], q % W); b[2] = std::max(b[2], q % W); b[1] = std::min(b[1], q / W); b[3] = std::max(b[3], q / W); }
+            ++grown; acc += (long)rg.size();
+          };
+          auto claim = [&](int q, int r) {
+            if (mine[q] == INT32_MAX) mineIdx.push_back(q);
+            if (mine[q] != INT32_MAX && mine[q] != r) lostStamp[std::max(mine[q], r)] = t;     // contested inside the tile: the higher rank loses
+            mine[q] = std::min(mine[q], r);
+          };
+          // SIM_SUPERROW: a row = the next 64 seeds that are ALIVE when the row is formed (the tile's list is scanned on), not 64 list entries
+          const bool superRow = getenv("SIM_SUPERROW") != nullptr;
+          std::vector<int> SR;
+          size_t scan = 0;
+          for (size_t base = 0; superRow ? scan < S.size() : base < S.size(); base += 64) {
+            if (superRow) {
+              SR.clear();
+              while (scan < S.size() && SR.size() < 64) {
+                const int r = S[scan++], sp = F.order[r];
+                if (!(prev[sp] != r || mine[sp] < r || cur[sp] < r)) SR.push_back(r);
+              }
+              if (SR.empty()) break;
+            }
+            const std::vector<int>& S_ = superRow ? SR : S;
+            const size_t base_ = superRow ? 0 : base;
+            ++specRows;
+            const size_t n = superRow ? SR.size() : std::min<size_t>(64, S.size() - base);
+            std::vector<std::vector<int>> RG(n);
+            std::vector<int> st(n, -1);            // -1 dead at row start, 0 small, 1 big
+            long maxSteps = 0;
+            for (size_t j = 0; j < n; ++j) {
+              const int r = S_[base_ + j], sp = F.order[r];
+              if (prev[sp] != r || mine[sp] < r || cur[sp] < r) continue;
+              auto used = [&](int q) { return mine[q] <= r || prev[q] < r || cur[q] < r; };
+              std::vector<int>& rg = RG[j];
+              double reg_angle = F.ang[sp];
+              float sumdx = float(std::cos(reg_angle)), sumdy = float(std::sin(reg_angle));
+              rg.push_back(sp);
+              bool big = false;
+              size_t k = 0;
+              for (; k < rg.size() && !big; ++k) {
+                const int px = rg[k] % W, py = rg[k] / W;
+                for (int yy = std::max(py - 1, 0); yy <= std::min(py + 1, H - 1) && !big; ++yy)
+                  for (int xx = std::max(px - 1, 0); xx <= std::min(px + 1, W - 1); ++xx) {
+                    const int q = yy * W + xx;
+                    if (used(q) || std::find(rg.begin(), rg.end(), q) != rg.end()) continue;
+                    if (aligned(F, q, reg_angle)) {
+                      if ((int)rg.size() == laneCap) { big = true; break; }
+                      rg.push_back(q);
+                      sumdx += F.c[q]; sumdy += F.s[q];
+                      reg_angle = fastAtan2(sumdy, sumdx) * kDEG_TO_RADS;
+                    }
+                  }
+              }
+              maxSteps = std::max<long>(maxSteps, (long)k);
+              st[j] = big ? 1 : 0;
+            }
+            specSteps += maxSteps;
+            for (size_t j = 0; j < n; ++j)
+              if (st[j] == 0) { for (int q : RG[j]) claim(q, S_[base_ + j]); record(S_[base_ + j], RG[j]); ++specSmall; }
+            for (size_t j = 0; j < n; ++j)
+              if (st[j] == 0) for (int q : RG[j]) if (mine[q] != S_[base_ + j]) { ++specLosers; break; }
+            for (size_t j = 0; j < n; ++j) {
+              if (st[j] != 1) continue;
+              const int r = S_[base_ + j], sp = F.order[r];
+              if (mine[sp] < r) { ++specKilledBig; continue; }
+              auto used = [&](int q) { return mine[q] <= r || prev[q] < r || cur[q] < r; };
+              grow(F, r, used, [&](int q) { claim(q, r); }, reg, tst);
+              record(r, reg);
+              ++specBig;
+            }
+          }
+        } else
         for (int r : tileSeeds[T]) {
           const int sp = F.order[r];
           if (!dirty[r] || prev[sp] != r) continue;
@@ -342,6 +426,9 @@ int main(int argc, char** argv) {
       for (int r = 0; r < R; ++r) if (cur[F.order[r]] == r && lastRun[r] != truthRun[r]) ++wrongRuns;
       std::printf("  carry round %2d: grown %6ld regions, %7ld px, changed-in %7ld, owner wrong %6ld, alive regions with a wrong last run %5ld\n",
                   t, grown, acc, changed, wrong, wrongRuns);
+      if (laneCap > 0)
+        std::printf("    lane speculation (cap %d): %ld rows, %ld lane-parallel steps, %ld small regions (%ld of them lost a pixel), %ld big, %ld big seeds taken first\n",
+                    laneCap, specRows, specSteps, specSmall, specLosers, specBig, specKilledBig);
       prev2 = prev;
       prev = cur;
     }
