@@ -45,6 +45,8 @@ constexpr double TX_2PI = 2 * TX_PI;
 //     time unchanged — the growers are bound by instruction issue (4 cycles x (VALU + SALU instructions) per SIMD matches the
 //     kernel time within 10 % in every variant), not by the miss rate (65 % of the 49 G/s ceiling of tools/probes/gather_rate.hip).
 constexpr int TX_GQ = 1024;       // queue entries of a region kept in LDS
+constexpr int TX_GQ_SPEC = 512;   // ... in the speculative round-1 kernel (its lanes' parked states take 2 KB of the wave's LDS)
+constexpr int TX_SPEC_CAP = 8;    // pixels a lane may take by itself before its region is handed to the whole wave (< minRegSize)
 constexpr int TX_BBLK = 256;      // arena block for the overflow of a large region's queue
 constexpr int TX_BMAXBLK = 128;   // => regions of up to TX_GQ + 32768 pixels
 
@@ -634,7 +636,7 @@ __device__ __forceinline__ int tx_pk_max_u16(int a, int b) {
   return (int)((max((unsigned)a >> 16, (unsigned)b >> 16) << 16) | max((unsigned)a & 0xFFFFu, (unsigned)b & 0xFFFFu));
 }
 
-template <bool SPARSE>
+template <bool SPARSE, bool SPEC = false, int GQ = TX_GQ>
 __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
                                              const float4* __restrict__ recAll, int2* __restrict__ ownAll,
                                              const int2* __restrict__ listAll, const int* __restrict__ tileCntAll,
@@ -644,7 +646,8 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
                                              int* __restrict__ arenaAll, int arenaCap, RxRect* __restrict__ rectAll,
                                              int rectCap, int img, int tile, int t, const int* __restrict__ rankAll,
                                              int* __restrict__ rgLostAll, int* __restrict__ tileTouchAll,
-                                             const TxDirtyLists& DL, int* q /* LDS, TX_GQ */, int* gb /* LDS, TX_BMAXBLK */) {
+                                             const TxDirtyLists& DL, int* q /* LDS, GQ */, int* gb /* LDS, TX_BMAXBLK */,
+                                             int* park = nullptr /* LDS, 8 x 64 (SPEC) */) {
   const DevParams& P = *Pp;
   RxCtl& c = ctl[img];
   if (c.state == 2 || c.overflow) return;
@@ -711,56 +714,25 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
   const int ndx = nm % 3 - 1, ndy = nm / 3 - 1;
 
   auto qget = [&](int k) -> int {
-    int e = tx_lds_read(&q[min(k, TX_GQ - 1)]);
-    if (k >= TX_GQ) {
-      const int o = k - TX_GQ;
+    int e = tx_lds_read(&q[min(k, GQ - 1)]);
+    if (k >= GQ) {
+      const int o = k - GQ;
       e = arena[gb[o / TX_BBLK] + o % TX_BBLK];
     }
     return e;
   };
 
-  for (int base = 0; base < n; base += 64) {
-    const bool valid = base + lane < n;
-    int2 se = make_int2(TX_INF, -1);
-    if (useDirty) se = dse;                               // (n <= 64: one row)
-    else if (valid) se = list[base + lane];
-    bool d = valid;
-    if (SPARSE && !useDirty) d = valid && rgDirty[se.x] == t;
-    float4 srec = make_float4(TX_NOTDEF, 0.f, 0.f, 0.f);
-    int2 so = make_int2(0, 0);
-    if (d) {
-      srec = rec[se.y];
-      so = tx_load_own(&own[se.y]);
-    }
-    const bool alive = d && (ci ? so.x : so.y) == se.x && (ci ? so.y : so.x) == se.x;
-    // region_grow seeds its sums with cos/sin of the unrounded double angle
-    float scos = 0.f, ssin = 0.f;
-    if (alive) {
-      double sn, cn;
-      sincos((double)srec.x * TX_DEG2RAD, &sn, &cn);
-      scos = (float)cn;
-      ssin = (float)sn;
-    }
-    // (the packed (y, x) of the row's seeds, 64 at a time: a scalar division per region costs more than this one per row)
-    const unsigned spyv = (unsigned)max(se.y, 0) / (unsigned)W;
-    const int sxyv = (int)((spyv << 16) | ((unsigned)max(se.y, 0) - spyv * (unsigned)W));
-    unsigned long long unusedMask = __builtin_amdgcn_ballot_w64(alive);
-    while (unusedMask) {
-      const int j = __ffsll((long long)unusedMask) - 1;
-      unusedMask &= unusedMask - 1ull;
-      const int r = tx_rl(se.x, j), sp = tx_rl(se.y, j);
-      const float sa = tx_rlf(srec.x, j);
-      float sumdx = tx_rlf(scos, j), sumdy = tx_rlf(ssin, j);
-      double reg_angle = (double)sa * TX_DEG2RAD;
-      int angCnt = 1;                                     // reg_angle is the angle of the sums at this pixel count (the seed angle at 1)
-      const int sxy = tx_rl(sxyv, j);
-      q[0] = sxy;                                         // every lane stores the same value
-      int cnt = 1, k = 0;
-      int bmin = sxy, bmax = bmin;                        // bounding box: packed 16-bit (y, x) minima / maxima
+  // One region, grown by the whole wave with the batched steps, from a given start: the seed alone (cnt = 1, k = 0, q[0] = the
+  // seed — every region of the plain schedule) or the prefix a lane has grown by itself (the speculative schedule below: q[0..cnt)
+  // hold its pixels, k is the first queue entry that has not been expanded, the sums are the lane's).  seedMask / seedPixV: the live
+  // seeds of the current list row and their pixels (a seed whose pixel is taken leaves the mask).  false: a capacity ran out.
+  auto growRegion = [&](const int r, const int sp, const float sa, float sumdx, float sumdy, int cnt, int k, int bmin, int bmax, int angCnt,
+                        unsigned long long& seedMask, const int seedPixV, const int pend0, const int pendRank0) -> bool {
+      double reg_angle = (double)sa * TX_DEG2RAD;         // (the angle of the sums at pixel count angCnt: the seed angle at 1)
       // pendOld = what stood in the owner word when this lane's claim of the last step arrived (r: it claimed nothing): a lower
       // rank -> this region does not hold the pixel it took; a higher rank that is not the pixel's own (initial) rank -> that
       // region just lost the pixel.  Contested claims are rare: one ballot decides for the wave.
-      int pendOld = r, pendRank = 0;
+      int pendOld = pend0, pendRank = pendRank0;
       auto stampLosers = [&]() {
         if (noteLost) {
           const bool contested = pendOld < r || (pendOld != r && pendOld != pendRank);
@@ -807,7 +779,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
           const int cnt0 = cnt;
           while (remaining) {
             int j2;
-            const int code = tx_accept_fast(sumdx, sumdy, rr.y, rr.z, qi, myxy, se.y, remaining, acc, unusedMask, cnt, bmin, bmax,
+            const int code = tx_accept_fast(sumdx, sumdy, rr.y, rr.z, qi, myxy, seedPixV, remaining, acc, seedMask, cnt, bmin, bmax,
                                             alignLo, alignHi, j2);
             if (code == 0) break;
             // lane j2 lies inside the margin of the vector filter: the reference's own expression decides
@@ -826,7 +798,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
             const float cj = tx_rlf(rr.y, j2), sj = tx_rlf(rr.z, j2);
             acc |= 1ull << j2;
             remaining &= ~__builtin_amdgcn_ballot_w64(qi == qj);          // the other copies of the accepted pixel
-            unusedMask &= ~__builtin_amdgcn_ballot_w64(se.y == qj);       // a seed of this row that was just taken
+            seedMask &= ~__builtin_amdgcn_ballot_w64(seedPixV == qj);       // a seed of this row that was just taken
             ++cnt;
             bmin = tx_pk_min_u16(bmin, xyj);
             bmax = tx_pk_max_u16(bmax, xyj);
@@ -863,10 +835,10 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
             const float cj = tx_rlf(rr.y, j2), sj = tx_rlf(rr.z, j2);
             accepted = accepted || lane == j2;          // the claims are issued together after the loop
             remaining &= ~__builtin_amdgcn_ballot_w64(qi == qj);          // the other copies of the accepted pixel
-            if (cnt < TX_GQ) {
+            if (cnt < GQ) {
               q[cnt] = xyj;                              // every active lane stores the same value
             } else {
-              const int o = cnt - TX_GQ;
+              const int o = cnt - GQ;
               if (o % TX_BBLK == 0) {
                 if (o / TX_BBLK >= TX_BMAXBLK) { dead = true; break; }
                 int nbk = 0;
@@ -886,7 +858,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
             bmax = tx_pk_max_u16(bmax, xyj);
             sumdx = __fadd_rn(sumdx, cj);
             sumdy = __fadd_rn(sumdy, sj);
-            unusedMask &= ~__builtin_amdgcn_ballot_w64(se.y == qj);   // a seed of this row that was just taken
+            seedMask &= ~__builtin_amdgcn_ballot_w64(seedPixV == qj);   // a seed of this row that was just taken
           }
         }
         if (accepted) {
@@ -898,12 +870,12 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
         }
         k += nb;
       };
-      while (k < cnt && cnt + 8 * 8 + 1 <= TX_GQ) oneStep(std::false_type{});
+      while (k < cnt && cnt + 8 * 8 + 1 <= GQ) oneStep(std::false_type{});
       while (k < cnt && !dead) oneStep(std::true_type{});
       asm volatile("" ::"v"(pendOld) : "memory");       // the claims of the region's last step
       stampLosers();
       asm volatile("" ::"v"(pendOld) : "memory");
-      if (dead) { c.overflow = 5; return; }
+      if (dead) { c.overflow = 5; return false; }
       // ---- the region is complete ----
       const bool first = lane == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1;   // the first ACTIVE lane
       if (first) {
@@ -920,13 +892,332 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
         }
         const int fl = __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1;
         off = tx_rl(off, fl); slot = tx_rl(slot, fl);
-        if (off < 0 || slot >= rectCap) { c.overflow = off < 0 ? 3 : 4; return; }
+        if (off < 0 || slot >= rectCap) { c.overflow = off < 0 ? 3 : 4; return false; }
         for (int i = lane; i < cnt; i += 64) arena[off + i] = qget(i);
         if (first) {
           RxRect& it = rects[slot];
           it.rank = r; it.off = off; it.cnt = cnt; it.sumdx = sumdx; it.sumdy = sumdy;
         }
       }
+      return true;
+  };
+
+  if constexpr (SPEC) {
+    // ------------------------------------------------------------------------------------------------------------------
+    // Speculative schedule of round 1 (the protocol of lsd_grow_image_spec, line_kernels.hip, with the owner words as the
+    // record of who holds what).  Most regions stay below nine pixels, and the plain schedule spends a whole wave's steps on
+    // each of them.  Here the wave collects 64 seeds of its list that are ALIVE (a "super-row", in rank order), every lane grows
+    // the region of its seed ALONE — no claims, against the owner words as they stand — up to TX_SPEC_CAP pixels, and then, in
+    // rank order:  a run of lanes that stayed below the cap is validated and committed together (a lane's speculative run equals
+    // its sequential run iff every pixel it ACCEPTED is still free of lower ranks when its turn comes: what it rejected stays
+    // rejected — owner words only go down within a round — and what it accepted decides everything it did afterwards); a lane
+    // that hit the cap is taken over by the whole wave where its last complete step ended (same condition on its prefix),
+    // or from its seed if the prefix does not stand; a lane whose seed is gone is dropped.  Two lanes of one run that want the
+    // same pixel settle it by their claims (atomicMin), and the loser is stamped for round 2, exactly as between tiles.
+    // ------------------------------------------------------------------------------------------------------------------
+    constexpr int CAP = TX_SPEC_CAP;
+    const int cap = min(CAP, minReg - 1);                 // a region that may yield a segment is never finished by a lane
+    const unsigned long long ltMask = (1ull << lane) - 1ull;
+    auto parkAt = [&](int row, int l) -> int& { return park[row * 64 + l]; };
+    auto wsync = [&]() {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto entryXY = [&](unsigned long long lst, int i, int sxy) -> int {          // packed (y << 16 | x) of list entry i
+      const int off = (int)((lst >> (8 * i)) & 0xFFull);
+      return (((sxy >> 16) + (off >> 4) - 8) << 16) | ((sxy & 0xFFFF) + (off & 15) - 8);
+    };
+    int pos = 0;
+    while (pos < n) {
+      // ---- collect: up to 64 alive seeds, in list order (several list rows per trip: their loads are issued together) ----
+      int nst = 0;
+      bool full = false;
+      while (!full && nst < 64 && pos < n) {
+        const int R = nst < 32 ? 4 : 2;
+        int2 se4[4];
+        int2 so4[4];
+        float an4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = pos + 64 * u + lane;
+          se4[u] = make_int2(TX_INF, -1);
+          if (u < R && idx < n) se4[u] = list[idx];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          so4[u] = make_int2(0, 0);
+          an4[u] = 0.f;
+          if (se4[u].y >= 0) {
+            so4[u] = tx_load_own(&own[se4[u].y]);
+            an4[u] = rec[se4[u].y].x;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (u >= R || full || pos >= n) continue;
+          const bool alive = se4[u].y >= 0 && so4[u].x == se4[u].x && so4[u].y == se4[u].x;
+          const unsigned long long bal = __builtin_amdgcn_ballot_w64(alive);
+          const int c = __popcll(bal);
+          if (nst + c > 64) { full = true; continue; }        // this row does not fit: it starts the next super-row
+          if (alive) {
+            const int at = nst + __popcll(bal & ltMask);
+            parkAt(0, at) = se4[u].x;
+            parkAt(1, at) = se4[u].y;
+            parkAt(2, at) = __float_as_int(an4[u]);
+          }
+          nst += c;
+          pos += 64;
+        }
+      }
+      if (nst == 0) continue;
+      wsync();
+      // ---- speculation: lane l < nst grows the region of staged seed l alone ----
+      // (everything a lane knows about its region is parked in LDS afterwards and read back where it is needed: nothing of it
+      // may stay in registers across the whole-wave growth below, whose loops have none to spare)
+      unsigned long long smallMask, bigMask;
+      {
+      const bool has = lane < nst;
+      const int r_l = has ? parkAt(0, lane) : TX_INF;
+      const int sp_l = has ? parkAt(1, lane) : 0;
+      const float sa_l = has ? __int_as_float(parkAt(2, lane)) : 0.f;
+      wsync();
+      const int spy = sp_l / W, spx = sp_l - spy * W;
+      float sumdx = 0.f, sumdy = 0.f;
+      double reg_angle = (double)sa_l * TX_DEG2RAD;
+      if (has) {
+        double sn, cn;
+        sincos(reg_angle, &sn, &cn);
+        sumdx = (float)cn;
+        sumdy = (float)sn;
+      }
+      unsigned long long lst = 0x88ull;                   // byte i: entry i as (dy + 8) << 4 | (dx + 8) relative to the seed
+      int cnt = 1, k = 0;
+      bool big = false;
+      {
+        bool active = has;
+        while (__builtin_amdgcn_ballot_w64(active)) {
+          if (active) {
+            const int off = (int)((lst >> (8 * k)) & 0xFFull);
+            const int px = spx + (off & 15) - 8, py = spy + (off >> 4) - 8;
+            const int cnt0 = cnt;                          // a step that hits the cap is abandoned: the state at its start stands
+            const unsigned long long lst0 = lst;
+            const float sdx0 = sumdx, sdy0 = sumdy;
+            int2 no[8];
+            float na[8];
+#pragma unroll
+            for (int nn = 0; nn < 8; ++nn) {
+              const int m = nn < 4 ? nn : nn + 1;         // the 3 x 3 block in raster order, centre skipped
+              const int nx = px + m % 3 - 1, ny = py + m / 3 - 1;
+              na[nn] = TX_NOTDEF;
+              no[nn] = make_int2(0, 0);
+              if (nx >= 0 && ny >= 0 && nx < W && ny < H) {
+                na[nn] = rec[ny * W + nx].x;
+                no[nn] = tx_load_own(&own[ny * W + nx]);
+              }
+            }
+#pragma unroll
+            for (int nn = 0; nn < 8; ++nn) {
+              if (big || na[nn] == TX_NOTDEF) continue;
+              const int prevv = ci ? no[nn].x : no[nn].y, curv = ci ? no[nn].y : no[nn].x;
+              if (prevv < r_l || curv <= r_l) continue;
+              const int m = nn < 4 ? nn : nn + 1;
+              const int nx = px + m % 3 - 1, ny = py + m / 3 - 1;
+              const int ox = nx - spx + 8, oy = ny - spy + 8;
+              if (((ox | oy) & ~15) == 0) {                // (beyond +-7 of the seed no pixel of the list lies)
+                const unsigned long long x = lst ^ ((unsigned long long)((oy << 4) | ox) * 0x0101010101010101ull);
+                const unsigned long long z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
+                const unsigned long long inList = cnt >= 8 ? ~0ull : ((1ull << (8 * cnt)) - 1ull);
+                if (z & inList) continue;                  // already mine
+              }
+              double n_theta = fabs(reg_angle - (double)na[nn] * TX_DEG2RAD);
+              if (n_theta > TX_3_2_PI) {
+                n_theta = fabs(n_theta - TX_2PI);
+              }
+              if (!(n_theta <= prec)) continue;
+              if (cnt == cap) { big = true; continue; }
+              const float4 rq = rec[ny * W + nx];
+              lst |= (unsigned long long)((oy << 4) | ox) << (8 * cnt);
+              ++cnt;
+              sumdx = __fadd_rn(sumdx, rq.y);
+              sumdy = __fadd_rn(sumdy, rq.z);
+              reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * TX_DEG2RAD;
+            }
+            if (big) { cnt = cnt0; lst = lst0; sumdx = sdx0; sumdy = sdy0; active = false; }
+            else {
+              ++k;
+              if (k >= cnt) active = false;
+            }
+          }
+        }
+      }
+      // ---- park the lanes' states; the whole wave works on one lane's region at a time from here on ----
+      const int sxy_l = (spy << 16) | spx;
+      parkAt(0, lane) = r_l;
+      parkAt(1, lane) = sxy_l;
+      parkAt(2, lane) = (int)(unsigned)(lst & 0xFFFFFFFFull);
+      parkAt(3, lane) = (int)(unsigned)(lst >> 32);
+      parkAt(4, lane) = cnt | (k << 8);
+      parkAt(5, lane) = __float_as_int(sumdx);
+      parkAt(6, lane) = __float_as_int(sumdy);
+      parkAt(7, lane) = __float_as_int(sa_l);
+      wsync();
+      smallMask = __builtin_amdgcn_ballot_w64(has && !big);
+      bigMask = __builtin_amdgcn_ballot_w64(has && big);
+      }
+      unsigned long long regrowMask = 0ull;                // lanes below the cap whose run does not stand (their seed does)
+      int lo = 0;
+      unsigned long long noSeeds = 0ull;
+      for (;;) {
+        int j;
+        bool scratch;
+        if (regrowMask) {
+          j = __ffsll((long long)regrowMask) - 1;
+          regrowMask &= regrowMask - 1ull;
+          scratch = true;
+        } else {
+          const unsigned long long bigAbove = lo < 64 ? (bigMask >> lo) << lo : 0ull;
+          const int jb = bigAbove ? __ffsll((long long)bigAbove) - 1 : 64;
+          const unsigned long long seg = smallMask & (jb < 64 ? (1ull << jb) - 1ull : ~0ull);
+          if (seg) {
+            // ---- a run of lanes below the cap: validated and committed together ----
+            smallMask &= ~seg;
+            const bool mine = (seg >> lane) & 1ull;
+            const int r = parkAt(0, lane), sxy_l = parkAt(1, lane), cnt = parkAt(4, lane) & 0xFF;
+            const unsigned long long lst = ((unsigned long long)(unsigned)parkAt(3, lane) << 32) | (unsigned long long)(unsigned)parkAt(2, lane);
+            int2 ow[CAP];
+#pragma unroll
+            for (int i = 0; i < CAP; ++i) {
+              ow[i] = make_int2(0, 0);
+              if (mine && i < cnt) {
+                const int xy = entryXY(lst, i, sxy_l);
+                ow[i] = tx_load_own(&own[(xy >> 16) * W + (xy & 0xFFFF)]);
+              }
+            }
+            bool ok = mine, seedGone = false;
+#pragma unroll
+            for (int i = 0; i < CAP; ++i) {
+              if (!(mine && i < cnt)) continue;
+              const int pv = ci ? ow[i].x : ow[i].y, cv = ci ? ow[i].y : ow[i].x;
+              if (pv < r || cv < r) { ok = false; if (i == 0) seedGone = true; }
+            }
+            if (ok) {
+              int bmin = sxy_l, bmax = sxy_l;
+              int olds[CAP];
+#pragma unroll
+              for (int i = 1; i < CAP; ++i) {
+                olds[i] = r;
+                if (i < cnt) {
+                  const int xy = entryXY(lst, i, sxy_l);
+                  int2* w = &own[(xy >> 16) * W + (xy & 0xFFFF)];
+                  olds[i] = __hip_atomic_fetch_min(ci ? &w->y : &w->x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  bmin = tx_pk_min_u16(bmin, xy);
+                  bmax = tx_pk_max_u16(bmax, xy);
+                }
+              }
+              rgSize[r] = cnt;
+              rgBox[r] = make_int2(bmin, bmax);
+              if (noteLost) {
+#pragma unroll
+                for (int i = 1; i < CAP; ++i) {
+                  if (i >= cnt) continue;
+                  const int pv = ci ? ow[i].x : ow[i].y;       // round 1: owner_0 is the trivial map, i.e. the pixel's own rank
+                  if (olds[i] < r) rgLost[r] = t;                              // a lower rank slipped in between the look and the claim
+                  else if (olds[i] != r && olds[i] != pv) rgLost[olds[i]] = t; // a higher rank held it: it has just lost the pixel
+                }
+              }
+            }
+            regrowMask = __builtin_amdgcn_ballot_w64(mine && !ok && !seedGone);
+            lo = jb;
+            if (regrowMask) continue;
+          }
+          if (jb >= 64) break;
+          j = jb;
+          bigMask &= ~(1ull << jb);
+          lo = jb + 1;
+          scratch = false;
+        }
+        // ---- lane j's region by the whole wave: from the prefix it has grown (if that stands), or from its seed ----
+        const int r = parkAt(0, j), sxy = parkAt(1, j);
+        const unsigned long long lstj = ((unsigned long long)(unsigned)parkAt(3, j) << 32) | (unsigned long long)(unsigned)parkAt(2, j);
+        const int meta = parkAt(4, j);
+        const int cntj = scratch ? 1 : (meta & 0xFF), kj = scratch ? 0 : (meta >> 8);
+        const float saj = __int_as_float(parkAt(7, j));
+        const int sp = (sxy >> 16) * W + (sxy & 0xFFFF);
+        // the prefix, one pixel per lane: does it still stand?
+        const int myxy = lane < cntj ? entryXY(lstj, lane, sxy) : sxy;
+        int2 ow = make_int2(0, 0);
+        if (lane < cntj) ow = tx_load_own(&own[(myxy >> 16) * W + (myxy & 0xFFFF)]);
+        const int pv = ci ? ow.x : ow.y, cv = ci ? ow.y : ow.x;
+        const unsigned long long taken = __builtin_amdgcn_ballot_w64(lane < cntj && (pv < r || cv < r));
+        if (taken & 1ull) continue;                        // the seed belongs to a lower rank: no region
+        float sdx, sdy;
+        int cnt2 = cntj, k2 = kj, bmin = sxy, bmax = sxy, pend0 = r, pendRank0 = 0;
+        if (taken == 0ull && cntj > 1) {
+          sdx = __int_as_float(parkAt(5, j));
+          sdy = __int_as_float(parkAt(6, j));
+          if (lane > 0 && lane < cntj) {
+            int2* w = &own[(myxy >> 16) * W + (myxy & 0xFFFF)];
+            pend0 = __hip_atomic_fetch_min(ci ? &w->y : &w->x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pendRank0 = pv;                                // (round 1: the pixel's own rank)
+          }
+          if (lane < cntj) q[lane] = myxy;
+          int mn = lane < cntj ? myxy : sxy, mx = mn;
+#pragma unroll
+          for (int o = 1; o < CAP; o <<= 1) {
+            mn = tx_pk_min_u16(mn, __shfl_xor(mn, o, 64));
+            mx = tx_pk_max_u16(mx, __shfl_xor(mx, o, 64));
+          }
+          bmin = tx_rl(mn, 0);
+          bmax = tx_rl(mx, 0);
+        } else {
+          double sn, cn;
+          sincos((double)saj * TX_DEG2RAD, &sn, &cn);
+          sdx = (float)cn;
+          sdy = (float)sn;
+          cnt2 = 1;
+          k2 = 0;
+          q[0] = sxy;                                       // every lane stores the same value
+        }
+        if (!growRegion(r, sp, saj, sdx, sdy, cnt2, k2, bmin, bmax, cnt2 == 1 ? 1 : 0, noSeeds, -1, pend0, pendRank0)) return;
+      }
+    }
+    return;
+  }
+  for (int base = 0; base < n; base += 64) {
+    const bool valid = base + lane < n;
+    int2 se = make_int2(TX_INF, -1);
+    if (useDirty) se = dse;                               // (n <= 64: one row)
+    else if (valid) se = list[base + lane];
+    bool d = valid;
+    if (SPARSE && !useDirty) d = valid && rgDirty[se.x] == t;
+    float4 srec = make_float4(TX_NOTDEF, 0.f, 0.f, 0.f);
+    int2 so = make_int2(0, 0);
+    if (d) {
+      srec = rec[se.y];
+      so = tx_load_own(&own[se.y]);
+    }
+    const bool alive = d && (ci ? so.x : so.y) == se.x && (ci ? so.y : so.x) == se.x;
+    // region_grow seeds its sums with cos/sin of the unrounded double angle
+    float scos = 0.f, ssin = 0.f;
+    if (alive) {
+      double sn, cn;
+      sincos((double)srec.x * TX_DEG2RAD, &sn, &cn);
+      scos = (float)cn;
+      ssin = (float)sn;
+    }
+    // (the packed (y, x) of the row's seeds, 64 at a time: a scalar division per region costs more than this one per row)
+    const unsigned spyv = (unsigned)max(se.y, 0) / (unsigned)W;
+    const int sxyv = (int)((spyv << 16) | ((unsigned)max(se.y, 0) - spyv * (unsigned)W));
+    unsigned long long unusedMask = __builtin_amdgcn_ballot_w64(alive);
+    while (unusedMask) {
+      const int j = __ffsll((long long)unusedMask) - 1;
+      unusedMask &= unusedMask - 1ull;
+      const int sxy = tx_rl(sxyv, j);
+      q[0] = sxy;                                         // every lane stores the same value
+      const int rj = tx_rl(se.x, j);
+      if (!growRegion(rj, tx_rl(se.y, j), tx_rlf(srec.x, j), tx_rlf(scos, j), tx_rlf(ssin, j), 1, 0, sxy, sxy, 1, unusedMask, se.y, rj, 0))
+        return;
     }
   }
 }
@@ -944,6 +1235,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   __shared__ int gb[TX_BMAXBLK];
   tx_grow_tile<false>(Pp, ctl, recAll, ownAll, listAll, tileCntAll, ts, ntx, nty, rgSizeAll, rgBoxAll, rgDirtyAll, tileActAll, TW, TH,
                    arenaAll, arenaCap, rectAll, rectCap, blockIdx.y + img0, blockIdx.x, t, rankAll, rgLostAll, tileTouchAll, DL, q, gb);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tx_grow_spec(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
+                                                const float4* __restrict__ recAll, int2* __restrict__ ownAll,
+                                                const int2* __restrict__ listAll, const int* __restrict__ tileCntAll,
+                                                int ts, int ntx, int nty, int* __restrict__ rgSizeAll,
+                                                int2* __restrict__ rgBoxAll, const int* __restrict__ rgDirtyAll,
+                                                const int* __restrict__ tileActAll, int TW, int TH,
+                                                int* __restrict__ arenaAll, int arenaCap, RxRect* __restrict__ rectAll,
+                                                int rectCap, int img0, int t, const int* __restrict__ rankAll,
+                                                int* __restrict__ rgLostAll, int* __restrict__ tileTouchAll, TxDirtyLists DL) {
+  __shared__ int q[TX_GQ_SPEC];
+  __shared__ int gb[TX_BMAXBLK];
+  __shared__ int park[8 * 64];
+  tx_grow_tile<false, true, TX_GQ_SPEC>(Pp, ctl, recAll, ownAll, listAll, tileCntAll, ts, ntx, nty, rgSizeAll, rgBoxAll, rgDirtyAll, tileActAll,
+                                        TW, TH, arenaAll, arenaCap, rectAll, rectCap, blockIdx.y + img0, blockIdx.x, t, rankAll, rgLostAll,
+                                        tileTouchAll, DL, q, gb, park);
 }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tx_grow_sparse(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
                                                        const float4* __restrict__ recAll, int2* __restrict__ ownAll,

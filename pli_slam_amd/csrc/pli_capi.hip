@@ -956,6 +956,15 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
               c->arenaCap, c->rects, c->rectCap, img0, t, (const int*)c->rankOf, lostRule ? c->rgLost : (int*)nullptr, c->tileTouch,
               fullRound2 && t == 2 ? noDL : DL);
         } else {
+          // round 1 in the speculative schedule (lanes grow the small regions of 64 alive seeds at a time, lsd_tile.hip): exact, built
+          // and measured in round 3, NOT the default — 37 ms against 22 ms of the plain schedule at 256 frames (the
+          // divergent per-lane accept path costs more instructions than the whole-wave steps it replaces).  Dev switch PLI_TX_SPEC=1.
+          const bool specRound1 = lostRule && P.minRegSize >= 3 && getenv("PLI_TX_SPEC") && atoi(getenv("PLI_TX_SPEC")) != 0;
+          if (specRound1)
+          TRL(c, "k_tx_grow", k_tx_grow_spec, dim3(ntile, nimg), dim3(64), txPad, c->dP, c->jrCtl, c->rec, c->own, c->txList,
+              c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty, c->tileAct, c->tilesW, c->tilesH, c->arena,
+              c->arenaCap, c->rects, c->rectCap, img0, t, (const int*)c->rankOf, lostRule ? c->rgLost : (int*)nullptr, c->tileTouch, noDL);
+          else
           TRL(c, "k_tx_grow", k_tx_grow, dim3(ntile, nimg), dim3(64), txPad, c->dP, c->jrCtl, c->rec, c->own, c->txList,
               c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty, c->tileAct, c->tilesW, c->tilesH, c->arena,
               c->arenaCap, c->rects, c->rectCap, img0, t, (const int*)c->rankOf, lostRule ? c->rgLost : (int*)nullptr, c->tileTouch, noDL);
