@@ -216,7 +216,10 @@ pli_status pli_batch_run_host(pli_ctx* ctx, int32_t nframes,
  * two submits may be in flight, so the copies of batch i+1 / i-1 overlap the kernels of batch i; a third submit first
  * waits for the oldest.  `left`, `right` and `table` should be pinned (pli_host_alloc, or memory the caller registered
  * with hipHostRegister) — pageable memory works but makes the copies synchronous.  pli_batch_wait(ctx, 0) waits for
- * the oldest outstanding submit (its table is then complete), pli_batch_wait(ctx, 1) for all of them. */
+ * the oldest outstanding submit (its table is then complete), pli_batch_wait(ctx, 1) for all of them.
+ * Footprint: the first submit allocates, beside the context's own buffers, two device staging slots of max_frames frames each
+ * (2 x width x height x max_frames bytes of images + max_frames table records per slot: 0.9 MB per frame at 752x480) and keeps
+ * them until pli_ctx_destroy. */
 pli_status pli_host_alloc(size_t bytes, void** out);
 void       pli_host_free(void* p);
 pli_status pli_batch_submit_host(pli_ctx* ctx, int32_t nframes,

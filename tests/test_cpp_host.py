@@ -132,3 +132,36 @@ def test_dropin_harness_builds_and_fails_loudly_without_a_device(tmp_path):
         assert int(read_dump(outp)["groups_left"][0, 0]) == 0
     else:
         assert r.returncode == 1 and "no HIP device" in r.stderr, (r.returncode, r.stderr)
+
+
+import pytest
+
+
+@pytest.mark.parametrize("sanitizer", ["thread", "address"])
+def test_adapters_under_sanitizers_with_a_mock_library(tmp_path, sanitizer):
+    """SURVEY §5 host hygiene: the drop-in harness (adapters, registry, Frame-level matchers, four std::threads per Frame) built with
+    -fsanitize=thread / address against tests/cpp/mock_pli.cpp — the C entry points with made-up deterministic results and the
+    library's threading contract (a lock per context) — and RUN here, without a GPU: no report from the sanitizer, the four-thread
+    run equals the sequential one, three repetitions are identical, the registry ends empty.  (The GPU suite runs the same harness on
+    the real library: tests/test_cpp_dropin.py.)"""
+    import numpy as np
+    from test_cpp_dropin import write_input, read_dump
+    exe = str(tmp_path / ("harness_" + sanitizer))
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=" + sanitizer, "-fno-omit-frame-pointer", "-pthread", "-I", ROOT, "-I",
+                        os.path.join(ROOT, "tests", "stubs"), os.path.join(ROOT, "tests", "cpp", "dropin_harness.cpp"),
+                        os.path.join(ROOT, "tests", "cpp", "mock_pli.cpp"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rng = np.random.default_rng(1)
+    frames = [(rng.integers(0, 256, (120, 160), dtype=np.uint8), rng.integers(0, 256, (120, 160), dtype=np.uint8)) for _ in range(6)]
+    dumps = {}
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66", ASAN_OPTIONS="detect_leaks=1 exitcode=66")
+    for mode in (1, 0):
+        inp, outp = str(tmp_path / "in"), str(tmp_path / ("out%d" % mode))
+        write_input(inp, frames, 3, mode, nfeatures=500, nlines=60)
+        r = subprocess.run([exe, inp, outp], capture_output=True, text=True, env=env)
+        assert r.returncode == 0 and "Sanitizer" not in r.stderr, (r.returncode, r.stderr[-3000:])
+        dumps[mode] = read_dump(outp)
+    a, b = dumps[1], dumps[0]
+    assert set(a) == set(b) and all(a[k].tobytes() == b[k].tobytes() for k in a)
+    assert len(set(a["hashes"].ravel().tolist())) == 1 and int(a["groups_left"][0, 0]) == 0
+    assert len(a["f0/mvKeys.f"]) >= 200 and len(a["f1/sbp0/match12"]) > 0 and int(a["f1/line_nmatches"][0, 0]) > 0
