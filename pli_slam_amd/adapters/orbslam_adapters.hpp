@@ -22,7 +22,10 @@
 #error "orbslam_adapters.hpp needs OpenCV 3 (it is meant to be compiled inside the PLI-SLAM tree)"
 #endif
 #include <opencv2/core/core.hpp>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <exception>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -56,6 +59,54 @@ struct LineParams {
   }
 };
 
+// Frame fusion.  Frame::Frame calls the four extractors of a group from four threads at the same time (Frame.cc:128-135).  When all
+// four calls of a frame are in flight together they are funnelled into ONE submission (pli_frame_extract: both eyes, points and
+// lines, and the two stereo matchers on top), and every thread takes its part from the frame's record: 2.7 ms per Frame instead of
+// 6.5 ms for four calls that queue behind the context's lock.  A call that finds itself alone for kWait (an integrator that calls
+// the extractors one after the other) switches the fusion off for this group for good and every call takes the per-call path —
+// the results are the same bytes either way (tests/test_cpp_dropin.py compares the two).
+struct FrameFusion {
+  static constexpr int kOrbL = 0, kOrbR = 1, kLineL = 2, kLineR = 3;
+  std::mutex m;
+  std::condition_variable cv;
+  bool enabled = true;
+  int arrived = 0;
+  uint64_t gen = 0;                          // frames fused so far
+  const uint8_t* img[4] = {nullptr, nullptr, nullptr, nullptr};
+  int64_t stride[4] = {0, 0, 0, 0};
+  std::vector<uint8_t> record;               // table record of the last fused frame (pli_table_layout)
+  std::exception_ptr error;                  // what the fused submission threw (every caller of that frame rethrows it)
+
+  // true: the frame was extracted in one submission and `record` holds it; false: take the per-call path
+  bool join(int kind, pli::Frontend& fe, const uint8_t* data, int w, int h, int64_t strideBytes) {
+    std::unique_lock<std::mutex> lk(m);
+    if (!enabled || img[kind] != nullptr) return false;     // (a second call of the same kind while a frame is collecting: not a Frame)
+    img[kind] = data; stride[kind] = strideBytes;
+    const uint64_t myGen = gen;
+    if (++arrived == 4) {
+      error = nullptr;
+      try {
+        fe.frameExtract(img[kOrbL], img[kOrbR], w, h, stride[kOrbL], stride[kOrbR], record);
+      } catch (...) {
+        error = std::current_exception();
+      }
+      arrived = 0;
+      for (int k = 0; k < 4; ++k) img[k] = nullptr;
+      ++gen;
+      cv.notify_all();
+    } else if (!cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::milliseconds(kWaitMs), [&] { return gen != myGen; })) {
+      // (system_clock: pthread_cond_timedwait, which gcc 11's ThreadSanitizer intercepts; the steady-clock wait is pthread_cond_clockwait)
+      img[kind] = nullptr;                   // nobody else came: withdraw, and do not wait again
+      --arrived;
+      enabled = false;
+      return false;
+    }
+    if (error) std::rethrow_exception(error);
+    return true;
+  }
+  static constexpr int kWaitMs = 2;
+};
+
 // One group = the extractors of one Frame constructor: ORB left/right + LSD left/right on one device context per image size.
 // orbMask / lineMask: which eye slots (bit 0 = left, bit 1 = right) are held by a living extractor.
 struct Group {
@@ -63,6 +114,7 @@ struct Group {
   OrbParams orb{};
   LineParams line{};
   int orbMask = 0, lineMask = 0;
+  FrameFusion fusion;
   std::mutex mu;
   std::map<std::pair<int, int>, std::shared_ptr<pli::Frontend>> ctx;     // by image size
 
@@ -186,7 +238,23 @@ class ORBextractor {
     std::shared_ptr<pli::Frontend> fe = group_->context(image.cols, image.rows);
     std::vector<pli_keypoint> kps;
     std::vector<uint8_t> desc;
-    const int n = fe->extractORB(eye_, image.data, image.cols, image.rows, (int64_t)image.step, kps, desc);
+    int n;
+    if (group_->orbMask == 3 && group_->lineMask == 3 &&
+        group_->fusion.join(eye_ ? pli_detail::FrameFusion::kOrbR : pli_detail::FrameFusion::kOrbL, *fe, image.data, image.cols, image.rows,
+                            (int64_t)image.step)) {
+      // the frame's record: counts, then this eye's keypoint table and descriptors
+      const pli_table_layout& Y = fe->layout();
+      const uint8_t* rec = group_->fusion.record.data();
+      n = reinterpret_cast<const int32_t*>(rec + Y.off_counts)[eye_];
+      kps.resize(n);
+      desc.resize((size_t)n * 32);
+      if (n) {
+        std::memcpy(kps.data(), rec + Y.off_kp[eye_], (size_t)n * sizeof(pli_keypoint));
+        std::memcpy(desc.data(), rec + Y.off_desc[eye_], (size_t)n * 32);
+      }
+    } else {
+      n = fe->extractORB(eye_, image.data, image.cols, image.rows, (int64_t)image.step, kps, desc);
+    }
     if (n < 0) return -1;
     // ORBextractor.cc:1135-1144: keypoints inside [vLappingArea[0], vLappingArea[1]] (level-0 x) go to the back of the
     // arrays (filled from the end), the others to the front in order; the return value is the number of front entries.
@@ -268,7 +336,21 @@ class Lineextractor {
     std::shared_ptr<pli::Frontend> fe = group_->context(image.cols, image.rows);
     std::vector<pli_keyline> kls;
     std::vector<uint8_t> desc;
-    fe->extractLines(eye_, image.data, image.cols, image.rows, (int64_t)image.step, kls, desc);
+    if (group_->orbMask == 3 && group_->lineMask == 3 &&
+        group_->fusion.join(eye_ ? pli_detail::FrameFusion::kLineR : pli_detail::FrameFusion::kLineL, *fe, image.data, image.cols, image.rows,
+                            (int64_t)image.step)) {
+      const pli_table_layout& Y = fe->layout();
+      const uint8_t* rec = group_->fusion.record.data();
+      const int n = reinterpret_cast<const int32_t*>(rec + Y.off_counts)[2 + eye_];
+      kls.resize(n);
+      desc.resize((size_t)n * 32);
+      if (n) {
+        std::memcpy(kls.data(), rec + Y.off_kl[eye_], (size_t)n * sizeof(pli_keyline));
+        std::memcpy(desc.data(), rec + Y.off_ldesc[eye_], (size_t)n * 32);
+      }
+    } else {
+      fe->extractLines(eye_, image.data, image.cols, image.rows, (int64_t)image.step, kls, desc);
+    }
     keylines.resize(kls.size());
     for (size_t i = 0; i < kls.size(); ++i) {
       PliKeyLine& k = keylines[i];

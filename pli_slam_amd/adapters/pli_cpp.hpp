@@ -81,6 +81,11 @@ class Frontend {
     desc.resize((size_t)n * 32);
   }
 
+  // the whole front-end of one Frame in one submission (pli_frame_extract): `record` = the frame's table record (layout())
+  void frameExtract(const uint8_t* left, const uint8_t* right, int w, int h, int64_t strideLeft, int64_t strideRight, std::vector<uint8_t>& record) {
+    record.resize((size_t)layout_.record_bytes);
+    check(pli_frame_extract(ctx_, left, right, w, h, strideLeft, strideRight, record.data()));
+  }
   // sizes of the device tables of the last per-call extractions: mvKeys, mvKeysRight, mvKeys_Line, mvKeysRight_Line (-1: not run)
   void lastCounts(int32_t counts[4]) { check(pli_last_counts(ctx_, counts)); }
   // the rig Frame::ComputeStereoMatches works with: mbf and fx = mK(0,0) (Frame.cc:1005-1008)

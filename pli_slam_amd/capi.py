@@ -105,6 +105,7 @@ _PROTOS = {
     "pli_batch_wait": (C.c_int32, [C.c_void_p, C.c_int32]),
     "pli_track_layout_get": (C.c_int32, [C.c_void_p, C.POINTER(TrackLayout)]),
     "pli_batch_track": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(TrackParams), C.c_void_p]),
+    "pli_frame_extract": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
     "pli_orb_extract": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p,
                                     C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]),
     "pli_orb_pyramid_level": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,

@@ -134,6 +134,11 @@ struct pli_ctx {
   uint8_t* ownTable = nullptr;
   std::vector<uint8_t> hostRec;
   bool orbDone[2] = {false, false}, lineDone[2] = {false, false};
+  bool frameFresh = false;                   // ownTable / hostRec hold the COMPLETE record of one Frame (pli_frame_extract): the stereo
+                                             // matchers hand it out without running again; any per-call extraction ends that
+  uint8_t* recPinned = nullptr;              // pinned staging of that record
+  uint8_t* pyrHost[2] = {nullptr, nullptr};  // pinned copy of an eye's pyramid block (pli_orb_pyramid_level)
+  bool pyrHostValid[2] = {false, false};     // ... is the one of the last extraction on that eye
   int orbCount[2] = {0, 0};                  // keypoints the last pli_orb_extract(_lapping) left in each eye's table
   int lineCount[2] = {0, 0};                 // keylines the last pli_line_extract left in each eye's table
   int monoCount[2] = {0, 0};                 // pli_orb_extract_lapping: first lapping-area keypoint of each eye's table
@@ -1203,6 +1208,8 @@ void pli_ctx_destroy(pli_ctx* c) {
   }
   if (c->sH2D) { hipStreamDestroy(c->sH2D); hipStreamDestroy(c->sD2H); }
   if (c->rxSeen) { hipHostFree(c->rxSeen); hipEventDestroy(c->evRxSeen); }
+  for (int e = 0; e < 2; ++e) if (c->pyrHost[e]) hipHostFree(c->pyrHost[e]);
+  if (c->recPinned) hipHostFree(c->recPinned);
   delete c;
 }
 
@@ -1354,6 +1361,39 @@ pli_status pli_batch_run_host(pli_ctx* c, int32_t nframes, const uint8_t* left, 
   return PLI_OK;
 }
 
+pli_status pli_frame_extract(pli_ctx* c, const uint8_t* left, const uint8_t* right, int32_t w, int32_t h, int64_t strideLeft,
+                             int64_t strideRight, void* record) {
+  CtxGuard guard__(c);
+  if (!c || !record) { g_err = "null argument"; return PLI_ERR_INVALID; }
+  pli_status st = checkImage(c, left, w, h, strideLeft);
+  if (st != PLI_OK) return st;
+  if ((st = checkImage(c, right, w, h, strideRight)) != PLI_OK) return st;
+  HIPCHK(hipSetDevice(c->device));
+  const int W = c->cfg.width, H = c->cfg.height;
+  HIPCHK(hipMemcpy2DAsync(c->inStage[0], W, left, strideLeft, W, H, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpy2DAsync(c->inStage[1], W, right, strideRight, W, H, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemsetAsync(c->ownTable, 0, (size_t)c->lay.record_bytes, c->stream));
+  c->frameFresh = false;
+  if ((st = pli_batch_run(c, 1, c->inStage[0], c->inStage[1], W, 0, PLI_RUN_ALL, c->ownTable)) != PLI_OK) return st;
+  if (!c->recPinned) HIPCHK(hipHostMalloc((void**)&c->recPinned, (size_t)c->lay.record_bytes, hipHostMallocDefault));
+  HIPCHK(hipMemcpyAsync(c->recPinned, c->ownTable, (size_t)c->lay.record_bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  std::memcpy(c->hostRec.data(), c->recPinned, (size_t)c->lay.record_bytes);
+  std::memcpy(record, c->recPinned, (size_t)c->lay.record_bytes);
+  const int32_t* counts = reinterpret_cast<const int32_t*>(c->hostRec.data() + c->lay.off_counts);
+  for (int e = 0; e < 2; ++e) {
+    c->orbDone[e] = c->lineDone[e] = true;
+    c->orbCount[e] = c->monoCount[e] = counts[e];
+    c->lineCount[e] = counts[2 + e];
+    c->pyrHostValid[e] = false;
+  }
+  const uint8_t* flags = reinterpret_cast<const uint8_t*>(counts + 6);
+  if (flags[0] || flags[1]) { g_err = "more segments pass the length cut than max_lines holds: raise pli_frontend_config.max_lines"; return PLI_ERR_CAPACITY; }
+  if (flags[2] || flags[3]) { g_err = "more keypoints than kp_cap holds"; return PLI_ERR_CAPACITY; }
+  c->frameFresh = true;
+  return PLI_OK;
+}
+
 pli_status pli_host_alloc(size_t bytes, void** out) {
   if (!out) { g_err = "null argument"; return PLI_ERR_INVALID; }
   *out = nullptr;
@@ -1446,6 +1486,8 @@ pli_status pli_orb_extract(pli_ctx* c, int32_t eye, const uint8_t* img, int32_t 
   HIPCHK(hipStreamSynchronize(c->stream));
   const int N = counts[eye];
   c->orbDone[eye] = true;
+  c->frameFresh = false;
+  c->pyrHostValid[eye] = false;
   c->orbCount[eye] = N;
   c->monoCount[eye] = N;
   *n = N;
@@ -1467,8 +1509,17 @@ pli_status pli_orb_pyramid_level(pli_ctx* c, int32_t eye, int32_t level, uint8_t
   if (h) *h = G.h;
   if (!dst) return PLI_OK;
   if (dstBytes < (int64_t)G.w * G.h) { g_err = "buffer too small"; return PLI_ERR_CAPACITY; }
-  HIPCHK(hipStreamSynchronize(c->stream));
-  HIPCHK(hipMemcpy2D(dst, G.w, c->pyr + (int64_t)eye * c->hp.pyrBlock + G.offset, G.pitch, G.w, G.h, hipMemcpyDeviceToHost));
+  // One device-to-host copy of the eye's whole pyramid block into pinned memory per extraction (1.3 MB at 752x480), then the levels
+  // are de-pitched on the host: eight pitched hipMemcpy2D calls into pageable memory cost 0.8 ms EACH (13 ms per extractor call of
+  // the adapters, which fill the public member mvImagePyramid).
+  if (!c->pyrHost[eye]) HIPCHK(hipHostMalloc((void**)&c->pyrHost[eye], (size_t)c->hp.pyrBlock, hipHostMallocDefault));
+  if (!c->pyrHostValid[eye]) {
+    HIPCHK(hipMemcpyAsync(c->pyrHost[eye], c->pyr + (int64_t)eye * c->hp.pyrBlock, (size_t)c->hp.pyrBlock, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->pyrHostValid[eye] = true;
+  }
+  const uint8_t* src = c->pyrHost[eye] + G.offset;
+  for (int y = 0; y < G.h; ++y) std::memcpy(dst + (size_t)y * G.w, src + (size_t)y * G.pitch, (size_t)G.w);
   return PLI_OK;
 }
 
@@ -1488,6 +1539,7 @@ pli_status pli_line_extract(pli_ctx* c, int32_t eye, const uint8_t* img, int32_t
   HIPCHK(hipStreamSynchronize(c->stream));
   const int N = counts[2 + eye];
   c->lineDone[eye] = true;
+  c->frameFresh = false;
   c->lineCount[eye] = N;
   *n = N;
   if (reinterpret_cast<const uint8_t*>(counts + 6)[eye]) {
@@ -1543,6 +1595,14 @@ pli_status pli_stereo_match_points(pli_ctx* c, float* uright, float* depth, int3
   CtxGuard guard__(c);
   if (!c) return PLI_ERR_INVALID;
   if (!c->orbDone[0] || !c->orbDone[1]) { g_err = "pli_orb_extract must run for both eyes first"; return PLI_ERR_STATE; }
+  if (c->frameFresh) {                                  // (pli_frame_extract has matched already)
+    const pli_table_layout& Yf = c->lay;
+    const int Nf = c->orbCount[0];
+    if (Nf > cap) { g_err = "output buffer too small"; return PLI_ERR_CAPACITY; }
+    if (uright) std::memcpy(uright, c->hostRec.data() + Yf.off_uright, (size_t)Nf * 4);
+    if (depth) std::memcpy(depth, c->hostRec.data() + Yf.off_depth, (size_t)Nf * 4);
+    return PLI_OK;
+  }
   HIPCHK(hipSetDevice(c->device));
   pli_status st = runStereoPoints(c, 1, c->ownTable);
   if (st != PLI_OK) return st;
@@ -1727,6 +1787,14 @@ pli_status pli_stereo_match_lines(pli_ctx* c, float* disp, double* le, int32_t c
   CtxGuard guard__(c);
   if (!c) return PLI_ERR_INVALID;
   if (!c->lineDone[0] || !c->lineDone[1]) { g_err = "pli_line_extract must run for both eyes first"; return PLI_ERR_STATE; }
+  if (c->frameFresh) {                                  // (pli_frame_extract has matched already)
+    const pli_table_layout& Yf = c->lay;
+    const int Nf = c->lineCount[0];
+    if (Nf > cap) { g_err = "output buffer too small"; return PLI_ERR_CAPACITY; }
+    if (disp) std::memcpy(disp, c->hostRec.data() + Yf.off_disp, (size_t)Nf * 8);
+    if (le) std::memcpy(le, c->hostRec.data() + Yf.off_le, (size_t)Nf * 24);
+    return PLI_OK;
+  }
   HIPCHK(hipSetDevice(c->device));
   pli_status st = runStereoLines(c, 1, c->ownTable);
   if (st != PLI_OK) return st;

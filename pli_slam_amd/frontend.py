@@ -298,6 +298,15 @@ class Frontend:
         check(self.L.pli_batch_run(self.h, nframes, C.c_void_p(dev_left), C.c_void_p(dev_right), stride, frame_stride,
                                    stages, C.c_void_p(dev_table)))
 
+    def frame_extract(self, left, right):
+        """pli_frame_extract: the whole front-end of one Frame (both eyes, points and lines, the two stereo matchers) in one
+        submission; returns the parsed record and leaves the per-call state behind (pyramid_level, compute_stereo_matches)."""
+        left, right = _u8(left), _u8(right)
+        rec = np.zeros(int(self.layout.record_bytes), np.uint8)
+        check(self.L.pli_frame_extract(self.h, ptr(left), ptr(right), left.shape[1], left.shape[0], left.strides[0],
+                                       right.strides[0], ptr(rec)))
+        return self.parse_record(rec, 0)
+
     def lsd_round_stats(self):
         """(rounds launched without a look by the last call, rounds its slowest image needed or -1, images that took the
         device-side fallback so far, rounds the next call plans from) — pli_lsd_round_stats; synchronises."""

@@ -30,6 +30,7 @@ struct KeyLine {      // field names as Thirdparty/line_descriptor/include/line_
 #include <map>
 #include <string>
 #include <thread>
+#include <chrono>
 
 using namespace ORB_SLAM3;
 using cv::line_descriptor::KeyLine;
@@ -66,18 +67,25 @@ class Frame {
       threadLeft_Line.join();
       threadRight_Line.join();
     } else {
+      const auto t0 = std::chrono::steady_clock::now();
       ExtractORB(0, imLeft, 0, 0);
       ExtractORB(1, imRight, 0, 0);
+      const auto t1 = std::chrono::steady_clock::now();
       ExtractLine(0, imLeft);
       ExtractLine(1, imRight);
+      const auto t2 = std::chrono::steady_clock::now();
+      stageSeconds[0] += std::chrono::duration<double>(t1 - t0).count();
+      stageSeconds[1] += std::chrono::duration<double>(t2 - t1).count();
     }
     N = (int)mvKeys.size();                                             // :143
     if (mvKeys.empty()) return;                                         // :146-149
     if (mvKeys_Line.empty()) return;
     mvKeysUn = mvKeys;                                                  // UndistortKeyPoints with mDistCoef = 0 (:151)
+    const auto t3 = std::chrono::steady_clock::now();
     ComputeStereoMatches_Lines();                                       // :158-163
     N_l = (int)mvKeys_Line.size();
     ComputeStereoMatches();
+    stageSeconds[2] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t3).count();
     mvpMapPoints = std::vector<MapPoint*>(N, static_cast<MapPoint*>(NULL));     // :171-174
     mvbOutlier = std::vector<bool>(N, false);
     mnMinX = 0.0f; mnMaxX = (float)imLeft.cols; mnMinY = 0.0f; mnMaxY = (float)imLeft.rows;   // ComputeImageBounds, no distortion (:182)
@@ -96,6 +104,7 @@ class Frame {
   void ComputeStereoMatches() { pli_frame::ComputeStereoMatches(*this); }                            // Frame.h:152
   void ComputeStereoMatches_Lines(bool initial = true) { pli_frame::ComputeStereoMatches_Lines(*this, initial); }   // Frame.h:154
 
+  static double stageSeconds[3];     // (sequential mode) ORB x2, lines x2, the two stereo matchers
   ORBextractor *mpORBextractorLeft, *mpORBextractorRight;
   Lineextractor *mpLineextractorLeft, *mpLineextractorRight;
   cv::Mat mK;
@@ -115,6 +124,8 @@ class Frame {
   float mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0;
   cv::Mat mTcw;
 };
+
+double Frame::stageSeconds[3] = {0, 0, 0};
 
 // ---- output: named arrays -------------------------------------------------------------------------------------------
 struct Dump {
@@ -242,6 +253,8 @@ int main(int argc, char** argv) {
     Dump out(argv[2]);
     if (!out.f) { std::perror(argv[2]); return 2; }
     std::vector<uint64_t> hashes;
+    double frameSeconds = 0.0;      // wall time of the Frame constructors (extraction x4 + the two stereo matchers), the first two frames left out
+    long framesTimed = 0;
     // pose of the last frame (a rotated, shifted world) and three motions: forward (tlc.z > mb), backward, sideways
     const cv::Mat Tlw = pose(0.02f, -0.015f, 0.3f, -0.2f, 0.5f);
     for (int rep = 0; rep < reps; ++rep) {
@@ -249,8 +262,10 @@ int main(int argc, char** argv) {
       std::unique_ptr<Frame> last;
       std::vector<std::unique_ptr<MapPoint>> lastPoints;
       for (int i = 0; i < nframes; ++i) {
+        const auto tFrame0 = std::chrono::steady_clock::now();
         std::unique_ptr<Frame> cur(new Frame(imgs[2 * i], imgs[2 * i + 1], mpORBextractorLeft, mpORBextractorRight, mpLineextractorLeft,
                                              mpLineextractorRight, K, bf, mode == 1));
+        if (rep > 0 || i >= 2) { frameSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tFrame0).count(); ++framesTimed; }
         Dump* o = rep == 0 ? &out : nullptr;
         const std::string pre = "f" + std::to_string(i) + "/";
         h = record(*cur, o, pre, h);
@@ -325,12 +340,17 @@ int main(int argc, char** argv) {
       hashes.push_back(h);
     }
     out.put("hashes", 'Q', (int)hashes.size(), 1, hashes.data());
+    const double msPerFrame = framesTimed ? frameSeconds / framesTimed * 1e3 : 0.0;
+    out.put("frame_ms", 'd', 1, 1, &msPerFrame);
     // destruction order as a System shutdown; the registry must end empty (contexts are released)
     delete mpORBextractorLeft; delete mpORBextractorRight; delete mpLineextractorLeft; delete mpLineextractorRight;
     const int left = (int)pli_detail::Registry::get().groups.size();
     out.put("groups_left", 'i', 1, 1, &left);
-    std::printf("dropin_harness: %d frames x %d repetitions (%s), hash %016llx\n", nframes, reps, mode == 1 ? "four threads" : "sequential",
-                (unsigned long long)hashes[0]);
+    std::printf("dropin_harness: %d frames x %d repetitions (%s), hash %016llx, %.3f ms per Frame constructor\n", nframes, reps,
+                mode == 1 ? "four threads" : "sequential", (unsigned long long)hashes[0], msPerFrame);
+    if (mode != 1)
+      std::printf("  per Frame: ORB x2 %.3f ms, lines x2 %.3f ms, stereo matchers %.3f ms\n", Frame::stageSeconds[0] * 1e3 / (nframes * reps),
+                  Frame::stageSeconds[1] * 1e3 / (nframes * reps), Frame::stageSeconds[2] * 1e3 / (nframes * reps));
   } catch (const std::exception& e) {
     std::fprintf(stderr, "dropin_harness: %s\n", e.what());
     return 1;

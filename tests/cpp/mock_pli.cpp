@@ -43,7 +43,18 @@ pli_status pli_ctx_create(const pli_frontend_config* cfg, int32_t, pli_ctx** out
   pli_ctx* c = new pli_ctx();
   c->cfg = *cfg;
   std::memset(&c->lay, 0, sizeof(c->lay));
-  c->lay.kp_cap = pli_kp_capacity(cfg); c->lay.kl_cap = pli_kl_capacity(cfg); c->lay.record_bytes = 1 << 16;
+  pli_table_layout& L = c->lay;
+  L.kp_cap = pli_kp_capacity(cfg); L.kl_cap = pli_kl_capacity(cfg);
+  int64_t o = 0;
+  auto take = [&](int64_t bytes) { const int64_t r = o; o = (o + bytes + 15) / 16 * 16; return r; };
+  L.off_counts = take(32);
+  for (int e = 0; e < 2; ++e) L.off_kp[e] = take((int64_t)L.kp_cap * sizeof(pli_keypoint));
+  for (int e = 0; e < 2; ++e) L.off_desc[e] = take((int64_t)L.kp_cap * 32);
+  L.off_uright = take((int64_t)L.kp_cap * 4); L.off_depth = take((int64_t)L.kp_cap * 4);
+  for (int e = 0; e < 2; ++e) L.off_kl[e] = take((int64_t)L.kl_cap * sizeof(pli_keyline));
+  for (int e = 0; e < 2; ++e) L.off_ldesc[e] = take((int64_t)L.kl_cap * 32);
+  L.off_disp = take((int64_t)L.kl_cap * 8); L.off_le = take((int64_t)L.kl_cap * 24);
+  L.record_bytes = o;
   *out = c;
   return PLI_OK;
 }
@@ -122,6 +133,23 @@ pli_status pli_stereo_match_lines(pli_ctx* c, float* disp, double* le, int32_t c
     disp[2 * i] = m ? 3.f + i : -1.f; disp[2 * i + 1] = m ? 4.f + i : -1.f;
     le[3 * i] = m ? 0.6 : 0.0; le[3 * i + 1] = m ? 0.8 : 0.0; le[3 * i + 2] = m ? -(double)i : 0.0;
   }
+  return PLI_OK;
+}
+pli_status pli_frame_extract(pli_ctx* c, const uint8_t* left, const uint8_t* right, int32_t w, int32_t h, int64_t sl, int64_t sr, void* record) {
+  Lock l(c);
+  uint8_t* rec = (uint8_t*)record;
+  std::memset(rec, 0, (size_t)c->lay.record_bytes);
+  int32_t* counts = (int32_t*)(rec + c->lay.off_counts);
+  const uint8_t* im[2] = {left, right};
+  const int64_t st[2] = {sl, sr};
+  for (int e = 0; e < 2; ++e) {
+    pli_status s = pli_orb_extract(c, e, im[e], w, h, st[e], (pli_keypoint*)(rec + c->lay.off_kp[e]), c->lay.kp_cap, rec + c->lay.off_desc[e], &counts[e]);
+    if (s != PLI_OK) return s;
+    s = pli_line_extract(c, e, im[e], w, h, st[e], (pli_keyline*)(rec + c->lay.off_kl[e]), c->lay.kl_cap, rec + c->lay.off_ldesc[e], &counts[2 + e]);
+    if (s != PLI_OK) return s;
+  }
+  pli_stereo_match_points(c, (float*)(rec + c->lay.off_uright), (float*)(rec + c->lay.off_depth), c->lay.kp_cap);
+  pli_stereo_match_lines(c, (float*)(rec + c->lay.off_disp), (double*)(rec + c->lay.off_le), c->lay.kl_cap);
   return PLI_OK;
 }
 pli_status pli_match_lines(pli_ctx* c, const uint8_t*, int32_t n1, const uint8_t*, int32_t n2, float, int32_t* m12, int32_t* n) {

@@ -125,8 +125,11 @@ def test_four_threads_equal_sequential_calls_and_repeat_identically(runs):
     assert t["hashes"][0, 0] == s["hashes"][0, 0]
     assert set(t) == set(s)
     for k in t:
-        if k != "hashes":
+        if k not in ("hashes", "frame_ms"):
             same(t[k], s[k], k)
+    # the four threads of a Frame are fused into one submission (FrameFusion); four calls in a row take the per-call path
+    print("Frame constructor: %.2f ms on four threads (fused), %.2f ms as four calls" % (t["frame_ms"][0, 0], s["frame_ms"][0, 0]))
+    assert t["frame_ms"][0, 0] < s["frame_ms"][0, 0]
     assert int(t["groups_left"][0, 0]) == 0, "extractor destruction left device contexts in the registry"
     n = [len(t["f%d/mvKeys.f" % i]) for i in range(50)]
     assert min(n) > 600 and min(len(t["f%d/mvKeys_Line.f" % i]) for i in range(50)) > 20

@@ -162,6 +162,6 @@ def test_adapters_under_sanitizers_with_a_mock_library(tmp_path, sanitizer):
         assert r.returncode == 0 and "Sanitizer" not in r.stderr, (r.returncode, r.stderr[-3000:])
         dumps[mode] = read_dump(outp)
     a, b = dumps[1], dumps[0]
-    assert set(a) == set(b) and all(a[k].tobytes() == b[k].tobytes() for k in a)
+    assert set(a) == set(b) and all(a[k].tobytes() == b[k].tobytes() for k in a if k != "frame_ms")
     assert len(set(a["hashes"].ravel().tolist())) == 1 and int(a["groups_left"][0, 0]) == 0
     assert len(a["f0/mvKeys.f"]) >= 200 and len(a["f1/sbp0/match12"]) > 0 and int(a["f1/line_nmatches"][0, 0]) > 0

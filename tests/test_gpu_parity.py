@@ -1098,3 +1098,25 @@ def test_look_free_rounds_and_device_side_fallback(gpu, monkeypatch):
             else:
                 for k in ("klL", "klR", "ldescL", "ldescR", "disp", "le"):
                     assert recs[f][k].tobytes() == first[f][k].tobytes(), (what, f, k)
+
+
+def test_frame_extract_equals_the_per_call_entry_points(cfg2):
+    """pli_frame_extract (what the adapters fuse the four extractor threads of a Frame into) against the four per-call entry points
+    and the two stereo matchers: the same record, and the per-call state it leaves (pyramid levels, stereo matchers without a rerun)."""
+    g, cfg, fe, fr, L, R = cfg2
+    rec = fe.frame_extract(L, R)
+    ur, dp = fe.compute_stereo_matches()                  # handed out from the frame's record
+    disp, le = fe.compute_stereo_matches_lines()
+    N, NL = len(rec["kpL"]), len(rec["klL"])
+    assert rec["uright"].tobytes() == ur[:N].tobytes() and rec["depth"].tobytes() == dp[:N].tobytes()
+    assert rec["disp"].tobytes() == disp[:NL].tobytes() and rec["le"].tobytes() == le[:NL].tobytes()
+    p0 = fe.pyramid_level(0, 0)
+    assert np.array_equal(p0, L) and fe.pyramid_level(1, 7).shape == fr.pyramid(1, 7).shape
+    assert_frame_equal(g, rec, g.po.Frame(ocfg(g, cfg)), L, R, "pli_frame_extract")
+    for eye, img, k in ((0, L, "L"), (1, R, "R")):       # the per-call path afterwards: same tables, and the stereo matchers run again
+        n, kp, desc = fe.orb_extract(eye, img)
+        assert kp.tobytes() == rec["kp" + k].tobytes() and np.array_equal(desc, rec["desc" + k])
+        m, kl, ld = fe.line_extract(eye, img)
+        assert kl.tobytes() == rec["kl" + k].tobytes() and np.array_equal(ld, rec["ldesc" + k])
+    ur2, dp2 = fe.compute_stereo_matches()
+    assert ur2[:N].tobytes() == ur[:N].tobytes() and dp2[:N].tobytes() == dp[:N].tobytes()
