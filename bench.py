@@ -595,6 +595,13 @@ def main():
                     f1.batch_run_device(1, d_left.data_ptr(), d_right.data_ptr(), W, W * H, t1.data_ptr())
                 torch.cuda.synchronize()
                 out["single_pair"] = {"ms": (time.perf_counter() - ts) / 10 * 1e3, "note": "one stereo pair per call, 10 calls"}
+                # ... and the shape System::TrackStereo issues: one Frame from HOST images through pli_frame_extract (what the C++
+                # adapters fuse the four extractor threads of Frame.cc:128-135 into), record back on the host
+                for rep in range(12):
+                    if rep == 2:
+                        ts = time.perf_counter()
+                    f1.frame_extract(images[rep % nuniq, 0], images[rep % nuniq, 1])
+                out["single_pair"]["frame_extract_host_ms"] = (time.perf_counter() - ts) / 10 * 1e3
                 del f1
             if not args.no_host_leg:
                 out["host_inclusive"] = host_inclusive_leg(fe, images, F, nuniq, W, H, rec_bytes, args.steps)

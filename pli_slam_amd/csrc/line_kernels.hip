@@ -1451,24 +1451,41 @@ __global__ __launch_bounds__(256) void k_keylines(const DevParams* __restrict__ 
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_sobel(const uint8_t* __restrict__ in, int64_t imgStride, int W, int H,
                                                int pitch, short2* __restrict__ dxy, int img0) {
-  // 4 adjacent pixels per thread: 6 bytes of each of the three rows, one 16-byte store of interleaved (dx, dy)
+  // 4 adjacent pixels per thread: ONE aligned dword of each of the three rows per thread — the byte on its left and the byte on its
+  // right come from the neighbouring lanes' dwords (the first and the last lane of a wave load theirs), where the earlier form
+  // issued 18 byte loads per thread — and one 16-byte store of interleaved (dx, dy).  (Rows are pitch = align64(W) bytes: a dword at
+  // x0 < W is inside the row.)
   const int img = blockIdx.z + img0, y = blockIdx.y, x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (x0 >= W) return;
+  const int lane = threadIdx.x & 63;
   const uint8_t* base = in + (int64_t)img * imgStride;
-  const uint8_t* r0 = base + (int64_t)reflect101(y - 1, H) * pitch;
-  const uint8_t* r1 = base + (int64_t)y * pitch;
-  const uint8_t* r2 = base + (int64_t)reflect101(y + 1, H) * pitch;
-  int a[6], b[6], c[6];
+  const uint8_t* rows[3] = {base + (int64_t)reflect101(y - 1, H) * pitch, base + (int64_t)y * pitch, base + (int64_t)reflect101(y + 1, H) * pitch};
+  const bool live = x0 < W;
+  int v[3][6];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const int xx = reflect101(min(x0 + k - 1, W), W);       // (columns past the image are not stored)
-    a[k] = r0[xx]; b[k] = r1[xx]; c[k] = r2[xx];
+  for (int r = 0; r < 3; ++r) {
+    unsigned cur = 0u;
+    if (live) cur = *reinterpret_cast<const unsigned*>(rows[r] + x0);
+    unsigned prev = (unsigned)__shfl_up((int)cur, 1, 64), next = (unsigned)__shfl_down((int)cur, 1, 64);
+    if (lane == 0 && live && x0 >= 4) prev = *reinterpret_cast<const unsigned*>(rows[r] + x0 - 4);
+    if (lane == 63 && x0 + 4 < W) next = *reinterpret_cast<const unsigned*>(rows[r] + x0 + 4);
+    v[r][1] = cur & 0xFF; v[r][2] = (cur >> 8) & 0xFF; v[r][3] = (cur >> 16) & 0xFF; v[r][4] = cur >> 24;
+    v[r][0] = x0 == 0 ? v[r][2] : (int)(prev >> 24);              // REFLECT_101: column -1 is column 1
+    v[r][5] = (int)(next & 0xFF);
+  }
+  if (!live) return;
+  if (x0 + 4 >= W) {
+    // the thread that holds the last column(s): columns past the image are not stored, column W is column W - 2
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int k = 1; k < 6; ++k)
+        if (x0 + k - 1 >= W) v[r][k] = rows[r][reflect101(min(x0 + k - 1, W), W)];
   }
   short2 o[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int gx = (a[k + 2] - a[k]) + 2 * (b[k + 2] - b[k]) + (c[k + 2] - c[k]);
-    const int gy = (c[k] - a[k]) + 2 * (c[k + 1] - a[k + 1]) + (c[k + 2] - a[k + 2]);
+    const int gx = (v[0][k + 2] - v[0][k]) + 2 * (v[1][k + 2] - v[1][k]) + (v[2][k + 2] - v[2][k]);
+    const int gy = (v[2][k] - v[0][k]) + 2 * (v[2][k + 1] - v[0][k + 1]) + (v[2][k + 2] - v[0][k + 2]);
     o[k] = make_short2((short)gx, (short)gy);      // interleaved: k_lbd gathers both with one 4-byte load
   }
   short2* dst = dxy + (int64_t)img * W * H + (int64_t)y * W + x0;
