@@ -56,6 +56,33 @@ def compare(d):
             close = seg.shape == want.shape and np.abs(seg - want).max(initial=0) <= 0.5
             hits.append((flags, "exact" if exact else "within 0.5 px" if close else "%d vs %d segments" % (len(seg), len(want))))
         res[name + " LSD per parity flags (0 u8, 2 u8+cosf, 8 f64, 10 f64+cosf)"] = hits
+        # stage 2 (tools/pin/pin_reference_extractors.cpp): the reference's own ORBextractor / Lineextractor on the same image — pins
+        # the quadtree's tie-break, the LSD seed order and the order of equal responses, which no primitive shows
+        if os.path.exists(os.path.join(d, name + "_ref_orb_kp_f.npy")):
+            rkf, rki, rd = g("ref_orb_kp_f"), g("ref_orb_kp_i"), g("ref_orb_desc")
+            orb_hits = []
+            for flags in (po.PARITY_LSD_F64, po.PARITY_LSD_F64 | po.PARITY_TRIG_F32_ORB):
+                fr = po.Frame(po.default_config(w, h, orb_nfeatures=1200, lsd_nfeatures=0, parity_flags=flags))
+                n, kp, desc = fr.orb_extract(0, img)
+                kf = np.stack([kp["x"], kp["y"], kp["size"], kp["angle"], kp["response"]], axis=1).astype(np.float32)
+                same_set = n == len(rkf) and np.array_equal(kf[:, :3], rkf[:, :3]) and np.array_equal(kp["octave"], rki[:, 0])
+                exact = same_set and np.array_equal(kf, rkf) and np.array_equal(desc, rd)
+                orb_hits.append((flags, "exact" if exact else "same keypoints, angles / bits differ" if same_set else
+                                 "%d vs %d keypoints (quadtree order or FAST differs)" % (n, len(rkf))))
+            res[name + " reference ORBextractor per parity flags (8 cos double, 9 cosf)"] = orb_hits
+            rlf, rli, rld = g("ref_kl_f"), g("ref_kl_i"), g("ref_kl_desc")
+            kl_hits = []
+            for flags in (0, po.PARITY_TRIG_F32_LBD, po.PARITY_LSD_F64, po.PARITY_LSD_F64 | po.PARITY_TRIG_F32_LBD, 14):
+                fr = po.Frame(po.default_config(w, h, lsd_nfeatures=0, parity_flags=flags))
+                m, kl, ld = fr.line_extract(0, img)
+                KF = ("angle", "pt_x", "pt_y", "response", "size", "startPointX", "startPointY", "endPointX", "endPointY", "sPointInOctaveX",
+                      "sPointInOctaveY", "ePointInOctaveX", "ePointInOctaveY", "lineLength")
+                lf = np.stack([kl[k_] for k_ in KF], axis=1).astype(np.float32) if m else np.zeros((0, 14), np.float32)
+                exact = m == len(rlf) and np.array_equal(lf, rlf) and np.array_equal(kl["class_id"], rli[:, 0]) and np.array_equal(ld, rld)
+                close = m == len(rlf) and np.abs(lf[:, 5:9] - rlf[:, 5:9]).max(initial=0) <= 0.5
+                kl_hits.append((flags, "exact" if exact else "end points within 0.5 px, another field differs" if close else
+                                "%d vs %d key lines" % (m, len(rlf))))
+            res[name + " reference Lineextractor per parity flags"] = kl_hits
     return res
 
 

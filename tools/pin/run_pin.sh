@@ -9,4 +9,13 @@ if [ -n "$1" ]; then export PKG_CONFIG_PATH="$1/lib/pkgconfig:$PKG_CONFIG_PATH";
 PC=opencv; pkg-config --exists opencv4 2>/dev/null && PC=opencv4
 g++ -std=c++11 -O2 "$HERE/pin_against_opencv.cpp" -o "$OUT/pin_against_opencv" $(pkg-config --cflags --libs $PC)
 "$OUT/pin_against_opencv" "$IN" "$OUT"
+# stage 2 (optional): the reference's OWN extractors, compiled where they lie:   PLI_SLAM_ROOT=/path/to/PLI-SLAM tools/pin/run_pin.sh [prefix]
+if [ -n "$PLI_SLAM_ROOT" ]; then
+  R="$PLI_SLAM_ROOT"
+  g++ -std=c++11 -O3 -march=native "$HERE/pin_reference_extractors.cpp" "$R/src/ORBextractor.cc" "$R/src/LineExtractor.cc" "$R/src/Config.cpp" \
+      "$R/Thirdparty/line_descriptor/src/LSDDetector_custom.cpp" "$R/Thirdparty/line_descriptor/src/binary_descriptor_custom.cpp" \
+      -I"$R" -I"$R/include" -I"$R/Thirdparty/line_descriptor/include" -I/usr/include/eigen3 -o "$OUT/pin_reference_extractors" \
+      $(pkg-config --cflags --libs $PC)
+  "$OUT/pin_reference_extractors" "$IN" "$OUT"
+fi
 python3 "$HERE/pin_compare.py" "$OUT"
