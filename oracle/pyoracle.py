@@ -78,6 +78,13 @@ _lib = None
 _ref = None
 
 
+def use_shipped_build():
+    """Back to oracle/liboracle.so (after use_native_build)."""
+    global _lib
+    _lib = None
+    lib()
+
+
 def use_native_build():
     """cpu_baseline leg of bench.py: rebuild the oracle ON THIS MACHINE with the reference's own flags (-O3 -march=native,
     CMakeLists.txt:12-13) into oracle/_native/ and use that library from here on; the shipped liboracle.so is built -march=x86-64-v3

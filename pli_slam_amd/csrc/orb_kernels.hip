@@ -26,6 +26,22 @@ __constant__ signed char c_orb_pattern[1024] = {
 // as shorts summing to 2^15 — the all-in-one-pixel weight 32768 does not fit a short and initInterTab2D
 // repairs the block to {32767, 0, 0, 1} — result (sum + 2^14) >> 15.
 // ---------------------------------------------------------------------------
+// k_ingest_copy16: the plain copy (no rectification maps) when rows, strides and both image bases are 16-byte aligned and the width
+// is a multiple of 16: one 16-byte load and one 16-byte store per thread, the (row, column) pairs of an image spread over the grid
+// (the byte form below issues four byte loads per thread and leaves most of a 256-thread row block idle at 752 columns).
+__global__ __launch_bounds__(256) void k_ingest_copy16(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right, int64_t stride,
+                                                       int64_t frameStride, uint8_t* __restrict__ pyr, int64_t pyrBlock, int W16, int H,
+                                                       int pitch, int img0) {
+  const int img = blockIdx.y + img0;
+  const uint8_t* src = ((img & 1) ? right : left) + (int64_t)(img >> 1) * frameStride;
+  uint8_t* dst = pyr + (int64_t)img * pyrBlock;
+  const int n = W16 * H;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int y = i / W16, x = (i - y * W16) * 16;
+    *reinterpret_cast<uint4*>(dst + (int64_t)y * pitch + x) = *reinterpret_cast<const uint4*>(src + (int64_t)y * stride + x);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_ingest(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
                                                 int64_t stride, int64_t frameStride, uint8_t* __restrict__ pyr,
                                                 int64_t pyrBlock, int W, int H, int pitch,

@@ -670,6 +670,15 @@ int foldRoundStats(pli_ctx* c) {
 
 pli_status runIngest(pli_ctx* c, const uint8_t* dl, const uint8_t* dr, int64_t stride, int64_t frameStride, int img0, int nimg) {
   const DevParams& P = c->hp;
+  const bool aligned16 = !c->rectMap[0] && !c->rectMap[1] && (P.W % 16) == 0 && (stride % 16) == 0 && (frameStride % 16) == 0 &&
+                         (reinterpret_cast<uintptr_t>(dl) % 16) == 0 && (reinterpret_cast<uintptr_t>(dr) % 16) == 0 && (P.lv[0].pitch % 16) == 0 &&
+                         (P.pyrBlock % 16) == 0 && !getenv("PLI_INGEST_BYTES");
+  if (aligned16) {
+    const int n16 = (P.W / 16) * P.H;
+    LAUNCH(c, "k_ingest", k_ingest_copy16, dim3(std::max(1, std::min((n16 + 255) / 256, 64)), nimg), dim3(256), 0, dl, dr, stride, frameStride,
+           c->pyr, P.pyrBlock, P.W / 16, P.H, P.lv[0].pitch, img0);
+    return PLI_OK;
+  }
   dim3 g((P.W + 1023) / 1024, P.H, nimg);
   LAUNCH(c, "k_ingest", k_ingest, g, dim3(256), 0, dl, dr, stride, frameStride, c->pyr, P.pyrBlock, P.W, P.H, P.lv[0].pitch,
          (const float2*)c->rectMap[0], (const float2*)c->rectMap[1], img0);
