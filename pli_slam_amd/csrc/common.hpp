@@ -113,6 +113,7 @@ struct TxDirtyLists {
   const int* order;    // [image][npix] seed pixel of a rank
   int ts, ntx, nty, W;
   int64_t npix;
+  const int* perm = nullptr;   // round 1: workgroup -> (image, tile) in order of decreasing work (k_tx_order), or null: the grid order
 };
 
 // arguments of k_tx_tail (lsd_tile.hip): the rounds t >= t0 of the tile relaxation in one persistent launch

@@ -1222,6 +1222,23 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
   }
 }
 
+// k_tx_order: the (image, tile) pairs of a launch of k_tx_grow in order of decreasing seed count (64 buckets of 64 seeds; inside a
+// bucket any order), by one workgroup: a histogram, its scan from the top, and a scatter with one cursor per bucket.
+__global__ __launch_bounds__(1024) void k_tx_order(const int* __restrict__ tileCntAll, int ntile, int nimg, int img0, int* __restrict__ perm) {
+  __shared__ int hist[64], cursor[64];
+  const int tid = threadIdx.x, n = ntile * nimg;
+  if (tid < 64) hist[tid] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) atomicAdd(&hist[min(63, tileCntAll[(int64_t)img0 * ntile + i] >> 6)], 1);
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int b = 63; b >= 0; --b) { cursor[b] = run; run += hist[b]; }
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) perm[atomicAdd(&cursor[min(63, tileCntAll[(int64_t)img0 * ntile + i] >> 6)], 1)] = i;
+}
+
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tx_grow(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
                                                 const float4* __restrict__ recAll, int2* __restrict__ ownAll,
                                                 const int2* __restrict__ listAll, const int* __restrict__ tileCntAll,
@@ -1233,8 +1250,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                                                 int* __restrict__ rgLostAll, int* __restrict__ tileTouchAll, TxDirtyLists DL) {
   __shared__ int q[TX_GQ];
   __shared__ int gb[TX_BMAXBLK];
+  // (the tiles with the most seeds first, k_tx_order: the waves that take longest start first and the launch does not end on a few of them)
+  int img = blockIdx.y, tile = blockIdx.x;
+  if (DL.perm) {
+    const int v = DL.perm[blockIdx.y * gridDim.x + blockIdx.x];
+    img = v / (int)gridDim.x;
+    tile = v - img * (int)gridDim.x;
+  }
   tx_grow_tile<false>(Pp, ctl, recAll, ownAll, listAll, tileCntAll, ts, ntx, nty, rgSizeAll, rgBoxAll, rgDirtyAll, tileActAll, TW, TH,
-                   arenaAll, arenaCap, rectAll, rectCap, blockIdx.y + img0, blockIdx.x, t, rankAll, rgLostAll, tileTouchAll, DL, q, gb);
+                   arenaAll, arenaCap, rectAll, rectCap, img + img0, tile, t, rankAll, rgLostAll, tileTouchAll, DL, q, gb);
 }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tx_grow_spec(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
                                                 const float4* __restrict__ recAll, int2* __restrict__ ownAll,

@@ -108,6 +108,7 @@ struct pli_ctx {
   // stream, so copies and kernels of neighbouring calls overlap (pli_batch_submit_host, the multi-GPU gather).
   // the rounds t >= tail t0 of the tile relaxation run in one persistent launch (lsd_tile.hip: k_tx_tail)
   unsigned* tailBar = nullptr;      // [0] barrier arrivals, [32] abort word
+  int* txPerm = nullptr;            // round 1: (image, tile) pairs in order of decreasing seed count (k_tx_order)
   int tailBlocks = 0;               // resident grid: CUs x blocks per CU (from the kernel's occupancy)
   int rxMargin = 3;
   int rxPlanned = 0;                // rounds the last call launched without looking (0: it looked)
@@ -594,6 +595,7 @@ pli_status allocAll(pli_ctx* c) {
       A(c->txDirtyList, (size_t)c->txNtx * c->txNty * c->txTs * c->txTs * NR);
       A(c->txDirtyCnt, (size_t)c->txNtx * c->txNty * NR);
       A(c->tailBar, 64);
+      A(c->txPerm, (size_t)c->txNtx * c->txNty * NR);
     }
   }
   A(c->jrCtl, NI);
@@ -978,10 +980,19 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
           TRL(c, "k_tx_grow", k_tx_grow_spec, dim3(ntile, nimg), dim3(64), txPad, c->dP, c->jrCtl, c->rec, c->own, c->txList,
               c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty, c->tileAct, c->tilesW, c->tilesH, c->arena,
               c->arenaCap, c->rects, c->rectCap, img0, t, (const int*)c->rankOf, lostRule ? c->rgLost : (int*)nullptr, c->tileTouch, noDL);
-          else
+          else {
+          // dev switch PLI_TX_ORDER=1: the heaviest tiles first (k_tx_order).  Measured, not the default: the launch does end on fewer
+          // stragglers, but consecutive workgroups no longer grow neighbouring tiles of one image and k_tx_grow goes from 23.2 to
+          // 31.3 ms at 256 frames (4K: 33.1 -> 44.2 ms) — the grid order's locality is worth more than the balance
+          TxDirtyLists r1DL = noDL;
+          if (getenv("PLI_TX_ORDER") && atoi(getenv("PLI_TX_ORDER")) != 0) {
+            TRL(c, "k_tx_order", k_tx_order, dim3(1), dim3(1024), 0, (const int*)c->txTileCnt, ntile, nimg, img0, c->txPerm + (int64_t)img0 * ntile);
+            r1DL.perm = c->txPerm + (int64_t)img0 * ntile;
+          }
           TRL(c, "k_tx_grow", k_tx_grow, dim3(ntile, nimg), dim3(64), txPad, c->dP, c->jrCtl, c->rec, c->own, c->txList,
               c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty, c->tileAct, c->tilesW, c->tilesH, c->arena,
-              c->arenaCap, c->rects, c->rectCap, img0, t, (const int*)c->rankOf, lostRule ? c->rgLost : (int*)nullptr, c->tileTouch, noDL);
+              c->arenaCap, c->rects, c->rectCap, img0, t, (const int*)c->rankOf, lostRule ? c->rgLost : (int*)nullptr, c->tileTouch, r1DL);
+          }
           if (c->sideChain) {                  // (pli_batch_run: the ORB chain forks here, behind round 1)
             auto f = std::move(c->sideChain);
             c->sideChain = nullptr;
