@@ -114,6 +114,7 @@ struct TxDirtyLists {
   int ts, ntx, nty, W;
   int64_t npix;
   const int* perm = nullptr;   // round 1: workgroup -> (image, tile) in order of decreasing work (k_tx_order), or null: the grid order
+  int xcdAffine = 0;           // round 1: all tiles of an image on ONE XCD (workgroups go to the 8 XCDs round robin)
 };
 
 // arguments of k_tx_tail (lsd_tile.hip): the rounds t >= t0 of the tile relaxation in one persistent launch

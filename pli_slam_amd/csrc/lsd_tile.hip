@@ -1256,6 +1256,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const int v = DL.perm[blockIdx.y * gridDim.x + blockIdx.x];
     img = v / (int)gridDim.x;
     tile = v - img * (int)gridDim.x;
+  } else if (DL.xcdAffine) {
+    // workgroup L runs on XCD L % 8: the k-th workgroup of an XCD takes tile k % ntile of image 8 * (k / ntile) + xcd, so that the
+    // tiles of one image — neighbours share their border pixels' records and owner words — meet in one L2 (gridDim.y % 8 == 0)
+    const int L = blockIdx.y * gridDim.x + blockIdx.x, xcd = L & 7, k = L >> 3;
+    img = (k / (int)gridDim.x) * 8 + xcd;
+    tile = k % (int)gridDim.x;
   }
   tx_grow_tile<false>(Pp, ctl, recAll, ownAll, listAll, tileCntAll, ts, ntx, nty, rgSizeAll, rgBoxAll, rgDirtyAll, tileActAll, TW, TH,
                    arenaAll, arenaCap, rectAll, rectCap, img + img0, tile, t, rankAll, rgLostAll, tileTouchAll, DL, q, gb);

@@ -985,6 +985,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
           // stragglers, but consecutive workgroups no longer grow neighbouring tiles of one image and k_tx_grow goes from 23.2 to
           // 31.3 ms at 256 frames (4K: 33.1 -> 44.2 ms) — the grid order's locality is worth more than the balance
           TxDirtyLists r1DL = noDL;
+          if ((nimg % 8) == 0 && getenv("PLI_TX_XCD") && atoi(getenv("PLI_TX_XCD")) != 0) r1DL.xcdAffine = 1;
           if (getenv("PLI_TX_ORDER") && atoi(getenv("PLI_TX_ORDER")) != 0) {
             TRL(c, "k_tx_order", k_tx_order, dim3(1), dim3(1024), 0, (const int*)c->txTileCnt, ntile, nimg, img0, c->txPerm + (int64_t)img0 * ntile);
             r1DL.perm = c->txPerm + (int64_t)img0 * ntile;
