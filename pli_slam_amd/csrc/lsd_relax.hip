@@ -831,13 +831,15 @@ __global__ __launch_bounds__(64) void k_rx_rect(const DevParams* __restrict__ Pp
                                                 int arenaCap, const RxRect* __restrict__ rectAll, int rectCap,
                                                 float4* __restrict__ rgSegAll, int img0, const double* __restrict__ mgAll) {
   __shared__ double st[3][64];
+  __shared__ double wc[RX_RECT_CACHE][64];
+  __shared__ int ec[RX_RECT_CACHE][64];
   const DevParams& P = *Pp;
   const int img = blockIdx.y + img0;
   const RxCtl& c = ctl[img];
   if (c.state == 2 || c.overflow) return;
   const int64_t npix = (int64_t)P.LW * P.LH;
   rx_rect_wave(P, c, recAll + img * npix, mgAll ? mgAll + img * npix : nullptr /* CV_64F pipeline: the gradient norm as a double plane */,
-               arenaAll + (int64_t)img * arenaCap, rectAll + (int64_t)img * rectCap, rectCap, rgSegAll + img * npix, blockIdx.x, gridDim.x, st);
+               arenaAll + (int64_t)img * arenaCap, rectAll + (int64_t)img * rectCap, rectCap, rgSegAll + img * npix, blockIdx.x, gridDim.x, st, wc, ec);
 }
 
 // ---- segments in seed-rank order (= detection order of the sequential algorithm) ------------------------

@@ -1343,6 +1343,8 @@ __global__ __launch_bounds__(256) void k_tx_tail(TxTailArgs A) {
   __shared__ int qs[4][TX_GQ];
   __shared__ int gbs[4][TX_BMAXBLK];
   __shared__ double sts[4][3][64];
+  __shared__ double wcs[4][RX_RECT_CACHE][64];
+  __shared__ int ecs[4][RX_RECT_CACHE][64];
   __shared__ int s_live, s_n;
   __shared__ int s_list[256];
   const DevParams& P = *A.Pp;
@@ -1461,7 +1463,7 @@ __global__ __launch_bounds__(256) void k_tx_tail(TxTailArgs A) {
         const RxCtl& c = A.ctl[img];
         if (c.state == 2 || c.overflow) continue;
         rx_rect_wave(P, c, A.rec + img * npix, A.mg ? A.mg + img * npix : nullptr, A.arena + (int64_t)img * A.arenaCap,
-                     A.rects + (int64_t)img * A.rectCap, A.rectCap, A.rgSeg + img * npix, gw % per, per, sts[wv]);
+                     A.rects + (int64_t)img * A.rectCap, A.rectCap, A.rgSeg + img * npix, gw % per, per, sts[wv], wcs[wv], ecs[wv]);
       }
     }
     if (!tx_grid_barrier(A.bar, ++epoch * G)) return;
