@@ -165,3 +165,16 @@ def test_adapters_under_sanitizers_with_a_mock_library(tmp_path, sanitizer):
     assert set(a) == set(b) and all(a[k].tobytes() == b[k].tobytes() for k in a if k != "frame_ms")
     assert len(set(a["hashes"].ravel().tolist())) == 1 and int(a["groups_left"][0, 0]) == 0
     assert len(a["f0/mvKeys.f"]) >= 200 and len(a["f1/sbp0/match12"]) > 0 and int(a["f1/line_nmatches"][0, 0]) > 0
+
+
+def test_extractor_registry_pairing_release_and_plibind(tmp_path):
+    """tests/cpp/registry_test.cpp (under AddressSanitizer, against the mock library): construction-order pairing as Tracking.cc
+    builds the extractors, eye slots given back on destruction, a System torn down and rebuilt three times leaves no group, the
+    monocular main / initial extractors in two groups, pliBind for an order the implicit rule gets wrong, lsd_refine != 0 refused."""
+    exe = str(tmp_path / "registry_test")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address", "-pthread", "-I", ROOT, "-I", os.path.join(ROOT, "tests", "stubs"),
+                        os.path.join(ROOT, "tests", "cpp", "registry_test.cpp"), os.path.join(ROOT, "tests", "cpp", "mock_pli.cpp"), "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "registry_test: ok" in r.stdout, r.stdout + r.stderr[-3000:]
