@@ -863,7 +863,8 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
         }
         if (accepted) {
           pendOld = __hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (noteLost) pendRank = rankOfPix[qi];
+          // (the pixel's own rank, which an unclaimed owner word holds: in round 1 owner_0 is the trivial map, so the word just read has it)
+          if (noteLost) pendRank = (SPARSE || t != 1) ? rankOfPix[qi] : prevv;
           // (later rounds) the 8x8 cell of every claimed pixel is noted: the next round's k_rx_diff only looks where a claim or the
           // round's k_tx_prep wrote
           if (SPARSE && tileTouch) tileTouch[(myxy >> 19) * TW + ((myxy & 0xFFFF) >> 3)] = t;
