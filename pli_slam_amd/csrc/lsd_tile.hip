@@ -729,18 +729,20 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
   auto growRegion = [&](const int r, const int sp, const float sa, float sumdx, float sumdy, int cnt, int k, int bmin, int bmax, int angCnt,
                         unsigned long long& seedMask, const int seedPixV, const int pend0, const int pendRank0) -> bool {
       double reg_angle = (double)sa * TX_DEG2RAD;         // (the angle of the sums at pixel count angCnt: the seed angle at 1)
-      // pendOld = what stood in the owner word when this lane's claim of the last step arrived (r: it claimed nothing): a lower
-      // rank -> this region does not hold the pixel it took; a higher rank that is not the pixel's own (initial) rank -> that
-      // region just lost the pixel.  Contested claims are rare: one ballot decides for the wave.
+      // pendOld = what stood in the owner word when this lane's claim of the last step arrived, pendRank = the own rank of the pixel it
+      // claimed — what an unclaimed word holds — (r and r: the lane claimed nothing): a lower rank -> this region does not hold the
+      // pixel it took; a higher rank that is not the pixel's own -> that region just lost the pixel.  Contested claims are rare:
+      // pendOld != pendRank covers both cases, and one compare and one ballot decide for the wave.
       int pendOld = pend0, pendRank = pendRank0;
       auto stampLosers = [&]() {
         if (noteLost) {
-          const bool contested = pendOld < r || (pendOld != r && pendOld != pendRank);
-          if (__builtin_amdgcn_ballot_w64(contested) != 0ull) {
+          if (__builtin_amdgcn_ballot_w64(pendOld != pendRank) != 0ull) {
+            const bool contested = pendOld < r || (pendOld != r && pendOld != pendRank);
             if (contested) rgLost[pendOld < r ? r : pendOld] = t;
           }
         }
         pendOld = r;
+        pendRank = r;
       };
       bool dead = false;
       // One step = up to 8 queue entries x 8 neighbours in one round trip (record + owner pair per lane), the accept loop, the
@@ -1153,7 +1155,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
         const unsigned long long taken = __builtin_amdgcn_ballot_w64(lane < cntj && (pv < r || cv < r));
         if (taken & 1ull) continue;                        // the seed belongs to a lower rank: no region
         float sdx, sdy;
-        int cnt2 = cntj, k2 = kj, bmin = sxy, bmax = sxy, pend0 = r, pendRank0 = 0;
+        int cnt2 = cntj, k2 = kj, bmin = sxy, bmax = sxy, pend0 = r, pendRank0 = r;
         if (taken == 0ull && cntj > 1) {
           sdx = __int_as_float(parkAt(5, j));
           sdy = __int_as_float(parkAt(6, j));
@@ -1217,7 +1219,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
       const int sxy = tx_rl(sxyv, j);
       q[0] = sxy;                                         // every lane stores the same value
       const int rj = tx_rl(se.x, j);
-      if (!growRegion(rj, tx_rl(se.y, j), tx_rlf(srec.x, j), tx_rlf(scos, j), tx_rlf(ssin, j), 1, 0, sxy, sxy, 1, unusedMask, se.y, rj, 0))
+      if (!growRegion(rj, tx_rl(se.y, j), tx_rlf(srec.x, j), tx_rlf(scos, j), tx_rlf(ssin, j), 1, 0, sxy, sxy, 1, unusedMask, se.y, rj, rj))
         return;
     }
   }
