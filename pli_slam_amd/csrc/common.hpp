@@ -113,8 +113,20 @@ struct TxDirtyLists {
   const int* order;    // [image][npix] seed pixel of a rank
   int ts, ntx, nty, W;
   int64_t npix;
+  int rmask = -1;              // index of a region in the per-region planes = its id & rmask: -1 when ids are dense ranks (the ordered
+                               // list), (1 << pixbits) - 1 when they are KEYS (gradient bin << pixbits | seed pixel, k_tx_sort): the seed pixel
   const int* perm = nullptr;   // round 1: workgroup -> (image, tile) in order of decreasing work (k_tx_order), or null: the grid order
   int xcdAffine = 0;           // round 1: all tiles of an image on ONE XCD (workgroups go to the 8 XCDs round robin)
+};
+
+constexpr int TX_EMIT_CAP = 16384;   // key mode: candidate segments of an image that k_tx_emit_sorted can order (LDS)
+// k_tx_sort in key mode (lsd_tile.hip)
+struct TxKeys {
+  const double* mg;                 // gradient norm plane, or null: rank mode
+  const unsigned long long* maxMg;  // per image: bits of the largest norm
+  double rho;
+  int nBins, pixbits;
+  int* idPlane;                     // out: own id of every pixel (TX_INF: undefined)
 };
 
 // arguments of k_tx_tail (lsd_tile.hip): the rounds t >= t0 of the tile relaxation in one persistent launch

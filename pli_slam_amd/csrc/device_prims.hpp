@@ -121,11 +121,18 @@ __device__ __forceinline__ void sincos_of_float(float a, bool f32, float* sn, fl
 // runs once per region and round: its seed goes on the list of the seed's tile (at most ts * ts seeds per tile: no overflow)
 __device__ __forceinline__ void tx_dirty_append(const TxDirtyLists& DL, int img, int o) {
   if (!DL.list) return;
-  const int sp = DL.order[(int64_t)img * DL.npix + o];
+  const int sp = DL.rmask != -1 ? (o & DL.rmask) : DL.order[(int64_t)img * DL.npix + o];
   const int sy = sp / DL.W, sx = sp - sy * DL.W;
   const int64_t tile = (int64_t)img * DL.ntx * DL.nty + (sy / DL.ts) * DL.ntx + sx / DL.ts;
   const int slot = atomicAdd(&DL.cnt[tile], 1);
   DL.list[tile * DL.ts * DL.ts + slot] = make_int2(o, sp);
 }
+
+// CV_64F pipeline (lsd_f64.hip): the gradient norm is a double plane, its maximum is kept as the bits of a double
+__device__ __forceinline__ double lsd_bin_coef64(unsigned long long maxBits, int nBins) {
+  const double maxGrad = __longlong_as_double((long long)maxBits);
+  return maxBits ? (double)(nBins - 1) / maxGrad : 0.0;
+}
+__device__ __forceinline__ int lsd_bin64(double norm, double binCoef, int nBins) { return min((int)(norm * binCoef), nBins - 1); }
 
 }  // namespace pli

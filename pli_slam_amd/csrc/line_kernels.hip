@@ -85,12 +85,6 @@ __device__ __forceinline__ double lsd_bin_coef(int maxG2, int nBins) {
   double maxGrad = sqrt((double)maxG2 / 4.0);
   return maxG2 > 0 ? (double)(nBins - 1) / maxGrad : 0.0;
 }
-// CV_64F pipeline (lsd_f64.hip): the gradient norm is a double plane, its maximum is kept as the bits of a double
-__device__ __forceinline__ double lsd_bin_coef64(unsigned long long maxBits, int nBins) {
-  const double maxGrad = __longlong_as_double((long long)maxBits);
-  return maxBits ? (double)(nBins - 1) / maxGrad : 0.0;
-}
-__device__ __forceinline__ int lsd_bin64(double norm, double binCoef, int nBins) { return min((int)(norm * binCoef), nBins - 1); }
 
 // LDS traffic of ONE wave is executed in order: a write by some lanes followed by a read by others needs no s_barrier,
 // only the compiler must keep the order
@@ -105,9 +99,12 @@ __device__ __forceinline__ void lsd_wave_sync() {
 __global__ __launch_bounds__(256) void k_lsd_hist(const int* __restrict__ g2a, int npix, int g2Thresh, int nBins,
                                                   const int* __restrict__ maxG2, unsigned short* __restrict__ chunkHist,
                                                   int nChunks, int img0, const double* __restrict__ mgAll,
-                                                  const unsigned long long* __restrict__ maxMg, double rho) {
+                                                  const unsigned long long* __restrict__ maxMg, double rho,
+                                                  const RxCtl* __restrict__ onlyUnsettled) {
   __shared__ int h[1024];
   const int img = blockIdx.y + img0, chunk = blockIdx.x, tid = threadIdx.x;
+  // (the ordered list only for the images the relaxation has left to the sequential grower: key mode of the tile relaxation)
+  if (onlyUnsettled && onlyUnsettled[img].state == 2 && !onlyUnsettled[img].overflow) return;
   for (int i = tid; i < nBins; i += 256) h[i] = 0;
   __syncthreads();
   if (mgAll) {                                          // CV_64F pipeline
@@ -138,10 +135,12 @@ __global__ __launch_bounds__(256) void k_lsd_hist(const int* __restrict__ g2a, i
 
 // per image: chunkBase[chunk][bin] = start of that chunk's pixels of that bin in the ordered list
 __global__ __launch_bounds__(1024) void k_lsd_scan(const unsigned short* __restrict__ chunkHist, int nChunks, int nBins,
-                                                   int* __restrict__ chunkBase, int* __restrict__ nDefined, int img0) {
+                                                   int* __restrict__ chunkBase, int* __restrict__ nDefined, int img0,
+                                                   const RxCtl* __restrict__ onlyUnsettled) {
   __shared__ int tot[1024];
   __shared__ int start[1024];
   const int img = blockIdx.x + img0, b = threadIdx.x;
+  if (onlyUnsettled && onlyUnsettled[img].state == 2 && !onlyUnsettled[img].overflow) return;
   const unsigned short* hin = chunkHist + (int64_t)img * nChunks * nBins;
   int* cb = chunkBase + (int64_t)img * nChunks * nBins;
   int run = 0;
@@ -221,7 +220,8 @@ __global__ __launch_bounds__(64) void k_lsd_scatter(const int* __restrict__ g2a,
                                                     int nChunks, int* __restrict__ order, int img0, int nimg,
                                                     const double* __restrict__ mgAll, const unsigned long long* __restrict__ maxMg,
                                                     double rho, int* __restrict__ rankAll,
-                                                    const int* __restrict__ groupOff, int chunksPerGroup, int nGroups) {
+                                                    const int* __restrict__ groupOff, int chunksPerGroup, int nGroups,
+                                                    const RxCtl* __restrict__ onlyUnsettled) {
   __shared__ int base[1024];
   // XCD-aware order: workgroup L runs on XCD L % 8, so all chunks of an image are dealt to ONE XCD (consecutive slots of
   // that XCD, i.e. close in time): the 4-byte stores of different chunks into the same lines of the ordered list then
@@ -230,6 +230,7 @@ __global__ __launch_bounds__(64) void k_lsd_scatter(const int* __restrict__ g2a,
   const int li = (L & 7) + 8 * (slot / nChunks), chunk = slot % nChunks, lane = threadIdx.x;
   if (li >= nimg) return;
   const int img = li + img0;
+  if (onlyUnsettled && onlyUnsettled[img].state == 2 && !onlyUnsettled[img].overflow) return;
   const int* cb = chunkBase + ((int64_t)img * nChunks + chunk) * nBins;
   if (groupOff) {                                        // (large images: k_lsd_scan_part / k_lsd_scan_groups)
     const int* go = groupOff + ((int64_t)img * nGroups + chunk / chunksPerGroup) * nBins;

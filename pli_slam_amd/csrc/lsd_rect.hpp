@@ -36,7 +36,7 @@ __device__ __forceinline__ void rx_wave_sync() {
 template <int LANES>
 __device__ __forceinline__ void rx_rect_region(bool on, const RxRect& it, const DevParams& P, const float4* __restrict__ rec,
                                                const double* __restrict__ mg, const int* __restrict__ arena,
-                                               float4* __restrict__ rgSeg, double (*st)[64], double (*wc)[64], int (*ec)[64]) {
+                                               float4* __restrict__ rgSeg, double (*st)[64], double (*wc)[64], int (*ec)[64], int rmask) {
   // wc / ec: the weights and the packed coordinates of the first RX_RECT_CACHE chunks of the list, kept in LDS by the first pass: the
   // second pass and the end-point pass read them there instead of walking list entry -> weight through global memory again (two
   // dependent round trips per chunk and pass; most regions fit the cache: 46 pixels on average)
@@ -139,7 +139,7 @@ __device__ __forceinline__ void rx_rect_region(bool on, const RxRect& it, const 
   e += 0.5;
   const double scale = P.lsdScale;
   if (scale != 1) e /= scale;
-  if (on && gl < 4) reinterpret_cast<float*>(&rgSeg[it.rank])[gl] = (float)e;
+  if (on && gl < 4) reinterpret_cast<float*>(&rgSeg[it.rank & rmask])[gl] = (float)e;
 }
 
 
@@ -147,7 +147,7 @@ __device__ __forceinline__ void rx_rect_region(bool on, const RxRect& it, const 
 __device__ __forceinline__ void rx_rect_wave(const DevParams& P, const RxCtl& c, const float4* __restrict__ rec, const double* __restrict__ mg,
                                              const int* __restrict__ arena, const RxRect* __restrict__ rects, int rectCap,
                                              float4* __restrict__ rgSeg, int first, int stride, double (*st)[64], double (*wc)[64],
-                                             int (*ec)[64]) {
+                                             int (*ec)[64], int rmask = -1) {
   const int nrect = min((int)(c.rectArena >> RX_ARENA_BITS), rectCap);
   const int lane = threadIdx.x & 63, g = lane >> 4;
   for (int w0 = first * 4; w0 < nrect; w0 += stride * 4) {
@@ -155,7 +155,7 @@ __device__ __forceinline__ void rx_rect_wave(const DevParams& P, const RxCtl& c,
     const bool have = w0 + g < nrect;
     if (have) it = rects[w0 + g];
     const bool small = have && it.cnt <= RX_RECT_GROUP_MAX;
-    if (__builtin_amdgcn_ballot_w64(small)) rx_rect_region<16>(small, it, P, rec, mg, arena, rgSeg, st, wc, ec);
+    if (__builtin_amdgcn_ballot_w64(small)) rx_rect_region<16>(small, it, P, rec, mg, arena, rgSeg, st, wc, ec, rmask);
     unsigned long long big = __builtin_amdgcn_ballot_w64(have && !small) & 0x0001000100010001ull;   // one bit per group
     while (big) {
       const int gl0 = __ffsll((long long)big) - 1;
@@ -163,7 +163,7 @@ __device__ __forceinline__ void rx_rect_wave(const DevParams& P, const RxCtl& c,
       RxRect bt;
       bt.rank = __shfl(it.rank, gl0, 64); bt.off = __shfl(it.off, gl0, 64); bt.cnt = __shfl(it.cnt, gl0, 64);
       bt.sumdx = __shfl(it.sumdx, gl0, 64); bt.sumdy = __shfl(it.sumdy, gl0, 64);
-      rx_rect_region<64>(true, bt, P, rec, mg, arena, rgSeg, st, wc, ec);
+      rx_rect_region<64>(true, bt, P, rec, mg, arena, rgSeg, st, wc, ec, rmask);
     }
   }
 }

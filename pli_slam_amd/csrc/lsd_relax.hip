@@ -829,7 +829,7 @@ __global__ __launch_bounds__(64) void k_rx_grow_wave(const DevParams* __restrict
 __global__ __launch_bounds__(64) void k_rx_rect(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
                                                 const float4* __restrict__ recAll, const int* __restrict__ arenaAll,
                                                 int arenaCap, const RxRect* __restrict__ rectAll, int rectCap,
-                                                float4* __restrict__ rgSegAll, int img0, const double* __restrict__ mgAll) {
+                                                float4* __restrict__ rgSegAll, int img0, const double* __restrict__ mgAll, int rmask) {
   __shared__ double st[3][64];
   __shared__ double wc[RX_RECT_CACHE][64];
   __shared__ int ec[RX_RECT_CACHE][64];
@@ -839,7 +839,7 @@ __global__ __launch_bounds__(64) void k_rx_rect(const DevParams* __restrict__ Pp
   if (c.state == 2 || c.overflow) return;
   const int64_t npix = (int64_t)P.LW * P.LH;
   rx_rect_wave(P, c, recAll + img * npix, mgAll ? mgAll + img * npix : nullptr /* CV_64F pipeline: the gradient norm as a double plane */,
-               arenaAll + (int64_t)img * arenaCap, rectAll + (int64_t)img * rectCap, rectCap, rgSegAll + img * npix, blockIdx.x, gridDim.x, st, wc, ec);
+               arenaAll + (int64_t)img * arenaCap, rectAll + (int64_t)img * rectCap, rectCap, rgSegAll + img * npix, blockIdx.x, gridDim.x, st, wc, ec, rmask);
 }
 
 // ---- segments in seed-rank order (= detection order of the sequential algorithm) ------------------------

@@ -71,11 +71,18 @@ __device__ __forceinline__ float tx_rlf(float v, int l) { return __int_as_float(
 // stages (ts = 64) whose partner sits in another wave go through LDS — the earlier form did every stage there (6.6 ms at 256
 // frames).
 // ---------------------------------------------------------------------------
+// KEY MODE (keys.mg != null; images of up to 2^20 scaled pixels, CV_64F detector): the id of a region is not its rank in the ordered
+// list but the KEY  (nBins - 1 - gradient bin) << pixbits | seed pixel  — the same total order (bins from the strongest gradient
+// down, raster order inside a bin), computed here from the gradient norm, so the histogram / scan / scatter passes that build the
+// ordered list (4.1 ms of the 56 ms step at 256 frames) do not run at all; per-region planes are indexed by id & rmask = the
+// seed pixel.  This kernel then also writes the plane of the pixels' own ids (what k_lsd_scatter writes in rank mode).
+// (struct TxKeys: common.hpp)
+
 template <int KPT, int NT>
 __device__ __forceinline__ void tx_sort_tile(const int* __restrict__ rankAll, const int* __restrict__ orderAll,
                                              int2* __restrict__ ownAll, int2* __restrict__ listAll,
                                              int* __restrict__ tileCntAll, int W, int H, int ts, int ntx, int nty, int img0,
-                                             unsigned* xch) {
+                                             unsigned* xch, const TxKeys& keys) {
   __shared__ int s_cnt;
   const int img = blockIdx.y + img0, tile = blockIdx.x, tid = threadIdx.x;
   constexpr int n2 = KPT * NT;
@@ -95,7 +102,16 @@ __device__ __forceinline__ void tx_sort_tile(const int* __restrict__ rankAll, co
     const int x = tx0 + i % ts, y = ty0 + i / ts;
     unsigned k = 0xFFFFFFFFu;
     if (x < W && y < H) {
-      const int r = rank[y * W + x];
+      int r;
+      if (keys.mg) {
+        const double v = keys.mg[img * npix + y * W + x];
+        r = TX_INF;
+        if (!(v <= keys.rho))
+          r = ((keys.nBins - 1 - lsd_bin64(v, lsd_bin_coef64(keys.maxMg[img], keys.nBins), keys.nBins)) << keys.pixbits) | (y * W + x);
+        keys.idPlane[img * npix + y * W + x] = r;
+      } else {
+        r = rank[y * W + x];
+      }
       if (r != TX_INF) {
         k = (unsigned)r;
         own[y * W + x] = make_int2(r, r);
@@ -160,25 +176,25 @@ __device__ __forceinline__ void tx_sort_tile(const int* __restrict__ rankAll, co
   for (int m = 0; m < KPT; ++m) {
     const int i = m * NT + tid;
     const unsigned k = xch[pad(i)];
-    if (k != 0xFFFFFFFFu) list[i] = make_int2((int)k, order[k]);
+    if (k != 0xFFFFFFFFu) list[i] = make_int2((int)k, keys.mg ? (int)(k & ((1u << keys.pixbits) - 1u)) : order[k]);
   }
   if (tid == 0) tileCntAll[(int64_t)img * ntx * nty + tile] = s_cnt;
 }
 
 __global__ __launch_bounds__(256) void k_tx_sort(const int* __restrict__ rankAll, const int* __restrict__ orderAll,
                                                  int2* __restrict__ ownAll, int2* __restrict__ listAll,
-                                                 int* __restrict__ tileCntAll, int W, int H, int ts, int ntx, int nty, int img0) {
+                                                 int* __restrict__ tileCntAll, int W, int H, int ts, int ntx, int nty, int img0, TxKeys keys) {
   __shared__ unsigned xch[16 * 256 + 256];
-  if (ts == 64) tx_sort_tile<16, 256>(rankAll, orderAll, ownAll, listAll, tileCntAll, W, H, ts, ntx, nty, img0, xch);
-  else if (ts == 32) tx_sort_tile<4, 256>(rankAll, orderAll, ownAll, listAll, tileCntAll, W, H, ts, ntx, nty, img0, xch);
-  else tx_sort_tile<1, 256>(rankAll, orderAll, ownAll, listAll, tileCntAll, W, H, ts, ntx, nty, img0, xch);
+  if (ts == 64) tx_sort_tile<16, 256>(rankAll, orderAll, ownAll, listAll, tileCntAll, W, H, ts, ntx, nty, img0, xch, keys);
+  else if (ts == 32) tx_sort_tile<4, 256>(rankAll, orderAll, ownAll, listAll, tileCntAll, W, H, ts, ntx, nty, img0, xch, keys);
+  else tx_sort_tile<1, 256>(rankAll, orderAll, ownAll, listAll, tileCntAll, W, H, ts, ntx, nty, img0, xch, keys);
 }
 // tiles of 128 x 128 (large batches): 1024 threads x 16 keys, 10 of the 105 stages through LDS
 __global__ __launch_bounds__(1024) void k_tx_sort128(const int* __restrict__ rankAll, const int* __restrict__ orderAll,
                                                      int2* __restrict__ ownAll, int2* __restrict__ listAll,
-                                                     int* __restrict__ tileCntAll, int W, int H, int ts, int ntx, int nty, int img0) {
+                                                     int* __restrict__ tileCntAll, int W, int H, int ts, int ntx, int nty, int img0, TxKeys keys) {
   __shared__ unsigned xch[16 * 1024 + 1024];
-  tx_sort_tile<16, 1024>(rankAll, orderAll, ownAll, listAll, tileCntAll, W, H, ts, ntx, nty, img0, xch);
+  tx_sort_tile<16, 1024>(rankAll, orderAll, ownAll, listAll, tileCntAll, W, H, ts, ntx, nty, img0, xch, keys);
 }
 
 // ---------------------------------------------------------------------------
@@ -195,11 +211,12 @@ __global__ __launch_bounds__(1024) void k_tx_sort128(const int* __restrict__ ran
 __device__ __forceinline__ void tx_mark_dirty(int o, int t, int* __restrict__ rgDirty, const int2* __restrict__ rgBox,
                                               int* __restrict__ tileAct, int TW, int TH, const TxDirtyLists& DL, int img,
                                               bool withBox = true) {
-  if (rgDirty[o] == t) return;
-  if (atomicExch(&rgDirty[o], t) == t) return;
+  const int oi = o & DL.rmask;                          // (the region's slot in the per-region planes)
+  if (rgDirty[oi] == t) return;
+  if (atomicExch(&rgDirty[oi], t) == t) return;
   tx_dirty_append(DL, img, o);
   if (!withBox) return;
-  const int2 b = rgBox[o];
+  const int2 b = rgBox[oi];
   const int tx0 = min(max((b.x & 0xFFFF) >> 3, 0), TW - 1), ty0 = min(max((b.x >> 16) >> 3, 0), TH - 1);
   const int tx1 = min(max((b.y & 0xFFFF) >> 3, 0), TW - 1), ty1 = min(max((b.y >> 16) >> 3, 0), TH - 1);
   for (int ty = ty0; ty <= ty1; ++ty)
@@ -225,7 +242,7 @@ __global__ __launch_bounds__(256) void k_tx_diff2(RxCtl* __restrict__ ctl, const
     const int2 ow = ownAll[base + y * W + x];
     const int o = (t & 1) ? ow.x : ow.y;               // owner_{t-1}
     if (o != INT_MAX) {
-      const int sp = orderAll[base + o];
+      const int sp = DL.rmask != -1 ? (o & DL.rmask) : orderAll[base + o];
       const int sx = sp % W, sy = sp / W;
       if (!rgLostAll && (sx / ts != x / ts || sy / ts != y / ts)) atomicMin(&tmin[(tid & 31) >> 3], o);
       if (sp != y * W + x) {
@@ -240,10 +257,10 @@ __global__ __launch_bounds__(256) void k_tx_diff2(RxCtl* __restrict__ ctl, const
         // by its rightful lower owner as well, and a pixel it was wrongly refused would have to be held by a lower region that
         // does not hold it in the end — which is then a change of the later rounds' kind.  tools/sim/sim_tile_relax.cpp replays
         // the rule: SIM_CARRY=1 SIM_LOST=1.)
-        if (rgLostAll[base + o] != 0)
+        if (rgLostAll[base + (o & DL.rmask)] != 0)
           tx_mark_dirty(o, t, rgDirtyAll + base, rgBoxAll + base, tileActAll + (int64_t)img * TW * TH, TW, TH, DL, img);
       } else {                                          // conservative rule: does its box (+1) leave the tile?
-        const int2 b = rgBoxAll[base + o];
+        const int2 b = rgBoxAll[base + (o & DL.rmask)];
         const int tx0 = (x / ts) * ts, ty0 = (y / ts) * ts;
         if ((b.x & 0xFFFF) - 1 < tx0 || (b.x >> 16) - 1 < ty0 || (b.y & 0xFFFF) + 1 >= tx0 + ts || (b.y >> 16) + 1 >= ty0 + ts)
           tx_mark_dirty(o, t, rgDirtyAll + base, rgBoxAll + base, tileActAll + (int64_t)img * TW * TH, TW, TH, DL, img);
@@ -299,8 +316,8 @@ __global__ __launch_bounds__(256) void k_tx_round2(RxCtl* __restrict__ ctl, int2
   for (int i = 0; i < 4; ++i) {
     sp[i] = -1; lost[i] = 0;
     if (o[i] != INT_MAX) {
-      sp[i] = orderAll[base + o[i]];
-      lost[i] = rgLostAll[base + o[i]];
+      sp[i] = DL.rmask != -1 ? (o[i] & DL.rmask) : orderAll[base + o[i]];
+      lost[i] = rgLostAll[base + (o[i] & DL.rmask)];
     }
   }
 #pragma unroll
@@ -394,7 +411,7 @@ __global__ __launch_bounds__(256) void k_tx_mark(RxCtl* __restrict__ ctl, const 
       const int2 op2 = ownAll[base + py * W + px];
       const int op = ci ? op2.x : op2.y;               // owner_{t-1} of the neighbour
       if (op == INT_MAX) continue;
-      if ((prev2 < op && prevv > op) || (prev2 == op && prevv < op) || rgLostAll[base + op] == t - 1)
+      if ((prev2 < op && prevv > op) || (prev2 == op && prevv < op) || rgLostAll[base + (op & DL.rmask)] == t - 1)
         tx_mark_dirty(op, t, rgDirty, rgBox, tileAct, TW, TH, DL, img);
     }
   }
@@ -473,7 +490,7 @@ __device__ __forceinline__ void tx_diffmark_block(RxCtl* ctl, const int2* ownAll
       const int2 op2 = ownAll[base + py * W + px];
       const int op = ci ? op2.x : op2.y;               // owner_{t-1} of the neighbour
       if (op == INT_MAX) continue;
-      if ((prev2 < op && prevv > op) || (prev2 == op && prevv < op) || rgLostAll[base + op] == t - 1)
+      if ((prev2 < op && prevv > op) || (prev2 == op && prevv < op) || rgLostAll[base + (op & DL.rmask)] == t - 1)
         tx_mark_dirty(op, t, rgDirty, rgBox, tileAct, TW, TH, DL, img);
     }
   }
@@ -497,7 +514,7 @@ __global__ __launch_bounds__(256) void k_tx_diffmark(RxCtl* __restrict__ ctl, co
 // that is per wave)
 __device__ __forceinline__ void tx_prep_block(RxCtl* ctl, int2* ownAll, const int* rankAll, const int* rgDirtyAll,
                                               const int* tileActAll, int W, int H, int TW, int TH, int t, int bx, int by, int img,
-                                              int full, int* tileTouchAll) {
+                                              int full, int* tileTouchAll, int rmask) {
   __shared__ int s_act;
   __shared__ int s_cell[4][4];
   RxCtl& c = ctl[img];
@@ -540,7 +557,7 @@ __device__ __forceinline__ void tx_prep_block(RxCtl* ctl, int2* ownAll, const in
     }
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) dirtyAt[i] = r[i] != TX_INF ? rgDirtyAll[base + (ci ? o[i].x : o[i].y)] : 0;
+  for (int i = 0; i < 4; ++i) dirtyAt[i] = r[i] != TX_INF ? rgDirtyAll[base + ((ci ? o[i].x : o[i].y) & rmask)] : 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     if (r[i] == TX_INF) continue;
@@ -557,8 +574,8 @@ __device__ __forceinline__ void tx_prep_block(RxCtl* ctl, int2* ownAll, const in
 __global__ __launch_bounds__(256) void k_tx_prep(RxCtl* __restrict__ ctl, int2* __restrict__ ownAll,
                                                  const int* __restrict__ rankAll, const int* __restrict__ rgDirtyAll,
                                                  const int* __restrict__ tileActAll, int W, int H, int TW, int TH, int t, int img0,
-                                                 int full, int* __restrict__ tileTouchAll) {
-  tx_prep_block(ctl, ownAll, rankAll, rgDirtyAll, tileActAll, W, H, TW, TH, t, blockIdx.x, blockIdx.y, blockIdx.z + img0, full, tileTouchAll);
+                                                 int full, int* __restrict__ tileTouchAll, int rmask) {
+  tx_prep_block(ctl, ownAll, rankAll, rgDirtyAll, tileActAll, W, H, TW, TH, t, blockIdx.x, blockIdx.y, blockIdx.z + img0, full, tileTouchAll, rmask);
 }
 
 // ---------------------------------------------------------------------------
@@ -738,7 +755,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
         if (noteLost) {
           if (__builtin_amdgcn_ballot_w64(pendOld != pendRank) != 0ull) {
             const bool contested = pendOld < r || (pendOld != r && pendOld != pendRank);
-            if (contested) rgLost[pendOld < r ? r : pendOld] = t;
+            if (contested) rgLost[(pendOld < r ? r : pendOld) & DL.rmask] = t;
           }
         }
         pendOld = r;
@@ -882,8 +899,8 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
       // ---- the region is complete ----
       const bool first = lane == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1;   // the first ACTIVE lane
       if (first) {
-        rgSize[r] = cnt;
-        rgBox[r] = make_int2(bmin, bmax);
+        rgSize[r & DL.rmask] = cnt;
+        rgBox[r & DL.rmask] = make_int2(bmin, bmax);
       }
       if (cnt >= minReg) {                              // the pixel list goes to k_rx_rect (region2rect)
         int off = 0, slot = 0;
@@ -1118,15 +1135,15 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
                   bmax = tx_pk_max_u16(bmax, xy);
                 }
               }
-              rgSize[r] = cnt;
-              rgBox[r] = make_int2(bmin, bmax);
+              rgSize[r & DL.rmask] = cnt;
+              rgBox[r & DL.rmask] = make_int2(bmin, bmax);
               if (noteLost) {
 #pragma unroll
                 for (int i = 1; i < CAP; ++i) {
                   if (i >= cnt) continue;
                   const int pv = ci ? ow[i].x : ow[i].y;       // round 1: owner_0 is the trivial map, i.e. the pixel's own rank
-                  if (olds[i] < r) rgLost[r] = t;                              // a lower rank slipped in between the look and the claim
-                  else if (olds[i] != r && olds[i] != pv) rgLost[olds[i]] = t; // a higher rank held it: it has just lost the pixel
+                  if (olds[i] < r) rgLost[r & DL.rmask] = t;                              // a lower rank slipped in between the look and the claim
+                  else if (olds[i] != r && olds[i] != pv) rgLost[olds[i] & DL.rmask] = t; // a higher rank held it: it has just lost the pixel
                 }
               }
             }
@@ -1193,7 +1210,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
     if (useDirty) se = dse;                               // (n <= 64: one row)
     else if (valid) se = list[base + lane];
     bool d = valid;
-    if (SPARSE && !useDirty) d = valid && rgDirty[se.x] == t;
+    if (SPARSE && !useDirty) d = valid && rgDirty[se.x & DL.rmask] == t;
     float4 srec = make_float4(TX_NOTDEF, 0.f, 0.f, 0.f);
     int2 so = make_int2(0, 0);
     if (d) {
@@ -1298,6 +1315,93 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   __shared__ int gb[TX_BMAXBLK];
   tx_grow_tile<true>(Pp, ctl, recAll, ownAll, listAll, tileCntAll, ts, ntx, nty, rgSizeAll, rgBoxAll, rgDirtyAll, tileActAll, TW, TH,
                    arenaAll, arenaCap, rectAll, rectCap, blockIdx.y + img0, blockIdx.x, t, rankAll, rgLostAll, tileTouchAll, DL, q, gb);
+}
+
+// ---------------------------------------------------------------------------
+// k_tx_collect / k_tx_emit_sorted (key mode; take the place of k_rx_count / k_rx_emit, which walk the ordered list): the segments of
+// the regions that are alive at the fixed point and large enough, in the order of their ids.  k_tx_collect lists the ids (any
+// order; the workgroup gathers them in LDS and takes its places in the image's list with ONE atomic — one per wave cost 7.8 ms at 256
+// frames, all on the same word), k_tx_emit_sorted sorts the list of an image — ids are distinct — with one workgroup (bitonic in LDS,
+// up to TX_EMIT_CAP = 16384 ids) and writes the first maxSeg segments.  An image with more candidates than that is left to the sequential grower (overflow 6).
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_tx_collect(RxCtl* __restrict__ ctl, const int* __restrict__ idPlaneAll, const int2* __restrict__ ownAll,
+                                                    const int* __restrict__ rgSizeAll, int64_t npix, int minReg, int* __restrict__ candAll,
+                                                    int* __restrict__ candCnt, int img0, int emitCap) {
+  constexpr int CAP = 1024;           // ids a workgroup gathers in LDS before its one atomic on the image's counter
+  __shared__ int s_n, s_base;
+  __shared__ int s_buf[CAP];
+  const int img = blockIdx.y + img0;
+  RxCtl& c = ctl[img];
+  if (c.state != 2 || c.overflow) return;
+  const int64_t base = (int64_t)img * npix;
+  const int tid = threadIdx.x, lane = tid & 63;
+  int* cand = candAll + (int64_t)img * TX_EMIT_CAP;
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  for (int64_t p0 = (int64_t)blockIdx.x * 256; p0 < npix; p0 += (int64_t)gridDim.x * 256) {
+    const int64_t p = p0 + tid;
+    bool e = false;
+    int id = TX_INF;
+    // (the size first: only the few pixels that are — or, stale, once were — seeds of a large enough region go on to the two other loads)
+    if (p < npix && rgSizeAll[base + p] >= minReg) {
+      id = idPlaneAll[base + p];
+      e = id != TX_INF && ownAll[base + p].x == id;
+    }
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(e);
+    if (bal) {
+      const int first = __ffsll((long long)bal) - 1;
+      int at = 0;
+      if (lane == first) at = atomicAdd(&s_n, __popcll(bal));
+      at = __shfl(at, first, 64) + __popcll(bal & ((1ull << lane) - 1ull));
+      if (e) {
+        if (at < CAP) s_buf[at] = id;
+        else {                                      // (more than CAP in one workgroup's share: straight to the image's list)
+          const int g = atomicAdd(&candCnt[img], 1);
+          if (g < emitCap) cand[g] = id;
+          else c.overflow = 6;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int n = min(s_n, CAP);
+  if (tid == 0 && n) s_base = atomicAdd(&candCnt[img], n);
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) {
+    if (s_base + i < emitCap) cand[s_base + i] = s_buf[i];
+    else c.overflow = 6;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_tx_emit_sorted(const RxCtl* __restrict__ ctl, const int* __restrict__ candAll, const int* __restrict__ candCnt,
+                                                         const float4* __restrict__ rgSegAll, int64_t npix, int rmask, float* __restrict__ segAll,
+                                                         int* __restrict__ nSeg, int maxSeg, int img0, int emitCap) {
+  extern __shared__ unsigned ks[];
+  const int img = blockIdx.x + img0;
+  if (ctl[img].state != 2 || ctl[img].overflow) return;
+  const int n = min(candCnt[img], emitCap), tid = threadIdx.x;
+  int n2 = 1;
+  while (n2 < n) n2 <<= 1;
+  for (int i = tid; i < n2; i += 1024) ks[i] = i < n ? (unsigned)candAll[(int64_t)img * TX_EMIT_CAP + i] : 0xFFFFFFFFu;
+  __syncthreads();
+  for (int k = 2; k <= n2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < n2; i += 1024) {
+        const int l = i ^ j;
+        if (l > i) {
+          const unsigned a = ks[i], b = ks[l];
+          if (((i & k) == 0) == (a > b)) { ks[i] = b; ks[l] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  float* seg = segAll + (int64_t)img * maxSeg * 4;
+  for (int i = tid; i < min(n, maxSeg); i += 1024) {
+    const float4 v = rgSegAll[img * npix + (int)(ks[i] & (unsigned)rmask)];
+    seg[4 * i + 0] = v.x; seg[4 * i + 1] = v.y; seg[4 * i + 2] = v.z; seg[4 * i + 3] = v.w;
+  }
+  if (tid == 0) nSeg[img] = min(n, maxSeg);
 }
 
 // ---------------------------------------------------------------------------
@@ -1426,7 +1530,7 @@ __global__ __launch_bounds__(256) void k_tx_tail(TxTailArgs A) {
       for (int i = 0; i < n; ++i) {
         const int64_t va = base + (int64_t)s_list[i] * G;
         const int il = (int)(va / (nbx * nbyB)), rem = (int)(va - (int64_t)il * (nbx * nbyB));
-        tx_prep_block(A.ctl, A.own, A.rank, A.rgDirty, A.tileAct, W, H, A.TW, A.TH, t, rem % nbx, rem / nbx, A.img0 + il, 0, A.tileTouch);
+        tx_prep_block(A.ctl, A.own, A.rank, A.rgDirty, A.tileAct, W, H, A.TW, A.TH, t, rem % nbx, rem / nbx, A.img0 + il, 0, A.tileTouch, A.DL.rmask);
         __syncthreads();
       }
     }
@@ -1466,7 +1570,7 @@ __global__ __launch_bounds__(256) void k_tx_tail(TxTailArgs A) {
         const RxCtl& c = A.ctl[img];
         if (c.state == 2 || c.overflow) continue;
         rx_rect_wave(P, c, A.rec + img * npix, A.mg ? A.mg + img * npix : nullptr, A.arena + (int64_t)img * A.arenaCap,
-                     A.rects + (int64_t)img * A.rectCap, A.rectCap, A.rgSeg + img * npix, gw % per, per, sts[wv], wcs[wv], ecs[wv]);
+                     A.rects + (int64_t)img * A.rectCap, A.rectCap, A.rgSeg + img * npix, gw % per, per, sts[wv], wcs[wv], ecs[wv], A.DL.rmask);
       }
     }
     if (!tx_grid_barrier(A.bar, ++epoch * G)) return;

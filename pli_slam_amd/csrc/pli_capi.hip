@@ -97,6 +97,7 @@ struct pli_ctx {
   int* lastSize = nullptr; int* arena = nullptr; int arenaCap = 0;
   RxCtl* jrCtl = nullptr;
   int2* txList = nullptr; int* txTileCnt = nullptr; int txTs = 64, txNtx = 0, txNty = 0;   // tile-sequential relaxation (lsd_tile.hip)
+  bool txKeys = false; int txPixBits = 0; int* txCand = nullptr; int* txCandCnt = nullptr;  // ... its key mode (region id = gradient bin | seed pixel: no ordered list)
   int2* txDirtyList = nullptr; int* txDirtyCnt = nullptr;                                  // per tile: the seeds stamped dirty in a round
   std::vector<RxCtl> jrHost;
   int lsdMode = 0;     // 0 auto, 1 relaxation, 2 sequential, 3 tile-sequential relaxation (cfg.lsd_mode, or PLI_LSD_MODE)
@@ -596,6 +597,17 @@ pli_status allocAll(pli_ctx* c) {
       A(c->txDirtyCnt, (size_t)c->txNtx * c->txNty * NR);
       A(c->tailBar, 64);
       A(c->txPerm, (size_t)c->txNtx * c->txNty * NR);
+      // key mode (lsd_tile.hip, k_tx_sort): ids of 10 + pixbits bits stay below TX_INF up to 2^20 scaled pixels.  PLI_TX_KEYS=0: ranks.
+      // (debug contexts keep the ordered list for PLI_DBG_LSD_ORDER: checked at run time)
+      c->txKeys = c->lsdF64 && npix <= ((size_t)1 << 20) && P.nBins <= 1024 && (npix + LSD_CHUNK - 1) / LSD_CHUNK <= 256 &&
+                  !(getenv("PLI_TX_KEYS") && atoi(getenv("PLI_TX_KEYS")) == 0);
+      if (c->txKeys) {
+        c->txPixBits = 1;
+        while (((size_t)1 << c->txPixBits) < npix) ++c->txPixBits;
+        A(c->txCand, (size_t)TX_EMIT_CAP * NR);
+        A(c->txCandCnt, NR);
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tx_emit_sorted), hipFuncAttributeMaxDynamicSharedMemorySize, TX_EMIT_CAP * 4));
+      }
     }
   }
   A(c->jrCtl, NI);
@@ -795,23 +807,34 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     LAUNCH(c, "k_lsd_grad", k_lsd_grad, g, dim3(256), 0, scaled, sStride, P.LW, P.LH, sPitch, P.g2Thresh, c->rec, c->g2, ownPlane,
            c->maxG2, c->debug ? c->angDbg : (float*)nullptr, img0, trigF32);
   }
+  // key mode of the tile relaxation (lsd_tile.hip): no ordered list — it is only built, at the end, for images left to the sequential grower
+  const bool lostRule0 = c->lsdMode != 1 && getenv("PLI_TX_BOXRULE") == nullptr;
+  const bool keyMode = !sequential && c->lsdMode != 1 && c->txKeys && !c->debug && lostRule0 && !getenv("PLI_TX_FULL2") &&
+                       !getenv("PLI_TX_OLDMARK") && !getenv("PLI_TX_CELLRULE");   // (k_rx_mark, lsd_relax.hip, indexes the region planes by rank)
+  auto orderPasses = [&](const RxCtl* only) -> pli_status {
   LAUNCH(c, "k_lsd_hist", k_lsd_hist, dim3(c->nChunks, nimg), dim3(256), 0, c->g2, npix, P.g2Thresh, P.nBins, c->maxG2,
-         c->chunkHist, c->nChunks, img0, c->mg, c->maxMg, P.rho);
+         c->chunkHist, c->nChunks, img0, c->mg, c->maxMg, P.rho, only);
   // (thousands of chunks per image — 4K —: the scan over the chunks in groups, lsd_scanGroups > 0)
   if (c->scanGroups > 0) {
     LAUNCH(c, "k_lsd_scan", k_lsd_scan_part, dim3(nimg, c->scanGroups), dim3(1024), 0, c->chunkHist, c->nChunks, P.nBins,
            c->scanChunksPerGroup, c->chunkBase, c->scanGroupOff, img0);
     LAUNCH(c, "k_lsd_scan", k_lsd_scan_groups, dim3(nimg), dim3(1024), 0, c->scanGroups, P.nBins, c->scanGroupOff, c->nDefined, img0);
   } else
-  LAUNCH(c, "k_lsd_scan", k_lsd_scan, dim3(nimg), dim3(1024), 0, c->chunkHist, c->nChunks, P.nBins, c->chunkBase, c->nDefined, img0);
+  LAUNCH(c, "k_lsd_scan", k_lsd_scan, dim3(nimg), dim3(1024), 0, c->chunkHist, c->nChunks, P.nBins, c->chunkBase, c->nDefined, img0, only);
   // 16 KB of unused dynamic LDS per single-wave workgroup caps the scatter at 8 waves per CU: with all chunks of an image on
   // one XCD (see the kernel) that keeps the ordered lists "open" in an XCD's 4 MB L2 to ~2 images, so the 4-byte stores of
   // different chunks merge into whole lines before they are evicted (2048 frames: 21.8 -> 15.3 ms; 32 KB starves the CUs)
   constexpr size_t scatterOccupancyPad = 16384;
   LAUNCH(c, "k_lsd_scatter", k_lsd_scatter, dim3((unsigned)(8 * ((nimg + 7) / 8) * c->nChunks)), dim3(64), scatterOccupancyPad, c->g2, npix, P.g2Thresh,
          P.nBins, c->maxG2, c->chunkBase, c->nChunks, c->order, img0, nimg, c->mg, c->maxMg, P.rho,
-         sequential ? (int*)nullptr : c->rankOf, (const int*)(c->scanGroups > 0 ? c->scanGroupOff : nullptr), c->scanChunksPerGroup,
-         c->scanGroups);
+         (sequential || only) ? (int*)nullptr : c->rankOf, (const int*)(c->scanGroups > 0 ? c->scanGroupOff : nullptr), c->scanChunksPerGroup,
+         c->scanGroups, only);
+    return PLI_OK;
+  };
+  if (!keyMode) {
+    pli_status os = orderPasses(nullptr);
+    if (os != PLI_OK) return os;
+  }
   if (sequential) {
     // speculative form (line_kernels.hip: lsd_grow_image_spec): the small regions of 64 seeds at a time, one per lane
     const bool spec = c->lsdSpec && P.minRegSize >= 2;
@@ -907,15 +930,18 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     if (tile) {
       // tile-sequential relaxation (lsd_tile.hip): per-tile seed lists once, then rounds of one wave per tile
       const int ts = c->txTs, ntile = c->txNtx * c->txNty;
+      TxKeys keys{};
+      if (keyMode) keys = TxKeys{c->mg, c->maxMg, P.rho, P.nBins, c->txPixBits, c->rankOf};
       if (ts == 128)
         TRL(c, "k_tx_sort", k_tx_sort128, dim3(ntile, nimg), dim3(1024), 0, c->rankOf, c->order, c->own, c->txList,
-            c->txTileCnt, P.LW, P.LH, ts, c->txNtx, c->txNty, img0);
+            c->txTileCnt, P.LW, P.LH, ts, c->txNtx, c->txNty, img0, keys);
       else
         TRL(c, "k_tx_sort", k_tx_sort, dim3(ntile, nimg), dim3(256), 0, c->rankOf, c->order, c->own, c->txList,
-            c->txTileCnt, P.LW, P.LH, ts, c->txNtx, c->txNty, img0);
+            c->txTileCnt, P.LW, P.LH, ts, c->txNtx, c->txNty, img0, keys);
       const bool fullRound2 = getenv("PLI_TX_FULL2") != nullptr;       // dev: regrow everything in round 2
       const size_t txPad = getenv("PLI_TX_LDSPAD") ? (size_t)atoi(getenv("PLI_TX_LDSPAD")) : 0;   // dev: occupancy cap of the tile growers
       TxDirtyLists DL{c->txDirtyList, c->txDirtyCnt, c->order, ts, c->txNtx, c->txNty, P.LW, npix64};
+      if (keyMode) DL.rmask = (1 << c->txPixBits) - 1;
       if (getenv("PLI_TX_NODIRTYLIST")) DL.list = nullptr;             // dev: every active tile walks its whole seed list
       TxDirtyLists noDL = DL; noDL.list = nullptr;
       // rounds >= 3: k_rx_diff + k_tx_mark as one kernel (k_tx_diffmark; the dev rules keep the separate passes)
@@ -966,7 +992,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
               (lostRule && t >= 3 && !getenv("PLI_TX_CELLRULE")) ? (const int*)c->rgLost : (const int*)nullptr, DL);
           if (!fused2)
           TRL(c, "k_tx_prep", k_tx_prep, dim3((P.LW + 31) / 32, (P.LH + 31) / 32, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf,
-              c->rgDirty, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, t == 2 ? 1 : 0, fusedDM ? c->tileTouch : (int*)nullptr);
+              c->rgDirty, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, t == 2 ? 1 : 0, fusedDM ? c->tileTouch : (int*)nullptr, DL.rmask);
           TRL(c, "k_tx_grow_sparse", k_tx_grow_sparse, dim3(ntile, nimg), dim3(64), txPad, c->dP, c->jrCtl, c->rec, c->own, c->txList,
               c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty, c->tileAct, c->tilesW, c->tilesH, c->arena,
               c->arenaCap, c->rects, c->rectCap, img0, t, (const int*)c->rankOf, lostRule ? c->rgLost : (int*)nullptr, c->tileTouch,
@@ -1002,7 +1028,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
           }
         }
         TRL(c, "k_rx_rect", k_rx_rect, dim3(rectBlocks, nimg), dim3(64), 0, c->dP, c->jrCtl, c->rec, c->arena, c->arenaCap, c->rects,
-            c->rectCap, c->rgSeg, img0, c->mg);
+            c->rectCap, c->rgSeg, img0, c->mg, DL.rmask);
         if (trace) {
           HIPCHK(hipMemcpyAsync(c->jrHost.data(), c->jrCtl + img0, sizeof(RxCtl) * nimg, hipMemcpyDeviceToHost, c->stream));
           HIPCHK(hipStreamSynchronize(c->stream));
@@ -1042,7 +1068,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
         TRL(c, "k_rx_grow_big", k_rx_grow_big, dim3(bigBlocks, nimg), dim3(64), 0, c->dP, c->jrCtl, c->rec, c->own, c->bigSeeds,
             c->bigCap, c->hand, c->handCap, c->lastSize, c->rgBox, c->arena, c->arenaCap, c->rects, c->rectCap, img0, t);
       TRL(c, "k_rx_rect", k_rx_rect, dim3(rectBlocks, nimg), dim3(64), 0, c->dP, c->jrCtl, c->rec, c->arena, c->arenaCap, c->rects,
-          c->rectCap, c->rgSeg, img0, c->mg);
+          c->rectCap, c->rgSeg, img0, c->mg, -1);
       if (trace) {
         HIPCHK(hipMemcpyAsync(c->jrHost.data(), c->jrCtl + img0, sizeof(RxCtl) * nimg, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -1054,12 +1080,25 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       { pli_status ls_ = look(t); if (ls_ != PLI_OK) return ls_; }
     }
     }
+    if (keyMode) {
+      HIPCHK(hipMemsetAsync(c->txCandCnt + img0, 0, sizeof(int) * nimg, c->stream));
+      int emitCap = TX_EMIT_CAP;                   // (test switch: a small list, so that images take the overflow path to the sequential grower)
+      if (const char* e = getenv("PLI_TX_EMITCAP")) emitCap = std::max(1, std::min(TX_EMIT_CAP, atoi(e)));
+      TRL(c, "k_tx_collect", k_tx_collect, dim3(std::max(1, std::min(64, (int)((npix64 + 2047) / 2048))), nimg), dim3(256), 0, c->jrCtl,
+          (const int*)c->rankOf, (const int2*)c->own, (const int*)c->lastSize, npix64, P.minRegSize, c->txCand, c->txCandCnt, img0, emitCap);
+      TRL(c, "k_tx_emit_sorted", k_tx_emit_sorted, dim3(nimg), dim3(1024), TX_EMIT_CAP * 4, (const RxCtl*)c->jrCtl, (const int*)c->txCand,
+          (const int*)c->txCandCnt, (const float4*)c->rgSeg, npix64, (1 << c->txPixBits) - 1, c->seg, c->nSeg, c->maxSeg, img0, emitCap);
+      // (the ordered lists of the images left to the sequential grower, decided on the device: normally none, and the three passes end at once)
+      pli_status os = orderPasses(c->jrCtl);
+      if (os != PLI_OK) return os;
+    } else {
     TRL(c, "k_rx_count", k_rx_count, dim3(c->rxChunks, nimg), dim3(256), 0, c->jrCtl, c->order, c->nDefined, c->own, c->lastSize,
            c->rxChunkCnt, c->rxChunks, npix64, P.minRegSize, img0);
     TRL(c, "k_rx_emit", k_rx_emit, dim3(c->rxChunks, nimg), dim3(256), 0, c->jrCtl, c->order, c->nDefined, c->own, c->lastSize,
            c->rgSeg, c->rxChunkCnt, c->rxChunks, npix64, P.minRegSize, c->seg, c->nSeg, c->maxSeg, img0);
+    }
     // images that ran out of a capacity (or did not settle) take the sequential grower
-    if (blocking) {
+    if (blocking && !keyMode) {
       for (int i = 0; i < nimg; ++i) {
         if (c->jrHost[i].overflow || c->jrHost[i].state != 2) {
           LAUNCH(c, "k_lsd_grow", k_lsd_grow, dim3(1), dim3(64), 0, c->dP, c->rec, c->mg, c->order, c->nDefined,
@@ -1070,6 +1109,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       // ... decided on the device: the waves of the settled images leave at once
       LAUNCH(c, "k_lsd_grow_unsettled", k_lsd_grow_unsettled, dim3(nimg), dim3(64), 0, c->dP, c->rec, c->mg, c->order, c->nDefined,
              c->regScratch, c->seg, c->nSeg, c->maxSeg, img0, nimg, c->jrCtl);
+      if (!blocking) {
       if (!c->rxSeen) {
         HIPCHK(hipHostMalloc((void**)&c->rxSeen, sizeof(int) * 4 * (size_t)c->NI, hipHostMallocDefault));
         HIPCHK(hipEventCreateWithFlags(&c->evRxSeen, hipEventDisableTiming));
@@ -1078,6 +1118,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
         HIPCHK(hipMemcpy2DAsync(c->rxSeen, 16, c->jrCtl + img0, sizeof(RxCtl), 16, nimg, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipEventRecord(c->evRxSeen, c->stream));
         c->rxSeenImages = nimg;
+      }
       }
     }
   }

@@ -1100,6 +1100,36 @@ def test_look_free_rounds_and_device_side_fallback(gpu, monkeypatch):
                     assert recs[f][k].tobytes() == first[f][k].tobytes(), (what, f, k)
 
 
+def test_key_mode_and_rank_mode_and_the_segment_list_overflow(gpu, monkeypatch):
+    """The tile relaxation names its regions by KEYS (gradient bin | seed pixel: no ordered list is built, lsd_tile.hip k_tx_sort)
+    for images of up to 2^20 scaled pixels, by their ranks in the ordered list otherwise (dev switch PLI_TX_KEYS=0).  Both give the
+    oracle's lines; and so does an image whose candidate segments do not fit the list k_tx_emit_sorted can order (forced with the
+    test switch PLI_TX_EMITCAP): it is counted as a slow-path image and redone by the sequential grower from an ordered list
+    built for it alone."""
+    g = gpu
+    W, H = 752, 480
+    cfg = g.capi.default_config(W, H, orb_nfeatures=1200, lsd_nfeatures=0, max_frames=3)
+    pairs = [g.synth.make_stereo_pair(90 + i, W, H) for i in range(3)]
+    imgs = np.stack([np.stack(p) for p in pairs])
+    out = {}
+    for what, env in (("keys", {}), ("ranks", {"PLI_TX_KEYS": "0"}), ("overflow", {"PLI_TX_EMITCAP": "100"})):
+        for k in ("PLI_TX_KEYS", "PLI_TX_EMITCAP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        fe = g.Frontend(cfg)
+        fe.batch_run_host(imgs)
+        out[what] = fe.batch_run_host(imgs)                  # (the second call: look-free rounds)
+        st = fe.lsd_round_stats()
+        assert (st[2] >= 1) == (what == "overflow"), (what, st)
+    assert len(out["keys"][0]["klL"]) > 100
+    for f, (L, R) in enumerate(pairs):
+        assert_frame_equal(g, out["keys"][f], g.po.Frame(ocfg(g, cfg)), L, R, "key mode frame %d" % f)
+        for what in ("ranks", "overflow"):
+            for k in ("klL", "klR", "ldescL", "ldescR", "disp", "le"):
+                assert out[what][f][k].tobytes() == out["keys"][f][k].tobytes(), (what, f, k)
+
+
 def test_frame_extract_equals_the_per_call_entry_points(cfg2):
     """pli_frame_extract (what the adapters fuse the four extractor threads of a Frame into) against the four per-call entry points
     and the two stereo matchers: the same record, and the per-call state it leaves (pyramid levels, stereo matchers without a rerun)."""
