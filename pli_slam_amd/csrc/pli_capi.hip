@@ -1380,7 +1380,8 @@ pli_status pli_batch_run(pli_ctx* c, int32_t nframes, const uint8_t* dl, const u
     };
     // (measured: +1.3 % at 32 frames, +1.4 % on the 4K configuration (16 frames), +1 % on a single pair; neutral at 64 and 128
     // frames, -0.5 % at 256, -3 % on the 720p configuration with its 2000 keypoints: up to 64 images it is)
-    if (sideDefer && !seqGrower && c->lsdMode != 1 && nimg <= 64) c->sideChain = sideChain;
+    static const int sideDeferMax = getenv("PLI_SIDE_DEFER_MAX") ? atoi(getenv("PLI_SIDE_DEFER_MAX")) : 64;   // (dev: images up to which the ORB chain starts behind round 1)
+    if (sideDefer && !seqGrower && c->lsdMode != 1 && nimg <= sideDeferMax) c->sideChain = sideChain;
     else if ((st = sideChain()) != PLI_OK) { c->lbdPreOnSide = false; return st; }
     st = runLines(c, 0, nimg, T);
     if (st == PLI_OK && c->sideChain) { auto f = std::move(c->sideChain); c->sideChain = nullptr; st = f(); }   // (not taken by runLines)
