@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Dev tool (GPU box): wide seed sweep of the round-3 schedules of the tile relaxation against the oracle — the default (late rounds in
 the persistent tail kernel), the tail from round 3 on, no tail (planned look-free rounds; the second call on the context plans from
-the first), the speculative round 1 (PLI_TX_SPEC=1), tiles of 16 / 32 / 64 — batches of 8 pairs, lsd_nfeatures = 0 (every segment
+the first), the speculative round 1 (PLI_TX_SPEC=1), tiles of 16 / 32 / 64, region ids as ranks instead of keys (PLI_TX_KEYS=0) — batches of 8 pairs, lsd_nfeatures = 0 (every segment
 and its LBD bits are compared), both detector pipelines.      python tools/cross_check_r03.py [first seed] [pairs]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,7 +15,8 @@ base = int(sys.argv[1]) if len(sys.argv) > 1 else 70000
 npairs = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 W, H, B = 752, 480, 8
 VARIANTS = [("default", {}), ("tail_t3", {"PLI_TX_TAIL_T0": "3"}), ("no_tail", {"PLI_TX_TAIL": "0"}), ("spec", {"PLI_TX_SPEC": "1"}),
-            ("spec_tail_t3_ts32", {"PLI_TX_SPEC": "1", "PLI_TX_TAIL_T0": "3", "PLI_TX_TS": "32"}), ("ts16", {"PLI_TX_TS": "16"})]
+            ("spec_tail_t3_ts32", {"PLI_TX_SPEC": "1", "PLI_TX_TAIL_T0": "3", "PLI_TX_TS": "32"}), ("ts16", {"PLI_TX_TS": "16"}),
+            ("ranks", {"PLI_TX_KEYS": "0"}), ("ranks_no_tail_ts32", {"PLI_TX_KEYS": "0", "PLI_TX_TAIL": "0", "PLI_TX_TS": "32"})]
 KEYS = sorted({k for _, e in VARIANTS for k in e})
 bad = 0
 for flags in (None, 0):
