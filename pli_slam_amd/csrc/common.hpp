@@ -120,6 +120,12 @@ struct TxDirtyLists {
 };
 
 constexpr int TX_EMIT_CAP = 16384;   // key mode: candidate segments of an image that k_tx_emit_sorted can order (LDS)
+// k_zero_ranges (orb_kernels.hip): buffers cleared by one launch
+struct ZeroRanges {
+  uint32_t* p[8];
+  int64_t words[8];
+};
+
 // k_tx_sort in key mode (lsd_tile.hip)
 struct TxKeys {
   const double* mg;                 // gradient norm plane, or null: rank mode

@@ -125,7 +125,9 @@ __device__ __forceinline__ void tx_dirty_append(const TxDirtyLists& DL, int img,
   const int sy = sp / DL.W, sx = sp - sy * DL.W;
   const int64_t tile = (int64_t)img * DL.ntx * DL.nty + (sy / DL.ts) * DL.ntx + sx / DL.ts;
   const int slot = atomicAdd(&DL.cnt[tile], 1);
-  DL.list[tile * DL.ts * DL.ts + slot] = make_int2(o, sp);
+  // (an image that ran out of a capacity is left by its growers, which then no longer take — and clear — its lists, while the
+  // bookkeeping passes of the remaining rounds may still stamp: nothing is written past a tile's list)
+  if (slot < DL.ts * DL.ts) DL.list[tile * DL.ts * DL.ts + slot] = make_int2(o, sp);
 }
 
 // CV_64F pipeline (lsd_f64.hip): the gradient norm is a double plane, its maximum is kept as the bits of a double

@@ -1352,7 +1352,7 @@ __global__ __launch_bounds__(256) void k_keylines(const DevParams* __restrict__ 
                                                   int64_t offKl1, int img0) {
   __shared__ int s_wc[4];
   __shared__ int s_base;
-  __shared__ float resp[4096];
+  __shared__ unsigned long long keys[4096];
   const DevParams& P = *Pp;
   const int img = blockIdx.x + img0, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n = nSeg[img];
@@ -1417,21 +1417,99 @@ __global__ __launch_bounds__(256) void k_keylines(const DevParams* __restrict__ 
   __threadfence_block();
   __syncthreads();
   if (M > nf && nf != 0) {
-    // top-N by response, equal responses keep detection order (stable): rank by counting, responses tiled through LDS
+    // top-N by response, equal responses keep detection order (stable): rank by counting.  A line's place in that order is ONE
+    // 64-bit key — the bits of its (positive) response above the complement of its index — and its rank the number of larger keys;
+    // the keys are tiled through LDS, a wave takes 64 of them with one load (a key per lane) and hands them round with readlane
+    // (2 readlanes + a 64-bit compare + an add per key; the earlier form read every response from LDS in every thread, one
+    // dependent LDS round trip per comparison: 189 us per image, a single pair's third-longest kernel).
+    auto keyOf = [](float resp, int idx) -> unsigned long long {
+      return ((unsigned long long)__float_as_uint(resp) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)idx);
+    };
+    if (M <= 4096) {
+      // ... and only for the nf lines that are kept: the nf-th largest key by radix select (eight passes of 8 bits from the top: a
+      // 256-bin LDS histogram of the keys that match the bits chosen so far, one wave finds the bin of the k-th from the top),
+      // then the lines at or above it (keys are distinct: exactly nf) rank themselves among each other
+      __shared__ int s_hist[256];
+      __shared__ unsigned long long s_pref, s_mask;
+      __shared__ int s_k, s_nsel;
+      __shared__ unsigned short s_sel[4096];
+      for (int j = tid; j < M; j += 256) keys[j] = keyOf(tk[j].response, j);
+      if (tid == 0) { s_pref = 0ull; s_mask = 0ull; s_k = nf - 1; s_nsel = 0; }
+      for (int shift = 56; shift >= 0; shift -= 8) {
+        s_hist[tid] = 0;
+        __syncthreads();
+        const unsigned long long pref = s_pref, mask = s_mask;
+        for (int j = tid; j < M; j += 256) {
+          const unsigned long long kj = keys[j];
+          if ((kj & mask) == pref) atomicAdd(&s_hist[(int)((kj >> shift) & 255ull)], 1);
+        }
+        __syncthreads();
+        if (tid < 64) {                              // lane l: the bins 255 - 4l .. 252 - 4l, from the top
+          const int b0 = 255 - 4 * tid;
+          const int h0 = s_hist[b0], h1 = s_hist[b0 - 1], h2 = s_hist[b0 - 2], h3 = s_hist[b0 - 3];
+          const int sum = h0 + h1 + h2 + h3;
+          int inc = sum;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const int t2 = __shfl_up(inc, o, 64);
+            if (tid >= o) inc += t2;
+          }
+          const int k = s_k, before = inc - sum;
+          if (before <= k && k < inc) {
+            int b = b0, c = before;
+            if (k >= c + h0) { c += h0; b = b0 - 1; if (k >= c + h1) { c += h1; b = b0 - 2; if (k >= c + h2) { c += h2; b = b0 - 3; } } }
+            s_pref = pref | ((unsigned long long)b << shift);
+            s_mask = mask | (255ull << shift);
+            s_k = k - c;
+          }
+        }
+        __syncthreads();
+      }
+      const unsigned long long kth = s_pref;
+      for (int j = tid; j < M; j += 256)
+        if (keys[j] >= kth) s_sel[atomicAdd(&s_nsel, 1)] = (unsigned short)j;
+      __syncthreads();
+      for (int i0 = 0; i0 < nf; i0 += 256) {
+        const int si = i0 + tid;
+        const int i = si < nf ? (int)s_sel[si] : 0;
+        const unsigned long long ki = si < nf ? keys[i] : ~0ull;
+        int rank = 0;
+        for (int j = 0; j < nf; j += 64) {
+          const unsigned long long kv = j + lane < nf ? keys[s_sel[j + lane]] : 0ull;
+          const int lo = (int)(unsigned)kv, hi = (int)(unsigned)(kv >> 32);
+#pragma unroll
+          for (int u = 0; u < 64; ++u) {
+            const unsigned long long kj = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hi, u) << 32) |
+                                          (unsigned long long)(unsigned)__builtin_amdgcn_readlane(lo, u);
+            rank += kj > ki ? 1 : 0;
+          }
+        }
+        if (si < nf) {
+          pli_keyline kl = tk[i];
+          kl.class_id = rank;
+          out[rank] = kl;
+        }
+      }
+    } else
     for (int i0 = 0; i0 < M; i0 += 256) {
       const int i = i0 + tid;
-      const float r = i < M ? tk[i].response : 0.f;
+      const unsigned long long ki = i < M ? keyOf(tk[i].response, i) : ~0ull;
       int rank = 0;
       for (int j0 = 0; j0 < M; j0 += 4096) {
         const int m = min(4096, M - j0);
         __syncthreads();
-        for (int j = tid; j < m; j += 256) resp[j] = tk[j0 + j].response;
+        for (int j = tid; j < m; j += 256) keys[j] = keyOf(tk[j0 + j].response, j0 + j);
         __syncthreads();
-        if (i < M)
-          for (int j = 0; j < m; ++j) {
-            const float rj = resp[j];
-            rank += (rj > r || (rj == r && j0 + j < i)) ? 1 : 0;
+        for (int j = 0; j < m; j += 64) {
+          const unsigned long long kv = j + lane < m ? keys[j + lane] : 0ull;      // (0: smaller than every key)
+          const int lo = (int)(unsigned)kv, hi = (int)(unsigned)(kv >> 32);
+#pragma unroll
+          for (int u = 0; u < 64; ++u) {
+            const unsigned long long kj = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hi, u) << 32) |
+                                          (unsigned long long)(unsigned)__builtin_amdgcn_readlane(lo, u);
+            rank += kj > ki ? 1 : 0;
           }
+        }
       }
       if (i < M && rank < nf) {
         pli_keyline kl = tk[i];

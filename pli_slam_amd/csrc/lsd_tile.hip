@@ -78,6 +78,54 @@ __device__ __forceinline__ float tx_rlf(float v, int l) { return __int_as_float(
 // seed pixel.  This kernel then also writes the plane of the pixels' own ids (what k_lsd_scatter writes in rank mode).
 // (struct TxKeys: common.hpp)
 
+// The bitonic network over KPT * NT keys, thread t holding the KPT consecutive keys t*KPT .. t*KPT+KPT-1 in registers (ascending
+// result): a compare distance j < KPT stays inside the thread, j < 64*KPT pairs lanes of one wave (ds_bpermute, no LDS memory, no
+// barrier), and only the stages whose partner sits in another wave go through xch (KPT * NT words of LDS).
+template <int KPT, int NT>
+__device__ __forceinline__ void tx_bitonic_regs(unsigned (&key)[KPT], unsigned* xch, int tid) {
+  constexpr int n2 = KPT * NT;
+#pragma unroll
+  for (int k = 2; k <= n2; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {             // (fully unrolled: the register array needs constant indices)
+      if (j >= KPT) {
+        const int pt = j / KPT;                           // partner thread = tid ^ pt
+        const bool asc = ((tid * KPT) & k) == 0;           // (k > j >= KPT: the direction depends on the thread only)
+        const bool lower = (tid & pt) == 0;
+        const bool keepMin = lower == asc;
+        if (pt < 64) {
+#pragma unroll
+          for (int u = 0; u < KPT; ++u) {
+            const unsigned o = (unsigned)__shfl_xor((int)key[u], pt, 64);
+            key[u] = keepMin ? min(key[u], o) : max(key[u], o);
+          }
+        } else {
+          __syncthreads();
+#pragma unroll
+          for (int u = 0; u < KPT; ++u) xch[u * NT + tid] = key[u];
+          __syncthreads();
+#pragma unroll
+          for (int u = 0; u < KPT; ++u) {
+            const unsigned o = xch[u * NT + (tid ^ pt)];
+            key[u] = keepMin ? min(key[u], o) : max(key[u], o);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < KPT; ++u) {
+          if ((u & j) == 0) {
+            const bool asc = ((tid * KPT + u) & k) == 0;
+            const unsigned a = key[u], b = key[u | j];
+            const bool sw = (a > b) == asc;
+            key[u] = sw ? b : a;
+            key[u | j] = sw ? a : b;
+          }
+        }
+      }
+    }
+  }
+}
+
 template <int KPT, int NT>
 __device__ __forceinline__ void tx_sort_tile(const int* __restrict__ rankAll, const int* __restrict__ orderAll,
                                              int2* __restrict__ ownAll, int2* __restrict__ listAll,
@@ -126,46 +174,7 @@ __device__ __forceinline__ void tx_sort_tile(const int* __restrict__ rankAll, co
   unsigned key[KPT];
 #pragma unroll
   for (int u = 0; u < KPT; ++u) key[u] = xch[pad(tid * KPT + u)];
-#pragma unroll
-  for (int k = 2; k <= n2; k <<= 1) {
-#pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {             // (fully unrolled: the register array needs constant indices)
-      if (j >= KPT) {
-        const int pt = j / KPT;                           // partner thread = tid ^ pt
-        const bool asc = ((tid * KPT) & k) == 0;           // (k > j >= KPT: the direction depends on the thread only)
-        const bool lower = (tid & pt) == 0;
-        const bool keepMin = lower == asc;
-        if (pt < 64) {
-#pragma unroll
-          for (int u = 0; u < KPT; ++u) {
-            const unsigned o = (unsigned)__shfl_xor((int)key[u], pt, 64);
-            key[u] = keepMin ? min(key[u], o) : max(key[u], o);
-          }
-        } else {
-          __syncthreads();
-#pragma unroll
-          for (int u = 0; u < KPT; ++u) xch[u * NT + tid] = key[u];
-          __syncthreads();
-#pragma unroll
-          for (int u = 0; u < KPT; ++u) {
-            const unsigned o = xch[u * NT + (tid ^ pt)];
-            key[u] = keepMin ? min(key[u], o) : max(key[u], o);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int u = 0; u < KPT; ++u) {
-          if ((u & j) == 0) {
-            const bool asc = ((tid * KPT + u) & k) == 0;
-            const unsigned a = key[u], b = key[u | j];
-            const bool sw = (a > b) == asc;
-            key[u] = sw ? b : a;
-            key[u | j] = sw ? a : b;
-          }
-        }
-      }
-    }
-  }
+  tx_bitonic_regs<KPT, NT>(key, xch, tid);
   int2* list = listAll + ((int64_t)img * ntx * nty + tile) * n2;
   const int* order = orderAll + img * npix;
   __syncthreads();
@@ -681,6 +690,8 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
   if (SPARSE && DL.list) {
     const int nd = DL.cnt[(int64_t)img * ntile + tile];
     if (nd == 0) return;
+    // (the list is taken: the next round's stamps start a new one — the host does not clear the counters between the rounds)
+    if (lane == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1) DL.cnt[(int64_t)img * ntile + tile] = 0;
     if (nd <= 64) {
       useDirty = true;
       if (lane < nd) dse = DL.list[((int64_t)img * ntile + tile) * ts * ts + lane];
@@ -1374,6 +1385,19 @@ __global__ __launch_bounds__(256) void k_tx_collect(RxCtl* __restrict__ ctl, con
   }
 }
 
+template <int KPT>
+__device__ __forceinline__ void tx_emit_sort(unsigned* ks, const int* __restrict__ cand, int n, int tid) {
+  // (thread t: the keys t*KPT .. t*KPT+KPT-1; the padding sorts to the end)
+  unsigned key[KPT];
+#pragma unroll
+  for (int u = 0; u < KPT; ++u) key[u] = tid * KPT + u < n ? (unsigned)cand[tid * KPT + u] : 0xFFFFFFFFu;
+  tx_bitonic_regs<KPT, 1024>(key, ks, tid);
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < KPT; ++u) ks[tid * KPT + u] = key[u];
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(1024) void k_tx_emit_sorted(const RxCtl* __restrict__ ctl, const int* __restrict__ candAll, const int* __restrict__ candCnt,
                                                          const float4* __restrict__ rgSegAll, int64_t npix, int rmask, float* __restrict__ segAll,
                                                          int* __restrict__ nSeg, int maxSeg, int img0, int emitCap) {
@@ -1381,21 +1405,14 @@ __global__ __launch_bounds__(1024) void k_tx_emit_sorted(const RxCtl* __restrict
   const int img = blockIdx.x + img0;
   if (ctl[img].state != 2 || ctl[img].overflow) return;
   const int n = min(candCnt[img], emitCap), tid = threadIdx.x;
-  int n2 = 1;
-  while (n2 < n) n2 <<= 1;
-  for (int i = tid; i < n2; i += 1024) ks[i] = i < n ? (unsigned)candAll[(int64_t)img * TX_EMIT_CAP + i] : 0xFFFFFFFFu;
-  __syncthreads();
-  for (int k = 2; k <= n2; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < n2; i += 1024) {
-        const int l = i ^ j;
-        if (l > i) {
-          const unsigned a = ks[i], b = ks[l];
-          if (((i & k) == 0) == (a > b)) { ks[i] = b; ks[l] = a; }
-        }
-      }
-      __syncthreads();
-    }
+  const int* cand = candAll + (int64_t)img * TX_EMIT_CAP;
+  // the sorting network of k_tx_sort, keys in registers: with n <= 1024 (the usual case) 10 of its 55 stages cross a wave and need
+  // the LDS and a barrier; the earlier all-LDS network spent a barrier on every stage (114 us for a single pair)
+  if (n <= 1024) tx_emit_sort<1>(ks, cand, n, tid);
+  else if (n <= 2048) tx_emit_sort<2>(ks, cand, n, tid);
+  else if (n <= 4096) tx_emit_sort<4>(ks, cand, n, tid);
+  else if (n <= 8192) tx_emit_sort<8>(ks, cand, n, tid);
+  else tx_emit_sort<16>(ks, cand, n, tid);
   float* seg = segAll + (int64_t)img * maxSeg * 4;
   for (int i = tid; i < min(n, maxSeg); i += 1024) {
     const float4 v = rgSegAll[img * npix + (int)(ks[i] & (unsigned)rmask)];

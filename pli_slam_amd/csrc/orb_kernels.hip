@@ -934,6 +934,24 @@ __global__ __launch_bounds__(64) void k_describe(const DevParams* __restrict__ P
 }
 
 // N (mvKeys.size()) per eye into the frame record
+// k_zero_ranges: up to 8 buffers cleared by ONE launch (what the relaxation zeroes at the start of a call: control blocks, stamp
+// planes, cell tables, counters — eight hipMemsetAsync launches before; a single pair's call spent 15 of its ~110 launches on fills).
+// blockIdx.y = the range; 16-byte stores on the aligned body, words at both ends.
+__global__ __launch_bounds__(256) void k_zero_ranges(ZeroRanges Z) {
+  const int r = blockIdx.y;
+  uint32_t* p = Z.p[r];
+  const int64_t n = Z.words[r];
+  if (!p || n <= 0) return;
+  const int64_t head = min<int64_t>(n, (int64_t)((16 - ((uintptr_t)p & 15)) & 15) >> 2);
+  const int64_t body = (n - head) >> 2;                          // uint4 stores
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+  uint4* b = reinterpret_cast<uint4*>(p + head);
+  for (int64_t i = tid; i < body; i += stride) b[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (tid < head) p[tid] = 0u;
+  const int64_t tail0 = head + 4 * body;
+  if (tid < n - tail0) p[tail0 + tid] = 0u;
+}
+
 __global__ void k_kp_counts(const DevParams* __restrict__ Pp, const int* __restrict__ kpSelCount,
                             uint8_t* __restrict__ table, int64_t recordBytes, int64_t offCounts, int nimg, int img0) {
   const DevParams& P = *Pp;

@@ -880,13 +880,29 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     int maxRounds = 96;
     if (const char* e = getenv("PLI_RX_MAXROUNDS")) maxRounds = std::max(1, atoi(e));
     const float precDeg = (float)(P.prec * 180.0 / 3.14159265358979323846);
-    HIPCHK(hipMemsetAsync(c->jrCtl + img0, 0, sizeof(RxCtl) * nimg, c->stream));
     if (c->rgClean) HIPCHK(hipMemsetAsync(c->rgClean + (int64_t)img0 * npix, 0, npix64 * nimg, c->stream));   // round stamps
-    HIPCHK(hipMemsetAsync(c->rgDirty + (int64_t)img0 * npix, 0, sizeof(int) * npix64 * nimg, c->stream));
     const bool lostRule = c->lsdMode != 1 && getenv("PLI_TX_BOXRULE") == nullptr;     // dev switch: the conservative round-2 rule
-    if (lostRule) HIPCHK(hipMemsetAsync(c->rgLost + (int64_t)img0 * npix, 0, sizeof(int) * npix64 * nimg, c->stream));
-    HIPCHK(hipMemsetAsync(c->tileTouch + (int64_t)img0 * c->tilesW * c->tilesH, 0, sizeof(int) * (size_t)c->tilesW * c->tilesH * nimg, c->stream));
-    HIPCHK(hipMemsetAsync(c->tileAct + (int64_t)img0 * c->tilesW * c->tilesH, 0, sizeof(int) * (size_t)c->tilesW * c->tilesH * nimg, c->stream));
+    {
+      // everything the relaxation wants zeroed at the start of a call, in one launch (k_zero_ranges): control blocks, the stamp planes,
+      // the cell tables, and the tile relaxation's per-tile dirty counters (cleared by their consumers from then on), the barrier words
+      // of k_tx_tail and the candidate counters of k_tx_collect
+      const int64_t cells = (int64_t)c->tilesW * c->tilesH;
+      const int64_t ntile64 = (int64_t)c->txNtx * c->txNty;
+      static_assert(sizeof(RxCtl) % 4 == 0, "RxCtl is cleared as words");
+      ZeroRanges Z{};
+      int zr = 0;
+      auto add = [&](void* p, int64_t words) { if (p && words > 0) { Z.p[zr] = (uint32_t*)p; Z.words[zr] = words; ++zr; } };
+      add(c->jrCtl + img0, (int64_t)(sizeof(RxCtl) / 4) * nimg);
+      add(c->rgDirty + (int64_t)img0 * npix, npix64 * nimg);
+      if (lostRule) add(c->rgLost + (int64_t)img0 * npix, npix64 * nimg);
+      add(c->tileTouch + (int64_t)img0 * cells, cells * nimg);
+      add(c->tileAct + (int64_t)img0 * cells, cells * nimg);
+      if (c->txDirtyCnt) add(c->txDirtyCnt + (int64_t)img0 * ntile64, ntile64 * nimg);
+      if (c->tailBar) add(c->tailBar, 64);
+      if (c->txCandCnt) add(c->txCandCnt + img0, nimg);
+      const int zb = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (npix64 * nimg / 4 + 255) / 256));
+      LAUNCH(c, "k_zero_ranges", k_zero_ranges, dim3(zb, zr), dim3(256), 0, Z);
+    }
     // (the rank plane was written by k_lsd_scatter)
     const dim3 raster((P.LW + 255) / 256, P.LH, nimg);
     const bool tile = c->lsdMode != 1;      // auto below RX_AUTO_IMAGES and mode 3: the tile-sequential relaxation
@@ -955,15 +971,21 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       for (int t = 1; t <= maxRounds && !allDone; ++t) {
         curT = t;
         if (useTail && t == tailT0) {
-          HIPCHK(hipMemsetAsync(c->txDirtyCnt + (int64_t)img0 * ntile, 0, sizeof(int) * (size_t)ntile * nimg, c->stream));
-          HIPCHK(hipMemsetAsync(c->tailBar, 0, 64 * sizeof(unsigned), c->stream));
+          // (the dirty counters are zero: every list of the last round was taken by its tile's wave; the barrier words were cleared
+          // with the control blocks)
           TxTailArgs ta{c->dP, c->jrCtl, c->rec, c->own, c->txList, c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty,
                         c->tileAct, c->tileTouch, c->tilesW, c->tilesH, c->arena, c->arenaCap, c->rects, c->rectCap, c->rgSeg, c->mg,
                         c->rankOf, c->rgLost, DL, img0, nimg, t, 96, c->tailBar};
-          LAUNCH(c, "k_tx_tail", k_tx_tail, dim3(c->tailBlocks), dim3(256), 0, ta);
+          // (a grid barrier costs 8 us with 256 workgroups and less with fewer: a few images do not need the whole chip in the late rounds)
+          // (single pair: k_tx_tail 149 us with 256 workgroups, 90 with 64)
+          int tb = std::min(c->tailBlocks, std::max(64, 8 * nimg));
+          if (const char* e = getenv("PLI_TX_TAIL_BLOCKS")) tb = std::max(1, std::min(c->tailBlocks, atoi(e)));     // dev switch
+          LAUNCH(c, "k_tx_tail", k_tx_tail, dim3(tb), dim3(256), 0, ta);
           break;
         }
-        if (t >= 2 && DL.list)
+        // (the per-tile dirty counters: cleared once per call with the control blocks, then by the wave that takes a tile's list;
+        // the dev schedule that regrows everything in round 2 does not read the lists it stamped)
+        if (t == 3 && DL.list && fullRound2)
           HIPCHK(hipMemsetAsync(c->txDirtyCnt + (int64_t)img0 * ntile, 0, sizeof(int) * (size_t)ntile * nimg, c->stream));
         const bool fused2 = t == 2 && !fullRound2 && lostRule && !getenv("PLI_TX_NOFUSE2");    // (dev switch: the two passes)
         if (fused2)
@@ -1081,7 +1103,6 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     }
     }
     if (keyMode) {
-      HIPCHK(hipMemsetAsync(c->txCandCnt + img0, 0, sizeof(int) * nimg, c->stream));
       int emitCap = TX_EMIT_CAP;                   // (test switch: a small list, so that images take the overflow path to the sequential grower)
       if (const char* e = getenv("PLI_TX_EMITCAP")) emitCap = std::max(1, std::min(TX_EMIT_CAP, atoi(e)));
       TRL(c, "k_tx_collect", k_tx_collect, dim3(std::max(1, std::min(64, (int)((npix64 + 2047) / 2048))), nimg), dim3(256), 0, c->jrCtl,
