@@ -584,7 +584,15 @@ pli_status allocAll(pli_ctx* c) {
     c->rxChunks = (int)((npix + 2047) / 2048);
     A(c->rxChunkCnt, (size_t)c->rxChunks * NR);
     // pixel lists for region2rect (<= npix per round) + queue overflow blocks; the lane growers also park hand-overs here
-    c->arenaCap = (int)std::min<size_t>((lane ? 8 : 3) * npix + 65536, (size_t)1 << 30);
+    // Words of arena per scaled pixel.  A round needs one word per pixel for the finished regions' lists — and, in the tile relaxation,
+    // queue overflow blocks for every region of more than TX_GQ pixels that is being grown, by EVERY tile it has seeds in at the
+    // same time in round 1: long parallel structures (blinds, corrugated walls; the "stripes" image of the tests) multiply that
+    // by the tiles a region crosses.  3 words per pixel sent all 512 stripes images to the sequential grower (455 ms per batch
+    // instead of 50); they need < 16, which is what a context gets as long as its arenas stay below 24 GiB.
+    size_t arenaFactor = lane ? 8 : 16;
+    if (!lane) arenaFactor = std::max<size_t>(3, std::min<size_t>(16, ((size_t)24 << 30) / (npix * 4 * NR)));
+    if (const char* e = getenv("PLI_RX_ARENA")) arenaFactor = (size_t)std::max(1, atoi(e));     // dev: words of arena per scaled pixel
+    c->arenaCap = (int)std::min<size_t>(arenaFactor * npix + 65536, (size_t)1 << 30);
     A(c->arena, (size_t)c->arenaCap * NR);
     if (tiles) {
       // (the measure is the number of 64-pixel tile waves the context can put on the chip, not the number of images)

@@ -554,6 +554,29 @@ def test_lsd_hostile_images(gpu, mode):
         assert kl.tobytes() == okl.tobytes() and np.array_equal(ld, old), name
 
 
+def test_long_parallel_structures_settle_without_the_fallback(gpu, monkeypatch):
+    """Full-size diagonal stripes: every flank is one region of thousands of pixels that has seeds in a dozen tiles, so round 1 of
+    the tile relaxation grows it a dozen times at once, each copy with its own queue overflow blocks.  With the arena a context
+    gets (16 words per scaled pixel) the image settles in a few rounds; with the 3 words of rounds 1-2 (dev switch PLI_RX_ARENA)
+    it runs out of blocks and is redone by the sequential grower — the same lines either way, the oracle's."""
+    g = gpu
+    W, H = 752, 480
+    yy, xx = np.mgrid[0:H, 0:W]
+    stripes = ((np.sin((xx + 2 * yy) / 5.0) * 0.5 + 0.5) * 255).astype(np.uint8)
+    cfg = g.capi.default_config(W, H, orb_nfeatures=300, lsd_nfeatures=0, max_frames=1, lsd_mode=3)
+    want = g.po.Frame(ocfg(g, cfg)).line_extract(0, stripes)
+    assert want[0] > 50
+    for arena, falls_back in ((None, False), ("3", True)):
+        if arena:
+            monkeypatch.setenv("PLI_RX_ARENA", arena)
+        fe = g.Frontend(cfg)
+        for _ in range(2):                                   # (the second call: look-free rounds)
+            n, kl, ld = fe.line_extract(0, stripes)
+            assert n == want[0] and kl.tobytes() == want[1].tobytes() and np.array_equal(ld, want[2]), arena
+        assert (fe.lsd_round_stats()[2] > 0) == falls_back, (arena, fe.lsd_round_stats())
+        monkeypatch.delenv("PLI_RX_ARENA", raising=False)
+
+
 def test_full_size_batch_properties(gpu):
     """BASELINE config at batch scale (96 EuRoC-size frames, 8 distinct pairs cycled), through size-independent
     properties: the two LSD schedules write byte-identical tables; a frame's record does not depend on its position
