@@ -1,0 +1,9 @@
+#!/bin/sh
+# Dev build of the library with extra compiler flags into build/variant/ (git-ignored; travels with gpurun), for A/B timing on one
+# box:   tools/build_variant.sh -DLSD_STATS ;  PLI_LIB_PATH=build/variant/libpli_frontend.so python bench.py ...
+set -e
+cd "$(dirname "$0")/.."
+mkdir -p build/variant
+cp pli_slam_amd/csrc/*.hip pli_slam_amd/csrc/*.hpp pli_slam_amd/csrc/Makefile build/variant/
+make -C build/variant -j6 EXTRA="$*" >/dev/null
+ls -la build/variant/libpli_frontend.so
