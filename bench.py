@@ -107,6 +107,9 @@ def kernel_bytes_per_image(name, g, n_kp, n_l, W, H):
         "k_rx_rect": 0,
         "k_rx_count": 0,
         "k_rx_emit": 0,
+        "k_tx_collect": 4 * Pp,                       # key mode: the size plane read once (ids / owners only at the few candidates)
+        "k_tx_emit_sorted": 0,
+        "k_zero_ranges": 8 * Pp,                      # the two stamp planes (+ control blocks, cell tables, counters)
         "k_keylines": 100 * n_l,
         "k_blur_lbd": 2 * P0,
         "k_sobel": P0 + 4 * P0,
