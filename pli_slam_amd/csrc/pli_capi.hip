@@ -37,9 +37,9 @@ inline int cvFloorf(float v) { int i = (int)v; return i - (i > v); }
 // lsd_mode auto: batches of at least this many images (2 per stereo frame) take the sequential wave grower (one wave
 // per image: work-efficient, its throughput keeps growing with the batch); below it the tile-sequential relaxation
 // (lsd_tile.hip: parallel inside an image, ~1.5x the sequential work per frame at large batches).  Measured, 752x480,
-// stereo frames/s: 256 frames 3908 (tile), 768 frames ~4200 (tile) vs 3474 (sequential), 1024 frames 4211 vs 4177,
-// 2048 frames 6057 (sequential).
-constexpr int RX_AUTO_IMAGES = 2048;     // images (2 per stereo frame): measured crossover of the tile relaxation and the sequential waves (1024 frames)
+// stereo frames/s (end of round 3, tile vs sequential): 768 frames 5489 vs 3715, 1024 frames 5440 vs 4584, 1280 frames 5497 vs 5435,
+// 1536 frames 5550 vs 5250, 1792 frames 5557 vs 5702, 2048 frames 5995 (sequential).  (Round 2: crossover at 1024 frames.)
+constexpr int RX_AUTO_IMAGES = 3328;     // images (2 per stereo frame): measured crossover of the tile relaxation and the sequential waves (1664 frames)
 // tiles of 32 for contexts of up to 32 frames of 752x480 (four times the waves where 64-pixel tiles leave the chip under-occupied: a
 // single stereo pair takes 4.6 instead of 7.3 ms with the round-1 code; now, frames/s with 32 vs 64: 16 frames 2228 vs 2066,
 // 32 frames 2930 vs 2777; from 64 frames on the extra border conflicts cost more: 3343 vs 3445, 128 frames 3568 vs 3782)
@@ -100,6 +100,7 @@ struct pli_ctx {
   bool txKeys = false; int txPixBits = 0; int* txCand = nullptr; int* txCandCnt = nullptr;  // ... its key mode (region id = gradient bin | seed pixel: no ordered list)
   int2* txDirtyList = nullptr; int* txDirtyCnt = nullptr;                                  // per tile: the seeds stamped dirty in a round
   std::vector<RxCtl> jrHost;
+  int rxImages = 0;    // images the relaxations' buffers are sized for
   int lsdMode = 0;     // 0 auto, 1 relaxation, 2 sequential, 3 tile-sequential relaxation (cfg.lsd_mode, or PLI_LSD_MODE)
   bool lsdSpec = !(getenv("PLI_LSD_SPEC") != nullptr && atoi(getenv("PLI_LSD_SPEC")) == 0);  // speculative sequential grower (PLI_LSD_SPEC=0: the plain one)
   int rxLastRounds = 0; // rounds the relaxation needed in an earlier call (the last one whose control blocks the host has seen)
@@ -558,7 +559,10 @@ pli_status allocAll(pli_ctx* c) {
     c->lsdMode = m;
   }
   if (c->lsdMode != 2) {     // buffers of the relaxations (in auto mode only batches below RX_AUTO_IMAGES use them)
-    const size_t NR = c->lsdMode == 0 ? std::min<size_t>(NI, RX_AUTO_IMAGES - 1) : NI;
+    // (auto mode: a context sized for the sequential regime keeps the relaxations' buffers — 20-30 MB per image — for 2047 images,
+    // as in round 2, and batches above that take the sequential grower: 2048 frames stay at ~160 GB of HBM instead of 289)
+    const size_t NR = c->lsdMode == 0 ? ((int)NI >= RX_AUTO_IMAGES ? std::min<size_t>(NI, 2047) : NI) : NI;
+    c->rxImages = (int)NR;
     const bool lane = c->lsdMode == 1, tiles = c->lsdMode == 0 || c->lsdMode == 3;
     A(c->own, npix * NR);
     if (lane) {               // lane / lane-group growers of lsd_relax.hip
@@ -588,9 +592,10 @@ pli_status allocAll(pli_ctx* c) {
     // queue overflow blocks for every region of more than TX_GQ pixels that is being grown, by EVERY tile it has seeds in at the
     // same time in round 1: long parallel structures (blinds, corrugated walls; the "stripes" image of the tests) multiply that
     // by the tiles a region crosses.  3 words per pixel sent all 512 stripes images to the sequential grower (455 ms per batch
-    // instead of 50); they need < 16, which is what a context gets as long as its arenas stay below 24 GiB.
+    // instead of 50); they need < 16, which is what a context gets as long as its arenas stay below 8 GiB (256 frames of 752 x 480:
+    // 7.6 GB; the contexts of thousands of images keep 3-4 words).
     size_t arenaFactor = lane ? 8 : 16;
-    if (!lane) arenaFactor = std::max<size_t>(3, std::min<size_t>(16, ((size_t)24 << 30) / (npix * 4 * NR)));
+    if (!lane) arenaFactor = std::max<size_t>(3, std::min<size_t>(16, ((size_t)8 << 30) / (npix * 4 * NR)));
     if (const char* e = getenv("PLI_RX_ARENA")) arenaFactor = (size_t)std::max(1, atoi(e));     // dev: words of arena per scaled pixel
     c->arenaCap = (int)std::min<size_t>(arenaFactor * npix + 65536, (size_t)1 << 30);
     A(c->arena, (size_t)c->arenaCap * NR);
@@ -766,7 +771,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   const DevParams& P = c->hp;
   const pli_table_layout& Y = c->lay;
   const int npix = P.LW * P.LH;
-  const bool sequential = c->lsdMode == 2 || (c->lsdMode == 0 && nimg >= RX_AUTO_IMAGES);
+  const bool sequential = c->lsdMode == 2 || (c->lsdMode == 0 && (nimg >= RX_AUTO_IMAGES || nimg > c->rxImages));
   int2* ownPlane = sequential ? (int2*)nullptr : c->own;
   const int trigF32 = (c->cfg.parity_flags & PLI_PARITY_TRIG_F32_LSD) ? 1 : 0;
   if (c->lsdF64) {
@@ -1370,7 +1375,7 @@ pli_status pli_batch_run(pli_ctx* c, int32_t nframes, const uint8_t* dl, const u
   // kernels wait for it and stretch the grower: 5170 -> 4287, 2048 frames 6067 -> 4942.
   static const int sideMax = getenv("PLI_SIDE_MAX") ? atoi(getenv("PLI_SIDE_MAX")) : INT_MAX;    // (dev: images below which the tile relaxation has the ORB chain beside it)
   static const int sideSeqMax = getenv("PLI_SIDE_SEQ_MAX") ? atoi(getenv("PLI_SIDE_SEQ_MAX")) : 2560;
-  const bool seqGrower = c->lsdMode == 2 || (c->lsdMode == 0 && nimg >= RX_AUTO_IMAGES);
+  const bool seqGrower = c->lsdMode == 2 || (c->lsdMode == 0 && (nimg >= RX_AUTO_IMAGES || nimg > c->rxImages));
   if ((seqGrower ? nimg <= sideSeqMax : nimg < sideMax) && (stages & PLI_RUN_ORB) && (stages & PLI_RUN_LINES) && !c->syncDebug) {
     if (!c->aux) {
       // (the line chain is the longer one: the ORB chain beside it takes what the line kernels leave free)
