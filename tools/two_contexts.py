@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Dev tool (GPU box): throughput of K contexts driven by K host threads, each with F/K frames per step, against one context with F."""
+"""Dev tool (GPU box): throughput of K contexts driven by K host threads, each with F/K frames per step, against one context with F
+(FULL=1 in the environment: every context takes F frames per step — K batches in flight, free running)."""
 import os, sys, time, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -12,7 +13,8 @@ dev = torch.device("cuda", 0)
 pairs = [synth.make_stereo_pair(s, W, H) for s in range(32)]
 imgs = torch.from_numpy(np.stack([np.stack(p) for p in pairs])).to(dev)
 for K in (1, 2, 4):
-    f = F // K
+    full = os.environ.get("FULL") == "1"
+    f = F if full else F // K
     ctxs = []
     for k in range(K):
         fe = Frontend(capi.default_config(W, H, max_frames=f), device=0)
@@ -35,5 +37,6 @@ for K in (1, 2, 4):
     [x.start() for x in th]; [x.join() for x in th]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print("contexts %d x %d frames: %.0f frames/s (%.1f ms per %d frames)" % (K, f, F * steps / dt, dt / steps * 1e3, F), flush=True)
+    tot = f * K
+    print("contexts %d x %d frames: %.0f frames/s (%.1f ms per %d frames)" % (K, f, tot * steps / dt, dt / steps * 1e3 * F / tot, F), flush=True)
     del ctxs
