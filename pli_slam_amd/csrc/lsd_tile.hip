@@ -1350,12 +1350,18 @@ __global__ __launch_bounds__(256) void k_tx_collect(RxCtl* __restrict__ ctl, con
   int* cand = candAll + (int64_t)img * TX_EMIT_CAP;
   if (tid == 0) s_n = 0;
   __syncthreads();
-  for (int64_t p0 = (int64_t)blockIdx.x * 256; p0 < npix; p0 += (int64_t)gridDim.x * 256) {
-    const int64_t p = p0 + tid;
+  for (int64_t p1 = (int64_t)blockIdx.x * 1024; p1 < npix; p1 += (int64_t)gridDim.x * 1024) {
+   // (four rows of 256 pixels per trip: their size loads are in flight together)
+   int sz[4];
+#pragma unroll
+   for (int u = 0; u < 4; ++u) sz[u] = p1 + u * 256 + tid < npix ? rgSizeAll[base + p1 + u * 256 + tid] : 0;
+#pragma unroll
+   for (int u = 0; u < 4; ++u) {
+    const int64_t p = p1 + u * 256 + tid;
     bool e = false;
     int id = TX_INF;
     // (the size first: only the few pixels that are — or, stale, once were — seeds of a large enough region go on to the two other loads)
-    if (p < npix && rgSizeAll[base + p] >= minReg) {
+    if (sz[u] >= minReg) {
       id = idPlaneAll[base + p];
       e = id != TX_INF && ownAll[base + p].x == id;
     }
@@ -1374,6 +1380,7 @@ __global__ __launch_bounds__(256) void k_tx_collect(RxCtl* __restrict__ ctl, con
         }
       }
     }
+   }
   }
   __syncthreads();
   const int n = min(s_n, CAP);

@@ -913,7 +913,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       if (c->txDirtyCnt) add(c->txDirtyCnt + (int64_t)img0 * ntile64, ntile64 * nimg);
       if (c->tailBar) add(c->tailBar, 64);
       if (c->txCandCnt) add(c->txCandCnt + img0, nimg);
-      const int zb = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (npix64 * nimg / 4 + 255) / 256));
+      const int zb = (int)std::max<int64_t>(1, std::min<int64_t>(8192, (npix64 * nimg / 4 + 255) / 256));
       LAUNCH(c, "k_zero_ranges", k_zero_ranges, dim3(zb, zr), dim3(256), 0, Z);
     }
     // (the rank plane was written by k_lsd_scatter)
