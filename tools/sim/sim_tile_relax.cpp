@@ -94,18 +94,27 @@ int main(int argc, char** argv) {
   // ---- truth: sequential ----
   std::vector<int> truth(N, INT32_MAX);
   std::vector<int> reg;
-  long tests = 0, regions = 0, bigRegions = 0, bigPix = 0, accepts = 0;
+  long tests = 0, regions = 0, bigRegions = 0, bigPix = 0, accepts = 0, aloneByAngle = 0;
   std::map<int, int> sizeHist;
   for (int r = 0; r < R; ++r) {
     if (truth[F.order[r]] != INT32_MAX) continue;
     grow(F, r, [&](int q) { return truth[q] != INT32_MAX; }, [&](int q) { truth[q] = r; }, reg, tests);
     ++regions;
+    if (reg.size() == 1) {                         // (how many of the one-pixel regions are alone by ANGLE: no neighbour aligned with the seed, used or not)
+      const int sp = F.order[r], px = sp % W, py = sp / W;
+      bool alone = true;
+      for (int yy = std::max(py - 1, 0); yy <= std::min(py + 1, H - 1); ++yy)
+        for (int xx = std::max(px - 1, 0); xx <= std::min(px + 1, W - 1); ++xx)
+          if (yy * W + xx != sp && aligned(F, yy * W + xx, F.ang[sp])) alone = false;
+      aloneByAngle += alone;
+    }
     accepts += (long)reg.size();
     sizeHist[std::min((int)reg.size(), 32)]++;
     if ((int)reg.size() >= F.minReg) { ++bigRegions; bigPix += (long)reg.size(); }
   }
   std::printf("sequential: %ld regions (%ld >= minReg holding %ld px), %ld pixels, %ld neighbour tests\n", regions, bigRegions, bigPix,
               accepts, tests);
+  std::printf("one-pixel regions alone by angle (no neighbour aligned with the seed's own angle): %ld\n", aloneByAngle);
   std::printf("size histogram (size:count, 32 = 32+):");
   for (auto& kv : sizeHist) std::printf(" %d:%d", kv.first, kv.second);
   std::printf("\n");
