@@ -904,7 +904,13 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       static_assert(sizeof(RxCtl) % 4 == 0, "RxCtl is cleared as words");
       ZeroRanges Z{};
       int zr = 0;
-      auto add = [&](void* p, int64_t words) { if (p && words > 0) { Z.p[zr] = (uint32_t*)p; Z.words[zr] = words; ++zr; } };
+      constexpr int zmax = (int)(sizeof(Z.p) / sizeof(Z.p[0]));
+      bool zfull = false;
+      auto add = [&](void* p, int64_t words) {
+        if (!p || words <= 0) return;
+        if (zr == zmax) { zfull = true; return; }
+        Z.p[zr] = (uint32_t*)p; Z.words[zr] = words; ++zr;
+      };
       add(c->jrCtl + img0, (int64_t)(sizeof(RxCtl) / 4) * nimg);
       add(c->rgDirty + (int64_t)img0 * npix, npix64 * nimg);
       if (lostRule) add(c->rgLost + (int64_t)img0 * npix, npix64 * nimg);
@@ -913,6 +919,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       if (c->txDirtyCnt) add(c->txDirtyCnt + (int64_t)img0 * ntile64, ntile64 * nimg);
       if (c->tailBar) add(c->tailBar, 64);
       if (c->txCandCnt) add(c->txCandCnt + img0, nimg);
+      if (zfull) { g_err = "k_zero_ranges: more buffers than ZeroRanges holds"; return PLI_ERR_INVALID; }
       const int zb = (int)std::max<int64_t>(1, std::min<int64_t>(8192, (npix64 * nimg / 4 + 255) / 256));
       LAUNCH(c, "k_zero_ranges", k_zero_ranges, dim3(zb, zr), dim3(256), 0, Z);
     }
