@@ -592,7 +592,12 @@ def main():
                 "path_achieved": fps / world * b_frame / 1e9, "path_frac": fps / world * b_frame / 1e9 / peak,
                 "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in
                                        sorted(prof.items(), key=lambda kv: -kv[1][1])},
-                "kernel_hbm_frac": dict(sorted(kfrac.items(), key=lambda kv: -kv[1]))}
+                "kernel_hbm_frac": dict(sorted(kfrac.items(), key=lambda kv: -kv[1])),
+                "kernel_ms_note": "HIP-event time between the launch's two events on the stream it ran on, summed per step.  The ORB chain ("
+                                  + ", ".join(orb_chain) + ") runs on a low-priority side stream beside the line chain: its times include "
+                                  "the wait for wave slots (alone, PLI_SIDE_MAX=0: k_resize_level 0.7 ms, k_fast_cells 3.4, k_octree 1.7 at 256 "
+                                  "frames), and the line chain's kernels are stretched by it (alone: k_tx_round2 1.7 ms, k_tx_diffmark 2.3); "
+                                  "DESIGN.md 5 has the table of every kernel alone"}
         what = C_["what"] if args.config else ("752x480 stereo pairs, extract + stereo Hamming match (BASELINE configs[1] shape, "
                                                "batched)")
         out = {
