@@ -135,13 +135,21 @@ int main(int argc, char** argv) {
       std::vector<int> mine(N, INT32_MAX);      // claims visible inside the running tile-wave (reset per tile via list)
       std::vector<int> touched;
       std::vector<char> doneRank;               // rule B: rank already processed this round by the running tile
+      // SIM_PHASES=K: round 1 in K phases by rank (quantiles of the ordered list), a grid-wide barrier between them: a phase sees every
+      // claim of the earlier phases (vis), whatever tile made it
+      const int K = (t == 1 && getenv("SIM_PHASES")) ? std::max(1, atoi(getenv("SIM_PHASES"))) : 1;
+      std::vector<int> vis(N, INT32_MAX);
+      for (int ph = 0; ph < K; ++ph) {
+      const int rLo = (int)((long)R * ph / K), rHi = (int)((long)R * (ph + 1) / K);
       for (int T = 0; T < NT; ++T) {
         touched.clear();
         const std::vector<int>& S = tileSeeds[T];
         const int tx0 = (T % TW) * TS, ty0 = (T / TW) * TS;
         for (int r : S) {
+          if (r < rLo || r >= rHi) continue;
           const int sp = F.order[r];
           auto used = [&](int q) {
+            if (vis[q] < r) return true;                     // claimed in an earlier phase of this round by a lower rank
             if (mine[q] <= r) return true;                   // claimed earlier this round by this tile-wave (lower rank)
             const int po = prev[q];
             if (po < r) {
@@ -162,6 +170,8 @@ int main(int argc, char** argv) {
           acc += (long)reg.size();
         }
         for (int q : touched) { cur[q] = std::min(cur[q], mine[q]); mine[q] = INT32_MAX; }
+      }
+      if (K > 1) vis = cur;
       }
       long changed = 0, wrong = 0;
       std::vector<char> tileChanged(NT, 0);
