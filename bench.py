@@ -660,7 +660,7 @@ def main():
                 rc = 3
             if not args.no_large_batch_leg and not args.config and (W, H) == (752, 480) and F < LARGE_BATCH:
                 # the same path at the batch size where the throughput of one GPU levels off (the sequential LSD schedule takes
-                # over above 1664 frames per call; ~190 GB of the 288 GB HBM): informational, never the headline value
+                # over above 1280 frames per call; ~236 GB of the 288 GB HBM): informational, never the headline value
                 try:
                     del fe
                     out["large_batch"] = large_batch_leg(capi, Frontend, nfeat, nlines, args.lsd_mode, local_rank, d_uniq, nuniq, W, H)

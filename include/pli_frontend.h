@@ -114,7 +114,7 @@ typedef struct pli_frontend_config {
   double  min_disp;           /* 1.0                                                       */
   double  line_horiz_th;      /* 0.1                                                       */
   /* execution strategy of the LSD region grower (results are identical):
-     0 = auto (by batch size: 3 below 1664 frames per call, 2 from there on — pli_capi.hip: RX_AUTO_IMAGES, a measured crossover; a context created for 1664 frames or more keeps the buffers of mode 3 for 1023 frames only),
+     0 = auto (by batch size: 3 below 1280 frames per call, 2 from there on — pli_capi.hip: RX_AUTO_IMAGES, a measured crossover; a context created for 1280 frames or more keeps the buffers of mode 3 for 1023 frames only),
      1 = rank-ordered relaxation, one region per lane / lane group (lsd_relax.hip),
      2 = sequential, one wave per image (line_kernels.hip: k_lsd_grow),
      3 = tile-sequential relaxation, one wave per 64x64 tile (lsd_tile.hip) */

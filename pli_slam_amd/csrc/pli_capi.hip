@@ -39,7 +39,9 @@ inline int cvFloorf(float v) { int i = (int)v; return i - (i > v); }
 // (lsd_tile.hip: parallel inside an image, ~1.5x the sequential work per frame at large batches).  Measured, 752x480,
 // stereo frames/s (end of round 3, tile vs sequential): 768 frames 5489 vs 3715, 1024 frames 5440 vs 4584, 1280 frames 5497 vs 5435,
 // 1536 frames 5550 vs 5250, 1792 frames 5557 vs 5702, 2048 frames 5995 (sequential).  (Round 2: crossover at 1024 frames.)
-constexpr int RX_AUTO_IMAGES = 3328;     // images (2 per stereo frame): measured crossover of the tile relaxation and the sequential waves (1664 frames)
+// The hand-over is put at 1280 frames, where the two are level: the relaxations' buffers cost 25 MB per image, and a context of
+// 1600 frames with them would take 250 of the 288 GB.
+constexpr int RX_AUTO_IMAGES = 2560;     // images (2 per stereo frame): 1280 frames
 // tiles of 32 for contexts of up to 32 frames of 752x480 (four times the waves where 64-pixel tiles leave the chip under-occupied: a
 // single stereo pair takes 4.6 instead of 7.3 ms with the round-1 code; now, frames/s with 32 vs 64: 16 frames 2228 vs 2066,
 // 32 frames 2930 vs 2777; from 64 frames on the extra border conflicts cost more: 3343 vs 3445, 128 frames 3568 vs 3782)
