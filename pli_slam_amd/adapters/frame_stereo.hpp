@@ -55,7 +55,9 @@ inline void ComputeStereoMatches(FrameT& F) {
   checkCount("N", (long)F.N, cnt[0]);
   // minZ = mb, maxD = mbf / minZ (:1005-1008): mb = mbf / fx is assigned after this call in the constructor (:197), so the
   // intended value is taken from the calibration the Frame carries: fx = mK(0,0)
-  fe->setStereoCamera(F.mbf, F.mK.template at<float>(0, 0));
+  // (through the extractor's group: every context of the group, present and future, takes the rig; a fused Frame that
+  // pli_frame_extract matched with another rig is matched again here, on its resident tables)
+  F.mpORBextractorLeft->pliSetStereoCamera(F.mbf, F.mK.template at<float>(0, 0));
   std::vector<float> ur, depth;
   fe->computeStereoMatches(ur, depth);
   for (int i = 0; i < F.N; ++i) { F.mvuRight[i] = ur[i]; F.mvDepth[i] = depth[i]; }

@@ -22,6 +22,7 @@
 #error "orbslam_adapters.hpp needs OpenCV 3 (it is meant to be compiled inside the PLI-SLAM tree)"
 #endif
 #include <opencv2/core/core.hpp>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -62,61 +63,93 @@ struct LineParams {
 // Frame fusion.  Frame::Frame calls the four extractors of a group from four threads at the same time (Frame.cc:128-135).  When all
 // four calls of a frame are in flight together they are funnelled into ONE submission (pli_frame_extract: both eyes, points and
 // lines, and the two stereo matchers on top), and every thread takes its part from the frame's record: 2.7 ms per Frame instead of
-// 6.5 ms for four calls that queue behind the context's lock.  A call that finds itself alone for kWait (an integrator that calls
-// the extractors one after the other) switches the fusion off for this group for good and every call takes the per-call path —
-// the results are the same bytes either way (tests/test_cpp_dropin.py compares the two).
+// 6.5 ms for four calls that queue behind the context's lock.  The results are the same bytes either way
+// (tests/test_cpp_dropin.py compares the two).
+//
+// A call that waits kWaitMs without its three partners withdraws and takes the per-call path — ONE frame is unfused, the next frame
+// tries again (a late thread on a host busy with LocalMapping / LoopClosing / the viewer must not cost every later Frame the fused
+// path).  Only kMaxMisses timeouts in a row — an integrator that calls the extractors one after the other — put the fusion to sleep,
+// and then for kCoolOff calls only, after which one call probes again (2 ms once every 32 frames).  The four calls of a Frame must
+// agree: the line extractors must be given the images (pointer, stride, size) the ORB extractors of the same eye were given, as
+// Frame.cc:128-135 does; if they differ (a ROI, a preprocessed copy) nobody is fused and every caller extracts from ITS image.
+// stats(): how many Frames went which way.
 struct FrameFusion {
   static constexpr int kOrbL = 0, kOrbR = 1, kLineL = 2, kLineR = 3;
+  static constexpr int kWaitMs = 2, kMaxMisses = 8, kCoolOff = 128;
+  struct Stats { uint64_t fused = 0, unfusedCalls = 0, timeouts = 0, mismatched = 0, sleeps = 0; };
   std::mutex m;
   std::condition_variable cv;
-  bool enabled = true;
   int arrived = 0;
-  uint64_t gen = 0;                          // frames fused so far
+  int misses = 0;                            // timeouts since the last fused frame
+  int asleep = 0;                            // calls left to skip before the next probe
+  uint64_t gen = 0;                          // frames collected so far (fused or released)
+  bool lastFused = false;                    // outcome of generation gen - 1
   const uint8_t* img[4] = {nullptr, nullptr, nullptr, nullptr};
   int64_t stride[4] = {0, 0, 0, 0};
+  int iw[4] = {0, 0, 0, 0}, ih[4] = {0, 0, 0, 0};
   std::vector<uint8_t> record;               // table record of the last fused frame (pli_table_layout)
   std::exception_ptr error;                  // what the fused submission threw (every caller of that frame rethrows it)
+  Stats st;
+
+  Stats stats() { std::lock_guard<std::mutex> lk(m); return st; }
 
   // true: the frame was extracted in one submission and `record` holds it; false: take the per-call path
   bool join(int kind, pli::Frontend& fe, const uint8_t* data, int w, int h, int64_t strideBytes) {
     std::unique_lock<std::mutex> lk(m);
-    if (!enabled || img[kind] != nullptr) return false;     // (a second call of the same kind while a frame is collecting: not a Frame)
-    img[kind] = data; stride[kind] = strideBytes;
+    if (asleep > 0) { --asleep; ++st.unfusedCalls; return false; }
+    if (img[kind] != nullptr) { ++st.unfusedCalls; return false; }     // (a second call of the same kind while a frame is collecting: not a Frame)
+    img[kind] = data; stride[kind] = strideBytes; iw[kind] = w; ih[kind] = h;
     const uint64_t myGen = gen;
     if (++arrived == 4) {
       error = nullptr;
-      try {
-        fe.frameExtract(img[kOrbL], img[kOrbR], w, h, stride[kOrbL], stride[kOrbR], record);
-      } catch (...) {
-        error = std::current_exception();
+      const bool agree = img[kLineL] == img[kOrbL] && img[kLineR] == img[kOrbR] && stride[kLineL] == stride[kOrbL] &&
+                         stride[kLineR] == stride[kOrbR] && iw[kOrbL] == iw[kOrbR] && ih[kOrbL] == ih[kOrbR] &&
+                         iw[kLineL] == iw[kOrbL] && ih[kLineL] == ih[kOrbL] && iw[kLineR] == iw[kOrbL] && ih[kLineR] == ih[kOrbL];
+      if (agree) {
+        try {
+          fe.frameExtract(img[kOrbL], img[kOrbR], iw[kOrbL], ih[kOrbL], stride[kOrbL], stride[kOrbR], record);
+        } catch (...) {
+          error = std::current_exception();
+        }
+        ++st.fused;
+        misses = 0;
+      } else {
+        ++st.mismatched;
+        st.unfusedCalls += 4;
       }
+      lastFused = agree;
       arrived = 0;
       for (int k = 0; k < 4; ++k) img[k] = nullptr;
       ++gen;
       cv.notify_all();
     } else if (!cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::milliseconds(kWaitMs), [&] { return gen != myGen; })) {
       // (system_clock: pthread_cond_timedwait, which gcc 11's ThreadSanitizer intercepts; the steady-clock wait is pthread_cond_clockwait)
-      img[kind] = nullptr;                   // nobody else came: withdraw, and do not wait again
+      img[kind] = nullptr;                   // the partners did not come in time: withdraw, this call goes alone
       --arrived;
-      enabled = false;
+      ++st.timeouts; ++st.unfusedCalls;
+      if (++misses >= kMaxMisses) { misses = 0; asleep = kCoolOff; ++st.sleeps; }
       return false;
     }
+    // (one Frame at a time per group: generation myGen's outcome is read before generation myGen + 1 can complete, because that
+    // needs this thread's next call)
+    if (!lastFused) return false;
     if (error) std::rethrow_exception(error);
     return true;
   }
-  static constexpr int kWaitMs = 2;
 };
 
 // One group = the extractors of one Frame constructor: ORB left/right + LSD left/right on one device context per image size.
-// orbMask / lineMask: which eye slots (bit 0 = left, bit 1 = right) are held by a living extractor.
+// orbMask / lineMask: which eye slots (bit 0 = left, bit 1 = right) are held by a living extractor (atomics: operator() reads
+// them while pliBind / a destructor may write them under the registry's lock).
 struct Group {
   bool hasOrb = false, hasLine = false;
   OrbParams orb{};
   LineParams line{};
-  int orbMask = 0, lineMask = 0;
+  std::atomic<int> orbMask{0}, lineMask{0};
   FrameFusion fusion;
   std::mutex mu;
   std::map<std::pair<int, int>, std::shared_ptr<pli::Frontend>> ctx;     // by image size
+  float rigBf = 0.f, rigFx = 0.f;            // the stereo rig (mbf, fx), once a Frame or pliSetStereoCamera has named it
 
   std::shared_ptr<pli::Frontend> context(int w, int h) {
     std::lock_guard<std::mutex> lk(mu);
@@ -124,6 +157,7 @@ struct Group {
     if (it != ctx.end()) return it->second;
     pli_frontend_config c;
     pli_config_default(&c, w, h);
+    if (rigBf > 0 && rigFx > 0) { c.bf = rigBf; c.fx = rigFx; }
     if (hasOrb) {
       c.orb_nfeatures = orb.nfeatures; c.orb_scale_factor = orb.scaleFactor; c.orb_nlevels = orb.nlevels;
       c.orb_ini_th_fast = orb.iniThFAST; c.orb_min_th_fast = orb.minThFAST;
@@ -139,6 +173,16 @@ struct Group {
     ctx[{w, h}] = fe;
     return fe;
   }
+  // The rig Frame::ComputeStereoMatches works with (mbf, fx = mK(0,0); Frame.cc:1005-1008).  The extractors' constructors do not
+  // know it (Tracking.cc:743-746), so a context starts with pli_config_default's EuRoC rig until the first Frame names its own:
+  // every context of the group — existing and future — takes it; a fused Frame that was matched with the old rig is matched
+  // again on its resident tables by the next ComputeStereoMatches (pli_set_stereo_camera drops the cached result).
+  void setRig(float bf, float fx) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (bf == rigBf && fx == rigFx) return;
+    rigBf = bf; rigFx = fx;
+    for (auto& kv : ctx) kv.second->setStereoCamera(bf, fx);
+  }
 };
 
 inline int freeEye(int mask) { return (mask & 1) ? 1 : 0; }
@@ -151,7 +195,7 @@ struct Registry {
   std::shared_ptr<Group> joinOrb(const OrbParams& p, int& eye) {
     std::lock_guard<std::mutex> lk(mu);
     for (auto& g : groups)
-      if (g->hasOrb && g->orb == p && g->orbMask != 3) { eye = freeEye(g->orbMask); g->orbMask |= 1 << eye; return g; }
+      if (g->hasOrb && g->orb == p && g->orbMask.load() != 3) { eye = freeEye(g->orbMask.load()); g->orbMask |= 1 << eye; return g; }
     for (auto& g : groups)
       if (!g->hasOrb) { g->hasOrb = true; g->orb = p; eye = 0; g->orbMask = 1; return g; }
     groups.push_back(std::make_shared<Group>());
@@ -162,7 +206,7 @@ struct Registry {
   std::shared_ptr<Group> joinLine(const LineParams& p, int& eye) {
     std::lock_guard<std::mutex> lk(mu);
     for (auto& g : groups)
-      if (g->hasLine && g->line == p && g->lineMask != 3) { eye = freeEye(g->lineMask); g->lineMask |= 1 << eye; return g; }
+      if (g->hasLine && g->line == p && g->lineMask.load() != 3) { eye = freeEye(g->lineMask.load()); g->lineMask |= 1 << eye; return g; }
     for (auto& g : groups)
       if (!g->hasLine) { g->hasLine = true; g->line = p; eye = 0; g->lineMask = 1; return g; }
     groups.push_back(std::make_shared<Group>());
@@ -176,9 +220,9 @@ struct Registry {
   void leave(const std::shared_ptr<Group>& g, bool isOrb, int eye) {
     if (!g) return;
     std::lock_guard<std::mutex> lk(mu);
-    if (isOrb) { g->orbMask &= ~(1 << eye); if (!g->orbMask) g->hasOrb = false; }
-    else { g->lineMask &= ~(1 << eye); if (!g->lineMask) g->hasLine = false; }
-    if (!g->orbMask && !g->lineMask)
+    if (isOrb) { g->orbMask &= ~(1 << eye); if (!g->orbMask.load()) g->hasOrb = false; }
+    else { g->lineMask &= ~(1 << eye); if (!g->lineMask.load()) g->hasLine = false; }
+    if (!g->orbMask.load() && !g->lineMask.load())
       for (size_t i = 0; i < groups.size(); ++i)
         if (groups[i] == g) { groups.erase(groups.begin() + i); break; }
   }
@@ -239,7 +283,7 @@ class ORBextractor {
     std::vector<pli_keypoint> kps;
     std::vector<uint8_t> desc;
     int n;
-    if (group_->orbMask == 3 && group_->lineMask == 3 &&
+    if (group_->orbMask.load() == 3 && group_->lineMask.load() == 3 &&
         group_->fusion.join(eye_ ? pli_detail::FrameFusion::kOrbR : pli_detail::FrameFusion::kOrbL, *fe, image.data, image.cols, image.rows,
                             (int64_t)image.step)) {
       // the frame's record: counts, then this eye's keypoint table and descriptors
@@ -297,6 +341,12 @@ class ORBextractor {
   // (not in the reference) the shared device context for an image size: Frame's stereo matchers run on it
   std::shared_ptr<pli::Frontend> pliContext(int w, int h) { return group_->context(w, h); }
   int pliEye() const { return eye_; }
+  // (not in the reference) the rig of the Frames this extractor serves: mbf and fx (Frame.cc:1005-1008).  Frame::ComputeStereoMatches
+  // (adapters/frame_stereo.hpp) calls it for every Frame; an integrator may call it once after reading the calibration
+  // (Tracking.cc:620-640) so that even the first fused Frame is matched with the right rig in its one submission.
+  void pliSetStereoCamera(float bf, float fx) { group_->setRig(bf, fx); }
+  // (not in the reference) Frames fused / calls that went alone / timeouts / mismatched frames / sleeps of this extractor's group
+  pli_detail::FrameFusion::Stats pliFusionStats() { return group_->fusion.stats(); }
 
  protected:
   int nfeatures;
@@ -336,7 +386,7 @@ class Lineextractor {
     std::shared_ptr<pli::Frontend> fe = group_->context(image.cols, image.rows);
     std::vector<pli_keyline> kls;
     std::vector<uint8_t> desc;
-    if (group_->orbMask == 3 && group_->lineMask == 3 &&
+    if (group_->orbMask.load() == 3 && group_->lineMask.load() == 3 &&
         group_->fusion.join(eye_ ? pli_detail::FrameFusion::kLineR : pli_detail::FrameFusion::kLineL, *fe, image.data, image.cols, image.rows,
                             (int64_t)image.step)) {
       const pli_table_layout& Y = fe->layout();

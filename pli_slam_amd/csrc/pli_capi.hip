@@ -141,6 +141,8 @@ struct pli_ctx {
   bool orbDone[2] = {false, false}, lineDone[2] = {false, false};
   bool frameFresh = false;                   // ownTable / hostRec hold the COMPLETE record of one Frame (pli_frame_extract): the stereo
                                              // matchers hand it out without running again; any per-call extraction ends that
+  bool pointsFresh = false;                  // ... and its mvuRight / mvDepth were computed with the CURRENT rig (pli_set_stereo_camera
+                                             // clears it: the point matcher then re-runs on the resident tables)
   uint8_t* recPinned = nullptr;              // pinned staging of that record
   uint8_t* pyrHost[2] = {nullptr, nullptr};  // pinned copy of an eye's pyramid block (pli_orb_pyramid_level)
   bool pyrHostValid[2] = {false, false};     // ... is the one of the last extraction on that eye
@@ -997,7 +999,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
           // with the control blocks)
           TxTailArgs ta{c->dP, c->jrCtl, c->rec, c->own, c->txList, c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty,
                         c->tileAct, c->tileTouch, c->tilesW, c->tilesH, c->arena, c->arenaCap, c->rects, c->rectCap, c->rgSeg, c->mg,
-                        c->rankOf, c->rgLost, DL, img0, nimg, t, 96, c->tailBar};
+                        c->rankOf, c->rgLost, DL, img0, nimg, t, maxRounds, c->tailBar};
           // (a grid barrier costs 8 us with 256 workgroups and less with fewer: a few images do not need the whole chip in the late rounds)
           // (single pair: k_tx_tail 149 us with 256 workgroups, 90 with 64)
           int tb = std::min(c->tailBlocks, std::max(64, 8 * nimg));
@@ -1375,6 +1377,10 @@ pli_status pli_batch_run(pli_ctx* c, int32_t nframes, const uint8_t* dl, const u
   uint8_t* T = (uint8_t*)table;
   pli_status st;
   const int nimg = 2 * nframes;
+  // a batch overwrites the pyramids and tables of images 0/1: whatever the per-call entry points cached about the last Frame
+  // on this context is gone (pli_frame_extract, which calls this, sets its own state afterwards)
+  c->frameFresh = c->pointsFresh = false;
+  for (int e = 0; e < 2; ++e) { c->orbDone[e] = c->lineDone[e] = false; c->pyrHostValid[e] = false; }
   if ((st = runIngest(c, dl, dr, stride, frameStride, 0, nimg)) != PLI_OK) return st;
   bool stereoPointsDone = false;
   // The ORB chain runs beside the line chain (fork after the ingest, join before the stereo matchers) except under the
@@ -1497,6 +1503,7 @@ pli_status pli_frame_extract(pli_ctx* c, const uint8_t* left, const uint8_t* rig
   if (flags[0] || flags[1]) { g_err = "more segments pass the length cut than max_lines holds: raise pli_frontend_config.max_lines"; return PLI_ERR_CAPACITY; }
   if (flags[2] || flags[3]) { g_err = "more keypoints than kp_cap holds"; return PLI_ERR_CAPACITY; }
   c->frameFresh = true;
+  c->pointsFresh = true;
   return PLI_OK;
 }
 
@@ -1681,6 +1688,8 @@ pli_status pli_set_stereo_camera(pli_ctx* c, float bf, float fx) {
   HIPCHK(hipStreamSynchronize(c->stream));           // kernels in flight read the old parameter block
   if (c->aux) HIPCHK(hipStreamSynchronize(c->aux));
   c->cfg.bf = bf; c->cfg.fx = fx;
+  c->pointsFresh = false;                            // a fused Frame's cached mvuRight / mvDepth belong to the old rig (Frame.cc:1005-1008,
+                                                     // 1131: maxD and bf / disparity); the line matcher does not read the rig
   c->hp.bf = bf;
   c->hp.maxD = c->cfg.stereo_maxd_inf ? std::numeric_limits<float>::infinity() : bf / (bf / fx);
   HIPCHK(hipMemcpy(c->dP, &c->hp, sizeof(DevParams), hipMemcpyHostToDevice));
@@ -1701,7 +1710,7 @@ pli_status pli_stereo_match_points(pli_ctx* c, float* uright, float* depth, int3
   CtxGuard guard__(c);
   if (!c) return PLI_ERR_INVALID;
   if (!c->orbDone[0] || !c->orbDone[1]) { g_err = "pli_orb_extract must run for both eyes first"; return PLI_ERR_STATE; }
-  if (c->frameFresh) {                                  // (pli_frame_extract has matched already)
+  if (c->frameFresh && c->pointsFresh) {                // (pli_frame_extract has matched already, with this rig)
     const pli_table_layout& Yf = c->lay;
     const int Nf = c->orbCount[0];
     if (Nf > cap) { g_err = "output buffer too small"; return PLI_ERR_CAPACITY; }
@@ -1717,6 +1726,11 @@ pli_status pli_stereo_match_points(pli_ctx* c, float* uright, float* depth, int3
   HIPCHK(hipMemcpyAsync(counts, c->ownTable + Y.off_counts, sizeof(counts), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   const int N = counts[0];
+  if (c->frameFresh && N > 0) {                         // the Frame's cached record follows the rig it was re-matched with
+    HIPCHK(hipMemcpy(c->hostRec.data() + Y.off_uright, c->ownTable + Y.off_uright, (size_t)N * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(c->hostRec.data() + Y.off_depth, c->ownTable + Y.off_depth, (size_t)N * 4, hipMemcpyDeviceToHost));
+  }
+  c->pointsFresh = c->frameFresh;
   if (N > cap) { g_err = "output buffer too small"; return PLI_ERR_CAPACITY; }
   if (N > 0) {
     if (uright) HIPCHK(hipMemcpy(uright, c->ownTable + Y.off_uright, (size_t)N * 4, hipMemcpyDeviceToHost));

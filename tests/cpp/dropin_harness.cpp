@@ -13,7 +13,11 @@
 // the arrays byte for byte with the oracle and with the ctypes path, the four-thread run with the sequential one, and
 // the repetitions with each other.
 //
-//   usage: dropin_harness <in> <out>      in: "PLIH" i32 W H nframes reps mode(1 = four threads) nfeatures nlines | images
+//   usage: dropin_harness <in> <out>
+//   in: "PLIH" i32 W H nframes reps mode(0 = four calls in a row, 1 = four threads, 2 = four threads, line extractors on copies of the images) nfeatures nlines rigChangeFrame(-1: never) delayFrame(-1: never) delayMs
+//       | f32 rig A: fx fy cx cy bf | f32 rig B (Frames from rigChangeFrame on) | images
+//   delayFrame: on that Frame (every repetition) the thread of the right line extractor starts delayMs late — a loaded host
+//   (VERDICT r3 item 7): that Frame goes unfused, the next ones must fuse again.
 #define PLI_ADAPTER_NO_KEYLINE_HEADER
 #define PLI_ADAPTER_KEYLINE_TYPE cv::line_descriptor::KeyLine
 #include <opencv2/core/core.hpp>
@@ -53,15 +57,21 @@ struct MapPoint {                      // the three MapPoint methods SearchByPro
 class Frame {
  public:
   Frame(const cv::Mat& imLeft, const cv::Mat& imRight, ORBextractor* extractorLeft, ORBextractor* extractorRight,
-        Lineextractor* LineextractorLeft, Lineextractor* LineextractorRight, cv::Mat& K, const float& bf, bool fourThreads)
+        Lineextractor* LineextractorLeft, Lineextractor* LineextractorRight, cv::Mat& K, const float& bf, bool fourThreads, int lateMs = 0, bool cloneLineImages = false)
       : mpORBextractorLeft(extractorLeft), mpORBextractorRight(extractorRight), mpLineextractorLeft(LineextractorLeft),
         mpLineextractorRight(LineextractorRight), mK(K.clone()), mbf(bf) {
     mvScaleFactors = mpORBextractorLeft->GetScaleFactors();            // :117-123
     if (fourThreads) {                                                  // :128-135
       std::thread threadLeft(&Frame::ExtractORB, this, 0, imLeft, 0, 0);
       std::thread threadRight(&Frame::ExtractORB, this, 1, imRight, 0, 0);
-      std::thread threadLeft_Line(&Frame::ExtractLine, this, 0, imLeft);
-      std::thread threadRight_Line(&Frame::ExtractLine, this, 1, imRight);
+      // (cloneLineImages: an integrator that hands the line extractors its own copies — the four calls are not ONE Frame's
+      // images any more and must not be fused onto the ORB extractors' images)
+      const cv::Mat lineLeft = cloneLineImages ? imLeft.clone() : imLeft, lineRight = cloneLineImages ? imRight.clone() : imRight;
+      std::thread threadLeft_Line(&Frame::ExtractLine, this, 0, lineLeft);
+      std::thread threadRight_Line([this, &lineRight, lateMs] {
+        if (lateMs > 0) std::this_thread::sleep_for(std::chrono::milliseconds(lateMs));
+        ExtractLine(1, lineRight);
+      });
       threadLeft.join();
       threadRight.join();
       threadLeft_Line.join();
@@ -229,9 +239,14 @@ int main(int argc, char** argv) {
   FILE* in = std::fopen(argv[1], "rb");
   if (!in) { std::perror(argv[1]); return 2; }
   char magic[4];
-  int32_t hd[7];
-  if (std::fread(magic, 1, 4, in) != 4 || std::memcmp(magic, "PLIH", 4) || std::fread(hd, 4, 7, in) != 7) { std::fprintf(stderr, "bad input header\n"); return 2; }
+  int32_t hd[10];
+  float rigs[10];
+  if (std::fread(magic, 1, 4, in) != 4 || std::memcmp(magic, "PLIH", 4) || std::fread(hd, 4, 10, in) != 10 || std::fread(rigs, 4, 10, in) != 10) {
+    std::fprintf(stderr, "bad input header\n");
+    return 2;
+  }
   const int W = hd[0], H = hd[1], nframes = hd[2], reps = hd[3], mode = hd[4], nFeatures = hd[5], lsdNFeatures = hd[6];
+  const int rigChangeFrame = hd[7], delayFrame = hd[8], delayMs = hd[9];
   std::vector<cv::Mat> imgs((size_t)nframes * 2);
   for (auto& m : imgs) {
     m.create(H, W, CV_8UC1);
@@ -245,10 +260,15 @@ int main(int argc, char** argv) {
     ORBextractor* mpORBextractorRight = new ORBextractor(nFeatures, 1.2f, 8, 20, 7);
     Lineextractor* mpLineextractorLeft = new Lineextractor(lsdNFeatures, 0.025, 0, 1.2, 0.6, 2.0, 22.5, 1.0, 0.6, 1024, false);
     Lineextractor* mpLineextractorRight = new Lineextractor(lsdNFeatures, 0.025, 0, 1.2, 0.6, 2.0, 22.5, 1.0, 0.6, 1024, false);
-    cv::Mat K = cv::Mat::eye(3, 3, CV_32F);
-    K.at<float>(0, 0) = 435.2046959714599f; K.at<float>(1, 1) = 435.2046959714599f;
-    K.at<float>(0, 2) = 367.4517211914062f; K.at<float>(1, 2) = 252.2008514404297f;
-    const float bf = 47.90639384423901f;
+    // the calibration Tracking::ParseCamParamFile reads (Tracking.cc:520-640): K and mbf, one per rig of the input
+    cv::Mat Ks[2];
+    float bfs[2];
+    for (int r = 0; r < 2; ++r) {
+      Ks[r] = cv::Mat::eye(3, 3, CV_32F);
+      Ks[r].at<float>(0, 0) = rigs[5 * r]; Ks[r].at<float>(1, 1) = rigs[5 * r + 1];
+      Ks[r].at<float>(0, 2) = rigs[5 * r + 2]; Ks[r].at<float>(1, 2) = rigs[5 * r + 3];
+      bfs[r] = rigs[5 * r + 4];
+    }
 
     Dump out(argv[2]);
     if (!out.f) { std::perror(argv[2]); return 2; }
@@ -263,8 +283,10 @@ int main(int argc, char** argv) {
       std::vector<std::unique_ptr<MapPoint>> lastPoints;
       for (int i = 0; i < nframes; ++i) {
         const auto tFrame0 = std::chrono::steady_clock::now();
+        const int rig = rigChangeFrame >= 0 && i >= rigChangeFrame ? 1 : 0;
+        cv::Mat& K = Ks[rig];
         std::unique_ptr<Frame> cur(new Frame(imgs[2 * i], imgs[2 * i + 1], mpORBextractorLeft, mpORBextractorRight, mpLineextractorLeft,
-                                             mpLineextractorRight, K, bf, mode == 1));
+                                             mpLineextractorRight, K, bfs[rig], mode >= 1, i == delayFrame ? delayMs : 0, mode == 2));
         if (rep > 0 || i >= 2) { frameSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tFrame0).count(); ++framesTimed; }
         Dump* o = rep == 0 ? &out : nullptr;
         const std::string pre = "f" + std::to_string(i) + "/";
@@ -342,13 +364,20 @@ int main(int argc, char** argv) {
     out.put("hashes", 'Q', (int)hashes.size(), 1, hashes.data());
     const double msPerFrame = framesTimed ? frameSeconds / framesTimed * 1e3 : 0.0;
     out.put("frame_ms", 'd', 1, 1, &msPerFrame);
+    {
+      const pli_detail::FrameFusion::Stats fs = mpORBextractorLeft->pliFusionStats();
+      const uint64_t v[5] = {fs.fused, fs.unfusedCalls, fs.timeouts, fs.mismatched, fs.sleeps};
+      out.put("fusion_stats", 'Q', 1, 5, v);
+      std::printf("dropin_harness: fusion: %llu Frames fused, %llu calls alone, %llu timeouts, %llu mismatched Frames, %llu sleeps\n",
+                  (unsigned long long)v[0], (unsigned long long)v[1], (unsigned long long)v[2], (unsigned long long)v[3], (unsigned long long)v[4]);
+    }
     // destruction order as a System shutdown; the registry must end empty (contexts are released)
     delete mpORBextractorLeft; delete mpORBextractorRight; delete mpLineextractorLeft; delete mpLineextractorRight;
     const int left = (int)pli_detail::Registry::get().groups.size();
     out.put("groups_left", 'i', 1, 1, &left);
     std::printf("dropin_harness: %d frames x %d repetitions (%s), hash %016llx, %.3f ms per Frame constructor\n", nframes, reps,
-                mode == 1 ? "four threads" : "sequential", (unsigned long long)hashes[0], msPerFrame);
-    if (mode != 1)
+                mode >= 1 ? "four threads" : "sequential", (unsigned long long)hashes[0], msPerFrame);
+    if (mode == 0)
       std::printf("  per Frame: ORB x2 %.3f ms, lines x2 %.3f ms, stereo matchers %.3f ms\n", Frame::stageSeconds[0] * 1e3 / (nframes * reps),
                   Frame::stageSeconds[1] * 1e3 / (nframes * reps), Frame::stageSeconds[2] * 1e3 / (nframes * reps));
   } catch (const std::exception& e) {

@@ -162,7 +162,21 @@ def test_adapters_under_sanitizers_with_a_mock_library(tmp_path, sanitizer):
         assert r.returncode == 0 and "Sanitizer" not in r.stderr, (r.returncode, r.stderr[-3000:])
         dumps[mode] = read_dump(outp)
     a, b = dumps[1], dumps[0]
-    assert set(a) == set(b) and all(a[k].tobytes() == b[k].tobytes() for k in a if k != "frame_ms")
+    assert set(a) == set(b) and all(a[k].tobytes() == b[k].tobytes() for k in a if k not in ("frame_ms", "fusion_stats"))
+    # a thread that comes 5 ms late on Frame 2 (that Frame goes unfused, the later ones fuse again), line extractors on copies of the
+    # images (nothing may fuse), and a rig that changes at Frame 3: the same bytes, no sanitizer report
+    for name, mode, kw in (("late", 1, dict(delay_frame=2, delay_ms=5)), ("copies", 2, {})):
+        inp, outp = str(tmp_path / "in"), str(tmp_path / ("out_" + name))
+        write_input(inp, frames, 3, mode, nfeatures=500, nlines=60, **kw)
+        r = subprocess.run([exe, inp, outp], capture_output=True, text=True, env=env)
+        assert r.returncode == 0 and "Sanitizer" not in r.stderr, (name, r.returncode, r.stderr[-3000:])
+        d = read_dump(outp)
+        assert all(d[k].tobytes() == b[k].tobytes() for k in b if k not in ("frame_ms", "fusion_stats")), name
+        fused, alone, timeouts, mismatched, sleeps = (int(v) for v in d["fusion_stats"][0])
+        if name == "late":
+            assert timeouts >= 3 and 6 * 3 - 3 - 6 <= fused <= 6 * 3 - 3, d["fusion_stats"]     # (slack: thread starts under a sanitizer are slow)
+        else:
+            assert fused == 0 and mismatched + timeouts > 0, d["fusion_stats"]
     assert len(set(a["hashes"].ravel().tolist())) == 1 and int(a["groups_left"][0, 0]) == 0
     assert len(a["f0/mvKeys.f"]) >= 200 and len(a["f1/sbp0/match12"]) > 0 and int(a["f1/line_nmatches"][0, 0]) > 0
 
