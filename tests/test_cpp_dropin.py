@@ -228,9 +228,10 @@ def check_f2f(t, nframes, rig_of, w, h, same_scene, floor):
             mono = c == 3
             cs = pre + "sbp%d/" % c
             q = po.track_queries(lkp, t[last + "mvDepth"].ravel(), Tlw, t[cs + "Tcw"], fx, fy, cx, cy, bf, 15.0 if mono else 7.0, mono, sf)
-            if c == 0:
+            forward_possible = 0.15 > bf / fx      # the harness moves the camera by 0.15: bForward / bBackward need |tlc.z| > mb = mbf / fx
+            if c == 0 and forward_possible:        # (EuRoC: mb = 0.11; KITTI: mb = 0.54, every case takes the +-1 octave window)
                 assert (q["max_level"][q["valid"] == 1] == -1).all(), "case 0 is meant to be the forward branch (ORBmatcher.cc:2196)"
-            if c == 1:
+            if c == 1 and forward_possible:
                 assert (q["min_level"][q["valid"] == 1] == 0).all(), "case 1 is meant to be the backward branch"
             on, obest = po.search_by_projection(q, t[last + "mDescriptors"], ckp, t[pre + "mDescriptors"], t[pre + "mvuRight"].ravel(),
                                                 (0.0, float(w), 0.0, float(h)), c != 2)
