@@ -306,7 +306,7 @@ def dry_tables(args, rank, world):
     start, count = shard_range(nbatch, rank, world)
     counts = [shard_range(nbatch, r, world)[1] for r in range(world)]
     pad = max(counts)
-    gath = TableGatherer(pad * rec, torch.device("cpu"))
+    gath = TableGatherer(pad * rec, torch.device("cpu"), force=args.force_dist)
     ok = True
     for step in range(args.warmup + args.steps):
         slot = gath.acquire()
@@ -349,6 +349,10 @@ def main():
     ap.add_argument("--lsd-mode", type=int, default=0, help="0 auto, 1 relaxation, 2 sequential waves, 3 tile-sequential relaxation")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--dry-tables", action="store_true", help="CPU exercise of sharding + gather (needs --backend gloo)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="with --gpus 1: initialise the process group anyway and run the multi-rank code path (TableGatherer on device "
+                         "tensors, halo exchange, barriers, all-reduces, the gathered-table parity leg) in a world of one rank: executes "
+                         "the RCCL calls of the 8-GPU run on a one-GPU box")
     ap.add_argument("--share-device", action="store_true",
                     help="all ranks run their kernels on GPU 0 (rehearsal of the multi-rank path on a one-GPU box; needs --backend gloo: "
                          "the tables are staged through the host for the gather and the halo)")
@@ -371,7 +375,7 @@ def main():
         if args.backend != "gloo":
             sys.exit("--dry-tables is the CPU exercise: use --backend gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("MASTER_PORT", str(free_port()) if world == 1 else "29533")
         dist.init_process_group("gloo", rank=rank, world_size=world)
         assert dist.get_world_size() == args.gpus
         sys.exit(dry_tables(args, rank, world))
@@ -385,8 +389,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     ctl = torch.device("cpu") if args.backend == "gloo" else dev        # where the small control tensors of the collectives live
-    if world > 1:
+    multi = world > 1 or args.force_dist                                 # the multi-rank code path (a world of one rank when forced)
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
         if args.backend == "gloo":
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -411,12 +418,12 @@ def main():
     else:
         F = args.frames_per_gpu or 256
     Fmax = F
-    if world > 1:                                     # equal table sizes for the gather (config 4 shards may differ by one)
+    if multi:                                         # equal table sizes for the gather (config 4 shards may differ by one)
         t = torch.tensor([F], device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         Fmax = int(t.item())
     # (config 3 on several ranks: the frame-to-frame matcher also sees the halo frame of the previous shard)
-    cfg = capi.default_config(W, H, orb_nfeatures=nfeat, lsd_nfeatures=nlines, max_frames=Fmax + (1 if (args.config == 3 and world > 1) else 0),
+    cfg = capi.default_config(W, H, orb_nfeatures=nfeat, lsd_nfeatures=nlines, max_frames=Fmax + (1 if (args.config == 3 and multi) else 0),
                               lsd_mode=args.lsd_mode)
     fe = Frontend(cfg, device=local_rank)
     # synthetic stream: up to --unique-frames distinct seeded stereo pairs per rank (seeds disjoint across ranks), cycled to F
@@ -437,7 +444,7 @@ def main():
     d_table = torch.zeros(Fmax * rec_bytes, dtype=torch.uint8, device=dev)
     # N > 1: the result tables are gathered to rank 0 over RCCL, double buffered, so that the gather of one step travels
     # while the kernels of the next run; every gather is complete before the closing barrier of the timed region
-    gath = TableGatherer(Fmax * rec_bytes, dev) if world > 1 else None
+    gath = TableGatherer(Fmax * rec_bytes, dev, force=args.force_dist) if multi else None
     fe.set_stream(torch.cuda.current_stream().cuda_stream)
     track = None
     if args.config == 3:
@@ -448,7 +455,7 @@ def main():
             return np.array([[np.cos(a_), -np.sin(a_), 0, -0.02 * t_], [np.sin(a_), np.cos(a_), 0, -0.007 * t_], [0, 0, 1, 0.01 * t_]],
                             np.float32)
         tl = fe.track_layout()
-        if world > 1:
+        if multi:
             # f2f matching across shard borders: the record of the frame before this shard's first one arrives from
             # the previous rank (1-frame halo, point-to-point) and the matcher runs over [halo | own frames]
             from pli_slam_amd.sharding import exchange_halo
@@ -467,9 +474,9 @@ def main():
         last_slot[0] = slot
         tbl = gath.table(slot) if gath else d_table
         fe.batch_run_device(F, d_left.data_ptr(), d_right.data_ptr(), W, W * H, tbl.data_ptr())
-        if track is not None and world > 1:
+        if track is not None and multi:
             d_halo_table[rec_bytes:(F + 1) * rec_bytes].copy_(tbl[:F * rec_bytes])
-            got = exchange_halo(d_halo_table, rec_bytes, F, counts=[F] * world)
+            got = exchange_halo(d_halo_table, rec_bytes, F, counts=[F] * world, force=args.force_dist)
             if got:       # [halo | frames]: F + 1 consecutive records
                 fe.batch_track_device(F + 1, d_halo_table.data_ptr(), track[0].data_ptr(), track[1], track[2].data_ptr())
             else:         # the first shard of the stream: nothing in front of its frame 0
@@ -483,7 +490,7 @@ def main():
     def fence():
         if gath:
             gath.drain()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -500,7 +507,7 @@ def main():
     fe.prof_enable(False)
     prof = fe.prof_report()
     frames_done = torch.tensor([float(F * args.steps)], dtype=torch.float64, device=ctl)
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -511,7 +518,7 @@ def main():
     # track of its first frame against the oracle's track over [last frame of the previous shard | own first frame] (config 3:
     # that track exists only through the halo exchange); rank 0 checks records of EVERY rank's gathered shard against the oracle.
     parity_multi = None
-    if world > 1 and not args.no_cpu_baseline:
+    if multi and not args.no_cpu_baseline:
         counts_r = [shard_range(BATCH4, r_, world)[1] * max(1, args.inflight) if args.config == 4 else F for r_ in range(world)]
 
         def pair_of(r_, i_):        # the stereo pair behind record i_ of rank r_ (the seeds / instants the ranks drew above)
@@ -617,11 +624,13 @@ def main():
         out["lsd_rounds"] = {"launched_without_host_look": rs[0], "needed_by_slowest_image": rs[1], "images_redone_by_device_fallback": rs[2],
                              "note": "relaxation rounds per step; an image that has not settled after the launched rounds is redone on the "
                                      "device by the sequential grower (exact, slow): needed = -1 would flag it"}
-        if world > 1:
+        if multi:
             out["gather"] = {"bytes_per_rank_per_step": Fmax * rec_bytes, "bytes_at_root_per_step": world * Fmax * rec_bytes,
                              "backend": args.backend, "staged_through_host": bool(gath.staged)}
             if args.share_device:
                 out["config"]["parallelism"] += "; ALL ranks share GPU 0 (rehearsal, not a scaling measurement)"
+            if args.force_dist and world == 1:
+                out["config"]["parallelism"] += "; --force-dist: the multi-rank code path in a process group of ONE rank"
             if parity_multi is not None:
                 out["parity"] = parity_multi
                 if not parity_multi["ok"]:
@@ -630,7 +639,7 @@ def main():
         if args.config == 4:
             out["config"]["batch_frames"] = BATCH4
             out["config"]["batches_in_flight"] = max(1, args.inflight)
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             # BASELINE.json configs[1] (a single stereo pair) beside the batch: latency of one pair through the same library
             if F > 1 and (W, H) == (752, 480):
                 f1 = Frontend(capi.default_config(W, H, orb_nfeatures=nfeat, lsd_nfeatures=nlines, max_frames=1), device=local_rank)
@@ -667,7 +676,7 @@ def main():
                 except Exception as e:                # (the headline line must not depend on this leg)
                     out["large_batch"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     sys.exit(rc)

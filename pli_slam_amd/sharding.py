@@ -56,7 +56,7 @@ def _host_staged(t, group=None):
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
-def exchange_halo(table, record_bytes, nframes_local, group=None, counts=None):
+def exchange_halo(table, record_bytes, nframes_local, group=None, counts=None, force=False):
     """1-frame halo for frame-to-frame matching across shard borders: every rank sends the record of its LAST
     frame to the next rank and receives the record of the frame before its first one.
 
@@ -67,8 +67,9 @@ def exchange_halo(table, record_bytes, nframes_local, group=None, counts=None):
     records starting at frame 0.  Point-to-point only (isend / irecv): no collective on the data path.
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (force and dist.is_initialized()):
         return False
+    # (force: a process group of ONE rank walks the same code — counts, neighbours, requests — and finds no neighbour)
     rank = dist.get_rank(group)
     if counts is not None:                               # the frame count of every rank, known to the caller: no exchange of counts
         all_counts = [int(c) for c in counts]
@@ -110,17 +111,20 @@ class TableGatherer:
         g.drain()                         # all gathers done; on dst, g.gathered(slot) holds every rank's table
     """
 
-    def __init__(self, table_bytes, device, depth=2, dst=0, group=None):
+    def __init__(self, table_bytes, device, depth=2, dst=0, group=None, force=False):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.dst, self.group, self.depth = dst, group, depth
+        # force: issue the collective even in a process group of ONE rank (bench.py --force-dist: the RCCL calls of the multi-GPU
+        # path executed on a one-GPU box)
+        self.active = self.world > 1 or (force and dist.is_initialized())
         self.tables = [torch.zeros(table_bytes, dtype=torch.uint8, device=device) for _ in range(depth)]
         self.bufs = [None] * depth
         # gloo + tables in HBM: the shard goes to a (pinned) host copy first and the root receives host buffers
-        self.staged = self.world > 1 and torch.device(device).type == "cuda" and dist.get_backend(group) == "gloo"
+        self.staged = self.active and torch.device(device).type == "cuda" and dist.get_backend(group) == "gloo"
         self.host = [torch.empty(table_bytes, dtype=torch.uint8).pin_memory() for _ in range(depth)] if self.staged else None
         bdev = torch.device("cpu") if self.staged else device
-        if self.world > 1 and self.rank == dst:
+        if self.active and self.rank == dst:
             self.bufs = [[torch.empty(table_bytes, dtype=torch.uint8, device=bdev) for _ in range(self.world)]
                          for _ in range(depth)]
         self.works = [None] * depth
@@ -138,7 +142,7 @@ class TableGatherer:
         return slot
 
     def submit(self, slot):
-        if self.world > 1:
+        if self.active:
             src = self.tables[slot]
             if self.staged:
                 self.host[slot].copy_(src)               # waits for the kernels on the current stream that fill the table
@@ -153,6 +157,6 @@ class TableGatherer:
 
     def gathered(self, slot):
         """On dst: the list of every rank's table of that slot (world size 1: just the local table)."""
-        if self.world == 1:
+        if not self.active:
             return [self.tables[slot]]
         return self.bufs[slot] if self.rank == self.dst else None

@@ -42,3 +42,13 @@ def test_three_uneven_ranks_under_torchrun():
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 3 and d["shards_ok"] and d["shard_frames"] == [86, 85, 85]
+
+
+def test_force_dist_one_rank_walks_the_gather_path():
+    """--force-dist (the switch tests/test_multirank_gpu.py uses to execute the RCCL calls on the one GPU of the test box): a process
+    group of ONE rank still issues the gather; here with gloo and dry tables."""
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--backend", "gloo", "--dry-tables", "--force-dist", "--steps", "2",
+                          "--warmup", "1", "--frames-per-gpu", "5"], env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["shards_ok"] is True and d["shard_frames"] == [5]

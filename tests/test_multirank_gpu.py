@@ -47,3 +47,32 @@ def test_default_workload_two_ranks_weak_scaling_line():
     d = run_bench("--frames-per-gpu", "16")
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["parity"]["ok"] is True
     assert d["parity"]["records_gathered"] == 32
+
+
+# ---- the RCCL calls themselves -------------------------------------------------------------------------------
+# `backend="nccl"` is RCCL on ROCm.  The two-rank rehearsals above use gloo with host staging because RCCL refuses two ranks on one
+# device; what they cannot show is that the calls the 8-GPU run makes — init_process_group("nccl", device_id=...), all_reduce and
+# barrier on device tensors, the asynchronous gather of DEVICE tables by TableGatherer, the halo walk — execute at all.  --force-dist
+# runs the multi-rank code path of bench.py in a process group of ONE rank on RCCL.
+
+def run_nccl_one_rank(*extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--backend", "nccl", "--force-dist", "--steps", "2", "--warmup", "1",
+                          *extra], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_rccl_path_executes_config4_gather_of_device_tables():
+    d = run_nccl_one_rank("--config", "4", "--inflight", "1")
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["frames_per_gpu"] == 256
+    assert d["gather"]["backend"] == "nccl" and d["gather"]["staged_through_host"] is False
+    p = d["parity"]                      # records of the table that CAME OUT of the RCCL gather against the oracle
+    assert p["ok"] is True and p["records_gathered"] == 256 and p["empty_records"] == 0 and p["pairs_mismatching"] == 0
+
+
+def test_rccl_path_executes_config3_halo_walk_and_track():
+    d = run_nccl_one_rank("--config", "3", "--frames-per-gpu", "6")
+    assert d["gather"]["backend"] == "nccl" and d["parity"]["ok"] is True and d["parity"]["pairs_mismatching"] == 0
+    assert d["parity"]["halo_tracks_checked_against_oracle"] == 0      # one rank: no predecessor, the halo walk finds no neighbour
