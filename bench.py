@@ -386,6 +386,7 @@ def main():
         if args.backend != "gloo":
             sys.exit("--share-device puts several ranks on one GPU, which RCCL refuses: use --backend gloo")
         local_rank = 0
+        os.environ.setdefault("PLI_TX_TAIL", "0")       # several processes on one device: no spinning kernel (pli_frontend.h "Sharing a device")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     ctl = torch.device("cpu") if args.backend == "gloo" else dev        # where the small control tensors of the collectives live

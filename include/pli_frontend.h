@@ -28,6 +28,18 @@
  *     extract calls, so a second Frame must not start extracting on a context
  *     while the first Frame's stereo matchers have not run yet.
  *     pli_ctx_destroy must not race with other calls on that context.
+ *   - Sharing a device.  Several contexts of ONE process may share a device
+ *     freely.  The late rounds of the LSD tile relaxation run in a persistent
+ *     kernel with a grid barrier (k_tx_tail) whose grid is sized for a device
+ *     it has to itself; the library starts such a kernel only when the
+ *     previous one of this process on that device has ended.  Several
+ *     PROCESSES on one device (ranks sharing a GPU) should set PLI_TX_TAIL=0
+ *     in their environment (the planned-rounds schedule, no spinning kernel):
+ *     without it two processes' tail kernels can each hold part of the
+ *     compute units the other needs; every barrier wait is bounded (about a
+ *     second), the kernels then give up and the images that had not settled
+ *     are redone by the sequential grower — results stay exact, the call
+ *     stalls, and pli_lsd_round_stats out[2] counts the images.
  */
 #ifndef PLI_FRONTEND_H
 #define PLI_FRONTEND_H

@@ -1435,9 +1435,12 @@ __global__ __launch_bounds__(1024) void k_tx_emit_sorted(const RxCtl* __restrict
 // last round without looking.  Here a resident grid walks the same blocks — tx_diffmark_block, tx_prep_block, tx_grow_tile,
 // rx_rect_wave: the code of the four kernels, unchanged — as VIRTUAL blocks / waves, with a grid barrier where a kernel
 // boundary was, and stops by itself when every image is at its fixed point (or out of a capacity).
-// The grid must be co-resident: the host sizes it from the occupancy of this kernel (pli_capi.hip).  A barrier that is not
-// passed within seconds (it cannot happen on a healthy device) raises the abort word, every block leaves, and the images
-// that have not settled take the device-side fallback like any other unsettled image.
+// The grid must be co-resident: the host sizes it from the occupancy of this kernel on a device it has to itself, and chains
+// the tails of one process per device (pli_capi.hip).  A barrier that is not passed within ~2^21 polls (about a second; a barrier
+// normally takes microseconds, the longest round of real work milliseconds) — another PROCESS holding the compute units the
+// rest of the grid needs, see "Sharing a device" in include/pli_frontend.h — raises the abort word, every block leaves, and the
+// images that have not settled take the device-side fallback like any other unsettled image (exact; counted in
+// pli_lsd_round_stats out[2]).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ bool tx_grid_barrier(unsigned* bar, unsigned target) {
   // One release (L2 write-back towards the other XCDs) and one acquire (L1 / stale-L2 invalidation) per BLOCK, by its first wave:
@@ -1456,7 +1459,7 @@ __device__ __forceinline__ bool tx_grid_barrier(unsigned* bar, unsigned target) 
     while (__hip_atomic_load(&bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(4);
       if ((++spins & 63u) == 0u &&
-          (__hip_atomic_load(&bar[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || spins > (1u << 23))) {
+          (__hip_atomic_load(&bar[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || spins > (1u << 21))) {
         __hip_atomic_store(&bar[32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = 0;
         break;

@@ -194,6 +194,10 @@ struct pli_ctx {
   }
 };
 
+// the last k_tx_tail launch on every device of this process (see the launch site)
+static std::mutex g_tailMu;
+static hipEvent_t g_tailEv[64] = {};
+
 struct CtxGuard {
   const pli_ctx* c;
   explicit CtxGuard(const pli_ctx* c_) : c(c_) { if (c) c->mu.lock(); }
@@ -1004,7 +1008,19 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
           // (single pair: k_tx_tail 149 us with 256 workgroups, 90 with 64)
           int tb = std::min(c->tailBlocks, std::max(64, 8 * nimg));
           if (const char* e = getenv("PLI_TX_TAIL_BLOCKS")) tb = std::max(1, std::min(c->tailBlocks, atoi(e)));     // dev switch
-          LAUNCH(c, "k_tx_tail", k_tx_tail, dim3(tb), dim3(256), 0, ta);
+          // k_tx_tail spins on a grid barrier, so its grid must be co-resident; the grid is sized for a device it has to itself.  Two
+          // tails in flight at once (two contexts of this process on one device) could each hold a part of the other's slots and spin
+          // until the barrier's timeout: tails of one process are chained per device — a tail starts when the previous one has ended.
+          // (Other PROCESSES on the device are out of reach of this chain: PLI_TX_TAIL=0 selects the planned-rounds schedule there,
+          // include/pli_frontend.h "Sharing a device".)
+          {
+            std::lock_guard<std::mutex> lk(g_tailMu);
+            hipEvent_t& ev = g_tailEv[c->device & 63];
+            if (ev) HIPCHK(hipStreamWaitEvent(c->stream, ev, 0));
+            else HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            LAUNCH(c, "k_tx_tail", k_tx_tail, dim3(tb), dim3(256), 0, ta);
+            HIPCHK(hipEventRecord(ev, c->stream));
+          }
           break;
         }
         // (the per-tile dirty counters: cleared once per call with the control blocks, then by the wave that takes a tile's list;
