@@ -343,6 +343,9 @@ def main():
     ap.add_argument("--nfeatures", type=int, default=0)
     ap.add_argument("--nlines", type=int, default=0)
     ap.add_argument("--unique-frames", type=int, default=64)
+    ap.add_argument("--real-images", action="store_true",
+                    help="the batch is cut from real photographs (pli_slam_amd/realdata.py, tests/golden/real/photos.npz) instead of "
+                         "synthetic scenes: rate, relaxation rounds and fallbacks on natural gradients (752x480 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true")
     ap.add_argument("--no-large-batch-leg", action="store_true")
@@ -435,6 +438,9 @@ def main():
         if args.config == 3:
             # one scene for all ranks, rank r holds the time slice [r * nuniq, r * nuniq + nuniq): consecutive shards of ONE stream
             pairs = list(ex.map(lambda t_: synth.make_stereo_pair(100, W, H, t=rank * nuniq + t_), range(nuniq)))
+        elif args.real_images:
+            from pli_slam_amd import realdata
+            pairs = realdata.frames_752x480(nuniq, seed=17 + rank, w=W, h=H)
         else:
             pairs = list(ex.map(lambda s_: synth.make_stereo_pair(s_, W, H), range(rank * nuniq, rank * nuniq + nuniq)))
     images = np.stack([np.stack(p) for p in pairs])                    # (nuniq, 2, H, W) u8
@@ -558,13 +564,31 @@ def main():
         avg_s = (total_ms / max(calls, 1)) * 1e-3
         peak = 8000.0
         achieved = per_img * 2 * F / avg_s / 1e9 if (per_img is not None and avg_s > 0) else None
+        issue = None       # what the dominant kernel is bound by, from the committed SQ passes of the same workload
+        step_traffic = None  # counter traffic of the WHOLE step (every kernel x its launches) against the algorithmic bytes
         traffic = None     # HBM bytes per launch from the committed PMC passes of the same workload, if any
         sector = None      # the growers are gather kernels: their ceiling is the rate of random 64-byte sector requests the chip
         try:               # sustains (tools/probes/gather_rate.hip, profiles/r02_gather_rate_probe.txt: 49 G/s), not the stream peak
-            tpath = [p_ for p_ in (os.path.join(ROOT, "profiles", "r03_traffic.json"), os.path.join(ROOT, "profiles", "r02_traffic.json"))
-                     if os.path.exists(p_)][0]
+            tpath = [p_ for p_ in (os.path.join(ROOT, "profiles", "r%02d_traffic.json" % n_) for n_ in (4, 3, 2)) if os.path.exists(p_)][0]
             tr = json.load(open(tpath))
-            k = tr["workloads"].get("%dx%d_F%d" % (W, H, F), {}).get(name)
+            wkey = "%dx%d_F%d" % (W, H, F)
+            k = tr["workloads"].get(wkey, {}).get(name)
+            isGather = lambda kn_: kn_.startswith(("k_tx_grow", "k_lsd_grow", "k_rx_grow"))
+            wl = tr["workloads"].get(wkey, {})
+            if wl and all("launches" in v_ for v_ in wl.values()):
+                tot = sum(v_["launches"] * ((1 if isGather(kn_) else 2) * v_["fetch_kb"] + v_["write_kb"]) * 1024 for kn_, v_ in wl.items()
+                          if "alias_of" not in v_)
+                step_traffic = {"bytes_per_step": tot, "algorithmic_bytes_per_step": b_frame * F, "ratio": tot / (b_frame * F),
+                                "hbm_GBps_at_this_rate": tot / (dt / args.steps) / 1e9, "source": os.path.basename(tpath),
+                                "note": "sum over the kernels of the committed FETCH_SIZE / WRITE_SIZE passes x their launches per step"}
+            iq = tr.get("issue", {}).get(wkey, {}).get(name)
+            if iq and iq["avg_ns"] > 0:
+                simd_quads = 1024 * iq["avg_ns"] * 2.4 / 4.0        # quad-cycles all SIMDs of the chip offer during one launch (2.4 GHz)
+                issue = {"valu_issue_frac": iq["active_valu_quad_cycles"] / simd_quads, "valu_wave_instructions": iq["valu"],
+                         "salu_wave_instructions": iq["salu"], "launch_ns_under_profiler": iq["avg_ns"], "source": os.path.basename(tpath),
+                         "note": "SQ_ACTIVE_INST_VALU / (1024 SIMDs x quad-cycles of the launch): the share of the chip's VALU issue "
+                                 "time the kernel uses; a kernel near 0.7-0.8 with 8 waves per SIMD is bound by its INSTRUCTION COUNT, "
+                                 "not by HBM"}
             if k:
                 # FETCH_SIZE counts 32-byte units for streaming kernels on gfx950 (MI355X_MICROARCH.md: x2) but 64 bytes per request
                 # of the growers' 8-byte gathers (TCC_MISS x 64 B agrees with the undoubled figure, profiles/README.md)
@@ -594,18 +618,28 @@ def main():
                 # end at once unless an image is left to the sequential grower)
                 if fr_ <= 1.0:
                     kfrac[kn] = round(fr_, 4)
+        side = orb_chain + ("k_stereo_points", "k_stereo_median", "k_blur_lbd", "k_sobel")
         roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": peak, "unit": "GB/s",
                 "frac": (achieved / peak) if achieved is not None else None, "traffic": traffic, "sector_requests": sector,
+                # the HBM roofline is the contract's; what actually limits the dominant kernel (an 8-byte-gather region grower) is
+                # the chip's instruction issue: `issue` carries the measured VALU-issue fraction, `limiter` says it in a word
+                "limiter": ("VALU instruction issue (not HBM): see issue.valu_issue_frac" if issue and issue["valu_issue_frac"] > 0.5
+                            else ("instruction issue / dependent latency (no committed SQ pass for this workload)" if name and
+                                  name.startswith(("k_tx_grow", "k_lsd_grow", "k_rx_grow")) else "hbm")),
+                "issue": issue, "step_traffic": step_traffic,
                 "avg_launch_ms": avg_s * 1e3, "launches": calls,
                 "path_achieved": fps / world * b_frame / 1e9, "path_frac": fps / world * b_frame / 1e9 / peak,
                 "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in
-                                       sorted(prof.items(), key=lambda kv: -kv[1][1])},
+                                       sorted(prof.items(), key=lambda kv: -kv[1][1]) if k not in side},
+                "side_stream_kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in
+                                                   sorted(prof.items(), key=lambda kv: -kv[1][1]) if k in side},
                 "kernel_hbm_frac": dict(sorted(kfrac.items(), key=lambda kv: -kv[1])),
-                "kernel_ms_note": "HIP-event time between the launch's two events on the stream it ran on, summed per step.  The ORB chain ("
-                                  + ", ".join(orb_chain) + ") runs on a low-priority side stream beside the line chain: its times include "
-                                  "the wait for wave slots (alone, PLI_SIDE_MAX=0: k_resize_level 0.7 ms, k_fast_cells 3.4, k_octree 1.7 at 256 "
-                                  "frames), and the line chain's kernels are stretched by it (alone: k_tx_round2 1.7 ms, k_tx_diffmark 2.3); "
-                                  "DESIGN.md 5 has the table of every kernel alone"}
+                "kernel_ms_note": "HIP-event time between the launch's two events on the stream it ran on, summed per step.  "
+                                  "side_stream_kernel_ms_per_step: the ORB chain, the stereo point matcher and the LBD's blur + Sobel run on a "
+                                  "low-priority side stream beside the line chain: their event times INCLUDE the wait for wave slots behind the "
+                                  "line kernels (alone, PLI_SIDE_MAX=0, 256 frames: k_resize_level 0.7 ms, k_fast_cells 3.4, k_octree 1.5, "
+                                  "k_blur_orb 1.0, k_describe 1.0) and are not comparable with the main stream's; the line chain's kernels are "
+                                  "stretched by them in turn (alone: k_tx_round2 1.8 ms, k_tx_diffmark 2.3).  DESIGN.md 5 has every kernel alone"}
         what = C_["what"] if args.config else ("752x480 stereo pairs, extract + stereo Hamming match (BASELINE configs[1] shape, "
                                                "batched)")
         out = {
@@ -614,7 +648,10 @@ def main():
             "value": fps, "unit": "stereo frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if args.config == 4 else "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic (%d distinct seeded EuRoC-shaped pairs per GPU, cycled)" % nuniq,
+            "vs_baseline": None, "dtype": "u8",
+            "data": ("real photographs (%d distinct 752x480 windows of the scikit-image sample photographs per GPU, enlarged 1.5-2.2x, "
+                     "cycled; the right eye of all but the Middlebury pair is the left one displaced)" % nuniq) if args.real_images else
+                    "synthetic (%d distinct seeded EuRoC-shaped pairs per GPU, cycled)" % nuniq,
             "config": {"workload": "%dxMI355X: %s; %dx%d, %d ORB kp (8 levels x1.2) + LSD/LBD (<=%d lines); %d stereo frames per "
                                    "GPU per step" % (world, what, W, H, nfeat, nlines, F),
                        "baseline_config": args.config or None, "frames_per_gpu": F, "bytes_per_frame": b_frame,

@@ -1,6 +1,10 @@
 #!/bin/bash
-# copies the summaries written by tools/make_profiles.sh (gpurun_out/prof_out) into profiles/ under the round's names
-R=$(cd "$(dirname "$0")/.." && pwd); O=$R/gpurun_out/prof_out; P=$R/profiles; N=${1:-r01}
-for f in kernel_stats_f2048_sequential.txt kernel_stats_f32_relaxation.txt kernel_stats_f1_relaxation.txt pmc_fetch_write_f2048.txt \
-         pmc_relaxation_f32.txt bench_default.json bench_f32_relaxation.json bench_f1_relaxation.json; do cp $O/$f $P/${N}_$f; done
-cp $O/traffic.json $P/${N}_traffic.json
+# copies the summaries written by tools/make_profiles.sh --round N (gpurun_out/prof_rNN) into profiles/ as rNN_* and builds
+# rNN_traffic.json (read back by bench.py for roofline.traffic / roofline.issue):   tools/install_profiles.sh --round N
+ROUND=4
+if [[ $1 == --round ]]; then ROUND=$2; fi
+RN=$(printf "r%02d" $ROUND)
+R=$(cd "$(dirname "$0")/.." && pwd); O=$R/gpurun_out/prof_$RN; P=$R/profiles
+for f in $O/kernel_stats_*.txt $O/pmc_*.txt $O/bench_*.json $O/sweep_*.jsonl; do [ -s "$f" ] && cp $f $P/${RN}_$(basename $f); done
+python3 $R/tools/make_traffic_json.py $O > $P/${RN}_traffic.json
+ls $P | grep $RN

@@ -1,22 +1,52 @@
 #!/usr/bin/env python3
-"""Builds profiles' traffic json (read back by bench.py for roofline.traffic) from the PMC summaries written by
-tools/make_profiles.sh:   python tools/make_traffic_json.py <prof_out dir> <frames of the default run> > r01_traffic.json"""
+"""profiles/rNN_traffic.json (read back by bench.py for roofline.traffic and roofline.issue) from the counter passes of
+tools/make_profiles.sh --round N:   python tools/make_traffic_json.py gpurun_out/prof_rNN > profiles/rNN_traffic.json
+
+  workloads.<WxH_Fn>.<kernel>  = {fetch_kb, write_kb}   per-launch averages of the FETCH_SIZE / WRITE_SIZE passes
+  issue.<WxH_Fn>.<kernel>      = {valu, salu, active_valu_quad_cycles, avg_ns, launches}  from the SQ passes (per launch)"""
 import json, os, sys
 
+WORKLOADS = {"default_f256": "752x480_F256", "f2048_sequential": "752x480_F2048", "config5_4k": "3840x2160_F16", "config3_720p": "1280x720_F64"}
+ALIAS = {"k_lsd_grow2_spec": "k_lsd_grow2", "k_lsd_grow_spec": "k_lsd_grow", "k_lsd_grad64": "k_lsd_grad", "k_lsd_blur64": "k_blur_lsd",
+         "k_lsd_resize64": "k_resize_lsd", "k_lsd_front64": "k_lsd_front"}
 
-def rows(path, kernels):
+
+def rows(path, counters):
+    """kernel -> counter -> (launches, avg per launch, avg ns) of a rocprof_summary.py pmc file"""
     out = {}
+    if not os.path.exists(path):
+        return out
     for line in open(path):
         p = line.split()
-        if len(p) >= 6 and p[0] in kernels and p[1] in ("FETCH_SIZE", "WRITE_SIZE"):
-            out.setdefault(p[0], {})["fetch_kb" if p[1] == "FETCH_SIZE" else "write_kb"] = float(p[4])
+        if len(p) >= 6 and p[1] in counters and p[0].startswith("k_"):
+            out.setdefault(p[0], {})[p[1]] = (int(p[2]), float(p[4]), float(p[5]))
     return out
 
 
-d, frames = sys.argv[1], sys.argv[2]
-doc = {"note": "HBM traffic per launch from rocprofv3 PMC passes (separate runs for FETCH_SIZE and WRITE_SIZE) of bench.py, keyed by "
-               "frames per GPU and kernel; per-launch averages. bytes = (2*FETCH_SIZE_KB + WRITE_SIZE_KB)*1024: FETCH_SIZE is "
-               "halved on gfx950 per MI355X_MICROARCH.md, checked on k_lsd_hist.",
-       "workloads": {frames: rows(os.path.join(d, "pmc_fetch_write_f%s.txt" % frames), ("k_lsd_grow2",)),
-                     "32": rows(os.path.join(d, "pmc_relaxation_f32.txt"), ("k_rx_grow_big", "k_rx_grow"))}}
+def alias(w):
+    for a, b in ALIAS.items():
+        if a in w and b not in w:
+            w[b] = dict(w[a], alias_of=a)           # (bench.py looks kernels up by its own profile names; sums skip the aliases)
+    return w
+
+
+d = sys.argv[1]
+doc = {"note": "HBM traffic per launch from rocprofv3 PMC passes (separate runs for FETCH_SIZE and WRITE_SIZE, bench.py --steps 1 "
+               "--warmup 0), per-launch averages per kernel, keyed by workload WxH_F<frames per GPU>.  bytes = (2*FETCH_SIZE_KB + "
+               "WRITE_SIZE_KB)*1024: FETCH_SIZE is halved on gfx950 for coalesced streams (MI355X_MICROARCH.md, checked on k_lsd_hist); "
+               "for gather kernels (the growers' 8-byte loads, one 64-byte request each) FETCH_SIZE x 1 is the truth (TCC_MISS x 64 B agrees).  "
+               "`issue`: SQ passes of the same workload — wave instructions per launch (SQ_INSTS_VALU / _SALU) and SQ_ACTIVE_INST_VALU "
+               "(quad-cycles in which a SIMD's VALU was executing): valu_issue_frac = active_valu_quad_cycles * 4 / (1024 SIMDs x cycles "
+               "of the launch at 2.4 GHz).  Kernel names as rocprofv3 reports them.",
+       "workloads": {}, "issue": {}}
+for name, key in WORKLOADS.items():
+    r = rows(os.path.join(d, "pmc_%s.txt" % name), ("FETCH_SIZE", "WRITE_SIZE"))
+    doc["workloads"][key] = alias({k: {"fetch_kb": v["FETCH_SIZE"][1], "write_kb": v["WRITE_SIZE"][1], "launches": v["FETCH_SIZE"][0]}
+                                   for k, v in r.items() if len(v) == 2})
+    s = rows(os.path.join(d, "pmc_sq_%s.txt" % name), ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU"))
+    if s:
+        doc["issue"][key] = alias({k: {"valu": v["SQ_INSTS_VALU"][1], "salu": v["SQ_INSTS_SALU"][1],
+                                       "active_valu_quad_cycles": v["SQ_ACTIVE_INST_VALU"][1], "avg_ns": v["SQ_ACTIVE_INST_VALU"][2],
+                                       "launches": v["SQ_ACTIVE_INST_VALU"][0]}
+                                   for k, v in s.items() if len(v) == 3})
 print(json.dumps(doc, indent=1))
