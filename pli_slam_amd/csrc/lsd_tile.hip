@@ -44,6 +44,9 @@ constexpr double TX_2PI = 2 * TX_PI;
 //   * the same bitmap only to skip the loads of seeds the wave itself has taken: a third of the L2 misses gone (854 M -> 577 M),
 //     time unchanged — the growers are bound by instruction issue (4 cycles x (VALU + SALU instructions) per SIMD matches the
 //     kernel time within 10 % in every variant), not by the miss rate (65 % of the 49 G/s ceiling of tools/probes/gather_rate.hip).
+#ifndef TX_CLAIM_SCOPE             // (diagnostic builds only: -DTX_CLAIM_SCOPE=__HIP_MEMORY_SCOPE_WORKGROUP times the claims as L2 atomics —
+#define TX_CLAIM_SCOPE __HIP_MEMORY_SCOPE_AGENT   // NOT coherent between the XCDs' L2s, so not exact unless an image stays on one XCD)
+#endif
 constexpr int TX_GQ = 1024;       // queue entries of a region kept in LDS
 constexpr int TX_GQ_SPEC = 512;   // ... in the speculative round-1 kernel (its lanes' parked states take 2 KB of the wave's LDS)
 constexpr int TX_SPEC_CAP = 8;    // pixels a lane may take by itself before its region is handed to the whole wave (< minRegSize)
@@ -52,9 +55,17 @@ constexpr int TX_BMAXBLK = 128;   // => regions of up to TX_GQ + 32768 pixels
 
 __device__ __forceinline__ int2 tx_load_own(const int2* p) {
   // bypass the per-CU L1: claims (atomics) are performed in L2 / memory
+#if defined(TX_OWN_LOAD) && TX_OWN_LOAD == 1      // diagnostic build: plain cached load (stale owner words cost regrowth, never exactness)
+  return *p;
+#elif defined(TX_OWN_LOAD) && TX_OWN_LOAD == 2    // diagnostic build: workgroup-scope load
+  unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+  return make_int2((int)(v & 0xFFFFFFFFull), (int)(v >> 32));
+#else
   unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
   return make_int2((int)(v & 0xFFFFFFFFull), (int)(v >> 32));
+#endif
 }
 __device__ __forceinline__ int tx_lds_read(const int* p) {
   typedef __attribute__((address_space(3))) const volatile int lds_cvint;
@@ -600,10 +611,29 @@ __global__ __launch_bounds__(256) void k_tx_prep(RxCtl* __restrict__ ctl, int2* 
 // Return 0: no candidate left; 1: lane j2 lies inside the margin of the vector filter and needs the exact test (`remaining`
 // already without the lanes up to j2).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int tx_accept_fast(float& sumdx, float& sumdy, float cosv, float sinv, int qi, int myxy, int seedPix,
+// Diagnostic builds (make EXTRA=-DTX_DIAG_PAD=n, never shipped): n x 4 idle VALU instructions (or, negative, |n| x 4 idle SALU
+// instructions) per accepted pixel — how the kernel's time follows its instruction count.
+#ifndef TX_DIAG_PAD
+#define TX_DIAG_PAD_ASM
+#elif TX_DIAG_PAD == 1
+#define TX_DIAG_PAD_ASM "v_mov_b32 %[t2], %[t2]\n\tv_mov_b32 %[t2], %[t2]\n\tv_mov_b32 %[t2], %[t2]\n\tv_mov_b32 %[t2], %[t2]\n\t"
+#elif TX_DIAG_PAD == 2
+#define TX_DIAG_PAD_ASM "v_mov_b32 %[t2], %[t2]\n\tv_mov_b32 %[t2], %[t2]\n\tv_mov_b32 %[t2], %[t2]\n\tv_mov_b32 %[t2], %[t2]\n\t" \
+                        "v_mov_b32 %[t2], %[t2]\n\tv_mov_b32 %[t2], %[t2]\n\tv_mov_b32 %[t2], %[t2]\n\tv_mov_b32 %[t2], %[t2]\n\t"
+#elif TX_DIAG_PAD == -1
+#define TX_DIAG_PAD_ASM "s_mov_b32 %[code], %[code]\n\ts_mov_b32 %[code], %[code]\n\ts_mov_b32 %[code], %[code]\n\ts_mov_b32 %[code], %[code]\n\t"
+#elif TX_DIAG_PAD == -2
+#define TX_DIAG_PAD_ASM "s_mov_b32 %[code], %[code]\n\ts_mov_b32 %[code], %[code]\n\ts_mov_b32 %[code], %[code]\n\ts_mov_b32 %[code], %[code]\n\t" \
+                        "s_mov_b32 %[code], %[code]\n\ts_mov_b32 %[code], %[code]\n\ts_mov_b32 %[code], %[code]\n\ts_mov_b32 %[code], %[code]\n\t"
+#endif
+// A pixel is identified by its packed (y << 16 | x) throughout (candidates `myxy`, the row's seeds `seedXY`): one v_readlane serves
+// the duplicate test, the seed test and the bounding box.  (Lanes that are not candidates may hold anything there — an
+// out-of-image neighbour packs to a negative value, a lane past the step's entries to some pixel: they are not in `remaining` /
+// `seeds`, so a match on them clears nothing.)
+__device__ __forceinline__ int tx_accept_fast(float& sumdx, float& sumdy, float cosv, float sinv, int myxy, int seedXY,
                                               unsigned long long& remaining, unsigned long long& acc, unsigned long long& seeds,
                                               int& cnt, int& bmin, int& bmax, float lo, float hi, int& j2) {
-  int code, sc, ss, sq, sxy;
+  int code, sc, ss, sxy;
   float t0, t1, t2, t3;
   unsigned long long m, sh;
   cnt = __builtin_amdgcn_readfirstlane(cnt);            // (wave-uniform values the register allocator may hold in vector registers)
@@ -629,16 +659,16 @@ __device__ __forceinline__ int tx_accept_fast(float& sumdx, float& sumdy, float 
       "s_cbranch_scc0 5f\n\t"
       "v_readlane_b32 %[sc], %[cs], %[j]\n\t"
       "v_readlane_b32 %[ss], %[sn], %[j]\n\t"
-      "v_readlane_b32 %[q], %[qi], %[j]\n\t"
       "v_readlane_b32 %[xy], %[mxy], %[j]\n\t"
       "s_bitset1_b64 %[acc], %[j]\n\t"
       "s_add_i32 %[cnt], %[cnt], 1\n\t"
+      TX_DIAG_PAD_ASM
       "v_add_f32_e32 %[sx], %[sc], %[sx]\n\t"
       "v_add_f32_e32 %[sy], %[ss], %[sy]\n\t"
-      "v_cmp_eq_u32_e32 vcc, %[q], %[sp]\n\t"
+      "v_cmp_eq_u32_e32 vcc, %[xy], %[sp]\n\t"
       "v_pk_min_u16 %[bmin], %[bmin], %[xy]\n\t"
       "s_andn2_b64 %[seeds], %[seeds], vcc\n\t"
-      "v_cmp_eq_u32_e32 vcc, %[q], %[qi]\n\t"
+      "v_cmp_eq_u32_e32 vcc, %[xy], %[mxy]\n\t"
       "v_pk_max_u16 %[bmax], %[bmax], %[xy]\n\t"
       "s_andn2_b64 %[rem], %[rem], vcc\n\t"
       "s_cbranch_scc1 1b\n"
@@ -649,9 +679,9 @@ __device__ __forceinline__ int tx_accept_fast(float& sumdx, float& sumdy, float 
       "s_mov_b32 %[code], 1\n"
       "9:\n\t"
       : [sx] "+v"(sumdx), [sy] "+v"(sumdy), [bmin] "+v"(bmin), [bmax] "+v"(bmax), [rem] "+s"(remaining), [acc] "+s"(acc),
-        [seeds] "+s"(seeds), [cnt] "+s"(cnt), [code] "=&s"(code), [j] "=&s"(j2), [q] "=&s"(sq), [xy] "=&s"(sxy), [sc] "=&s"(sc),
+        [seeds] "+s"(seeds), [cnt] "+s"(cnt), [code] "=&s"(code), [j] "=&s"(j2), [xy] "=&s"(sxy), [sc] "=&s"(sc),
         [ss] "=&s"(ss), [m] "=&s"(m), [sh] "=&s"(sh), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
-      : [cs] "v"(cosv), [sn] "v"(sinv), [qi] "v"(qi), [mxy] "v"(myxy), [sp] "v"(seedPix), [lo] "s"(lo), [hi] "s"(hi)
+      : [cs] "v"(cosv), [sn] "v"(sinv), [mxy] "v"(myxy), [sp] "v"(seedXY), [lo] "s"(lo), [hi] "s"(hi)
       : "vcc", "scc");
   return code;
 }
@@ -753,7 +783,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
   // One region, grown by the whole wave with the batched steps, from a given start: the seed alone (cnt = 1, k = 0, q[0] = the
   // seed — every region of the plain schedule) or the prefix a lane has grown by itself (the speculative schedule below: q[0..cnt)
   // hold its pixels, k is the first queue entry that has not been expanded, the sums are the lane's).  seedMask / seedPixV: the live
-  // seeds of the current list row and their pixels (a seed whose pixel is taken leaves the mask).  false: a capacity ran out.
+  // seeds of the current list row and their pixels, packed (y << 16 | x) (a seed whose pixel is taken leaves the mask).  false: a capacity ran out.
   auto growRegion = [&](const int r, const int sp, const float sa, float sumdx, float sumdy, int cnt, int k, int bmin, int bmax, int angCnt,
                         unsigned long long& seedMask, const int seedPixV, const int pend0, const int pendRank0) -> bool {
       double reg_angle = (double)sa * TX_DEG2RAD;         // (the angle of the sums at pixel count angCnt: the seed angle at 1)
@@ -809,7 +839,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
           const int cnt0 = cnt;
           while (remaining) {
             int j2;
-            const int code = tx_accept_fast(sumdx, sumdy, rr.y, rr.z, qi, myxy, seedPixV, remaining, acc, seedMask, cnt, bmin, bmax,
+            const int code = tx_accept_fast(sumdx, sumdy, rr.y, rr.z, myxy, seedPixV, remaining, acc, seedMask, cnt, bmin, bmax,
                                             alignLo, alignHi, j2);
             if (code == 0) break;
             // lane j2 lies inside the margin of the vector filter: the reference's own expression decides
@@ -823,12 +853,11 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
             }
             // (the sums live in vector registers, so the compiler takes this decision for lane-dependent: say it is not)
             if (!__builtin_amdgcn_readfirstlane((int)(n_theta <= prec))) continue;
-            const int qj = tx_rl(qi, j2);
             const int xyj = tx_rl(myxy, j2);
             const float cj = tx_rlf(rr.y, j2), sj = tx_rlf(rr.z, j2);
             acc |= 1ull << j2;
-            remaining &= ~__builtin_amdgcn_ballot_w64(qi == qj);          // the other copies of the accepted pixel
-            seedMask &= ~__builtin_amdgcn_ballot_w64(seedPixV == qj);       // a seed of this row that was just taken
+            remaining &= ~__builtin_amdgcn_ballot_w64(myxy == xyj);        // the other copies of the accepted pixel
+            seedMask &= ~__builtin_amdgcn_ballot_w64(seedPixV == xyj);      // a seed of this row that was just taken
             ++cnt;
             bmin = tx_pk_min_u16(bmin, xyj);
             bmax = tx_pk_max_u16(bmax, xyj);
@@ -860,11 +889,10 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
               }
               if (!__builtin_amdgcn_readfirstlane((int)(n_theta <= prec))) continue;
             }
-            const int qj = tx_rl(qi, j2);
             const int xyj = tx_rl(myxy, j2);
             const float cj = tx_rlf(rr.y, j2), sj = tx_rlf(rr.z, j2);
             accepted = accepted || lane == j2;          // the claims are issued together after the loop
-            remaining &= ~__builtin_amdgcn_ballot_w64(qi == qj);          // the other copies of the accepted pixel
+            remaining &= ~__builtin_amdgcn_ballot_w64(myxy == xyj);        // the other copies of the accepted pixel
             if (cnt < GQ) {
               q[cnt] = xyj;                              // every active lane stores the same value
             } else {
@@ -888,11 +916,11 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
             bmax = tx_pk_max_u16(bmax, xyj);
             sumdx = __fadd_rn(sumdx, cj);
             sumdy = __fadd_rn(sumdy, sj);
-            seedMask &= ~__builtin_amdgcn_ballot_w64(seedPixV == qj);   // a seed of this row that was just taken
+            seedMask &= ~__builtin_amdgcn_ballot_w64(seedPixV == xyj);  // a seed of this row that was just taken
           }
         }
         if (accepted) {
-          pendOld = __hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          pendOld = __hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
           // (the pixel's own rank, which an unclaimed owner word holds: in round 1 owner_0 is the trivial map, so the word just read has it)
           if (noteLost) pendRank = (SPARSE || t != 1) ? rankOfPix[qi] : prevv;
           // (later rounds) the 8x8 cell of every claimed pixel is noted: the next round's k_rx_diff only looks where a claim or the
@@ -1239,7 +1267,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
     }
     // (the packed (y, x) of the row's seeds, 64 at a time: a scalar division per region costs more than this one per row)
     const unsigned spyv = (unsigned)max(se.y, 0) / (unsigned)W;
-    const int sxyv = (int)((spyv << 16) | ((unsigned)max(se.y, 0) - spyv * (unsigned)W));
+    const int sxyv = se.y < 0 ? -1 : (int)((spyv << 16) | ((unsigned)se.y - spyv * (unsigned)W));   // (-1: no pixel packs to it)
     unsigned long long unusedMask = __builtin_amdgcn_ballot_w64(alive);
     while (unusedMask) {
       const int j = __ffsll((long long)unusedMask) - 1;
@@ -1247,7 +1275,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
       const int sxy = tx_rl(sxyv, j);
       q[0] = sxy;                                         // every lane stores the same value
       const int rj = tx_rl(se.x, j);
-      if (!growRegion(rj, tx_rl(se.y, j), tx_rlf(srec.x, j), tx_rlf(scos, j), tx_rlf(ssin, j), 1, 0, sxy, sxy, 1, unusedMask, se.y, rj, rj))
+      if (!growRegion(rj, tx_rl(se.y, j), tx_rlf(srec.x, j), tx_rlf(scos, j), tx_rlf(ssin, j), 1, 0, sxy, sxy, 1, unusedMask, sxyv, rj, rj))
         return;
     }
   }

@@ -4,6 +4,6 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p build/variant
-cp pli_slam_amd/csrc/*.hip pli_slam_amd/csrc/*.hpp pli_slam_amd/csrc/Makefile build/variant/
-make -C build/variant -j6 EXTRA="$*" >/dev/null
-ls -la build/variant/libpli_frontend.so
+D=${VARIANT_DIR:-build/variant}; mkdir -p $D; cp pli_slam_amd/csrc/*.hip pli_slam_amd/csrc/*.hpp pli_slam_amd/csrc/Makefile $D/
+sed -i "s|\.\./\.\./include|$(pwd)/include|g" $D/Makefile; make -C $D -j6 EXTRA="$*" >/dev/null
+ls -la $D/libpli_frontend.so
