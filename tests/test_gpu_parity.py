@@ -168,10 +168,13 @@ def test_golden_vectors_small(gpu, name, flags):
 
 
 @pytest.mark.parametrize("seed,W,H,nf,nl", [(1, 752, 480, 1000, 500), (2, 640, 480, 800, 0), (3, 376, 240, 500, 60),
-                                           (4, 200, 136, 150, 30), (5, 643, 481, 600, 0), (6, 333, 245, 300, 40)])
+                                           (4, 200, 136, 150, 30), (5, 643, 481, 600, 0), (6, 333, 245, 300, 40),
+                                           # KITTI00-02.yaml:9,21-22,28,41 (Examples/Stereo/stereo_kitti.cc): 1241x376, fx 718.856, bf 386.1448
+                                           (7, 1241, 376, 2000, 500)])
 def test_other_shapes_and_parameters(gpu, seed, W, H, nf, nl):
     g = gpu
-    cfg = g.capi.default_config(W, H, orb_nfeatures=nf, lsd_nfeatures=nl, max_frames=1)
+    rig = dict(bf=386.1448, fx=718.856, max_lines=500) if W == 1241 else {}
+    cfg = g.capi.default_config(W, H, orb_nfeatures=nf, lsd_nfeatures=nl, max_frames=1, **rig)
     L, R = g.synth.make_stereo_pair(seed, W, H)
     rec = g.Frontend(cfg).batch_run_host(np.stack([L, R])[None])[0]
     assert_frame_equal(g, rec, g.po.Frame(ocfg(g, cfg)), L, R, "seed %d %dx%d" % (seed, W, H))

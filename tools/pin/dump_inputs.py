@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Writes the seeded synthetic inputs of the OpenCV pin (tools/pin/pin_against_opencv.cpp) as raw u8 files + inputs.txt."""
+"""Writes the inputs of the OpenCV pin (tools/pin/pin_against_opencv.cpp, pin_reference_extractors.cpp) as raw u8 files + inputs.txt:
+seeded synthetic scenes, hostile patterns, and (round 4) the shapes the test-suite gained — a KITTI-sized frame (1241x376, the
+reference's second stereo example) and real photographs (tests/golden/real/photos.npz: a Middlebury stereo eye, a natural scene, print)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -17,6 +19,11 @@ def inputs():
     yy, xx = np.mgrid[0:240, 0:376]
     yield "checker", (((xx // 16) + (yy // 16)) % 2 * 200 + 20).astype(np.uint8)
     yield "odd_643x481", synth.make_stereo_pair(5, 643, 481)[0]
+    yield "kitti_1241x376", synth.make_stereo_pair(900, 1241, 376)[0]
+    from pli_slam_amd import realdata
+    ph = realdata.photos()
+    for name in ("motorcycle_left", "camera", "text"):
+        yield "photo_" + name, ph[name]
 
 
 if __name__ == "__main__":
