@@ -171,9 +171,11 @@ __device__ __forceinline__ void tx_sort_tile(const int* __restrict__ rankAll, co
       } else {
         r = rank[y * W + x];
       }
+      // owner_0 = the trivial map, written for EVERY pixel of the tile (an undefined pixel is nobody's: INT_MAX in both components):
+      // the front pass does not initialise the plane for this schedule
+      own[y * W + x] = r != TX_INF ? make_int2(r, r) : make_int2(INT_MAX, INT_MAX);
       if (r != TX_INF) {
         k = (unsigned)r;
-        own[y * W + x] = make_int2(r, r);
         ++valid;
       }
     }

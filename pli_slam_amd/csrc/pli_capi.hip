@@ -780,7 +780,9 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   const pli_table_layout& Y = c->lay;
   const int npix = P.LW * P.LH;
   const bool sequential = c->lsdMode == 2 || (c->lsdMode == 0 && (nimg >= RX_AUTO_IMAGES || nimg > c->rxImages));
-  int2* ownPlane = sequential ? (int2*)nullptr : c->own;
+  // (the owner plane's start value: the lane relaxation takes it from the front pass; the tile relaxation's k_tx_sort writes the
+  // trivial map for every pixel itself — 8 bytes per scaled pixel less for the front pass to store)
+  int2* ownPlane = (sequential || c->lsdMode != 1) ? (int2*)nullptr : c->own;
   const int trigF32 = (c->cfg.parity_flags & PLI_PARITY_TRIG_F32_LSD) ? 1 : 0;
   if (c->lsdF64) {
     // OpenCV 3.x: the detector works on the CV_64FC1 copy of the image (lsd_f64.hip).  The scaled double image lives in

@@ -283,7 +283,7 @@ def test_kitti_rig_first_frame_and_rig_change_fused_equals_per_call_equals_oracl
     depth_ratio = []
     for i, (L, R) in enumerate(frames):
         rig = kitti_runs["rig_of"](i)
-        cfg = capi.default_config(KITTI_W, KITTI_H, orb_nfeatures=KITTI_NFEATURES, lsd_nfeatures=KITTI_NLINES, max_lines=KITTI_NLINES,
+        cfg = capi.default_config(KITTI_W, KITTI_H, orb_nfeatures=KITTI_NFEATURES, lsd_nfeatures=KITTI_NLINES,
                                   max_frames=1, bf=rig[4], fx=rig[0])
         want, fr, counts = oracle_containers(po, cfg, L, R)
         for k, v in want.items():
@@ -293,7 +293,7 @@ def test_kitti_rig_first_frame_and_rig_change_fused_equals_per_call_equals_oracl
         assert len(want["mvKeys.f"]) > 1200 and len(want["mvKeys_Line.f"]) > 20
         # what the bug looked like: the same Frame matched with the OTHER rig has other depths (guards the test's own power)
         other = KITTI_RIG if rig is EUROC_RIG else EUROC_RIG
-        cfg2 = capi.default_config(KITTI_W, KITTI_H, orb_nfeatures=KITTI_NFEATURES, lsd_nfeatures=KITTI_NLINES, max_lines=KITTI_NLINES,
+        cfg2 = capi.default_config(KITTI_W, KITTI_H, orb_nfeatures=KITTI_NFEATURES, lsd_nfeatures=KITTI_NLINES,
                                    max_frames=1, bf=other[4], fx=other[0])
         wrong, _, _ = oracle_containers(po, cfg2, L, R)
         assert wrong["mvDepth"].tobytes() != want["mvDepth"].tobytes()

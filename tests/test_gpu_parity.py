@@ -173,7 +173,7 @@ def test_golden_vectors_small(gpu, name, flags):
                                            (7, 1241, 376, 2000, 500)])
 def test_other_shapes_and_parameters(gpu, seed, W, H, nf, nl):
     g = gpu
-    rig = dict(bf=386.1448, fx=718.856, max_lines=500) if W == 1241 else {}
+    rig = dict(bf=386.1448, fx=718.856) if W == 1241 else {}
     cfg = g.capi.default_config(W, H, orb_nfeatures=nf, lsd_nfeatures=nl, max_frames=1, **rig)
     L, R = g.synth.make_stereo_pair(seed, W, H)
     rec = g.Frontend(cfg).batch_run_host(np.stack([L, R])[None])[0]

@@ -121,7 +121,7 @@ def test_photographs_every_lsd_schedule(gpu, mode, monkeypatch):
         for name in PHOTO_NAMES + ["motorcycle_left", "motorcycle_right"]:
             img = ph[name]
             H, W = img.shape
-            cfg = g.capi.default_config(W, H, orb_nfeatures=300, lsd_nfeatures=0, max_lines=4000, max_frames=1, lsd_mode=mode)
+            cfg = g.capi.default_config(W, H, orb_nfeatures=300, lsd_nfeatures=0, max_frames=1, lsd_mode=mode)
             fe = g.Frontend(cfg)
             n, kl, ld = fe.line_extract(0, img)
             m, okl, old = g.po.Frame(ocfg(g, cfg)).line_extract(0, img)
