@@ -614,7 +614,7 @@ __global__ __launch_bounds__(256) void k_tx_prep(RxCtl* __restrict__ ctl, int2* 
 // already without the lanes up to j2).
 // ---------------------------------------------------------------------------
 // Diagnostic builds (make EXTRA=-DTX_DIAG_PAD=n, never shipped): n x 4 idle VALU instructions (or, negative, |n| x 4 idle SALU
-// instructions) per accepted pixel — how the kernel's time follows its instruction count.
+// instructions) per iteration of the accept loop (at its top, where no hazard slot hides them) — how the kernel's time follows its instruction count.
 #ifndef TX_DIAG_PAD
 #define TX_DIAG_PAD_ASM
 #elif TX_DIAG_PAD == 1
@@ -643,6 +643,7 @@ __device__ __forceinline__ int tx_accept_fast(float& sumdx, float& sumdy, float 
   hi = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hi)));
   asm volatile(
       "1:\n\t"
+      TX_DIAG_PAD_ASM
       "v_mul_f32_e32 %[t0], %[sy], %[sy]\n\t"
       "v_mul_f32_e32 %[t1], %[sy], %[sn]\n\t"
       "v_fmac_f32_e32 %[t0], %[sx], %[sx]\n\t"
@@ -664,7 +665,6 @@ __device__ __forceinline__ int tx_accept_fast(float& sumdx, float& sumdy, float 
       "v_readlane_b32 %[xy], %[mxy], %[j]\n\t"
       "s_bitset1_b64 %[acc], %[j]\n\t"
       "s_add_i32 %[cnt], %[cnt], 1\n\t"
-      TX_DIAG_PAD_ASM
       "v_add_f32_e32 %[sx], %[sc], %[sx]\n\t"
       "v_add_f32_e32 %[sy], %[ss], %[sy]\n\t"
       "v_cmp_eq_u32_e32 vcc, %[xy], %[sp]\n\t"
@@ -922,7 +922,11 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
           }
         }
         if (accepted) {
+#if defined(TX_DIAG_NOWAIT)     // diagnostic build (NOT exact: contested claims go unnoticed): non-returning claims, nothing to wait for
+          (void)__hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
+#else
           pendOld = __hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
+#endif
           // (the pixel's own rank, which an unclaimed owner word holds: in round 1 owner_0 is the trivial map, so the word just read has it)
           if (noteLost) pendRank = (SPARSE || t != 1) ? rankOfPix[qi] : prevv;
           // (later rounds) the 8x8 cell of every claimed pixel is noted: the next round's k_rx_diff only looks where a claim or the
