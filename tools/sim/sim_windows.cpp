@@ -113,6 +113,198 @@ int main(int argc, char** argv) {
   std::vector<std::vector<int>> tileSeeds(NT);
   for (int r = 0; r < R; ++r) { const int p = F.order[r]; tileSeeds[(p / W / TS) * TW + (p % W) / TS].push_back(r); }
 
+  // ---- shared first steps (round-4 idea): the alive seeds of a 64-entry list row start in groups of up to G; the first step of
+  // a group's members (the seed's 8 neighbours) is decided against the state at group time — the members do not see each other —,
+  // their claims go out together (lowest rank wins a pixel, the loser is noted), then the members continue one after the other
+  // in rank order.  Counted: regions started, first steps saved (members - groups), members whose seed a lower member took,
+  // regions that lose a pixel to a lower rank AFTER claiming it (they are regrown in round 2), pixels wrong after the round.
+  for (int G : {1, 4, 8}) {
+    std::vector<int> own(N, INT32_MAX);
+    std::vector<char> lost(R, 0);
+    long regionsStarted = 0, groups = 0, members = 0, deadInGroup = 0, steps = 0, firstSteps = 0;
+    auto claim = [&](int q, int r) {
+      if (own[q] != INT32_MAX && own[q] > r) lost[own[q]] = 1;
+      if (own[q] < r) lost[r] = 1;
+      own[q] = std::min(own[q], r);
+    };
+    // tiles in a round-robin of rows (all tiles advance one row at a time: a coarse stand-in for concurrent tile waves)
+    size_t maxRows = 0;
+    for (auto& S : tileSeeds) maxRows = std::max(maxRows, (S.size() + 63) / 64);
+    for (size_t row = 0; row < maxRows; ++row)
+      for (int T = 0; T < NT; ++T) {
+        const std::vector<int>& S = tileSeeds[T];
+        if (row * 64 >= S.size()) continue;
+        const size_t e = std::min(S.size(), row * 64 + 64);
+        std::vector<int> alive;
+        for (size_t i = row * 64; i < e; ++i) if (own[F.order[S[i]]] >= S[i]) alive.push_back(S[i]);   // (alive at the row fetch)
+        size_t a = 0;
+        while (a < alive.size()) {
+          // the next group: up to G seeds that are still alive now
+          std::vector<int> grp;
+          while (a < alive.size() && (int)grp.size() < G) { const int r = alive[a++]; if (own[F.order[r]] >= r) grp.push_back(r); }
+          if (grp.empty()) break;
+          ++groups; members += (long)grp.size();
+          // first steps against the state at group time
+          std::vector<std::vector<int>> firstAcc(grp.size());
+          std::vector<float> sdx(grp.size()), sdy(grp.size());
+          const std::vector<int> snap = own;                    // (small images: a copy per group is affordable)
+          for (size_t m = 0; m < grp.size(); ++m) {
+            const int r = grp[m], sp = F.order[r], px = sp % W, py = sp / W;
+            double reg_angle = F.ang[sp];
+            float sx = float(std::cos(reg_angle)), sy = float(std::sin(reg_angle));
+            for (int yy = std::max(py - 1, 0); yy <= std::min(py + 1, H - 1); ++yy)
+              for (int xx = std::max(px - 1, 0); xx <= std::min(px + 1, W - 1); ++xx) {
+                const int q = yy * W + xx;
+                if (q == sp) continue;
+                const bool used = snap[q] < r || F.rankOf[q] < r;
+                if (!used && aligned(F, q, reg_angle)) {
+                  firstAcc[m].push_back(q);
+                  sx += F.c[q]; sy += F.s[q];
+                  reg_angle = fastAtan2(sy, sx) * kDEG_TO_RADS;
+                }
+              }
+            sdx[m] = sx; sdy[m] = sy;
+          }
+          ++firstSteps;
+          // a member whose seed a lower member accepted is dropped before the claims
+          std::vector<char> dead(grp.size(), 0);
+          for (size_t m = 1; m < grp.size(); ++m)
+            for (size_t l = 0; l < m && !dead[m]; ++l)
+              if (!dead[l]) for (int q : firstAcc[l]) if (q == F.order[grp[m]]) { dead[m] = 1; break; }
+          for (size_t m = 0; m < grp.size(); ++m) {
+            if (dead[m]) { ++deadInGroup; continue; }
+            claim(F.order[grp[m]], grp[m]);
+            for (int q : firstAcc[m]) claim(q, grp[m]);
+          }
+          // continuations, one after the other in rank order (a member that lost its seed in the meantime does not continue)
+          for (size_t m = 0; m < grp.size(); ++m) {
+            if (dead[m]) continue;
+            const int r = grp[m], sp = F.order[r];
+            ++regionsStarted;
+            if (own[sp] != r) continue;
+            // continue the BFS from the first step's state: queue = seed + first accepts, k = 1
+            std::vector<int> regq; regq.push_back(sp);
+            for (int q : firstAcc[m]) regq.push_back(q);
+            float sx = sdx[m], sy = sdy[m];
+            double reg_angle = regq.size() > 1 ? fastAtan2(sy, sx) * kDEG_TO_RADS : F.ang[sp];
+            size_t k = 1;
+            while (k < regq.size()) {
+              const size_t nb = std::min<size_t>(8, regq.size() - k);
+              ++steps;
+              for (size_t e2 = k; e2 < k + nb; ++e2) {
+                const int px = regq[e2] % W, py = regq[e2] / W;
+                for (int yy = std::max(py - 1, 0); yy <= std::min(py + 1, H - 1); ++yy)
+                  for (int xx = std::max(px - 1, 0); xx <= std::min(px + 1, W - 1); ++xx) {
+                    const int q = yy * W + xx;
+                    const bool used = own[q] <= r || F.rankOf[q] < r;
+                    if (!used && aligned(F, q, reg_angle)) {
+                      claim(q, r);
+                      regq.push_back(q);
+                      sx += F.c[q]; sy += F.s[q];
+                      reg_angle = fastAtan2(sy, sx) * kDEG_TO_RADS;
+                    }
+                  }
+              }
+              k += nb;
+            }
+          }
+        }
+      }
+    long wrong = 0, losers = 0;
+    for (int q = 0; q < N; ++q) wrong += own[q] != truth[q];
+    for (int r = 0; r < R; ++r) losers += lost[r];
+    std::printf("shared first steps, groups of %d: %ld regions started in %ld groups (%.2f per group), %ld members dropped (seed taken in the group), first steps %ld "
+                "+ later steps %ld = %ld (sequential: %ld); regions that lost a claimed pixel %ld; wrong after round 1 %ld px\n",
+                G, regionsStarted, groups, (double)members / groups, deadInGroup, firstSteps, steps, firstSteps + steps, seqSteps, losers, wrong);
+  }
+  // ---- the same with the members' claims DEFERRED to their turn: at its turn a member's first step stands iff its seed is still its
+  // own and none of the pixels it accepted has been claimed by a lower rank since the group formed (what it rejected stays rejected:
+  // owners only go down within a round); a member whose first step does not stand starts again from its seed.  No speculative claim
+  // ever reaches the owner map, so nothing is regrown because of the grouping.
+  for (int G : {4, 8}) {
+    std::vector<int> own(N, INT32_MAX);
+    std::vector<char> lost(R, 0);
+    long regionsStarted = 0, groups = 0, members = 0, redo = 0, steps = 0, firstSteps = 0, onePix = 0, seedGone = 0;
+    auto claim = [&](int q, int r) {
+      if (own[q] != INT32_MAX && own[q] > r) lost[own[q]] = 1;
+      if (own[q] < r) lost[r] = 1;
+      own[q] = std::min(own[q], r);
+    };
+    size_t maxRows = 0;
+    for (auto& S : tileSeeds) maxRows = std::max(maxRows, (S.size() + 63) / 64);
+    for (size_t row = 0; row < maxRows; ++row)
+      for (int T = 0; T < NT; ++T) {
+        const std::vector<int>& S = tileSeeds[T];
+        if (row * 64 >= S.size()) continue;
+        const size_t e = std::min(S.size(), row * 64 + 64);
+        std::vector<int> alive;
+        for (size_t i = row * 64; i < e; ++i) if (own[F.order[S[i]]] >= S[i]) alive.push_back(S[i]);
+        size_t a = 0;
+        while (a < alive.size()) {
+          std::vector<int> grp;
+          while (a < alive.size() && (int)grp.size() < G) { const int r = alive[a++]; if (own[F.order[r]] >= r) grp.push_back(r); }
+          if (grp.empty()) break;
+          ++groups; members += (long)grp.size(); ++firstSteps;
+          std::vector<std::vector<int>> firstAcc(grp.size());
+          std::vector<float> sdx(grp.size()), sdy(grp.size());
+          for (size_t m = 0; m < grp.size(); ++m) {                 // (nothing is claimed here: the state is the same for every member)
+            const int r = grp[m], sp = F.order[r], px = sp % W, py = sp / W;
+            double reg_angle = F.ang[sp];
+            float sx = float(std::cos(reg_angle)), sy = float(std::sin(reg_angle));
+            for (int yy = std::max(py - 1, 0); yy <= std::min(py + 1, H - 1); ++yy)
+              for (int xx = std::max(px - 1, 0); xx <= std::min(px + 1, W - 1); ++xx) {
+                const int q = yy * W + xx;
+                if (q == sp) continue;
+                const bool used = own[q] < r || F.rankOf[q] < r;
+                if (!used && aligned(F, q, reg_angle)) { firstAcc[m].push_back(q); sx += F.c[q]; sy += F.s[q]; reg_angle = fastAtan2(sy, sx) * kDEG_TO_RADS; }
+              }
+            sdx[m] = sx; sdy[m] = sy;
+          }
+          for (size_t m = 0; m < grp.size(); ++m) {
+            const int r = grp[m], sp = F.order[r];
+            if (own[sp] < r) { ++seedGone; continue; }               // taken by a lower member in the meantime
+            ++regionsStarted;
+            bool stands = true;
+            for (int q : firstAcc[m]) if (own[q] < r) { stands = false; break; }
+            std::vector<int> regq; regq.push_back(sp);
+            float sx, sy; double reg_angle; size_t k;
+            claim(sp, r);
+            if (stands) {
+              for (int q : firstAcc[m]) { claim(q, r); regq.push_back(q); }
+              sx = sdx[m]; sy = sdy[m];
+              reg_angle = regq.size() > 1 ? fastAtan2(sy, sx) * kDEG_TO_RADS : F.ang[sp];
+              k = 1;
+              if (regq.size() == 1) ++onePix;
+            } else {
+              ++redo;
+              reg_angle = F.ang[sp]; sx = float(std::cos(reg_angle)); sy = float(std::sin(reg_angle)); k = 0;
+            }
+            while (k < regq.size()) {
+              const size_t nb = std::min<size_t>(8, regq.size() - k);
+              ++steps;
+              for (size_t e2 = k; e2 < k + nb; ++e2) {
+                const int px = regq[e2] % W, py = regq[e2] / W;
+                for (int yy = std::max(py - 1, 0); yy <= std::min(py + 1, H - 1); ++yy)
+                  for (int xx = std::max(px - 1, 0); xx <= std::min(px + 1, W - 1); ++xx) {
+                    const int q = yy * W + xx;
+                    const bool used = own[q] <= r || F.rankOf[q] < r;
+                    if (!used && aligned(F, q, reg_angle)) { claim(q, r); regq.push_back(q); sx += F.c[q]; sy += F.s[q]; reg_angle = fastAtan2(sy, sx) * kDEG_TO_RADS; }
+                  }
+              }
+              k += nb;
+            }
+          }
+        }
+      }
+    long wrong = 0, losers = 0;
+    for (int q = 0; q < N; ++q) wrong += own[q] != truth[q];
+    for (int r = 0; r < R; ++r) losers += lost[r];
+    std::printf("shared first steps, claims deferred, groups of %d: %ld regions in %ld groups (%.2f per group), %ld members found their seed gone, %ld first steps "
+                "redone, %ld one-pixel regions closed without a step of their own; shared steps %ld + later steps %ld = %ld (sequential %ld); regions that lost a "
+                "claimed pixel %ld; wrong after round 1 %ld px\n", G, regionsStarted, groups, (double)members / groups, seedGone, redo, onePix, firstSteps, steps,
+                firstSteps + steps, seqSteps, losers, wrong);
+  }
+  if (getenv("SIMW_GROUPS_ONLY")) return 0;
   const int Ks[] = {1, 8, 32, 128, 512, 2048, 0};
   for (int K : Ks) {
     auto winOf = [&](int r) -> int { return K == 0 ? binOf[r] : (int)((long)r * K / R); };
