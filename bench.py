@@ -587,8 +587,7 @@ def main():
                 issue = {"valu_issue_frac": iq["active_valu_quad_cycles"] / simd_quads, "valu_wave_instructions": iq["valu"],
                          "salu_wave_instructions": iq["salu"], "launch_ns_under_profiler": iq["avg_ns"], "source": os.path.basename(tpath),
                          "note": "SQ_ACTIVE_INST_VALU / (1024 SIMDs x quad-cycles of the launch): the share of the chip's VALU issue "
-                                 "time the kernel uses; a kernel near 0.7-0.8 with 8 waves per SIMD is bound by its INSTRUCTION COUNT, "
-                                 "not by HBM"}
+                                 "time the kernel uses (profiler run, 2.4 GHz assumed)"}
             if k:
                 # FETCH_SIZE counts 32-byte units for streaming kernels on gfx950 (MI355X_MICROARCH.md: x2) but 64 bytes per request
                 # of the growers' 8-byte gathers (TCC_MISS x 64 B agrees with the undoubled figure, profiles/README.md)
@@ -623,9 +622,10 @@ def main():
                 "frac": (achieved / peak) if achieved is not None else None, "traffic": traffic, "sector_requests": sector,
                 # the HBM roofline is the contract's; what actually limits the dominant kernel (an 8-byte-gather region grower) is
                 # the chip's instruction issue: `issue` carries the measured VALU-issue fraction, `limiter` says it in a word
-                "limiter": ("VALU instruction issue (not HBM): see issue.valu_issue_frac" if issue and issue["valu_issue_frac"] > 0.5
-                            else ("instruction issue / dependent latency (no committed SQ pass for this workload)" if name and
-                                  name.startswith(("k_tx_grow", "k_lsd_grow", "k_rx_grow")) else "hbm")),
+                "limiter": ("dependent memory round trips per batched step at the occupancy limit of 8 waves per SIMD (waves parked in "
+                            "s_waitcnt 71 % of their cycles; +20 % instructions cost +4 % time, one more round trip per region +10 %: "
+                            "DESIGN.md 5 'Round 4'), neither HBM bandwidth nor instruction issue"
+                            if name and name.startswith(("k_tx_grow", "k_lsd_grow", "k_rx_grow")) else "hbm"),
                 "issue": issue, "step_traffic": step_traffic,
                 "avg_launch_ms": avg_s * 1e3, "launches": calls,
                 "path_achieved": fps / world * b_frame / 1e9, "path_frac": fps / world * b_frame / 1e9 / peak,

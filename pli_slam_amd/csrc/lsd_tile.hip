@@ -832,6 +832,15 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
           rr = rec[qi];
           oo = tx_load_own(&own[qi]);
         }
+#if defined(TX_DIAG_TRIP)     // diagnostic build: the FIRST step of every region makes its load round trip twice (what is one trip per region worth?)
+        if (k == 0 && cnt == 1 && ok) {
+          asm volatile("" ::"v"(rr.x), "v"(oo.x) : "memory");
+          const float4 r2 = rec[qi + (__float_as_int(rr.x) == 0x7fc01234 ? 1 : 0)];      // (address depends on the first trip's data)
+          const int2 o2 = tx_load_own(&own[qi + (oo.x == 0x7fc01234 ? 1 : 0)]);
+          asm volatile("" ::"v"(r2.x), "v"(o2.x) : "memory");
+          if (__float_as_int(r2.y) == 0x7fc01234 && o2.y == 0x12345678) rr.x = r2.x;      // (never true; keeps the loads)
+        }
+#endif
         const int prevv = ci ? oo.x : oo.y, curv = ci ? oo.y : oo.x;
         const bool cand = ok && rr.x != TX_NOTDEF && !(prevv < r || curv <= r);
         unsigned long long remaining = __builtin_amdgcn_ballot_w64(cand);
