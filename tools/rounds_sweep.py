@@ -2,7 +2,9 @@
 """Round-count robustness of the LSD relaxation: batches of 256 DISTINCT seeded stereo pairs, and the hostile
 images of tests/test_gpu_parity.py::test_lsd_hostile_images at 752x480, through `lsd_mode` auto at F = 256.  Per batch: the rounds
 the slowest image needed, the rounds launched without a host look, images that took the device-side fallback, ms per step.
-  python tools/rounds_sweep.py [nbatches] > profiles/r03_rounds_sweep.json
+  python tools/rounds_sweep.py [nbatches] > profiles/rNN_rounds_sweep.json
+  python tools/rounds_sweep.py --real [nbatches] > profiles/rNN_rounds_real.json     batches of 256 DISTINCT 752x480 windows of the real
+                                   photographs (pli_slam_amd/realdata.py), and every photograph alone (one window of it filling a batch)
 """
 import json
 import os
@@ -18,6 +20,9 @@ from pli_slam_amd import capi, synth
 from pli_slam_amd.frontend import Frontend
 
 W, H, F = 752, 480, 256
+REAL = len(sys.argv) > 1 and sys.argv[1] == "--real"
+if REAL:
+    del sys.argv[1]
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 cfg = capi.default_config(W, H, orb_nfeatures=1200, lsd_nfeatures=100, max_frames=F)
 fe = Frontend(cfg)
@@ -41,6 +46,23 @@ def run(images, reps=3):
     return out
 
 
+if REAL:
+    from pli_slam_amd import realdata
+    res = {"workload": "752x480 windows of real photographs (tests/golden/real), 1200 kp + <=100 lines, F = 256, lsd_mode auto", "batches": []}
+    for b in range(nb):
+        frames = realdata.frames_752x480(F, seed=100 + b)
+        res["batches"].append({"frames": "256 distinct windows, seed %d" % (100 + b), "calls": run(np.stack([np.stack(p) for p in frames]))})
+    names = sorted(k for k in realdata.photos() if k != "motorcycle_right")
+    for i, name in enumerate(names):          # one photograph at a time: frames i, i + 13, ... of a seeded set are windows of photograph i
+        frames = [f for j, f in enumerate(realdata.frames_752x480(len(names) * 8, seed=7)) if j % len(names) == i]
+        images = np.stack([np.stack(frames[j % len(frames)]) for j in range(F)])
+        res["batches"].append({"frames": "photograph %s: 8 windows, cycled" % name, "calls": run(images, reps=2)})
+    needed = [c["needed"] for b in res["batches"] for c in b["calls"]]
+    ms = [c["ms"] for b in res["batches"][:nb] for c in b["calls"][1:]]
+    res["summary"] = {"rounds_min": min(needed), "rounds_max": max(needed), "ms_median_of_the_mixed_batches": float(np.median(ms)),
+                      "fallback_images_total": res["batches"][-1]["calls"][-1]["fallback_images_total"]}
+    print(json.dumps(res, indent=1))
+    sys.exit(0)
 res = {"workload": "752x480, 1200 kp + <=100 lines, F = 256, lsd_mode auto", "batches": []}
 with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as ex:
     for b in range(nb):
