@@ -600,10 +600,12 @@ pli_status allocAll(pli_ctx* c) {
     // queue overflow blocks for every region of more than TX_GQ pixels that is being grown, by EVERY tile it has seeds in at the
     // same time in round 1: long parallel structures (blinds, corrugated walls; the "stripes" image of the tests) multiply that
     // by the tiles a region crosses.  3 words per pixel sent all 512 stripes images to the sequential grower (455 ms per batch
-    // instead of 50); they need < 16, which is what a context gets as long as its arenas stay below 8 GiB (256 frames of 752 x 480:
-    // 7.6 GB; the contexts of thousands of images keep 3-4 words).
+    // instead of 50); they need < 16 (8 is not enough: round 3's last commit budgeted 8 GiB, which gave the 256-frame context 8 words,
+    // and the stripes batch took the fallback again, 507 ms — found by tools/rounds_sweep.py in round 4).  A context gets 16 words per
+    // pixel as long as its arenas stay below 18 GiB (256 frames of 752 x 480: 17.0 GB of the 288 GB HBM); larger contexts share that
+    // budget (512 frames: 8 words, thousands of images: 3-4).
     size_t arenaFactor = lane ? 8 : 16;
-    if (!lane) arenaFactor = std::max<size_t>(3, std::min<size_t>(16, ((size_t)8 << 30) / (npix * 4 * NR)));
+    if (!lane) arenaFactor = std::max<size_t>(3, std::min<size_t>(16, ((size_t)18 << 30) / (npix * 4 * NR)));
     if (const char* e = getenv("PLI_RX_ARENA")) arenaFactor = (size_t)std::max(1, atoi(e));     // dev: words of arena per scaled pixel
     c->arenaCap = (int)std::min<size_t>(arenaFactor * npix + 65536, (size_t)1 << 30);
     A(c->arena, (size_t)c->arenaCap * NR);

@@ -580,6 +580,25 @@ def test_long_parallel_structures_settle_without_the_fallback(gpu, monkeypatch):
         monkeypatch.delenv("PLI_RX_ARENA", raising=False)
 
 
+def test_stripes_in_a_256_frame_context_do_not_take_the_fallback(gpu):
+    """The arena a context gets per image depends on how many images it is sized for.  The bench's context (256 frames) must keep
+    the 16 words per pixel long parallel structures need: with 8 (round 3's last commit) every stripes image overflowed and was
+    redone by the sequential grower — exact, ten times slower, and only tools/rounds_sweep.py noticed."""
+    g = gpu
+    W, H = 752, 480
+    yy, xx = np.mgrid[0:H, 0:W]
+    stripes = ((np.sin((xx + 2 * yy) / 5.0) * 0.5 + 0.5) * 255).astype(np.uint8)
+    cfg = g.capi.default_config(W, H, orb_nfeatures=300, lsd_nfeatures=0, max_frames=256)
+    fe = g.Frontend(cfg)
+    batch = np.broadcast_to(stripes, (2, 2, H, W)).copy()
+    for _ in range(2):
+        recs = fe.batch_run_host(batch, stages=g.capi.RUN_LINES)
+    st = fe.lsd_round_stats()
+    assert st[2] == 0 and 0 < st[1] <= 8, "stripes in the 256-frame context: round stats %s" % (st,)
+    m, kl, ld = g.po.Frame(ocfg(g, cfg)).line_extract(0, stripes)
+    assert len(recs[0]["klL"]) == m and recs[0]["klL"].tobytes() == kl.tobytes()
+
+
 def test_full_size_batch_properties(gpu):
     """BASELINE config at batch scale (96 EuRoC-size frames, 8 distinct pairs cycled), through size-independent
     properties: the two LSD schedules write byte-identical tables; a frame's record does not depend on its position
