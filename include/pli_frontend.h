@@ -500,6 +500,13 @@ pli_status pli_bow_transform(pli_ctx* ctx, const pli_vocab* vocab, const uint8_t
 /* ------------------------------------------------------------------------ */
 /* Measurement hooks (bench.py / tests only).                                */
 /* ------------------------------------------------------------------------ */
+/* Tracing: with PLI_ROCTX=1 in the environment when the library is loaded, every entry point, every stage of a call
+ * (ingest, ORB chain, line chain, stereo matchers) and every kernel launch is bracketed by roctxRangePush / roctxRangePop
+ * (rocprofiler-sdk's marker library, found at run time), so that `rocprofv3 --kernel-trace --marker-trace -- <program>` shows which
+ * call and stage a kernel belongs to.  Without the switch nothing is loaded and nothing is pushed.  Returns the number of ranges
+ * pushed so far by this process (0 when tracing is off). */
+int64_t pli_trace_ranges(void);
+
 /* When enabled every kernel launch of the context is bracketed by HIP events on
  * the context stream; pli_prof_report writes "name calls total_ms\n" lines. */
 pli_status pli_prof_enable(pli_ctx* ctx, int32_t on);

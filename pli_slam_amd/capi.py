@@ -155,6 +155,7 @@ _PROTOS = {
     "pli_debug_fetch": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
                                     C.POINTER(C.c_int64)]),
     "pli_version": (C.c_char_p, []),
+    "pli_trace_ranges": (C.c_int64, []),
 }
 
 

@@ -13,6 +13,8 @@
 #include <string>
 #include <functional>
 #include <mutex>
+#include <atomic>
+#include <dlfcn.h>
 
 using namespace pli;
 
@@ -194,6 +196,39 @@ struct pli_ctx {
   }
 };
 
+// roctx ranges ("rocprofv3 counters + roctx ranges per kernel").  With PLI_ROCTX=1 in the environment every stage of a call
+// (ingest, ORB chain, line chain, the two stereo matchers, the entry points themselves) and every kernel launch is bracketed by
+// roctxRangePush / roctxRangePop, so that `rocprofv3 --kernel-trace --marker-trace` shows which call and stage a kernel belongs
+// to.  The marker library is looked up at run time (rocprofiler-sdk's, then roctracer's): no link-time dependency, nothing is
+// loaded and nothing is pushed without the switch.  pli_trace_ranges() counts the ranges pushed so far.
+struct PliRoctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  std::atomic<long long> pushed{0};
+  PliRoctx() {
+    const char* e = getenv("PLI_ROCTX");
+    if (!e || atoi(e) == 0) return;
+    for (const char* lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+      void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+      if (!h) continue;
+      push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+      pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+      if (push && pop) break;
+      push = nullptr; pop = nullptr;
+    }
+  }
+};
+static PliRoctx g_roctx;
+struct TraceRange {
+  bool on;
+  explicit TraceRange(const char* name) : on(g_roctx.push != nullptr) {
+    if (on) { g_roctx.push(name); g_roctx.pushed.fetch_add(1, std::memory_order_relaxed); }
+  }
+  ~TraceRange() { if (on) g_roctx.pop(); }
+  TraceRange(const TraceRange&) = delete;
+  TraceRange& operator=(const TraceRange&) = delete;
+};
+
 // the last k_tx_tail launch on every device of this process (see the launch site)
 static std::mutex g_tailMu;
 static hipEvent_t g_tailEv[64] = {};
@@ -208,6 +243,7 @@ struct CtxGuard {
 
 #define LAUNCH(c, name, kern, grid, block, shmem, ...)                       \
   do {                                                                       \
+    TraceRange tr__(name);                                                   \
     (c)->profBegin(name);                                                    \
     hipLaunchKernelGGL(kern, grid, block, shmem, (c)->stream, __VA_ARGS__);  \
     (c)->profEnd();                                                          \
@@ -706,6 +742,7 @@ int foldRoundStats(pli_ctx* c) {
 }
 
 pli_status runIngest(pli_ctx* c, const uint8_t* dl, const uint8_t* dr, int64_t stride, int64_t frameStride, int img0, int nimg) {
+  TraceRange range__("pli:ingest");
   const DevParams& P = c->hp;
   const bool aligned16 = !c->rectMap[0] && !c->rectMap[1] && (P.W % 16) == 0 && (stride % 16) == 0 && (frameStride % 16) == 0 &&
                          (reinterpret_cast<uintptr_t>(dl) % 16) == 0 && (reinterpret_cast<uintptr_t>(dr) % 16) == 0 && (P.lv[0].pitch % 16) == 0 &&
@@ -723,6 +760,7 @@ pli_status runIngest(pli_ctx* c, const uint8_t* dl, const uint8_t* dr, int64_t s
 }
 
 pli_status runOrb(pli_ctx* c, int img0, int nimg, uint8_t* table) {
+  TraceRange range__("pli:orb chain");
   const DevParams& P = c->hp;
   const pli_table_layout& Y = c->lay;
   for (int l = 1; l < P.nlevels; ++l) {
@@ -770,6 +808,7 @@ pli_status runOrb(pli_ctx* c, int img0, int nimg, uint8_t* table) {
 // needs the image only, not the lines: pli_batch_run puts it on the side stream (after the ORB chain) when the LSD front does
 // not use the u8 scratch plane itself (CV_64F detector).
 pli_status runLbdPre(pli_ctx* c, int img0, int nimg) {
+  TraceRange range__("pli:lbd blur+sobel");
   const DevParams& P = c->hp;
   LAUNCH(c, "k_blur_lbd", k_blur, dim3(c->l0Tiles, nimg), dim3(256), 0, c->jobLbd, c->pyr, P.pyrBlock, c->tmp8, c->tmp8Stride, img0);
   dim3 g((P.W + 1023) / 1024, P.H, nimg);
@@ -778,6 +817,7 @@ pli_status runLbdPre(pli_ctx* c, int img0, int nimg) {
 }
 
 pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
+  TraceRange range__("pli:line chain");
   const DevParams& P = c->hp;
   const pli_table_layout& Y = c->lay;
   const int npix = P.LW * P.LH;
@@ -1201,6 +1241,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
 }
 
 pli_status runStereoPoints(pli_ctx* c, int nframes, uint8_t* table) {
+  TraceRange range__("pli:stereo points");
   const DevParams& P = c->hp;
   const pli_table_layout& Y = c->lay;
   LAUNCH(c, "k_stereo_points", k_stereo_points, dim3(P.kpCap, nframes), dim3(64), 0, c->dP, c->pyr, table, Y.record_bytes,
@@ -1212,6 +1253,7 @@ pli_status runStereoPoints(pli_ctx* c, int nframes, uint8_t* table) {
 }
 
 pli_status runStereoLines(pli_ctx* c, int nframes, uint8_t* table) {
+  TraceRange range__("pli:stereo lines");
   const pli_table_layout& Y = c->lay;
   // (many lines per frame: the pair distances by several workgroups per frame, see the kernel)
   const int cap = c->hp.klCap;
@@ -1389,6 +1431,7 @@ pli_status pli_ctx_sync(pli_ctx* c) {
 pli_status pli_batch_run(pli_ctx* c, int32_t nframes, const uint8_t* dl, const uint8_t* dr, int64_t stride,
                          int64_t frameStride, uint32_t stages, void* table) {
   CtxGuard guard__(c);
+  TraceRange range__("pli_batch_run");
   if (!c || !dl || !dr || !table) { g_err = "null argument"; return PLI_ERR_INVALID; }
   if (nframes < 1 || nframes > c->cfg.max_frames) { g_err = "nframes exceeds the context's max_frames"; return PLI_ERR_INVALID; }
   if (stride < c->cfg.width) { g_err = "stride < width"; return PLI_ERR_INVALID; }
@@ -1470,6 +1513,7 @@ pli_status pli_batch_run(pli_ctx* c, int32_t nframes, const uint8_t* dl, const u
 pli_status pli_batch_run_host(pli_ctx* c, int32_t nframes, const uint8_t* left, const uint8_t* right, int64_t stride,
                               int64_t frameStride, uint32_t stages, void* table) {
   CtxGuard guard__(c);
+  TraceRange range__("pli_batch_run_host");
   if (!c || !left || !right || !table) { g_err = "null argument"; return PLI_ERR_INVALID; }
   if (nframes < 1 || nframes > c->cfg.max_frames) { g_err = "nframes exceeds the context's max_frames"; return PLI_ERR_INVALID; }
   HIPCHK(hipSetDevice(c->device));
@@ -1496,6 +1540,7 @@ pli_status pli_batch_run_host(pli_ctx* c, int32_t nframes, const uint8_t* left, 
 pli_status pli_frame_extract(pli_ctx* c, const uint8_t* left, const uint8_t* right, int32_t w, int32_t h, int64_t strideLeft,
                              int64_t strideRight, void* record) {
   CtxGuard guard__(c);
+  TraceRange range__("pli_frame_extract");
   if (!c || !record) { g_err = "null argument"; return PLI_ERR_INVALID; }
   pli_status st = checkImage(c, left, w, h, strideLeft);
   if (st != PLI_OK) return st;
@@ -1556,6 +1601,7 @@ pli_status pli_batch_wait(pli_ctx* c, int32_t all) {
 pli_status pli_batch_submit_host(pli_ctx* c, int32_t nframes, const uint8_t* left, const uint8_t* right, int64_t stride,
                                  int64_t frameStride, uint32_t stages, void* table) {
   CtxGuard guard__(c);
+  TraceRange range__("pli_batch_submit_host");
   if (!c || !left || !right || !table) { g_err = "null argument"; return PLI_ERR_INVALID; }
   if (nframes < 1 || nframes > c->cfg.max_frames) { g_err = "nframes exceeds the context's max_frames"; return PLI_ERR_INVALID; }
   if (stride < c->cfg.width) { g_err = "stride < width"; return PLI_ERR_INVALID; }
@@ -1606,6 +1652,7 @@ pli_status pli_batch_submit_host(pli_ctx* c, int32_t nframes, const uint8_t* lef
 pli_status pli_orb_extract(pli_ctx* c, int32_t eye, const uint8_t* img, int32_t w, int32_t h, int64_t stride,
                            pli_keypoint* kp, int32_t cap, uint8_t* desc, int32_t* n) {
   CtxGuard guard__(c);
+  TraceRange range__("pli_orb_extract");
   if (!c || eye < 0 || eye > 1 || !n) { g_err = "bad argument"; return PLI_ERR_INVALID; }
   *n = 0;
   pli_status st = checkImage(c, img, w, h, stride);
@@ -1659,6 +1706,7 @@ pli_status pli_orb_pyramid_level(pli_ctx* c, int32_t eye, int32_t level, uint8_t
 pli_status pli_line_extract(pli_ctx* c, int32_t eye, const uint8_t* img, int32_t w, int32_t h, int64_t stride,
                             pli_keyline* kl, int32_t cap, uint8_t* desc, int32_t* n) {
   CtxGuard guard__(c);
+  TraceRange range__("pli_line_extract");
   if (!c || eye < 0 || eye > 1 || !n) { g_err = "bad argument"; return PLI_ERR_INVALID; }
   *n = 0;
   pli_status st = checkImage(c, img, w, h, stride);
@@ -1728,6 +1776,7 @@ pli_status pli_last_counts(pli_ctx* c, int32_t counts[4]) {
 
 pli_status pli_stereo_match_points(pli_ctx* c, float* uright, float* depth, int32_t cap) {
   CtxGuard guard__(c);
+  TraceRange range__("pli_stereo_match_points");
   if (!c) return PLI_ERR_INVALID;
   if (!c->orbDone[0] || !c->orbDone[1]) { g_err = "pli_orb_extract must run for both eyes first"; return PLI_ERR_STATE; }
   if (c->frameFresh && c->pointsFresh) {                // (pli_frame_extract has matched already, with this rig)
@@ -1925,6 +1974,7 @@ pli_status pli_stereo_fisheye_tables(pli_ctx* c, const pli_keypoint* kpL, const 
 
 pli_status pli_stereo_match_lines(pli_ctx* c, float* disp, double* le, int32_t cap) {
   CtxGuard guard__(c);
+  TraceRange range__("pli_stereo_match_lines");
   if (!c) return PLI_ERR_INVALID;
   if (!c->lineDone[0] || !c->lineDone[1]) { g_err = "pli_line_extract must run for both eyes first"; return PLI_ERR_STATE; }
   if (c->frameFresh) {                                  // (pli_frame_extract has matched already)
@@ -2217,6 +2267,7 @@ pli_status pli_track_layout_get(const pli_ctx* c, pli_track_layout* out) {
 pli_status pli_batch_track(pli_ctx* c, int32_t nframes, const void* table, const float* poses, const pli_track_params* tpar,
                            void* track) {
   CtxGuard guard__(c);
+  TraceRange range__("pli_batch_track");
   if (!c || !table || !poses || !tpar || !track) { g_err = "null argument"; return PLI_ERR_INVALID; }
   if (nframes < 1 || nframes > c->cfg.max_frames) { g_err = "nframes exceeds the context's max_frames"; return PLI_ERR_INVALID; }
   if (!(tpar->max_x > tpar->min_x) || !(tpar->max_y > tpar->min_y) || !(tpar->fx > 0) || !(tpar->fy > 0)) { g_err = "bad track parameters"; return PLI_ERR_INVALID; }
@@ -2331,6 +2382,8 @@ pli_status pli_bow_transform(pli_ctx* c, const pli_vocab* v, const uint8_t* desc
 }
 
 // ---- measurement -----------------------------------------------------------
+int64_t pli_trace_ranges(void) { return (int64_t)g_roctx.pushed.load(std::memory_order_relaxed); }
+
 pli_status pli_prof_enable(pli_ctx* c, int32_t on) {
   CtxGuard guard__(c);
   if (!c) return PLI_ERR_INVALID;

@@ -1195,3 +1195,28 @@ def test_frame_extract_equals_the_per_call_entry_points(cfg2):
         assert kl.tobytes() == rec["kl" + k].tobytes() and np.array_equal(ld, rec["ldesc" + k])
     ur2, dp2 = fe.compute_stereo_matches()
     assert ur2[:N].tobytes() == ur[:N].tobytes() and dp2[:N].tobytes() == dp[:N].tobytes()
+
+
+def test_roctx_ranges_are_pushed_when_asked_for(gpu):
+    """with PLI_ROCTX=1 the library brackets its entry points, stages and kernel launches with roctx ranges (the
+    marker library is found at run time); without the switch nothing is pushed.  Run in child processes: the switch is read when
+    the library is loaded."""
+    import subprocess, sys
+    code = ("import numpy as np\n"
+            "from pli_slam_amd import capi, synth\n"
+            "from pli_slam_amd.frontend import Frontend\n"
+            "L, R = synth.make_stereo_pair(3, 376, 240)\n"
+            "fe = Frontend(capi.default_config(376, 240, orb_nfeatures=500, lsd_nfeatures=60, max_frames=1))\n"
+            "rec = fe.batch_run_host(np.stack([L, R])[None])[0]\n"
+            "print('RANGES', capi.lib().pli_trace_ranges(), len(rec['kpL']))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for flag in ("0", "1"):
+        env = dict(os.environ, PLI_ROCTX=flag, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("RANGES")][-1].split()
+        out[flag] = (int(line[1]), int(line[2]))
+    assert out["0"][0] == 0, "ranges pushed without the switch: %s" % (out,)
+    assert out["1"][0] > 40, "PLI_ROCTX=1: only %d ranges for a whole frame (entry point + stages + ~60 kernel launches)" % out["1"][0]
+    assert out["0"][1] == out["1"][1] > 100

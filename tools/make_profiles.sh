@@ -9,6 +9,7 @@
 #     plain    the same workloads without the profiler attached (bench_<name>_plain.json) and the default bench line
 #     sweep4k  config 5 at F = 16 / 32 / 64 (is 4K's rate the plateau?)
 #     real     the headline batch on frames cut from real photographs (bench.py --real-images): rate, relaxation rounds, fallbacks
+#     markers  rocprofv3 --kernel-trace --marker-trace with PLI_ROCTX=1 (F = 32): the library's roctx ranges — entry point > stage > launch
 ROUND=4
 if [[ $1 == --round ]]; then ROUND=$2; shift; shift; fi
 RN=$(printf "r%02d" $ROUND)
@@ -16,7 +17,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$RN
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-WHAT="${*:-stats pmc sq plain sweep4k real}"
+WHAT="${*:-stats pmc sq plain sweep4k real markers}"
 run_stats() {  # name, bench args
   local name=$1; shift
   rm -rf $R/gpurun_out/ps_$name
@@ -57,6 +58,12 @@ if [[ $WHAT == *sq* ]]; then
       run_pmc $name "$grp" "$@"
     done
   done
+fi
+if [[ $WHAT == *markers* ]]; then
+  rm -rf $R/gpurun_out/pm
+  PLI_ROCTX=1 timeout 600 rocprofv3 --kernel-trace --marker-trace --stats -d $R/gpurun_out/pm -o s -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-leg --no-large-batch-leg --frames-per-gpu 32 > $O/markers.log 2>&1
+  python3 $R/tools/rocprof_summary.py markers $(find $R/gpurun_out/pm -name "*.db" | head -1) > $O/marker_ranges_f32.txt
+  rm -rf $R/gpurun_out/pm
 fi
 cd $R
 if [[ $WHAT == *plain* ]]; then
