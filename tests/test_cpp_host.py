@@ -174,7 +174,9 @@ def test_adapters_under_sanitizers_with_a_mock_library(tmp_path, sanitizer):
         assert all(d[k].tobytes() == b[k].tobytes() for k in b if k not in ("frame_ms", "fusion_stats")), name
         fused, alone, timeouts, mismatched, sleeps = (int(v) for v in d["fusion_stats"][0])
         if name == "late":
-            assert timeouts >= 3 and 6 * 3 - 3 - 6 <= fused <= 6 * 3 - 3, d["fusion_stats"]     # (slack: thread starts under a sanitizer are slow)
+            # (deterministic: Frame 2 of each repetition cannot fuse — its fourth thread comes 5 ms after a 2 ms wait — and its waiters
+            # time out; how many OTHER Frames fuse depends on how promptly a loaded machine under a sanitizer starts threads: a floor only)
+            assert timeouts >= 3 and 3 <= fused <= 6 * 3 - 3, d["fusion_stats"]
         else:
             assert fused == 0 and mismatched + timeouts > 0, d["fusion_stats"]
     assert len(set(a["hashes"].ravel().tolist())) == 1 and int(a["groups_left"][0, 0]) == 0
