@@ -939,7 +939,8 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     if (const char* e = getenv("PLI_JR_BLOCKS")) growBlocks = std::max(1, atoi(e));
     int bigBlocks = std::max(64, std::min(1024, 16384 / nimg));
     if (const char* e = getenv("PLI_JR_BIGBLOCKS")) bigBlocks = std::max(1, atoi(e));
-    const int rectBlocks = std::max(64, std::min(2048, 32768 / nimg));
+    int rectBlocks = std::max(64, std::min(2048, 32768 / nimg));
+    if (const char* e = getenv("PLI_RECT_BLOCKS")) rectBlocks = std::max(1, atoi(e));      // dev: waves per image of k_rx_rect
     int bigThresh = RX_HAND;
     if (const char* e = getenv("PLI_JR_BIG")) bigThresh = atoi(e);
     int maxRounds = 96;
