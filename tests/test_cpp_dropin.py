@@ -306,6 +306,19 @@ def test_kitti_rig_first_frame_and_rig_change_fused_equals_per_call_equals_oracl
 
 
 @pytest.mark.gpu
+def test_kitti_rig_handed_over_before_the_first_frame(runs, kitti_runs):
+    """`extractor->pliSetStereoCamera(mbf, fx)` once after reading the calibration: the context is created with
+    the Frame's rig, so the first fused Frame needs no second matching pass — and carries the same bytes."""
+    frames = kitti_runs["frames"][:3]
+    res = run_harness(runs["exe"], runs["dir"], "kitti_preset", frames, 1, 3, nfeatures=KITTI_NFEATURES, nlines=KITTI_NLINES, rig=KITTI_RIG)
+    t = kitti_runs["threads"]
+    for k in res:
+        if k.startswith("f") and "/" in k and int(k[1:k.index("/")]) < 3 and "sbp" not in k and "line_" not in k and "Tlw" not in k:
+            same(res[k], t[k], "rig preset: " + k)
+    assert int(res["fusion_stats"][0, 0]) >= 1
+
+
+@pytest.mark.gpu
 def test_kitti_frame_to_frame_matchers(kitti_runs):
     check_f2f(kitti_runs["threads"], 6, kitti_runs["rig_of"], KITTI_W, KITTI_H, same_scene=lambda i: i % 3 != 0, floor=4 * 4 * 30)
 
