@@ -304,6 +304,102 @@ int main(int argc, char** argv) {
                 "claimed pixel %ld; wrong after round 1 %ld px\n", G, regionsStarted, groups, (double)members / groups, seedGone, redo, onePix, firstSteps, steps,
                 firstSteps + steps, seqSteps, losers, wrong);
   }
+  // ---- small regions grown 8 at a time for ALL their steps (the generalisation): the alive seeds of a row form groups of up to G; a
+  // group advances in lockstep, one queue entry per member and step (an octet of lanes: its 8 neighbours), claims go out after every
+  // step (members see each other's claims from the next step on, like tiles do); a member that reaches CAP pixels leaves the group
+  // and is finished by the whole wave (8 entries per step) after the group; a member that finishes is NOT replaced (no refill).
+  // Counted: wave steps (group steps + whole-wave steps), regions that lost a claimed pixel, pixels wrong after round 1.
+  for (int G : {8}) for (int CAP : {8, 16}) {
+    std::vector<int> own(N, INT32_MAX);
+    std::vector<char> lost(R, 0);
+    long regionsStarted = 0, groups = 0, members = 0, groupSteps = 0, waveSteps = 0, handed = 0;
+    auto claim = [&](int q, int r) {
+      if (own[q] != INT32_MAX && own[q] > r) lost[own[q]] = 1;
+      if (own[q] < r) lost[r] = 1;
+      own[q] = std::min(own[q], r);
+    };
+    struct M { int r; std::vector<int> q; size_t k; float sx, sy; double ang; bool done, big; };
+    size_t maxRows = 0;
+    for (auto& S : tileSeeds) maxRows = std::max(maxRows, (S.size() + 63) / 64);
+    for (size_t row = 0; row < maxRows; ++row)
+      for (int T = 0; T < NT; ++T) {
+        const std::vector<int>& S = tileSeeds[T];
+        if (row * 64 >= S.size()) continue;
+        const size_t e = std::min(S.size(), row * 64 + 64);
+        std::vector<int> alive;
+        for (size_t i = row * 64; i < e; ++i) if (own[F.order[S[i]]] >= S[i]) alive.push_back(S[i]);
+        size_t a = 0;
+        while (a < alive.size()) {
+          std::vector<M> grp;
+          while (a < alive.size() && (int)grp.size() < G) {
+            const int r = alive[a++];
+            if (own[F.order[r]] < r) continue;
+            const int sp = F.order[r];
+            claim(sp, r);
+            grp.push_back(M{r, {sp}, 0, float(std::cos(F.ang[sp])), float(std::sin(F.ang[sp])), F.ang[sp], false, false});
+          }
+          if (grp.empty()) break;
+          ++groups; members += (long)grp.size(); regionsStarted += (long)grp.size();
+          // lockstep: one queue entry per member and step
+          for (;;) {
+            bool any = false;
+            std::vector<std::pair<int, int>> claims;            // (pixel, rank) of this step, applied after it
+            for (auto& m : grp) {
+              if (m.done || m.big) continue;
+              if (own[m.q[0]] != m.r) { m.done = true; continue; }              // its seed was taken: the member dies
+              if (m.k >= m.q.size()) { m.done = true; continue; }
+              any = true;
+              const int px = m.q[m.k] % W, py = m.q[m.k] / W;
+              for (int yy = std::max(py - 1, 0); yy <= std::min(py + 1, H - 1); ++yy)
+                for (int xx = std::max(px - 1, 0); xx <= std::min(px + 1, W - 1); ++xx) {
+                  const int q = yy * W + xx;
+                  bool mine = false;
+                  for (int z : m.q) if (z == q) { mine = true; break; }
+                  const bool used = mine || own[q] < m.r || F.rankOf[q] < m.r;
+                  if (!used && aligned(F, q, m.ang)) {
+                    if ((int)m.q.size() == CAP) { m.big = true; break; }
+                    m.q.push_back(q); claims.push_back({q, m.r});
+                    m.sx += F.c[q]; m.sy += F.s[q];
+                    m.ang = fastAtan2(m.sy, m.sx) * kDEG_TO_RADS;
+                  }
+                }
+              if (!m.big) ++m.k;
+            }
+            if (!any) break;
+            ++groupSteps;
+            for (auto& c : claims) claim(c.first, c.second);
+          }
+          // the members that outgrew the group: finished one after the other by the whole wave (the step in which a member hit the cap
+          // is repeated there: the model restarts that queue entry)
+          for (auto& m : grp) {
+            if (!m.big || own[m.q[0]] != m.r) continue;
+            ++handed;
+            const int r = m.r;
+            size_t k = m.k;
+            while (k < m.q.size()) {
+              const size_t nb = std::min<size_t>(8, m.q.size() - k);
+              ++waveSteps;
+              for (size_t e2 = k; e2 < k + nb; ++e2) {
+                const int px = m.q[e2] % W, py = m.q[e2] / W;
+                for (int yy = std::max(py - 1, 0); yy <= std::min(py + 1, H - 1); ++yy)
+                  for (int xx = std::max(px - 1, 0); xx <= std::min(px + 1, W - 1); ++xx) {
+                    const int q = yy * W + xx;
+                    const bool used = own[q] <= r || F.rankOf[q] < r;
+                    if (!used && aligned(F, q, m.ang)) { claim(q, r); m.q.push_back(q); m.sx += F.c[q]; m.sy += F.s[q]; m.ang = fastAtan2(m.sy, m.sx) * kDEG_TO_RADS; }
+                  }
+              }
+              k += nb;
+            }
+          }
+        }
+      }
+    long wrong = 0, losers = 0;
+    for (int q = 0; q < N; ++q) wrong += own[q] != truth[q];
+    for (int r = 0; r < R; ++r) losers += lost[r];
+    std::printf("octet groups of %d, cap %d px: %ld regions in %ld groups (%.2f per group), %ld handed to the whole wave; group steps %ld + whole-wave steps %ld = %ld "
+                "(today's schedule in this model: 151063, sequential %ld); regions that lost a claimed pixel %ld; wrong after round 1 %ld px\n",
+                G, CAP, regionsStarted, groups, (double)members / groups, handed, groupSteps, waveSteps, groupSteps + waveSteps, seqSteps, losers, wrong);
+  }
   if (getenv("SIMW_GROUPS_ONLY")) return 0;
   const int Ks[] = {1, 8, 32, 128, 512, 2048, 0};
   for (int K : Ks) {
