@@ -342,7 +342,7 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--nfeatures", type=int, default=0)
     ap.add_argument("--nlines", type=int, default=0)
-    ap.add_argument("--unique-frames", type=int, default=64)
+    ap.add_argument("--unique-frames", type=int, default=256, help="distinct seeded stereo pairs per GPU (cycled to the batch size); 256 = every frame of the headline batch is distinct")
     ap.add_argument("--real-images", action="store_true",
                     help="the batch is cut from real photographs (pli_slam_amd/realdata.py, tests/golden/real/photos.npz) instead of "
                          "synthetic scenes: rate, relaxation rounds and fallbacks on natural gradients (752x480 only)")
