@@ -172,3 +172,51 @@ def test_real_frames_batch_rounds_and_fallbacks(gpu):
     for i in (0, 5, 13, 14, 27):               # (13: a motorcycle frame with its real right eye)
         assert_frame_equal(g, recs[i], g.po.Frame(ocfg(g, cfg)), frames[i][0], frames[i][1], "real frame %d" % i)
         assert recs2[i]["klL"].tobytes() == recs[i]["klL"].tobytes() and recs2[i]["uright"].tobytes() == recs[i]["uright"].tobytes()
+
+
+@pytest.mark.gpu
+def test_frame_to_frame_tracking_on_the_real_stereo_pair(gpu):
+    """pli_batch_track (SearchByProjection(CurrentFrame, LastFrame) + match() of the line descriptors, Tracking.cc:3046-3058) on four
+    instants of the Middlebury pair — a 640x440 window drifting by (3, 1) px per instant over the real left / right images, so depths
+    come from real stereo matches — equals the oracle's restatement; and the tracks are real: most stereo points of an instant are
+    found again in the next one a few pixels away."""
+    import torch
+    g = gpu
+    L0, R0, _ = realdata.motorcycle()
+    W, H, F = 640, 440, 4
+    frames = [(np.ascontiguousarray(L0[10 + t:10 + t + H, 20 + 3 * t:20 + 3 * t + W]),
+               np.ascontiguousarray(R0[10 + t:10 + t + H, 20 + 3 * t:20 + 3 * t + W])) for t in range(F)]
+    cfg = g.capi.default_config(W, H, orb_nfeatures=1200, lsd_nfeatures=100, max_frames=F, bf=100.0, fx=500.0)
+    fe = g.Frontend(cfg)
+    imgs = np.stack([np.stack(f) for f in frames])
+    left, right = np.ascontiguousarray(imgs[:, 0]), np.ascontiguousarray(imgs[:, 1])
+    table = np.zeros(fe.table_bytes(F), np.uint8)
+    g.capi.check(fe.L.pli_batch_run_host(fe.h, F, g.capi.ptr(left), g.capi.ptr(right), W, W * H, g.capi.RUN_ALL, g.capi.ptr(table)))
+    recs = [fe.parse_record(table, f) for f in range(F)]
+    poses = np.stack([np.eye(4, dtype=np.float32)[:3] for _ in range(F)])          # the motion model's prediction: no motion
+    tp = fe.track_params(th=15.0, mono=False, check_orientation=True, nnr_lines=0.9)
+    tl = fe.track_layout()
+    d_table = torch.from_numpy(table).cuda()
+    d_poses = torch.from_numpy(poses.reshape(-1)).cuda()
+    d_track = torch.zeros(F * tl.record_bytes, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    fe.batch_track_device(F, d_table.data_ptr(), d_poses.data_ptr(), tp, d_track.data_ptr())
+    fe.sync()
+    track = d_track.cpu().numpy()
+    sf = np.cumprod(np.concatenate([[np.float32(1.0)], np.full(7, np.float32(1.2), np.float32)])).astype(np.float32)
+    for f in range(1, F):
+        last, cur = recs[f - 1], recs[f]
+        tr = fe.parse_track(track, f)
+        q = g.po.track_queries(last["kpL"], last["depth"], poses[f - 1], poses[f], tp.fx, tp.fy, tp.cx, tp.cy, tp.bf, tp.th, False, sf)
+        on, obest = g.po.search_by_projection(q, last["descL"], cur["kpL"], cur["descL"], cur["uright"], (0.0, float(W), 0.0, float(H)), True)
+        assert tr["counts"][1] == on and np.array_equal(tr["best"], obest), "instant %d point tracks" % f
+        ln, lm = g.po.match_lines(last["ldescL"], cur["ldescL"], 0.9, True)
+        assert tr["counts"][3] == ln and np.array_equal(tr["lines"], lm), "instant %d line tracks" % f
+        # the tracks are physical: a tracked keypoint sits where the window's drift puts it, (-3, -1) px from its last position
+        m = np.flatnonzero(obest >= 0)
+        dx = cur["kpL"]["x"][obest[m]] - last["kpL"]["x"][m]
+        dy = cur["kpL"]["y"][obest[m]] - last["kpL"]["y"][m]
+        good = (np.abs(dx + 3) <= 2.5) & (np.abs(dy + 1) <= 2.5)
+        nstereo = int((last["depth"] > 0).sum())
+        print("instant %d: %d stereo points, %d tracked, %.2f of them at the drift; %d of %d lines matched" % (f, nstereo, on, good.mean(), ln, len(last["ldescL"])))
+        assert on > 0.5 * nstereo and good.mean() > 0.8 and ln > 0.3 * len(last["ldescL"])
