@@ -62,6 +62,18 @@ def test_oracle_stereo_points_against_middlebury_ground_truth(oracle):
     # depth = bf / disparity (Frame.cc:1131)
     ok = ur >= 0
     assert np.allclose(dp[ok], np.float32(100.0) / (kp["x"][ok] - ur[ok]), rtol=1e-6)
+    # the stereo LINE matcher (Frame.cc:1156-1307) against the same ground truth, at the matched lines' end points
+    _, kl, _ = fr.line_extract(0, L)
+    fr.line_extract(1, R)
+    disp, _, _ = fr.stereo_lines()
+    errs = []
+    for i in np.flatnonzero(disp[:, 0] >= 0):
+        for (x, y), d in (((kl["startPointX"][i], kl["startPointY"][i]), disp[i, 0]), ((kl["endPointX"][i], kl["endPointY"][i]), disp[i, 1])):
+            gv = gt[min(int(y), gt.shape[0] - 1), min(int(x), gt.shape[1] - 1)]
+            if gv > 0:
+                errs.append(abs(d - gv))
+    print("oracle: %d stereo lines, %d end points with ground truth, median |error| %.2f px" % (int((disp[:, 0] >= 0).sum()), len(errs), np.median(errs)))
+    assert len(errs) > 40 and np.median(errs) < 3.0
 
 
 # ---- GPU ---------------------------------------------------------------------------------------------------------------------
