@@ -25,6 +25,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <map>
@@ -76,6 +77,11 @@ struct LineParams {
 struct FrameFusion {
   static constexpr int kOrbL = 0, kOrbR = 1, kLineL = 2, kLineR = 3;
   static constexpr int kWaitMs = 2, kMaxMisses = 8, kCoolOff = 128;
+  // (PLI_FUSION_WAIT_MS: the rendezvous wait for test runs under a sanitizer, where a thread start alone takes milliseconds)
+  static int waitMs() {
+    static const int ms = [] { const char* e = std::getenv("PLI_FUSION_WAIT_MS"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : kWaitMs; }();
+    return ms;
+  }
   struct Stats { uint64_t fused = 0, unfusedCalls = 0, timeouts = 0, mismatched = 0, sleeps = 0; };
   std::mutex m;
   std::condition_variable cv;
@@ -122,7 +128,7 @@ struct FrameFusion {
       for (int k = 0; k < 4; ++k) img[k] = nullptr;
       ++gen;
       cv.notify_all();
-    } else if (!cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::milliseconds(kWaitMs), [&] { return gen != myGen; })) {
+    } else if (!cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::milliseconds(waitMs()), [&] { return gen != myGen; })) {
       // (system_clock: pthread_cond_timedwait, which gcc 11's ThreadSanitizer intercepts; the steady-clock wait is pthread_cond_clockwait)
       img[kind] = nullptr;                   // the partners did not come in time: withdraw, this call goes alone
       --arrived;
