@@ -93,14 +93,18 @@ struct FrameFusion {
   const uint8_t* img[4] = {nullptr, nullptr, nullptr, nullptr};
   int64_t stride[4] = {0, 0, 0, 0};
   int iw[4] = {0, 0, 0, 0}, ih[4] = {0, 0, 0, 0};
-  std::vector<uint8_t> record;               // table record of the last fused frame (pli_table_layout)
+  // table record of the last fused frame (pli_table_layout).  Every caller of that frame takes a reference under the lock and reads
+  // its part outside it: a Frame that (against the protocol) starts before the previous one's callers have copied their parts
+  // gets a record of its own, it cannot overwrite theirs
+  std::shared_ptr<std::vector<uint8_t>> record;
+  typedef std::shared_ptr<const std::vector<uint8_t>> RecordRef;
   std::exception_ptr error;                  // what the fused submission threw (every caller of that frame rethrows it)
   Stats st;
 
   Stats stats() { std::lock_guard<std::mutex> lk(m); return st; }
 
   // true: the frame was extracted in one submission and `record` holds it; false: take the per-call path
-  bool join(int kind, pli::Frontend& fe, const uint8_t* data, int w, int h, int64_t strideBytes) {
+  bool join(int kind, pli::Frontend& fe, const uint8_t* data, int w, int h, int64_t strideBytes, RecordRef& rec) {
     std::unique_lock<std::mutex> lk(m);
     if (asleep > 0) { --asleep; ++st.unfusedCalls; return false; }
     if (img[kind] != nullptr) { ++st.unfusedCalls; return false; }     // (a second call of the same kind while a frame is collecting: not a Frame)
@@ -112,8 +116,9 @@ struct FrameFusion {
                          stride[kLineR] == stride[kOrbR] && iw[kOrbL] == iw[kOrbR] && ih[kOrbL] == ih[kOrbR] &&
                          iw[kLineL] == iw[kOrbL] && ih[kLineL] == ih[kOrbL] && iw[kLineR] == iw[kOrbL] && ih[kLineR] == ih[kOrbL];
       if (agree) {
+        if (!record || record.use_count() > 1) record = std::make_shared<std::vector<uint8_t>>();     // (recycled once its readers are gone)
         try {
-          fe.frameExtract(img[kOrbL], img[kOrbR], iw[kOrbL], ih[kOrbL], stride[kOrbL], stride[kOrbR], record);
+          fe.frameExtract(img[kOrbL], img[kOrbR], iw[kOrbL], ih[kOrbL], stride[kOrbL], stride[kOrbR], *record);
         } catch (...) {
           error = std::current_exception();
         }
@@ -140,6 +145,7 @@ struct FrameFusion {
     // needs this thread's next call)
     if (!lastFused) return false;
     if (error) std::rethrow_exception(error);
+    rec = record;
     return true;
   }
 };
@@ -289,12 +295,13 @@ class ORBextractor {
     std::vector<pli_keypoint> kps;
     std::vector<uint8_t> desc;
     int n;
+    pli_detail::FrameFusion::RecordRef fused;
     if (group_->orbMask.load() == 3 && group_->lineMask.load() == 3 &&
         group_->fusion.join(eye_ ? pli_detail::FrameFusion::kOrbR : pli_detail::FrameFusion::kOrbL, *fe, image.data, image.cols, image.rows,
-                            (int64_t)image.step)) {
+                            (int64_t)image.step, fused)) {
       // the frame's record: counts, then this eye's keypoint table and descriptors
       const pli_table_layout& Y = fe->layout();
-      const uint8_t* rec = group_->fusion.record.data();
+      const uint8_t* rec = fused->data();
       n = reinterpret_cast<const int32_t*>(rec + Y.off_counts)[eye_];
       kps.resize(n);
       desc.resize((size_t)n * 32);
@@ -392,11 +399,12 @@ class Lineextractor {
     std::shared_ptr<pli::Frontend> fe = group_->context(image.cols, image.rows);
     std::vector<pli_keyline> kls;
     std::vector<uint8_t> desc;
+    pli_detail::FrameFusion::RecordRef fused;
     if (group_->orbMask.load() == 3 && group_->lineMask.load() == 3 &&
         group_->fusion.join(eye_ ? pli_detail::FrameFusion::kLineR : pli_detail::FrameFusion::kLineL, *fe, image.data, image.cols, image.rows,
-                            (int64_t)image.step)) {
+                            (int64_t)image.step, fused)) {
       const pli_table_layout& Y = fe->layout();
-      const uint8_t* rec = group_->fusion.record.data();
+      const uint8_t* rec = fused->data();
       const int n = reinterpret_cast<const int32_t*>(rec + Y.off_counts)[2 + eye_];
       kls.resize(n);
       desc.resize((size_t)n * 32);
