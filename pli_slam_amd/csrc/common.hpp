@@ -119,6 +119,9 @@ struct TxDirtyLists {
   int xcdAffine = 0;           // round 1: all tiles of an image on ONE XCD (workgroups go to the 8 XCDs round robin)
 };
 
+// "no rank / no id": what the rank plane (k_lsd_scatter) and the id plane (k_tx_sort, key mode) hold for a pixel without a level-line
+// angle.  INT_MAX since round 5 (0x7F7F7F7F before): key-mode ids use all 31 bits on images of more than 2^20 scaled pixels.
+constexpr int LSD_ID_INF = 0x7FFFFFFF;
 constexpr int TX_EMIT_CAP = 16384;   // key mode: candidate segments of an image that k_tx_emit_sorted can order (LDS)
 // k_zero_ranges (orb_kernels.hip): buffers cleared by one launch
 struct ZeroRanges {
@@ -133,6 +136,9 @@ struct TxKeys {
   double rho;
   int nBins, pixbits;
   int* idPlane;                     // out: own id of every pixel (TX_INF: undefined)
+  float4* recPack = nullptr;        // packed round 1 (lsd_tile.hip): the pixel records, whose fourth word is owner_1 during round 1
+  int lazyMargin = 8;               // LAZY ids: units of the 2^-22 fixed point around a bin boundary that the double plane decides (>= 4; test switch)
+  int pack = 0;                     // 0: owner plane; 1: k_tx_sort writes the unclaimed words (ids); 2: the front pass wrote them (LAZY ids)
 };
 
 // arguments of k_tx_tail (lsd_tile.hip): the rounds t >= t0 of the tile relaxation in one persistent launch

@@ -137,4 +137,15 @@ __device__ __forceinline__ double lsd_bin_coef64(unsigned long long maxBits, int
 }
 __device__ __forceinline__ int lsd_bin64(double norm, double binCoef, int nBins) { return min((int)(norm * binCoef), nBins - 1); }
 
+// Packed round 1 of the tile relaxation (lsd_tile.hip): the fourth word of a pixel record is the pixel's owner word.  Bit 31 set:
+// nobody has claimed the pixel; the low bits then carry either the pixel's own id (written by k_tx_sort) or, in the LAZY form, its
+// gradient norm in 2^-22 fixed point (written by the front pass, which does not know the ids yet) — enough to order the pixel's
+// gradient bin against a region's without the double plane, except within a few units of a bin boundary (lsd_tile.hip decides those
+// from the double).  Bit 31 clear: the id of the region that holds the pixel (claims are unsigned atomic minima).
+constexpr unsigned TX_UNCLAIMED = 0x80000000u;
+constexpr double TX_FIX22 = 4194304.0;
+__device__ __forceinline__ float tx_unclaimed_norm_word(double norm) {
+  return __int_as_float((int)(TX_UNCLAIMED | (unsigned)fmin(norm * TX_FIX22, 2147418112.0 /* 0x7FFF0000 */)));
+}
+
 }  // namespace pli

@@ -172,8 +172,10 @@ __global__ __launch_bounds__(1024) void k_lsd_scan(const unsigned short* __restr
 // per bin and writes, per (group, bin), the offset k_lsd_scatter adds to the group-local value when it loads a chunk's bases.
 __global__ __launch_bounds__(1024) void k_lsd_scan_part(const unsigned short* __restrict__ chunkHist, int nChunks, int nBins,
                                                         int chunksPerGroup, int* __restrict__ chunkBase,
-                                                        int* __restrict__ groupOff, int img0) {
+                                                        int* __restrict__ groupOff, int img0,
+                                                        const RxCtl* __restrict__ onlyUnsettled) {
   const int img = blockIdx.x + img0, g = blockIdx.y, b = threadIdx.x;
+  if (onlyUnsettled && onlyUnsettled[img].state == 2 && !onlyUnsettled[img].overflow) return;
   if (b >= nBins) return;
   const int c0 = g * chunksPerGroup, c1 = min(c0 + chunksPerGroup, nChunks);
   const unsigned short* hin = chunkHist + (int64_t)img * nChunks * nBins;
@@ -188,10 +190,12 @@ __global__ __launch_bounds__(1024) void k_lsd_scan_part(const unsigned short* __
   groupOff[((int64_t)img * gridDim.y + g) * nBins + b] = run;
 }
 __global__ __launch_bounds__(1024) void k_lsd_scan_groups(int nGroups, int nBins, int* __restrict__ groupOff,
-                                                          int* __restrict__ nDefined, int img0) {
+                                                          int* __restrict__ nDefined, int img0,
+                                                          const RxCtl* __restrict__ onlyUnsettled) {
   __shared__ int tot[1024];
   __shared__ int start[1024];
   const int img = blockIdx.x + img0, b = threadIdx.x;
+  if (onlyUnsettled && onlyUnsettled[img].state == 2 && !onlyUnsettled[img].overflow) return;
   int* go = groupOff + (int64_t)img * nGroups * nBins;
   int run = 0;
   if (b < nBins)
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(64) void k_lsd_scatter(const int* __restrict__ g2a,
   const int* g = g2a + (int64_t)img * npix;
   const double* gd = mgAll + (int64_t)img * npix;
   int* ord = order + (int64_t)img * npix;
-  // (relaxations) the rank of every pixel — its slot in the ordered list, 0x7F7F7F7F for an undefined pixel — is written here,
+  // (relaxations) the rank of every pixel — its slot in the ordered list, LSD_ID_INF for an undefined pixel — is written here,
   // in raster order, instead of being scattered from the list afterwards
   int* rk = rankAll ? rankAll + (int64_t)img * npix : nullptr;
   const int nbits = 32 - __clz(max(nBins - 1, 1));
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(64) void k_lsd_scatter(const int* __restrict__ g2a,
       // lanes with the same bin (match-any by bits: one ballot per bin bit instead of one round per distinct bin)
       unsigned long long peers = __builtin_amdgcn_ballot_w64(def);
       if (!peers) {
-        if (rk && i < npix) rk[i] = 0x7F7F7F7F;
+        if (rk && i < npix) rk[i] = LSD_ID_INF;
         continue;
       }
       for (int b = 0; b < nbits; ++b) {
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(64) void k_lsd_scatter(const int* __restrict__ g2a,
         cnt = __popcll(peers);
         last = (peers >> lane) == 1ull;
       }
-      const int slot = def ? base[bin] + rank : 0x7F7F7F7F;
+      const int slot = def ? base[bin] + rank : LSD_ID_INF;
       if (def) ord[slot] = i;
       if (rk && i < npix) rk[i] = slot;
       // single-wave block: the LDS operations of a wave execute in order (a block barrier would also wait for the stores)

@@ -71,7 +71,9 @@ __global__ __launch_bounds__(256) void k_lsd_resize64(const double* __restrict__
 __global__ __launch_bounds__(256) void k_lsd_grad64(const double* __restrict__ scaled, int W, int H, double rho,
                                                     float4* __restrict__ rec, double* __restrict__ mg, int2* __restrict__ own,
                                                     unsigned long long* __restrict__ maxMg, float* __restrict__ angDbg, int img0,
-                                                    int trigF32) {
+                                                    int flags /* bit 0: PLI_PARITY_TRIG_F32_LSD; bit 1: rec.w = tx_unclaimed_norm_word */) {
+  const int trigF32 = flags & 1;
+  const bool packW = (flags & 2) != 0;
   __shared__ unsigned long long wmax[4];
   const int img = blockIdx.z + img0;
   const int x = blockIdx.x * 256 + threadIdx.x;
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad64(const double* __restrict__ s
         }
       }
       const int64_t o = (int64_t)img * W * H + (int64_t)y * W + x;
-      rec[o] = make_float4(a, cx, sy, 0.f);
+      rec[o] = make_float4(a, cx, sy, packW ? tx_unclaimed_norm_word(norm) : 0.f);
       mg[o] = norm;
       if (own) own[o] = make_int2(0x7FFFFFFF, 0x7FFFFFFF);
       if (angDbg) angDbg[o] = a;
@@ -129,7 +131,9 @@ __global__ __launch_bounds__(256) void k_lsd_front64(const uint8_t* __restrict__
                                                      const double* __restrict__ kern, int radius, const int* __restrict__ tab,
                                                      int dw, int dh, double rho, float4* __restrict__ rec, double* __restrict__ mg,
                                                      int2* __restrict__ own, unsigned long long* __restrict__ maxMg, int img0,
-                                                     int trigF32) {
+                                                     int flags /* as k_lsd_grad64 */) {
+  const int trigF32 = flags & 1;
+  const bool packW = (flags & 2) != 0;
   __shared__ uint8_t tile[FS_H + 2 * FR][FS_W + 2 * FR + 2];
   __shared__ double rows[FS_H + 2 * FR][FS_W];               // row-filtered window; afterwards the scaled tile (scl)
   __shared__ double blur[FS_H][FS_W];
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(256) void k_lsd_front64(const uint8_t* __restrict__
       }
     }
     const int64_t o = (int64_t)img * dw * dh + (int64_t)y * dw + x;
-    rec[o] = make_float4(a, cx, sy, 0.f);
+    rec[o] = make_float4(a, cx, sy, packW ? tx_unclaimed_norm_word(norm) : 0.f);
     mg[o] = norm;
     if (own) own[o] = make_int2(0x7FFFFFFF, 0x7FFFFFFF);
   }

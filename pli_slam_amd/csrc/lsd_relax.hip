@@ -38,7 +38,7 @@
 namespace pli {
 
 constexpr float RX_NOTDEF = -1024.f;
-constexpr int RX_INF = 0x7F7F7F7F;          // rank plane of undefined pixels (hipMemset 0x7F)
+constexpr int RX_INF = LSD_ID_INF;          // rank plane of undefined pixels
 
 __device__ __forceinline__ int2 rx_load_own(const int2* p) {
   // bypass the per-CU L1: claims of other workgroups (and our own atomics) are served from L2 / memory
@@ -75,7 +75,7 @@ __device__ __forceinline__ int rx_block_append(bool flag, int* counter, int* lds
 }
 
 // ---- setup -------------------------------------------------------------------------------------
-// (the rank plane — rank of every pixel, 0x7F7F7F7F where undefined — is written by k_lsd_scatter, line_kernels.hip)
+// (the rank plane — rank of every pixel, LSD_ID_INF where undefined — is written by k_lsd_scatter, line_kernels.hip)
 
 // owner_0: the lowest-ranked 3x3 neighbour whose own angle accepts the pixel (a heuristic: any owner_0 is valid)
 __global__ __launch_bounds__(256) void k_rx_guess(const float4* __restrict__ recAll, const int* __restrict__ rankAll,
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void k_rx_classify(RxCtl* __restrict__ ctl, co
   const int2 o = ownAll[base + p];
   if (o.x != o.y) return;
   const int r = rankAll[base + p];
-  if (o.x != r) return;                              // (undefined pixels: INT_MAX != RX_INF)
+  if (r == RX_INF || o.x != r) return;               // (undefined pixels)
   // alive in both maps: grown (or carried) in round t-1
   const int2 b = rgBoxAll[base + r];
   const int tx0 = max((b.x & 0xFFFF) - 1, 0) >> 3, ty0 = max((b.x >> 16) - 1, 0) >> 3;

@@ -28,7 +28,7 @@
 namespace pli {
 
 constexpr float TX_NOTDEF = -1024.f;
-constexpr int TX_INF = 0x7F7F7F7F;          // rank plane of undefined pixels (hipMemset 0x7F)
+constexpr int TX_INF = LSD_ID_INF;          // rank / id plane of undefined pixels
 constexpr double TX_PI = 3.14159265358979323846;
 constexpr double TX_DEG2RAD = TX_PI / 180;
 constexpr double TX_3_2_PI = (3 * TX_PI) / 2;
@@ -47,7 +47,16 @@ constexpr double TX_2PI = 2 * TX_PI;
 #ifndef TX_CLAIM_SCOPE             // (diagnostic builds only: -DTX_CLAIM_SCOPE=__HIP_MEMORY_SCOPE_WORKGROUP times the claims as L2 atomics —
 #define TX_CLAIM_SCOPE __HIP_MEMORY_SCOPE_AGENT   // NOT coherent between the XCDs' L2s, so not exact unless an image stays on one XCD)
 #endif
-constexpr int TX_GQ = 1024;       // queue entries of a region kept in LDS
+// Shared first steps (round 5): the alive seeds of a list row start in GROUPS of up to TX_GROUP — octet g of the wave fetches the 8
+// neighbours of member g's seed, ONE load round trip for the group; the fetched records are parked in LDS and every member takes
+// its first step from them at its turn, in id order, with nothing claimed before that (see tx_grow_tile).  0: every region fetches
+// its own first step (the schedule of rounds 2-4; A/B builds).
+#ifndef TX_GROUP
+#define TX_GROUP 8
+#endif
+static_assert(TX_GROUP == 0 || TX_GROUP == 2 || TX_GROUP == 4 || TX_GROUP == 8, "a group member is an octet of lanes");
+constexpr int TX_GQ = 768;        // queue entries of a region kept in LDS
+constexpr int TX_PARK = 4 * 64;   // the parked first-step records of a group: angle, cos, sin, owner_{t-1} per lane
 constexpr int TX_GQ_SPEC = 512;   // ... in the speculative round-1 kernel (its lanes' parked states take 2 KB of the wave's LDS)
 constexpr int TX_SPEC_CAP = 8;    // pixels a lane may take by itself before its region is handed to the whole wave (< minRegSize)
 constexpr int TX_BBLK = 256;      // arena block for the overflow of a large region's queue
@@ -67,6 +76,18 @@ __device__ __forceinline__ int2 tx_load_own(const int2* p) {
   return make_int2((int)(v & 0xFFFFFFFFull), (int)(v >> 32));
 #endif
 }
+// PACKED ROUND 1 (round 5).  In round 1 owner_0 is the trivial map, so the one owner word a test needs is owner_1 — and a step's
+// record and owner fetches are two gathers of the same 3 x 3 blocks from two planes (4.5 + 3.75 sixty-four-byte sectors per octet of
+// lanes).  With the CV_64F detector the fourth word of the 16-byte pixel record is free (the gradient norm lives in its own double
+// plane): k_tx_sort puts owner_1's start value there, round 1 reads ONE 16-byte word per neighbour and claims into it, and
+// k_tx_round2 moves the result into the owner plane.  The load bypasses the per-CU L1 like tx_load_own (claims are performed in L2).
+typedef float tx_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 tx_load_rec16(const float4* p) {
+  tx_v4f v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ int* tx_rec_owner(const float4* p) { return reinterpret_cast<int*>(const_cast<float4*>(p)) + 3; }
 __device__ __forceinline__ int tx_lds_read(const int* p) {
   typedef __attribute__((address_space(3))) const volatile int lds_cvint;
   return *(lds_cvint*)p;
@@ -172,8 +193,11 @@ __device__ __forceinline__ void tx_sort_tile(const int* __restrict__ rankAll, co
         r = rank[y * W + x];
       }
       // owner_0 = the trivial map, written for EVERY pixel of the tile (an undefined pixel is nobody's: INT_MAX in both components):
-      // the front pass does not initialise the plane for this schedule
-      own[y * W + x] = r != TX_INF ? make_int2(r, r) : make_int2(INT_MAX, INT_MAX);
+      // the front pass does not initialise the plane for this schedule.  Packed round 1: owner_1's start value into the pixel
+      // record instead, with the "unclaimed" bit (k_tx_round2 writes the owner plane); LAZY ids: the front pass has written the word
+      if (keys.pack == 1) {
+        if (r != TX_INF) *tx_rec_owner(keys.recPack + img * npix + y * W + x) = (int)(TX_UNCLAIMED | (unsigned)r);
+      } else if (keys.pack == 0) own[y * W + x] = r != TX_INF ? make_int2(r, r) : make_int2(INT_MAX, INT_MAX);
       if (r != TX_INF) {
         k = (unsigned)r;
         ++valid;
@@ -306,17 +330,19 @@ __global__ __launch_bounds__(256) void k_tx_diff2(RxCtl* __restrict__ ctl, const
 // carried, its own rank otherwise.  The first pixel that finds o stamps it (rgDirty, the cells under its box, the dirty list
 // of its tile).  32 x 32 pixels per block, the four rows of a thread in flight together.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tx_round2(RxCtl* __restrict__ ctl, int2* __restrict__ ownAll,
+template <bool PACKED>
+__device__ __forceinline__ void tx_round2_block(RxCtl* __restrict__ ctl, int2* __restrict__ ownAll,
                                                    const int* __restrict__ rankAll, const int* __restrict__ orderAll,
                                                    const int2* __restrict__ rgBoxAll, int* __restrict__ rgDirtyAll,
                                                    int* __restrict__ tileActAll, int W, int H, int TW, int TH, int t, int img0,
                                                    const int* __restrict__ rgLostAll, TxDirtyLists DL,
-                                                   int* __restrict__ tileTouchAll) {
+                                                   int* __restrict__ tileTouchAll, const float4* __restrict__ recPack) {
   const int img = blockIdx.z + img0;
   RxCtl& c = ctl[img];
   if (c.state == 2) return;
   const int tid = threadIdx.x;
   if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { c.nSmall = 0; c.nBig = 0; c.nHand = 0; c.nextBig = 0; c.rectArena = 0ull; c.changed = 0; c.changedOdd = 0; }
+  // (packed round 1: owner_1 comes from the pixel records and the owner plane is WRITTEN here, both components, every pixel; t == 2)
   const int64_t base = (int64_t)img * W * H;
   const int ci = t & 1;
   const int x = blockIdx.x * 32 + (tid & 31);
@@ -329,9 +355,12 @@ __global__ __launch_bounds__(256) void k_tx_round2(RxCtl* __restrict__ ctl, int2
     ow[i] = make_int2(INT_MAX, INT_MAX);
     r[i] = TX_INF;
     if (x < W && y < H) {
-      ow[i] = ownAll[base + y * W + x];
+      if (PACKED) ow[i].y = *tx_rec_owner(recPack + base + y * W + x);
+      else ow[i] = ownAll[base + y * W + x];
       r[i] = rankAll[base + y * W + x];
     }
+    // (packed: an unclaimed word — bit 31 — stands for the pixel's own id; an undefined pixel is nobody's)
+    if (PACKED) ow[i].y = r[i] == TX_INF ? INT_MAX : (ow[i].y < 0 ? r[i] : ow[i].y);
     o[i] = ci ? ow[i].x : ow[i].y;                     // owner_{t-1}
   }
 #pragma unroll
@@ -345,13 +374,21 @@ __global__ __launch_bounds__(256) void k_tx_round2(RxCtl* __restrict__ ctl, int2
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     so[i] = make_int2(0, 0);
-    if (sp[i] >= 0) so[i] = ownAll[base + sp[i]];
+    if (sp[i] >= 0) {
+      if (PACKED) {                                    // (sp is o's seed pixel: unclaimed means o holds it)
+        so[i].y = *tx_rec_owner(recPack + base + sp[i]);
+        if (so[i].y < 0) so[i].y = o[i];
+      } else so[i] = ownAll[base + sp[i]];
+    }
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    if (o[i] == INT_MAX) continue;
     const int y = blockIdx.y * 32 + i * 8 + (tid >> 5);
     const int p = y * W + x;
+    if (o[i] == INT_MAX) {
+      if (PACKED && x < W && y < H) ownAll[base + p] = make_int2(INT_MAX, INT_MAX);     // (an undefined pixel)
+      continue;
+    }
     // (p is o's seed: o holds it, so o is alive)
     const bool dead = sp[i] != p && (ci ? so[i].x : so[i].y) != o[i];
     const bool dirty = dead || lost[i] != 0;
@@ -359,11 +396,22 @@ __global__ __launch_bounds__(256) void k_tx_round2(RxCtl* __restrict__ ctl, int2
     // (a pixel that falls back to its own rank makes its cell differ between owner_1 and owner_2: noted for round 3's diff)
     if (dirty && tileTouchAll) tileTouchAll[(int64_t)img * TW * TH + (y >> 3) * TW + (x >> 3)] = t;
     const int cur = dirty ? r[i] : o[i];
-    if (cur != (ci ? ow[i].y : ow[i].x)) {
+    if (PACKED || cur != (ci ? ow[i].y : ow[i].x)) {
       if (ci) ow[i].y = cur; else ow[i].x = cur;
       ownAll[base + p] = ow[i];
     }
   }
+}
+
+// (two instances: a test of the argument inside the unrolled row loops keeps the four rows' loads from being issued together)
+__global__ __launch_bounds__(256) void k_tx_round2(RxCtl* __restrict__ ctl, int2* __restrict__ ownAll,
+                                                   const int* __restrict__ rankAll, const int* __restrict__ orderAll,
+                                                   const int2* __restrict__ rgBoxAll, int* __restrict__ rgDirtyAll,
+                                                   int* __restrict__ tileActAll, int W, int H, int TW, int TH, int t, int img0,
+                                                   const int* __restrict__ rgLostAll, TxDirtyLists DL,
+                                                   int* __restrict__ tileTouchAll, const float4* __restrict__ recPack) {
+  if (recPack) tx_round2_block<true>(ctl, ownAll, rankAll, orderAll, rgBoxAll, rgDirtyAll, tileActAll, W, H, TW, TH, t, img0, rgLostAll, DL, tileTouchAll, recPack);
+  else tx_round2_block<false>(ctl, ownAll, rankAll, orderAll, rgBoxAll, rgDirtyAll, tileActAll, W, H, TW, TH, t, img0, rgLostAll, DL, tileTouchAll, recPack);
 }
 
 // ---------------------------------------------------------------------------
@@ -632,9 +680,12 @@ __global__ __launch_bounds__(256) void k_tx_prep(RxCtl* __restrict__ ctl, int2* 
 // the duplicate test, the seed test and the bounding box.  (Lanes that are not candidates may hold anything there — an
 // out-of-image neighbour packs to a negative value, a lane past the step's entries to some pixel: they are not in `remaining` /
 // `seeds`, so a match on them clears nothing.)
+// `grp` / grpXY: the candidates of the current group's parked first steps and their pixels — an accepted pixel leaves that mask as it
+// leaves `seeds` (the members that come later must not take what a lower id of this wave holds by then).
 __device__ __forceinline__ int tx_accept_fast(float& sumdx, float& sumdy, float cosv, float sinv, int myxy, int seedXY,
                                               unsigned long long& remaining, unsigned long long& acc, unsigned long long& seeds,
-                                              int& cnt, int& bmin, int& bmax, float lo, float hi, int& j2) {
+                                              int& cnt, int& bmin, int& bmax, float lo, float hi, int& j2,
+                                              unsigned long long& grp, int grpXY) {
   int code, sc, ss, sxy;
   float t0, t1, t2, t3;
   unsigned long long m, sh;
@@ -670,8 +721,15 @@ __device__ __forceinline__ int tx_accept_fast(float& sumdx, float& sumdy, float 
       "v_cmp_eq_u32_e32 vcc, %[xy], %[sp]\n\t"
       "v_pk_min_u16 %[bmin], %[bmin], %[xy]\n\t"
       "s_andn2_b64 %[seeds], %[seeds], vcc\n\t"
+#if TX_GROUP
+      "v_cmp_eq_u32_e32 vcc, %[xy], %[gxy]\n\t"
+      "v_pk_max_u16 %[bmax], %[bmax], %[xy]\n\t"
+      "s_andn2_b64 %[grp], %[grp], vcc\n\t"
+      "v_cmp_eq_u32_e32 vcc, %[xy], %[mxy]\n\t"
+#else
       "v_cmp_eq_u32_e32 vcc, %[xy], %[mxy]\n\t"
       "v_pk_max_u16 %[bmax], %[bmax], %[xy]\n\t"
+#endif
       "s_andn2_b64 %[rem], %[rem], vcc\n\t"
       "s_cbranch_scc1 1b\n"
       "4:\n\t"
@@ -682,8 +740,9 @@ __device__ __forceinline__ int tx_accept_fast(float& sumdx, float& sumdy, float 
       "9:\n\t"
       : [sx] "+v"(sumdx), [sy] "+v"(sumdy), [bmin] "+v"(bmin), [bmax] "+v"(bmax), [rem] "+s"(remaining), [acc] "+s"(acc),
         [seeds] "+s"(seeds), [cnt] "+s"(cnt), [code] "=&s"(code), [j] "=&s"(j2), [xy] "=&s"(sxy), [sc] "=&s"(sc),
-        [ss] "=&s"(ss), [m] "=&s"(m), [sh] "=&s"(sh), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
-      : [cs] "v"(cosv), [sn] "v"(sinv), [mxy] "v"(myxy), [sp] "v"(seedXY), [lo] "s"(lo), [hi] "s"(hi)
+        [ss] "=&s"(ss), [m] "=&s"(m), [sh] "=&s"(sh), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),
+        [grp] "+s"(grp)
+      : [cs] "v"(cosv), [sn] "v"(sinv), [mxy] "v"(myxy), [sp] "v"(seedXY), [lo] "s"(lo), [hi] "s"(hi), [gxy] "v"(grpXY)
       : "vcc", "scc");
   return code;
 }
@@ -694,7 +753,9 @@ __device__ __forceinline__ int tx_pk_max_u16(int a, int b) {
   return (int)((max((unsigned)a >> 16, (unsigned)b >> 16) << 16) | max((unsigned)a & 0xFFFFu, (unsigned)b & 0xFFFFu));
 }
 
-template <bool SPARSE, bool SPEC = false, int GQ = TX_GQ>
+// PACK (t == 1, not SPARSE, not SPEC): round 1 with owner_1 inside the pixel records (see tx_load_rec16).  1: the unclaimed words
+// carry the pixels' own ids (k_tx_sort wrote them); 2 (key mode): they carry the gradient norm (the front pass wrote them, LAZY ids).
+template <bool SPARSE, bool SPEC = false, int GQ = TX_GQ, int PACK = 0>
 __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
                                              const float4* __restrict__ recAll, int2* __restrict__ ownAll,
                                              const int2* __restrict__ listAll, const int* __restrict__ tileCntAll,
@@ -705,7 +766,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
                                              int rectCap, int img, int tile, int t, const int* __restrict__ rankAll,
                                              int* __restrict__ rgLostAll, int* __restrict__ tileTouchAll,
                                              const TxDirtyLists& DL, int* q /* LDS, GQ */, int* gb /* LDS, TX_BMAXBLK */,
-                                             int* park = nullptr /* LDS, 8 x 64 (SPEC) */) {
+                                             int* park /* LDS, TX_PARK (SPEC: 8 x 64) */, const TxKeys* keysp = nullptr /* PACK == 2 */) {
   const DevParams& P = *Pp;
   RxCtl& c = ctl[img];
   if (c.state == 2 || c.overflow) return;
@@ -717,7 +778,8 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
   const int64_t npix = (int64_t)W * H;
   // (later rounds) the seeds stamped dirty for this round were listed per tile by whoever stamped them: up to 64 of them are
   // sorted by rank in registers and taken as the tile's only row; a longer list falls back to the walk over all the seeds
-  int2 dse = make_int2(TX_INF, -1);
+  // (the row of list entries a lane works on; the dirty list is sorted straight into it)
+  int2 se = make_int2(TX_INF, -1);
   bool useDirty = false;
   if (SPARSE && DL.list) {
     const int nd = DL.cnt[(int64_t)img * ntile + tile];
@@ -726,17 +788,17 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
     if (lane == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1) DL.cnt[(int64_t)img * ntile + tile] = 0;
     if (nd <= 64) {
       useDirty = true;
-      if (lane < nd) dse = DL.list[((int64_t)img * ntile + tile) * ts * ts + lane];
+      if (lane < nd) se = DL.list[((int64_t)img * ntile + tile) * ts * ts + lane];
       // bitonic sort of the 64 (rank, seed pixel) pairs, ascending by rank (ranks are distinct; the padding is TX_INF)
 #pragma unroll
       for (int k2 = 2; k2 <= 64; k2 <<= 1) {
 #pragma unroll
         for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-          const int ox = __shfl_xor(dse.x, j2, 64), oy = __shfl_xor(dse.y, j2, 64);
+          const int ox = __shfl_xor(se.x, j2, 64), oy = __shfl_xor(se.y, j2, 64);
           const bool up = (lane & k2) == 0, lowHalf = (lane & j2) == 0;
           const bool takeMin = lowHalf == up;
-          const bool swap = takeMin ? ox < dse.x : ox > dse.x;
-          if (swap) { dse.x = ox; dse.y = oy; }
+          const bool swap = takeMin ? ox < se.x : ox > se.x;
+          if (swap) { se.x = ox; se.y = oy; }
         }
       }
       n = nd;
@@ -773,6 +835,70 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
   const int nm = (lane & 7) < 4 ? (lane & 7) : (lane & 7) + 1;      // 8 neighbours, raster order, centre skipped
   const int ndx = nm % 3 - 1, ndy = nm / 3 - 1;
 
+  // ---- PACK: is the pixel with owner word w free for region id r? ----
+  // A claimed word (bit 31 clear) holds the id of the region that has the pixel: free iff that id is higher.  An unclaimed word
+  // stands for the pixel's own id.  PACK == 1: the id is in the word.  PACK == 2 (LAZY): the id (gradient bin from the strongest
+  // down, then the pixel index) is not, but the word has the gradient norm in 2^-22 fixed point F, and the region knows where the
+  // bins below and above its own begin (T0f, T1f, from its bin b and the image's bin width, +- 4 units: kfix is rounded to 2^-8, the
+  // shifts truncate, F is truncated): F > T1f + margin: a higher bin, i.e. a lower id, used; F < T0f - margin: a lower bin, free;
+  // strictly between: the region's own bin, the pixel index decides; within the margin of a bin boundary (~1e-5 of the pixels) the double plane decides.
+  unsigned lzKfix = 0u;
+  int lzMargin = 1 << 30, lzNb1 = 0, lzPixBits = 0, lzCoefLo = 0, lzCoefHi = 0;     // (the bin coefficient: a double in two scalar registers)
+  const double* lzMg = nullptr;
+  if (PACK == 2) {
+    const unsigned long long mb = keysp->maxMg[img];
+    const double maxGrad = __longlong_as_double((long long)mb);
+    lzNb1 = keysp->nBins - 1;
+    lzPixBits = keysp->pixbits;
+    lzMg = keysp->mg + img * npix;
+    {
+      const long long cb = __double_as_longlong(lsd_bin_coef64(mb, keysp->nBins));
+      lzCoefLo = __builtin_amdgcn_readfirstlane((int)(cb & 0xFFFFFFFFll));
+      lzCoefHi = __builtin_amdgcn_readfirstlane((int)(cb >> 32));
+    }
+    // (an image whose largest norm does not fit the fixed point — no 8-bit image has one — leaves every unclaimed pixel to the double plane)
+    if (mb != 0ull && maxGrad < 500.0) {
+      lzKfix = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(maxGrad / (double)lzNb1 * 1073741824.0 + 0.5));
+      lzMargin = keysp->lazyMargin;
+    }
+  }
+  // (bin b begins at b * kfix >> 8 in the fixed point; kfix < 2^30 and b < 2^10: two 24-bit multiplies instead of a 64-bit one)
+  auto lazyT = [&](const int b) -> int {
+    return (int)((__umul24((unsigned)b, lzKfix >> 12) << 4) + (__umul24((unsigned)b, lzKfix & 0xFFFu) >> 8));
+  };
+  // One region's view of the bins: [tBelow, ...) the bins below its own end before tBelow (F < tBelow: free), its own bin's interior
+  // is tSame .. tSame + tSpan (the pixel index decides), F > tAbove: a higher bin (used); everything else is within the margin of a
+  // boundary.  (Signed compares: F < 2^31.)
+  struct LazyBins { int tBelow, tSame; unsigned tSpan; int tAbove; };
+  auto lazyBins = [&](const int b) -> LazyBins {
+    const int T0 = lazyT(b), T1 = b + 1 > lzNb1 ? 0x7FFFFFEF - min(lzMargin, 1 << 20) : lazyT(b + 1);
+    LazyBins L;
+    if (lzMargin >= (1 << 20)) {                          // (no fixed point to trust, or the test switch: everything unclaimed is left to the double plane)
+      L.tBelow = INT_MIN; L.tSame = 0; L.tSpan = 0u; L.tAbove = INT_MAX;
+      return L;
+    }
+    L.tBelow = T0 - lzMargin;
+    L.tSame = T0 + lzMargin + 1;
+    L.tSpan = T1 - lzMargin > L.tSame ? (unsigned)(T1 - lzMargin - L.tSame) : 0u;
+    L.tAbove = T1 + lzMargin;
+    return L;
+  };
+  auto freeFor = [&](const int w, const int r, const int b, const int spix, const LazyBins& L, const int qi, const bool ok) -> bool {
+    if (PACK != 2) return (int)((unsigned)w & 0x7FFFFFFFu) > r;
+    const int F = w & 0x7FFFFFFF;
+    const bool uncl = w < 0, below = F < L.tBelow, same = (unsigned)(F - L.tSame) < L.tSpan, above = F > L.tAbove;
+    bool fr = (w > r) | (uncl & (below | (same & (qi > spix))));       // (a claimed word is a non-negative id; an unclaimed one is negative: never > r)
+    const bool amb = ok & uncl & !(below | same | above);
+    if (__builtin_amdgcn_ballot_w64(amb) != 0ull) {
+      if (amb) {
+        const double coef = __longlong_as_double(((long long)lzCoefHi << 32) | (long long)(unsigned)lzCoefLo);
+        const int bq = lsd_bin64(lzMg[qi], coef, lzNb1 + 1);
+        fr = bq < b || (bq == b && qi > spix);
+      }
+    }
+    return fr;
+  };
+
   auto qget = [&](int k) -> int {
     int e = tx_lds_read(&q[min(k, GQ - 1)]);
     if (k >= GQ) {
@@ -786,16 +912,33 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
   // seed — every region of the plain schedule) or the prefix a lane has grown by itself (the speculative schedule below: q[0..cnt)
   // hold its pixels, k is the first queue entry that has not been expanded, the sums are the lane's).  seedMask / seedPixV: the live
   // seeds of the current list row and their pixels, packed (y << 16 | x) (a seed whose pixel is taken leaves the mask).  false: a capacity ran out.
-  auto growRegion = [&](const int r, const int sp, const float sa, float sumdx, float sumdy, int cnt, int k, int bmin, int bmax, int angCnt,
-                        unsigned long long& seedMask, const int seedPixV, const int pend0, const int pendRank0) -> bool {
-      double reg_angle = (double)sa * TX_DEG2RAD;         // (the angle of the sums at pixel count angCnt: the seed angle at 1)
+  // grpCand / grpXY / preOct (shared first steps): the candidates of the current group's parked first steps, their pixels, and the
+  // octet of lanes that holds THIS region's (-1: the region fetches its first step itself).
+  auto growRegion = [&](const int r, const float sa, float sumdx, float sumdy, int cnt, int k, int bmin, int bmax,
+                        unsigned long long& seedMask, const int seedPixV, const int pend0, const int pendRank0,
+                        unsigned long long& grpCand, const int grpXY, const int preOct) -> bool {
+      // the region angle for the reference's own expression, taken when a candidate needs it (the angle of the sums at pixel count
+      // angCnt; with the seed alone it is the seed's level-line angle itself)
+      double reg_angle = 0.0;
+      int angCnt = -1;
       // pendOld = what stood in the owner word when this lane's claim of the last step arrived, pendRank = the own rank of the pixel it
       // claimed — what an unclaimed word holds — (r and r: the lane claimed nothing): a lower rank -> this region does not hold the
       // pixel it took; a higher rank that is not the pixel's own -> that region just lost the pixel.  Contested claims are rare:
       // pendOld != pendRank covers both cases, and one compare and one ballot decide for the wave.
       int pendOld = pend0, pendRank = pendRank0;
+      // (LAZY ids: the region's bin, its seed pixel, and where the bins around its own begin)
+      const int rBin = PACK == 2 ? lzNb1 - (r >> lzPixBits) : 0, rSeedPix = PACK == 2 ? (r & ((1 << lzPixBits) - 1)) : 0;
+      LazyBins rBins{};
+      if (PACK == 2) rBins = lazyBins(rBin);
       auto stampLosers = [&]() {
-        if (noteLost) {
+        if (noteLost && PACK) {
+          // (the word a claim found: unclaimed — bit 31 —, or a region's id: a lower one keeps the pixel and THIS region has lost it,
+          // a higher one has just lost it)
+          const bool contested = pendOld >= 0 && pendOld != r;
+          if (__builtin_amdgcn_ballot_w64(contested) != 0ull) {
+            if (contested) rgLost[max(pendOld, r) & DL.rmask] = t;
+          }
+        } else if (noteLost) {
           if (__builtin_amdgcn_ballot_w64(pendOld != pendRank) != 0ull) {
             const bool contested = pendOld < r || (pendOld != r && pendOld != pendRank);
             if (contested) rgLost[(pendOld < r ? r : pendOld) & DL.rmask] = t;
@@ -805,6 +948,43 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
         pendRank = r;
       };
       bool dead = false;
+      // The accept loop of a step whose queue entries fit the LDS queue (tx_accept_fast): walks the candidates `remaining` in lane order;
+      // accepted lanes write their queue entries after the loop (they are accepted in increasing lane order).  True for the accepted lanes.
+      auto acceptBatch = [&](unsigned long long remaining, const float ang, const float cosv, const float sinv, const int myxy) -> bool {
+        unsigned long long acc = 0ull;
+        const int cnt0 = cnt;
+        while (remaining) {
+          int j2;
+          const int code = tx_accept_fast(sumdx, sumdy, cosv, sinv, myxy, seedPixV, remaining, acc, seedMask, cnt, bmin, bmax,
+                                          alignLo, alignHi, j2, grpCand, grpXY);
+          if (code == 0) break;
+          // lane j2 lies inside the margin of the vector filter: the reference's own expression decides
+          if (angCnt != cnt) {
+            reg_angle = (double)(cnt == 1 ? sa : fast_atan2_deg(sumdy, sumdx)) * TX_DEG2RAD;
+            angCnt = cnt;
+          }
+          double n_theta = fabs(reg_angle - (double)tx_rlf(ang, j2) * TX_DEG2RAD);
+          if (n_theta > TX_3_2_PI) {
+            n_theta = fabs(n_theta - TX_2PI);
+          }
+          // (the sums live in vector registers, so the compiler takes this decision for lane-dependent: say it is not)
+          if (!__builtin_amdgcn_readfirstlane((int)(n_theta <= prec))) continue;
+          const int xyj = tx_rl(myxy, j2);
+          const float cj = tx_rlf(cosv, j2), sj = tx_rlf(sinv, j2);
+          acc |= 1ull << j2;
+          remaining &= ~__builtin_amdgcn_ballot_w64(myxy == xyj);        // the other copies of the accepted pixel
+          seedMask &= ~__builtin_amdgcn_ballot_w64(seedPixV == xyj);      // a seed of this row that was just taken
+          if (TX_GROUP) grpCand &= ~__builtin_amdgcn_ballot_w64(grpXY == xyj);   // ... a candidate of a member that comes later
+          ++cnt;
+          bmin = tx_pk_min_u16(bmin, xyj);
+          bmax = tx_pk_max_u16(bmax, xyj);
+          sumdx = __fadd_rn(sumdx, cj);
+          sumdy = __fadd_rn(sumdy, sj);
+        }
+        const bool accepted = (acc >> lane) & 1ull;
+        if (accepted) q[cnt0 + __popcll(acc & ((1ull << lane) - 1ull))] = myxy;
+        return accepted;
+      };
       // One step = up to 8 queue entries x 8 neighbours in one round trip (record + owner pair per lane), the accept loop, the
       // claims.  Two loops, the usual one first (the queue entries of the step fit the LDS queue) and the overflow form after
       // it: as two instances inside ONE loop they shared their loop-carried state and the compiler moved ~20 registers per step.
@@ -828,55 +1008,20 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
         int2 oo;
         asm volatile("" : "=v"(rr.x), "=v"(rr.y), "=v"(rr.z), "=v"(oo.x), "=v"(oo.y));
         rr.w = 0.f;
-        if (ok) {
+        if (PACK) asm volatile("" : "=v"(rr.w));
+        if (PACK) {
+          if (ok) rr = tx_load_rec16(&rec[qi]);
+        } else if (ok) {
           rr = rec[qi];
           oo = tx_load_own(&own[qi]);
         }
-#if defined(TX_DIAG_TRIP)     // diagnostic build: the FIRST step of every region makes its load round trip twice (what is one trip per region worth?)
-        if (k == 0 && cnt == 1 && ok) {
-          asm volatile("" ::"v"(rr.x), "v"(oo.x) : "memory");
-          const float4 r2 = rec[qi + (__float_as_int(rr.x) == 0x7fc01234 ? 1 : 0)];      // (address depends on the first trip's data)
-          const int2 o2 = tx_load_own(&own[qi + (oo.x == 0x7fc01234 ? 1 : 0)]);
-          asm volatile("" ::"v"(r2.x), "v"(o2.x) : "memory");
-          if (__float_as_int(r2.y) == 0x7fc01234 && o2.y == 0x12345678) rr.x = r2.x;      // (never true; keeps the loads)
-        }
-#endif
         const int prevv = ci ? oo.x : oo.y, curv = ci ? oo.y : oo.x;
-        const bool cand = ok && rr.x != TX_NOTDEF && !(prevv < r || curv <= r);
+        bool cand;
+        if (PACK) cand = freeFor(__float_as_int(rr.w), r, rBin, rSeedPix, rBins, qi, ok && rr.x != TX_NOTDEF) && ok && rr.x != TX_NOTDEF;
+        else cand = ok && rr.x != TX_NOTDEF && !(prevv < r || curv <= r);
         unsigned long long remaining = __builtin_amdgcn_ballot_w64(cand);
         if (!SPILL) {
-          // tx_accept_fast; accepted lanes write their queue entries after the loop (they are accepted in increasing lane order)
-          unsigned long long acc = 0ull;
-          const int cnt0 = cnt;
-          while (remaining) {
-            int j2;
-            const int code = tx_accept_fast(sumdx, sumdy, rr.y, rr.z, myxy, seedPixV, remaining, acc, seedMask, cnt, bmin, bmax,
-                                            alignLo, alignHi, j2);
-            if (code == 0) break;
-            // lane j2 lies inside the margin of the vector filter: the reference's own expression decides
-            if (angCnt != cnt) {
-              reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * TX_DEG2RAD;
-              angCnt = cnt;
-            }
-            double n_theta = fabs(reg_angle - (double)tx_rlf(rr.x, j2) * TX_DEG2RAD);
-            if (n_theta > TX_3_2_PI) {
-              n_theta = fabs(n_theta - TX_2PI);
-            }
-            // (the sums live in vector registers, so the compiler takes this decision for lane-dependent: say it is not)
-            if (!__builtin_amdgcn_readfirstlane((int)(n_theta <= prec))) continue;
-            const int xyj = tx_rl(myxy, j2);
-            const float cj = tx_rlf(rr.y, j2), sj = tx_rlf(rr.z, j2);
-            acc |= 1ull << j2;
-            remaining &= ~__builtin_amdgcn_ballot_w64(myxy == xyj);        // the other copies of the accepted pixel
-            seedMask &= ~__builtin_amdgcn_ballot_w64(seedPixV == xyj);      // a seed of this row that was just taken
-            ++cnt;
-            bmin = tx_pk_min_u16(bmin, xyj);
-            bmax = tx_pk_max_u16(bmax, xyj);
-            sumdx = __fadd_rn(sumdx, cj);
-            sumdy = __fadd_rn(sumdy, sj);
-          }
-          accepted = (acc >> lane) & 1ull;
-          if (accepted) q[cnt0 + __popcll(acc & ((1ull << lane) - 1ull))] = myxy;
+          accepted = acceptBatch(remaining, rr.x, rr.y, rr.z, myxy);
         } else {
           while (remaining) {
             // the alignment test in vector form with the exact expression inside the margin (see k_lsd_grow)
@@ -891,7 +1036,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
             const unsigned long long sure = __builtin_amdgcn_ballot_w64(sd2 >= alignHi * n2);
             if (__builtin_expect(!((sure >> j2) & 1ull), 0)) {
               if (angCnt != cnt) {
-                reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * TX_DEG2RAD;
+                reg_angle = (double)(cnt == 1 ? sa : fast_atan2_deg(sumdy, sumdx)) * TX_DEG2RAD;
                 angCnt = cnt;
               }
               double n_theta = fabs(reg_angle - (double)tx_rlf(rr.x, j2) * TX_DEG2RAD);
@@ -928,22 +1073,46 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
             sumdx = __fadd_rn(sumdx, cj);
             sumdy = __fadd_rn(sumdy, sj);
             seedMask &= ~__builtin_amdgcn_ballot_w64(seedPixV == xyj);  // a seed of this row that was just taken
+            if (TX_GROUP) grpCand &= ~__builtin_amdgcn_ballot_w64(grpXY == xyj);
           }
         }
         if (accepted) {
 #if defined(TX_DIAG_NOWAIT)     // diagnostic build (NOT exact: contested claims go unnoticed): non-returning claims, nothing to wait for
           (void)__hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
 #else
-          pendOld = __hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
+          if (PACK) pendOld = (int)__hip_atomic_fetch_min(reinterpret_cast<unsigned*>(tx_rec_owner(&rec[qi])), (unsigned)r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
+          else pendOld = __hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
 #endif
           // (the pixel's own rank, which an unclaimed owner word holds: in round 1 owner_0 is the trivial map, so the word just read has it)
-          if (noteLost) pendRank = (SPARSE || t != 1) ? rankOfPix[qi] : prevv;
+          if (noteLost && !PACK) pendRank = (SPARSE || t != 1) ? rankOfPix[qi] : prevv;
           // (later rounds) the 8x8 cell of every claimed pixel is noted: the next round's k_rx_diff only looks where a claim or the
           // round's k_tx_prep wrote
           if (SPARSE && tileTouch) tileTouch[(myxy >> 19) * TW + ((myxy & 0xFFFF) >> 3)] = t;
         }
         k += nb;
       };
+      if (TX_GROUP && preOct >= 0) {
+        // The region's FIRST step from the group's parked fetch (cnt == 1, k == 0): the lanes of octet preOct hold the seed's 8
+        // neighbours as they stood at group time, minus what this wave's own lower ids have taken since (the accept loops keep
+        // grpCand) — what a fetch of its own would show now, except for claims other tiles' waves made in between, which the
+        // claim's returned value settles like any other stale read.  No candidate left: the region is its seed, without a step.
+        const unsigned long long octet = 0xFFull << (8 * preOct);
+        const unsigned long long remaining = grpCand & octet;
+        grpCand &= ~octet;
+        if (remaining) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          const float pa = __int_as_float(tx_lds_read(&park[lane])), pc = __int_as_float(tx_lds_read(&park[64 + lane])),
+                      ps = __int_as_float(tx_lds_read(&park[128 + lane]));
+          if (acceptBatch(remaining, pa, pc, ps, grpXY)) {
+            const int qi = (grpXY >> 16) * W + (grpXY & 0xFFFF);
+            if (PACK) pendOld = (int)__hip_atomic_fetch_min(reinterpret_cast<unsigned*>(tx_rec_owner(&rec[qi])), (unsigned)r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
+            else pendOld = __hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
+            if (noteLost && !PACK) pendRank = (SPARSE || t != 1) ? rankOfPix[qi] : tx_lds_read(&park[192 + lane]);
+            if (SPARSE && tileTouch) tileTouch[(grpXY >> 19) * TW + ((grpXY & 0xFFFF) >> 3)] = t;
+          }
+        }
+        k = 1;
+      }
       while (k < cnt && cnt + 8 * 8 + 1 <= GQ) oneStep(std::false_type{});
       while (k < cnt && !dead) oneStep(std::true_type{});
       asm volatile("" ::"v"(pendOld) : "memory");       // the claims of the region's last step
@@ -1253,30 +1422,41 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
           k2 = 0;
           q[0] = sxy;                                       // every lane stores the same value
         }
-        if (!growRegion(r, sp, saj, sdx, sdy, cnt2, k2, bmin, bmax, cnt2 == 1 ? 1 : 0, noSeeds, -1, pend0, pendRank0)) return;
+        unsigned long long noGroup = 0ull;
+        if (!growRegion(r, saj, sdx, sdy, cnt2, k2, bmin, bmax, noSeeds, -1, pend0, pendRank0, noGroup, -1, -1)) return;
       }
     }
     return;
   }
   for (int base = 0; base < n; base += 64) {
     const bool valid = base + lane < n;
-    int2 se = make_int2(TX_INF, -1);
-    if (useDirty) se = dse;                               // (n <= 64: one row)
-    else if (valid) se = list[base + lane];
+    if (!useDirty) {                                      // (the dirty list: n <= 64, one row, already there)
+      se = make_int2(TX_INF, -1);
+      if (valid) se = list[base + lane];
+    }
     bool d = valid;
     if (SPARSE && !useDirty) d = valid && rgDirty[se.x & DL.rmask] == t;
     float4 srec = make_float4(TX_NOTDEF, 0.f, 0.f, 0.f);
     int2 so = make_int2(0, 0);
-    if (d) {
+    if (PACK) {
+      // (the seed's angle and its owner word by two small loads: the 16-byte load's result is a 4-register tuple that the allocator
+      // would keep — and spill — whole for as long as the angles of the row are in use)
+      if (d) {
+        srec.x = rec[se.y].x;
+        srec.w = __int_as_float(__hip_atomic_load(tx_rec_owner(&rec[se.y]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      }
+    } else if (d) {
       srec = rec[se.y];
       so = tx_load_own(&own[se.y]);
     }
-    const bool alive = d && (ci ? so.x : so.y) == se.x && (ci ? so.y : so.x) == se.x;
+    // (PACK: a seed is alive while nobody has claimed its pixel)
+    const bool alive = PACK ? d && __float_as_int(srec.w) < 0 : d && (ci ? so.x : so.y) == se.x && (ci ? so.y : so.x) == se.x;
+    const float seedAng = srec.x;
     // region_grow seeds its sums with cos/sin of the unrounded double angle
     float scos = 0.f, ssin = 0.f;
     if (alive) {
       double sn, cn;
-      sincos((double)srec.x * TX_DEG2RAD, &sn, &cn);
+      sincos((double)seedAng * TX_DEG2RAD, &sn, &cn);
       scos = (float)cn;
       ssin = (float)sn;
     }
@@ -1284,14 +1464,71 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
     const unsigned spyv = (unsigned)max(se.y, 0) / (unsigned)W;
     const int sxyv = se.y < 0 ? -1 : (int)((spyv << 16) | ((unsigned)se.y - spyv * (unsigned)W));   // (-1: no pixel packs to it)
     unsigned long long unusedMask = __builtin_amdgcn_ballot_w64(alive);
+    // the current group: its members (lanes of this row, as they stood when it formed), what is left of their parked candidates and
+    // the candidates' pixels, packed like sxyv; onePix: the seeds of the row that turned out to be regions of one pixel
+    unsigned long long grpMembers = 0ull, grpCand = 0ull, onePix = 0ull;
+    int grpXY = -1;
     while (unusedMask) {
       const int j = __ffsll((long long)unusedMask) - 1;
+      int preOct = -1;
+      if (TX_GROUP) {
+        if (!((grpMembers >> j) & 1ull)) {
+          // ---- a new group: seed j and the next alive seeds of the row, up to TX_GROUP; octet g fetches member g's 8 neighbours.
+          // The members hand their pixel and id to their octets through the first words of the queue (no region is being grown).
+          const int idx = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(unusedMask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)unusedMask, 0u));
+          const bool member = ((unusedMask >> lane) & 1ull) != 0ull && idx < TX_GROUP;
+          grpMembers = __builtin_amdgcn_ballot_w64(member);
+          if (member) {
+            q[idx] = sxyv;
+            q[8 + idx] = se.x;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          const int msxy = tx_lds_read(&q[pi]), mr = tx_lds_read(&q[8 + pi]);
+          const int nx = (msxy & 0xFFFF) + ndx, ny = (msxy >> 16) + ndy;
+          const bool ok = pi < __popcll(grpMembers) && nx >= 0 && ny >= 0 && nx < W && ny < H;
+          float4 rr = make_float4(TX_NOTDEF, 0.f, 0.f, 0.f);
+          int2 oo = make_int2(0, 0);
+          if (PACK) {
+            if (ok) rr = tx_load_rec16(&rec[ny * W + nx]);
+          } else if (ok) {
+            rr = rec[ny * W + nx];
+            oo = tx_load_own(&own[ny * W + nx]);
+          }
+          const int prevv = ci ? oo.x : oo.y, curv = ci ? oo.y : oo.x;
+          if (PACK) {
+            const int mBin = PACK == 2 ? lzNb1 - (mr >> lzPixBits) : 0;
+            const bool def = ok && rr.x != TX_NOTDEF;
+            LazyBins mBins{};
+            if (PACK == 2) mBins = lazyBins(mBin);
+            grpCand = __builtin_amdgcn_ballot_w64(freeFor(__float_as_int(rr.w), mr, mBin, PACK == 2 ? (mr & ((1 << lzPixBits) - 1)) : 0, mBins,
+                                                          ny * W + nx, def) && def);
+          } else
+          grpCand = __builtin_amdgcn_ballot_w64(ok && rr.x != TX_NOTDEF && !(prevv < mr || curv <= mr));
+          grpXY = ok ? ((ny << 16) | nx) : -1;
+          park[lane] = __float_as_int(rr.x);
+          park[64 + lane] = __float_as_int(rr.y);
+          park[128 + lane] = __float_as_int(rr.z);
+          park[192 + lane] = prevv;
+        }
+        preOct = __popcll(grpMembers & ((1ull << j) - 1ull));
+      }
       unusedMask &= unusedMask - 1ull;
+      if (TX_GROUP && minReg > 1 && (grpCand & (0xFFull << (8 * preOct))) == 0ull) {
+        // nothing to take around the seed (as parked, minus what the lower ids of this wave took since): a region of one pixel —
+        // no step, no claim; its size and box are stored with the row's other such regions below
+        onePix |= 1ull << j;
+        continue;
+      }
       const int sxy = tx_rl(sxyv, j);
       q[0] = sxy;                                         // every lane stores the same value
       const int rj = tx_rl(se.x, j);
-      if (!growRegion(rj, tx_rl(se.y, j), tx_rlf(srec.x, j), tx_rlf(scos, j), tx_rlf(ssin, j), 1, 0, sxy, sxy, 1, unusedMask, sxyv, rj, rj))
+      if (!growRegion(rj, tx_rlf(seedAng, j), tx_rlf(scos, j), tx_rlf(ssin, j), 1, 0, sxy, sxy, unusedMask, sxyv, rj, rj,
+                      grpCand, grpXY, preOct))
         return;
+    }
+    if ((onePix >> lane) & 1ull) {
+      rgSize[se.x & DL.rmask] = 1;
+      rgBox[se.x & DL.rmask] = make_int2(sxyv, sxyv);
     }
   }
 }
@@ -1324,6 +1561,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                                                 int* __restrict__ rgLostAll, int* __restrict__ tileTouchAll, TxDirtyLists DL) {
   __shared__ int q[TX_GQ];
   __shared__ int gb[TX_BMAXBLK];
+  __shared__ int park[TX_PARK];
   // (the tiles with the most seeds first, k_tx_order: the waves that take longest start first and the launch does not end on a few of them)
   int img = blockIdx.y, tile = blockIdx.x;
   if (DL.perm) {
@@ -1338,7 +1576,53 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     tile = k % (int)gridDim.x;
   }
   tx_grow_tile<false>(Pp, ctl, recAll, ownAll, listAll, tileCntAll, ts, ntx, nty, rgSizeAll, rgBoxAll, rgDirtyAll, tileActAll, TW, TH,
-                   arenaAll, arenaCap, rectAll, rectCap, img + img0, tile, t, rankAll, rgLostAll, tileTouchAll, DL, q, gb);
+                   arenaAll, arenaCap, rectAll, rectCap, img + img0, tile, t, rankAll, rgLostAll, tileTouchAll, DL, q, gb, park);
+}
+// round 1 with owner_1 packed into the pixel records (CV_64F detector; the host picks it, pli_capi.hip)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tx_grow_p1(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
+                                                const float4* __restrict__ recAll, int2* __restrict__ ownAll,
+                                                const int2* __restrict__ listAll, const int* __restrict__ tileCntAll,
+                                                int ts, int ntx, int nty, int* __restrict__ rgSizeAll,
+                                                int2* __restrict__ rgBoxAll, const int* __restrict__ rgDirtyAll,
+                                                const int* __restrict__ tileActAll, int TW, int TH,
+                                                int* __restrict__ arenaAll, int arenaCap, RxRect* __restrict__ rectAll,
+                                                int rectCap, int img0, int t, const int* __restrict__ rankAll,
+                                                int* __restrict__ rgLostAll, int* __restrict__ tileTouchAll, TxDirtyLists DL, TxKeys keys) {
+  __shared__ int q[TX_GQ];
+  __shared__ int gb[TX_BMAXBLK];
+  __shared__ int park[TX_PARK];
+  int img = blockIdx.y, tile = blockIdx.x;
+  if (DL.xcdAffine) {                                     // (as in k_tx_grow)
+    const int L = blockIdx.y * gridDim.x + blockIdx.x, xcd = L & 7, k = L >> 3;
+    img = (k / (int)gridDim.x) * 8 + xcd;
+    tile = k % (int)gridDim.x;
+  }
+  tx_grow_tile<false, false, TX_GQ, 1>(Pp, ctl, recAll, ownAll, listAll, tileCntAll, ts, ntx, nty, rgSizeAll, rgBoxAll, rgDirtyAll, tileActAll,
+                                       TW, TH, arenaAll, arenaCap, rectAll, rectCap, img + img0, tile, 1, rankAll, rgLostAll, tileTouchAll, DL,
+                                       q, gb, park);
+}
+// ... and with LAZY ids (key mode: the front pass wrote the unclaimed words, k_tx_sort touches neither the records nor the owner plane)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tx_grow_p2(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
+                                                const float4* __restrict__ recAll, int2* __restrict__ ownAll,
+                                                const int2* __restrict__ listAll, const int* __restrict__ tileCntAll,
+                                                int ts, int ntx, int nty, int* __restrict__ rgSizeAll,
+                                                int2* __restrict__ rgBoxAll, const int* __restrict__ rgDirtyAll,
+                                                const int* __restrict__ tileActAll, int TW, int TH,
+                                                int* __restrict__ arenaAll, int arenaCap, RxRect* __restrict__ rectAll,
+                                                int rectCap, int img0, int t, const int* __restrict__ rankAll,
+                                                int* __restrict__ rgLostAll, int* __restrict__ tileTouchAll, TxDirtyLists DL, TxKeys keys) {
+  __shared__ int q[TX_GQ];
+  __shared__ int gb[TX_BMAXBLK];
+  __shared__ int park[TX_PARK];
+  int img = blockIdx.y, tile = blockIdx.x;
+  if (DL.xcdAffine) {
+    const int L = blockIdx.y * gridDim.x + blockIdx.x, xcd = L & 7, k = L >> 3;
+    img = (k / (int)gridDim.x) * 8 + xcd;
+    tile = k % (int)gridDim.x;
+  }
+  tx_grow_tile<false, false, TX_GQ, 2>(Pp, ctl, recAll, ownAll, listAll, tileCntAll, ts, ntx, nty, rgSizeAll, rgBoxAll, rgDirtyAll, tileActAll,
+                                       TW, TH, arenaAll, arenaCap, rectAll, rectCap, img + img0, tile, 1, rankAll, rgLostAll, tileTouchAll, DL,
+                                       q, gb, park, &keys);
 }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tx_grow_spec(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
                                                 const float4* __restrict__ recAll, int2* __restrict__ ownAll,
@@ -1367,8 +1651,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                                                        int* __restrict__ rgLostAll, int* __restrict__ tileTouchAll, TxDirtyLists DL) {
   __shared__ int q[TX_GQ];
   __shared__ int gb[TX_BMAXBLK];
+  __shared__ int park[TX_PARK];
   tx_grow_tile<true>(Pp, ctl, recAll, ownAll, listAll, tileCntAll, ts, ntx, nty, rgSizeAll, rgBoxAll, rgDirtyAll, tileActAll, TW, TH,
-                   arenaAll, arenaCap, rectAll, rectCap, blockIdx.y + img0, blockIdx.x, t, rankAll, rgLostAll, tileTouchAll, DL, q, gb);
+                   arenaAll, arenaCap, rectAll, rectCap, blockIdx.y + img0, blockIdx.x, t, rankAll, rgLostAll, tileTouchAll, DL, q, gb, park);
 }
 
 // ---------------------------------------------------------------------------
@@ -1519,6 +1804,7 @@ __device__ __forceinline__ bool tx_grid_barrier(unsigned* bar, unsigned target) 
 __global__ __launch_bounds__(256) void k_tx_tail(TxTailArgs A) {
   __shared__ int qs[4][TX_GQ];
   __shared__ int gbs[4][TX_BMAXBLK];
+  __shared__ int parks[4][TX_PARK];
   __shared__ double sts[4][3][64];
   __shared__ double wcs[4][RX_RECT_CACHE][64];
   __shared__ int ecs[4][RX_RECT_CACHE][64];
@@ -1626,7 +1912,7 @@ __global__ __launch_bounds__(256) void k_tx_tail(TxTailArgs A) {
         const int il = (int)(va / ntile);
         tx_grow_tile<true>(A.Pp, A.ctl, A.rec, A.own, A.list, A.tileCnt, A.ts, A.ntx, A.nty, A.rgSize, A.rgBox, A.rgDirty, A.tileAct, A.TW,
                            A.TH, A.arena, A.arenaCap, A.rects, A.rectCap, A.img0 + il, (int)(va - (int64_t)il * ntile), t, A.rank, A.rgLost,
-                           A.tileTouch, A.DL, qs[wv], gbs[wv]);
+                           A.tileTouch, A.DL, qs[wv], gbs[wv], parks[wv]);
       }
       __syncthreads();
     }

@@ -656,13 +656,17 @@ pli_status allocAll(pli_ctx* c) {
       A(c->txDirtyCnt, (size_t)c->txNtx * c->txNty * NR);
       A(c->tailBar, 64);
       A(c->txPerm, (size_t)c->txNtx * c->txNty * NR);
-      // key mode (lsd_tile.hip, k_tx_sort): ids of 10 + pixbits bits stay below TX_INF up to 2^20 scaled pixels.  PLI_TX_KEYS=0: ranks.
-      // (debug contexts keep the ordered list for PLI_DBG_LSD_ORDER: checked at run time)
-      c->txKeys = c->lsdF64 && npix <= ((size_t)1 << 20) && P.nBins <= 1024 && (npix + LSD_CHUNK - 1) / LSD_CHUNK <= 256 &&
+      // key mode (lsd_tile.hip, k_tx_sort): ids of (bits of nBins - 1) + pixbits bits must stay below LSD_ID_INF = 2^31 - 1: with 1024 bins
+      // up to 2^21 scaled pixels (1280 x 720 scales to 1536 x 864 = 1.33 M; 3840 x 2160 to 11.9 M pixels = 24 bits: ranks).
+      // PLI_TX_KEYS=0: ranks.  (debug contexts keep the ordered list for PLI_DBG_LSD_ORDER: checked at run time)
+      c->txPixBits = 1;
+      while (((size_t)1 << c->txPixBits) < npix) ++c->txPixBits;
+      int binBits = 1;
+      while ((1 << binBits) < P.nBins) ++binBits;
+      // (the largest id is (nBins - 1) << pixbits | npix - 1: strictly below 2^31 - 1 unless every bit is used AND the image fills 2^pixbits)
+      c->txKeys = c->lsdF64 && P.nBins <= 1024 && (binBits + c->txPixBits < 31 || (binBits + c->txPixBits == 31 && npix < ((size_t)1 << c->txPixBits))) &&
                   !(getenv("PLI_TX_KEYS") && atoi(getenv("PLI_TX_KEYS")) == 0);
       if (c->txKeys) {
-        c->txPixBits = 1;
-        while (((size_t)1 << c->txPixBits) < npix) ++c->txPixBits;
         A(c->txCand, (size_t)TX_EMIT_CAP * NR);
         A(c->txCandCnt, NR);
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tx_emit_sorted), hipFuncAttributeMaxDynamicSharedMemorySize, TX_EMIT_CAP * 4));
@@ -825,7 +829,20 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   // (the owner plane's start value: the lane relaxation takes it from the front pass; the tile relaxation's k_tx_sort writes the
   // trivial map for every pixel itself — 8 bytes per scaled pixel less for the front pass to store)
   int2* ownPlane = (sequential || c->lsdMode != 1) ? (int2*)nullptr : c->own;
-  const int trigF32 = (c->cfg.parity_flags & PLI_PARITY_TRIG_F32_LSD) ? 1 : 0;
+  // key mode of the tile relaxation (lsd_tile.hip): no ordered list — it is only built, at the end, for images left to the sequential grower
+  const bool lostRule0 = c->lsdMode != 1 && getenv("PLI_TX_BOXRULE") == nullptr;
+  const bool keyMode = !sequential && c->lsdMode != 1 && c->txKeys && !c->debug && lostRule0 && !getenv("PLI_TX_FULL2") &&
+                       !getenv("PLI_TX_OLDMARK") && !getenv("PLI_TX_CELLRULE");   // (k_rx_mark, lsd_relax.hip, indexes the region planes by rank)
+  // packed round 1 (lsd_tile.hip, tx_load_rec16): owner_1 lives in the fourth word of the pixel records during round 1 — one
+  // 16-byte gather per neighbour instead of two.  Needs the CV_64F detector (the word is free: the gradient norms have their own
+  // plane) and the default schedule (k_tx_round2 moves the result into the owner plane).  In key mode the front pass writes the
+  // unclaimed words itself (2: LAZY ids), otherwise k_tx_sort does (1).  Dev switch PLI_TX_PACK1=0 / 1.
+  int packMode = 0;
+  if (!sequential && c->lsdMode != 1 && c->lsdF64 && c->mg && lostRule0 && !c->debug && !getenv("PLI_TX_FULL2") && !getenv("PLI_TX_NOFUSE2") &&
+      !(getenv("PLI_TX_SPEC") && atoi(getenv("PLI_TX_SPEC")) != 0) && !(getenv("PLI_TX_ORDER") && atoi(getenv("PLI_TX_ORDER")) != 0))
+    packMode = keyMode ? 2 : 1;
+  if (const char* e = getenv("PLI_TX_PACK1")) packMode = std::min(packMode, std::max(0, atoi(e)));
+  const int trigF32 = ((c->cfg.parity_flags & PLI_PARITY_TRIG_F32_LSD) ? 1 : 0) | (packMode == 2 ? 2 : 0);
   if (c->lsdF64) {
     // OpenCV 3.x: the detector works on the CV_64FC1 copy of the image (lsd_f64.hip).  The scaled double image lives in
     // the grower's overflow area (same size, not in use before the growers run).
@@ -872,18 +889,14 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     LAUNCH(c, "k_lsd_grad", k_lsd_grad, g, dim3(256), 0, scaled, sStride, P.LW, P.LH, sPitch, P.g2Thresh, c->rec, c->g2, ownPlane,
            c->maxG2, c->debug ? c->angDbg : (float*)nullptr, img0, trigF32);
   }
-  // key mode of the tile relaxation (lsd_tile.hip): no ordered list — it is only built, at the end, for images left to the sequential grower
-  const bool lostRule0 = c->lsdMode != 1 && getenv("PLI_TX_BOXRULE") == nullptr;
-  const bool keyMode = !sequential && c->lsdMode != 1 && c->txKeys && !c->debug && lostRule0 && !getenv("PLI_TX_FULL2") &&
-                       !getenv("PLI_TX_OLDMARK") && !getenv("PLI_TX_CELLRULE");   // (k_rx_mark, lsd_relax.hip, indexes the region planes by rank)
   auto orderPasses = [&](const RxCtl* only) -> pli_status {
   LAUNCH(c, "k_lsd_hist", k_lsd_hist, dim3(c->nChunks, nimg), dim3(256), 0, c->g2, npix, P.g2Thresh, P.nBins, c->maxG2,
          c->chunkHist, c->nChunks, img0, c->mg, c->maxMg, P.rho, only);
   // (thousands of chunks per image — 4K —: the scan over the chunks in groups, lsd_scanGroups > 0)
   if (c->scanGroups > 0) {
     LAUNCH(c, "k_lsd_scan", k_lsd_scan_part, dim3(nimg, c->scanGroups), dim3(1024), 0, c->chunkHist, c->nChunks, P.nBins,
-           c->scanChunksPerGroup, c->chunkBase, c->scanGroupOff, img0);
-    LAUNCH(c, "k_lsd_scan", k_lsd_scan_groups, dim3(nimg), dim3(1024), 0, c->scanGroups, P.nBins, c->scanGroupOff, c->nDefined, img0);
+           c->scanChunksPerGroup, c->chunkBase, c->scanGroupOff, img0, only);
+    LAUNCH(c, "k_lsd_scan", k_lsd_scan_groups, dim3(nimg), dim3(1024), 0, c->scanGroups, P.nBins, c->scanGroupOff, c->nDefined, img0, only);
   } else
   LAUNCH(c, "k_lsd_scan", k_lsd_scan, dim3(nimg), dim3(1024), 0, c->chunkHist, c->nChunks, P.nBins, c->chunkBase, c->nDefined, img0, only);
   // 16 KB of unused dynamic LDS per single-wave workgroup caps the scatter at 8 waves per CU: with all chunks of an image on
@@ -1021,6 +1034,10 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       const int ts = c->txTs, ntile = c->txNtx * c->txNty;
       TxKeys keys{};
       if (keyMode) keys = TxKeys{c->mg, c->maxMg, P.rho, P.nBins, c->txPixBits, c->rankOf};
+      const bool pack1 = packMode != 0;
+      if (pack1) { keys.recPack = c->rec; keys.pack = packMode; }
+      // (test switch: a wide margin sends every unclaimed pixel of the LAZY form through the double plane; the results must not change)
+      if (const char* e = getenv("PLI_TX_LAZY_MARGIN")) keys.lazyMargin = std::max(4, std::min(0x3FFFFFFF, atoi(e)));
       if (ts == 128)
         TRL(c, "k_tx_sort", k_tx_sort128, dim3(ntile, nimg), dim3(1024), 0, c->rankOf, c->order, c->own, c->txList,
             c->txTileCnt, P.LW, P.LH, ts, c->txNtx, c->txNty, img0, keys);
@@ -1075,7 +1092,8 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
         const bool fused2 = t == 2 && !fullRound2 && lostRule && !getenv("PLI_TX_NOFUSE2");    // (dev switch: the two passes)
         if (fused2)
           TRL(c, "k_tx_round2", k_tx_round2, dim3((P.LW + 31) / 32, (P.LH + 31) / 32, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->order,
-              c->rgBox, c->rgDirty, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, (const int*)c->rgLost, DL, c->tileTouch);
+              c->rgBox, c->rgDirty, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, (const int*)c->rgLost, DL, c->tileTouch,
+              pack1 ? (const float4*)c->rec : (const float4*)nullptr);
         else if (t >= 3 && fusedDM)
           TRL(c, "k_tx_diffmark", k_tx_diffmark, dim3((P.LW + 31) / 32, (c->tilesH + 7) / 8, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf,
               c->rgBox, c->rgDirty, c->tileAct, (const int*)c->tileTouch, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, (const int*)c->rgLost, DL);
@@ -1123,6 +1141,15 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
             TRL(c, "k_tx_order", k_tx_order, dim3(1), dim3(1024), 0, (const int*)c->txTileCnt, ntile, nimg, img0, c->txPerm + (int64_t)img0 * ntile);
             r1DL.perm = c->txPerm + (int64_t)img0 * ntile;
           }
+          if (packMode == 2)
+          TRL(c, "k_tx_grow", k_tx_grow_p2, dim3(ntile, nimg), dim3(64), txPad, c->dP, c->jrCtl, c->rec, c->own, c->txList,
+              c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty, c->tileAct, c->tilesW, c->tilesH, c->arena,
+              c->arenaCap, c->rects, c->rectCap, img0, t, (const int*)c->rankOf, lostRule ? c->rgLost : (int*)nullptr, c->tileTouch, r1DL, keys);
+          else if (packMode == 1)
+          TRL(c, "k_tx_grow", k_tx_grow_p1, dim3(ntile, nimg), dim3(64), txPad, c->dP, c->jrCtl, c->rec, c->own, c->txList,
+              c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty, c->tileAct, c->tilesW, c->tilesH, c->arena,
+              c->arenaCap, c->rects, c->rectCap, img0, t, (const int*)c->rankOf, lostRule ? c->rgLost : (int*)nullptr, c->tileTouch, r1DL, keys);
+          else
           TRL(c, "k_tx_grow", k_tx_grow, dim3(ntile, nimg), dim3(64), txPad, c->dP, c->jrCtl, c->rec, c->own, c->txList,
               c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty, c->tileAct, c->tilesW, c->tilesH, c->arena,
               c->arenaCap, c->rects, c->rectCap, img0, t, (const int*)c->rankOf, lostRule ? c->rgLost : (int*)nullptr, c->tileTouch, r1DL);

@@ -1175,6 +1175,40 @@ def test_key_mode_and_rank_mode_and_the_segment_list_overflow(gpu, monkeypatch):
                 assert out[what][f][k].tobytes() == out["keys"][f][k].tobytes(), (what, f, k)
 
 
+def test_round1_owner_word_forms(gpu, monkeypatch):
+    """Round 1 of the tile relaxation keeps owner_1 in the fourth word of the pixel records (lsd_tile.hip, "PACKED ROUND 1"): written by
+    the front pass as the gradient norm in fixed point (LAZY ids, key mode: the default), or by k_tx_sort as the pixel's id (rank mode;
+    PLI_TX_PACK1=1), or not at all (PLI_TX_PACK1=0: the owner plane, rounds 1-4's form).  All of them give the oracle's lines; and so
+    does the LAZY form when EVERY unclaimed pixel is sent through the exact double-plane test (PLI_TX_LAZY_MARGIN wide) or when the
+    margin around a bin boundary is at its floor."""
+    g = gpu
+    W, H = 752, 480
+    cfg = g.capi.default_config(W, H, orb_nfeatures=300, lsd_nfeatures=0, max_frames=2)
+    pairs = [g.synth.make_stereo_pair(190 + i, W, H) for i in range(2)]
+    imgs = np.stack([np.stack(p) for p in pairs])
+    keys = ("PLI_TX_PACK1", "PLI_TX_LAZY_MARGIN", "PLI_TX_KEYS", "PLI_TX_TAIL")
+    out = {}
+    for what, env in (("lazy", {}), ("lazy_all_exact", {"PLI_TX_LAZY_MARGIN": "2000000"}), ("lazy_margin4", {"PLI_TX_LAZY_MARGIN": "4"}),
+                      ("sort_written_keys", {"PLI_TX_PACK1": "1"}), ("sort_written_ranks", {"PLI_TX_KEYS": "0"}),
+                      ("owner_plane", {"PLI_TX_PACK1": "0"}), ("owner_plane_ranks_no_tail", {"PLI_TX_PACK1": "0", "PLI_TX_KEYS": "0", "PLI_TX_TAIL": "0"})):
+        for k in keys:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        fe = g.Frontend(cfg)
+        fe.batch_run_host(imgs)
+        out[what] = fe.batch_run_host(imgs)
+        assert fe.lsd_round_stats()[2] == 0, (what, fe.lsd_round_stats())      # nobody on the slow path
+    for k in keys:
+        monkeypatch.delenv(k, raising=False)
+    assert len(out["lazy"][0]["klL"]) > 100
+    for f, (L, R) in enumerate(pairs):
+        assert_frame_equal(g, out["lazy"][f], g.po.Frame(ocfg(g, cfg)), L, R, "lazy ids frame %d" % f)
+        for what in out:
+            for k in ("klL", "klR", "ldescL", "ldescR", "disp", "le"):
+                assert out[what][f][k].tobytes() == out["lazy"][f][k].tobytes(), (what, f, k)
+
+
 def test_frame_extract_equals_the_per_call_entry_points(cfg2):
     """pli_frame_extract (what the adapters fuse the four extractor threads of a Frame into) against the four per-call entry points
     and the two stereo matchers: the same record, and the per-call state it leaves (pyramid levels, stereo matchers without a rerun)."""

@@ -5,7 +5,8 @@ bits are compared), both detector pipelines (parity_flags default and 0), batche
   python tools/cross_check.py [--set schedules|tile|sizes] [first seed] [pairs]
     schedules  lsd_mode 1 / 2 / 3 with 64- and 128-pixel tiles                                   (the round-2 sweep)
     tile       the tile relaxation's variants: tail kernel from round 8 / 3 / none, speculative round 1, tiles of 16 / 32,
-               region ids as ranks instead of keys; two calls per context (the second plans from the first)  (the round-3 sweep)
+               region ids as ranks instead of keys, round 1's owner word in the owner plane / written by the sort / lazy with every
+               unclaimed pixel through the exact test; two calls per context (the second plans from the first)  (the round-3 sweep)
     sizes      four image sizes, lsd_mode 1 and 2, one image per call                              (the round-1 sweep)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,7 +28,8 @@ SETS = {
     "tile": [(n, {"lsd_mode": 3}, e) for n, e in (
         ("default", {}), ("tail_t3", {"PLI_TX_TAIL_T0": "3"}), ("no_tail", {"PLI_TX_TAIL": "0"}), ("spec", {"PLI_TX_SPEC": "1"}),
         ("spec_tail_t3_ts32", {"PLI_TX_SPEC": "1", "PLI_TX_TAIL_T0": "3", "PLI_TX_TS": "32"}), ("ts16", {"PLI_TX_TS": "16"}),
-        ("ranks", {"PLI_TX_KEYS": "0"}), ("ranks_no_tail_ts32", {"PLI_TX_KEYS": "0", "PLI_TX_TAIL": "0", "PLI_TX_TS": "32"}))],
+        ("ranks", {"PLI_TX_KEYS": "0"}), ("ranks_no_tail_ts32", {"PLI_TX_KEYS": "0", "PLI_TX_TAIL": "0", "PLI_TX_TS": "32"}),
+        ("owner_plane", {"PLI_TX_PACK1": "0"}), ("sort_written", {"PLI_TX_PACK1": "1"}), ("lazy_all_exact", {"PLI_TX_LAZY_MARGIN": "2000000"}))],
 }
 bad = 0
 if which == "sizes":
