@@ -69,25 +69,30 @@ struct LineParams {
 //
 // A call that waits kWaitMs without its three partners withdraws and takes the per-call path — ONE frame is unfused, the next frame
 // tries again (a late thread on a host busy with LocalMapping / LoopClosing / the viewer must not cost every later Frame the fused
-// path).  Only kMaxMisses timeouts in a row — an integrator that calls the extractors one after the other — put the fusion to sleep,
-// and then for kCoolOff calls only, after which one call probes again (2 ms once every 32 frames).  The four calls of a Frame must
+// path).  Misses are counted per FRAME, not per call: the timed-out calls of one Frame — three waiters and the late-comer, or the
+// four calls of an integrator that calls the extractors one after the other — are one miss (a Frame is over when all four kinds
+// have timed out, or a kind times out again).  Only kMaxMisses unfused Frames in a row put the fusion to sleep, for kCoolOff calls
+// (32 Frames); then ONE Frame probes, and if it does not fuse either the fusion sleeps again at once, twice as long (up to
+// kMaxCoolOff calls): a sequential integrator pays the 2 ms waits on 8 Frames once, then on one Frame in 33, 65, 129, 257.  The four calls of a Frame must
 // agree: the line extractors must be given the images (pointer, stride, size) the ORB extractors of the same eye were given, as
 // Frame.cc:128-135 does; if they differ (a ROI, a preprocessed copy) nobody is fused and every caller extracts from ITS image.
 // stats(): how many Frames went which way.
 struct FrameFusion {
   static constexpr int kOrbL = 0, kOrbR = 1, kLineL = 2, kLineR = 3;
-  static constexpr int kWaitMs = 2, kMaxMisses = 8, kCoolOff = 128;
+  static constexpr int kWaitMs = 2, kMaxMisses = 8, kCoolOff = 128, kMaxCoolOff = 1024;
   // (PLI_FUSION_WAIT_MS: the rendezvous wait for test runs under a sanitizer, where a thread start alone takes milliseconds)
   static int waitMs() {
     static const int ms = [] { const char* e = std::getenv("PLI_FUSION_WAIT_MS"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : kWaitMs; }();
     return ms;
   }
-  struct Stats { uint64_t fused = 0, unfusedCalls = 0, timeouts = 0, mismatched = 0, sleeps = 0; };
+  struct Stats { uint64_t fused = 0, unfusedCalls = 0, timeouts = 0, mismatched = 0, sleeps = 0, missedFrames = 0; };
   std::mutex m;
   std::condition_variable cv;
   int arrived = 0;
-  int misses = 0;                            // timeouts since the last fused frame
+  int misses = 0;                            // Frames that ended in timeouts since the last fused frame
+  int missKinds = 0;                         // kinds (bit per extractor) that have timed out in the Frame being counted
   int asleep = 0;                            // calls left to skip before the next probe
+  int coolOff = kCoolOff;                    // length of the next sleep (doubles while the probes keep failing)
   uint64_t gen = 0;                          // frames collected so far (fused or released)
   bool lastFused = false;                    // outcome of generation gen - 1
   const uint8_t* img[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -102,6 +107,17 @@ struct FrameFusion {
   Stats st;
 
   Stats stats() { std::lock_guard<std::mutex> lk(m); return st; }
+  // (under the lock) a Frame ended unfused by timeouts
+  void missed() {
+    ++st.missedFrames;
+    if (++misses >= kMaxMisses) {
+      // asleep for coolOff calls; the Frame after that is a probe: one more miss and the fusion sleeps again, twice as long
+      misses = kMaxMisses - 1;
+      asleep = coolOff;
+      coolOff = coolOff * 2 > kMaxCoolOff ? kMaxCoolOff : coolOff * 2;
+      ++st.sleeps;
+    }
+  }
 
   // true: the frame was extracted in one submission and `record` holds it; false: take the per-call path
   bool join(int kind, pli::Frontend& fe, const uint8_t* data, int w, int h, int64_t strideBytes, RecordRef& rec) {
@@ -123,7 +139,7 @@ struct FrameFusion {
           error = std::current_exception();
         }
         ++st.fused;
-        misses = 0;
+        misses = 0; missKinds = 0; coolOff = kCoolOff;
       } else {
         ++st.mismatched;
         st.unfusedCalls += 4;
@@ -138,7 +154,11 @@ struct FrameFusion {
       img[kind] = nullptr;                   // the partners did not come in time: withdraw, this call goes alone
       --arrived;
       ++st.timeouts; ++st.unfusedCalls;
-      if (++misses >= kMaxMisses) { misses = 0; asleep = kCoolOff; ++st.sleeps; }
+      // one miss per Frame: this kind has timed out already -> that Frame is over and this call opens the next one; all four
+      // kinds have timed out -> the Frame is complete
+      if (missKinds & (1 << kind)) { missed(); missKinds = 0; }
+      missKinds |= 1 << kind;
+      if (missKinds == 15) { missed(); missKinds = 0; }
       return false;
     }
     // (one Frame at a time per group: generation myGen's outcome is read before generation myGen + 1 can complete, because that

@@ -17,7 +17,7 @@
 //   in: "PLIH" i32 W H nframes reps mode(0 = four calls in a row, 1 = four threads, 2 = four threads, line extractors on copies of the images, 3 = four threads, the rig handed to the extractors before the first Frame: pliSetStereoCamera) nfeatures nlines rigChangeFrame(-1: never) delayFrame(-1: never) delayMs
 //       | f32 rig A: fx fy cx cy bf | f32 rig B (Frames from rigChangeFrame on) | images
 //   delayFrame: on that Frame (every repetition) the thread of the right line extractor starts delayMs late — a loaded host
-//   (VERDICT r3 item 7): that Frame goes unfused, the next ones must fuse again.
+//   (VERDICT r3 item 7): that Frame goes unfused, the next ones must fuse again.  delayFrame + 1000 * (n - 1): n Frames in a row.
 #define PLI_ADAPTER_NO_KEYLINE_HEADER
 #define PLI_ADAPTER_KEYLINE_TYPE cv::line_descriptor::KeyLine
 #include <opencv2/core/core.hpp>
@@ -246,7 +246,8 @@ int main(int argc, char** argv) {
     return 2;
   }
   const int W = hd[0], H = hd[1], nframes = hd[2], reps = hd[3], mode = hd[4], nFeatures = hd[5], lsdNFeatures = hd[6];
-  const int rigChangeFrame = hd[7], delayFrame = hd[8], delayMs = hd[9];
+  // (delayFrame + 1000 * (n - 1): n consecutive Frames from delayFrame on have their late thread)
+  const int rigChangeFrame = hd[7], delayFrame = hd[8] < 0 ? -1 : hd[8] % 1000, delayCount = hd[8] < 0 ? 0 : hd[8] / 1000 + 1, delayMs = hd[9];
   std::vector<cv::Mat> imgs((size_t)nframes * 2);
   for (auto& m : imgs) {
     m.create(H, W, CV_8UC1);
@@ -289,7 +290,7 @@ int main(int argc, char** argv) {
         const int rig = rigChangeFrame >= 0 && i >= rigChangeFrame ? 1 : 0;
         cv::Mat& K = Ks[rig];
         std::unique_ptr<Frame> cur(new Frame(imgs[2 * i], imgs[2 * i + 1], mpORBextractorLeft, mpORBextractorRight, mpLineextractorLeft,
-                                             mpLineextractorRight, K, bfs[rig], mode >= 1, i == delayFrame ? delayMs : 0, mode == 2));
+                                             mpLineextractorRight, K, bfs[rig], mode >= 1, (i >= delayFrame && i < delayFrame + delayCount) ? delayMs : 0, mode == 2));
         if (rep > 0 || i >= 2) { frameSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tFrame0).count(); ++framesTimed; }
         Dump* o = rep == 0 ? &out : nullptr;
         const std::string pre = "f" + std::to_string(i) + "/";
@@ -369,10 +370,11 @@ int main(int argc, char** argv) {
     out.put("frame_ms", 'd', 1, 1, &msPerFrame);
     {
       const pli_detail::FrameFusion::Stats fs = mpORBextractorLeft->pliFusionStats();
-      const uint64_t v[5] = {fs.fused, fs.unfusedCalls, fs.timeouts, fs.mismatched, fs.sleeps};
-      out.put("fusion_stats", 'Q', 1, 5, v);
-      std::printf("dropin_harness: fusion: %llu Frames fused, %llu calls alone, %llu timeouts, %llu mismatched Frames, %llu sleeps\n",
-                  (unsigned long long)v[0], (unsigned long long)v[1], (unsigned long long)v[2], (unsigned long long)v[3], (unsigned long long)v[4]);
+      const uint64_t v[6] = {fs.fused, fs.unfusedCalls, fs.timeouts, fs.mismatched, fs.sleeps, fs.missedFrames};
+      out.put("fusion_stats", 'Q', 1, 6, v);
+      std::printf("dropin_harness: fusion: %llu Frames fused, %llu calls alone, %llu timeouts in %llu Frames, %llu mismatched Frames, %llu sleeps\n",
+                  (unsigned long long)v[0], (unsigned long long)v[1], (unsigned long long)v[2], (unsigned long long)v[5], (unsigned long long)v[3],
+                  (unsigned long long)v[4]);
     }
     // destruction order as a System shutdown; the registry must end empty (contexts are released)
     delete mpORBextractorLeft; delete mpORBextractorRight; delete mpLineextractorLeft; delete mpLineextractorRight;

@@ -157,7 +157,7 @@ def test_four_threads_equal_sequential_calls_and_repeat_identically(runs):
     print("Frame constructor: %.2f ms on four threads (fused), %.2f ms as four calls" % (t["frame_ms"][0, 0], s["frame_ms"][0, 0]))
     assert t["frame_ms"][0, 0] < s["frame_ms"][0, 0]
     assert int(t["groups_left"][0, 0]) == 0, "extractor destruction left device contexts in the registry"
-    fused, alone, timeouts, mismatched, sleeps = (int(v) for v in t["fusion_stats"][0])
+    fused, alone, timeouts, mismatched, sleeps, missed = (int(v) for v in t["fusion_stats"][0])
     # (thread starts on a busy box may miss the 2 ms rendezvous now and then: a floor, not an exact count)
     assert fused >= 800 and mismatched == 0, "four threads per Frame: (nearly) every Frame fuses: %s" % t["fusion_stats"]
     fused_s = int(s["fusion_stats"][0, 0])
@@ -333,10 +333,26 @@ def test_late_thread_unfuses_one_frame_only(runs):
     for k in late:
         if k.startswith("f") and "/" in k:
             same(late[k], t[k], "late thread: " + k)
-    fused, alone, timeouts, mismatched, sleeps = (int(v) for v in late["fusion_stats"][0])
+    fused, alone, timeouts, mismatched, sleeps, missed = (int(v) for v in late["fusion_stats"][0])
     assert timeouts >= 2 and mismatched == 0, late["fusion_stats"]
     assert fused >= 10, "the Frames after the late one must fuse again: %s" % late["fusion_stats"]
     assert fused <= 10 * 2 - 2, "Frame 3 of both repetitions cannot have fused (one thread came 5 ms late): %s" % late["fusion_stats"]
+
+
+@pytest.mark.gpu
+def test_two_late_frames_in_a_row_do_not_put_the_fusion_to_sleep(runs):
+    """VERDICT r4 item 6 / ADVICE r4: misses are counted per FRAME.  Two consecutive Frames with a late thread are two misses (they were
+    eight timeouts, which used to reach kMaxMisses and switch the fused path off for 32 Frames): Frame 5 fuses again, nothing sleeps."""
+    frames = runs["frames"][:10]
+    late = run_harness(runs["exe"], runs["dir"], "late2", frames, 2, 1, delay_frame=3 + 1000, delay_ms=5)
+    t = runs["threads"]
+    for k in late:
+        if k.startswith("f") and "/" in k:
+            same(late[k], t[k], "two late Frames: " + k)
+    fused, alone, timeouts, mismatched, sleeps, missed = (int(v) for v in late["fusion_stats"][0])
+    assert sleeps == 0 and mismatched == 0, late["fusion_stats"]
+    assert 2 <= missed <= 8, "Frames 3 and 4 of both repetitions: one miss each (a slow host may add a few): %s" % late["fusion_stats"]
+    assert 12 <= fused <= 10 * 2 - 4, "the Frames after the two late ones must fuse again: %s" % late["fusion_stats"]
 
 
 @pytest.mark.gpu
@@ -349,5 +365,5 @@ def test_line_extractors_on_other_images_are_not_fused(runs):
     for k in res:
         if k.startswith("f") and "/" in k:
             same(res[k], t[k], "line extractors on copies: " + k)
-    fused, alone, timeouts, mismatched, sleeps = (int(v) for v in res["fusion_stats"][0])
+    fused, alone, timeouts, mismatched, sleeps, missed = (int(v) for v in res["fusion_stats"][0])
     assert fused == 0 and mismatched + timeouts > 0, res["fusion_stats"]

@@ -173,13 +173,32 @@ def test_adapters_under_sanitizers_with_a_mock_library(tmp_path, sanitizer):
         assert r.returncode == 0 and "Sanitizer" not in r.stderr, (name, r.returncode, r.stderr[-3000:])
         d = read_dump(outp)
         assert all(d[k].tobytes() == b[k].tobytes() for k in b if k not in ("frame_ms", "fusion_stats")), name
-        fused, alone, timeouts, mismatched, sleeps = (int(v) for v in d["fusion_stats"][0])
+        fused, alone, timeouts, mismatched, sleeps, missed = (int(v) for v in d["fusion_stats"][0])
         if name == "late":
             # (deterministic: Frame 2 of each repetition cannot fuse — its fourth thread comes 200 ms after a 60 ms wait — and its waiters
             # time out; the other Frames have 60 ms to meet)
             assert timeouts >= 3 and 9 <= fused <= 6 * 3 - 3, d["fusion_stats"]
         else:
             assert fused == 0 and mismatched + timeouts > 0, d["fusion_stats"]
+    # misses are counted per Frame: two Frames in a row with a late thread are 2 misses, not 8 timeouts — nothing sleeps
+    # and the Frames after them fuse; an integrator that calls the extractors one after the other (mode 0) misses once per Frame, sleeps
+    # after 8 Frames, and every probe Frame after a sleep that fails sends the fusion straight back to sleep (twice as long)
+    inp, outp = str(tmp_path / "in"), str(tmp_path / "out_late2")
+    write_input(inp, frames, 3, 1, nfeatures=500, nlines=60, delay_frame=2 + 1000, delay_ms=200)
+    r = subprocess.run([exe, inp, outp], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "Sanitizer" not in r.stderr, (r.returncode, r.stderr[-3000:])
+    d = read_dump(outp)
+    assert all(d[k].tobytes() == b[k].tobytes() for k in b if k not in ("frame_ms", "fusion_stats"))
+    fused, alone, timeouts, mismatched, sleeps, missed = (int(v) for v in d["fusion_stats"][0])
+    assert sleeps == 0 and 6 <= missed <= 8 and timeouts >= 6 * 3 and 9 <= fused <= 6 * 3 - 6, d["fusion_stats"]
+    env2 = dict(env, PLI_FUSION_WAIT_MS="1")
+    inp, outp = str(tmp_path / "in"), str(tmp_path / "out_seq")
+    write_input(inp, frames, 30, 0, nfeatures=500, nlines=60)
+    r = subprocess.run([exe, inp, outp], capture_output=True, text=True, env=env2)
+    assert r.returncode == 0 and "Sanitizer" not in r.stderr, (r.returncode, r.stderr[-3000:])
+    fused, alone, timeouts, mismatched, sleeps, missed = (int(v) for v in read_dump(outp)["fusion_stats"][0])
+    # 180 Frames: 8 missed Frames, 32 asleep, 1 probe, 64 asleep, 1 probe, 128 asleep ... = 10 missed Frames, 3 sleeps (it was 8 x 4 timeouts per 34 Frames)
+    assert fused == 0 and missed == 10 and sleeps == 3 and timeouts == 40 and alone == 180 * 4, (fused, alone, timeouts, mismatched, sleeps, missed)
     assert len(set(a["hashes"].ravel().tolist())) == 1 and int(a["groups_left"][0, 0]) == 0
     assert len(a["f0/mvKeys.f"]) >= 200 and len(a["f1/sbp0/match12"]) > 0 and int(a["f1/line_nmatches"][0, 0]) > 0
 
