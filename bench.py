@@ -347,6 +347,7 @@ def main():
                     help="the batch is cut from real photographs (pli_slam_amd/realdata.py, tests/golden/real/photos.npz) instead of "
                          "synthetic scenes: rate, relaxation rounds and fallbacks on natural gradients (752x480 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=18.0, help="budget of the CPU-baseline leg (the oracle on the host cores)")
     ap.add_argument("--no-host-leg", action="store_true")
     ap.add_argument("--no-large-batch-leg", action="store_true")
     ap.add_argument("--lsd-mode", type=int, default=0, help="0 auto, 1 relaxation, 2 sequential waves, 3 tile-sequential relaxation")
@@ -383,6 +384,8 @@ def main():
         assert dist.get_world_size() == args.gpus
         sys.exit(dry_tables(args, rank, world))
 
+    if args.real_images and (args.config in (3, 5) or (args.width or 752) != 752 or (args.height or 480) != 480):
+        sys.exit("--real-images cuts 752x480 windows from the photographs: not with --config 3 / 5 or another --width / --height")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the front-end has no CPU path")
     if args.share_device:
@@ -528,10 +531,17 @@ def main():
     if multi and not args.no_cpu_baseline:
         counts_r = [shard_range(BATCH4, r_, world)[1] * max(1, args.inflight) if args.config == 4 else F for r_ in range(world)]
 
+        real_cache = {}
+
         def pair_of(r_, i_):        # the stereo pair behind record i_ of rank r_ (the seeds / instants the ranks drew above)
             nu = min(counts_r[r_], args.unique_frames)
             if args.config == 3:
                 return synth.make_stereo_pair(100, W, H, t=r_ * nu + (i_ % nu))
+            if args.real_images:    # (the windows rank r_ cut from the photographs: the same seed gives the same windows)
+                if r_ not in real_cache:
+                    from pli_slam_amd import realdata
+                    real_cache[r_] = realdata.frames_752x480(nu, seed=17 + r_, w=W, h=H)
+                return real_cache[r_][i_ % nu]
             return synth.make_stereo_pair(r_ * nu + (i_ % nu), W, H)
         halo = {"checked": 0, "bad": 0}
         if track is not None and rank > 0 and F > 0:
@@ -568,21 +578,37 @@ def main():
         step_traffic = None  # counter traffic of the WHOLE step (every kernel x its launches) against the algorithmic bytes
         traffic = None     # HBM bytes per launch from the committed PMC passes of the same workload, if any
         sector = None      # the growers are gather kernels: their ceiling is the rate of random 64-byte sector requests the chip
+        counters_note = None   # why a counter-derived field is null, or which committed workload stood in for this one
         try:               # sustains (tools/probes/gather_rate.hip, profiles/r02_gather_rate_probe.txt: 49 G/s), not the stream peak
-            tpath = [p_ for p_ in (os.path.join(ROOT, "profiles", "r%02d_traffic.json" % n_) for n_ in (4, 3, 2)) if os.path.exists(p_)][0]
+            tpath = [p_ for p_ in (os.path.join(ROOT, "profiles", "r%02d_traffic.json" % n_) for n_ in (5, 4, 3, 2)) if os.path.exists(p_)][0]
             tr = json.load(open(tpath))
             wkey = "%dx%d_F%d" % (W, H, F)
+            src_F = F
+            if wkey not in tr["workloads"]:
+                # no counter pass was committed for this batch size (a shard of config 4, another --frames-per-gpu): the nearest committed
+                # workload of the SAME image size stands in, its per-launch counters scaled by the ratio of the batch sizes (the
+                # kernels of the path are per-image work), and the line says so
+                same = sorted((abs(int(k_.split("_F")[1]) - F), k_) for k_ in tr["workloads"] if k_.startswith("%dx%d_F" % (W, H)))
+                if same:
+                    wkey = same[0][1]
+                    src_F = int(wkey.split("_F")[1])
+                    counters_note = "no committed counter pass for F = %d: %s of %s scaled by %d / %d" % (F, wkey, os.path.basename(tpath), F, src_F)
+                else:
+                    counters_note = "no committed counter pass for %dx%d in %s" % (W, H, os.path.basename(tpath))
+            scale_F = F / float(src_F)
             k = tr["workloads"].get(wkey, {}).get(name)
+            if k and scale_F != 1.0:
+                k = dict(k, fetch_kb=k["fetch_kb"] * scale_F, write_kb=k["write_kb"] * scale_F)
             isGather = lambda kn_: kn_.startswith(("k_tx_grow", "k_lsd_grow", "k_rx_grow"))
             wl = tr["workloads"].get(wkey, {})
             if wl and all("launches" in v_ for v_ in wl.values()):
-                tot = sum(v_["launches"] * ((1 if isGather(kn_) else 2) * v_["fetch_kb"] + v_["write_kb"]) * 1024 for kn_, v_ in wl.items()
-                          if "alias_of" not in v_)
+                tot = scale_F * sum(v_["launches"] * ((1 if isGather(kn_) else 2) * v_["fetch_kb"] + v_["write_kb"]) * 1024 for kn_, v_ in wl.items()
+                                    if "alias_of" not in v_)
                 step_traffic = {"bytes_per_step": tot, "algorithmic_bytes_per_step": b_frame * F, "ratio": tot / (b_frame * F),
-                                "hbm_GBps_at_this_rate": tot / (dt / args.steps) / 1e9, "source": os.path.basename(tpath),
+                                "hbm_GBps_at_this_rate": tot / (dt / args.steps) / 1e9, "source": os.path.basename(tpath), "source_workload": wkey,
                                 "note": "sum over the kernels of the committed FETCH_SIZE / WRITE_SIZE passes x their launches per step"}
             iq = tr.get("issue", {}).get(wkey, {}).get(name)
-            if iq and iq["avg_ns"] > 0:
+            if iq and iq["avg_ns"] > 0 and scale_F == 1.0:
                 simd_quads = 1024 * iq["avg_ns"] * 2.4 / 4.0        # quad-cycles all SIMDs of the chip offer during one launch (2.4 GHz)
                 issue = {"valu_issue_frac": iq["active_valu_quad_cycles"] / simd_quads, "valu_wave_instructions": iq["valu"],
                          "salu_wave_instructions": iq["salu"], "launch_ns_under_profiler": iq["avg_ns"], "source": os.path.basename(tpath),
@@ -597,8 +623,8 @@ def main():
                     rate = k["fetch_kb"] * 1024 / 64 / avg_s / 1e9      # FETCH_SIZE counts 64 B per request of these kernels
                     sector = {"achieved": rate, "peak": 49.0, "unit": "G 64-byte sector requests/s (L2 misses)", "frac": rate / 49.0,
                               "note": "peak measured by tools/probes/gather_rate.hip; requests per launch from the committed FETCH_SIZE pass"}
-        except Exception:
-            pass
+        except Exception as e:     # (the headline does not depend on the committed counter files; the line says what went wrong)
+            counters_note = "counter files not usable: %r" % (e,)
         # every kernel of the step against the HBM peak: algorithmic bytes per image (table above) x images per step / its time per step
         # (a kernel of the ORB chain is timed on the side stream, beside the line chain: its fraction is a lower bound)
         kfrac = {}
@@ -618,14 +644,14 @@ def main():
                 if fr_ <= 1.0:
                     kfrac[kn] = round(fr_, 4)
         side = orb_chain + ("k_stereo_points", "k_stereo_median", "k_blur_lbd", "k_sobel")
-        roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": peak, "unit": "GB/s",
+        grower = bool(name) and name.startswith(("k_tx_grow", "k_lsd_grow", "k_rx_grow"))
+        # `frac` is against the HBM peak, as the contract asks; a region grower is a chain of dependent gathers at the occupancy limit of
+        # 8 waves per SIMD, so `bound` / `limiter` name that category (the measurements behind it: DESIGN.md 5) and `issue`, `sector_requests`
+        # and `step_traffic` carry what the committed counter passes of this workload say — null, with `counters_note`, when there are none
+        roof = {"bound": "latency (wave slots)" if grower else "hbm", "kernel": name, "achieved": achieved, "peak": peak, "unit": "GB/s",
                 "frac": (achieved / peak) if achieved is not None else None, "traffic": traffic, "sector_requests": sector,
-                # the HBM roofline is the contract's; what actually limits the dominant kernel (an 8-byte-gather region grower) is
-                # the chip's instruction issue: `issue` carries the measured VALU-issue fraction, `limiter` says it in a word
-                "limiter": ("dependent memory round trips per batched step at the occupancy limit of 8 waves per SIMD (waves parked in "
-                            "s_waitcnt 71 % of their cycles; +20 % instructions cost +4 % time, one more round trip per region +10 %: "
-                            "DESIGN.md 5 'Round 4'), neither HBM bandwidth nor instruction issue"
-                            if name and name.startswith(("k_tx_grow", "k_lsd_grow", "k_rx_grow")) else "hbm"),
+                "limiter": "latency/occupancy (DESIGN.md 5)" if grower else "hbm",
+                "counters_note": counters_note,
                 "issue": issue, "step_traffic": step_traffic,
                 "avg_launch_ms": avg_s * 1e3, "launches": calls,
                 "path_achieved": fps / world * b_frame / 1e9, "path_frac": fps / world * b_frame / 1e9 / peak,
@@ -677,6 +703,10 @@ def main():
         if args.config == 4:
             out["config"]["batch_frames"] = BATCH4
             out["config"]["batches_in_flight"] = max(1, args.inflight)
+        if multi and not args.no_cpu_baseline:
+            # the multi-rank line carries the CPU baseline too (rule d): rank 0 times the oracle on a sample of ITS shard after the
+            # timed region; the other ranks wait at the closing barrier below
+            out["cpu_baseline"] = cpu_baseline(images, bytes(cfg), budget_s=args.cpu_baseline_seconds)
         if not multi and not args.no_cpu_baseline:
             # BASELINE.json configs[1] (a single stereo pair) beside the batch: latency of one pair through the same library
             if F > 1 and (W, H) == (752, 480):
@@ -699,7 +729,7 @@ def main():
                 del f1
             if not args.no_host_leg:
                 out["host_inclusive"] = host_inclusive_leg(fe, images, F, nuniq, W, H, rec_bytes, args.steps)
-            out["cpu_baseline"] = cpu_baseline(images, bytes(cfg))
+            out["cpu_baseline"] = cpu_baseline(images, bytes(cfg), budget_s=args.cpu_baseline_seconds)
             # the table the last timed step left in d_table is the one that is checked
             out["parity"] = parity_check(fe, cfg, d_table, images, F, nuniq, rec_bytes)
             if not out["parity"]["ok"]:

@@ -25,6 +25,18 @@ def test_gpus2_self_launches_two_ranks_and_root_receives_both_shards():
     assert d["gathered_bytes_per_step"] == 256 * 4096
 
 
+def test_gpus8_config4_is_32_frames_per_rank_and_256_records_at_the_root():
+    """SURVEY 8e / BASELINE configs[3] exactly: `bench.py --gpus 8 --config 4` cuts the 256-frame batch into 32 frames per rank and the
+    root receives all 256 records (eight gloo ranks on the CPU, dry tables)."""
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--backend", "gloo", "--dry-tables", "--config", "4",
+                          "--steps", "2", "--warmup", "1"], env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["shards_ok"] is True
+    assert d["batch_frames"] == 256 and d["shard_frames"] == [32] * 8
+    assert d["gathered_bytes_per_step"] == 256 * 4096
+
+
 def test_gpus_must_match_world_size():
     env = _clean_env()
     env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29611")

@@ -96,8 +96,9 @@ def _worker_halo(rank, world, path, nframes, rec):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,nframes", [(2, 8), (3, 7), (3, 2)])
+@pytest.mark.parametrize("world,nframes", [(2, 8), (3, 7), (3, 2), (8, 256), (8, 7)])
 def test_one_frame_halo_across_shard_borders_gloo(world, nframes):
-    """rank r receives the table record of frame start_r - 1 (f2f matching across shard borders)."""
+    """rank r receives the table record of frame start_r - 1 (f2f matching across shard borders).  (8, 256): the
+    partition of BASELINE configs[3] (32 frames per rank); (8, 7): eight ranks, the last one without frames."""
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker_halo, args=(world, os.path.join(d, "rdv"), nframes, 128), nprocs=world, join=True)

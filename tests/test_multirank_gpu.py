@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 def run_bench(*extra):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "2", "--warmup", "1",
-                          *extra], env=env, capture_output=True, text=True, timeout=900)
+                          "--cpu-baseline-seconds", "3", *extra], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
 
@@ -47,6 +47,16 @@ def test_default_workload_two_ranks_weak_scaling_line():
     d = run_bench("--frames-per-gpu", "16")
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["parity"]["ok"] is True
     assert d["parity"]["records_gathered"] == 32
+    # the multi-rank line is complete by the bench contract: every key of the single-rank line, the CPU baseline
+    # (rank 0 times the oracle after the timed region) and the roofline object with its counter fields or the note that says why not
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "parity", "gather"):
+        assert k in d, k
+    cb = d["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] in ("port", "reference") and cb["sample"]
+    rf = d["roofline"]
+    assert rf["bound"] and rf["achieved"] > 0 and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1
+    assert rf["traffic"] is not None or rf["counters_note"]
 
 
 # ---- the RCCL calls themselves -------------------------------------------------------------------------------
@@ -59,7 +69,7 @@ def run_nccl_one_rank(*extra):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     out = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--backend", "nccl", "--force-dist", "--steps", "2", "--warmup", "1",
-                          *extra], env=env, capture_output=True, text=True, timeout=900)
+                          "--cpu-baseline-seconds", "3", *extra], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
 
