@@ -214,3 +214,23 @@ def test_extractor_registry_pairing_release_and_plibind(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and "registry_test: ok" in r.stdout, r.stdout + r.stderr[-3000:]
+
+
+def test_pin_stage3_source_compiles_and_reports_equal_layouts_against_the_stand_in_headers(tmp_path):
+    """tools/pin/adapters_against_opencv.cpp is the one-command check for a machine that HAS OpenCV (tools/pin/run_pin.sh stage 3): the
+    adapters against the real headers, cv::KeyPoint / KeyLine offsets against pli_keypoint / pli_keyline.  Here it is kept compiling —
+    and its offset table kept honest — against the stand-in headers and the mock library."""
+    inc = tmp_path / "inc"
+    (inc / "opencv2" / "features2d").mkdir(parents=True)
+    (inc / "opencv2" / "features2d" / "features2d.hpp").write_text("#include <opencv2/core/core.hpp>\n")
+    (inc / "line_descriptor_custom.hpp").write_text(
+        "#pragma once\n#include <opencv2/core/core.hpp>\nnamespace cv { namespace line_descriptor {\n"
+        "struct KeyLine { float angle; int class_id; int octave; cv::Point2f pt; float response; float size; float startPointX, startPointY, "
+        "endPointX, endPointY, sPointInOctaveX, sPointInOctaveY, ePointInOctaveX, ePointInOctaveY; float lineLength; int numOfPixels; };\n}}\n")
+    exe = str(tmp_path / "adp")
+    r = subprocess.run(["g++", "-std=c++17", "-I", ROOT, "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "stubs"), "-I", str(inc),
+                        os.path.join(ROOT, "tools", "pin", "adapters_against_opencv.cpp"), os.path.join(ROOT, "tests", "cpp", "mock_pli.cpp"),
+                        "-pthread", "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "layouts agree" in r.stdout and "differs" not in r.stdout, r.stdout

@@ -18,4 +18,19 @@ if [ -n "$PLI_SLAM_ROOT" ]; then
       $(pkg-config --cflags --libs $PC)
   "$OUT/pin_reference_extractors" "$IN" "$OUT"
 fi
+# stage 3 (with PLI_SLAM_ROOT; round 5): the C++ drop-in against the REAL OpenCV headers — the GPU suite compiles the adapters against
+# tests/stubs/opencv2 only — and the field offsets of cv::KeyPoint / cv::line_descriptor::KeyLine against pli_keypoint / pli_keyline
+if [ -n "$PLI_SLAM_ROOT" ]; then
+  R="$PLI_SLAM_ROOT"
+  INC="-I$ROOT -I$ROOT/include -I$R/Thirdparty/line_descriptor/include $(pkg-config --cflags $PC)"
+  g++ -std=c++11 -fsyntax-only $INC "$HERE/adapters_against_opencv.cpp" && echo "stage 3: the adapters compile against the installed OpenCV headers"
+  # (the linked run prints the offsets; the library is only needed to resolve the symbols: none of it is called)
+  if [ -f "$ROOT/pli_slam_amd/csrc/libpli_frontend.so" ]; then
+    g++ -std=c++11 -O1 $INC "$HERE/adapters_against_opencv.cpp" -o "$OUT/adapters_against_opencv" -L"$ROOT/pli_slam_amd/csrc" -lpli_frontend \
+        -Wl,-rpath,"$ROOT/pli_slam_amd/csrc" $(pkg-config --libs $PC) -pthread && "$OUT/adapters_against_opencv" | tee "$OUT/adapter_layouts.txt"
+  else
+    g++ -std=c++11 -O1 $INC "$HERE/adapters_against_opencv.cpp" "$ROOT/tests/cpp/mock_pli.cpp" -o "$OUT/adapters_against_opencv" \
+        $(pkg-config --libs $PC) -pthread && "$OUT/adapters_against_opencv" | tee "$OUT/adapter_layouts.txt"
+  fi
+fi
 python3 "$HERE/pin_compare.py" "$OUT"
