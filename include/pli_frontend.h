@@ -39,7 +39,11 @@
  *     compute units the other needs; every barrier wait is bounded (about a
  *     second), the kernels then give up and the images that had not settled
  *     are redone by the sequential grower — results stay exact, the call
- *     stalls, and pli_lsd_round_stats out[2] counts the images.
+ *     stalls, and pli_lsd_round_stats out[2] counts the images.  A process
+ *     that sees this happen once (the control blocks of a call come back with
+ *     unsettled images although the persistent kernel ran) switches itself to
+ *     the planned-rounds schedule on that device for the rest of its life and
+ *     says so once on stderr: the stall is paid at most twice, not per call.
  */
 #ifndef PLI_FRONTEND_H
 #define PLI_FRONTEND_H

@@ -167,6 +167,7 @@ struct TxTailArgs {
   TxDirtyLists DL;
   int img0, nimg, t0, maxRounds;
   unsigned* bar;       // [0] arrivals (zeroed by the host before the launch), [32] abort word (its own line)
+  int forceAbort = 0;  // test switch: behave as if the first grid barrier had timed out
 };
 
 // a region in mid-growth, handed from the lane grower to the wave grower

@@ -1810,6 +1810,10 @@ __global__ __launch_bounds__(256) void k_tx_tail(TxTailArgs A) {
   __shared__ int ecs[4][RX_RECT_CACHE][64];
   __shared__ int s_live, s_n;
   __shared__ int s_list[256];
+  if (A.forceAbort) {                                    // (test switch: what every block does when a barrier times out)
+    if (threadIdx.x == 0) __hip_atomic_store(&A.bar[32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   const DevParams& P = *A.Pp;
   const int W = P.LW, H = P.LH;
   const int64_t npix = (int64_t)W * H;

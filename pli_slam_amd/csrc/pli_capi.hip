@@ -116,6 +116,8 @@ struct pli_ctx {
   unsigned* tailBar = nullptr;      // [0] barrier arrivals, [32] abort word
   int* txPerm = nullptr;            // round 1: (image, tile) pairs in order of decreasing seed count (k_tx_order)
   int tailBlocks = 0;               // resident grid: CUs x blocks per CU (from the kernel's occupancy)
+  bool tailLaunched = false;        // this call launched k_tx_tail ...
+  bool rxSeenTail = false;          // ... and so did the call whose control blocks are on their way to the host (rxSeen)
   int rxMargin = 3;
   int rxPlanned = 0;                // rounds the last call launched without looking (0: it looked)
   int* rxSeen = nullptr;            // pinned: {state, changed, overflow, rounds} per image of the last look-free call
@@ -231,7 +233,13 @@ struct TraceRange {
 
 // the last k_tx_tail launch on every device of this process (see the launch site)
 static std::mutex g_tailMu;
-static hipEvent_t g_tailEv[64] = {};
+constexpr int TAIL_MAX_DEVICES = 64;
+static hipEvent_t g_tailEv[TAIL_MAX_DEVICES] = {};
+// ... and whether a tail of this process has ever been ABORTED on a device (its grid barrier timed out: somebody else — another
+// process — holds compute units the resident grid needs).  From then on this process runs the planned-rounds schedule on that device
+// instead of stalling a second per call (include/pli_frontend.h "Sharing a device").
+static bool g_tailAborted[TAIL_MAX_DEVICES] = {};
+static bool g_tailWarned = false;
 
 struct CtxGuard {
   const pli_ctx* c;
@@ -639,12 +647,24 @@ pli_status allocAll(pli_ctx* c) {
     // instead of 50); they need < 16 (8 is not enough: round 3's last commit budgeted 8 GiB, which gave the 256-frame context 8 words,
     // and the stripes batch took the fallback again, 507 ms — found by tools/rounds_sweep.py in round 4).  A context gets 16 words per
     // pixel as long as its arenas stay below 18 GiB (256 frames of 752 x 480: 17.0 GB of the 288 GB HBM); larger contexts share that
-    // budget (512 frames: 8 words, thousands of images: 3-4).
+    // budget (512 frames: 8 words; a 2047-image context of the auto mode: ~10 words, 19 GB).  The budget is also clamped to a
+    // quarter of what the device has FREE when the context is created (several large contexts in one process, a part with less HBM),
+    // and an allocation that still fails is retried with half the words down to 3 before the context gives up.
     size_t arenaFactor = lane ? 8 : 16;
-    if (!lane) arenaFactor = std::max<size_t>(3, std::min<size_t>(16, ((size_t)18 << 30) / (npix * 4 * NR)));
+    if (!lane) {
+      size_t budget = (size_t)18 << 30, freeB = 0, totalB = 0;
+      if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB > 0) budget = std::min(budget, freeB / 4);
+      arenaFactor = std::max<size_t>(3, std::min<size_t>(16, budget / (npix * 4 * NR)));
+    }
     if (const char* e = getenv("PLI_RX_ARENA")) arenaFactor = (size_t)std::max(1, atoi(e));     // dev: words of arena per scaled pixel
-    c->arenaCap = (int)std::min<size_t>(arenaFactor * npix + 65536, (size_t)1 << 30);
-    A(c->arena, (size_t)c->arenaCap * NR);
+    for (;;) {
+      c->arenaCap = (int)std::min<size_t>(arenaFactor * npix + 65536, (size_t)1 << 30);
+      const pli_status as = c->dalloc(&c->arena, (size_t)c->arenaCap * NR);
+      if (as == PLI_OK) break;
+      if (lane || arenaFactor <= 3) return as;
+      (void)hipGetLastError();                              // (the failed allocation's error state)
+      arenaFactor = std::max<size_t>(3, arenaFactor / 2);
+    }
     if (tiles) {
       // (the measure is the number of 64-pixel tile waves the context can put on the chip, not the number of images)
       c->txTs = (int64_t)NI * ((P.LW + 63) / 64) * ((P.LH + 63) / 64) <= TX_SMALL_TILE_WAVES ? 32 : 64;
@@ -739,6 +759,18 @@ int foldRoundStats(pli_ctx* c) {
     else settled = std::max(settled, h[3]);
   }
   c->rxSlowImages += unsettled + overflowed;
+  // An image that has not settled although the self-terminating tail kernel ran (it walks up to 96 rounds): the tail was aborted —
+  // its grid barrier timed out because the resident grid did not fit beside somebody else's work (another PROCESS on the device).
+  // This process runs the planned-rounds schedule on that device from now on instead of stalling ~1 s in every call.
+  if (unsettled && c->rxSeenTail && c->device >= 0 && c->device < TAIL_MAX_DEVICES) {
+    std::lock_guard<std::mutex> lk(g_tailMu);
+    g_tailAborted[c->device] = true;
+    if (!g_tailWarned) {
+      g_tailWarned = true;
+      std::fprintf(stderr, "pli_frontend: the persistent relaxation kernel did not finish on device %d (another process on the device?); "
+                           "this process uses the planned-rounds schedule there from now on (as with PLI_TX_TAIL=0)\n", c->device);
+    }
+  }
   if (unsettled) c->rxLastRounds = std::min(96, c->rxLastRounds + c->rxMargin);        // not enough rounds: plan more next time
   else if (settled > 0) c->rxLastRounds = std::max(settled, c->rxLastRounds - 1);       // (follows a calmer stream down slowly)
   c->rxSeenImages = 0;
@@ -1003,7 +1035,9 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       if (const char* e = getenv("PLI_TX_TAIL_BPC")) bpc = std::max(1, atoi(e));
       c->tailBlocks = perCu < 1 ? -1 : std::min(perCu, bpc) * std::max(1, cus);
     }
-    const bool tailPossible = tile && c->tailBar && c->tailBlocks > 0 && !getenv("PLI_RX_PLAN") && !trace && !perRound && !getenv("PLI_RX_BLOCKING") &&
+    c->tailLaunched = false;
+    const bool tailLatched = c->device < 0 || c->device >= TAIL_MAX_DEVICES || g_tailAborted[c->device];   // (no chain slot for the device: no tail)
+    const bool tailPossible = tile && c->tailBar && c->tailBlocks > 0 && !tailLatched && !getenv("PLI_RX_PLAN") && !trace && !perRound && !getenv("PLI_RX_BLOCKING") &&
                               !(getenv("PLI_TX_TAIL") && atoi(getenv("PLI_TX_TAIL")) == 0) && lostRule && !getenv("PLI_TX_FULL2") &&
                               !getenv("PLI_TX_CELLRULE") && !getenv("PLI_TX_OLDMARK") && !getenv("PLI_TX_FULLDIFF") &&
                               !getenv("PLI_TX_NOFUSEDM") && !getenv("PLI_TX_NODIRTYLIST");
@@ -1077,7 +1111,9 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
           // include/pli_frontend.h "Sharing a device".)
           {
             std::lock_guard<std::mutex> lk(g_tailMu);
-            hipEvent_t& ev = g_tailEv[c->device & 63];
+            hipEvent_t& ev = g_tailEv[c->device];             // (0 <= device < TAIL_MAX_DEVICES: tailPossible)
+            c->tailLaunched = true;
+            ta.forceAbort = getenv("PLI_TX_TAIL_FORCE_ABORT") ? 1 : 0;   // test switch: the kernel leaves at once, as after a barrier timeout
             if (ev) HIPCHK(hipStreamWaitEvent(c->stream, ev, 0));
             else HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             LAUNCH(c, "k_tx_tail", k_tx_tail, dim3(tb), dim3(256), 0, ta);
@@ -1251,6 +1287,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
         HIPCHK(hipMemcpy2DAsync(c->rxSeen, 16, c->jrCtl + img0, sizeof(RxCtl), 16, nimg, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipEventRecord(c->evRxSeen, c->stream));
         c->rxSeenImages = nimg;
+        c->rxSeenTail = c->tailLaunched;
       }
       }
     }

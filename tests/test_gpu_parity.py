@@ -11,6 +11,8 @@ import os
 import numpy as np
 import pytest
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 pytestmark = pytest.mark.gpu
 
 
@@ -1254,3 +1256,48 @@ def test_roctx_ranges_are_pushed_when_asked_for(gpu):
     assert out["0"][0] == 0, "ranges pushed without the switch: %s" % (out,)
     assert out["1"][0] > 40, "PLI_ROCTX=1: only %d ranges for a whole frame (entry point + stages + ~60 kernel launches)" % out["1"][0]
     assert out["0"][1] == out["1"][1] > 100
+
+
+def test_an_aborted_tail_kernel_switches_the_process_to_planned_rounds(gpu, tmp_path):
+    """several PROCESSES on one device can keep the persistent relaxation kernel (k_tx_tail) from becoming resident; its grid
+    barrier then times out, the kernel gives up, and the unsettled images take the exact fallback.  A process that sees this once must
+    not stall in every later call: it latches the planned-rounds schedule for that device.  Run in a process of its own (the latch is
+    per process), with the test switch that raises the abort word before the launch."""
+    import subprocess, sys, textwrap
+    script = tmp_path / "abort.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r)
+        import numpy as np
+        from oracle import pyoracle as po
+        from pli_slam_amd import capi, synth
+        from pli_slam_amd.frontend import Frontend
+        W, H = 752, 480
+        cfg = capi.default_config(W, H, orb_nfeatures=300, lsd_nfeatures=0, max_frames=1)
+        L, R = synth.make_stereo_pair(321, W, H)
+        imgs = np.stack([L, R])[None]
+        fe = Frontend(cfg)
+        fr = po.Frame(po.Config.from_buffer_copy(bytes(cfg)))
+        want = [fr.line_extract(e, im) for e, im in ((0, L), (1, R))]
+        def same(rec):
+            return all(rec["kl" + k].tobytes() == want[e][1].tobytes() and np.array_equal(rec["ldesc" + k], want[e][2]) for e, k in ((0, "L"), (1, "R")))
+        r0 = fe.batch_run_host(imgs)[0]; s0 = fe.lsd_round_stats()
+        os.environ["PLI_TX_TAIL_FORCE_ABORT"] = "1"
+        r1 = fe.batch_run_host(imgs)[0]; s1 = fe.lsd_round_stats()
+        del os.environ["PLI_TX_TAIL_FORCE_ABORT"]
+        r2 = fe.batch_run_host(imgs)[0]; s2 = fe.lsd_round_stats()
+        r3 = fe.batch_run_host(imgs)[0]; s3 = fe.lsd_round_stats()
+        import json
+        print("RESULT" + json.dumps([bool(same(r0)), bool(same(r1)), bool(same(r2)), bool(same(r3)), [int(v) for v in s0], [int(v) for v in s1],
+                                     [int(v) for v in s2], [int(v) for v in s3]]))
+    """ % ROOT))
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1]
+    import json
+    ok0, ok1, ok2, ok3, s0, s1, s2, s3 = json.loads(line[len("RESULT"):])
+    assert ok0 and ok1 and ok2 and ok3, line                  # exact on every path
+    assert s0[0] == -1 and s0[2] == 0, line                   # call 1: the tail kernel, nobody on the slow path
+    assert s1[2] >= 2, line                                   # the aborted tail: both images redone by the sequential grower
+    assert s2[0] >= 1 and s3[0] >= 1 and s3[2] == s2[2] == s1[2], line   # latched: planned rounds from then on, no further slow-path images
+    assert "planned-rounds schedule" in out.stderr
