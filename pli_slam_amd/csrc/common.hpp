@@ -125,8 +125,8 @@ constexpr int LSD_ID_INF = 0x7FFFFFFF;
 constexpr int TX_EMIT_CAP = 16384;   // key mode: candidate segments of an image that k_tx_emit_sorted can order (LDS)
 // k_zero_ranges (orb_kernels.hip): buffers cleared by one launch
 struct ZeroRanges {
-  uint32_t* p[8];
-  int64_t words[8];
+  uint32_t* p[12];
+  int64_t words[12];
 };
 
 // k_tx_sort in key mode (lsd_tile.hip)
@@ -137,6 +137,8 @@ struct TxKeys {
   int nBins, pixbits;
   int* idPlane;                     // out: own id of every pixel (TX_INF: undefined)
   float4* recPack = nullptr;        // packed round 1 (lsd_tile.hip): the pixel records, whose fourth word is owner_1 during round 1
+  int* zeroA = nullptr;             // planes of one word per pixel index that the sort clears on its way (rgDirty, rgLost), or null
+  int* zeroB = nullptr;
   int lazyMargin = 8;               // LAZY ids: units of the 2^-22 fixed point around a bin boundary that the double plane decides (>= 4; test switch)
   int pack = 0;                     // 0: owner plane; 1: k_tx_sort writes the unclaimed words (ids); 2: the front pass wrote them (LAZY ids)
 };

@@ -195,6 +195,10 @@ __device__ __forceinline__ void tx_sort_tile(const int* __restrict__ rankAll, co
       // owner_0 = the trivial map, written for EVERY pixel of the tile (an undefined pixel is nobody's: INT_MAX in both components):
       // the front pass does not initialise the plane for this schedule.  Packed round 1: owner_1's start value into the pixel
       // record instead, with the "unclaimed" bit (k_tx_round2 writes the owner plane); LAZY ids: the front pass has written the word
+      // (the two stamp planes of the relaxation — one word per pixel index each — start every call at zero: cleared here, beside the id
+      // plane's store, instead of by a fill kernel of their own)
+      if (keys.zeroA) keys.zeroA[img * npix + y * W + x] = 0;
+      if (keys.zeroB) keys.zeroB[img * npix + y * W + x] = 0;
       if (keys.pack == 1) {
         if (r != TX_INF) *tx_rec_owner(keys.recPack + img * npix + y * W + x) = (int)(TX_UNCLAIMED | (unsigned)r);
       } else if (keys.pack == 0) own[y * W + x] = r != TX_INF ? make_int2(r, r) : make_int2(INT_MAX, INT_MAX);
@@ -649,6 +653,187 @@ __global__ __launch_bounds__(256) void k_tx_prep(RxCtl* __restrict__ ctl, int2* 
 }
 
 // ---------------------------------------------------------------------------
+// Rounds >= 3 of large batches, CELL LISTS (round 5).  k_tx_diffmark and k_tx_prep walk every block of every image and let most
+// of them leave after a look at their cells' stamps; from round 3 on a round touches a few per cent of the cells, and what the
+// 133 000 + 267 000 workgroups of a 256-frame batch cost is the dependent chain "stamps -> barrier -> pixels -> barrier" of the many
+// that find one or two cells (rounds 3 to 7: 3.5 ms).  Here the cells with work are LISTED first (one thread per cell, a streaming
+// pass over the stamp plane; the per-image control updates of the two kernels ride on it) and one WAVE per listed cell does the
+// cell's 64 pixels — lane = pixel, no LDS beyond 64 bytes, no block barrier:
+//   k_tx_cells(mode 0) -> k_tx_diffmark_cells -> k_tx_cells(mode 1) -> k_tx_prep_cells -> k_tx_grow_sparse -> k_rx_rect.
+// Same marks, same rewritten cells as the block kernels (which stay: small batches — fewer launches —, k_tx_tail, dev switches).
+// ---------------------------------------------------------------------------
+// mode 0 (before the diff of round t): cells touched in round t - 1; resets the per-round counters of the image (what block (0, 0)
+// of k_tx_diffmark does).  mode 1 (after it): cells active in round t, stamped as touched (k_tx_prep rewrites them); declares the
+// fixed point of an image whose round-t flag stayed clear and clears the other round's flag (block (0, 0) of k_tx_prep).
+__global__ __launch_bounds__(1024) void k_tx_cells(RxCtl* __restrict__ ctl, const int* __restrict__ stampAll, int* __restrict__ tileTouchAll,
+                                                   int ncell, int nimg, int img0, int t, int mode, int* __restrict__ list, int* __restrict__ cnt) {
+  // One workgroup per image builds the image's list (ordered by cell; its length is stored once: no counter to clear, no atomics —
+  // one counter for the batch serialises 65 000 wave atomics on one address, 0.5 ms a launch).
+  __shared__ int wsum[16];
+  __shared__ int s_base;
+  const int il = blockIdx.x, img = img0 + il, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  RxCtl& c = ctl[img];
+  if (c.state == 2) { if (tid == 0) cnt[il] = 0; return; }
+  bool settled = false;
+  if (mode == 0) {
+    if (tid == 0) { c.nSmall = 0; c.nBig = 0; c.nHand = 0; c.nextBig = 0; c.rectArena = 0ull; }
+  } else {
+    settled = ((t & 1) ? c.changedOdd : c.changed) == 0;             // (nobody writes THIS round's flag in this kernel)
+    __syncthreads();                                                  // (every thread has read state and flag before thread 0 writes)
+    if (tid == 0) {
+      if (settled) { c.state = 2; c.rounds = t; }
+      else if (t & 1) c.changed = 0;
+      else c.changedOdd = 0;
+    }
+    if (settled) { if (tid == 0) cnt[il] = 0; return; }
+  }
+  if (tid == 0) s_base = 0;
+  const int* stamp = stampAll + (int64_t)img * ncell;
+  int* out = list + (int64_t)il * ncell;
+  const int want0 = mode == 0 ? t - 1 : t;
+  for (int c0 = 0; c0 < ncell; c0 += 1024) {
+    const int cell = c0 + tid;
+    const bool want = cell < ncell && stamp[cell] == want0;
+    if (want && mode == 1) tileTouchAll[(int64_t)img * ncell + cell] = t;      // (this cell is rewritten)
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(want);
+    if (lane == 0) wsum[wv] = __popcll(bal);
+    __syncthreads();
+    int before = s_base;
+    for (int w = 0; w < wv; ++w) before += wsum[w];
+    if (want) out[before + __popcll(bal & ((1ull << lane) - 1ull))] = cell;
+    __syncthreads();
+    if (tid == 0) { int tot = 0; for (int w = 0; w < 16; ++w) tot += wsum[w]; s_base += tot; }
+    __syncthreads();
+  }
+  if (tid == 0) cnt[il] = s_base;
+}
+
+// one wave per listed cell (four cells at a time: their pixels' owner words are fetched together): the changed pixels of a cell
+// (owner_{t-1} != owner_{t-2}) and the rule of k_tx_mark on their neighbours
+__global__ __launch_bounds__(256) void k_tx_diffmark_cells(RxCtl* __restrict__ ctl, const int2* __restrict__ ownAll, const int* __restrict__ rankAll,
+                                                           const int2* __restrict__ rgBoxAll, int* __restrict__ rgDirtyAll,
+                                                           int* __restrict__ tileActAll, int W, int H, int TW, int TH, int t, int img0,
+                                                           const int* __restrict__ rgLostAll, TxDirtyLists DL, const int* __restrict__ list,
+                                                           const int* __restrict__ cnt) {
+  constexpr int U = 4;
+  __shared__ unsigned char slots[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int il = blockIdx.y, ncell = TW * TH;
+  const int n = cnt[il];
+  const int ci = t & 1;
+  const int img = img0 + il;
+  const int64_t base = (int64_t)img * W * H;
+  RxCtl& c = ctl[img];
+  int* tileAct = tileActAll + (int64_t)img * ncell;
+  int* rgDirty = rgDirtyAll + base;
+  const int2* rgBox = rgBoxAll + base;
+  const int* lst = list + (int64_t)il * ncell;
+  for (int i0 = (blockIdx.x * 4 + wv) * U; i0 < n; i0 += gridDim.x * 4 * U) {
+    int cells[U];
+    int2 ow[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      cells[u] = i0 + u < n ? lst[i0 + u] : -1;
+      ow[u] = make_int2(0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (cells[u] < 0) continue;
+      const int x = (cells[u] % TW) * 8 + (lane & 7), y = (cells[u] / TW) * 8 + (lane >> 3);
+      if (x < W && y < H) ow[u] = ownAll[base + y * W + x];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int2 o = ow[u];
+      const unsigned long long bal = __builtin_amdgcn_ballot_w64(o.x != o.y);
+      if (bal == 0ull) continue;
+      const int cell = cells[u], cx = cell % TW, cy = cell / TW;
+      if (lane == 0) {
+        tileAct[cell] = t;                                // a changed cell is active
+        int* flag = (t & 1) ? &c.changedOdd : &c.changed;
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(flag, 1);
+      }
+      // the (changed pixel, neighbour) pairs of the cell, 64 at a time: pair j = (the (j / 9)-th changed pixel, position j % 9 of its 3 x 3 block)
+      if ((bal >> lane) & 1ull) slots[wv][__popcll(bal & ((1ull << lane) - 1ull))] = (unsigned char)lane;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int npairs = 9 * __popcll(bal);
+      for (int j0 = 0; j0 < npairs; j0 += 64) {
+        const int j = j0 + lane;
+        const int e = min(j, npairs - 1) / 9, k = j - 9 * (j / 9);
+        const int src = slots[wv][e];
+        const int ox = __shfl(o.x, src, 64), oy = __shfl(o.y, src, 64);
+        if (j >= npairs) continue;
+        const int px0 = cx * 8 + (src & 7), py0 = cy * 8 + (src >> 3);
+        const int prevv = ci ? ox : oy, prev2 = ci ? oy : ox;
+        if (k == 4) {
+          // the seed of a region changed hands: it died (its last box is released) or is newly alive (only this pixel)
+          const int r = rankAll[base + py0 * W + px0];
+          if (r == TX_INF) continue;
+          const bool a1 = prevv == r, a2 = prev2 == r;
+          if (a1 != a2) tx_mark_dirty(r, t, rgDirty, rgBox, tileAct, TW, TH, DL, img, a2);
+        } else {
+          const int px = px0 + k % 3 - 1, py = py0 + k / 3 - 1;
+          if (px < 0 || py < 0 || px >= W || py >= H) continue;
+          const int2 op2 = ownAll[base + py * W + px];
+          const int op = ci ? op2.x : op2.y;             // owner_{t-1} of the neighbour
+          if (op == INT_MAX) continue;
+          if ((prev2 < op && prevv > op) || (prev2 == op && prevv < op) || rgLostAll[base + (op & DL.rmask)] == t - 1)
+            tx_mark_dirty(op, t, rgDirty, rgBox, tileAct, TW, TH, DL, img);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();                   // (the slots are reused by the wave's next cell)
+    }
+  }
+}
+
+// one wave per listed cell, four cells at a time: owner_t of the cells' pixels (k_tx_prep's rule)
+__global__ __launch_bounds__(256) void k_tx_prep_cells(const RxCtl* __restrict__ ctl, int2* __restrict__ ownAll, const int* __restrict__ rankAll,
+                                                       const int* __restrict__ rgDirtyAll, int W, int H, int TW, int TH, int t, int img0, int rmask,
+                                                       const int* __restrict__ list, const int* __restrict__ cnt) {
+  constexpr int U = 4;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int il = blockIdx.y, ncell = TW * TH;
+  const int n = cnt[il];
+  const int ci = t & 1;
+  const int img = img0 + il;
+  const int64_t base = (int64_t)img * W * H;
+  const int* lst = list + (int64_t)il * ncell;
+  for (int i0 = (blockIdx.x * 4 + wv) * U; i0 < n; i0 += gridDim.x * 4 * U) {
+    int p[U], r[U], dirtyAt[U];
+    int2 o[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int cell = i0 + u < n ? lst[i0 + u] : -1;
+      const int x = cell < 0 ? W : (cell % TW) * 8 + (lane & 7), y = cell < 0 ? H : (cell / TW) * 8 + (lane >> 3);
+      p[u] = (x < W && y < H) ? y * W + x : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      r[u] = TX_INF;
+      o[u] = make_int2(0, 0);
+      if (p[u] >= 0) {
+        r[u] = rankAll[base + p[u]];
+        o[u] = ownAll[base + p[u]];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) dirtyAt[u] = r[u] != TX_INF ? rgDirtyAll[base + ((ci ? o[u].x : o[u].y) & rmask)] : 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (r[u] == TX_INF) continue;
+      const int prevv = ci ? o[u].x : o[u].y;
+      const int cur = dirtyAt[u] != t ? prevv : r[u];
+      if (cur != (ci ? o[u].y : o[u].x)) {
+        if (ci) o[u].y = cur; else o[u].x = cur;
+        ownAll[base + p[u]] = o[u];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // k_tx_grow: one wave per tile walks the tile's seeds in rank order.
 // ---------------------------------------------------------------------------
 // ---------------------------------------------------------------------------
@@ -883,20 +1068,25 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
     L.tAbove = T1 + lzMargin;
     return L;
   };
-  auto freeFor = [&](const int w, const int r, const int b, const int spix, const LazyBins& L, const int qi, const bool ok) -> bool {
-    if (PACK != 2) return (int)((unsigned)w & 0x7FFFFFFFu) > r;
+  // (as a wave mask, already restricted to the lanes `def` that hold a defined pixel: the compiler keeps lane predicates that meet at a
+  // branch as 0 / 1 registers and compares them back into masks)
+  auto freeMask = [&](const int w, const int r, const int b, const int spix, const LazyBins& L, const int qi, const bool def) -> unsigned long long {
+    if (PACK != 2) return __builtin_amdgcn_ballot_w64(def && (int)((unsigned)w & 0x7FFFFFFFu) > r);
     const int F = w & 0x7FFFFFFF;
     const bool uncl = w < 0, below = F < L.tBelow, same = (unsigned)(F - L.tSame) < L.tSpan, above = F > L.tAbove;
-    bool fr = (w > r) | (uncl & (below | (same & (qi > spix))));       // (a claimed word is a non-negative id; an unclaimed one is negative: never > r)
-    const bool amb = ok & uncl & !(below | same | above);
-    if (__builtin_amdgcn_ballot_w64(amb) != 0ull) {
-      if (amb) {
+    // (a claimed word is a non-negative id; an unclaimed one is negative: never > r)
+    unsigned long long m = __builtin_amdgcn_ballot_w64(def & ((w > r) | (uncl & (below | (same & (qi > spix))))));
+    const unsigned long long amb = __builtin_amdgcn_ballot_w64(def & uncl & !(below | same | above));
+    if (amb != 0ull) {
+      bool fr = false;
+      if (__builtin_amdgcn_inverse_ballot_w64(amb)) {
         const double coef = __longlong_as_double(((long long)lzCoefHi << 32) | (long long)(unsigned)lzCoefLo);
         const int bq = lsd_bin64(lzMg[qi], coef, lzNb1 + 1);
         fr = bq < b || (bq == b && qi > spix);
       }
+      m |= __builtin_amdgcn_ballot_w64(fr);
     }
-    return fr;
+    return m;
   };
 
   auto qget = [&](int k) -> int {
@@ -925,7 +1115,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
       // claimed — what an unclaimed word holds — (r and r: the lane claimed nothing): a lower rank -> this region does not hold the
       // pixel it took; a higher rank that is not the pixel's own -> that region just lost the pixel.  Contested claims are rare:
       // pendOld != pendRank covers both cases, and one compare and one ballot decide for the wave.
-      int pendOld = pend0, pendRank = pendRank0;
+      int pendOld = PACK ? -1 : pend0, pendRank = pendRank0;      // (PACK: "unclaimed" stands for "this lane claimed nothing")
       // (LAZY ids: the region's bin, its seed pixel, and where the bins around its own begin)
       const int rBin = PACK == 2 ? lzNb1 - (r >> lzPixBits) : 0, rSeedPix = PACK == 2 ? (r & ((1 << lzPixBits) - 1)) : 0;
       LazyBins rBins{};
@@ -934,10 +1124,12 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
         if (noteLost && PACK) {
           // (the word a claim found: unclaimed — bit 31 —, or a region's id: a lower one keeps the pixel and THIS region has lost it,
           // a higher one has just lost it)
-          const bool contested = pendOld >= 0 && pendOld != r;
-          if (__builtin_amdgcn_ballot_w64(contested) != 0ull) {
-            if (contested) rgLost[max(pendOld, r) & DL.rmask] = t;
+          // (a claim never finds the region's own id: the accept loop takes a pixel once)
+          if (__builtin_amdgcn_ballot_w64(pendOld >= 0) != 0ull) {
+            if (pendOld >= 0) rgLost[max(pendOld, r) & DL.rmask] = t;
           }
+          pendOld = -1;
+          return;
         } else if (noteLost) {
           if (__builtin_amdgcn_ballot_w64(pendOld != pendRank) != 0ull) {
             const bool contested = pendOld < r || (pendOld != r && pendOld != pendRank);
@@ -981,8 +1173,9 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
           sumdx = __fadd_rn(sumdx, cj);
           sumdy = __fadd_rn(sumdy, sj);
         }
-        const bool accepted = (acc >> lane) & 1ull;
-        if (accepted) q[cnt0 + __popcll(acc & ((1ull << lane) - 1ull))] = myxy;
+        // (the accepted lanes straight from the scalar mask: one s_and_saveexec; their queue slots by v_mbcnt)
+        const bool accepted = __builtin_amdgcn_inverse_ballot_w64(acc);
+        if (accepted) q[cnt0 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(acc >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)acc, 0u))] = myxy;
         return accepted;
       };
       // One step = up to 8 queue entries x 8 neighbours in one round trip (record + owner pair per lane), the accept loop, the
@@ -1002,7 +1195,8 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
         const int e = SPILL ? qget(min(k + pi, cnt - 1)) : tx_lds_read(&q[min(k + pi, cnt - 1)]);
         const int nx = (e & 0xFFFF) + ndx, ny = (e >> 16) + ndy;
         const bool ok = pi < nb && nx >= 0 && ny >= 0 && nx < W && ny < H;
-        const int qi = ok ? ny * W + nx : -1;
+        // (the pixel's index with a 24-bit multiply, full rate; lanes outside `ok` hold anything: nothing of theirs is used)
+        const int qi = (int)(__umul24((unsigned)ny, (unsigned)W) + (unsigned)nx);
         const int myxy = (ny << 16) | nx;
         float4 rr;
         int2 oo;
@@ -1010,16 +1204,15 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
         rr.w = 0.f;
         if (PACK) asm volatile("" : "=v"(rr.w));
         if (PACK) {
-          if (ok) rr = tx_load_rec16(&rec[qi]);
+          if (ok) rr = tx_load_rec16(rec + (unsigned)qi);
         } else if (ok) {
-          rr = rec[qi];
-          oo = tx_load_own(&own[qi]);
+          rr = rec[(unsigned)qi];
+          oo = tx_load_own(own + (unsigned)qi);
         }
         const int prevv = ci ? oo.x : oo.y, curv = ci ? oo.y : oo.x;
-        bool cand;
-        if (PACK) cand = freeFor(__float_as_int(rr.w), r, rBin, rSeedPix, rBins, qi, ok && rr.x != TX_NOTDEF) && ok && rr.x != TX_NOTDEF;
-        else cand = ok && rr.x != TX_NOTDEF && !(prevv < r || curv <= r);
-        unsigned long long remaining = __builtin_amdgcn_ballot_w64(cand);
+        unsigned long long remaining;
+        if (PACK) remaining = freeMask(__float_as_int(rr.w), r, rBin, rSeedPix, rBins, qi, ok && rr.x != TX_NOTDEF);
+        else remaining = __builtin_amdgcn_ballot_w64(ok && rr.x != TX_NOTDEF && !(prevv < r || curv <= r));
         if (!SPILL) {
           accepted = acceptBatch(remaining, rr.x, rr.y, rr.z, myxy);
         } else {
@@ -1080,8 +1273,8 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
 #if defined(TX_DIAG_NOWAIT)     // diagnostic build (NOT exact: contested claims go unnoticed): non-returning claims, nothing to wait for
           (void)__hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
 #else
-          if (PACK) pendOld = (int)__hip_atomic_fetch_min(reinterpret_cast<unsigned*>(tx_rec_owner(&rec[qi])), (unsigned)r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
-          else pendOld = __hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
+          if (PACK) pendOld = (int)__hip_atomic_fetch_min(reinterpret_cast<unsigned*>(tx_rec_owner(rec + (unsigned)qi)), (unsigned)r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
+          else pendOld = __hip_atomic_fetch_min(ci ? &own[(unsigned)qi].y : &own[(unsigned)qi].x, r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
 #endif
           // (the pixel's own rank, which an unclaimed owner word holds: in round 1 owner_0 is the trivial map, so the word just read has it)
           if (noteLost && !PACK) pendRank = (SPARSE || t != 1) ? rankOfPix[qi] : prevv;
@@ -1500,8 +1693,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
             const bool def = ok && rr.x != TX_NOTDEF;
             LazyBins mBins{};
             if (PACK == 2) mBins = lazyBins(mBin);
-            grpCand = __builtin_amdgcn_ballot_w64(freeFor(__float_as_int(rr.w), mr, mBin, PACK == 2 ? (mr & ((1 << lzPixBits) - 1)) : 0, mBins,
-                                                          ny * W + nx, def) && def);
+            grpCand = freeMask(__float_as_int(rr.w), mr, mBin, PACK == 2 ? (mr & ((1 << lzPixBits) - 1)) : 0, mBins, ny * W + nx, def);
           } else
           grpCand = __builtin_amdgcn_ballot_w64(ok && rr.x != TX_NOTDEF && !(prevv < mr || curv <= mr));
           grpXY = ok ? ((ny << 16) | nx) : -1;

@@ -116,6 +116,8 @@ struct pli_ctx {
   unsigned* tailBar = nullptr;      // [0] barrier arrivals, [32] abort word
   int* txPerm = nullptr;            // round 1: (image, tile) pairs in order of decreasing seed count (k_tx_order)
   int tailBlocks = 0;               // resident grid: CUs x blocks per CU (from the kernel's occupancy)
+  int* txCellList = nullptr;        // rounds >= 3 of large batches: the cells with work, listed (k_tx_cells) ...
+  int* txCellCnt = nullptr;         // ... and the lists' lengths, two per round (zeroed with the control blocks)
   bool tailLaunched = false;        // this call launched k_tx_tail ...
   bool rxSeenTail = false;          // ... and so did the call whose control blocks are on their way to the host (rxSeen)
   int rxMargin = 3;
@@ -675,6 +677,8 @@ pli_status allocAll(pli_ctx* c) {
       A(c->txDirtyList, (size_t)c->txNtx * c->txNty * c->txTs * c->txTs * NR);
       A(c->txDirtyCnt, (size_t)c->txNtx * c->txNty * NR);
       A(c->tailBar, 64);
+      A(c->txCellList, (size_t)c->tilesW * c->tilesH * NR);
+      A(c->txCellCnt, (size_t)2 * NR);
       A(c->txPerm, (size_t)c->txNtx * c->txNty * NR);
       // key mode (lsd_tile.hip, k_tx_sort): ids of (bits of nBins - 1) + pixbits bits must stay below LSD_ID_INF = 2^31 - 1: with 1024 bins
       // up to 2^21 scaled pixels (1280 x 720 scales to 1536 x 864 = 1.33 M; 3840 x 2160 to 11.9 M pixels = 24 bits: ranks).
@@ -1010,8 +1014,11 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
         Z.p[zr] = (uint32_t*)p; Z.words[zr] = words; ++zr;
       };
       add(c->jrCtl + img0, (int64_t)(sizeof(RxCtl) / 4) * nimg);
-      add(c->rgDirty + (int64_t)img0 * npix, npix64 * nimg);
-      if (lostRule) add(c->rgLost + (int64_t)img0 * npix, npix64 * nimg);
+      // (tile relaxation: k_tx_sort clears the two per-pixel stamp planes while it writes the id plane)
+      if (c->lsdMode == 1 || getenv("PLI_TX_ZERO_BY_FILL")) {
+        add(c->rgDirty + (int64_t)img0 * npix, npix64 * nimg);
+        if (lostRule) add(c->rgLost + (int64_t)img0 * npix, npix64 * nimg);
+      }
       add(c->tileTouch + (int64_t)img0 * cells, cells * nimg);
       add(c->tileAct + (int64_t)img0 * cells, cells * nimg);
       if (c->txDirtyCnt) add(c->txDirtyCnt + (int64_t)img0 * ntile64, ntile64 * nimg);
@@ -1070,6 +1077,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       if (keyMode) keys = TxKeys{c->mg, c->maxMg, P.rho, P.nBins, c->txPixBits, c->rankOf};
       const bool pack1 = packMode != 0;
       if (pack1) { keys.recPack = c->rec; keys.pack = packMode; }
+      if (!getenv("PLI_TX_ZERO_BY_FILL")) { keys.zeroA = c->rgDirty; keys.zeroB = lostRule ? c->rgLost : (int*)nullptr; }
       // (test switch: a wide margin sends every unclaimed pixel of the LAZY form through the double plane; the results must not change)
       if (const char* e = getenv("PLI_TX_LAZY_MARGIN")) keys.lazyMargin = std::max(4, std::min(0x3FFFFFFF, atoi(e)));
       if (ts == 128)
@@ -1090,6 +1098,10 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       // rounds >= tailT0 in one persistent launch that ends by itself when every image is at its fixed point (no host look, no
       // planned round count; dev switches: PLI_TX_TAIL=0, PLI_TX_TAIL_T0, PLI_TX_TAIL_BPC)
       const bool useTail = tailPossible && fusedDM && DL.list;
+      // rounds 3 .. tail start of a large batch by cell lists (six lean launches per round instead of four that walk every block;
+      // a small batch keeps the four: launches are what it pays for).  Dev switch PLI_TX_CELLS=0 / 1.
+      bool useCells = fusedDM && DL.list && c->txCellList && nimg >= 16;
+      if (const char* e = getenv("PLI_TX_CELLS")) useCells = atoi(e) != 0 && fusedDM && DL.list && c->txCellList;
       int tailT0 = 8;
       if (const char* e = getenv("PLI_TX_TAIL_T0")) tailT0 = std::max(3, atoi(e));
       for (int t = 1; t <= maxRounds && !allDone; ++t) {
@@ -1126,11 +1138,27 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
         if (t == 3 && DL.list && fullRound2)
           HIPCHK(hipMemsetAsync(c->txDirtyCnt + (int64_t)img0 * ntile, 0, sizeof(int) * (size_t)ntile * nimg, c->stream));
         const bool fused2 = t == 2 && !fullRound2 && lostRule && !getenv("PLI_TX_NOFUSE2");    // (dev switch: the two passes)
+        bool cellsDone = false;
         if (fused2)
           TRL(c, "k_tx_round2", k_tx_round2, dim3((P.LW + 31) / 32, (P.LH + 31) / 32, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->order,
               c->rgBox, c->rgDirty, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, (const int*)c->rgLost, DL, c->tileTouch,
               pack1 ? (const float4*)c->rec : (const float4*)nullptr);
-        else if (t >= 3 && fusedDM)
+        else if (t >= 3 && fusedDM && useCells) {
+          // cell lists (lsd_tile.hip "CELL LISTS"): the cells touched in round t - 1 -> their changed pixels' marks -> the active cells
+          // -> their owner words.  A list and its length per image stay on the device; a few workgroups per image stride over its list.
+          const int ncell = c->tilesW * c->tilesH;
+          const dim3 lg(nimg), wg(8, nimg);
+          int* cntA = c->txCellCnt + img0;
+          int* cntB = c->txCellCnt + c->rxImages + img0;
+          int* lst = c->txCellList + (int64_t)img0 * ncell;
+          TRL(c, "k_tx_cells", k_tx_cells, lg, dim3(1024), 0, c->jrCtl, (const int*)c->tileTouch, c->tileTouch, ncell, nimg, img0, t, 0, lst, cntA);
+          TRL(c, "k_tx_diffmark", k_tx_diffmark_cells, wg, dim3(256), 0, c->jrCtl, (const int2*)c->own, (const int*)c->rankOf, (const int2*)c->rgBox,
+              c->rgDirty, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, (const int*)c->rgLost, DL, (const int*)lst, (const int*)cntA);
+          TRL(c, "k_tx_cells", k_tx_cells, lg, dim3(1024), 0, c->jrCtl, (const int*)c->tileAct, c->tileTouch, ncell, nimg, img0, t, 1, lst, cntB);
+          TRL(c, "k_tx_prep", k_tx_prep_cells, wg, dim3(256), 0, (const RxCtl*)c->jrCtl, c->own, (const int*)c->rankOf, (const int*)c->rgDirty, P.LW,
+              P.LH, c->tilesW, c->tilesH, t, img0, DL.rmask, (const int*)lst, (const int*)cntB);
+          cellsDone = true;
+        } else if (t >= 3 && fusedDM)
           TRL(c, "k_tx_diffmark", k_tx_diffmark, dim3((P.LW + 31) / 32, (c->tilesH + 7) / 8, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf,
               c->rgBox, c->rgDirty, c->tileAct, (const int*)c->tileTouch, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, (const int*)c->rgLost, DL);
         else if (t == 2 && !fullRound2)
@@ -1151,7 +1179,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
           TRL(c, "k_rx_mark", k_rx_mark, dim3((P.LW + 31) / 32, (c->tilesH + 7) / 8, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->rgBox,
               c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, t >= 3 ? 1 : 0,
               (lostRule && t >= 3 && !getenv("PLI_TX_CELLRULE")) ? (const int*)c->rgLost : (const int*)nullptr, DL);
-          if (!fused2)
+          if (!fused2 && !cellsDone)
           TRL(c, "k_tx_prep", k_tx_prep, dim3((P.LW + 31) / 32, (P.LH + 31) / 32, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf,
               c->rgDirty, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, t == 2 ? 1 : 0, fusedDM ? c->tileTouch : (int*)nullptr, DL.rmask);
           TRL(c, "k_tx_grow_sparse", k_tx_grow_sparse, dim3(ntile, nimg), dim3(64), txPad, c->dP, c->jrCtl, c->rec, c->own, c->txList,

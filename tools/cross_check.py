@@ -29,7 +29,8 @@ SETS = {
         ("default", {}), ("tail_t3", {"PLI_TX_TAIL_T0": "3"}), ("no_tail", {"PLI_TX_TAIL": "0"}), ("spec", {"PLI_TX_SPEC": "1"}),
         ("spec_tail_t3_ts32", {"PLI_TX_SPEC": "1", "PLI_TX_TAIL_T0": "3", "PLI_TX_TS": "32"}), ("ts16", {"PLI_TX_TS": "16"}),
         ("ranks", {"PLI_TX_KEYS": "0"}), ("ranks_no_tail_ts32", {"PLI_TX_KEYS": "0", "PLI_TX_TAIL": "0", "PLI_TX_TS": "32"}),
-        ("owner_plane", {"PLI_TX_PACK1": "0"}), ("sort_written", {"PLI_TX_PACK1": "1"}), ("lazy_all_exact", {"PLI_TX_LAZY_MARGIN": "2000000"}))],
+        ("owner_plane", {"PLI_TX_PACK1": "0"}), ("sort_written", {"PLI_TX_PACK1": "1"}), ("lazy_all_exact", {"PLI_TX_LAZY_MARGIN": "2000000"}),
+        ("block_rounds", {"PLI_TX_CELLS": "0"}), ("cells_no_tail", {"PLI_TX_CELLS": "1", "PLI_TX_TAIL": "0"}))],
 }
 bad = 0
 if which == "sizes":
