@@ -665,47 +665,68 @@ __global__ __launch_bounds__(256) void k_tx_prep(RxCtl* __restrict__ ctl, int2* 
 // mode 0 (before the diff of round t): cells touched in round t - 1; resets the per-round counters of the image (what block (0, 0)
 // of k_tx_diffmark does).  mode 1 (after it): cells active in round t, stamped as touched (k_tx_prep rewrites them); declares the
 // fixed point of an image whose round-t flag stayed clear and clears the other round's flag (block (0, 0) of k_tx_prep).
+constexpr int TX_CELL_CHUNK = 8192;      // cells a workgroup of k_tx_cells lists (one atomic on the image's counter per workgroup)
 __global__ __launch_bounds__(1024) void k_tx_cells(RxCtl* __restrict__ ctl, const int* __restrict__ stampAll, int* __restrict__ tileTouchAll,
                                                    int ncell, int nimg, int img0, int t, int mode, int* __restrict__ list, int* __restrict__ cnt) {
-  // One workgroup per image builds the image's list (ordered by cell; its length is stored once: no counter to clear, no atomics —
-  // one counter for the batch serialises 65 000 wave atomics on one address, 0.5 ms a launch).
+  // A workgroup per (chunk of 8192 cells, image): its cells with work are compacted in order (ballots + a prefix over the 16 waves)
+  // and take their places in the image's list with ONE atomic (752 x 480: one workgroup per image; one counter for the whole batch
+  // serialised 65 000 wave atomics on one address, 0.5 ms a launch).  The counters — per image, round and mode — are zeroed once
+  // per call with the control blocks.
   __shared__ int wsum[16];
   __shared__ int s_base;
-  const int il = blockIdx.x, img = img0 + il, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  __shared__ int buf[TX_CELL_CHUNK];
+  const int il = blockIdx.y, img = img0 + il, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   RxCtl& c = ctl[img];
-  if (c.state == 2) { if (tid == 0) cnt[il] = 0; return; }
-  bool settled = false;
+  if (c.state == 2) return;
   if (mode == 0) {
-    if (tid == 0) { c.nSmall = 0; c.nBig = 0; c.nHand = 0; c.nextBig = 0; c.rectArena = 0ull; }
+    if (blockIdx.x == 0 && tid == 0) { c.nSmall = 0; c.nBig = 0; c.nHand = 0; c.nextBig = 0; c.rectArena = 0ull; }
   } else {
-    settled = ((t & 1) ? c.changedOdd : c.changed) == 0;             // (nobody writes THIS round's flag in this kernel)
-    __syncthreads();                                                  // (every thread has read state and flag before thread 0 writes)
-    if (tid == 0) {
+    // (nobody writes THIS round's flag in this kernel, and `state` only moves to 2 for an image whose flag is clear: every workgroup
+    // of the image decides the same way whatever it sees of the first one's stores)
+    const bool settled = ((t & 1) ? c.changedOdd : c.changed) == 0;
+    if (blockIdx.x == 0 && tid == 0) {
       if (settled) { c.state = 2; c.rounds = t; }
       else if (t & 1) c.changed = 0;
       else c.changedOdd = 0;
     }
-    if (settled) { if (tid == 0) cnt[il] = 0; return; }
+    if (settled) return;
   }
-  if (tid == 0) s_base = 0;
+  // every thread looks at 8 consecutive cells (their stamps are in flight together), the counts are scanned once over the workgroup
   const int* stamp = stampAll + (int64_t)img * ncell;
-  int* out = list + (int64_t)il * ncell;
   const int want0 = mode == 0 ? t - 1 : t;
-  for (int c0 = 0; c0 < ncell; c0 += 1024) {
-    const int cell = c0 + tid;
-    const bool want = cell < ncell && stamp[cell] == want0;
-    if (want && mode == 1) tileTouchAll[(int64_t)img * ncell + cell] = t;      // (this cell is rewritten)
-    const unsigned long long bal = __builtin_amdgcn_ballot_w64(want);
-    if (lane == 0) wsum[wv] = __popcll(bal);
-    __syncthreads();
-    int before = s_base;
-    for (int w = 0; w < wv; ++w) before += wsum[w];
-    if (want) out[before + __popcll(bal & ((1ull << lane) - 1ull))] = cell;
-    __syncthreads();
-    if (tid == 0) { int tot = 0; for (int w = 0; w < 16; ++w) tot += wsum[w]; s_base += tot; }
-    __syncthreads();
+  const int c0 = blockIdx.x * TX_CELL_CHUNK + tid * 8;
+  int st[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) st[u] = c0 + u < ncell ? stamp[c0 + u] : want0 - 1;
+  unsigned m = 0u;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) m |= (st[u] == want0 ? 1u : 0u) << u;
+  const int mine = __popc(m);
+  int incl = mine;                                       // inclusive prefix over the wave
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
   }
-  if (tid == 0) cnt[il] = s_base;
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  int before = incl - mine, total = 0;
+  for (int w = 0; w < 16; ++w) {
+    const int v = wsum[w];
+    if (w < wv) before += v;
+    total += v;
+  }
+  if (total == 0) return;
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+    if ((m >> u) & 1u) {
+      buf[before++] = c0 + u;
+      if (mode == 1) tileTouchAll[(int64_t)img * ncell + c0 + u] = t;          // (this cell is rewritten)
+    }
+  if (tid == 0) s_base = atomicAdd(&cnt[il], total);
+  __syncthreads();
+  int* out = list + (int64_t)il * ncell + s_base;
+  for (int i = tid; i < total; i += 1024) out[i] = buf[i];
 }
 
 // one wave per listed cell (four cells at a time: their pixels' owner words are fetched together): the changed pixels of a cell

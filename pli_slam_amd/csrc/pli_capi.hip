@@ -233,6 +233,7 @@ struct TraceRange {
   TraceRange& operator=(const TraceRange&) = delete;
 };
 
+constexpr int TX_CELL_ROUNDS = 100;   // rounds of a call that can run on cell lists (two list lengths per round and image, zeroed per call)
 // the last k_tx_tail launch on every device of this process (see the launch site)
 static std::mutex g_tailMu;
 constexpr int TAIL_MAX_DEVICES = 64;
@@ -678,7 +679,7 @@ pli_status allocAll(pli_ctx* c) {
       A(c->txDirtyCnt, (size_t)c->txNtx * c->txNty * NR);
       A(c->tailBar, 64);
       A(c->txCellList, (size_t)c->tilesW * c->tilesH * NR);
-      A(c->txCellCnt, (size_t)2 * NR);
+      A(c->txCellCnt, (size_t)2 * TX_CELL_ROUNDS * NR);
       A(c->txPerm, (size_t)c->txNtx * c->txNty * NR);
       // key mode (lsd_tile.hip, k_tx_sort): ids of (bits of nBins - 1) + pixbits bits must stay below LSD_ID_INF = 2^31 - 1: with 1024 bins
       // up to 2^21 scaled pixels (1280 x 720 scales to 1536 x 864 = 1.33 M; 3840 x 2160 to 11.9 M pixels = 24 bits: ranks).
@@ -1023,6 +1024,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       add(c->tileAct + (int64_t)img0 * cells, cells * nimg);
       if (c->txDirtyCnt) add(c->txDirtyCnt + (int64_t)img0 * ntile64, ntile64 * nimg);
       if (c->tailBar) add(c->tailBar, 64);
+      if (c->txCellCnt) add(c->txCellCnt, (int64_t)2 * TX_CELL_ROUNDS * c->rxImages);
       if (c->txCandCnt) add(c->txCandCnt + img0, nimg);
       if (zfull) { g_err = "k_zero_ranges: more buffers than ZeroRanges holds"; return PLI_ERR_INVALID; }
       const int zb = (int)std::max<int64_t>(1, std::min<int64_t>(8192, (npix64 * nimg / 4 + 255) / 256));
@@ -1100,7 +1102,8 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       const bool useTail = tailPossible && fusedDM && DL.list;
       // rounds 3 .. tail start of a large batch by cell lists (six lean launches per round instead of four that walk every block;
       // a small batch keeps the four: launches are what it pays for).  Dev switch PLI_TX_CELLS=0 / 1.
-      bool useCells = fusedDM && DL.list && c->txCellList && nimg >= 16;
+      // (measured: 256 frames of 752 x 480 +2 %, 64 of 1280 x 720 +1 %, 16 of 4K +2 %; 32 frames of 752 x 480 -4 %: a million cells is the line)
+      bool useCells = fusedDM && DL.list && c->txCellList && (int64_t)c->tilesW * c->tilesH * nimg >= (1 << 20);
       if (const char* e = getenv("PLI_TX_CELLS")) useCells = atoi(e) != 0 && fusedDM && DL.list && c->txCellList;
       int tailT0 = 8;
       if (const char* e = getenv("PLI_TX_TAIL_T0")) tailT0 = std::max(3, atoi(e));
@@ -1143,13 +1146,15 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
           TRL(c, "k_tx_round2", k_tx_round2, dim3((P.LW + 31) / 32, (P.LH + 31) / 32, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->order,
               c->rgBox, c->rgDirty, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, (const int*)c->rgLost, DL, c->tileTouch,
               pack1 ? (const float4*)c->rec : (const float4*)nullptr);
-        else if (t >= 3 && fusedDM && useCells) {
+        else if (t >= 3 && fusedDM && useCells && t < TX_CELL_ROUNDS) {
           // cell lists (lsd_tile.hip "CELL LISTS"): the cells touched in round t - 1 -> their changed pixels' marks -> the active cells
-          // -> their owner words.  A list and its length per image stay on the device; a few workgroups per image stride over its list.
+          // -> their owner words.  A list and its length per image (and round: zeroed once per call) stay on the device; a few
+          // workgroups per image stride over its list.
           const int ncell = c->tilesW * c->tilesH;
-          const dim3 lg(nimg), wg(8, nimg);
-          int* cntA = c->txCellCnt + img0;
-          int* cntB = c->txCellCnt + c->rxImages + img0;
+          // (8192 = TX_CELL_CHUNK cells per listing workgroup; the consumers: 32 waves per image, more for large images)
+          const dim3 lg((unsigned)((ncell + 8191) / 8192), nimg), wg((unsigned)std::max(8, std::min(256, std::max(ncell / 1024, 4096 / nimg))), nimg);
+          int* cntA = c->txCellCnt + ((int64_t)2 * t) * c->rxImages + img0;
+          int* cntB = c->txCellCnt + ((int64_t)2 * t + 1) * c->rxImages + img0;
           int* lst = c->txCellList + (int64_t)img0 * ncell;
           TRL(c, "k_tx_cells", k_tx_cells, lg, dim3(1024), 0, c->jrCtl, (const int*)c->tileTouch, c->tileTouch, ncell, nimg, img0, t, 0, lst, cntA);
           TRL(c, "k_tx_diffmark", k_tx_diffmark_cells, wg, dim3(256), 0, c->jrCtl, (const int2*)c->own, (const int*)c->rankOf, (const int2*)c->rgBox,
