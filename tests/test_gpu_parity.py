@@ -1182,17 +1182,20 @@ def test_round1_owner_word_forms(gpu, monkeypatch):
     the front pass as the gradient norm in fixed point (LAZY ids, key mode: the default), or by k_tx_sort as the pixel's id (rank mode;
     PLI_TX_PACK1=1), or not at all (PLI_TX_PACK1=0: the owner plane, rounds 1-4's form).  All of them give the oracle's lines; and so
     does the LAZY form when EVERY unclaimed pixel is sent through the exact double-plane test (PLI_TX_LAZY_MARGIN wide) or when the
-    margin around a bin boundary is at its floor."""
+    margin around a bin boundary is at its floor.  Also here: the later rounds' bookkeeping on cell lists instead of block walks."""
     g = gpu
     W, H = 752, 480
     cfg = g.capi.default_config(W, H, orb_nfeatures=300, lsd_nfeatures=0, max_frames=2)
     pairs = [g.synth.make_stereo_pair(190 + i, W, H) for i in range(2)]
     imgs = np.stack([np.stack(p) for p in pairs])
-    keys = ("PLI_TX_PACK1", "PLI_TX_LAZY_MARGIN", "PLI_TX_KEYS", "PLI_TX_TAIL")
+    keys = ("PLI_TX_PACK1", "PLI_TX_LAZY_MARGIN", "PLI_TX_KEYS", "PLI_TX_TAIL", "PLI_TX_CELLS")
     out = {}
     for what, env in (("lazy", {}), ("lazy_all_exact", {"PLI_TX_LAZY_MARGIN": "2000000"}), ("lazy_margin4", {"PLI_TX_LAZY_MARGIN": "4"}),
                       ("sort_written_keys", {"PLI_TX_PACK1": "1"}), ("sort_written_ranks", {"PLI_TX_KEYS": "0"}),
-                      ("owner_plane", {"PLI_TX_PACK1": "0"}), ("owner_plane_ranks_no_tail", {"PLI_TX_PACK1": "0", "PLI_TX_KEYS": "0", "PLI_TX_TAIL": "0"})):
+                      ("owner_plane", {"PLI_TX_PACK1": "0"}), ("owner_plane_ranks_no_tail", {"PLI_TX_PACK1": "0", "PLI_TX_KEYS": "0", "PLI_TX_TAIL": "0"}),
+                      # rounds >= 3 on cell lists (k_tx_cells + a wave per listed cell; the default from a million cells per call up), up to
+                      # the tail kernel's round 8 and without the tail kernel
+                      ("cell_lists", {"PLI_TX_CELLS": "1"}), ("cell_lists_no_tail_ranks", {"PLI_TX_CELLS": "1", "PLI_TX_TAIL": "0", "PLI_TX_KEYS": "0"})):
         for k in keys:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
