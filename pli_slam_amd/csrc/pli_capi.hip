@@ -1099,6 +1099,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
                            !getenv("PLI_TX_NOFUSEDM");
       // rounds >= tailT0 in one persistent launch that ends by itself when every image is at its fixed point (no host look, no
       // planned round count; dev switches: PLI_TX_TAIL=0, PLI_TX_TAIL_T0, PLI_TX_TAIL_BPC)
+      static const int sideForkRound = getenv("PLI_SIDE_FORK_ROUND") ? atoi(getenv("PLI_SIDE_FORK_ROUND")) : 1;
       const bool useTail = tailPossible && fusedDM && DL.list;
       // rounds 3 .. tail start of a large batch by cell lists (six lean launches per round instead of four that walk every block;
       // a small batch keeps the four: launches are what it pays for).  Dev switch PLI_TX_CELLS=0 / 1.
@@ -1223,12 +1224,18 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
               c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty, c->tileAct, c->tilesW, c->tilesH, c->arena,
               c->arenaCap, c->rects, c->rectCap, img0, t, (const int*)c->rankOf, lostRule ? c->rgLost : (int*)nullptr, c->tileTouch, r1DL);
           }
-          if (c->sideChain) {                  // (pli_batch_run: the ORB chain forks here, behind round 1)
+          if (c->sideChain && sideForkRound <= 1) {       // (pli_batch_run: the ORB chain forks here, behind round 1)
             auto f = std::move(c->sideChain);
             c->sideChain = nullptr;
             pli_status ss = f();
             if (ss != PLI_OK) return ss;
           }
+        }
+        if (c->sideChain && t >= 2 && t == sideForkRound) {   // (dev switch PLI_SIDE_FORK_ROUND: ... behind the growth of a later round)
+          auto f = std::move(c->sideChain);
+          c->sideChain = nullptr;
+          pli_status ss = f();
+          if (ss != PLI_OK) return ss;
         }
         TRL(c, "k_rx_rect", k_rx_rect, dim3(rectBlocks, nimg), dim3(64), 0, c->dP, c->jrCtl, c->rec, c->arena, c->arenaCap, c->rects,
             c->rectCap, c->rgSeg, img0, c->mg, DL.rmask);
@@ -1590,8 +1597,13 @@ pli_status pli_batch_run(pli_ctx* c, int32_t nframes, const uint8_t* dl, const u
     };
     // (measured: +1.3 % at 32 frames, +1.4 % on the 4K configuration (16 frames), +1 % on a single pair; neutral at 64 and 128
     // frames, -0.5 % at 256, -3 % on the 720p configuration with its 2000 keypoints: up to 64 images it is)
-    static const int sideDeferMax = getenv("PLI_SIDE_DEFER_MAX") ? atoi(getenv("PLI_SIDE_DEFER_MAX")) : 64;   // (dev: images up to which the ORB chain starts behind round 1)
-    if (sideDefer && !seqGrower && c->lsdMode != 1 && nimg <= sideDeferMax) c->sideChain = sideChain;
+    // Round 5, with round 1 a tenth shorter when it has the chip to itself: 256 frames of 752 x 480 +1.9 % (47.4 -> 46.6 ms), 128 frames +2 %,
+    // 512 frames +0.3 %, 1024 frames -0.4 %; 64 frames of 1280 x 720 (2000 keypoints: a longer ORB chain) still -1.3 %.  So: up to 64
+    // images always, up to 1024 images of EuRoC-sized frames (< 0.5 M pixels).  Behind a LATER round (PLI_SIDE_FORK_ROUND = 3 / 4 / 5 / 7)
+    // it is 47.4 / 47.5 / 47.9 / 48.4 ms: the rounds that leave the chip idle are too short for the chain.
+    static const int sideDeferMax = getenv("PLI_SIDE_DEFER_MAX") ? atoi(getenv("PLI_SIDE_DEFER_MAX")) : -1;   // (dev: images up to which the ORB chain starts behind round 1)
+    const bool deferSide = sideDeferMax >= 0 ? nimg <= sideDeferMax : (nimg <= 64 || (nimg <= 1024 && (int64_t)c->hp.W * c->hp.H < 500000));
+    if (sideDefer && !seqGrower && c->lsdMode != 1 && deferSide) c->sideChain = sideChain;
     else if ((st = sideChain()) != PLI_OK) { c->lbdPreOnSide = false; return st; }
     st = runLines(c, 0, nimg, T);
     if (st == PLI_OK && c->sideChain) { auto f = std::move(c->sideChain); c->sideChain = nullptr; st = f(); }   // (not taken by runLines)
