@@ -1099,7 +1099,14 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
                            !getenv("PLI_TX_NOFUSEDM");
       // rounds >= tailT0 in one persistent launch that ends by itself when every image is at its fixed point (no host look, no
       // planned round count; dev switches: PLI_TX_TAIL=0, PLI_TX_TAIL_T0, PLI_TX_TAIL_BPC)
-      static const int sideForkRound = getenv("PLI_SIDE_FORK_ROUND") ? atoi(getenv("PLI_SIDE_FORK_ROUND")) : 1;
+      // Where the deferred ORB chain forks from the line chain (pli_batch_run): behind round 1's growth for small batches, behind round 2's
+      // for large ones.  Same-box runs at 256 frames, step in ms for a fork behind round 1 / behind round 2's owner pass (-2) / behind
+      // round 2 / behind round 3: synthetic stream 46.8 / 47.0 / 47.4 / 47.8; frames cut from photographs 33.5 / 31.7 / 30.9 / 31.8 (64 windows)
+      // and 34.7 / 32.7 / 32.1 / 32.8 (256 windows) — round 4's library on that box: 48.9 and 31.3.  k_tx_round2 streams every owner word
+      // once and is what the ORB kernels stretch most (2 -> 6-8 ms); natural images have a short round 1 and long sparse rounds that
+      // host the chain well.  Round 2 loses 1.3 % on the synthetic stream and wins 8 % on photographs: round 2 it is.  PLI_SIDE_FORK_ROUND overrides.
+      static const int sideForkEnv = getenv("PLI_SIDE_FORK_ROUND") ? atoi(getenv("PLI_SIDE_FORK_ROUND")) : 0;
+      const int sideForkRound = sideForkEnv ? sideForkEnv : (nimg <= 64 ? 1 : 2);
       const bool useTail = tailPossible && fusedDM && DL.list;
       // rounds 3 .. tail start of a large batch by cell lists (six lean launches per round instead of four that walk every block;
       // a small batch keeps the four: launches are what it pays for).  Dev switch PLI_TX_CELLS=0 / 1.
@@ -1143,11 +1150,17 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
           HIPCHK(hipMemsetAsync(c->txDirtyCnt + (int64_t)img0 * ntile, 0, sizeof(int) * (size_t)ntile * nimg, c->stream));
         const bool fused2 = t == 2 && !fullRound2 && lostRule && !getenv("PLI_TX_NOFUSE2");    // (dev switch: the two passes)
         bool cellsDone = false;
-        if (fused2)
+        if (fused2) {
           TRL(c, "k_tx_round2", k_tx_round2, dim3((P.LW + 31) / 32, (P.LH + 31) / 32, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->order,
               c->rgBox, c->rgDirty, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, (const int*)c->rgLost, DL, c->tileTouch,
               pack1 ? (const float4*)c->rec : (const float4*)nullptr);
-        else if (t >= 3 && fusedDM && useCells && t < TX_CELL_ROUNDS) {
+          if (c->sideChain && sideForkRound == -2) {      // (dev switch: the ORB chain forks behind round 2's pass over the owner map, before its growth)
+            auto f = std::move(c->sideChain);
+            c->sideChain = nullptr;
+            pli_status ss = f();
+            if (ss != PLI_OK) return ss;
+          }
+        } else if (t >= 3 && fusedDM && useCells && t < TX_CELL_ROUNDS) {
           // cell lists (lsd_tile.hip "CELL LISTS"): the cells touched in round t - 1 -> their changed pixels' marks -> the active cells
           // -> their owner words.  A list and its length per image (and round: zeroed once per call) stay on the device; a few
           // workgroups per image stride over its list.
@@ -1224,7 +1237,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
               c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty, c->tileAct, c->tilesW, c->tilesH, c->arena,
               c->arenaCap, c->rects, c->rectCap, img0, t, (const int*)c->rankOf, lostRule ? c->rgLost : (int*)nullptr, c->tileTouch, r1DL);
           }
-          if (c->sideChain && sideForkRound <= 1) {       // (pli_batch_run: the ORB chain forks here, behind round 1)
+          if (c->sideChain && sideForkRound <= 1 && sideForkRound != -2) {       // (pli_batch_run: the ORB chain forks here, behind round 1)
             auto f = std::move(c->sideChain);
             c->sideChain = nullptr;
             pli_status ss = f();
@@ -1600,7 +1613,7 @@ pli_status pli_batch_run(pli_ctx* c, int32_t nframes, const uint8_t* dl, const u
     // Round 5, with round 1 a tenth shorter when it has the chip to itself: 256 frames of 752 x 480 +1.9 % (47.4 -> 46.6 ms), 128 frames +2 %,
     // 512 frames +0.3 %, 1024 frames -0.4 %; 64 frames of 1280 x 720 (2000 keypoints: a longer ORB chain) still -1.3 %.  So: up to 64
     // images always, up to 1024 images of EuRoC-sized frames (< 0.5 M pixels).  Behind a LATER round (PLI_SIDE_FORK_ROUND = 3 / 4 / 5 / 7)
-    // it is 47.4 / 47.5 / 47.9 / 48.4 ms: the rounds that leave the chip idle are too short for the chain.
+    // it is 47.4 / 47.5 / 47.9 / 48.4 ms on the synthetic stream; which round it forks behind: runLines (sideForkRound).
     static const int sideDeferMax = getenv("PLI_SIDE_DEFER_MAX") ? atoi(getenv("PLI_SIDE_DEFER_MAX")) : -1;   // (dev: images up to which the ORB chain starts behind round 1)
     const bool deferSide = sideDeferMax >= 0 ? nimg <= sideDeferMax : (nimg <= 64 || (nimg <= 1024 && (int64_t)c->hp.W * c->hp.H < 500000));
     if (sideDefer && !seqGrower && c->lsdMode != 1 && deferSide) c->sideChain = sideChain;

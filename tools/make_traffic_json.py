@@ -8,7 +8,10 @@ import json, os, sys
 
 WORKLOADS = {"default_f256": "752x480_F256", "f2048_sequential": "752x480_F2048", "config5_4k": "3840x2160_F16", "config3_720p": "1280x720_F64"}
 ALIAS = {"k_lsd_grow2_spec": "k_lsd_grow2", "k_lsd_grow_spec": "k_lsd_grow", "k_lsd_grad64": "k_lsd_grad", "k_lsd_blur64": "k_blur_lsd",
-         "k_lsd_resize64": "k_resize_lsd", "k_lsd_front64": "k_lsd_front"}
+         "k_lsd_resize64": "k_resize_lsd", "k_lsd_front64": "k_lsd_front",
+         # round 5: round 1 of the tile relaxation has three instances (lazy ids / sort-written ids / owner plane) and the later
+         # rounds' bookkeeping two forms; bench.py's profile names are the left-hand kernels' roles
+         "k_tx_grow_p2": "k_tx_grow", "k_tx_grow_p1": "k_tx_grow", "k_tx_diffmark_cells": "k_tx_diffmark", "k_tx_prep_cells": "k_tx_prep"}
 
 
 def rows(path, counters):
