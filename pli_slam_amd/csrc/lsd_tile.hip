@@ -42,8 +42,8 @@ constexpr double TX_2PI = 2 * TX_PI;
 //     fire-and-forget): k_tx_grow 24.4 -> 28.2 ms, later rounds 24.3 -> 31.0 ms — the claims of OTHER tiles' waves made in the same
 //     round are no longer seen and are regrown a round later;
 //   * the same bitmap only to skip the loads of seeds the wave itself has taken: a third of the L2 misses gone (854 M -> 577 M),
-//     time unchanged — the growers are bound by instruction issue (4 cycles x (VALU + SALU instructions) per SIMD matches the
-//     kernel time within 10 % in every variant), not by the miss rate (65 % of the 49 G/s ceiling of tools/probes/gather_rate.hip).
+//     time unchanged.  (What binds the round-1 grower, as far as rounds 4 and 5 could separate it: VALU issue time — 71 % of the
+//     chip's —, the two dependent trips of a step at 8 waves per SIMD, and the gather rate, in comparable shares: DESIGN.md 5 "Round 5".)
 #ifndef TX_CLAIM_SCOPE             // (diagnostic builds only: -DTX_CLAIM_SCOPE=__HIP_MEMORY_SCOPE_WORKGROUP times the claims as L2 atomics —
 #define TX_CLAIM_SCOPE __HIP_MEMORY_SCOPE_AGENT   // NOT coherent between the XCDs' L2s, so not exact unless an image stays on one XCD)
 #endif
@@ -858,9 +858,9 @@ __global__ __launch_bounds__(256) void k_tx_prep_cells(const RxCtl* __restrict__
 // k_tx_grow: one wave per tile walks the tile's seeds in rank order.
 // ---------------------------------------------------------------------------
 // ---------------------------------------------------------------------------
-// The accept loop of a batched step, hand-scheduled like lsd_accept_fast (line_kernels.hip): the tile growers are bound by
-// the scalar unit (SQ counters at 256 frames: 188 000 SALU against 120 000 VALU instructions per tile wave, and one scalar
-// instruction per cycle and CU makes 73 % of the kernel's time), so the loop keeps 12 scalar instructions per accepted pixel.
+// The accept loop of a batched step, hand-scheduled like lsd_accept_fast (line_kernels.hip): half of the round-1 grower's vector
+// instructions are issued here (an accepted pixel costs 20 VALU + 14 SALU; 413 000 accepted pixels per 752 x 480 image), and the
+// kernel's time follows its instruction count at about half weight (DESIGN.md 5 "Round 5").
 // State: the float sums, `remaining` (candidates not yet decided; lane order = test order), `acc` (lanes accepted in this
 // batch, in increasing lane order: a lane's queue slot is cnt0 + its rank in acc), `seeds` (live seeds of the current list
 // row: a seed whose pixel is taken leaves it), cnt, and the bounding box as packed 16-bit (y, x) minima / maxima.
@@ -868,7 +868,7 @@ __global__ __launch_bounds__(256) void k_tx_prep_cells(const RxCtl* __restrict__
 // already without the lanes up to j2).
 // ---------------------------------------------------------------------------
 // Diagnostic builds (make EXTRA=-DTX_DIAG_PAD=n, never shipped): n x 4 idle VALU instructions (or, negative, |n| x 4 idle SALU
-// instructions) per iteration of the accept loop (at its top, where no hazard slot hides them) — how the kernel's time follows its instruction count.
+// instructions) per iteration of the accept loop (at its top, where no hazard slot hides them) — how the kernel's time follows its instruction count (NOTEBOOK.md "R4-5").
 #ifndef TX_DIAG_PAD
 #define TX_DIAG_PAD_ASM
 #elif TX_DIAG_PAD == 1
