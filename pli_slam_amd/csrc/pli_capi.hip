@@ -1105,7 +1105,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       // and 34.7 / 32.7 / 32.1 / 32.8 (256 windows) — round 4's library on that box: 48.9 and 31.3.  k_tx_round2 streams every owner word
       // once and is what the ORB kernels stretch most (2 -> 6-8 ms); natural images have a short round 1 and long sparse rounds that
       // host the chain well.  Round 2 loses 1.3 % on the synthetic stream and wins 8 % on photographs: round 2 it is.  PLI_SIDE_FORK_ROUND overrides.
-      static const int sideForkEnv = getenv("PLI_SIDE_FORK_ROUND") ? atoi(getenv("PLI_SIDE_FORK_ROUND")) : 0;
+      const int sideForkEnv = getenv("PLI_SIDE_FORK_ROUND") ? atoi(getenv("PLI_SIDE_FORK_ROUND")) : 0;
       const int sideForkRound = sideForkEnv ? sideForkEnv : (nimg <= 64 ? 1 : 2);
       const bool useTail = tailPossible && fusedDM && DL.list;
       // rounds 3 .. tail start of a large batch by cell lists (six lean launches per round instead of four that walk every block;
@@ -1614,7 +1614,7 @@ pli_status pli_batch_run(pli_ctx* c, int32_t nframes, const uint8_t* dl, const u
     // 512 frames +0.3 %, 1024 frames -0.4 %; 64 frames of 1280 x 720 (2000 keypoints: a longer ORB chain) still -1.3 %.  So: up to 64
     // images always, up to 1024 images of EuRoC-sized frames (< 0.5 M pixels).  Behind a LATER round (PLI_SIDE_FORK_ROUND = 3 / 4 / 5 / 7)
     // it is 47.4 / 47.5 / 47.9 / 48.4 ms on the synthetic stream; which round it forks behind: runLines (sideForkRound).
-    static const int sideDeferMax = getenv("PLI_SIDE_DEFER_MAX") ? atoi(getenv("PLI_SIDE_DEFER_MAX")) : -1;   // (dev: images up to which the ORB chain starts behind round 1)
+    const int sideDeferMax = getenv("PLI_SIDE_DEFER_MAX") ? atoi(getenv("PLI_SIDE_DEFER_MAX")) : -1;   // (dev: images up to which the ORB chain starts behind round 1)
     const bool deferSide = sideDeferMax >= 0 ? nimg <= sideDeferMax : (nimg <= 64 || (nimg <= 1024 && (int64_t)c->hp.W * c->hp.H < 500000));
     if (sideDefer && !seqGrower && c->lsdMode != 1 && deferSide) c->sideChain = sideChain;
     else if ((st = sideChain()) != PLI_OK) { c->lbdPreOnSide = false; return st; }

@@ -1304,3 +1304,38 @@ def test_an_aborted_tail_kernel_switches_the_process_to_planned_rounds(gpu, tmp_
     assert s1[2] >= 2, line                                   # the aborted tail: both images redone by the sequential grower
     assert s2[0] >= 1 and s3[0] >= 1 and s3[2] == s2[2] == s1[2], line   # latched: planned rounds from then on, no further slow-path images
     assert "planned-rounds schedule" in out.stderr
+
+
+def test_where_the_orb_chain_forks_does_not_change_a_byte(gpu, monkeypatch):
+    """pli_batch_run puts the ORB chain on a side stream that forks from the line chain before it starts, behind round 1's growth
+    (batches of up to 64 images), or behind round 2's (larger batches; DESIGN.md 5: worth +-3 % on the synthetic stream and +-8 % on
+    photographs).  Wherever it forks (dev switches PLI_SIDE_DEFER_MAX, PLI_SIDE_FORK_ROUND) the tables are the same bytes."""
+    g = gpu
+    W, H = 376, 240
+    F = 40                                                    # 80 images: above the small-batch line
+    cfg = g.capi.default_config(W, H, orb_nfeatures=400, lsd_nfeatures=40, max_frames=F)
+    pairs = [g.synth.make_stereo_pair(700 + i, W, H) for i in range(8)]
+    imgs = np.stack([np.stack(pairs[i % 8]) for i in range(F)])
+    out = {}
+    for what, env in (("default", {}), ("before_the_line_chain", {"PLI_SIDE_DEFER_MAX": "0"}), ("round1", {"PLI_SIDE_DEFER_MAX": "4096", "PLI_SIDE_FORK_ROUND": "1"}),
+                      ("round2_pass", {"PLI_SIDE_DEFER_MAX": "4096", "PLI_SIDE_FORK_ROUND": "-2"}), ("round3", {"PLI_SIDE_DEFER_MAX": "4096", "PLI_SIDE_FORK_ROUND": "3"}),
+                      ("never_in_the_rounds", {"PLI_SIDE_DEFER_MAX": "4096", "PLI_SIDE_FORK_ROUND": "90"}), ("no_side_stream", {"PLI_SIDE_MAX": "0"})):
+        for k in ("PLI_SIDE_DEFER_MAX", "PLI_SIDE_FORK_ROUND"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            if k != "PLI_SIDE_MAX":
+                monkeypatch.setenv(k, v)
+        if what == "no_side_stream":
+            continue                                          # (PLI_SIDE_MAX is read once per process: covered by tools/ab_env.sh runs, not here)
+        fe = g.Frontend(cfg)
+        fe.batch_run_host(imgs)
+        out[what] = fe.batch_run_host(imgs)
+    for k in ("PLI_SIDE_DEFER_MAX", "PLI_SIDE_FORK_ROUND"):
+        monkeypatch.delenv(k, raising=False)
+    fr = g.po.Frame(ocfg(g, cfg))
+    assert_frame_equal(g, out["default"][3], fr, pairs[3][0], pairs[3][1], "default fork, frame 3")
+    for what in out:
+        for f in range(F):
+            for k in out["default"][f]:
+                a, b = out[what][f][k], out["default"][f][k]
+                assert (a.tobytes() == b.tobytes()) if hasattr(a, "tobytes") else a == b, (what, f, k)
