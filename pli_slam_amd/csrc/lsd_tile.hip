@@ -1063,7 +1063,8 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
       lzCoefHi = __builtin_amdgcn_readfirstlane((int)(cb >> 32));
     }
     // (an image whose largest norm does not fit the fixed point — no 8-bit image has one — leaves every unclaimed pixel to the double plane)
-    if (mb != 0ull && maxGrad < 500.0) {
+    // ... and so does an image whose bin width does not fit the 32-bit kfix (fewer than ~130 bins: the host does not choose the lazy form then)
+    if (mb != 0ull && maxGrad < 500.0 && maxGrad / (double)lzNb1 < 3.99) {
       lzKfix = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(maxGrad / (double)lzNb1 * 1073741824.0 + 0.5));
       lzMargin = keysp->lazyMargin;
     }
@@ -1891,37 +1892,42 @@ __global__ __launch_bounds__(256) void k_tx_collect(RxCtl* __restrict__ ctl, con
   int* cand = candAll + (int64_t)img * TX_EMIT_CAP;
   if (tid == 0) s_n = 0;
   __syncthreads();
-  for (int64_t p1 = (int64_t)blockIdx.x * 1024; p1 < npix; p1 += (int64_t)gridDim.x * 1024) {
-   // (four rows of 256 pixels per trip: their size loads are in flight together)
-   int sz[4];
+  // the size plane is streamed sixteen pixels per thread and trip (four 16-byte loads in flight); the few pixels that are — or, stale,
+  // once were — seeds of a large enough region go on to the two gathers that decide (their own id, the owner of their pixel)
+  const int* rgSize = rgSizeAll + base;
+  const bool vec = (npix & 3) == 0 && ((uintptr_t)rgSize & 15) == 0;
+  for (int64_t p1 = (int64_t)blockIdx.x * 4096; p1 < npix; p1 += (int64_t)gridDim.x * 4096) {
+    int sz[16];
 #pragma unroll
-   for (int u = 0; u < 4; ++u) sz[u] = p1 + u * 256 + tid < npix ? rgSizeAll[base + p1 + u * 256 + tid] : 0;
-#pragma unroll
-   for (int u = 0; u < 4; ++u) {
-    const int64_t p = p1 + u * 256 + tid;
-    bool e = false;
-    int id = TX_INF;
-    // (the size first: only the few pixels that are — or, stale, once were — seeds of a large enough region go on to the two other loads)
-    if (sz[u] >= minReg) {
-      id = idPlaneAll[base + p];
-      e = id != TX_INF && ownAll[base + p].x == id;
+    for (int u = 0; u < 4; ++u) {
+      const int64_t p = p1 + u * 1024 + tid * 4;
+      int4 v = make_int4(0, 0, 0, 0);
+      if (vec && p + 3 < npix) v = *reinterpret_cast<const int4*>(rgSize + p);
+      else {
+        if (p < npix) v.x = rgSize[p];
+        if (p + 1 < npix) v.y = rgSize[p + 1];
+        if (p + 2 < npix) v.z = rgSize[p + 2];
+        if (p + 3 < npix) v.w = rgSize[p + 3];
+      }
+      sz[4 * u] = v.x; sz[4 * u + 1] = v.y; sz[4 * u + 2] = v.z; sz[4 * u + 3] = v.w;
     }
-    const unsigned long long bal = __builtin_amdgcn_ballot_w64(e);
-    if (bal) {
-      const int first = __ffsll((long long)bal) - 1;
-      int at = 0;
-      if (lane == first) at = atomicAdd(&s_n, __popcll(bal));
-      at = __shfl(at, first, 64) + __popcll(bal & ((1ull << lane) - 1ull));
-      if (e) {
-        if (at < CAP) s_buf[at] = id;
-        else {                                      // (more than CAP in one workgroup's share: straight to the image's list)
-          const int g = atomicAdd(&candCnt[img], 1);
-          if (g < emitCap) cand[g] = id;
-          else c.overflow = 6;
-        }
+    unsigned hits = 0u;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) hits |= (sz[j] >= minReg ? 1u : 0u) << j;
+    while (hits) {
+      const int j = __ffs(hits) - 1;
+      hits &= hits - 1u;
+      const int64_t p = p1 + (j >> 2) * 1024 + tid * 4 + (j & 3);
+      const int id = idPlaneAll[base + p];
+      if (id == TX_INF || ownAll[base + p].x != id) continue;
+      const int at = atomicAdd(&s_n, 1);
+      if (at < CAP) s_buf[at] = id;
+      else {                                        // (more than CAP in one workgroup's share: straight to the image's list)
+        const int g = atomicAdd(&candCnt[img], 1);
+        if (g < emitCap) cand[g] = id;
+        else c.overflow = 6;
       }
     }
-   }
   }
   __syncthreads();
   const int n = min(s_n, CAP);

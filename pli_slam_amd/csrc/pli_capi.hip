@@ -877,7 +877,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   int packMode = 0;
   if (!sequential && c->lsdMode != 1 && c->lsdF64 && c->mg && lostRule0 && !c->debug && !getenv("PLI_TX_FULL2") && !getenv("PLI_TX_NOFUSE2") &&
       !(getenv("PLI_TX_SPEC") && atoi(getenv("PLI_TX_SPEC")) != 0) && !(getenv("PLI_TX_ORDER") && atoi(getenv("PLI_TX_ORDER")) != 0))
-    packMode = keyMode ? 2 : 1;
+    packMode = (keyMode && P.nBins > 128) ? 2 : 1;      // (the lazy form's fixed-point bin width needs maxGrad / (nBins - 1) < 4: tests/test_lazy_ids_cpu.py)
   if (const char* e = getenv("PLI_TX_PACK1")) packMode = std::min(packMode, std::max(0, atoi(e)));
   const int trigF32 = ((c->cfg.parity_flags & PLI_PARITY_TRIG_F32_LSD) ? 1 : 0) | (packMode == 2 ? 2 : 0);
   if (c->lsdF64) {

@@ -1339,3 +1339,19 @@ def test_where_the_orb_chain_forks_does_not_change_a_byte(gpu, monkeypatch):
             for k in out["default"][f]:
                 a, b = out[what][f][k], out["default"][f][k]
                 assert (a.tobytes() == b.tobytes()) if hasattr(a, "tobytes") else a == b, (what, f, k)
+
+
+@pytest.mark.parametrize("nbins", [64, 129, 200, 1024])
+def test_lsd_bin_counts_through_the_packed_round_one(gpu, nbins):
+    """`lsd_n_bins` (Lineextractor's quantisation of the gradient norm into seed bins) through round 1's packed owner word: the lazy form's
+    fixed-point bin width needs more than 128 bins (tests/test_lazy_ids_cpu.py found 17 bins overflowing it), below that the ids are
+    written into the records by the sort.  Every count gives the oracle's lines."""
+    g = gpu
+    W, H = 752, 480
+    cfg = g.capi.default_config(W, H, orb_nfeatures=300, lsd_nfeatures=0, max_frames=1, lsd_n_bins=nbins)
+    L, R = g.synth.make_stereo_pair(420 + nbins, W, H)
+    fe = g.Frontend(cfg)
+    rec = fe.batch_run_host(np.stack([L, R])[None])[0]
+    assert fe.lsd_round_stats()[2] == 0
+    assert len(rec["klL"]) > 50
+    assert_frame_equal(g, rec, g.po.Frame(ocfg(g, cfg)), L, R, "lsd_n_bins = %d" % nbins)
