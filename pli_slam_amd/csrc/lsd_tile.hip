@@ -340,12 +340,16 @@ __device__ __forceinline__ void tx_round2_block(RxCtl* __restrict__ ctl, int2* _
                                                    const int2* __restrict__ rgBoxAll, int* __restrict__ rgDirtyAll,
                                                    int* __restrict__ tileActAll, int W, int H, int TW, int TH, int t, int img0,
                                                    const int* __restrict__ rgLostAll, TxDirtyLists DL,
-                                                   int* __restrict__ tileTouchAll, const float4* __restrict__ recPack) {
+                                                   int* __restrict__ tileTouchAll, const float4* __restrict__ recPack, int keepRect) {
   const int img = blockIdx.z + img0;
   RxCtl& c = ctl[img];
   if (c.state == 2) return;
   const int tid = threadIdx.x;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { c.nSmall = 0; c.nBig = 0; c.nHand = 0; c.nextBig = 0; c.rectArena = 0ull; c.changed = 0; c.changedOdd = 0; }
+  // (keepRect: round 1's region2rect pass runs beside this kernel and still reads the round's list counter: k_tx_reset_rect clears it later)
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+    c.nSmall = 0; c.nBig = 0; c.nHand = 0; c.nextBig = 0; c.changed = 0; c.changedOdd = 0;
+    if (!keepRect) c.rectArena = 0ull;
+  }
   // (packed round 1: owner_1 comes from the pixel records and the owner plane is WRITTEN here, both components, every pixel; t == 2)
   const int64_t base = (int64_t)img * W * H;
   const int ci = t & 1;
@@ -413,9 +417,14 @@ __global__ __launch_bounds__(256) void k_tx_round2(RxCtl* __restrict__ ctl, int2
                                                    const int2* __restrict__ rgBoxAll, int* __restrict__ rgDirtyAll,
                                                    int* __restrict__ tileActAll, int W, int H, int TW, int TH, int t, int img0,
                                                    const int* __restrict__ rgLostAll, TxDirtyLists DL,
-                                                   int* __restrict__ tileTouchAll, const float4* __restrict__ recPack) {
-  if (recPack) tx_round2_block<true>(ctl, ownAll, rankAll, orderAll, rgBoxAll, rgDirtyAll, tileActAll, W, H, TW, TH, t, img0, rgLostAll, DL, tileTouchAll, recPack);
-  else tx_round2_block<false>(ctl, ownAll, rankAll, orderAll, rgBoxAll, rgDirtyAll, tileActAll, W, H, TW, TH, t, img0, rgLostAll, DL, tileTouchAll, recPack);
+                                                   int* __restrict__ tileTouchAll, const float4* __restrict__ recPack, int keepRect) {
+  if (recPack) tx_round2_block<true>(ctl, ownAll, rankAll, orderAll, rgBoxAll, rgDirtyAll, tileActAll, W, H, TW, TH, t, img0, rgLostAll, DL, tileTouchAll, recPack, keepRect);
+  else tx_round2_block<false>(ctl, ownAll, rankAll, orderAll, rgBoxAll, rgDirtyAll, tileActAll, W, H, TW, TH, t, img0, rgLostAll, DL, tileTouchAll, recPack, keepRect);
+}
+// (after round 1's region2rect pass, when it ran beside k_tx_round2: the list counter of the images that are still relaxing starts round 2 at zero)
+__global__ __launch_bounds__(256) void k_tx_reset_rect(RxCtl* __restrict__ ctl, int nimg, int img0) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < nimg && ctl[img0 + i].state != 2) ctl[img0 + i].rectArena = 0ull;
 }
 
 // ---------------------------------------------------------------------------

@@ -69,6 +69,8 @@ struct pli_ctx {
   // stage); both chains are launch/latency bound there (+4 % on a single pair, +2.5 % at 32 frames, nothing from 256 frames on)
   hipStream_t aux = nullptr;
   hipEvent_t evFork = nullptr, evJoin = nullptr, evLbdPre = nullptr;
+  hipStream_t aux2 = nullptr;        // round 1's region2rect pass beside round 2's pass over the owner map (runLines)
+  hipEvent_t evRectFork = nullptr, evRectDone = nullptr;
   std::function<pli_status()> sideChain;     // pli_batch_run -> runLines: enqueues the side stream's work (see pli_batch_run)
   bool lbdPreOnSide = false;                 // the LBD's blur + Sobel of this call ran on the side stream (pli_batch_run)
   bool syncDebug = getenv("PLI_SYNC_DEBUG") != nullptr;
@@ -1107,6 +1109,9 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       // host the chain well.  Round 2 loses 1.3 % on the synthetic stream and wins 8 % on photographs: round 2 it is.  PLI_SIDE_FORK_ROUND overrides.
       const int sideForkEnv = getenv("PLI_SIDE_FORK_ROUND") ? atoi(getenv("PLI_SIDE_FORK_ROUND")) : 0;
       const int sideForkRound = sideForkEnv ? sideForkEnv : (nimg <= 64 ? 1 : 2);
+      // (round 1's region2rect pass on a stream of its own beside k_tx_round2: the default schedule only; dev switch PLI_RECT_ASIDE=0)
+      const bool rectAside = lostRule && !fullRound2 && !getenv("PLI_TX_NOFUSE2") && !trace && !perRound && !blocking && maxRounds >= 2 && !c->syncDebug &&
+                             !(getenv("PLI_RECT_ASIDE") && atoi(getenv("PLI_RECT_ASIDE")) == 0);
       const bool useTail = tailPossible && fusedDM && DL.list;
       // rounds 3 .. tail start of a large batch by cell lists (six lean launches per round instead of four that walk every block;
       // a small batch keeps the four: launches are what it pays for).  Dev switch PLI_TX_CELLS=0 / 1.
@@ -1153,7 +1158,11 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
         if (fused2) {
           TRL(c, "k_tx_round2", k_tx_round2, dim3((P.LW + 31) / 32, (P.LH + 31) / 32, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->order,
               c->rgBox, c->rgDirty, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, (const int*)c->rgLost, DL, c->tileTouch,
-              pack1 ? (const float4*)c->rec : (const float4*)nullptr);
+              pack1 ? (const float4*)c->rec : (const float4*)nullptr, rectAside ? 1 : 0);
+          if (rectAside) {                               // (round 1's region2rect pass has run beside this kernel: join, then the counter)
+            HIPCHK(hipStreamWaitEvent(c->stream, c->evRectDone, 0));
+            TRL(c, "k_tx_reset_rect", k_tx_reset_rect, dim3((nimg + 255) / 256), dim3(256), 0, c->jrCtl, nimg, img0);
+          }
           if (c->sideChain && sideForkRound == -2) {      // (dev switch: the ORB chain forks behind round 2's pass over the owner map, before its growth)
             auto f = std::move(c->sideChain);
             c->sideChain = nullptr;
@@ -1250,6 +1259,34 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
           pli_status ss = f();
           if (ss != PLI_OK) return ss;
         }
+        if (t == 1 && rectAside) {
+          // Round 1's region2rect pass (gather / latency bound, 2.9 ms at 256 frames) beside round 2's pass over the owner map (bandwidth
+          // bound, 2.1 ms): the two touch disjoint data — the pass reads the round's pixel lists and writes the segment plane, k_tx_round2
+          // reads the packed owner words and writes the owner plane — except the list counter, which k_tx_round2 leaves alone here and
+          // k_tx_reset_rect clears after the join, before round 2's growth allocates from it.
+          if (!c->aux2) {
+            HIPCHK(hipStreamCreateWithFlags(&c->aux2, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&c->evRectFork, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&c->evRectDone, hipEventDisableTiming));
+          }
+          hipStream_t mainS = c->stream;
+          HIPCHK(hipEventRecord(c->evRectFork, mainS));
+          HIPCHK(hipStreamWaitEvent(c->aux2, c->evRectFork, 0));
+          c->stream = c->aux2;
+          hipError_t le = hipSuccess;
+          {
+            auto launchRect = [&]() -> pli_status {
+              TRL(c, "k_rx_rect", k_rx_rect, dim3(rectBlocks, nimg), dim3(64), 0, c->dP, c->jrCtl, c->rec, c->arena, c->arenaCap, c->rects,
+                  c->rectCap, c->rgSeg, img0, c->mg, DL.rmask);
+              return PLI_OK;
+            };
+            const pli_status rs = launchRect();
+            c->stream = mainS;
+            if (rs != PLI_OK) return rs;
+          }
+          (void)le;
+          HIPCHK(hipEventRecord(c->evRectDone, c->aux2));
+        } else
         TRL(c, "k_rx_rect", k_rx_rect, dim3(rectBlocks, nimg), dim3(64), 0, c->dP, c->jrCtl, c->rec, c->arena, c->arenaCap, c->rects,
             c->rectCap, c->rgSeg, img0, c->mg, DL.rmask);
         if (trace) {
@@ -1485,6 +1522,7 @@ void pli_ctx_destroy(pli_ctx* c) {
   if (c->scratch) hipFree(c->scratch);
   for (hipEvent_t e : c->evPool) hipEventDestroy(e);
   if (c->ownStream && c->stream) hipStreamDestroy(c->stream);
+  if (c->aux2) { hipStreamSynchronize(c->aux2); hipStreamDestroy(c->aux2); hipEventDestroy(c->evRectFork); hipEventDestroy(c->evRectDone); }
   if (c->aux) { hipStreamSynchronize(c->aux); hipStreamDestroy(c->aux); hipEventDestroy(c->evFork); hipEventDestroy(c->evJoin); hipEventDestroy(c->evLbdPre); }
   for (int e = 0; e < 2; ++e) if (c->rectMap[e]) hipFree(c->rectMap[e]);
   for (int s = 0; s < 2; ++s) {
