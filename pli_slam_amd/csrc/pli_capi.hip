@@ -1110,8 +1110,11 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       const int sideForkEnv = getenv("PLI_SIDE_FORK_ROUND") ? atoi(getenv("PLI_SIDE_FORK_ROUND")) : 0;
       const int sideForkRound = sideForkEnv ? sideForkEnv : (nimg <= 64 ? 1 : 2);
       // (round 1's region2rect pass on a stream of its own beside k_tx_round2: the default schedule only; dev switch PLI_RECT_ASIDE=0)
+      // (a single pair pays 0.06 ms for the two events and the reset launch and has nothing to overlap: from 8 images on)
+      // (the ORB chain's stream when the chain is waiting to fork behind round 2 or later: idle until then)
+      const bool rectOnSide = c->sideChain && c->aux && (sideForkRound >= 2 || sideForkRound == -2) && !getenv("PLI_RECT_OWN_STREAM");
       const bool rectAside = lostRule && !fullRound2 && !getenv("PLI_TX_NOFUSE2") && !trace && !perRound && !blocking && maxRounds >= 2 && !c->syncDebug &&
-                             !(getenv("PLI_RECT_ASIDE") && atoi(getenv("PLI_RECT_ASIDE")) == 0);
+                             (getenv("PLI_RECT_ASIDE") ? atoi(getenv("PLI_RECT_ASIDE")) != 0 : (nimg >= 8 && (rectOnSide || c->sH2D == nullptr)));
       const bool useTail = tailPossible && fusedDM && DL.list;
       // rounds 3 .. tail start of a large batch by cell lists (six lean launches per round instead of four that walk every block;
       // a small batch keeps the four: launches are what it pays for).  Dev switch PLI_TX_CELLS=0 / 1.
@@ -1264,15 +1267,23 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
           // bound, 2.1 ms): the two touch disjoint data — the pass reads the round's pixel lists and writes the segment plane, k_tx_round2
           // reads the packed owner words and writes the owner plane — except the list counter, which k_tx_round2 leaves alone here and
           // k_tx_reset_rect clears after the join, before round 2's growth allocates from it.
-          if (!c->aux2) {
-            HIPCHK(hipStreamCreateWithFlags(&c->aux2, hipStreamNonBlocking));
+          if (!c->evRectFork) {
             HIPCHK(hipEventCreateWithFlags(&c->evRectFork, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&c->evRectDone, hipEventDisableTiming));
           }
+          // Which stream: the runtime maps streams onto FOUR hardware queues, and a context that pipelines host batches already has
+          // four (kernels, the ORB chain's side stream, the two copy streams) — a fifth shares a queue with a copy stream, and the
+          // host-inclusive rate fell from 0.99x to 0.93x of the resident one.  The ORB chain's stream is idle until the chain forks
+          // (behind round 2 in large batches): the pass borrows it then; otherwise a stream of its own, unless the host pipeline is in use.
+          hipStream_t rectS = rectOnSide ? c->aux : c->aux2;
+          if (!rectS) {
+            HIPCHK(hipStreamCreateWithFlags(&c->aux2, hipStreamNonBlocking));
+            rectS = c->aux2;
+          }
           hipStream_t mainS = c->stream;
           HIPCHK(hipEventRecord(c->evRectFork, mainS));
-          HIPCHK(hipStreamWaitEvent(c->aux2, c->evRectFork, 0));
-          c->stream = c->aux2;
+          HIPCHK(hipStreamWaitEvent(rectS, c->evRectFork, 0));
+          c->stream = rectS;
           hipError_t le = hipSuccess;
           {
             auto launchRect = [&]() -> pli_status {
@@ -1285,7 +1296,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
             if (rs != PLI_OK) return rs;
           }
           (void)le;
-          HIPCHK(hipEventRecord(c->evRectDone, c->aux2));
+          HIPCHK(hipEventRecord(c->evRectDone, rectS));
         } else
         TRL(c, "k_rx_rect", k_rx_rect, dim3(rectBlocks, nimg), dim3(64), 0, c->dP, c->jrCtl, c->rec, c->arena, c->arenaCap, c->rects,
             c->rectCap, c->rgSeg, img0, c->mg, DL.rmask);
@@ -1522,7 +1533,8 @@ void pli_ctx_destroy(pli_ctx* c) {
   if (c->scratch) hipFree(c->scratch);
   for (hipEvent_t e : c->evPool) hipEventDestroy(e);
   if (c->ownStream && c->stream) hipStreamDestroy(c->stream);
-  if (c->aux2) { hipStreamSynchronize(c->aux2); hipStreamDestroy(c->aux2); hipEventDestroy(c->evRectFork); hipEventDestroy(c->evRectDone); }
+  if (c->aux2) { hipStreamSynchronize(c->aux2); hipStreamDestroy(c->aux2); }
+  if (c->evRectFork) { hipEventDestroy(c->evRectFork); hipEventDestroy(c->evRectDone); }
   if (c->aux) { hipStreamSynchronize(c->aux); hipStreamDestroy(c->aux); hipEventDestroy(c->evFork); hipEventDestroy(c->evJoin); hipEventDestroy(c->evLbdPre); }
   for (int e = 0; e < 2; ++e) if (c->rectMap[e]) hipFree(c->rectMap[e]);
   for (int s = 0; s < 2; ++s) {
