@@ -79,8 +79,10 @@ __device__ __forceinline__ int2 tx_load_own(const int2* p) {
 // PACKED ROUND 1 (round 5).  In round 1 owner_0 is the trivial map, so the one owner word a test needs is owner_1 — and a step's
 // record and owner fetches are two gathers of the same 3 x 3 blocks from two planes (4.5 + 3.75 sixty-four-byte sectors per octet of
 // lanes).  With the CV_64F detector the fourth word of the 16-byte pixel record is free (the gradient norm lives in its own double
-// plane): k_tx_sort puts owner_1's start value there, round 1 reads ONE 16-byte word per neighbour and claims into it, and
-// k_tx_round2 moves the result into the owner plane.  The load bypasses the per-CU L1 like tx_load_own (claims are performed in L2).
+// plane): owner_1's start value goes there — written by the front pass as "unclaimed | gradient norm" (lazy ids, key mode) or by
+// k_tx_sort as "unclaimed | id" (rank mode) —, round 1 reads ONE 16-byte word per neighbour and claims into it (unsigned atomicMin:
+// an unclaimed word is above every id), and k_tx_round2 moves the result into the owner plane.  The load bypasses the per-CU L1
+// like tx_load_own (claims are performed in L2).
 typedef float tx_v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 tx_load_rec16(const float4* p) {
   tx_v4f v;
@@ -665,8 +667,8 @@ __global__ __launch_bounds__(256) void k_tx_prep(RxCtl* __restrict__ ctl, int2* 
 // Rounds >= 3 of large batches, CELL LISTS (round 5).  k_tx_diffmark and k_tx_prep walk every block of every image and let most
 // of them leave after a look at their cells' stamps; from round 3 on a round touches a few per cent of the cells, and what the
 // 133 000 + 267 000 workgroups of a 256-frame batch cost is the dependent chain "stamps -> barrier -> pixels -> barrier" of the many
-// that find one or two cells (rounds 3 to 7: 3.5 ms).  Here the cells with work are LISTED first (one thread per cell, a streaming
-// pass over the stamp plane; the per-image control updates of the two kernels ride on it) and one WAVE per listed cell does the
+// that find one or two cells (rounds 3 to 7: 3.5 ms).  Here the cells with work are LISTED first (a streaming pass over the stamp
+// plane, eight cells per thread; the per-image control updates of the two kernels ride on it) and one WAVE per listed cell does the
 // cell's 64 pixels — lane = pixel, no LDS beyond 64 bytes, no block barrier:
 //   k_tx_cells(mode 0) -> k_tx_diffmark_cells -> k_tx_cells(mode 1) -> k_tx_prep_cells -> k_tx_grow_sparse -> k_rx_rect.
 // Same marks, same rewritten cells as the block kernels (which stay: small batches — fewer launches —, k_tx_tail, dev switches).
