@@ -676,14 +676,16 @@ __global__ __launch_bounds__(256) void k_tx_prep(RxCtl* __restrict__ ctl, int2* 
 // mode 0 (before the diff of round t): cells touched in round t - 1; resets the per-round counters of the image (what block (0, 0)
 // of k_tx_diffmark does).  mode 1 (after it): cells active in round t, stamped as touched (k_tx_prep rewrites them); declares the
 // fixed point of an image whose round-t flag stayed clear and clears the other round's flag (block (0, 0) of k_tx_prep).
-constexpr int TX_CELL_CHUNK = 8192;      // cells a workgroup of k_tx_cells lists (one atomic on the image's counter per workgroup)
-__global__ __launch_bounds__(1024) void k_tx_cells(RxCtl* __restrict__ ctl, const int* __restrict__ stampAll, int* __restrict__ tileTouchAll,
+// (256 threads, 8 KB of LDS: the kernel runs while the ORB chain's workgroups fill the CUs, and a 1024-thread workgroup waits for
+// sixteen wave slots of ONE CU to be free at once — 0.5 ms a launch in the default line against 0.017 alone)
+constexpr int TX_CELL_CHUNK = 2048;      // cells a workgroup of k_tx_cells lists (one atomic on the image's counter per workgroup)
+__global__ __launch_bounds__(256) void k_tx_cells(RxCtl* __restrict__ ctl, const int* __restrict__ stampAll, int* __restrict__ tileTouchAll,
                                                    int ncell, int nimg, int img0, int t, int mode, int* __restrict__ list, int* __restrict__ cnt) {
-  // A workgroup per (chunk of 8192 cells, image): its cells with work are compacted in order (ballots + a prefix over the 16 waves)
-  // and take their places in the image's list with ONE atomic (752 x 480: one workgroup per image; one counter for the whole batch
+  // A workgroup per (chunk of 2048 cells, image): its cells with work are compacted in order (a prefix over the lanes and the 4 waves)
+  // and take their places in the image's list with ONE atomic (752 x 480: four workgroups per image; one counter for the whole batch
   // serialised 65 000 wave atomics on one address, 0.5 ms a launch).  The counters — per image, round and mode — are zeroed once
   // per call with the control blocks.
-  __shared__ int wsum[16];
+  __shared__ int wsum[4];
   __shared__ int s_base;
   __shared__ int buf[TX_CELL_CHUNK];
   const int il = blockIdx.y, img = img0 + il, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -722,7 +724,7 @@ __global__ __launch_bounds__(1024) void k_tx_cells(RxCtl* __restrict__ ctl, cons
   if (lane == 63) wsum[wv] = incl;
   __syncthreads();
   int before = incl - mine, total = 0;
-  for (int w = 0; w < 16; ++w) {
+  for (int w = 0; w < 4; ++w) {
     const int v = wsum[w];
     if (w < wv) before += v;
     total += v;
@@ -737,19 +739,21 @@ __global__ __launch_bounds__(1024) void k_tx_cells(RxCtl* __restrict__ ctl, cons
   if (tid == 0) s_base = atomicAdd(&cnt[il], total);
   __syncthreads();
   int* out = list + (int64_t)il * ncell + s_base;
-  for (int i = tid; i < total; i += 1024) out[i] = buf[i];
+  for (int i = tid; i < total; i += 256) out[i] = buf[i];
 }
 
 // one wave per listed cell (four cells at a time: their pixels' owner words are fetched together): the changed pixels of a cell
 // (owner_{t-1} != owner_{t-2}) and the rule of k_tx_mark on their neighbours
-__global__ __launch_bounds__(256) void k_tx_diffmark_cells(RxCtl* __restrict__ ctl, const int2* __restrict__ ownAll, const int* __restrict__ rankAll,
+// (single-wave workgroups: the waves do not talk to each other, and the kernel runs beside the ORB chain — the smaller the workgroup,
+// the sooner it finds its wave slots)
+__global__ __launch_bounds__(64) void k_tx_diffmark_cells(RxCtl* __restrict__ ctl, const int2* __restrict__ ownAll, const int* __restrict__ rankAll,
                                                            const int2* __restrict__ rgBoxAll, int* __restrict__ rgDirtyAll,
                                                            int* __restrict__ tileActAll, int W, int H, int TW, int TH, int t, int img0,
                                                            const int* __restrict__ rgLostAll, TxDirtyLists DL, const int* __restrict__ list,
                                                            const int* __restrict__ cnt) {
   constexpr int U = 4;
-  __shared__ unsigned char slots[4][64];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __shared__ unsigned char slots[1][64];
+  const int lane = threadIdx.x & 63, wv = 0;
   const int il = blockIdx.y, ncell = TW * TH;
   const int n = cnt[il];
   const int ci = t & 1;
@@ -760,7 +764,7 @@ __global__ __launch_bounds__(256) void k_tx_diffmark_cells(RxCtl* __restrict__ c
   int* rgDirty = rgDirtyAll + base;
   const int2* rgBox = rgBoxAll + base;
   const int* lst = list + (int64_t)il * ncell;
-  for (int i0 = (blockIdx.x * 4 + wv) * U; i0 < n; i0 += gridDim.x * 4 * U) {
+  for (int i0 = blockIdx.x * U; i0 < n; i0 += gridDim.x * U) {
     int cells[U];
     int2 ow[U];
 #pragma unroll
@@ -821,18 +825,18 @@ __global__ __launch_bounds__(256) void k_tx_diffmark_cells(RxCtl* __restrict__ c
 }
 
 // one wave per listed cell, four cells at a time: owner_t of the cells' pixels (k_tx_prep's rule)
-__global__ __launch_bounds__(256) void k_tx_prep_cells(const RxCtl* __restrict__ ctl, int2* __restrict__ ownAll, const int* __restrict__ rankAll,
+__global__ __launch_bounds__(64) void k_tx_prep_cells(const RxCtl* __restrict__ ctl, int2* __restrict__ ownAll, const int* __restrict__ rankAll,
                                                        const int* __restrict__ rgDirtyAll, int W, int H, int TW, int TH, int t, int img0, int rmask,
                                                        const int* __restrict__ list, const int* __restrict__ cnt) {
   constexpr int U = 4;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
   const int il = blockIdx.y, ncell = TW * TH;
   const int n = cnt[il];
   const int ci = t & 1;
   const int img = img0 + il;
   const int64_t base = (int64_t)img * W * H;
   const int* lst = list + (int64_t)il * ncell;
-  for (int i0 = (blockIdx.x * 4 + wv) * U; i0 < n; i0 += gridDim.x * 4 * U) {
+  for (int i0 = blockIdx.x * U; i0 < n; i0 += gridDim.x * U) {
     int p[U], r[U], dirtyAt[U];
     int2 o[U];
 #pragma unroll

@@ -1177,16 +1177,16 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
           // -> their owner words.  A list and its length per image (and round: zeroed once per call) stay on the device; a few
           // workgroups per image stride over its list.
           const int ncell = c->tilesW * c->tilesH;
-          // (8192 = TX_CELL_CHUNK cells per listing workgroup; the consumers: 32 waves per image, more for large images)
-          const dim3 lg((unsigned)((ncell + 8191) / 8192), nimg), wg((unsigned)std::max(8, std::min(256, std::max(ncell / 1024, 4096 / nimg))), nimg);
+          // (2048 = TX_CELL_CHUNK cells per listing workgroup; the consumers: 32 waves per image, more for large images)
+          const dim3 lg((unsigned)((ncell + 2047) / 2048), nimg), wg((unsigned)(4 * std::max(8, std::min(256, std::max(ncell / 1024, 4096 / nimg)))), nimg);      // (single-wave workgroups)
           int* cntA = c->txCellCnt + ((int64_t)2 * t) * c->rxImages + img0;
           int* cntB = c->txCellCnt + ((int64_t)2 * t + 1) * c->rxImages + img0;
           int* lst = c->txCellList + (int64_t)img0 * ncell;
-          TRL(c, "k_tx_cells", k_tx_cells, lg, dim3(1024), 0, c->jrCtl, (const int*)c->tileTouch, c->tileTouch, ncell, nimg, img0, t, 0, lst, cntA);
-          TRL(c, "k_tx_diffmark", k_tx_diffmark_cells, wg, dim3(256), 0, c->jrCtl, (const int2*)c->own, (const int*)c->rankOf, (const int2*)c->rgBox,
+          TRL(c, "k_tx_cells", k_tx_cells, lg, dim3(256), 0, c->jrCtl, (const int*)c->tileTouch, c->tileTouch, ncell, nimg, img0, t, 0, lst, cntA);
+          TRL(c, "k_tx_diffmark", k_tx_diffmark_cells, wg, dim3(64), 0, c->jrCtl, (const int2*)c->own, (const int*)c->rankOf, (const int2*)c->rgBox,
               c->rgDirty, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, (const int*)c->rgLost, DL, (const int*)lst, (const int*)cntA);
-          TRL(c, "k_tx_cells", k_tx_cells, lg, dim3(1024), 0, c->jrCtl, (const int*)c->tileAct, c->tileTouch, ncell, nimg, img0, t, 1, lst, cntB);
-          TRL(c, "k_tx_prep", k_tx_prep_cells, wg, dim3(256), 0, (const RxCtl*)c->jrCtl, c->own, (const int*)c->rankOf, (const int*)c->rgDirty, P.LW,
+          TRL(c, "k_tx_cells", k_tx_cells, lg, dim3(256), 0, c->jrCtl, (const int*)c->tileAct, c->tileTouch, ncell, nimg, img0, t, 1, lst, cntB);
+          TRL(c, "k_tx_prep", k_tx_prep_cells, wg, dim3(64), 0, (const RxCtl*)c->jrCtl, c->own, (const int*)c->rankOf, (const int*)c->rgDirty, P.LW,
               P.LH, c->tilesW, c->tilesH, t, img0, DL.rmask, (const int*)lst, (const int*)cntB);
           cellsDone = true;
         } else if (t >= 3 && fusedDM)
