@@ -1121,7 +1121,11 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       // (measured: 256 frames of 752 x 480 +2 %, 64 of 1280 x 720 +1 %, 16 of 4K +2 %; 32 frames of 752 x 480 -4 %: a million cells is the line)
       bool useCells = fusedDM && DL.list && c->txCellList && (int64_t)c->tilesW * c->tilesH * nimg >= (1 << 20);
       if (const char* e = getenv("PLI_TX_CELLS")) useCells = atoi(e) != 0 && fusedDM && DL.list && c->txCellList;
-      int tailT0 = 8;
+      // The persistent kernel takes over at round 8 — at round 12 when the rounds before it run on cell lists: their launches are lean, and
+      // a large batch still has the ORB chain on the chip around round 8, beside which the tail's 256 workgroups of 50 KB LDS, which must
+      // ALL be resident, wait for their compute units (k_tx_tail 0.7 ms alone, 2.6 ms in the default line).  256 frames, same box, start
+      // at 8 / 12 / 14 / 16: synthetic 46.0-46.1 / 45.7 / 45.6 / 45.6 ms, photographs 29.2-29.3 / 29.3 / 29.4 / 29.7.
+      int tailT0 = useCells ? 12 : 8;
       if (const char* e = getenv("PLI_TX_TAIL_T0")) tailT0 = std::max(3, atoi(e));
       for (int t = 1; t <= maxRounds && !allDone; ++t) {
         curT = t;
