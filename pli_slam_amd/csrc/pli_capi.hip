@@ -1108,7 +1108,11 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       // once and is what the ORB kernels stretch most (2 -> 6-8 ms); natural images have a short round 1 and long sparse rounds that
       // host the chain well.  Round 2 loses 1.3 % on the synthetic stream and wins 8 % on photographs: round 2 it is.  PLI_SIDE_FORK_ROUND overrides.
       const int sideForkEnv = getenv("PLI_SIDE_FORK_ROUND") ? atoi(getenv("PLI_SIDE_FORK_ROUND")) : 0;
-      const int sideForkRound = sideForkEnv ? sideForkEnv : (nimg <= 64 ? 1 : 2);
+      // (round 5's last builds — cell kernels with small workgroups, the tail from round 12 — moved the balance: what waits now is the END of the
+      // line chain, 1024-thread / 64 KB workgroups (k_tx_emit_sorted, the gated k_lsd_scan, k_keylines) that find no room while the ORB chain
+      // still fills every hole, so the chain should END earlier: same box, fork behind round 1 / round 2's owner pass / round 2 / round 3:
+      // synthetic 45.0 / 45.0 / 45.4-45.5 / 46.2 ms, photographs 28.6 / 28.5 / 29.5 / 30.0.  Behind round 2's owner pass it is.)
+      const int sideForkRound = sideForkEnv ? sideForkEnv : (nimg <= 64 ? 1 : -2);
       // (round 1's region2rect pass on a stream of its own beside k_tx_round2: the default schedule only; dev switch PLI_RECT_ASIDE=0)
       // (a single pair pays 0.06 ms for the two events and the reset launch and has nothing to overlap: from 8 images on)
       // (the ORB chain's stream when the chain is waiting to fork behind round 2 or later: idle until then)
