@@ -665,7 +665,7 @@ def main():
                                   "low-priority side stream beside the line chain: their event times INCLUDE the wait for wave slots behind the "
                                   "line kernels (alone, PLI_SIDE_MAX=0, 256 frames: k_resize_level 0.7 ms, k_fast_cells 3.4, k_octree 1.5, "
                                   "k_blur_orb 1.0, k_describe 1.0) and are not comparable with the main stream's; the line chain's kernels are "
-                                  "stretched by them in turn (alone: k_tx_round2 2.1 ms, k_tx_grow_sparse 2.9; the chain forks behind round 2 of a "
+                                  "stretched by them in turn (alone: k_tx_round2 2.1 ms, k_tx_grow_sparse 2.9; the chain forks behind round 2's owner pass of a "
                                   "large batch).  DESIGN.md 5 / 7 have every kernel alone"}
         what = C_["what"] if args.config else ("752x480 stereo pairs, extract + stereo Hamming match (BASELINE configs[1] shape, "
                                                "batched)")
