@@ -577,7 +577,7 @@ def main():
         issue = None       # what the dominant kernel is bound by, from the committed SQ passes of the same workload
         step_traffic = None  # counter traffic of the WHOLE step (every kernel x its launches) against the algorithmic bytes
         traffic = None     # HBM bytes per launch from the committed PMC passes of the same workload, if any
-        sector = None      # the growers are gather kernels: their ceiling is the rate of random 64-byte sector requests the chip
+        sector = None      # the growers are gather kernels: their ceiling is the rate of random 128-byte line requests the chip
         counters_note = None   # why a counter-derived field is null, or which committed workload stood in for this one
         try:               # sustains (tools/probes/gather_rate.hip, profiles/r02_gather_rate_probe.txt: 49 G/s), not the stream peak
             tpath = [p_ for p_ in (os.path.join(ROOT, "profiles", "r%02d_traffic.json" % n_) for n_ in (5, 4, 3, 2)) if os.path.exists(p_)][0]
@@ -599,14 +599,17 @@ def main():
             k = tr["workloads"].get(wkey, {}).get(name)
             if k and scale_F != 1.0:
                 k = dict(k, fetch_kb=k["fetch_kb"] * scale_F, write_kb=k["write_kb"] * scale_F)
-            isGather = lambda kn_: kn_.startswith(("k_tx_grow", "k_lsd_grow", "k_rx_grow"))
+            # bytes = 2 x FETCH_SIZE + WRITE_SIZE for EVERY kernel: the L2 reads memory in 128-byte lines — streams and the growers'
+            # random 16-byte gathers alike (TCC_EA0_RDREQ_128B = TCC_EA0_RDREQ for each kernel of the step and for the patterns of known
+            # size of tools/probes/read_amp.hip: profiles/r05_counter_calibration.txt) — and FETCH_SIZE tallies a request as 64 bytes.
+            # (Rounds 2-4 and the first round-5 lines counted the growers' requests as 64-byte sectors: their traffic was understated.)
             wl = tr["workloads"].get(wkey, {})
             if wl and all("launches" in v_ for v_ in wl.values()):
-                tot = scale_F * sum(v_["launches"] * ((1 if isGather(kn_) else 2) * v_["fetch_kb"] + v_["write_kb"]) * 1024 for kn_, v_ in wl.items()
-                                    if "alias_of" not in v_)
+                tot = scale_F * sum(v_["launches"] * (2 * v_["fetch_kb"] + v_["write_kb"]) * 1024 for kn_, v_ in wl.items() if "alias_of" not in v_)
                 step_traffic = {"bytes_per_step": tot, "algorithmic_bytes_per_step": b_frame * F, "ratio": tot / (b_frame * F),
                                 "hbm_GBps_at_this_rate": tot / (dt / args.steps) / 1e9, "source": os.path.basename(tpath), "source_workload": wkey,
-                                "note": "sum over the kernels of the committed FETCH_SIZE / WRITE_SIZE passes x their launches per step"}
+                                "note": "sum over the kernels of the committed FETCH_SIZE / WRITE_SIZE passes x their launches per step; "
+                                        "every read request is a 128-byte line (2 x FETCH_SIZE), the growers' gathers included"}
             iq = tr.get("issue", {}).get(wkey, {}).get(name)
             if iq and iq["avg_ns"] > 0 and scale_F == 1.0:
                 simd_quads = 1024 * iq["avg_ns"] * 2.4 / 4.0        # quad-cycles all SIMDs of the chip offer during one launch (2.4 GHz)
@@ -615,14 +618,14 @@ def main():
                          "note": "SQ_ACTIVE_INST_VALU / (1024 SIMDs x quad-cycles of the launch): the share of the chip's VALU issue "
                                  "time the kernel uses (profiler run, 2.4 GHz assumed)"}
             if k:
-                # FETCH_SIZE counts 32-byte units for streaming kernels on gfx950 (MI355X_MICROARCH.md: x2) but 64 bytes per request
-                # of the growers' 8-byte gathers (TCC_MISS x 64 B agrees with the undoubled figure, profiles/README.md)
-                gather = name.startswith(("k_tx_grow", "k_lsd_grow", "k_rx_grow"))
-                traffic = ((1 if gather else 2) * k["fetch_kb"] + k["write_kb"]) * 1024
+                # FETCH_SIZE tallies every read request as 64 bytes on gfx950 (MI355X_MICROARCH.md: x2); the requests are 128-byte lines
+                # for the growers' gathers as well (profiles/r05_counter_calibration.txt)
+                traffic = (2 * k["fetch_kb"] + k["write_kb"]) * 1024
                 if name.startswith(("k_tx_grow", "k_lsd_grow", "k_rx_grow")) and avg_s > 0:
-                    rate = k["fetch_kb"] * 1024 / 64 / avg_s / 1e9      # FETCH_SIZE counts 64 B per request of these kernels
-                    sector = {"achieved": rate, "peak": 49.0, "unit": "G 64-byte sector requests/s (L2 misses)", "frac": rate / 49.0,
-                              "note": "peak measured by tools/probes/gather_rate.hip; requests per launch from the committed FETCH_SIZE pass"}
+                    rate = k["fetch_kb"] * 1024 / 64 / avg_s / 1e9      # requests per second (FETCH_SIZE = requests x 64 B)
+                    sector = {"achieved": rate, "peak": 49.0, "unit": "G 128-byte line requests/s (L2 misses)", "frac": rate / 49.0,
+                              "note": "peak measured by tools/probes/gather_rate.hip (random gathers: 49 G lines/s = 6.3 TB/s, the HBM "
+                                      "rate a stream reaches too); requests per launch from the committed FETCH_SIZE pass"}
         except Exception as e:     # (the headline does not depend on the committed counter files; the line says what went wrong)
             counters_note = "counter files not usable: %r" % (e,)
         # every kernel of the step against the HBM peak: algorithmic bytes per image (table above) x images per step / its time per step
@@ -645,12 +648,15 @@ def main():
                     kfrac[kn] = round(fr_, 4)
         side = orb_chain + ("k_stereo_points", "k_stereo_median", "k_blur_lbd", "k_sobel")
         grower = bool(name) and name.startswith(("k_tx_grow", "k_lsd_grow", "k_rx_grow"))
-        # `frac` is against the HBM peak, as the contract asks; a region grower is a chain of dependent gathers at the occupancy limit of
-        # 8 waves per SIMD, so `bound` / `limiter` name that category (the measurements behind it: DESIGN.md 5) and `issue`, `sector_requests`
-        # and `step_traffic` carry what the committed counter passes of this workload say — null, with `counters_note`, when there are none
+        # `frac` is against the HBM peak by ALGORITHMIC bytes, as the contract asks.  A region grower is a chain of dependent random
+        # gathers at the occupancy limit of 8 waves per SIMD: `bound` names that category; every 16-byte gather that misses the L2 moves a
+        # 128-byte line, so its MEASURED traffic (`traffic`, `traffic_GBps`) is tens of times its algorithmic bytes and about half of what
+        # the memory system delivers to gathers (`sector_requests`) — `limiter` names the three shares (the measurements behind them:
+        # DESIGN.md 5); `issue`, `sector_requests` and `step_traffic` carry what the committed counter passes of this workload say —
+        # null, with `counters_note`, when there are none
         roof = {"bound": "latency (wave slots)" if grower else "hbm", "kernel": name, "achieved": achieved, "peak": peak, "unit": "GB/s",
-                "frac": (achieved / peak) if achieved is not None else None, "traffic": traffic, "sector_requests": sector,
-                "limiter": "latency/occupancy (DESIGN.md 5)" if grower else "hbm",
+                "frac": (achieved / peak) if achieved is not None else None, "traffic": traffic, "traffic_GBps": (traffic / avg_s / 1e9) if (traffic and avg_s > 0) else None, "sector_requests": sector,
+                "limiter": "dependent trips at 8 waves per SIMD / VALU issue / 128-byte lines for 16-byte gathers (DESIGN.md 5)" if grower else "hbm",
                 "counters_note": counters_note,
                 "issue": issue, "step_traffic": step_traffic,
                 "avg_launch_ms": avg_s * 1e3, "launches": calls,

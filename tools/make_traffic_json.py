@@ -36,8 +36,9 @@ def alias(w):
 d = sys.argv[1]
 doc = {"note": "HBM traffic per launch from rocprofv3 PMC passes (separate runs for FETCH_SIZE and WRITE_SIZE, bench.py --steps 1 "
                "--warmup 0), per-launch averages per kernel, keyed by workload WxH_F<frames per GPU>.  bytes = (2*FETCH_SIZE_KB + "
-               "WRITE_SIZE_KB)*1024: FETCH_SIZE is halved on gfx950 for coalesced streams (MI355X_MICROARCH.md, checked on k_lsd_hist); "
-               "for gather kernels (the growers' 8-byte loads, one 64-byte request each) FETCH_SIZE x 1 is the truth (TCC_MISS x 64 B agrees).  "
+               "WRITE_SIZE_KB)*1024 for EVERY kernel: FETCH_SIZE tallies a read request as 64 bytes on gfx950 (MI355X_MICROARCH.md) and every "
+               "request of these kernels is a 128-byte line, the growers' random 16-byte gathers included (TCC_EA0_RDREQ_128B = TCC_EA0_RDREQ; "
+               "profiles/r05_counter_calibration.txt; the files of rounds 2-4 said x 1 for the growers, which understated them).  "
                "`issue`: SQ passes of the same workload — wave instructions per launch (SQ_INSTS_VALU / _SALU) and SQ_ACTIVE_INST_VALU "
                "(quad-cycles in which a SIMD's VALU was executing): valu_issue_frac = active_valu_quad_cycles * 4 / (1024 SIMDs x cycles "
                "of the launch at 2.4 GHz).  Kernel names as rocprofv3 reports them.",
