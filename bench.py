@@ -628,6 +628,12 @@ def main():
                                       "rate a stream reaches too); requests per launch from the committed FETCH_SIZE pass"}
         except Exception as e:     # (the headline does not depend on the committed counter files; the line says what went wrong)
             counters_note = "counter files not usable: %r" % (e,)
+        traffic_rate = (traffic / avg_s / 1e9) if (traffic and avg_s > 0) else None
+        if args.real_images and traffic is not None:
+            # the committed counter passes are of the SYNTHETIC batch: the bytes stand as an upper bound for these (calmer) frames, a rate
+            # formed with this run's launch time would not be a measurement
+            traffic_rate, sector = None, None
+            counters_note = ((counters_note + "; ") if counters_note else "") + "counter passes are of the synthetic batch, not of these frames"
         # every kernel of the step against the HBM peak: algorithmic bytes per image (table above) x images per step / its time per step
         # (a kernel of the ORB chain is timed on the side stream, beside the line chain: its fraction is a lower bound)
         kfrac = {}
@@ -655,7 +661,7 @@ def main():
         # DESIGN.md 5); `issue`, `sector_requests` and `step_traffic` carry what the committed counter passes of this workload say —
         # null, with `counters_note`, when there are none
         roof = {"bound": "latency (wave slots)" if grower else "hbm", "kernel": name, "achieved": achieved, "peak": peak, "unit": "GB/s",
-                "frac": (achieved / peak) if achieved is not None else None, "traffic": traffic, "traffic_GBps": (traffic / avg_s / 1e9) if (traffic and avg_s > 0) else None, "sector_requests": sector,
+                "frac": (achieved / peak) if achieved is not None else None, "traffic": traffic, "traffic_GBps": traffic_rate, "sector_requests": sector,
                 "limiter": "dependent trips at 8 waves per SIMD / VALU issue / 128-byte lines for 16-byte gathers (DESIGN.md 5)" if grower else "hbm",
                 "counters_note": counters_note,
                 "issue": issue, "step_traffic": step_traffic,

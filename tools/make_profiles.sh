@@ -2,7 +2,7 @@
 # GPU box: regenerates the rocprofv3 summaries kept under profiles/ for ONE round (written to gpurun_out/prof_rNN/; copy them
 # into profiles/ with tools/install_profiles.sh --round N).  rocprofv3 is run from /tmp with the program directly after "--";
 # counters in their own passes (--kernel-trace --pmc only, never with a trace domain: gpurun refuses that combination).
-#   tools/make_profiles.sh --round N [stats] [pmc] [sq] [plain] [sweep4k] [real]      (default: all groups)
+#   tools/make_profiles.sh --round N [stats] [pmc] [sq] [plain] [sweep4k] [real] [markers] [extras]      (default: all groups)
 #     stats    rocprofv3 --kernel-trace --stats of the headline batch, F = 32, configs 2 / 3 / 5, the 2048-frame batch
 #     pmc      FETCH_SIZE and WRITE_SIZE passes (separate runs) of the headline batch and configs 3 / 5 / the 2048-frame batch
 #     sq       SQ / TCC counter passes of the headline batch (instruction counts and issue cycles of every kernel)
@@ -10,6 +10,7 @@
 #     sweep4k  config 5 at F = 16 / 32 / 64 (is 4K's rate the plateau?)
 #     real     the headline batch on frames cut from real photographs (bench.py --real-images): rate, relaxation rounds, fallbacks
 #     markers  rocprofv3 --kernel-trace --marker-trace with PLI_ROCTX=1 (F = 32): the library's roctx ranges — entry point > stage > launch
+#     extras   the headline batch with every kernel alone (per-round times), and the real-image batch with round 4's 64 distinct windows
 ROUND=4
 if [[ $1 == --round ]]; then ROUND=$2; shift; shift; fi
 RN=$(printf "r%02d" $ROUND)
@@ -17,7 +18,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$RN
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-WHAT="${*:-stats pmc sq plain sweep4k real markers}"
+WHAT="${*:-stats pmc sq plain sweep4k real markers extras}"
 run_stats() {  # name, bench args
   local name=$1; shift
   rm -rf $R/gpurun_out/ps_$name
@@ -83,5 +84,10 @@ if [[ $WHAT == *sweep4k* ]]; then
 fi
 if [[ $WHAT == *real* ]]; then
   timeout 900 python3 bench.py --steps 5 --warmup 1 --real-images --no-host-leg --no-large-batch-leg 2>/dev/null | grep '^{"metric"' | tail -1 > $O/bench_real_images_f256.json
+fi
+if [[ $WHAT == *extras* ]]; then
+  # the headline batch with every kernel alone and in a row, per-round times (name@round); round 4's real-image workload (64 distinct windows)
+  PLI_SIDE_MAX=0 PLI_RX_PROFROUNDS=1 timeout 900 python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-host-leg --no-large-batch-leg 2>/dev/null | grep '^{"metric"' | tail -1 > $O/bench_default_f256_alone_per_round.json
+  timeout 900 python3 bench.py --steps 5 --warmup 1 --real-images --unique-frames 64 --no-cpu-baseline --no-host-leg --no-large-batch-leg 2>/dev/null | grep '^{"metric"' | tail -1 > $O/bench_real_images_64windows_f256.json
 fi
 ls -la $O
