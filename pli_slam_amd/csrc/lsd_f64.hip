@@ -127,23 +127,23 @@ constexpr int FT_W = 64, FT_H = 16;        // scaled pixels per tile
 constexpr int FS_W = 64, FS_H = 20;        // blurred source window (columns, rows) a tile may need
 constexpr int FR = 3;                      // largest blur radius
 
-__global__ __launch_bounds__(256) void k_lsd_front64(const uint8_t* __restrict__ pyr, int64_t pyrBlock, int sw, int sh, int pitch,
-                                                     const double* __restrict__ kern, int radius, const int* __restrict__ tab,
-                                                     int dw, int dh, double rho, float4* __restrict__ rec, double* __restrict__ mg,
-                                                     int2* __restrict__ own, unsigned long long* __restrict__ maxMg, int img0,
-                                                     int flags /* as k_lsd_grad64 */) {
+// (R > 0: the blur radius at compile time — the taps unrolled with the kernel in registers, the same products summed in the same order;
+// R = 0: any radius up to FR, the taps looped.  OpenCV's default sigma_scale 0.6 gives radius 3 for every scale >= 1.)
+template <int R>
+__device__ __forceinline__ void lsd_front64_tile(const uint8_t* __restrict__ pyr, int64_t pyrBlock, int sw, int sh, int pitch,
+                                                 const double* __restrict__ kern, int radius, const int* __restrict__ tab,
+                                                 int dw, int dh, double rho, float4* __restrict__ rec, double* __restrict__ mg,
+                                                 int2* __restrict__ own, unsigned long long* __restrict__ maxMg, int img0, int flags,
+                                                 uint8_t (*tile)[FS_W + 2 * FR + 2], double (*rows)[FS_W], double (*blur)[FS_W],
+                                                 unsigned long long* wmax) {
   const int trigF32 = flags & 1;
   const bool packW = (flags & 2) != 0;
-  __shared__ uint8_t tile[FS_H + 2 * FR][FS_W + 2 * FR + 2];
-  __shared__ double rows[FS_H + 2 * FR][FS_W];               // row-filtered window; afterwards the scaled tile (scl)
-  __shared__ double blur[FS_H][FS_W];
   static_assert((FT_H + 1) * (FT_W + 1) <= (FS_H + 2 * FR) * FS_W, "the scaled tile reuses the row buffer");
   double (*scl)[FT_W + 1] = reinterpret_cast<double (*)[FT_W + 1]>(&rows[0][0]);
-  __shared__ unsigned long long wmax[4];
   const int img = blockIdx.z + img0, tid = threadIdx.x;
   const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
   const uint8_t* src = pyr + (int64_t)img * pyrBlock;
-  const int r = radius, n = 2 * r + 1;
+  const int r = R > 0 ? R : radius, n = 2 * r + 1;
   // scaled pixels of this tile (with the +1 halo of the 2x2 gradient), and the source window they read
   const int x1 = min(x0 + FT_W, dw - 1), y1 = min(y0 + FT_H, dh - 1);          // last scaled column / row needed
   const int sx0 = tab[x0], sx1 = min(tab[x1] + 1, sw - 1);
@@ -152,9 +152,26 @@ __global__ __launch_bounds__(256) void k_lsd_front64(const uint8_t* __restrict__
   const int tw = cw + 2 * r, th = ch + 2 * r;
   // (thread = (column lx, row group ly): no division by the window width anywhere)
   const int lx = tid & 63, ly = tid >> 6;
-  for (int ty = ly; ty < th; ty += 4) {
-    const int sy = reflect101(sy0 + ty - r, sh);
-    for (int tx = lx; tx < tw; tx += 64) tile[ty][tx] = src[(int64_t)sy * pitch + reflect101(sx0 + tx - r, sw)];
+  if (R > 0 && sw > 2 * R && sh > 2 * R) {
+    // the window leaves the image by at most R < sw, sh pixels: ONE reflection, no loop — and a fixed trip count, so that the (up to
+    // 14) byte loads of a thread are in flight together
+    auto refl = [](int p, int len) { return p < 0 ? -p : (p >= len ? 2 * len - 2 - p : p); };
+    static_assert((FS_H + 2 * FR + 3) / 4 == 7 && FS_W + 2 * FR <= 128, "rows / columns a thread stages");
+    const int c0 = refl(sx0 + lx - R, sw), c1 = refl(sx0 + lx + 64 - R, sw);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int ty = ly + 4 * i;
+      if (ty < th) {
+        const uint8_t* row = src + (int64_t)refl(sy0 + ty - R, sh) * pitch;
+        if (lx < tw) tile[ty][lx] = row[c0];
+        if (lx + 64 < tw) tile[ty][lx + 64] = row[c1];
+      }
+    }
+  } else {
+    for (int ty = ly; ty < th; ty += 4) {
+      const int sy = reflect101(sy0 + ty - r, sh);
+      for (int tx = lx; tx < tw; tx += 64) tile[ty][tx] = src[(int64_t)sy * pitch + reflect101(sx0 + tx - r, sw)];
+    }
   }
   __syncthreads();
   double k[7];
@@ -163,23 +180,37 @@ __global__ __launch_bounds__(256) void k_lsd_front64(const uint8_t* __restrict__
   if (lx < cw)
     for (int ty = ly; ty < th; ty += 4) {
       double s = k[0] * (double)tile[ty][lx];
-      for (int j = 1; j < n; ++j) s += k[j] * (double)tile[ty][lx + j];
+      if (R > 0) {
+#pragma unroll
+        for (int j = 1; j < 2 * R + 1; ++j) s += k[j] * (double)tile[ty][lx + j];
+      } else {
+        for (int j = 1; j < n; ++j) s += k[j] * (double)tile[ty][lx + j];
+      }
       rows[ty][lx] = s;
     }
   __syncthreads();
   if (lx < cw)
     for (int ty = ly; ty < ch; ty += 4) {
-      double s = k[r] * rows[ty + r][lx];
-      for (int j = 1; j <= r; ++j) s += k[r + j] * (rows[ty + r + j][lx] + rows[ty + r - j][lx]);
+      double s;
+      if (R > 0) {
+        s = k[R] * rows[ty + R][lx];
+#pragma unroll
+        for (int j = 1; j <= R; ++j) s += k[R + j] * (rows[ty + R + j][lx] + rows[ty + R - j][lx]);
+      } else {
+        s = k[r] * rows[ty + r][lx];
+        for (int j = 1; j <= r; ++j) s += k[r + j] * (rows[ty + r + j][lx] + rows[ty + r - j][lx]);
+      }
       blur[ty][lx] = s;
     }
   __syncthreads();
   const int nx = x1 - x0 + 1, ny = y1 - y0 + 1;
-  for (int tx = lx; tx < nx; tx += 64) {
+  // thread = (column lx, rows ly, ly + 4, ..); the 65th column (the +1 halo of the 2x2 gradient) is spread over the first ny threads,
+  // one row each, instead of a second pass of the whole workgroup for one lane's worth of pixels
+  auto resizeCol = [&](int tx, int tyFirst, int tyStep) {
     const int dx = x0 + tx;
     const int sx = tab[dx] - sx0, sxn = min(sx + sx0 + 1, sw - 1) - sx0;
     const double a0 = (double)__int_as_float(tab[dw + 2 * dx]), a1 = (double)__int_as_float(tab[dw + 2 * dx + 1]);
-    for (int ty = ly; ty < ny; ty += 4) {
+    for (int ty = tyFirst; ty < ny; ty += tyStep) {
       const int dy = y0 + ty;
       const int sy = tab[3 * dw + dy];
       const int sya = min(max(sy, 0), sh - 1) - sy0, syb = min(max(sy + 1, 0), sh - 1) - sy0;
@@ -188,7 +219,9 @@ __global__ __launch_bounds__(256) void k_lsd_front64(const uint8_t* __restrict__
       const double t1 = blur[syb][sx] * a0 + blur[syb][sxn] * a1;
       scl[ty][tx] = t0 * b0 + t1 * b1;
     }
-  }
+  };
+  if (lx < nx) resizeCol(lx, ly, 4);
+  if (nx > FT_W && tid < ny) resizeCol(FT_W, tid, FT_H + 1);
   __syncthreads();
   unsigned long long m = 0ull;
   for (int i = tid; i < FT_W * FT_H; i += 256) {
@@ -221,6 +254,19 @@ __global__ __launch_bounds__(256) void k_lsd_front64(const uint8_t* __restrict__
     m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
     if (m) atomicMax(&maxMg[img], m);
   }
+}
+
+__global__ __launch_bounds__(256) void k_lsd_front64(const uint8_t* __restrict__ pyr, int64_t pyrBlock, int sw, int sh, int pitch,
+                                                     const double* __restrict__ kern, int radius, const int* __restrict__ tab,
+                                                     int dw, int dh, double rho, float4* __restrict__ rec, double* __restrict__ mg,
+                                                     int2* __restrict__ own, unsigned long long* __restrict__ maxMg, int img0,
+                                                     int flags /* as k_lsd_grad64 */) {
+  __shared__ uint8_t tile[FS_H + 2 * FR][FS_W + 2 * FR + 2];
+  __shared__ double rows[FS_H + 2 * FR][FS_W];               // row-filtered window; afterwards the scaled tile (scl)
+  __shared__ double blur[FS_H][FS_W];
+  __shared__ unsigned long long wmax[4];
+  if (radius == FR) lsd_front64_tile<FR>(pyr, pyrBlock, sw, sh, pitch, kern, radius, tab, dw, dh, rho, rec, mg, own, maxMg, img0, flags, tile, rows, blur, wmax);
+  else lsd_front64_tile<0>(pyr, pyrBlock, sw, sh, pitch, kern, radius, tab, dw, dh, rho, rec, mg, own, maxMg, img0, flags, tile, rows, blur, wmax);
 }
 
 }  // namespace pli

@@ -206,6 +206,8 @@ def test_tiny_budgets_and_small_images(gpu):
     dict(orb_nlevels=3, lsd_scale=1.5, lsd_sigma_scale=0.8, lsd_ang_th=30.0, lsd_mode=2, matching_s_ws=5, line_sim_th=0.6,
          best_lr_matches=0),
     dict(orb_scale_factor=2.7, orb_nlevels=3, lsd_scale=2.6),      # resize windows too wide for the LDS staging: direct path
+    dict(lsd_sigma_scale=0.4),                                     # blur radius 2: the fused front pass with looped taps
+    dict(lsd_sigma_scale=0.25, lsd_scale=1.3),                     # blur radius 1
 ])
 def test_non_default_algorithm_parameters(gpu, over):
     """The yaml-tunable parameters of both extractors and the line matcher away from their defaults
