@@ -115,6 +115,14 @@ __device__ __forceinline__ float tx_rlf(float v, int l) { return __int_as_float(
 // The bitonic network over KPT * NT keys, thread t holding the KPT consecutive keys t*KPT .. t*KPT+KPT-1 in registers (ascending
 // result): a compare distance j < KPT stays inside the thread, j < 64*KPT pairs lanes of one wave (ds_bpermute, no LDS memory, no
 // barrier), and only the stages whose partner sits in another wave go through xch (KPT * NT words of LDS).
+// (Round 5, measured at 256 frames: the kernel's 2.3 ms follow neither its VALU count — the compare-exchanges as one v_med3_u32 each
+// instead of min + max + select halve it: 2.29 -> 2.30 ms — nor the crossbar: lane exchanges by DPP row shifts and gfx950's
+// v_permlane16/32_swap instead of ds_bpermute: 8.1 ms.  Its 7.8 GB of loads and 4-byte row-tiled stores are what it waits for.)
+__device__ __forceinline__ unsigned tx_umed3(unsigned a, unsigned b, unsigned c) {      // median of three (v_med3_u32)
+  unsigned r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 template <int KPT, int NT>
 __device__ __forceinline__ void tx_bitonic_regs(unsigned (&key)[KPT], unsigned* xch, int tid) {
   constexpr int n2 = KPT * NT;
@@ -126,12 +134,13 @@ __device__ __forceinline__ void tx_bitonic_regs(unsigned (&key)[KPT], unsigned* 
         const int pt = j / KPT;                           // partner thread = tid ^ pt
         const bool asc = ((tid * KPT) & k) == 0;           // (k > j >= KPT: the direction depends on the thread only)
         const bool lower = (tid & pt) == 0;
-        const bool keepMin = lower == asc;
+        // (the smaller or the larger of two keys in ONE instruction: the median of the two and 0 resp. UINT_MAX)
+        const unsigned sel = (lower == asc) ? 0u : 0xFFFFFFFFu;
         if (pt < 64) {
 #pragma unroll
           for (int u = 0; u < KPT; ++u) {
             const unsigned o = (unsigned)__shfl_xor((int)key[u], pt, 64);
-            key[u] = keepMin ? min(key[u], o) : max(key[u], o);
+            key[u] = tx_umed3(key[u], o, sel);
           }
         } else {
           __syncthreads();
@@ -141,18 +150,17 @@ __device__ __forceinline__ void tx_bitonic_regs(unsigned (&key)[KPT], unsigned* 
 #pragma unroll
           for (int u = 0; u < KPT; ++u) {
             const unsigned o = xch[u * NT + (tid ^ pt)];
-            key[u] = keepMin ? min(key[u], o) : max(key[u], o);
+            key[u] = tx_umed3(key[u], o, sel);
           }
         }
       } else {
 #pragma unroll
         for (int u = 0; u < KPT; ++u) {
           if ((u & j) == 0) {
-            const bool asc = ((tid * KPT + u) & k) == 0;
+            const unsigned sel = (((tid * KPT + u) & k) == 0) ? 0u : 0xFFFFFFFFu;      // ascending: the smaller key first
             const unsigned a = key[u], b = key[u | j];
-            const bool sw = (a > b) == asc;
-            key[u] = sw ? b : a;
-            key[u | j] = sw ? a : b;
+            key[u] = tx_umed3(a, b, sel);
+            key[u | j] = tx_umed3(a, b, ~sel);
           }
         }
       }
@@ -178,6 +186,7 @@ __device__ __forceinline__ void tx_sort_tile(const int* __restrict__ rankAll, co
   // (padded by one word per 16: the strided side of the transposition is bank-conflict free)
   auto pad = [](int i) -> int { return i + (i >> 4); };
   int valid = 0;
+  const double binCoef = keys.mg ? lsd_bin_coef64(keys.maxMg[img], keys.nBins) : 0.0;     // (one division per thread, not one per pixel)
 #pragma unroll
   for (int m = 0; m < KPT; ++m) {
     const int i = m * NT + tid;
@@ -189,7 +198,7 @@ __device__ __forceinline__ void tx_sort_tile(const int* __restrict__ rankAll, co
         const double v = keys.mg[img * npix + y * W + x];
         r = TX_INF;
         if (!(v <= keys.rho))
-          r = ((keys.nBins - 1 - lsd_bin64(v, lsd_bin_coef64(keys.maxMg[img], keys.nBins), keys.nBins)) << keys.pixbits) | (y * W + x);
+          r = ((keys.nBins - 1 - lsd_bin64(v, binCoef, keys.nBins)) << keys.pixbits) | (y * W + x);
         keys.idPlane[img * npix + y * W + x] = r;
       } else {
         r = rank[y * W + x];
