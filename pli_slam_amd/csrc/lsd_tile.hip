@@ -187,6 +187,26 @@ __device__ __forceinline__ void tx_sort_tile(const int* __restrict__ rankAll, co
   auto pad = [](int i) -> int { return i + (i >> 4); };
   int valid = 0;
   const double binCoef = keys.mg ? lsd_bin_coef64(keys.maxMg[img], keys.nBins) : 0.0;     // (one division per thread, not one per pixel)
+  // (all loads of the thread first — the stores below may alias them for all the compiler knows, and a load that waits for the
+  // previous pixel's stores made this phase KPT dependent round trips)
+  double vIn[KPT];
+  int rIn[KPT];
+  // (unconditional, from clamped coordinates: a load under a lane predicate is waited for at the end of its branch)
+  if (keys.mg) {
+#pragma unroll
+    for (int m = 0; m < KPT; ++m) {
+      const int i = m * NT + tid;
+      vIn[m] = keys.mg[img * npix + min(ty0 + i / ts, H - 1) * W + min(tx0 + i % ts, W - 1)];
+      rIn[m] = TX_INF;
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < KPT; ++m) {
+      const int i = m * NT + tid;
+      rIn[m] = rank[min(ty0 + i / ts, H - 1) * W + min(tx0 + i % ts, W - 1)];
+      vIn[m] = 0.0;
+    }
+  }
 #pragma unroll
   for (int m = 0; m < KPT; ++m) {
     const int i = m * NT + tid;
@@ -195,13 +215,13 @@ __device__ __forceinline__ void tx_sort_tile(const int* __restrict__ rankAll, co
     if (x < W && y < H) {
       int r;
       if (keys.mg) {
-        const double v = keys.mg[img * npix + y * W + x];
+        const double v = vIn[m];
         r = TX_INF;
         if (!(v <= keys.rho))
           r = ((keys.nBins - 1 - lsd_bin64(v, binCoef, keys.nBins)) << keys.pixbits) | (y * W + x);
         keys.idPlane[img * npix + y * W + x] = r;
       } else {
-        r = rank[y * W + x];
+        r = rIn[m];
       }
       // owner_0 = the trivial map, written for EVERY pixel of the tile (an undefined pixel is nobody's: INT_MAX in both components):
       // the front pass does not initialise the plane for this schedule.  Packed round 1: owner_1's start value into the pixel
@@ -382,23 +402,33 @@ __device__ __forceinline__ void tx_round2_block(RxCtl* __restrict__ ctl, int2* _
     if (PACKED) ow[i].y = r[i] == TX_INF ? INT_MAX : (ow[i].y < 0 ? r[i] : ow[i].y);
     o[i] = ci ? ow[i].x : ow[i].y;                     // owner_{t-1}
   }
+  // (the gathers of the four rows unconditional, from an index that is valid either way — slot 0 for a pixel without an owner —, so
+  // that they are in flight together: a load under a lane predicate is waited for at the end of its branch)
+  if (DL.rmask != -1) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    sp[i] = -1; lost[i] = 0;
-    if (o[i] != INT_MAX) {
-      sp[i] = DL.rmask != -1 ? (o[i] & DL.rmask) : orderAll[base + o[i]];
-      lost[i] = rgLostAll[base + (o[i] & DL.rmask)];
+    for (int i = 0; i < 4; ++i) {
+      sp[i] = o[i] != INT_MAX ? (o[i] & DL.rmask) : -1;
+      lost[i] = rgLostAll[base + max(sp[i], 0)];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      sp[i] = -1; lost[i] = 0;
+      if (o[i] != INT_MAX) {
+        sp[i] = orderAll[base + o[i]];
+        lost[i] = rgLostAll[base + (o[i] & DL.rmask)];
+      }
     }
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    so[i] = make_int2(0, 0);
-    if (sp[i] >= 0) {
-      if (PACKED) {                                    // (sp is o's seed pixel: unclaimed means o holds it)
-        so[i].y = *tx_rec_owner(recPack + base + sp[i]);
-        if (so[i].y < 0) so[i].y = o[i];
-      } else so[i] = ownAll[base + sp[i]];
-    }
+    if (PACKED) so[i] = make_int2(0, *tx_rec_owner(recPack + base + max(sp[i], 0)));
+    else so[i] = ownAll[base + max(sp[i], 0)];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (sp[i] < 0) { so[i] = make_int2(0, 0); lost[i] = 0; }
+    else if (PACKED && so[i].y < 0) so[i].y = o[i];    // (sp is o's seed pixel: unclaimed means o holds it)
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
