@@ -28,10 +28,12 @@ namespace pli_frame {
 // (the reference reads the same object: `mpORBextractorLeft->mvImagePyramid[0].rows`, Frame.cc:983).
 template <class FrameT>
 inline std::shared_ptr<pli::Frontend> contextOf(FrameT& F) {
-  if (!F.mpORBextractorLeft || F.mpORBextractorLeft->mvImagePyramid.empty() || F.mpORBextractorLeft->mvImagePyramid[0].empty())
+  // (with ORBextractor::pliCopyPyramidBack(false) the member stays empty: the extractor remembers the size of its last image)
+  int w = 0, h = 0;
+  if (F.mpORBextractorLeft) F.mpORBextractorLeft->pliLastImageSize(w, h);
+  if (!F.mpORBextractorLeft || w <= 0 || h <= 0)
     throw std::logic_error("pli_frame: the left ORB extractor has not run (Frame.cc:128-135 comes first)");
-  const cv::Mat& im0 = F.mpORBextractorLeft->mvImagePyramid[0];
-  return F.mpORBextractorLeft->pliContext(im0.cols, im0.rows);
+  return F.mpORBextractorLeft->pliContext(w, h);
 }
 
 inline void checkCount(const char* what, long frameSide, int deviceSide) {

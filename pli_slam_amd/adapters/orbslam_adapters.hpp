@@ -312,6 +312,7 @@ class ORBextractor {
     cv::Mat image = _image.getMat();
     pli_detail::checkGray(image, "ORBextractor");
     std::shared_ptr<pli::Frontend> fe = group_->context(image.cols, image.rows);
+    lastW_ = image.cols; lastH_ = image.rows;
     std::vector<pli_keypoint> kps;
     std::vector<uint8_t> desc;
     int n;
@@ -352,15 +353,23 @@ class ORBextractor {
       _keypoints[j] = cv::KeyPoint(k.x, k.y, k.size, k.angle, k.response, k.octave, -1);
       std::memcpy(D.ptr(j), desc.data() + (size_t)order[j] * 32, 32);
     }
-    // public member the stereo matcher and drawers read (ORBextractor.h:87); levels come back without the border
-    for (int l = 0; l < nlevels; ++l) {
-      int w = 0, h = 0;
-      pli::check(pli_orb_pyramid_level(fe->handle(), eye_, l, nullptr, 0, &w, &h));
-      mvImagePyramid[l].create(h, w, CV_8U);
-      pli::check(pli_orb_pyramid_level(fe->handle(), eye_, l, mvImagePyramid[l].data, (int64_t)w * h, &w, &h));
+    // public member the stereo matcher and drawers read (ORBextractor.h:87); levels come back without the border.  An integrator
+    // that uses adapters/frame_stereo.hpp (the stereo matchers run on the device, on the resident pyramids) and no drawer of the
+    // pyramid can switch the copy off — pliCopyPyramidBack(false): 1.3 MB per eye and Frame stay on the device, the member is left empty
+    if (pliPyramidFlag().load(std::memory_order_relaxed)) {
+      for (int l = 0; l < nlevels; ++l) {
+        int w = 0, h = 0;
+        pli::check(pli_orb_pyramid_level(fe->handle(), eye_, l, nullptr, 0, &w, &h));
+        mvImagePyramid[l].create(h, w, CV_8U);
+        pli::check(pli_orb_pyramid_level(fe->handle(), eye_, l, mvImagePyramid[l].data, (int64_t)w * h, &w, &h));
+      }
+    } else {
+      for (int l = 0; l < nlevels; ++l) mvImagePyramid[l].release();
     }
     return mono;
   }
+  // (not in the reference) whether operator() fills mvImagePyramid (default: yes, as the reference's ComputePyramid does); process-wide
+  static void pliCopyPyramidBack(bool on) { pliPyramidFlag().store(on, std::memory_order_relaxed); }
 
   int inline GetLevels() { return nlevels; }
   float inline GetScaleFactor() { return scaleFactor; }
@@ -374,6 +383,8 @@ class ORBextractor {
   // (not in the reference) the shared device context for an image size: Frame's stereo matchers run on it
   std::shared_ptr<pli::Frontend> pliContext(int w, int h) { return group_->context(w, h); }
   int pliEye() const { return eye_; }
+  // (not in the reference) size of the image of the last operator() call (0 x 0 before the first): what mvImagePyramid[0] says when it is copied back
+  void pliLastImageSize(int& w, int& h) const { w = lastW_; h = lastH_; }
   // (not in the reference) the rig of the Frames this extractor serves: mbf and fx (Frame.cc:1005-1008).  Frame::ComputeStereoMatches
   // (adapters/frame_stereo.hpp) calls it for every Frame; an integrator may call it once after reading the calibration
   // (Tracking.cc:620-640) so that even the first fused Frame is matched with the right rig in its one submission.
@@ -382,6 +393,8 @@ class ORBextractor {
   pli_detail::FrameFusion::Stats pliFusionStats() { return group_->fusion.stats(); }
 
  protected:
+  static std::atomic<bool>& pliPyramidFlag() { static std::atomic<bool> on{true}; return on; }
+  int lastW_ = 0, lastH_ = 0;
   int nfeatures;
   double scaleFactor;
   int nlevels, iniThFAST, minThFAST;

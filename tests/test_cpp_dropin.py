@@ -367,3 +367,25 @@ def test_line_extractors_on_other_images_are_not_fused(runs):
             same(res[k], t[k], "line extractors on copies: " + k)
     fused, alone, timeouts, mismatched, sleeps, missed = (int(v) for v in res["fusion_stats"][0])
     assert fused == 0 and mismatched + timeouts > 0, res["fusion_stats"]
+
+
+@pytest.mark.gpu
+def test_pyramid_copy_back_can_be_switched_off(runs):
+    """An integrator that runs the stereo matchers through adapters/frame_stereo.hpp (on the device, on the resident pyramids) does
+    not need ORBextractor::mvImagePyramid on the host: pliCopyPyramidBack(false) leaves the member empty and every other container
+    of the Frame as it was."""
+    frames = runs["frames"][:6]
+    res = run_harness(runs["exe"], runs["dir"], "nopyr", frames, 1, 4)
+    t = runs["threads"]
+    seen = 0
+    for k in res:
+        if not (k.startswith("f") and "/" in k):
+            continue
+        if "pyrL" in k:
+            assert res[k].size == 0, "the pyramid member must be left empty: " + k
+            seen += 1
+        else:
+            same(res[k], t[k], "pyramid not copied back: " + k)
+    assert seen >= len(frames)
+    fused = int(res["fusion_stats"][0][0])
+    assert fused >= len(frames) - 1, res["fusion_stats"]
