@@ -110,22 +110,26 @@ __global__ __launch_bounds__(256) void k_lsd_hist(const int* __restrict__ g2a, i
   if (mgAll) {                                          // CV_64F pipeline
     const double bc = lsd_bin_coef64(maxMg[img], nBins);
     const double* g = mgAll + (int64_t)img * npix;
+    // (the thread's loads unconditional, from a clamped index, and all of them before the first use: a load under a lane predicate is
+    // waited for at the end of its branch — sixteen round trips one after the other)
+    double v[LSD_CHUNK / 256];
+#pragma unroll
+    for (int k = 0; k < LSD_CHUNK / 256; ++k) v[k] = g[min(chunk * LSD_CHUNK + k * 256 + tid, npix - 1)];
+#pragma unroll
     for (int k = 0; k < LSD_CHUNK / 256; ++k) {
-      int i = chunk * LSD_CHUNK + k * 256 + tid;
-      if (i < npix) {
-        const double v = g[i];
-        if (!(v <= rho)) atomicAdd(&h[lsd_bin64(v, bc, nBins)], 1);
-      }
+      const int i = chunk * LSD_CHUNK + k * 256 + tid;
+      if (i < npix && !(v[k] <= rho)) atomicAdd(&h[lsd_bin64(v[k], bc, nBins)], 1);
     }
   } else {
     const double bc = lsd_bin_coef(maxG2[img], nBins);
     const int* g = g2a + (int64_t)img * npix;
+    int v[LSD_CHUNK / 256];
+#pragma unroll
+    for (int k = 0; k < LSD_CHUNK / 256; ++k) v[k] = g[min(chunk * LSD_CHUNK + k * 256 + tid, npix - 1)];
+#pragma unroll
     for (int k = 0; k < LSD_CHUNK / 256; ++k) {
-      int i = chunk * LSD_CHUNK + k * 256 + tid;
-      if (i < npix) {
-        int v = g[i];
-        if (v > g2Thresh) atomicAdd(&h[lsd_bin(v, bc)], 1);
-      }
+      const int i = chunk * LSD_CHUNK + k * 256 + tid;
+      if (i < npix && v[k] > g2Thresh) atomicAdd(&h[lsd_bin(v[k], bc)], 1);
     }
   }
   __syncthreads();
@@ -256,15 +260,26 @@ __global__ __launch_bounds__(64) void k_lsd_scatter(const int* __restrict__ g2a,
   for (int it0 = 0; it0 < LSD_CHUNK / 64; it0 += GRP) {
     if (chunk * LSD_CHUNK + it0 * 64 >= npix) break;
     int vals[GRP];                               // the bin of the pixel, -1 = not defined
+    // (unconditional loads from a clamped index, all before the first use: under the lane predicate i < npix each load was waited for
+    // at the end of its branch, and the group's loads were NOT in flight together)
+    if (f64) {
+      double vv[GRP];
 #pragma unroll
-    for (int u = 0; u < GRP; ++u) {
-      const int i = chunk * LSD_CHUNK + (it0 + u) * 64 + lane;
-      int b = -1;
-      if (i < npix) {
-        if (f64) { const double v = gd[i]; if (!(v <= rho)) b = lsd_bin64(v, bc, nBins); }
-        else { const int v = g[i]; if (v > g2Thresh) b = lsd_bin(v, bc); }
+      for (int u = 0; u < GRP; ++u) vv[u] = gd[min(chunk * LSD_CHUNK + (it0 + u) * 64 + lane, npix - 1)];
+#pragma unroll
+      for (int u = 0; u < GRP; ++u) {
+        const int i = chunk * LSD_CHUNK + (it0 + u) * 64 + lane;
+        vals[u] = (i < npix && !(vv[u] <= rho)) ? lsd_bin64(vv[u], bc, nBins) : -1;
       }
-      vals[u] = b;
+    } else {
+      int vv[GRP];
+#pragma unroll
+      for (int u = 0; u < GRP; ++u) vv[u] = g[min(chunk * LSD_CHUNK + (it0 + u) * 64 + lane, npix - 1)];
+#pragma unroll
+      for (int u = 0; u < GRP; ++u) {
+        const int i = chunk * LSD_CHUNK + (it0 + u) * 64 + lane;
+        vals[u] = (i < npix && vv[u] > g2Thresh) ? lsd_bin(vv[u], bc) : -1;
+      }
     }
 #pragma unroll
     for (int u = 0; u < GRP; ++u) {

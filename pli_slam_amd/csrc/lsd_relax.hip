@@ -845,11 +845,12 @@ __global__ __launch_bounds__(64) void k_rx_rect(const DevParams* __restrict__ Pp
 // ---- segments in seed-rank order (= detection order of the sequential algorithm) ------------------------
 constexpr int RX_CCHUNK = 2048;   // ranks per block
 
-__device__ __forceinline__ bool rx_emits(const int* order, const int2* own, const int* rgSize, int i, int n, int minReg) {
+// (the size first: it is read in rank order — by the callers, for all the ranks of a thread at once and from a clamped index: a load
+// under the lane predicate i < n is waited for at the end of its branch —, and only the ~1.5 % of the ranks whose region is large
+// enough go on to the two dependent gathers)
+__device__ __forceinline__ bool rx_emits(const int* order, const int2* own, int size, int i, int n, int minReg) {
   if (i >= n) return false;
-  // (the size first: it is read in rank order, and only the ~1.5 % of the ranks whose region is large enough go on to the
-  // two dependent gathers)
-  return rgSize[i] >= minReg && own[order[i]].x == i;
+  return size >= minReg && own[order[i]].x == i;
 }
 
 __global__ __launch_bounds__(256) void k_rx_count(const RxCtl* __restrict__ ctl, const int* __restrict__ orderAll,
@@ -862,9 +863,12 @@ __global__ __launch_bounds__(256) void k_rx_count(const RxCtl* __restrict__ ctl,
   const int n = nDefined[img];
   const int tid = threadIdx.x;
   int cntv = 0;
+  int sz[RX_CCHUNK / 256];
+#pragma unroll
+  for (int j = 0; j < RX_CCHUNK / 256; ++j) sz[j] = rgSizeAll[img * npix + min((int)blockIdx.x * RX_CCHUNK + j * 256 + tid, max(n - 1, 0))];
+#pragma unroll
   for (int j = 0; j < RX_CCHUNK / 256; ++j)
-    cntv += rx_emits(orderAll + img * npix, ownAll + img * npix, rgSizeAll + img * npix,
-                     blockIdx.x * RX_CCHUNK + j * 256 + tid, n, minReg) ? 1 : 0;
+    cntv += rx_emits(orderAll + img * npix, ownAll + img * npix, sz[j], blockIdx.x * RX_CCHUNK + j * 256 + tid, n, minReg) ? 1 : 0;
   cntv = wave_sum_i32(cntv);
   if ((tid & 63) == 0) wsum[tid >> 6] = cntv;
   __syncthreads();
@@ -893,9 +897,13 @@ __global__ __launch_bounds__(256) void k_rx_emit(const RxCtl* __restrict__ ctl, 
   __syncthreads();
   int base = sbase;
   float* seg = segAll + (int64_t)img * maxSeg * 4;
+  int sz[RX_CCHUNK / 256];
+#pragma unroll
+  for (int j = 0; j < RX_CCHUNK / 256; ++j) sz[j] = rgSizeAll[img * npix + min((int)blockIdx.x * RX_CCHUNK + j * 256 + tid, max(n - 1, 0))];
+#pragma unroll
   for (int j = 0; j < RX_CCHUNK / 256; ++j) {
     const int i = blockIdx.x * RX_CCHUNK + j * 256 + tid;
-    const bool e = rx_emits(orderAll + img * npix, ownAll + img * npix, rgSizeAll + img * npix, i, n, minReg);
+    const bool e = rx_emits(orderAll + img * npix, ownAll + img * npix, sz[j], i, n, minReg);
     const unsigned long long bal = __builtin_amdgcn_ballot_w64(e);
     __syncthreads();
     if (lane == 0) wsum[wv] = __popcll(bal);
