@@ -342,9 +342,17 @@ pli_status pli_match_lines(pli_ctx* ctx, const uint8_t* desc1, int32_t n1,
  * :2259-2265).  Queries with valid == 0 (no map point / outlier / behind the
  * camera) are skipped.  The current frame is described by its keypoints, descriptors,
  * mvuRight and the image bounds used by the 64x48 grid (mnMinX..mnMaxY).
- * Reproduces the sequential "already assigned" exclusion, TH_HIGH = 100, the
- * 30-bin rotation histogram and ComputeThreeMaxima (:2449-2490).
- * best_idx2[i] = matched current keypoint or -1.  *nmatches as the reference. */
+ * "Not available" is the reference's test :2255-2257 — CurrentFrame.mvpMapPoints[i2] is set AND has
+ * Observations() > 0 — in both of its uses: cur_occupied[i2] != 0 (may be NULL) marks the keypoints that hold
+ * such a map point BEFORE the call, and a match made in this call takes its keypoint away from the queries
+ * behind it unless the query says its own map point has no observations (valid = 1 | PLI_PROJ_NO_OBSERVATIONS:
+ * the temporal points Tracking::UpdateLastFrame creates in localisation mode; such a keypoint can be matched
+ * again and the last writer holds it).  TH_HIGH = 100, the 30-bin rotation histogram and
+ * ComputeThreeMaxima (:2449-2490) run on the device.
+ * best_idx2[i] = matched current keypoint or -1 after the rotation filter; raw_idx2 (may be NULL) = the same
+ * before it (a maintainer replays :2280-2282 from raw_idx2 in query order and :2315-2317 for the queries with
+ * raw_idx2[i] >= 0 > best_idx2[i], as the adapter does).  *nmatches as the reference. */
+#define PLI_PROJ_NO_OBSERVATIONS 2
 typedef struct pli_proj_query {
   float u, v, radius, ur;
   int32_t min_level, max_level;
@@ -354,10 +362,10 @@ typedef struct pli_proj_query {
 pli_status pli_search_by_projection(pli_ctx* ctx,
                                     const pli_proj_query* q, const uint8_t* qdesc, int32_t nq,
                                     const pli_keypoint* cur_kp, const uint8_t* cur_desc,
-                                    const float* cur_uright, int32_t ncur,
+                                    const float* cur_uright, const uint8_t* cur_occupied, int32_t ncur,
                                     float min_x, float max_x, float min_y, float max_y,
                                     int32_t check_orientation,
-                                    int32_t* best_idx2, int32_t* nmatches);
+                                    int32_t* best_idx2, int32_t* raw_idx2, int32_t* nmatches);
 
 /* --- Frame-to-frame track matching of a batch (BASELINE config 3), on the device tables of pli_batch_run ---
  * Frame i (i >= 1) of the batch against frame i-1, as Tracking::TrackWithMotionModel does per frame:

@@ -408,7 +408,11 @@ static inline int matchLines(const uint8_t* d1, int n1, const uint8_t* d2, int n
 static inline int searchByProjection(const pli_proj_query* q, const uint8_t* qdesc, int nq,
                                      const pli_keypoint* kp, const uint8_t* desc, const float* uright, int ncur,
                                      float mnMinX, float mnMaxX, float mnMinY, float mnMaxY, bool checkOri,
-                                     std::vector<int>& best_idx2) {
+                                     std::vector<int>& best_idx2, const uint8_t* occupied = nullptr,
+                                     std::vector<int>* raw_idx2 = nullptr) {
+  // occupied[i2]: CurrentFrame.mvpMapPoints[i2] holds a map point with Observations() > 0 before the call (:2255-2257);
+  // q[i].valid bit 1 (PLI_PROJ_NO_OBSERVATIONS): LastFrame's map point i has no observations, so the keypoint it is written to
+  // (:2280) stays available to the queries behind it.  best_idx2 = the matches after the rotation filter, raw_idx2 before it.
   const int COLS = 64, ROWS = 48, HISTO_LENGTH = 30, TH_HIGH = 100;
   best_idx2.assign(nq, -1);
   const float gwInv = static_cast<float>(COLS) / (mnMaxX - mnMinX);
@@ -422,9 +426,10 @@ static inline int searchByProjection(const pli_proj_query* q, const uint8_t* qde
     grid[(size_t)px * ROWS + py].push_back(i);
   }
   std::vector<char> assigned(ncur, 0);
-  std::vector<int> owner(ncur, -1);
+  if (occupied)
+    for (int i = 0; i < ncur; ++i) assigned[i] = occupied[i] != 0;
   int nmatches = 0;
-  std::vector<int> rotHist[30];
+  std::vector<int> rotHist[30];      // (the QUERY of every histogram entry: its keypoint is best_idx2[query])
   const float factor = 1.0f / HISTO_LENGTH;
   for (int i = 0; i < nq; ++i) {
     if (!q[i].valid) continue;
@@ -464,18 +469,19 @@ static inline int searchByProjection(const pli_proj_query* q, const uint8_t* qde
         }
       }
     if (bestIdx2 >= 0 && bestDist <= TH_HIGH) {
-      assigned[bestIdx2] = 1;
-      owner[bestIdx2] = i;
+      if (!(q[i].valid & 2)) assigned[bestIdx2] = 1;    // CurrentFrame.mvpMapPoints[bestIdx2] = pMP: not available while pMP has observations
+      best_idx2[i] = bestIdx2;
       nmatches++;
       if (checkOri) {
         float rot = q[i].angle - kp[bestIdx2].angle;
         if (rot < 0.0) rot += 360.0f;
         int bin = (int)std::round(rot * factor);
         if (bin == HISTO_LENGTH) bin = 0;
-        rotHist[bin].push_back(bestIdx2);
+        rotHist[bin].push_back(i);
       }
     }
   }
+  if (raw_idx2) *raw_idx2 = best_idx2;
   if (checkOri) {
     // ComputeThreeMaxima, ORBmatcher.cc:2449-2490
     int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
@@ -489,10 +495,8 @@ static inline int searchByProjection(const pli_proj_query* q, const uint8_t* qde
     else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
     for (int i = 0; i < HISTO_LENGTH; i++)
       if (i != ind1 && i != ind2 && i != ind3)
-        for (int idx2 : rotHist[i]) { owner[idx2] = -1; nmatches--; }
+        for (int iq : rotHist[i]) { best_idx2[iq] = -1; nmatches--; }
   }
-  for (int i2 = 0; i2 < ncur; ++i2)
-    if (owner[i2] >= 0) best_idx2[owner[i2]] = i2;
   return nmatches;
 }
 

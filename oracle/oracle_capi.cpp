@@ -247,10 +247,11 @@ int orc_match_lines(const uint8_t* d1, int n1, const uint8_t* d2, int n2, float 
 }
 int orc_search_by_projection(const pli_proj_query* q, const uint8_t* qdesc, int nq, const pli_keypoint* kp,
                              const uint8_t* desc, const float* uright, int ncur, float minx, float maxx, float miny,
-                             float maxy, int checkOri, int* best_idx2) {
-  std::vector<int> B;
-  int r = searchByProjection(q, qdesc, nq, kp, desc, uright, ncur, minx, maxx, miny, maxy, checkOri != 0, B);
+                             float maxy, int checkOri, int* best_idx2, const uint8_t* occupied, int* raw_idx2) {
+  std::vector<int> B, Raw;
+  int r = searchByProjection(q, qdesc, nq, kp, desc, uright, ncur, minx, maxx, miny, maxy, checkOri != 0, B, occupied, &Raw);
   std::memcpy(best_idx2, B.data(), B.size() * 4);
+  if (raw_idx2) std::memcpy(raw_idx2, Raw.data(), Raw.size() * 4);
   return r;
 }
 void orc_track_queries(const pli_keypoint* lastKp, const float* lastDepth, int n, const float* Tlw, const float* Tcw, float fx,

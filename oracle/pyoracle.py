@@ -303,17 +303,19 @@ def match_lines(d1, d2, nnr, best_lr=True):
     return n, m
 
 
-def search_by_projection(q, qdesc, kp, desc, uright, bounds, check_ori=True):
+def search_by_projection(q, qdesc, kp, desc, uright, bounds, check_ori=True, occupied=None, with_raw=False):
     q = np.ascontiguousarray(q, PROJ_QUERY_DT)
     qdesc = np.ascontiguousarray(qdesc, np.uint8)
     kp = np.ascontiguousarray(kp, KEYPOINT_DT)
     desc = np.ascontiguousarray(desc, np.uint8)
     uright = np.ascontiguousarray(uright, np.float32)
     best = np.full(q.shape[0], -1, np.int32)
+    raw = np.full(q.shape[0], -1, np.int32)
+    oc = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
     n = lib().orc_search_by_projection(_p(q), _p(qdesc), q.shape[0], _p(kp), _p(desc), _p(uright), kp.shape[0],
                                        C.c_float(bounds[0]), C.c_float(bounds[1]), C.c_float(bounds[2]),
-                                       C.c_float(bounds[3]), int(check_ori), _p(best))
-    return n, best
+                                       C.c_float(bounds[3]), int(check_ori), _p(best), None if oc is None else _p(oc), _p(raw))
+    return (n, best, raw) if with_raw else (n, best)
 
 
 def track_queries(last_kp, last_depth, Tlw, Tcw, fx, fy, cx, cy, bf, th, mono, scale_factors):

@@ -569,13 +569,14 @@ class PliORBmatcher {
       else { Q.min_level = nLastOctave - 1; Q.max_level = nLastOctave + 1; }
       Q.ur = Q.u - CurrentFrame.mbf * invzc;
       Q.angle = LastFrame.mvKeysUn[i].angle;
-      Q.valid = 1;                                      // (the image-bounds test :2225-2228 is done by the library)
+      // (the image-bounds test :2225-2228 is done by the library; a map point without observations — UpdateLastFrame's temporal points in
+      // localisation mode — does not make the keypoint it is written to unavailable to the queries behind it, :2255-2257)
+      Q.valid = pMP->Observations() > 0 ? 1 : (1 | PLI_PROJ_NO_OBSERVATIONS);
       const cv::Mat dMP = pMP->GetDescriptor();
       std::memcpy(&qdesc[(size_t)i * 32], dMP.ptr<uint8_t>(), 32);
     }
     // the current frame: keypoints, descriptors, mvuRight; keypoints that already hold a map point with observations are
-    // not available (:2259-2261) — they are handed over as valid = 0 queries cannot express that, so their uRight gate is
-    // left alone and they are removed from the candidate set by marking them taken beforehand
+    // not available (:2255-2257): handed over as the `cur_occupied` mask
     const int M = CurrentFrame.N;
     std::vector<pli_keypoint> kp((size_t)M);
     for (int j = 0; j < M; ++j) {
@@ -588,16 +589,21 @@ class PliORBmatcher {
       if (CurrentFrame.mvpMapPoints[j] && CurrentFrame.mvpMapPoints[j]->Observations() > 0) { occupied[j] = 1; anyOccupied = true; }
     std::shared_ptr<pli::Frontend> fe = pli_detail::Registry::get().any();
     if (!fe) throw std::logic_error("SearchByProjection: no extractor has run yet (no device context)");
-    std::vector<int> best;
-    if (anyOccupied) throw std::logic_error("SearchByProjection(F, F): current keypoints with observed map points are not supported "
-                                            "(TrackWithMotionModel clears mvpMapPoints before the call, Tracking.cc:2717)");
+    std::vector<int> best, raw;
     const int nmatches = fe->searchByProjection(q, qdesc.data(), kp, CurrentFrame.mDescriptors.data, CurrentFrame.mvuRight.data(),
                                                 CurrentFrame.mnMinX, CurrentFrame.mnMaxX, CurrentFrame.mnMinY, CurrentFrame.mnMaxY,
-                                                mbCheckOrientation, best);
+                                                mbCheckOrientation, best, anyOccupied ? occupied.data() : nullptr, &raw);
+    // the reference's writes, replayed in its order: every match as it was made (:2280-2282: the last writer holds the keypoint,
+    // std::map::insert keeps the first pair of a key), then the rotation filter's removals (:2315-2317)
     for (int i = 0; i < N; ++i)
-      if (best[i] >= 0) {
-        CurrentFrame.mvpMapPoints[best[i]] = LastFrame.mvpMapPoints[i];
-        match12.insert(std::pair<int, int>(best[i], i));
+      if (raw[i] >= 0) {
+        CurrentFrame.mvpMapPoints[raw[i]] = LastFrame.mvpMapPoints[i];
+        match12.insert(std::pair<int, int>(raw[i], i));
+      }
+    for (int i = 0; i < N; ++i)
+      if (raw[i] >= 0 && best[i] < 0) {
+        CurrentFrame.mvpMapPoints[raw[i]] = static_cast<MapPointT*>(nullptr);
+        match12.erase(raw[i]);
       }
     return nmatches;
   }

@@ -117,11 +117,14 @@ class Frontend {
   // core of ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, ...)
   int searchByProjection(const std::vector<pli_proj_query>& q, const uint8_t* qdesc, const std::vector<pli_keypoint>& cur,
                          const uint8_t* curDesc, const float* curURight, float minX, float maxX, float minY, float maxY,
-                         bool checkOrientation, std::vector<int>& bestIdx2) {
+                         bool checkOrientation, std::vector<int>& bestIdx2, const uint8_t* curOccupied = nullptr,
+                         std::vector<int>* rawIdx2 = nullptr) {
     bestIdx2.assign(q.size(), -1);
+    if (rawIdx2) rawIdx2->assign(q.size(), -1);
     int32_t n = 0;
-    check(pli_search_by_projection(ctx_, q.data(), qdesc, (int)q.size(), cur.data(), curDesc, curURight, (int)cur.size(),
-                                   minX, maxX, minY, maxY, checkOrientation ? 1 : 0, bestIdx2.data(), &n));
+    check(pli_search_by_projection(ctx_, q.data(), qdesc, (int)q.size(), cur.data(), curDesc, curURight, curOccupied, (int)cur.size(),
+                                   minX, maxX, minY, maxY, checkOrientation ? 1 : 0, bestIdx2.data(),
+                                   rawIdx2 ? rawIdx2->data() : nullptr, &n));
     return n;
   }
   // Frame::ComputeStereoFromRGBD(imDepth) Frame.cc:1309 (depth: CV_32F, row stride in floats)

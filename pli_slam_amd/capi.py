@@ -131,8 +131,8 @@ _PROTOS = {
     "pli_match_lines": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_void_p,
                                     C.POINTER(C.c_int32)]),
     "pli_search_by_projection": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
-                                             C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
-                                             C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]),
+                                             C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
+                                             C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "pli_search_local_map": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
                                          C.c_float, C.c_void_p, C.POINTER(C.c_int32)]),

@@ -140,6 +140,7 @@ struct TxKeys {
   int* zeroA = nullptr;             // planes of one word per pixel index that the sort clears on its way (rgDirty, rgLost), or null
   int* zeroB = nullptr;
   int lazyMargin = 8;               // LAZY ids: units of the 2^-22 fixed point around a bin boundary that the double plane decides (>= 4; test switch)
+  int2* hot = nullptr;              // round 6: round 1's words live in 8-byte hot records {angle, owner word} instead (lsd_tile.hip "HOT RECORDS")
   int pack = 0;                     // 0: owner plane; 1: k_tx_sort writes the unclaimed words (ids); 2: the front pass wrote them (LAZY ids)
 };
 

@@ -90,6 +90,19 @@ __device__ __forceinline__ float4 tx_load_rec16(const float4* p) {
   return make_float4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ int* tx_rec_owner(const float4* p) { return reinterpret_cast<int*>(const_cast<float4*>(p)) + 3; }
+// HOT RECORDS (round 6).  The 16-byte record puts 8 pixels on a 128-byte line; what a round-1 test needs of a neighbour is its level-line
+// angle and its owner word.  With keys.hot set the front pass writes those two words to a plane of their own (8 bytes per pixel, 16
+// pixels per line: half the footprint of a tile wave's working set), round 1 gathers and claims there, and cos / sin of a candidate
+// come from the angle (v_cos_f32 / v_sin_f32) for the vector filter — the exact values of the 16-byte record are summed only where
+// the reference's own expression needs them (see growRegion: foldExact).
+typedef int tx_v2i __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int2 tx_load_hot8(const int2* p) {
+  tx_v2i v;
+  asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return make_int2(v.x, v.y);
+}
+__device__ __forceinline__ float tx_hw_cos_deg(float a) { return __builtin_amdgcn_cosf(a * (1.f / 360.f)); }
+__device__ __forceinline__ float tx_hw_sin_deg(float a) { return __builtin_amdgcn_sinf(a * (1.f / 360.f)); }
 __device__ __forceinline__ int tx_lds_read(const int* p) {
   typedef __attribute__((address_space(3))) const volatile int lds_cvint;
   return *(lds_cvint*)p;
@@ -231,7 +244,10 @@ __device__ __forceinline__ void tx_sort_tile(const int* __restrict__ rankAll, co
       if (keys.zeroA) keys.zeroA[img * npix + y * W + x] = 0;
       if (keys.zeroB) keys.zeroB[img * npix + y * W + x] = 0;
       if (keys.pack == 1) {
-        if (r != TX_INF) *tx_rec_owner(keys.recPack + img * npix + y * W + x) = (int)(TX_UNCLAIMED | (unsigned)r);
+        if (r != TX_INF) {
+          if (keys.hot) keys.hot[img * npix + y * W + x].y = (int)(TX_UNCLAIMED | (unsigned)r);
+          else *tx_rec_owner(keys.recPack + img * npix + y * W + x) = (int)(TX_UNCLAIMED | (unsigned)r);
+        }
       } else if (keys.pack == 0) own[y * W + x] = r != TX_INF ? make_int2(r, r) : make_int2(INT_MAX, INT_MAX);
       if (r != TX_INF) {
         k = (unsigned)r;
@@ -371,11 +387,14 @@ __device__ __forceinline__ void tx_round2_block(RxCtl* __restrict__ ctl, int2* _
                                                    const int2* __restrict__ rgBoxAll, int* __restrict__ rgDirtyAll,
                                                    int* __restrict__ tileActAll, int W, int H, int TW, int TH, int t, int img0,
                                                    const int* __restrict__ rgLostAll, TxDirtyLists DL,
-                                                   int* __restrict__ tileTouchAll, const float4* __restrict__ recPack, int keepRect) {
+                                                   int* __restrict__ tileTouchAll, const float4* __restrict__ recPack, int keepRect,
+                                                   const int2* __restrict__ hotPack) {
   const int img = blockIdx.z + img0;
   RxCtl& c = ctl[img];
   if (c.state == 2) return;
   const int tid = threadIdx.x;
+  // (round 1's owner words: the fourth word of the 16-byte records, or the second of the 8-byte hot records)
+  auto packWord = [&](int64_t p) -> int { return hotPack ? hotPack[p].y : *tx_rec_owner(recPack + p); };
   // (keepRect: round 1's region2rect pass runs beside this kernel and still reads the round's list counter: k_tx_reset_rect clears it later)
   if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
     c.nSmall = 0; c.nBig = 0; c.nHand = 0; c.nextBig = 0; c.changed = 0; c.changedOdd = 0;
@@ -394,7 +413,7 @@ __device__ __forceinline__ void tx_round2_block(RxCtl* __restrict__ ctl, int2* _
     ow[i] = make_int2(INT_MAX, INT_MAX);
     r[i] = TX_INF;
     if (x < W && y < H) {
-      if (PACKED) ow[i].y = *tx_rec_owner(recPack + base + y * W + x);
+      if (PACKED) ow[i].y = packWord(base + y * W + x);
       else ow[i] = ownAll[base + y * W + x];
       r[i] = rankAll[base + y * W + x];
     }
@@ -422,7 +441,7 @@ __device__ __forceinline__ void tx_round2_block(RxCtl* __restrict__ ctl, int2* _
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    if (PACKED) so[i] = make_int2(0, *tx_rec_owner(recPack + base + max(sp[i], 0)));
+    if (PACKED) so[i] = make_int2(0, packWord(base + max(sp[i], 0)));
     else so[i] = ownAll[base + max(sp[i], 0)];
   }
 #pragma unroll
@@ -458,9 +477,10 @@ __global__ __launch_bounds__(256) void k_tx_round2(RxCtl* __restrict__ ctl, int2
                                                    const int2* __restrict__ rgBoxAll, int* __restrict__ rgDirtyAll,
                                                    int* __restrict__ tileActAll, int W, int H, int TW, int TH, int t, int img0,
                                                    const int* __restrict__ rgLostAll, TxDirtyLists DL,
-                                                   int* __restrict__ tileTouchAll, const float4* __restrict__ recPack, int keepRect) {
-  if (recPack) tx_round2_block<true>(ctl, ownAll, rankAll, orderAll, rgBoxAll, rgDirtyAll, tileActAll, W, H, TW, TH, t, img0, rgLostAll, DL, tileTouchAll, recPack, keepRect);
-  else tx_round2_block<false>(ctl, ownAll, rankAll, orderAll, rgBoxAll, rgDirtyAll, tileActAll, W, H, TW, TH, t, img0, rgLostAll, DL, tileTouchAll, recPack, keepRect);
+                                                   int* __restrict__ tileTouchAll, const float4* __restrict__ recPack, int keepRect,
+                                                   const int2* __restrict__ hotPack) {
+  if (recPack || hotPack) tx_round2_block<true>(ctl, ownAll, rankAll, orderAll, rgBoxAll, rgDirtyAll, tileActAll, W, H, TW, TH, t, img0, rgLostAll, DL, tileTouchAll, recPack, keepRect, hotPack);
+  else tx_round2_block<false>(ctl, ownAll, rankAll, orderAll, rgBoxAll, rgDirtyAll, tileActAll, W, H, TW, TH, t, img0, rgLostAll, DL, tileTouchAll, recPack, keepRect, hotPack);
 }
 // (after round 1's region2rect pass, when it ran beside k_tx_round2: the list counter of the images that are still relaxing starts round 2 at zero)
 __global__ __launch_bounds__(256) void k_tx_reset_rect(RxCtl* __restrict__ ctl, int nimg, int img0) {
@@ -1015,7 +1035,7 @@ __device__ __forceinline__ int tx_pk_max_u16(int a, int b) {
 
 // PACK (t == 1, not SPARSE, not SPEC): round 1 with owner_1 inside the pixel records (see tx_load_rec16).  1: the unclaimed words
 // carry the pixels' own ids (k_tx_sort wrote them); 2 (key mode): they carry the gradient norm (the front pass wrote them, LAZY ids).
-template <bool SPARSE, bool SPEC = false, int GQ = TX_GQ, int PACK = 0>
+template <bool SPARSE, bool SPEC = false, int GQ = TX_GQ, int PACK = 0, bool HOT = false>
 __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
                                              const float4* __restrict__ recAll, int2* __restrict__ ownAll,
                                              const int2* __restrict__ listAll, const int* __restrict__ tileCntAll,
@@ -1074,8 +1094,10 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
     }
     if (!__builtin_amdgcn_ballot_w64(act)) return;
   }
+  static_assert(!HOT || PACK != 0, "the hot records carry round 1's packed owner word");
   const float4* rec = recAll + img * npix;
   int2* own = ownAll + img * npix;
+  int2* hot = HOT ? keysp->hot + img * npix : nullptr;      // (HOT: {level-line angle, owner word} per pixel)
   const int2* list = listAll + ((int64_t)img * ntile + tile) * ts * ts;
   int* rgSize = rgSizeAll + img * npix;
   int2* rgBox = rgBoxAll + img * npix;
@@ -1279,7 +1301,15 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
         asm volatile("" : "=v"(rr.x), "=v"(rr.y), "=v"(rr.z), "=v"(oo.x), "=v"(oo.y));
         rr.w = 0.f;
         if (PACK) asm volatile("" : "=v"(rr.w));
-        if (PACK) {
+        if (HOT) {
+          if (ok) {
+            const int2 h = tx_load_hot8(hot + (unsigned)qi);
+            rr.x = __int_as_float(h.x);
+            rr.w = __int_as_float(h.y);
+          }
+          rr.y = tx_hw_cos_deg(rr.x);
+          rr.z = tx_hw_sin_deg(rr.x);
+        } else if (PACK) {
           if (ok) rr = tx_load_rec16(rec + (unsigned)qi);
         } else if (ok) {
           rr = rec[(unsigned)qi];
@@ -1349,7 +1379,8 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
 #if defined(TX_DIAG_NOWAIT)     // diagnostic build (NOT exact: contested claims go unnoticed): non-returning claims, nothing to wait for
           (void)__hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
 #else
-          if (PACK) pendOld = (int)__hip_atomic_fetch_min(reinterpret_cast<unsigned*>(tx_rec_owner(rec + (unsigned)qi)), (unsigned)r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
+          if (HOT) pendOld = (int)__hip_atomic_fetch_min(reinterpret_cast<unsigned*>(&hot[(unsigned)qi].y), (unsigned)r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
+          else if (PACK) pendOld = (int)__hip_atomic_fetch_min(reinterpret_cast<unsigned*>(tx_rec_owner(rec + (unsigned)qi)), (unsigned)r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
           else pendOld = __hip_atomic_fetch_min(ci ? &own[(unsigned)qi].y : &own[(unsigned)qi].x, r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
 #endif
           // (the pixel's own rank, which an unclaimed owner word holds: in round 1 owner_0 is the trivial map, so the word just read has it)
@@ -1374,7 +1405,8 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
                       ps = __int_as_float(tx_lds_read(&park[128 + lane]));
           if (acceptBatch(remaining, pa, pc, ps, grpXY)) {
             const int qi = (grpXY >> 16) * W + (grpXY & 0xFFFF);
-            if (PACK) pendOld = (int)__hip_atomic_fetch_min(reinterpret_cast<unsigned*>(tx_rec_owner(&rec[qi])), (unsigned)r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
+            if (HOT) pendOld = (int)__hip_atomic_fetch_min(reinterpret_cast<unsigned*>(&hot[qi].y), (unsigned)r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
+            else if (PACK) pendOld = (int)__hip_atomic_fetch_min(reinterpret_cast<unsigned*>(tx_rec_owner(&rec[qi])), (unsigned)r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
             else pendOld = __hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
             if (noteLost && !PACK) pendRank = (SPARSE || t != 1) ? rankOfPix[qi] : tx_lds_read(&park[192 + lane]);
             if (SPARSE && tileTouch) tileTouch[(grpXY >> 19) * TW + ((grpXY & 0xFFFF) >> 3)] = t;
@@ -1710,7 +1742,13 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
     if (PACK) {
       // (the seed's angle and its owner word by two small loads: the 16-byte load's result is a 4-register tuple that the allocator
       // would keep — and spill — whole for as long as the angles of the row are in use)
-      if (d) {
+      if (HOT) {
+        if (d) {
+          const int2 h = tx_load_own(&hot[se.y]);           // (one 8-byte load past the per-CU L1, like the owner pairs of the later rounds)
+          srec.x = __int_as_float(h.x);
+          srec.w = __int_as_float(h.y);
+        }
+      } else if (d) {
         srec.x = rec[se.y].x;
         srec.w = __int_as_float(__hip_atomic_load(tx_rec_owner(&rec[se.y]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
       }
@@ -1757,7 +1795,15 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
           const bool ok = pi < __popcll(grpMembers) && nx >= 0 && ny >= 0 && nx < W && ny < H;
           float4 rr = make_float4(TX_NOTDEF, 0.f, 0.f, 0.f);
           int2 oo = make_int2(0, 0);
-          if (PACK) {
+          if (HOT) {
+            if (ok) {
+              const int2 h = tx_load_hot8(&hot[ny * W + nx]);
+              rr.x = __int_as_float(h.x);
+              rr.w = __int_as_float(h.y);
+            }
+            rr.y = tx_hw_cos_deg(rr.x);
+            rr.z = tx_hw_sin_deg(rr.x);
+          } else if (PACK) {
             if (ok) rr = tx_load_rec16(&rec[ny * W + nx]);
           } else if (ok) {
             rr = rec[ny * W + nx];
@@ -1892,6 +1938,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                                        TW, TH, arenaAll, arenaCap, rectAll, rectCap, img + img0, tile, 1, rankAll, rgLostAll, tileTouchAll, DL,
                                        q, gb, park, &keys);
 }
+// ... and both with round 1's words in the 8-byte hot records (round 6; keys.hot)
+#define TX_GROW_HOT_KERNEL(NAME, PACKV)                                                                                                     \
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void NAME(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl, \
+                                                const float4* __restrict__ recAll, int2* __restrict__ ownAll,                                \
+                                                const int2* __restrict__ listAll, const int* __restrict__ tileCntAll,                        \
+                                                int ts, int ntx, int nty, int* __restrict__ rgSizeAll,                                       \
+                                                int2* __restrict__ rgBoxAll, const int* __restrict__ rgDirtyAll,                             \
+                                                const int* __restrict__ tileActAll, int TW, int TH,                                          \
+                                                int* __restrict__ arenaAll, int arenaCap, RxRect* __restrict__ rectAll,                      \
+                                                int rectCap, int img0, int t, const int* __restrict__ rankAll,                               \
+                                                int* __restrict__ rgLostAll, int* __restrict__ tileTouchAll, TxDirtyLists DL, TxKeys keys) { \
+  __shared__ int q[TX_GQ];                                                                                                                   \
+  __shared__ int gb[TX_BMAXBLK];                                                                                                             \
+  __shared__ int park[TX_PARK];                                                                                                              \
+  int img = blockIdx.y, tile = blockIdx.x;                                                                                                   \
+  if (DL.xcdAffine) {                                                                                                                        \
+    const int L = blockIdx.y * gridDim.x + blockIdx.x, xcd = L & 7, k = L >> 3;                                                              \
+    img = (k / (int)gridDim.x) * 8 + xcd;                                                                                                    \
+    tile = k % (int)gridDim.x;                                                                                                               \
+  }                                                                                                                                          \
+  tx_grow_tile<false, false, TX_GQ, PACKV, true>(Pp, ctl, recAll, ownAll, listAll, tileCntAll, ts, ntx, nty, rgSizeAll, rgBoxAll, rgDirtyAll, \
+                                                 tileActAll, TW, TH, arenaAll, arenaCap, rectAll, rectCap, img + img0, tile, 1, rankAll,      \
+                                                 rgLostAll, tileTouchAll, DL, q, gb, park, &keys);                                            \
+}
+TX_GROW_HOT_KERNEL(k_tx_grow_h1, 1)
+TX_GROW_HOT_KERNEL(k_tx_grow_h2, 2)
+#undef TX_GROW_HOT_KERNEL
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tx_grow_spec(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
                                                 const float4* __restrict__ recAll, int2* __restrict__ ownAll,
                                                 const int2* __restrict__ listAll, const int* __restrict__ tileCntAll,

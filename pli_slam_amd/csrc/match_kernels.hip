@@ -514,13 +514,18 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const pli_proj_quer
                                                              float maxX, float minY, float maxY, int checkOri,
                                                              int* __restrict__ owner /* ncur */,
                                                              int* __restrict__ bestIdx2 /* nq */,
-                                                             int* __restrict__ nmatchesOut) {
+                                                             int* __restrict__ nmatchesOut,
+                                                             const uint8_t* __restrict__ occupied /* ncur or null */,
+                                                             int* __restrict__ rawIdx2 /* nq or null: the matches before the rotation filter */) {
   __shared__ int hist[30];
   __shared__ int keep[30];
   const int lane = threadIdx.x;
   const float gwInv = __fdiv_rn((float)GRID_COLS, __fsub_rn(maxX, minX));
   const float ghInv = __fdiv_rn((float)GRID_ROWS, __fsub_rn(maxY, minY));
-  for (int i = lane; i < ncur; i += 64) owner[i] = -1;
+  // (a keypoint that holds a map point with observations before the call is not available, ORBmatcher.cc:2259-2261; a match made in
+  // this call takes its keypoint away from the later queries only if ITS map point has observations — PLI_PROJ_NO_OBSERVATIONS, bit 1 of
+  // `valid`, marks the queries whose map point has none: Tracking::UpdateLastFrame's temporal points in localisation mode)
+  for (int i = lane; i < ncur; i += 64) owner[i] = (occupied && occupied[i]) ? INT_MAX : -1;
   for (int i = lane; i < nq; i += 64) bestIdx2[i] = -1;
   if (lane < 30) hist[lane] = 0;
   __syncthreads();
@@ -575,7 +580,8 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const pli_proj_quer
     if (best != ~0ull && (int)(best >> 40) <= 100) {
       const int b2 = (int)(best & 0xFFFFFFFull);
       if (lane == 0) {
-        owner[b2] = i;
+        if (!(Q.valid & 2)) owner[b2] = i;
+        bestIdx2[i] = b2;
         if (checkOri) {
           float rot = __fsub_rn(Q.angle, kp[b2].angle);
           if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
@@ -603,24 +609,22 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const pli_proj_quer
       for (int i = 0; i < 30; ++i) keep[i] = (i == ind1 || i == ind2 || i == ind3);
     }
     __syncthreads();
-    int removed = 0;
-    for (int i2 = lane; i2 < ncur; i2 += 64) {
-      const int o = owner[i2];
-      if (o < 0) continue;
-      float rot = __fsub_rn(q[o].angle, kp[i2].angle);
-      if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-      int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
-      if (bin == 30) bin = 0;
-      if (!(bin >= 0 && bin < 30 && keep[bin])) { owner[i2] = -1; ++removed; }
-    }
-    removed = wave_sum_i32(removed);
-    nmatches -= removed;
   }
+  // the rotation filter, per accepted query (:2303-2320: every entry of a rejected bin takes one off nmatches)
   __syncthreads();
-  for (int i2 = lane; i2 < ncur; i2 += 64) {
-    const int o = owner[i2];
-    if (o >= 0) bestIdx2[o] = i2;
+  int removed = 0;
+  for (int i = lane; i < nq; i += 64) {
+    const int b = bestIdx2[i];
+    if (rawIdx2) rawIdx2[i] = b;
+    if (b < 0 || !checkOri) continue;
+    float rot = __fsub_rn(q[i].angle, kp[b].angle);
+    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+    int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+    if (bin == 30) bin = 0;
+    if (!(bin >= 0 && bin < 30 && keep[bin])) { bestIdx2[i] = -1; ++removed; }
   }
+  removed = wave_sum_i32(removed);
+  nmatches -= removed;
   if (lane == 0) *nmatchesOut = nmatches;
 }
 
@@ -832,7 +836,7 @@ __device__ __forceinline__ void proj_assign_dev(int lane, int* owner, const pli_
                                                 int ncur, float minX, float maxX, float minY, float maxY, int mode,
                                                 int checkOri, float nnratio, const unsigned long long* __restrict__ candKeys,
                                                 const int* __restrict__ candCount, int* __restrict__ bestIdx2,
-                                                int* __restrict__ nmatchesOut) {
+                                                int* __restrict__ nmatchesOut, int* __restrict__ rawIdx2 /* mode 0, or null */) {
   __shared__ int hist[30];
   __shared__ int keep[30];
   const float gwInv = __fdiv_rn((float)GRID_COLS, __fsub_rn(maxX, minX));
@@ -882,8 +886,10 @@ __device__ __forceinline__ void proj_assign_dev(int lane, int* owner, const pli_
         accept = !(bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2));
       }
       if (accept) {
-        owner[b1] = i;                                  // every lane stores the same value
-        if (mode == 1) bestIdx2[i] = b1;
+        // (every lane stores the same value.  Mode 0: a query whose map point has no observations — bit 1 of `valid` — does not take
+        // its keypoint away from the queries behind it, ORBmatcher.cc:2259-2261)
+        if (mode == 1 || !(q[i].valid & 2)) owner[b1] = i;
+        bestIdx2[i] = b1;
         if (mode == 0 && checkOri && lane == 0) {
           float rot = __fsub_rn(q[i].angle, kp[b1].angle);
           if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
@@ -912,24 +918,21 @@ __device__ __forceinline__ void proj_assign_dev(int lane, int* owner, const pli_
         for (int i = 0; i < 30; ++i) keep[i] = (i == ind1 || i == ind2 || i == ind3);
       }
       __syncthreads();
-      int removed = 0;
-      for (int i2 = lane; i2 < ncur; i2 += 64) {
-        const int o = owner[i2];
-        if (o < 0 || o == INT_MAX) continue;
-        float rot = __fsub_rn(q[o].angle, kp[i2].angle);
-        if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-        int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
-        if (bin == 30) bin = 0;
-        if (!(bin >= 0 && bin < 30 && keep[bin])) { owner[i2] = -1; ++removed; }
-      }
-      removed = wave_sum_i32(removed);
-      nmatches -= removed;
-      __syncthreads();
     }
-    for (int i2 = lane; i2 < ncur; i2 += 64) {
-      const int o = owner[i2];
-      if (o >= 0 && o != INT_MAX) bestIdx2[o] = i2;
+    // the rotation filter, per accepted query (:2303-2320: every entry of a rejected bin takes one off nmatches)
+    int removed = 0;
+    for (int i = lane; i < nq; i += 64) {
+      const int b = bestIdx2[i];
+      if (rawIdx2) rawIdx2[i] = b;
+      if (b < 0 || !checkOri) continue;
+      float rot = __fsub_rn(q[i].angle, kp[b].angle);
+      if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+      int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+      if (bin == 30) bin = 0;
+      if (!(bin >= 0 && bin < 30 && keep[bin])) { bestIdx2[i] = -1; ++removed; }
     }
+    removed = wave_sum_i32(removed);
+    nmatches -= removed;
   }
   if (lane == 0) *nmatchesOut = nmatches;
 }
@@ -940,10 +943,10 @@ __global__ __launch_bounds__(64) void k_proj_assign(const pli_proj_query* __rest
                                                     int ncur, float minX, float maxX, float minY, float maxY, int mode,
                                                     int checkOri, float nnratio, const unsigned long long* __restrict__ candKeys,
                                                     const int* __restrict__ candCount, int* __restrict__ bestIdx2,
-                                                    int* __restrict__ nmatchesOut) {
+                                                    int* __restrict__ nmatchesOut, int* __restrict__ rawIdx2) {
   extern __shared__ int owner[];
   proj_assign_dev(threadIdx.x, owner, q, qdesc, nq, kp, desc, uright, occupied, ncur, minX, maxX, minY, maxY, mode, checkOri, nnratio,
-                  candKeys, candCount, bestIdx2, nmatchesOut);
+                  candKeys, candCount, bestIdx2, nmatchesOut, rawIdx2);
 }
 
 // ---------------------------------------------------------------------------
@@ -1128,7 +1131,7 @@ __global__ __launch_bounds__(64) void k_track_assign(const uint8_t* __restrict__
                   reinterpret_cast<const pli_keypoint*>(cur + tp.offKp0), cur + tp.offDesc0,
                   reinterpret_cast<const float*>(cur + tp.offUr), nullptr, ncur, tp.minX, tp.maxX, tp.minY, tp.maxY, 0, tp.checkOri, 0.f,
                   candKeysAll + (int64_t)frame * tp.kpCap * PROJ_K, candCountAll + (int64_t)frame * tp.kpCap,
-                  reinterpret_cast<int*>(out + tp.toffBest), counts + 1);
+                  reinterpret_cast<int*>(out + tp.toffBest), counts + 1, nullptr);
 }
 
 // one workgroup per frame pair: knn2 both ways, ratio tests, mutual check (descriptor tables of <= klCap lines)

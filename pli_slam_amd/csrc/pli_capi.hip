@@ -95,6 +95,7 @@ struct pli_ctx {
   bool lsdF64 = false; double* mg = nullptr; unsigned long long* maxMg = nullptr; double* tmp64 = nullptr; double* kern64 = nullptr;
   int* lsdTab64 = nullptr; int lsdRadius = 0;
   bool lsdFront64 = false;                   // the fused blur -> resize -> gradient pass applies (lsd_f64.hip: k_lsd_front64)
+  int2* hot = nullptr;                       // tile relaxation, CV_64F detector: round 1's 8-byte hot records {angle, owner word} (lsd_tile.hip)
   int2* own = nullptr; RxSeed* smallSeeds = nullptr; RxSeed* bigSeeds = nullptr; int bigCap = 0;
   RxHand* hand = nullptr; int handCap = 0; RxRect* rects = nullptr; int rectCap = 0; int* rankOf = nullptr; int2* rgBox = nullptr; float4* rgSeg = nullptr; uint8_t* rgClean = nullptr;
   int* rgLost = nullptr;                     // tile relaxation: round in which a region last lost a contested claim (per rank)
@@ -622,6 +623,7 @@ pli_status allocAll(pli_ctx* c) {
     c->rxImages = (int)NR;
     const bool lane = c->lsdMode == 1, tiles = c->lsdMode == 0 || c->lsdMode == 3;
     A(c->own, npix * NR);
+    if (tiles && c->lsdF64) A(c->hot, npix * NR);
     if (lane) {               // lane / lane-group growers of lsd_relax.hip
       A(c->smallSeeds, npix * NR);
       c->bigCap = (int)(npix / RX_HAND + 64);               // a region listed as large had >= RX_HAND pixels of its own
@@ -881,6 +883,10 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       !(getenv("PLI_TX_SPEC") && atoi(getenv("PLI_TX_SPEC")) != 0) && !(getenv("PLI_TX_ORDER") && atoi(getenv("PLI_TX_ORDER")) != 0))
     packMode = (keyMode && P.nBins > 128) ? 2 : 1;      // (the lazy form's fixed-point bin width needs maxGrad / (nBins - 1) < 4: tests/test_lazy_ids_cpu.py)
   if (const char* e = getenv("PLI_TX_PACK1")) packMode = std::min(packMode, std::max(0, atoi(e)));
+  // round 6: round 1's words in 8-byte hot records of their own (lsd_tile.hip "HOT RECORDS"); dev switch PLI_TX_HOT=0 / 1
+  bool hotMode = packMode != 0 && c->hot != nullptr && P.prec <= 1.0;
+  if (const char* e = getenv("PLI_TX_HOT")) hotMode = hotMode && atoi(e) != 0;
+  int2* hotPlane = hotMode ? c->hot : (int2*)nullptr;
   const int trigF32 = ((c->cfg.parity_flags & PLI_PARITY_TRIG_F32_LSD) ? 1 : 0) | (packMode == 2 ? 2 : 0);
   if (c->lsdF64) {
     // OpenCV 3.x: the detector works on the CV_64FC1 copy of the image (lsd_f64.hip).  The scaled double image lives in
@@ -892,7 +898,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       HIPCHK(hipMemsetAsync(c->maxMg + img0, 0, sizeof(unsigned long long) * nimg, c->stream));
       LAUNCH(c, "k_lsd_front", k_lsd_front64, dim3((P.LW + 63) / 64, (P.LH + 15) / 16, nimg), dim3(256), 0, c->pyr + P.lv[0].offset,
              P.pyrBlock, P.W, P.H, P.lv[0].pitch, c->kern64, c->lsdRadius, c->lsdTab64, P.LW, P.LH, P.rho, c->rec, c->mg, ownPlane,
-             c->maxMg, img0, trigF32);
+             c->maxMg, img0, trigF32, hotPlane);
     } else {
     if (c->cfg.lsd_scale != 1) {
       LAUNCH(c, "k_blur_lsd", k_lsd_blur64, gb, dim3(256), 0, c->pyr + P.lv[0].offset, P.pyrBlock, P.W, P.H, P.lv[0].pitch,
@@ -908,7 +914,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
                             hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipMemsetAsync(c->maxMg + img0, 0, sizeof(unsigned long long) * nimg, c->stream));
     LAUNCH(c, "k_lsd_grad", k_lsd_grad64, dim3((P.LW + 255) / 256, (P.LH + 15) / 16, nimg), dim3(256), 0, scaled64, P.LW, P.LH, P.rho,
-           c->rec, c->mg, ownPlane, c->maxMg, c->debug ? c->angDbg : (float*)nullptr, img0, trigF32);
+           c->rec, c->mg, ownPlane, c->maxMg, c->debug ? c->angDbg : (float*)nullptr, img0, trigF32, hotPlane);
     }
   } else {
     const uint8_t* scaled;
@@ -1080,7 +1086,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       TxKeys keys{};
       if (keyMode) keys = TxKeys{c->mg, c->maxMg, P.rho, P.nBins, c->txPixBits, c->rankOf};
       const bool pack1 = packMode != 0;
-      if (pack1) { keys.recPack = c->rec; keys.pack = packMode; }
+      if (pack1) { keys.recPack = c->rec; keys.pack = packMode; keys.hot = hotPlane; }
       if (!getenv("PLI_TX_ZERO_BY_FILL")) { keys.zeroA = c->rgDirty; keys.zeroB = lostRule ? c->rgLost : (int*)nullptr; }
       // (test switch: a wide margin sends every unclaimed pixel of the LAZY form through the double plane; the results must not change)
       if (const char* e = getenv("PLI_TX_LAZY_MARGIN")) keys.lazyMargin = std::max(4, std::min(0x3FFFFFFF, atoi(e)));
@@ -1169,7 +1175,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
         if (fused2) {
           TRL(c, "k_tx_round2", k_tx_round2, dim3((P.LW + 31) / 32, (P.LH + 31) / 32, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->order,
               c->rgBox, c->rgDirty, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, (const int*)c->rgLost, DL, c->tileTouch,
-              pack1 ? (const float4*)c->rec : (const float4*)nullptr, rectAside ? 1 : 0);
+              (pack1 && !hotPlane) ? (const float4*)c->rec : (const float4*)nullptr, rectAside ? 1 : 0, (const int2*)hotPlane);
           if (rectAside) {                               // (round 1's region2rect pass has run beside this kernel: join, then the counter)
             HIPCHK(hipStreamWaitEvent(c->stream, c->evRectDone, 0));
             TRL(c, "k_tx_reset_rect", k_tx_reset_rect, dim3((nimg + 255) / 256), dim3(256), 0, c->jrCtl, nimg, img0);
@@ -1244,7 +1250,15 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
             TRL(c, "k_tx_order", k_tx_order, dim3(1), dim3(1024), 0, (const int*)c->txTileCnt, ntile, nimg, img0, c->txPerm + (int64_t)img0 * ntile);
             r1DL.perm = c->txPerm + (int64_t)img0 * ntile;
           }
-          if (packMode == 2)
+          if (hotPlane && packMode == 2)
+          TRL(c, "k_tx_grow", k_tx_grow_h2, dim3(ntile, nimg), dim3(64), txPad, c->dP, c->jrCtl, c->rec, c->own, c->txList,
+              c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty, c->tileAct, c->tilesW, c->tilesH, c->arena,
+              c->arenaCap, c->rects, c->rectCap, img0, t, (const int*)c->rankOf, lostRule ? c->rgLost : (int*)nullptr, c->tileTouch, r1DL, keys);
+          else if (hotPlane)
+          TRL(c, "k_tx_grow", k_tx_grow_h1, dim3(ntile, nimg), dim3(64), txPad, c->dP, c->jrCtl, c->rec, c->own, c->txList,
+              c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty, c->tileAct, c->tilesW, c->tilesH, c->arena,
+              c->arenaCap, c->rects, c->rectCap, img0, t, (const int*)c->rankOf, lostRule ? c->rgLost : (int*)nullptr, c->tileTouch, r1DL, keys);
+          else if (packMode == 2)
           TRL(c, "k_tx_grow", k_tx_grow_p2, dim3(ntile, nimg), dim3(64), txPad, c->dP, c->jrCtl, c->rec, c->own, c->txList,
               c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty, c->tileAct, c->tilesW, c->tilesH, c->arena,
               c->arenaCap, c->rects, c->rectCap, img0, t, (const int*)c->rankOf, lostRule ? c->rgLost : (int*)nullptr, c->tileTouch, r1DL, keys);
@@ -2281,7 +2295,7 @@ constexpr int PROJ_CAND = 64;                 // PROJ_K of match_kernels.hip
 static pli_status projectionSearch(pli_ctx* c, int mode, const pli_proj_query* q, const uint8_t* qdesc, int32_t nq,
                                    const pli_keypoint* kp, const uint8_t* desc, const float* uright, const uint8_t* occupied,
                                    int32_t ncur, float minX, float maxX, float minY, float maxY, int32_t checkOri,
-                                   float nnratio, int32_t* best, int32_t* nmatches) {
+                                   float nnratio, int32_t* best, int32_t* nmatches, int32_t* raw = nullptr) {
   if (!c || nq < 0 || ncur < 0 || (nq > 0 && (!q || !qdesc || !best)) || (ncur > 0 && (!kp || !desc || !uright))) { g_err = "bad argument"; return PLI_ERR_INVALID; }
   if (nmatches) *nmatches = 0;
   if (nq == 0) return PLI_OK;
@@ -2292,8 +2306,10 @@ static pli_status projectionSearch(pli_ctx* c, int mode, const pli_proj_query* q
   const size_t bq = alignUp((size_t)nq * sizeof(pli_proj_query), 256), bqd = alignUp((size_t)nq * 32, 256);
   const size_t bk = alignUp((size_t)nc * sizeof(pli_keypoint), 256), bd = alignUp((size_t)nc * 32, 256), bu = alignUp((size_t)nc * 4, 256);
   const size_t bo = alignUp((size_t)nc * 4, 256), bb = alignUp((size_t)nq * 4, 256), bc = alignUp((size_t)nc, 256);
+  for (int i = 0; i < nq; ++i)
+    if (mode == 0 && (q[i].valid & ~3)) { g_err = "pli_proj_query.valid: 0, 1 or 1 | PLI_PROJ_NO_OBSERVATIONS"; return PLI_ERR_INVALID; }
   const size_t bkeys = twoPhase ? alignUp((size_t)nq * PROJ_CAND * 8, 256) : 0, bcc = twoPhase ? alignUp((size_t)nq * 4, 256) : 0;
-  pli_status st = ensureScratch(c, bq + bqd + bk + bd + bu + bo + bb + bc + bkeys + bcc + 256);
+  pli_status st = ensureScratch(c, bq + bqd + bk + bd + bu + bo + 2 * bb + bc + bkeys + bcc + 256);
   if (st != PLI_OK) return st;
   uint8_t* p = (uint8_t*)c->scratch;
   pli_proj_query* dq = (pli_proj_query*)p; p += bq;
@@ -2303,6 +2319,7 @@ static pli_status projectionSearch(pli_ctx* c, int mode, const pli_proj_query* q
   float* du = (float*)p; p += bu;
   int* down = (int*)p; p += bo;
   int* dbest = (int*)p; p += bb;
+  int* draw = (int*)p; p += bb;
   uint8_t* docc = p; p += bc;
   unsigned long long* dkeys = (unsigned long long*)p; p += bkeys;
   int* dcc = (int*)p; p += bcc;
@@ -2315,7 +2332,8 @@ static pli_status projectionSearch(pli_ctx* c, int mode, const pli_proj_query* q
     HIPCHK(hipMemcpyAsync(du, uright, (size_t)ncur * 4, hipMemcpyHostToDevice, c->stream));
     if (occupied) HIPCHK(hipMemcpyAsync(docc, occupied, (size_t)ncur, hipMemcpyHostToDevice, c->stream));
   }
-  const uint8_t* occ = (mode == 1 && occupied && ncur > 0) ? (const uint8_t*)docc : (const uint8_t*)nullptr;
+  const uint8_t* occ = (occupied && ncur > 0) ? (const uint8_t*)docc : (const uint8_t*)nullptr;
+  int* rawOut = (mode == 0 && raw) ? draw : (int*)nullptr;
   if (twoPhase) {
     // a second-best farther than 100 / nnratio can no longer reject a best of <= 100 (ORBmatcher.cc:124-126)
     int limit = 100;
@@ -2323,16 +2341,17 @@ static pli_status projectionSearch(pli_ctx* c, int mode, const pli_proj_query* q
     LAUNCH(c, "k_proj_candidates", k_proj_candidates, dim3(nq), dim3(64), 0, dq, dqd, nq, dk, ddsc, du, ncur, minX, maxX, minY, maxY,
            mode == 0 ? 1 : 0, limit, dkeys, dcc);
     LAUNCH(c, "k_proj_assign", k_proj_assign, dim3(1), dim3(64), (size_t)nc * 4, dq, dqd, nq, dk, ddsc, du, occ, ncur, minX, maxX,
-           minY, maxY, mode, checkOri, nnratio, dkeys, dcc, dbest, dcnt);
+           minY, maxY, mode, checkOri, nnratio, dkeys, dcc, dbest, dcnt, rawOut);
   } else if (mode == 0) {
     LAUNCH(c, "k_search_by_projection", k_search_by_projection, dim3(1), dim3(64), 0, dq, dqd, nq, dk, ddsc, du, ncur, minX, maxX,
-           minY, maxY, checkOri, down, dbest, dcnt);
+           minY, maxY, checkOri, down, dbest, dcnt, occ, rawOut);
   } else {
     LAUNCH(c, "k_search_local_map", k_search_local_map, dim3(1), dim3(64), 0, dq, dqd, nq, dk, ddsc, du, occ, ncur, minX, maxX,
            minY, maxY, nnratio, down, dbest, dcnt);
   }
   int cnt = 0;
   HIPCHK(hipMemcpyAsync(best, dbest, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+  if (rawOut) HIPCHK(hipMemcpyAsync(raw, draw, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(&cnt, dcnt, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (nmatches) *nmatches = cnt;
@@ -2340,11 +2359,12 @@ static pli_status projectionSearch(pli_ctx* c, int mode, const pli_proj_query* q
 }
 
 pli_status pli_search_by_projection(pli_ctx* c, const pli_proj_query* q, const uint8_t* qdesc, int32_t nq,
-                                    const pli_keypoint* kp, const uint8_t* desc, const float* uright, int32_t ncur,
+                                    const pli_keypoint* kp, const uint8_t* desc, const float* uright,
+                                    const uint8_t* occupied, int32_t ncur,
                                     float minX, float maxX, float minY, float maxY, int32_t checkOri,
-                                    int32_t* best, int32_t* nmatches) {
+                                    int32_t* best, int32_t* raw, int32_t* nmatches) {
   CtxGuard guard__(c);
-  return projectionSearch(c, 0, q, qdesc, nq, kp, desc, uright, nullptr, ncur, minX, maxX, minY, maxY, checkOri, 0.0f, best, nmatches);
+  return projectionSearch(c, 0, q, qdesc, nq, kp, desc, uright, occupied, ncur, minX, maxX, minY, maxY, checkOri, 0.0f, best, nmatches, raw);
 }
 
 pli_status pli_search_local_map(pli_ctx* c, const pli_proj_query* q, const uint8_t* qdesc, int32_t nq,

@@ -126,18 +126,24 @@ class Frontend:
         check(self.L.pli_match_lines(self.h, ptr(d1), d1.shape[0], ptr(d2), d2.shape[0], nnr, ptr(m), C.byref(n)))
         return n.value, m
 
-    def search_by_projection(self, queries, qdesc, cur_kp, cur_desc, cur_uright, bounds, check_orientation=True):
+    def search_by_projection(self, queries, qdesc, cur_kp, cur_desc, cur_uright, bounds, check_orientation=True, occupied=None,
+                             with_raw=False):
+        """pli_search_by_projection; `occupied`: per current keypoint, holds a map point with observations before the call;
+        with_raw: also the matches before the rotation filter (n, best, raw)."""
         q = np.ascontiguousarray(queries, PROJ_QUERY_DT)
         qd = np.ascontiguousarray(qdesc, np.uint8)
         kp = np.ascontiguousarray(cur_kp, KEYPOINT_DT)
         de = np.ascontiguousarray(cur_desc, np.uint8)
         ur = np.ascontiguousarray(cur_uright, np.float32)
         best = np.full(q.shape[0], -1, np.int32)
+        raw = np.full(q.shape[0], -1, np.int32) if with_raw else None
+        oc = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
         n = C.c_int32()
         check(self.L.pli_search_by_projection(self.h, ptr(q), ptr(qd), q.shape[0], ptr(kp), ptr(de), ptr(ur),
-                                              kp.shape[0], bounds[0], bounds[1], bounds[2], bounds[3],
-                                              int(check_orientation), ptr(best), C.byref(n)))
-        return n.value, best
+                                              None if oc is None else ptr(oc), kp.shape[0], bounds[0], bounds[1], bounds[2],
+                                              bounds[3], int(check_orientation), ptr(best), None if raw is None else ptr(raw),
+                                              C.byref(n)))
+        return (n.value, best, raw) if with_raw else (n.value, best)
 
     def vocab_create(self, k, L, parent, is_leaf, desc, weight):
         """DBoW2 vocabulary (node list as in ORBvoc.txt); returns an opaque handle for bow_transform."""

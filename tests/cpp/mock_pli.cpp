@@ -160,10 +160,15 @@ pli_status pli_match_lines(pli_ctx* c, const uint8_t*, int32_t n1, const uint8_t
   return PLI_OK;
 }
 pli_status pli_search_by_projection(pli_ctx* c, const pli_proj_query* q, const uint8_t*, int32_t nq, const pli_keypoint*, const uint8_t*,
-                                    const float*, int32_t ncur, float, float, float, float, int32_t, int32_t* best, int32_t* n) {
+                                    const float*, const uint8_t* occ, int32_t ncur, float, float, float, float, int32_t, int32_t* best,
+                                    int32_t* raw, int32_t* n) {
   Lock l(c);
   int k = 0;
-  for (int i = 0; i < nq; ++i) { best[i] = (q[i].valid && i < ncur && (i % 2) == 0) ? i : -1; k += best[i] >= 0; }
+  for (int i = 0; i < nq; ++i) {
+    best[i] = (q[i].valid && i < ncur && (i % 2) == 0 && !(occ && occ[i])) ? i : -1;
+    if (raw) raw[i] = best[i];
+    k += best[i] >= 0;
+  }
   *n = k;
   return PLI_OK;
 }

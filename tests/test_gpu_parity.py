@@ -224,6 +224,11 @@ def test_non_default_algorithm_parameters(gpu, over):
 # ---------------------------------------------------------------------------------------------
 # config 3: 1280x720, 8 levels, 2000 kp + 200 lines, frame-to-frame track match
 # ---------------------------------------------------------------------------------------------
+def n_all(best, obest, q):
+    """(an upper bound for the number of matches of a masked search: every valid query)"""
+    return int((q["valid"] != 0).sum()) + 1
+
+
 def test_config3_f2f(gpu):
     g = gpu
     W, H = 1280, 720
@@ -254,6 +259,24 @@ def test_config3_f2f(gpu):
         on, obest = g.po.search_by_projection(q, last["descL"], cur["kpL"], cur["descL"], cur["uright"], bounds, chk)
         assert n == on and np.array_equal(best, obest)
     assert on > 100
+    # ... with 30 % of the current keypoints already holding an observed map point (ORBmatcher.cc:2255-2257), and with a third of the
+    # last frame's map points without observations (their matches do not take the keypoint away: the same keypoint is matched again)
+    rng0 = np.random.default_rng(30)
+    occ = (rng0.random(len(cur["kpL"])) < 0.3).astype(np.uint8)
+    qn = q.copy()
+    qn["valid"] = np.where((qn["valid"] != 0) & (rng0.random(len(qn)) < 0.33), 3, qn["valid"])
+    qq = np.concatenate([qn, qn])                     # (every map point twice: the second copy meets what the first left behind)
+    qqd = np.concatenate([last["descL"], last["descL"]])
+    for chk in (True, False):
+        n, best, raw = fe.search_by_projection(q, last["descL"], cur["kpL"], cur["descL"], cur["uright"], bounds, chk, occupied=occ, with_raw=True)
+        on, obest, oraw = g.po.search_by_projection(q, last["descL"], cur["kpL"], cur["descL"], cur["uright"], bounds, chk, occupied=occ, with_raw=True)
+        assert n == on and np.array_equal(best, obest) and np.array_equal(raw, oraw)
+        assert not occ[best[best >= 0]].any() and 50 < on < n_all(best, obest, q)
+        n, best, raw = fe.search_by_projection(qq, qqd, cur["kpL"], cur["descL"], cur["uright"], bounds, chk, occupied=occ, with_raw=True)
+        on, obest, oraw = g.po.search_by_projection(qq, qqd, cur["kpL"], cur["descL"], cur["uright"], bounds, chk, occupied=occ, with_raw=True)
+        assert n == on and np.array_equal(best, obest) and np.array_equal(raw, oraw)
+        taken = raw[raw >= 0]
+        assert len(taken) > len(np.unique(taken))     # some keypoint was matched twice: by a query without observations first
     # local map tracking: SearchByProjection(F, vpMapPoints, th) ORBmatcher.cc:44 with the last frame's
     # points standing in for the local map (each twice, so that later map points meet occupied keypoints), and
     # match(MapLines, Frame) LineMatcher.cpp:161
@@ -354,6 +377,15 @@ def test_projection_searches_dense_windows(gpu, ncur, nq):
         on, obest = g.po.search_by_projection(q, qd, kp, desc, ur, bounds, ori)
         assert n == on and np.array_equal(best, obest)
     assert on > nq // 20
+    # ... the frame-to-frame search with occupied keypoints and map points without observations (both kernels: the two-phase one
+    # and, at 17000 keypoints, the scan)
+    qn = q.copy()
+    qn["valid"] = np.where((qn["valid"] != 0) & (rng.random(nq) < 0.4), 3, qn["valid"])
+    for ori in (True, False):
+        n, best, raw = fe.search_by_projection(qn, qd, kp, desc, ur, bounds, ori, occupied=occ, with_raw=True)
+        on, obest, oraw = g.po.search_by_projection(qn, qd, kp, desc, ur, bounds, ori, occupied=occ, with_raw=True)
+        assert n == on and np.array_equal(best, obest) and np.array_equal(raw, oraw)
+        assert not occ[raw[raw >= 0]].any()
 
 
 @pytest.mark.parametrize("nl,nr,nq", [(1500, 1400, 900), (300, 5000, 2500), (0, 40, 30)])

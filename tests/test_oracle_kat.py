@@ -244,6 +244,27 @@ def test_search_by_projection_exclusive_assignment(oracle):
     qd = np.zeros((2, 32), np.uint8)
     n, best = oracle.search_by_projection(q, qd, kp, desc, np.full(2, -1, np.float32), (0, 752, 0, 480), False)
     assert best.tolist() == [0, 1] and n == 2      # the second query cannot take keypoint 0 again
+    # ORBmatcher.cc:2255-2257: a keypoint is unavailable while the map point it holds has observations.  Keypoint 0 taken before the
+    # call: both queries are left with keypoint 1, the first one gets it
+    n, best = oracle.search_by_projection(q, qd, kp, desc, np.full(2, -1, np.float32), (0, 752, 0, 480), False, occupied=[1, 0])
+    assert best.tolist() == [1, -1] and n == 1
+    # ... and a map point WITHOUT observations (UpdateLastFrame's temporal points) does not take its keypoint away: the second query
+    # matches keypoint 0 too, nmatches counts both (:2280-2282)
+    q3 = q.copy(); q3["valid"] = [3, 1]
+    n, best, raw = oracle.search_by_projection(q3, qd, kp, desc, np.full(2, -1, np.float32), (0, 752, 0, 480), False, with_raw=True)
+    assert best.tolist() == [0, 0] and raw.tolist() == [0, 0] and n == 2
+    # the rotation filter (:2303-2320) works per histogram entry: three queries agree on a rotation of 0 degrees, one (without
+    # observations, first on the shared keypoint) is 180 degrees off and is removed — raw keeps it
+    # (ComputeThreeMaxima keeps a second bin with at least a tenth of the first one's entries: twelve agree)
+    K = 12
+    kp4 = np.zeros(K, oracle.KEYPOINT_DT)
+    kp4["x"] = 50.0 + 40.0 * np.arange(K); kp4["y"] = 100.0; kp4["angle"] = 10.0
+    q4 = np.zeros(K + 1, oracle.PROJ_QUERY_DT)
+    q4["u"] = np.concatenate([[50.0], kp4["x"]]); q4["v"] = 100.0; q4["radius"] = 5.0; q4["min_level"] = -1; q4["max_level"] = 1
+    q4["angle"] = [190.0] + [10.0] * K; q4["valid"] = [3] + [1] * K
+    n, best, raw = oracle.search_by_projection(q4, np.zeros((K + 1, 32), np.uint8), kp4, np.zeros((K, 32), np.uint8), np.full(K, -1, np.float32),
+                                               (0, 752, 0, 480), True, with_raw=True)
+    assert raw.tolist() == [0] + list(range(K)) and best.tolist() == [-1] + list(range(K)) and n == K
 
 
 def test_search_local_map_ratio_and_levels(oracle):
