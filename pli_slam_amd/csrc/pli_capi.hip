@@ -884,8 +884,8 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     packMode = (keyMode && P.nBins > 128) ? 2 : 1;      // (the lazy form's fixed-point bin width needs maxGrad / (nBins - 1) < 4: tests/test_lazy_ids_cpu.py)
   if (const char* e = getenv("PLI_TX_PACK1")) packMode = std::min(packMode, std::max(0, atoi(e)));
   // round 6: round 1's words in 8-byte hot records of their own (lsd_tile.hip "HOT RECORDS"); dev switch PLI_TX_HOT=0 / 1
-  bool hotMode = packMode != 0 && c->hot != nullptr && P.prec <= 1.0;
-  if (const char* e = getenv("PLI_TX_HOT")) hotMode = hotMode && atoi(e) != 0;
+  bool hotMode = false;                                   // (not the default until the parity sweeps have run on it)
+  if (const char* e = getenv("PLI_TX_HOT")) hotMode = atoi(e) != 0 && packMode != 0 && c->hot != nullptr && P.prec <= 1.0;
   int2* hotPlane = hotMode ? c->hot : (int2*)nullptr;
   const int trigF32 = ((c->cfg.parity_flags & PLI_PARITY_TRIG_F32_LSD) ? 1 : 0) | (packMode == 2 ? 2 : 0);
   if (c->lsdF64) {
