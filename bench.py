@@ -295,6 +295,36 @@ def self_launch(args, argv):
     return subprocess.call(cmd, env=env)
 
 
+def rank_evidence(rank, world, my_ms, device_id, shared_device):
+    """What makes a multi-rank line self-proving (every rank calls it; the result is the same everywhere): how many ranks took part
+    (an all-reduce of ones), WHICH devices they ran on (an all-gather of each rank's device identity: N distinct ones unless the run is
+    a shared-device rehearsal), and every rank's own time over the timed region (min / max / the slowest rank: a straggler shows)."""
+    import torch
+    import torch.distributed as dist
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    one = torch.ones(1, dtype=torch.int64, device=dev)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    ms = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+    dist.all_gather(ms, torch.tensor([my_ms], dtype=torch.float64, device=dev))
+    ids = [None] * world
+    dist.all_gather_object(ids, str(device_id))
+    per = [float(t.item()) for t in ms]
+    distinct = len(set(ids))
+    return {"ranks_seen": int(one.item()), "devices": ids, "distinct_devices": distinct,
+            "one_device_per_rank": bool(distinct == world),
+            "rehearsal_on_shared_device": bool(shared_device or distinct < world),
+            "per_rank_ms": {"min": min(per), "max": max(per), "slowest_rank": int(per.index(max(per))), "all": per}}
+
+
+def device_identity(local_rank):
+    """A string that differs between the GPUs of a node: the device's UUID when the runtime reports one, its PCI bus id otherwise."""
+    import torch
+    p = torch.cuda.get_device_properties(local_rank)
+    uuid = getattr(p, "uuid", None)
+    bus = "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0))
+    return "%s uuid=%s pci=%s" % (p.name, uuid, bus)
+
+
 def dry_tables(args, rank, world):
     """CPU exercise of the multi-rank path (sharding + gather of the result tables), no kernels: every rank fills the
     records of its shard with a pattern derived from the global frame index, rank 0 checks what arrives."""
@@ -308,6 +338,7 @@ def dry_tables(args, rank, world):
     pad = max(counts)
     gath = TableGatherer(pad * rec, torch.device("cpu"), force=args.force_dist)
     ok = True
+    t_start = time.perf_counter()
     for step in range(args.warmup + args.steps):
         slot = gath.acquire()
         t = gath.table(slot)
@@ -322,10 +353,14 @@ def dry_tables(args, rank, world):
                 s_r, c_r = shard_range(nbatch, r, world)
                 for f in range(c_r):
                     ok &= bool((got[r][f * rec:(f + 1) * rec] == int((s_r + f + 7 * step) % 251)).all())
+    my_ms = (time.perf_counter() - t_start) * 1e3
     dist.barrier()
+    # (no devices in the dry run: a rank's identity is its process)
+    ev = rank_evidence(rank, world, my_ms, "cpu pid=%d" % os.getpid(), False)
     if rank == 0:
         print(json.dumps({"dry_tables": True, "n_gpus": world, "backend": args.backend, "batch_frames": nbatch,
-                          "shard_frames": counts, "gathered_bytes_per_step": sum(counts) * rec, "shards_ok": bool(ok)}), flush=True)
+                          "shard_frames": counts, "gathered_bytes_per_step": sum(counts) * rec, "shards_ok": bool(ok),
+                          "ranks": ev}), flush=True)
     dist.destroy_process_group()
     return 0 if ok else 1
 
@@ -517,7 +552,9 @@ def main():
     fe.prof_enable(False)
     prof = fe.prof_report()
     frames_done = torch.tensor([float(F * args.steps)], dtype=torch.float64, device=ctl)
+    ranks_ev = None
     if multi:
+        ranks_ev = rank_evidence(rank, world, dt / args.steps * 1e3, device_identity(local_rank), args.share_device)
         t = torch.tensor([dt], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -704,6 +741,15 @@ def main():
         if multi:
             out["gather"] = {"bytes_per_rank_per_step": Fmax * rec_bytes, "bytes_at_root_per_step": world * Fmax * rec_bytes,
                              "backend": args.backend, "staged_through_host": bool(gath.staged)}
+            # who took part: ranks counted by an all-reduce, the devices they ran on (N distinct ones, or the line says "rehearsal"),
+            # every rank's own ms per step (the headline uses the slowest)
+            out["gather"].update({"ranks_seen": ranks_ev["ranks_seen"], "devices": ranks_ev["devices"],
+                                  "distinct_devices": ranks_ev["distinct_devices"], "one_device_per_rank": ranks_ev["one_device_per_rank"],
+                                  "rehearsal_on_shared_device": ranks_ev["rehearsal_on_shared_device"]})
+            out["per_rank_ms"] = ranks_ev["per_rank_ms"]
+            if ranks_ev["ranks_seen"] != world or (world > 1 and not args.share_device and not ranks_ev["one_device_per_rank"]):
+                out["value"] = None                     # (not the run the line claims to be)
+                rc = 3
             if args.share_device:
                 out["config"]["parallelism"] += "; ALL ranks share GPU 0 (rehearsal, not a scaling measurement)"
             if args.force_dist and world == 1:

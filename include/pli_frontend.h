@@ -293,6 +293,12 @@ pli_status pli_line_extract(pli_ctx* ctx, int32_t eye,
  *   out[3] the round count the next call plans from */
 pli_status pli_lsd_round_stats(pli_ctx* ctx, int32_t out[4]);
 
+/* Self-test of the device the context runs on (not a reference function): the largest absolute error of the hardware cosine / sine
+ * (v_cos_f32 / v_sin_f32 of angle / 360) against cos / sin of EVERY float angle in [0, 360] degrees.  Round 1 of the LSD tile
+ * relaxation runs its vector filter on those (csrc/lsd_tile.hip "HOT RECORDS"); its error budget assumes 4e-6, and the GPU suite
+ * asserts that this call reports less.  About a second of device time. */
+pli_status pli_selftest_hot_trig(pli_ctx* ctx, double* max_abs_err);
+
 /* The stereo rig of Frame::ComputeStereoMatches (Frame.cc:1005-1008: minZ = mb, maxD = mbf / minZ, depth = mbf / disparity):
  * replaces pli_frontend_config.bf / .fx of an existing context (the extractors' constructors, which create the context in
  * the adapters, do not know the camera; the Frame does: mbf and mK(0,0)).  A no-op when the values are the ones in use. */

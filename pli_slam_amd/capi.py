@@ -113,6 +113,7 @@ _PROTOS = {
     "pli_line_extract": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p,
                                      C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]),
     "pli_lsd_round_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "pli_selftest_hot_trig": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double)]),
     "pli_set_stereo_camera": (C.c_int32, [C.c_void_p, C.c_float, C.c_float]),
     "pli_last_counts": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
     "pli_stereo_match_points": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
@@ -173,6 +174,8 @@ def lib():
                                "the front-end has no CPU fallback")
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _PROTOS.items():
+            if os.environ.get("PLI_LIB_PATH") and not hasattr(L, name):
+                continue        # (an A/B build of an earlier round, tools/ab_libs.sh: it lacks the entry points added since)
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args

@@ -53,6 +53,8 @@ struct DevParams {
   int minRegSize;
   double prec, lsdScale;
   float alignLo, alignHi;     // cos^2(prec + margin), cos^2(prec - margin): bounds of the vector form of the alignment test
+  double hotBand2;            // hot records, test switch: added to the band inside which a candidate of the exact test takes the exact sums (rad; 0)
+  double rectApproxBand;      // region2rect, a region with approximate sums: |angle_diff(theta, reg_angle) - prec| below this -> the exact sums (rad)
   int alignFilter, alignPad;  // 0: prec too wide for the vector form, every test takes the exact path
   int parityFlags, parityPad; // pli_frontend_config::parity_flags (PLI_PARITY_*)
   double rho;                 // LSD gradient threshold quant / sin(prec) (the CV_64F pipeline compares the double norm with it)
@@ -102,6 +104,8 @@ constexpr int RX_HAND = RX_QCAP - 8;   // a lane hands its region to the wave gr
 struct RxRect {
   int rank, off, cnt;
   float sumdx, sumdy;
+  int approx;      // 1: the sums are the hot-record grower's filter sums (lsd_tile.hip "HOT RECORDS"): within 2e-4 rad of the exact ones in
+                   // direction — region2rect recomputes the exact ones where its one use of the region angle is that close to call (lsd_rect.hpp)
 };
 
 // tile-sequential relaxation, rounds >= 2: the seeds stamped dirty in a round, per tile of their seed pixel (appended by whoever

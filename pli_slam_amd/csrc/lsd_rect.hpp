@@ -119,7 +119,43 @@ __device__ __forceinline__ void rx_rect_region(bool on, const RxRect& it, const 
   const bool wide = fabs(Ixx) > fabs(Iyy);
   double theta = (double)fast_atan2_deg(wide ? (float)(lambda - Ixx) : (float)Ixy, wide ? (float)Ixy : (float)(lambda - Iyy));
   theta *= RX_DEG2RAD;
-  if (rx_angle_diff(theta, reg_angle) > prec) theta += RX_PI;
+  double adiff = rx_angle_diff(theta, reg_angle);
+  // A region grown on the hot records (lsd_tile.hip) hands over the sums of its vector filter: cos / sin from v_cos_f32 / v_sin_f32,
+  // within 2e-4 rad of the exact sums in direction (5e-4 rad through fastAtan2's octant seams).  The region angle has this ONE use — on
+  // which side of `prec` the inertia axis lies —, so the approximate one decides unless the difference is within rectApproxBand (2e-3 rad)
+  // of prec; there (one region in a thousand) the group sums the exact cos / sin of the 16-byte records in list order, as region_grow does.
+  {
+    const bool need = on && it.approx != 0 && fabs(adiff - prec) < P.rectApproxBand;
+    if (__builtin_amdgcn_ballot_w64(need)) {
+      int cm = need ? cnt : 0;
+#pragma unroll
+      for (int o = 32; o >= LANES; o >>= 1) cm = max(cm, __shfl_xor(cm, o, 64));
+      float sx = 0.f, sy = 0.f;
+      for (int c0 = 0; c0 < cm; c0 += LANES) {
+        const int kk = c0 + gl;
+        float cy = 0.f, cz = 0.f;
+        if (need && kk < cnt) {
+          const int e = lst[kk];
+          const float4 r = rec[(e >> 16) * W + (e & 0xFFFF)];
+          cy = r.y; cz = r.z;
+          if (kk == 0) {                                  // the seed: region_grow starts its sums with cos / sin of the unrounded double angle
+            double sn, cs;
+            sincos((double)r.x * RX_DEG2RAD, &sn, &cs);
+            cy = (float)cs; cz = (float)sn;
+          }
+        }
+        for (int j = 0; j < LANES; ++j) {
+          const float vy = __shfl(cy, g0 + j, 64), vz = __shfl(cz, g0 + j, 64);
+          if (need && c0 + j < cnt) {
+            sx = (c0 + j == 0) ? vy : __fadd_rn(sx, vy);
+            sy = (c0 + j == 0) ? vz : __fadd_rn(sy, vz);
+          }
+        }
+      }
+      if (need) adiff = rx_angle_diff(theta, (double)fast_atan2_deg(sy, sx) * RX_DEG2RAD);
+    }
+  }
+  if (adiff > prec) theta += RX_PI;
   double dxr, dyr;
   sincos(theta, &dyr, &dxr);
   double l_min = 0, l_max = 0;
@@ -151,7 +187,7 @@ __device__ __forceinline__ void rx_rect_wave(const DevParams& P, const RxCtl& c,
   const int nrect = min((int)(c.rectArena >> RX_ARENA_BITS), rectCap);
   const int lane = threadIdx.x & 63, g = lane >> 4;
   for (int w0 = first * 4; w0 < nrect; w0 += stride * 4) {
-    RxRect it = {0, 0, 0, 1.f, 0.f};
+    RxRect it = {0, 0, 0, 1.f, 0.f, 0};
     const bool have = w0 + g < nrect;
     if (have) it = rects[w0 + g];
     const bool small = have && it.cnt <= RX_RECT_GROUP_MAX;
@@ -162,7 +198,7 @@ __device__ __forceinline__ void rx_rect_wave(const DevParams& P, const RxCtl& c,
       big &= big - 1ull;
       RxRect bt;
       bt.rank = __shfl(it.rank, gl0, 64); bt.off = __shfl(it.off, gl0, 64); bt.cnt = __shfl(it.cnt, gl0, 64);
-      bt.sumdx = __shfl(it.sumdx, gl0, 64); bt.sumdy = __shfl(it.sumdy, gl0, 64);
+      bt.sumdx = __shfl(it.sumdx, gl0, 64); bt.sumdy = __shfl(it.sumdy, gl0, 64); bt.approx = __shfl(it.approx, gl0, 64);
       rx_rect_region<64>(true, bt, P, rec, mg, arena, rgSeg, st, wc, ec, rmask);
     }
   }

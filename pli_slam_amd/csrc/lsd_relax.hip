@@ -572,7 +572,7 @@ __global__ __launch_bounds__(256) void k_rx_grow(const DevParams* __restrict__ P
       if (off + cnt > arenaCap || slot >= rectCap) { c.overflow = off + cnt > arenaCap ? 3 : 4; continue; }
       for (int i = 0; i < cnt; ++i) arena[off + i] = mq[i * 256 + tid];
       RxRect& it = rects[slot];
-      it.rank = r; it.off = off; it.cnt = cnt; it.sumdx = sumdx; it.sumdy = sumdy;
+      it.rank = r; it.off = off; it.cnt = cnt; it.sumdx = sumdx; it.sumdy = sumdy; it.approx = 0;
     }
   }
 }
@@ -792,7 +792,7 @@ __device__ __forceinline__ void rx_grow_groups(const DevParams* __restrict__ Pp,
             for (int i = gl; i < cnt; i += RX_GL) arena[off + i] = qget(i);
             if (gl == 0) {
               RxRect& it = rects[slot];
-              it.rank = r; it.off = off; it.cnt = cnt; it.sumdx = sumdx; it.sumdy = sumdy;
+              it.rank = r; it.off = off; it.cnt = cnt; it.sumdx = sumdx; it.sumdy = sumdy; it.approx = 0;
             }
           }
         }

@@ -59,6 +59,7 @@ constexpr int TX_GQ = 768;        // queue entries of a region kept in LDS
 constexpr int TX_PARK = 4 * 64;   // the parked first-step records of a group: angle, cos, sin, owner_{t-1} per lane
 constexpr int TX_GQ_SPEC = 512;   // ... in the speculative round-1 kernel (its lanes' parked states take 2 KB of the wave's LDS)
 constexpr int TX_SPEC_CAP = 8;    // pixels a lane may take by itself before its region is handed to the whole wave (< minRegSize)
+constexpr int TX_HOT_RESYNC = 1024;   // hot records: pixels after which the filter's sums are replaced by the exact ones (tx_grow_tile)
 constexpr int TX_BBLK = 256;      // arena block for the overflow of a large region's queue
 constexpr int TX_BMAXBLK = 128;   // => regions of up to TX_GQ + 32768 pixels
 
@@ -109,6 +110,23 @@ __device__ __forceinline__ int tx_lds_read(const int* p) {
 }
 __device__ __forceinline__ int tx_rl(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ float tx_rlf(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+// k_tx_hot_trig_err (self-test, pli_selftest_hot_trig): the largest |tx_hw_cos_deg(a) - cos(a deg)| and |tx_hw_sin_deg(a) - sin(a deg)| over
+// EVERY float a in [0, 360] — the `d` of the error budget in tx_grow_tile.  The level-line angles are fastAtan2 results: floats of that range.
+__global__ __launch_bounds__(256) void k_tx_hot_trig_err(unsigned long long* __restrict__ maxErrBits) {
+  const unsigned last = 0x43B40000u;                     // 360.0f
+  double worst = 0.0;
+  for (unsigned long long b = (unsigned long long)blockIdx.x * 256 + threadIdx.x; b <= last; b += (unsigned long long)gridDim.x * 256) {
+    const float a = __int_as_float((int)(unsigned)b);
+    double sn, cs;
+    sincos((double)a * TX_DEG2RAD, &sn, &cs);
+    worst = fmax(worst, fmax(fabs((double)tx_hw_cos_deg(a) - cs), fabs((double)tx_hw_sin_deg(a) - sn)));
+  }
+  unsigned long long w = (unsigned long long)__double_as_longlong(worst);   // (non-negative doubles order like their bits)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(w, o, 64); w = t > w ? t : w; }
+  if ((threadIdx.x & 63) == 0) atomicMax(maxErrBits, w);
+}
 
 // ---------------------------------------------------------------------------
 // k_tx_sort: the seeds of every tile in rank order.  One workgroup of 256 threads per tile sorts the ranks of the tile's
@@ -1209,6 +1227,118 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
       // angCnt; with the seed alone it is the seed's level-line angle itself)
       double reg_angle = 0.0;
       int angCnt = -1;
+      // HOT: sumdx / sumdy are the FILTER's sums — the seed's exact cos / sin plus v_cos_f32 / v_sin_f32 of every accepted pixel's angle.
+      // Where the reference's own expression is evaluated (a candidate inside the filter's margin) the region angle must come from the
+      // sums region_grow forms: the exact cos / sin of the 16-byte records added in the order of acceptance.  exSx / exSy hold them for
+      // the first exCnt queue entries and are brought up to date only when asked for (foldQueue: one gather of the records per 64
+      // entries, then the adds in order).  Why the filter may run on the approximate sums: an accepted pixel lies within prec + margin
+      // of the sum's direction, so |sum| grows by at least cos(prec + margin) >= 0.54 per pixel (prec <= 1 rad, checked by the host), and
+      // the direction of the filter's sums is off the exact one by at most 2 u m + 1.1 d, u = 2^-24 (the roundings of the two
+      // accumulations over the m pixels since the sums last agreed), d = the largest |v_cos - cos| (tests/test_gpu_parity.py measures it
+      // over every float angle: < 4e-6); the sums are made to agree again every TX_HOT_RESYNC = 1024 pixels: below 1.4e-4 rad, and the
+      // candidate's own direction adds 1.5 d.  The margin is 0.05 deg = 8.7e-4 rad, of which fastAtan2 uses 1.7e-4 (NOTEBOOK.md R1).
+      // (the three words live in LDS — exs = the words behind the queue-block table —: the step loops have neither vector nor scalar
+      // registers to spare, and a scalar register the compiler cannot keep costs a v_readlane per use)
+      int* const exs = gb + TX_BMAXBLK;                   // [0] exCnt, [1] / [2] the bits of exSx / exSy, [3] the pixel count at which the filter's sums were last exact
+      if (HOT) {
+        exs[0] = cnt; exs[1] = __float_as_int(sumdx); exs[2] = __float_as_int(sumdy); exs[3] = cnt;   // (every lane stores the same values)
+      }
+      auto foldQueue = [&](const int upto) {              // (the entries exCnt .. upto - 1 are in the queue)
+#if defined(TX_DIAG_HOT_NOFOLD)      // diagnostic build, NOT exact: what the exact sums cost (events decided on the filter's sums)
+        return;
+#endif
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        int exCnt = __builtin_amdgcn_readfirstlane(tx_lds_read(&exs[0]));
+        float ex = __int_as_float(tx_lds_read(&exs[1])), ey = __int_as_float(tx_lds_read(&exs[2]));
+        while (exCnt < upto) {
+          // (2 x 64 entries per trip; the gathers unconditional, from an entry that exists either way, so that they are in flight together)
+          const int n4 = min(128, upto - exCnt);
+          float cy[2], cz[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int e = qget(min(exCnt + 64 * u + lane, upto - 1));
+            const float4 cr = rec[(e >> 16) * W + (e & 0xFFFF)];
+            cy[u] = cr.y; cz[u] = cr.z;
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int nn = min(64, n4 - 64 * u);
+            for (int j = 0; j < nn; ++j) {
+              ex = __fadd_rn(ex, tx_rlf(cy[u], j));
+              ey = __fadd_rn(ey, tx_rlf(cz[u], j));
+            }
+          }
+          exCnt += n4;
+        }
+        exs[0] = exCnt; exs[1] = __float_as_int(ex); exs[2] = __float_as_int(ey);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      };
+      auto exSx = [&]() -> float { return __int_as_float(tx_lds_read(&exs[1])); };
+      auto exSy = [&]() -> float { return __int_as_float(tx_lds_read(&exs[2])); };
+      // the exact sums at this moment of a step: the queue up to the step's start, then the lanes accepted so far (in lane order)
+      auto exactSums = [&](const int cnt0, const unsigned long long accSoFar, const int myxy, float& ax, float& ay) {
+        foldQueue(cnt0);
+        ax = exSx(); ay = exSy();
+        if (accSoFar) {
+          float cy = 0.f, cz = 0.f;
+          if ((accSoFar >> lane) & 1ull) {
+            const float4 cr = rec[(myxy >> 16) * W + (myxy & 0xFFFF)];
+            cy = cr.y; cz = cr.z;
+          }
+          unsigned long long m = accSoFar;
+          while (m) {
+            const int j = __ffsll((long long)m) - 1;
+            m &= m - 1ull;
+            ax = __fadd_rn(ax, tx_rlf(cy, j));
+            ay = __fadd_rn(ay, tx_rlf(cz, j));
+          }
+        }
+      };
+      // (whenever the exact sums of the moment are known the filter goes on from them: the two agree again at this pixel count)
+      auto filterFrom = [&](const float ax, const float ay) {
+        sumdx = ax; sumdy = ay;
+        exs[3] = cnt;
+      };
+      // The reference's own expression for a candidate of level-line angle angJ (a lane inside the margin of the vector filter).  The
+      // region angle is fastAtan2 of the sums — cached per pixel count —; exactAt brings the exact sums on the hot records.  There a
+      // SECOND band comes first: fastAtan2 of the FILTER's sums is within the direction bound of fastAtan2 of the exact ones when both lie
+      // in one octant of the approximation, i.e. when the filter's sums are farther than that bound from the axes and diagonals (inside
+      // an octant the polynomial's slope is below 1.002, and its float evaluation adds 2e-6 rad) — so a candidate farther than that from
+      // prec is decided without the exact sums.  The bound grows with the pixels accepted since the two pairs of sums last agreed (they
+      // are made to agree whenever the exact ones are known): a few 1e-5 rad against the margin's 8.7e-4, so few events are left that
+      // gather the 16-byte records of the region's pixels.
+      auto alignedExact = [&](const float angJ, auto&& exactAt) -> bool {
+        const double aj = (double)angJ * TX_DEG2RAD;
+        auto ntheta = [&](const double ra) -> double {
+          double n = fabs(ra - aj);
+          if (n > TX_3_2_PI) {
+            n = fabs(n - TX_2PI);
+          }
+          return n;
+        };
+        if (HOT) {
+          // (nothing cached between the events of a region: they are rare, and the step loops have no registers to spare)
+          if (cnt == 1) return ntheta((double)sa * TX_DEG2RAD) <= prec;
+          // (the direction bound of the comment above for the m pixels since the sums last agreed: sqrt(2) (1.85 d + 2 u m) = 1.05e-5 +
+          // 1.7e-7 m, times the polynomial's slope 1.002, plus 2e-6 for its evaluation — with room to spare)
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          const float dirBound = 1.5e-5f + 1.8e-7f * (float)(cnt + 64 - tx_lds_read(&exs[3]));
+          const float fx = fabsf(sumdx), fy = fabsf(sumdy), mn = fminf(fx, fy), mx = fmaxf(fx, fy);
+          if (mn > dirBound * mx && mx - mn > 2.1f * dirBound * mx) {
+            const double n1 = ntheta((double)fast_atan2_deg(sumdy, sumdx) * TX_DEG2RAD);
+            if (fabs(n1 - prec) > (double)dirBound + P.hotBand2) return n1 <= prec;
+          }
+          float ax, ay;
+          exactAt(ax, ay);
+          filterFrom(ax, ay);
+          return ntheta((double)fast_atan2_deg(ay, ax) * TX_DEG2RAD) <= prec;
+        }
+        if (angCnt != cnt) {
+          reg_angle = (double)(cnt == 1 ? sa : fast_atan2_deg(sumdy, sumdx)) * TX_DEG2RAD;
+          angCnt = cnt;
+        }
+        return ntheta(reg_angle) <= prec;
+      };
       // pendOld = what stood in the owner word when this lane's claim of the last step arrived, pendRank = the own rank of the pixel it
       // claimed — what an unclaimed word holds — (r and r: the lane claimed nothing): a lower rank -> this region does not hold the
       // pixel it took; a higher rank that is not the pixel's own -> that region just lost the pixel.  Contested claims are rare:
@@ -1249,16 +1379,9 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
                                           alignLo, alignHi, j2, grpCand, grpXY);
           if (code == 0) break;
           // lane j2 lies inside the margin of the vector filter: the reference's own expression decides
-          if (angCnt != cnt) {
-            reg_angle = (double)(cnt == 1 ? sa : fast_atan2_deg(sumdy, sumdx)) * TX_DEG2RAD;
-            angCnt = cnt;
-          }
-          double n_theta = fabs(reg_angle - (double)tx_rlf(ang, j2) * TX_DEG2RAD);
-          if (n_theta > TX_3_2_PI) {
-            n_theta = fabs(n_theta - TX_2PI);
-          }
           // (the sums live in vector registers, so the compiler takes this decision for lane-dependent: say it is not)
-          if (!__builtin_amdgcn_readfirstlane((int)(n_theta <= prec))) continue;
+          if (!__builtin_amdgcn_readfirstlane((int)alignedExact(tx_rlf(ang, j2), [&](float& ax, float& ay) { exactSums(cnt0, acc, myxy, ax, ay); })))
+            continue;
           const int xyj = tx_rl(myxy, j2);
           const float cj = tx_rlf(cosv, j2), sj = tx_rlf(sinv, j2);
           acc |= 1ull << j2;
@@ -1287,6 +1410,12 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
         // loads of this step are issued, so those loads see the region's own claims.
         asm volatile("" ::"v"(pendOld) : "memory");
         stampLosers();
+        // (the filter's sums and the exact ones agree again every TX_HOT_RESYNC pixels: a step adds at most 64, so the count cannot
+        // pass a multiple of TX_HOT_RESYNC without a step starting in the 64 behind it)
+        if (HOT && cnt >= TX_HOT_RESYNC && (cnt & (TX_HOT_RESYNC - 1)) < 64) {
+          foldQueue(cnt);
+          filterFrom(exSx(), exSy());
+        }
         bool accepted = false;
         const int nb = min(8, cnt - k);
         // (one predicate for the whole fetch: the lanes outside it keep whatever their registers hold, and stay out of `cand`)
@@ -1334,15 +1463,12 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
             remaining &= ~1ull << j2;
             const unsigned long long sure = __builtin_amdgcn_ballot_w64(sd2 >= alignHi * n2);
             if (__builtin_expect(!((sure >> j2) & 1ull), 0)) {
-              if (angCnt != cnt) {
-                reg_angle = (double)(cnt == 1 ? sa : fast_atan2_deg(sumdy, sumdx)) * TX_DEG2RAD;
-                angCnt = cnt;
-              }
-              double n_theta = fabs(reg_angle - (double)tx_rlf(rr.x, j2) * TX_DEG2RAD);
-              if (n_theta > TX_3_2_PI) {
-                n_theta = fabs(n_theta - TX_2PI);
-              }
-              if (!__builtin_amdgcn_readfirstlane((int)(n_theta <= prec))) continue;
+              // (this loop puts a pixel into the queue as it accepts it)
+              if (!__builtin_amdgcn_readfirstlane((int)alignedExact(tx_rlf(rr.x, j2), [&](float& ax, float& ay) {
+                    foldQueue(cnt);
+                    ax = exSx(); ay = exSy();
+                  })))
+                continue;
             }
             const int xyj = tx_rl(myxy, j2);
             const float cj = tx_rlf(rr.y, j2), sj = tx_rlf(rr.z, j2);
@@ -1441,6 +1567,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
         if (first) {
           RxRect& it = rects[slot];
           it.rank = r; it.off = off; it.cnt = cnt; it.sumdx = sumdx; it.sumdy = sumdy;
+          it.approx = HOT ? 1 : 0;                        // (HOT: the filter's sums; region2rect asks for the exact ones when it needs them)
         }
       }
       return true;
@@ -1950,7 +2077,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                                                 int rectCap, int img0, int t, const int* __restrict__ rankAll,                               \
                                                 int* __restrict__ rgLostAll, int* __restrict__ tileTouchAll, TxDirtyLists DL, TxKeys keys) { \
   __shared__ int q[TX_GQ];                                                                                                                   \
-  __shared__ int gb[TX_BMAXBLK];                                                                                                             \
+  __shared__ int gb[TX_BMAXBLK + 4];        /* (+ the exact sums' three words, tx_grow_tile) */                                              \
   __shared__ int park[TX_PARK];                                                                                                              \
   int img = blockIdx.y, tile = blockIdx.x;                                                                                                   \
   if (DL.xcdAffine) {                                                                                                                        \

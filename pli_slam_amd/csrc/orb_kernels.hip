@@ -10,6 +10,7 @@
 // All arithmetic that decides a result is integer or explicitly ordered IEEE
 // float (see device_prims.hpp); the library is built with -ffp-contract=off.
 #include "kernels.hpp"
+#include <type_traits>
 #include "device_prims.hpp"
 
 namespace pli {
@@ -171,6 +172,7 @@ __global__ __launch_bounds__(256) void k_resize_level(const uint8_t* __restrict_
 // Output: packed (y<<20 | x<<8 | score), coordinates relative to (minBX,minBY).
 // ---------------------------------------------------------------------------
 constexpr int FT_PITCH = 72;
+constexpr int FT_SP = 68;        // pitch of the padded score map (64 + 2, rounded to 4 bytes)
 
 __device__ __forceinline__ bool has9(unsigned m16) {
   unsigned m = m16 | (m16 << 16);
@@ -181,30 +183,36 @@ __device__ __forceinline__ bool has9(unsigned m16) {
   return (r & 0xFFFFu) != 0;
 }
 
-// max over the 16 arcs of 9 of the minimum of a[] (a has 16 entries, circular)
+// max over the 16 arcs of 9 of the minimum of a[] (a has 16 entries, circular): 9 = 3 x 3, so the minimum of an arc is the minimum
+// of three minima of three — 16 + 16 v_min3 and 8 v_max3 (round 6; the doubling form min2 -> min4 -> min8 -> +1 took 93 two-input ops)
+__device__ __forceinline__ int tx_min3(int a, int b, int c) { return min(min(a, b), c); }
+__device__ __forceinline__ int tx_max3(int a, int b, int c) { return max(max(a, b), c); }
 __device__ __forceinline__ int arc9_maxmin(const int a[16]) {
-  int e[24];
+  int m3[16];
 #pragma unroll
-  for (int i = 0; i < 24; ++i) e[i] = a[i & 15];
-  int m2[23], m4[21], m8[17];
+  for (int i = 0; i < 16; ++i) m3[i] = tx_min3(a[i], a[(i + 1) & 15], a[(i + 2) & 15]);
+  int m9[16];
 #pragma unroll
-  for (int i = 0; i < 23; ++i) m2[i] = min(e[i], e[i + 1]);
+  for (int i = 0; i < 16; ++i) m9[i] = tx_min3(m3[i], m3[(i + 3) & 15], m3[(i + 6) & 15]);
+  int t[6];
 #pragma unroll
-  for (int i = 0; i < 21; ++i) m4[i] = min(m2[i], m2[i + 2]);
-#pragma unroll
-  for (int i = 0; i < 17; ++i) m8[i] = min(m4[i], m4[i + 4]);
-  int best = -256;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) best = max(best, min(m8[i], e[i + 8]));
-  return best;
+  for (int i = 0; i < 5; ++i) t[i] = tx_max3(m9[3 * i], m9[3 * i + 1], m9[3 * i + 2]);
+  t[5] = m9[15];
+  return max(tx_max3(t[0], t[1], t[2]), tx_max3(t[3], t[4], t[5]));
 }
 
 __global__ __launch_bounds__(256) void k_fast_cells(const DevParams* __restrict__ Pp, const uint8_t* __restrict__ pyr,
                                                     uint32_t* __restrict__ cellCand, int* __restrict__ cellCount, int img0) {
   __shared__ __attribute__((aligned(16))) uint8_t tile[FT_PITCH * 68];
-  __shared__ uint8_t score[64 * 64];
-  __shared__ unsigned short clist[64 * 64];   // corners at minTh: pixel index | dark << 12 | bright << 13
-  __shared__ int s_nc;
+  // the score map with a border of zeros (pitch FT_SP, pixel (x, y) at (y + 1) * FT_SP + x + 1): the 8 neighbours of the non-maximum
+  // suppression are read without bounds tests; zeroed once per cell with 4-byte stores (everything that is not a corner scores 0)
+  __shared__ __attribute__((aligned(16))) uint8_t score[FT_SP * 66 + 4];
+  __shared__ unsigned nmsBits[64 * 2];        // one bit per pixel of the 64 x 64 box: a strict maximum of its 3 x 3 block
+  // corners at minTh (pixel indices): the DARK ones from the front, the BRIGHT ones from the back — a ring of 16 cannot hold an arc of 9
+  // darker and an arc of 9 brighter samples, so a corner is one or the other, and each kind takes its score from its own pass (round 6:
+  // one list whose lanes mixed the kinds ran both passes for every wave)
+  __shared__ unsigned short clist[64 * 64];
+  __shared__ int s_nc, s_nb;
   __shared__ int s_any;
   __shared__ int s_wc[64];     // survivors per (chunk, wave)
   __shared__ int s_off[64];    // their exclusive prefix
@@ -246,7 +254,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams* __restrict_
     reinterpret_cast<uint32_t*>(tile)[y * (FT_PITCH / 4) + k] =
         *reinterpret_cast<const uint32_t*>(im + (int64_t)(iniY + y) * G.pitch + (iniX - ox) + 4 * k);
   }
-  if (tid == 0) { s_any = 0; s_nc = 0; }
+  if (tid == 0) { s_any = 0; s_nc = 0; s_nb = 0; }
+  for (int i = tid; i < (FT_SP * 66 + 4) / 4; i += 256) reinterpret_cast<uint32_t*>(score)[i] = 0u;
+  if (tid < 128) nmsBits[tid] = 0u;
   __syncthreads();
   const int minTh = P.minTh, iniTh = P.iniTh;
   const int npix = iw * ih;
@@ -270,64 +280,50 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams* __restrict_
     FT_RING(-3) FT_RING(1 * FT_PITCH - 3) FT_RING(2 * FT_PITCH - 2) FT_RING(3 * FT_PITCH - 1)
 #undef FT_RING
     const bool cd = has9(mDark & 0xFFFFu), cb = has9(mBright & 0xFFFFu);   // (bit order reversed: a contiguous arc stays one)
-    score[y * 64 + x] = 0;
-    if (cd || cb) clist[atomicAdd(&s_nc, 1)] = (unsigned short)(i | (cd ? 0x1000 : 0) | (cb ? 0x2000 : 0));
+    if (cd) clist[atomicAdd(&s_nc, 1)] = (unsigned short)i;
+    else if (cb) clist[4095 - atomicAdd(&s_nb, 1)] = (unsigned short)i;
   }
   __syncthreads();
-  // pass 2, corners only (densely packed lanes): the exact corner score
-  const int nc = s_nc;
-  for (int j = tid; j < nc; j += 256) {
-    const int e = clist[j], i = e & 0xFFF;
-    const bool cd = (e & 0x1000) != 0, cb = (e & 0x2000) != 0;
-    const int y = (int)(((float)i + 0.5f) * invIw), x = i - y * iw;
-    const uint8_t* p = &tile[(y + 3) * FT_PITCH + x + 3 + ox];
-    const int v = p[0];
-    int d[16];
-    d[0] = v - p[3 * FT_PITCH + 0];   d[1] = v - p[3 * FT_PITCH + 1];   d[2] = v - p[2 * FT_PITCH + 2];
-    d[3] = v - p[1 * FT_PITCH + 3];   d[4] = v - p[3];                  d[5] = v - p[-1 * FT_PITCH + 3];
-    d[6] = v - p[-2 * FT_PITCH + 2];  d[7] = v - p[-3 * FT_PITCH + 1];  d[8] = v - p[-3 * FT_PITCH + 0];
-    d[9] = v - p[-3 * FT_PITCH - 1];  d[10] = v - p[-2 * FT_PITCH - 2]; d[11] = v - p[-1 * FT_PITCH - 3];
-    d[12] = v - p[-3];                d[13] = v - p[1 * FT_PITCH - 3];  d[14] = v - p[2 * FT_PITCH - 2];
-    d[15] = v - p[3 * FT_PITCH - 1];
-    int arc = -256;
-    if (cd) arc = max(arc, arc9_maxmin(d));
-    if (cb) {
-      int nd[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) nd[k] = -d[k];
-      arc = max(arc, arc9_maxmin(nd));
-    }
-    score[y * 64 + x] = (uint8_t)(arc - 1);            // cornerScore<16>
-  }
-  __syncthreads();
-  // Non-maximum suppression does not depend on the threshold (a survivor is strictly greater than its 8 neighbours
-  // inside the interior): one flag bit per pixel of this thread (pixel i = ck * 256 + tid, at most 16 chunks).
-  const int nchunks = (npix + 255) / 256;
-  unsigned mxBits = 0;
-#pragma unroll 1
-  for (int ck = 0; ck < nchunks; ++ck) {
-    const int i = ck * 256 + tid;
-    if (i < npix) {
+  // pass 2, corners only (densely packed lanes): the exact corner score = the largest threshold at which the pixel is still a corner
+  // of its kind = max over the 16 arcs of 9 of the smallest (centre - ring) resp. (ring - centre), minus one (cornerScore<16>)
+  const int ncd = s_nc, ncb = s_nb, nc = ncd + ncb;
+  auto cornerAt = [&](int j) -> int { return j < ncd ? clist[j] : clist[4095 - (j - ncd)]; };
+  auto scorePass = [&](auto brightTag) {
+    constexpr bool BRIGHT = decltype(brightTag)::value;
+    const int n = BRIGHT ? ncb : ncd;
+    for (int j = tid; j < n; j += 256) {
+      const int i = BRIGHT ? clist[4095 - j] : clist[j];
       const int y = (int)(((float)i + 0.5f) * invIw), x = i - y * iw;
-      const int s = score[y * 64 + x];
-      bool mx = s > 0;
-      if (mx) {
-#pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-          for (int dx = -1; dx <= 1; ++dx) {
-            if (dx == 0 && dy == 0) continue;
-            const int xx = x + dx, yy = y + dy;
-            const int n = (xx < 0 || yy < 0 || xx >= iw || yy >= ih) ? 0 : score[yy * 64 + xx];
-            mx = mx && (s > n);
-          }
-      }
-      if (mx) {
-        mxBits |= 1u << ck;
-        if (s >= iniTh) s_any = 1;           // benign race: all writers store 1
-      }
+      const uint8_t* p = &tile[(y + 3) * FT_PITCH + x + 3 + ox];
+      const int v = p[0];
+      auto df = [&](int o) -> int { return BRIGHT ? (int)p[o] - v : v - (int)p[o]; };     // ring - centre (bright), centre - ring (dark)
+      int d[16];
+      d[0] = df(3 * FT_PITCH + 0);   d[1] = df(3 * FT_PITCH + 1);   d[2] = df(2 * FT_PITCH + 2);   d[3] = df(1 * FT_PITCH + 3);
+      d[4] = df(3);                  d[5] = df(-1 * FT_PITCH + 3);  d[6] = df(-2 * FT_PITCH + 2);  d[7] = df(-3 * FT_PITCH + 1);
+      d[8] = df(-3 * FT_PITCH + 0);  d[9] = df(-3 * FT_PITCH - 1);  d[10] = df(-2 * FT_PITCH - 2); d[11] = df(-1 * FT_PITCH - 3);
+      d[12] = df(-3);                d[13] = df(1 * FT_PITCH - 3);  d[14] = df(2 * FT_PITCH - 2);  d[15] = df(3 * FT_PITCH - 1);
+      score[(y + 1) * FT_SP + x + 1] = (uint8_t)(arc9_maxmin(d) - 1);
+    }
+  };
+  scorePass(std::false_type{});
+  scorePass(std::true_type{});
+  __syncthreads();
+  // Non-maximum suppression does not depend on the threshold (a survivor is strictly greater than its 8 neighbours inside the
+  // interior; everything outside it, and every non-corner, scores 0 in the padded map).  Only corners can survive: the pass runs over
+  // the corner list — dense lanes, 8 byte reads, no bounds tests — and leaves one bit per survivor (round 6: it used to visit every
+  // pixel of the cell, a fifth of the kernel's instructions).
+  for (int j = tid; j < nc; j += 256) {
+    const int i = cornerAt(j);
+    const int y = (int)(((float)i + 0.5f) * invIw), x = i - y * iw;
+    const uint8_t* sp = &score[(y + 1) * FT_SP + x + 1];
+    const int s = sp[0];
+    const int n = max(tx_max3(tx_max3(sp[-FT_SP - 1], sp[-FT_SP], sp[-FT_SP + 1]), sp[-1], sp[1]), tx_max3(sp[FT_SP - 1], sp[FT_SP], sp[FT_SP + 1]));
+    if (s > n) {                                          // (s > n >= 0: a corner)
+      atomicOr(&nmsBits[y * 2 + (x >> 5)], 1u << (x & 31));
+      if (s >= iniTh) s_any = 1;                          // benign race: all writers store 1
     }
   }
+  const int nchunks = (npix + 255) / 256;
   __syncthreads();
   const int thr = s_any ? iniTh : 1;     // score > 0 <=> corner at minTh
   // ordered (raster) compaction in one go: per (chunk, wave) survivor counts by ballot, one 64-entry scan, then the writes
@@ -338,10 +334,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams* __restrict_
 #pragma unroll 1
   for (int ck = 0; ck < nchunks; ++ck) {
     bool surv = false;
-    if ((mxBits >> ck) & 1u) {
-      const int i = ck * 256 + tid;
+    const int i = ck * 256 + tid;
+    if (i < npix) {
       const int y = (int)(((float)i + 0.5f) * invIw), x = i - y * iw;
-      surv = score[y * 64 + x] >= thr;
+      surv = ((nmsBits[y * 2 + (x >> 5)] >> (x & 31)) & 1u) != 0u && score[(y + 1) * FT_SP + x + 1] >= thr;
     }
     const unsigned long long bal = __ballot(surv);
     if (lane == 0) s_wc[ck * 4 + wv] = __popcll(bal);
@@ -374,7 +370,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const DevParams* __restrict_
     const int pos = s_off[ck * 4 + wv] + r;
     if (pos < CELL_CAP) {
       const int xr = x + 3 + cj * G.wCell, yr = y + 3 + ci * G.hCell;
-      out[pos] = ((uint32_t)yr << 20) | ((uint32_t)xr << 8) | (uint32_t)score[y * 64 + x];
+      out[pos] = ((uint32_t)yr << 20) | ((uint32_t)xr << 8) | (uint32_t)score[(y + 1) * FT_SP + x + 1];
     }
   }
   if (tid == 0) cellCount[cellIdx] = s_base < CELL_CAP ? s_base : CELL_CAP;

@@ -420,7 +420,14 @@ pli_status buildGeometry(pli_ctx* c) {
     // (cos, sin) is within prec  <=>  dot > 0 and dot^2 >= cos^2(prec) |sum|^2.  The sequential grower uses it with a
     // margin on both sides (fastAtan2 is within 0.01 deg of atan2) and decides only the pixels inside the margin with
     // the reference's own expression.
-    const double margin = 0.05 * 3.14159265358979323846 / 180;
+    double margin = 0.05 * 3.14159265358979323846 / 180;
+    // (test switch PLI_ALIGN_MARGIN_DEG: a wide margin sends many more candidates through the exact expression — and, on the hot records,
+    // through the exact sums; the results must not change)
+    if (const char* e = getenv("PLI_ALIGN_MARGIN_DEG")) margin = std::max(0.05, std::min(20.0, atof(e))) * 3.14159265358979323846 / 180;
+    P.hotBand2 = 0.0;
+    if (const char* e = getenv("PLI_TX_HOT_BAND2")) P.hotBand2 = std::max(0.0, atof(e));              // test switch: 10 = the exact sums at every event
+    P.rectApproxBand = 2e-3;
+    if (const char* e = getenv("PLI_RECT_APPROX_BAND")) P.rectApproxBand = std::max(2e-3, atof(e));     // test switch: 10 = every region
     P.alignFilter = (P.prec + margin < 1.5) && (P.prec - margin > 0.01);
     const double cl = std::cos(P.prec + margin), ch = std::cos(P.prec - margin);
     // (without the filter: every candidate is a "maybe", none is "sure")
@@ -885,7 +892,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   if (const char* e = getenv("PLI_TX_PACK1")) packMode = std::min(packMode, std::max(0, atoi(e)));
   // round 6: round 1's words in 8-byte hot records of their own (lsd_tile.hip "HOT RECORDS"); dev switch PLI_TX_HOT=0 / 1
   bool hotMode = false;                                   // (not the default until the parity sweeps have run on it)
-  if (const char* e = getenv("PLI_TX_HOT")) hotMode = atoi(e) != 0 && packMode != 0 && c->hot != nullptr && P.prec <= 1.0;
+  if (const char* e = getenv("PLI_TX_HOT")) hotMode = atoi(e) != 0 && packMode != 0 && c->hot != nullptr && P.prec <= 1.0 && P.alignFilter != 0;
   int2* hotPlane = hotMode ? c->hot : (int2*)nullptr;
   const int trigF32 = ((c->cfg.parity_flags & PLI_PARITY_TRIG_F32_LSD) ? 1 : 0) | (packMode == 2 ? 2 : 0);
   if (c->lsdF64) {
@@ -1927,6 +1934,21 @@ pli_status pli_line_extract(pli_ctx* c, int32_t eye, const uint8_t* img, int32_t
     if (kl) HIPCHK(hipMemcpy(kl, c->ownTable + Y.off_kl[eye], (size_t)N * sizeof(pli_keyline), hipMemcpyDeviceToHost));
     if (desc) HIPCHK(hipMemcpy(desc, c->ownTable + Y.off_ldesc[eye], (size_t)N * 32, hipMemcpyDeviceToHost));
   }
+  return PLI_OK;
+}
+
+pli_status pli_selftest_hot_trig(pli_ctx* c, double* max_abs_err) {
+  CtxGuard guard__(c);
+  if (!c || !max_abs_err) { g_err = "bad argument"; return PLI_ERR_INVALID; }
+  HIPCHK(hipSetDevice(c->device));
+  pli_status st = ensureScratch(c, 256);
+  if (st != PLI_OK) return st;
+  HIPCHK(hipMemsetAsync(c->scratch, 0, 8, c->stream));
+  LAUNCH(c, "k_tx_hot_trig_err", k_tx_hot_trig_err, dim3(4096), dim3(256), 0, (unsigned long long*)c->scratch);
+  unsigned long long bits = 0;
+  HIPCHK(hipMemcpyAsync(&bits, c->scratch, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  std::memcpy(max_abs_err, &bits, 8);
   return PLI_OK;
 }
 

@@ -320,6 +320,12 @@ class Frontend:
         check(self.L.pli_lsd_round_stats(self.h, out))
         return tuple(int(v) for v in out)
 
+    def selftest_hot_trig(self):
+        """Largest |v_cos / v_sin - cos / sin| over every float angle in [0, 360] degrees on this device (pli_selftest_hot_trig)."""
+        out = C.c_double()
+        check(self.L.pli_selftest_hot_trig(self.h, C.byref(out)))
+        return out.value
+
     def sync(self):
         check(self.L.pli_ctx_sync(self.h))
 

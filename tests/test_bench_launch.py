@@ -34,6 +34,11 @@ def test_gpus8_config4_is_32_frames_per_rank_and_256_records_at_the_root():
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 8 and d["shards_ok"] is True
     assert d["batch_frames"] == 256 and d["shard_frames"] == [32] * 8
+    # the line proves who took part: eight ranks counted by an all-reduce, eight distinct identities, every rank's own time
+    r = d["ranks"]
+    assert r["ranks_seen"] == 8 and r["distinct_devices"] == 8 and r["one_device_per_rank"] and not r["rehearsal_on_shared_device"]
+    assert len(r["per_rank_ms"]["all"]) == 8 and r["per_rank_ms"]["max"] == max(r["per_rank_ms"]["all"])
+    assert r["per_rank_ms"]["all"][r["per_rank_ms"]["slowest_rank"]] == r["per_rank_ms"]["max"]
     assert d["gathered_bytes_per_step"] == 256 * 4096
 
 

@@ -1248,6 +1248,58 @@ def test_round1_owner_word_forms(gpu, monkeypatch):
                 assert out[what][f][k].tobytes() == out["lazy"][f][k].tobytes(), (what, f, k)
 
 
+def test_hot_records_hardware_trig_error_is_inside_the_budget(gpu):
+    """Round 1 on the 8-byte hot records runs its vector filter on v_cos_f32 / v_sin_f32 (lsd_tile.hip "HOT RECORDS"); the error
+    budget that keeps the filter's decisions inside the margin of the exact expression assumes |error| < 4e-6 for every float angle."""
+    g = gpu
+    fe = g.Frontend(g.capi.default_config(128, 128))
+    err = fe.selftest_hot_trig()
+    assert 0.0 < err < 4e-6, err
+
+
+def test_hot_records_round1(gpu, monkeypatch):
+    """Round 1 of the tile relaxation on 8-byte hot records {level-line angle, owner word} (PLI_TX_HOT; lazy ids / key mode and
+    sort-written ids / rank mode): the oracle's lines, byte for byte — also when a wide filter margin sends a third of the candidates
+    through the exact expression (and so through the exact sums folded from the 16-byte records in the middle of a region's growth),
+    when region2rect recomputes the exact sums for EVERY region, with 32-pixel tiles, without the tail kernel, on the stripes image
+    (regions of thousands of pixels: the queue's overflow blocks and the resynchronisation of the filter's sums), and against the
+    16-byte records of the same build."""
+    g = gpu
+    W, H = 752, 480
+    cfg = g.capi.default_config(W, H, orb_nfeatures=300, lsd_nfeatures=0, max_frames=3)
+    pairs = [g.synth.make_stereo_pair(290 + i, W, H) for i in range(2)]
+    yy, xx = np.mgrid[0:H, 0:W]
+    stripes = (((xx + yy // 3) // 7) % 2 * 170 + 40).astype(np.uint8)
+    pairs.append((stripes, np.ascontiguousarray(stripes[:, ::-1])))
+    imgs = np.stack([np.stack(p) for p in pairs])
+    keys = ("PLI_TX_HOT", "PLI_TX_KEYS", "PLI_ALIGN_MARGIN_DEG", "PLI_RECT_APPROX_BAND", "PLI_TX_TS", "PLI_TX_TAIL", "PLI_RX_ARENA", "PLI_TX_HOT_BAND2")
+    out = {}
+    for what, env in (("rec16", {"PLI_TX_HOT": "0"}), ("hot", {"PLI_TX_HOT": "1"}), ("hot_ranks", {"PLI_TX_HOT": "1", "PLI_TX_KEYS": "0"}),
+                      ("hot_wide_margin", {"PLI_TX_HOT": "1", "PLI_ALIGN_MARGIN_DEG": "4"}),
+                      ("hot_wide_margin_ranks", {"PLI_TX_HOT": "1", "PLI_ALIGN_MARGIN_DEG": "8", "PLI_TX_KEYS": "0", "PLI_TX_TAIL": "0"}),
+                      ("hot_rect_exact", {"PLI_TX_HOT": "1", "PLI_RECT_APPROX_BAND": "10"}),
+                      # (the second band off: every candidate inside the margin takes the exact sums)
+                      ("hot_every_event_exact", {"PLI_TX_HOT": "1", "PLI_TX_HOT_BAND2": "10", "PLI_ALIGN_MARGIN_DEG": "4"}),
+                      ("hot_ts32_arena3", {"PLI_TX_HOT": "1", "PLI_TX_TS": "32", "PLI_RX_ARENA": "3", "PLI_ALIGN_MARGIN_DEG": "1"})):
+        for k in keys:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        fe = g.Frontend(cfg)
+        fe.batch_run_host(imgs)
+        out[what] = fe.batch_run_host(imgs)
+        if "arena3" not in what:
+            assert fe.lsd_round_stats()[2] == 0, (what, fe.lsd_round_stats())      # nobody on the slow path
+    for k in keys:
+        monkeypatch.delenv(k, raising=False)
+    assert len(out["hot"][0]["klL"]) > 100
+    for f, (L, R) in enumerate(pairs):
+        assert_frame_equal(g, out["hot"][f], g.po.Frame(ocfg(g, cfg)), L, R, "hot records frame %d" % f)
+        for what in out:
+            for k in ("klL", "klR", "ldescL", "ldescR", "disp", "le"):
+                assert out[what][f][k].tobytes() == out["hot"][f][k].tobytes(), (what, f, k)
+
+
 def test_frame_extract_equals_the_per_call_entry_points(cfg2):
     """pli_frame_extract (what the adapters fuse the four extractor threads of a Frame into) against the four per-call entry points
     and the two stereo matchers: the same record, and the per-call state it leaves (pyramid levels, stereo matchers without a rerun)."""

@@ -7,7 +7,8 @@ bits are compared), both detector pipelines (parity_flags default and 0), batche
     tile       the tile relaxation's variants: tail kernel from round 8 / 3 / none, speculative round 1, tiles of 16 / 32,
                region ids as ranks instead of keys, round 1's owner word in the owner plane / written by the sort / lazy with every
                unclaimed pixel through the exact test; two calls per context (the second plans from the first)  (the round-3 sweep)
-    sizes      four image sizes, lsd_mode 1 and 2, one image per call                              (the round-1 sweep)"""
+    sizes      four image sizes, lsd_mode 1 and 2, one image per call                              (the round-1 sweep)
+    hot        round 1 of the tile relaxation on the 8-byte hot records (round 6): key / rank mode, wide filter margin, exact rect sums"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from concurrent.futures import ThreadPoolExecutor
@@ -31,6 +32,12 @@ SETS = {
         ("ranks", {"PLI_TX_KEYS": "0"}), ("ranks_no_tail_ts32", {"PLI_TX_KEYS": "0", "PLI_TX_TAIL": "0", "PLI_TX_TS": "32"}),
         ("owner_plane", {"PLI_TX_PACK1": "0"}), ("sort_written", {"PLI_TX_PACK1": "1"}), ("lazy_all_exact", {"PLI_TX_LAZY_MARGIN": "2000000"}),
         ("block_rounds", {"PLI_TX_CELLS": "0"}), ("cells_no_tail", {"PLI_TX_CELLS": "1", "PLI_TX_TAIL": "0"}))],
+    # round 6: round 1 on the 8-byte hot records against the 16-byte ones, key and rank mode, a wide filter margin (the exact sums
+    # folded in mid-growth), region2rect's exact sums for every region
+    "hot": [(n, {"lsd_mode": 3}, e) for n, e in (
+        ("rec16", {"PLI_TX_HOT": "0"}), ("hot", {"PLI_TX_HOT": "1"}), ("hot_ranks", {"PLI_TX_HOT": "1", "PLI_TX_KEYS": "0"}),
+        ("hot_margin2", {"PLI_TX_HOT": "1", "PLI_ALIGN_MARGIN_DEG": "2"}), ("hot_margin2_all_exact", {"PLI_TX_HOT": "1", "PLI_ALIGN_MARGIN_DEG": "2", "PLI_TX_HOT_BAND2": "10"}), ("hot_rect_exact", {"PLI_TX_HOT": "1", "PLI_RECT_APPROX_BAND": "10"}),
+        ("hot_ts32_no_tail", {"PLI_TX_HOT": "1", "PLI_TX_TS": "32", "PLI_TX_TAIL": "0"}))],
 }
 bad = 0
 if which == "sizes":
