@@ -467,7 +467,7 @@ def main():
     # (config 3 on several ranks: the frame-to-frame matcher also sees the halo frame of the previous shard)
     cfg = capi.default_config(W, H, orb_nfeatures=nfeat, lsd_nfeatures=nlines, max_frames=Fmax + (1 if (args.config == 3 and multi) else 0),
                               lsd_mode=args.lsd_mode)
-    fe = Frontend(cfg, device=local_rank)
+    fe = Frontend(cfg, device=local_rank, dev=False)      # (the product library: PLI_USE_DEV_LIB=1 — the tools — swaps in the development build)
     # synthetic stream: up to --unique-frames distinct seeded stereo pairs per rank (seeds disjoint across ranks), cycled to F
     # frames; config 3: consecutive frames t = 0..nuniq-1 of ONE scene (the motion of synth.make_stereo_pair)
     nuniq = min(F, args.unique_frames)
@@ -733,8 +733,10 @@ def main():
                        "baseline_config": args.config or None, "frames_per_gpu": F, "bytes_per_frame": b_frame,
                        "parallelism": "frame-batch data parallel, %d rank(s), gather of result tables to rank 0" % world},
             "roofline": roof,
+            "library": os.path.basename(getattr(fe.L, "_name", "?")),
         }
         rs = fe.lsd_round_stats()
+        out["lsd_arena_words_per_pixel"] = fe.lsd_arena_words() if hasattr(fe.L, "pli_lsd_arena_words") else None
         out["lsd_rounds"] = {"launched_without_host_look": rs[0], "needed_by_slowest_image": rs[1], "images_redone_by_device_fallback": rs[2],
                              "note": "relaxation rounds per step; an image that has not settled after the launched rounds is redone on the "
                                      "device by the sequential grower (exact, slow): needed = -1 would flag it"}
@@ -769,7 +771,7 @@ def main():
         if not multi and not args.no_cpu_baseline:
             # BASELINE.json configs[1] (a single stereo pair) beside the batch: latency of one pair through the same library
             if F > 1 and (W, H) == (752, 480):
-                f1 = Frontend(capi.default_config(W, H, orb_nfeatures=nfeat, lsd_nfeatures=nlines, max_frames=1), device=local_rank)
+                f1 = Frontend(capi.default_config(W, H, orb_nfeatures=nfeat, lsd_nfeatures=nlines, max_frames=1), device=local_rank, dev=False)
                 f1.set_stream(torch.cuda.current_stream().cuda_stream)
                 t1 = torch.zeros(rec_bytes, dtype=torch.uint8, device=dev)
                 for rep in range(12):
@@ -817,7 +819,7 @@ def large_batch_leg(capi, Frontend, nfeat, nlines, lsd_mode, device, d_uniq, nun
     import torch
     dev = d_uniq.device
     F = LARGE_BATCH
-    fe = Frontend(capi.default_config(W, H, orb_nfeatures=nfeat, lsd_nfeatures=nlines, max_frames=F, lsd_mode=lsd_mode), device=device)
+    fe = Frontend(capi.default_config(W, H, orb_nfeatures=nfeat, lsd_nfeatures=nlines, max_frames=F, lsd_mode=lsd_mode), device=device, dev=False)
     fe.set_stream(torch.cuda.current_stream().cuda_stream)
     d_img = d_uniq[torch.arange(F, device=dev) % nuniq].contiguous()
     d_left, d_right = d_img[:, 0].contiguous(), d_img[:, 1].contiguous()

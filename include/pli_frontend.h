@@ -293,6 +293,12 @@ pli_status pli_line_extract(pli_ctx* ctx, int32_t eye,
  *   out[3] the round count the next call plans from */
 pli_status pli_lsd_round_stats(pli_ctx* ctx, int32_t out[4]);
 
+/* Words of arena per scaled LSD pixel the context's relaxation got (region pixel lists and queue overflow blocks): 16 unless the
+ * context is large or the device was short of free memory when it was created (then 3..15: results are unchanged, but batches of
+ * long parallel structures may run out of it and take the slow device-side fallback, counted in pli_lsd_round_stats out[2]; the
+ * library says so once on stderr); 0 for lsd_mode 2. */
+pli_status pli_lsd_arena_words(pli_ctx* ctx, int32_t* words_per_pixel);
+
 /* Self-test of the device the context runs on (not a reference function): the largest absolute error of the hardware cosine / sine
  * (v_cos_f32 / v_sin_f32 of angle / 360) against cos / sin of EVERY float angle in [0, 360] degrees.  Round 1 of the LSD tile
  * relaxation runs its vector filter on those (csrc/lsd_tile.hip "HOT RECORDS"); its error budget assumes 4e-6, and the GPU suite

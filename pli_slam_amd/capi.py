@@ -11,7 +11,12 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("PLI_LIB_PATH") or os.path.join(_HERE, "csrc", "libpli_frontend.so")      # (PLI_LIB_PATH: dev builds, e.g. -DLSD_STATS)
+# The product library and its development build (-DPLI_DEV: the shelved schedules and the test / tuning switches of tools/README.md,
+# read from the environment — the product library reads four documented variables and nothing else).  PLI_LIB_PATH (Python side):
+# another build in place of both (tools/build_variant.sh); PLI_USE_DEV_LIB=1: the development build wherever the product one is asked
+# for (the tools that run bench.py under environment switches).
+LIB_PATH = os.environ.get("PLI_LIB_PATH") or os.path.join(_HERE, "csrc", "libpli_frontend.so")
+DEV_LIB_PATH = os.environ.get("PLI_LIB_PATH") or os.path.join(_HERE, "csrc", "libpli_frontend_dev.so")
 
 KEYPOINT_DT = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                         ("response", "<f4"), ("octave", "<i4")])
@@ -82,6 +87,7 @@ class PliError(RuntimeError):
 
 
 _lib = None
+_dev_lib = None
 
 _PROTOS = {
     "pli_config_default": (None, [C.POINTER(Config), C.c_int32, C.c_int32]),
@@ -114,6 +120,7 @@ _PROTOS = {
                                      C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]),
     "pli_lsd_round_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
     "pli_selftest_hot_trig": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double)]),
+    "pli_lsd_arena_words": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
     "pli_set_stereo_camera": (C.c_int32, [C.c_void_p, C.c_float, C.c_float]),
     "pli_last_counts": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
     "pli_stereo_match_points": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
@@ -165,27 +172,37 @@ def exported_symbols():
     return sorted(_PROTOS)
 
 
-def lib():
-    """Load libpli_frontend.so; raise if it has not been built."""
-    global _lib
+def _load(path):
+    if not os.path.exists(path):
+        raise RuntimeError("%s is not built (python -c 'import __graft_entry__ as g; g.build()'); the front-end has no CPU fallback"
+                           % os.path.basename(path))
+    L = C.CDLL(path)
+    for name, (res, args) in _PROTOS.items():
+        if os.environ.get("PLI_LIB_PATH") and not hasattr(L, name):
+            continue        # (an A/B build of an earlier round, tools/ab_libs.sh: it lacks the entry points added since)
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    return L
+
+
+def lib(dev=False):
+    """Load libpli_frontend.so (dev: libpli_frontend_dev.so); raise if it has not been built."""
+    global _lib, _dev_lib
+    if dev or os.environ.get("PLI_USE_DEV_LIB", "0") not in ("", "0"):
+        if _dev_lib is None:
+            _dev_lib = _load(DEV_LIB_PATH)
+        return _dev_lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError("libpli_frontend.so is not built (python -c 'import __graft_entry__ as g; g.build()'); "
-                               "the front-end has no CPU fallback")
-        L = C.CDLL(LIB_PATH)
-        for name, (res, args) in _PROTOS.items():
-            if os.environ.get("PLI_LIB_PATH") and not hasattr(L, name):
-                continue        # (an A/B build of an earlier round, tools/ab_libs.sh: it lacks the entry points added since)
-            fn = getattr(L, name)
-            fn.restype = res
-            fn.argtypes = args
-        _lib = L
+        _lib = _load(LIB_PATH)
     return _lib
 
 
 def check(status):
     if status != PLI_OK:
-        raise PliError(status, lib().pli_last_error().decode("utf-8", "replace"))
+        # (the message is thread-local state of the library that failed: with both builds loaded, the one that has a message)
+        msgs = [L.pli_last_error().decode("utf-8", "replace") for L in (_lib, _dev_lib) if L is not None]
+        raise PliError(status, " | ".join(m for m in msgs if m) or "?")
 
 
 def default_config(width, height, **over):

@@ -145,6 +145,7 @@ struct TxKeys {
   int* zeroB = nullptr;
   int lazyMargin = 8;               // LAZY ids: units of the 2^-22 fixed point around a bin boundary that the double plane decides (>= 4; test switch)
   int2* hot = nullptr;              // round 6: round 1's words live in 8-byte hot records {angle, owner word} instead (lsd_tile.hip "HOT RECORDS")
+  const float2* cold = nullptr;     // ... and the records' exact {cos, sin} in a plane of their own when the 16-byte records are not written
   int pack = 0;                     // 0: owner plane; 1: k_tx_sort writes the unclaimed words (ids); 2: the front pass wrote them (LAZY ids)
 };
 
@@ -175,6 +176,8 @@ struct TxTailArgs {
   int img0, nimg, t0, maxRounds;
   unsigned* bar;       // [0] arrivals (zeroed by the host before the launch), [32] abort word (its own line)
   int forceAbort = 0;  // test switch: behave as if the first grid barrier had timed out
+  int2* hot = nullptr; // the hot records {angle, ..}: the growers take the angles from there (and `rec` is not read), or null
+  const float2* cold = nullptr;   // ... with the exact {cos, sin} plane beside them
 };
 
 // a region in mid-growth, handed from the lane grower to the wave grower

@@ -110,7 +110,7 @@ __device__ __forceinline__ void glibc_sincosf(float y, float* sn, float* cs) {
 __device__ __forceinline__ void sincos_of_float(float a, bool f32, float* sn, float* cs) {
   if (f32) glibc_sincosf(a, sn, cs);
   else {
-#if defined(PLI_DIAG_NOSINCOS)      // (diagnostic build, wrong results: what the double sincos costs the front pass)
+#if defined(PLI_DIAG_NOSINCOS) && defined(PLI_DEV)      // (diagnostic development build, wrong results: what the double sincos costs the front pass)
     *sn = a * 0.25f; *cs = 1.f - a * 0.125f;
 #else
     double s, c;

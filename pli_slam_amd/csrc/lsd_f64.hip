@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void k_lsd_grad64(const double* __restrict__ s
                                                     float4* __restrict__ rec, double* __restrict__ mg, int2* __restrict__ own,
                                                     unsigned long long* __restrict__ maxMg, float* __restrict__ angDbg, int img0,
                                                     int flags /* bit 0: PLI_PARITY_TRIG_F32_LSD; bit 1: rec.w = tx_unclaimed_norm_word */,
-                                                    int2* __restrict__ hot /* or null: round 1's 8-byte hot records {angle, owner word} (lsd_tile.hip) */) {
+                                                    int2* __restrict__ hot /* or null: round 1's 8-byte hot records {angle, owner word} (lsd_tile.hip) */,
+                                                    float2* __restrict__ cold /* or null: {cos, sin} beside the hot records when rec is not written */) {
   const int trigF32 = flags & 1;
   const bool packW = (flags & 2) != 0;
   __shared__ unsigned long long wmax[4];
@@ -99,8 +100,9 @@ __global__ __launch_bounds__(256) void k_lsd_grad64(const double* __restrict__ s
         }
       }
       const int64_t o = (int64_t)img * W * H + (int64_t)y * W + x;
-      rec[o] = make_float4(a, cx, sy, (packW && !hot) ? tx_unclaimed_norm_word(norm) : 0.f);
+      if (rec) rec[o] = make_float4(a, cx, sy, (packW && !hot) ? tx_unclaimed_norm_word(norm) : 0.f);
       if (hot) hot[o] = make_int2(__float_as_int(a), packW ? __float_as_int(tx_unclaimed_norm_word(norm)) : 0);
+      if (cold) cold[o] = make_float2(a == F64_NOTDEF ? F64_NOTDEF : cx, sy);      // (cos = NOTDEF: no level-line angle)
       mg[o] = norm;
       if (own) own[o] = make_int2(0x7FFFFFFF, 0x7FFFFFFF);
       if (angDbg) angDbg[o] = a;
@@ -136,7 +138,7 @@ __device__ __forceinline__ void lsd_front64_tile(const uint8_t* __restrict__ pyr
                                                  const double* __restrict__ kern, int radius, const int* __restrict__ tab,
                                                  int dw, int dh, double rho, float4* __restrict__ rec, double* __restrict__ mg,
                                                  int2* __restrict__ own, unsigned long long* __restrict__ maxMg, int img0, int flags,
-                                                 int2* __restrict__ hot, uint8_t (*tile)[FS_W + 2 * FR + 2], double (*rows)[FS_W], double (*blur)[FS_W],
+                                                 int2* __restrict__ hot, float2* __restrict__ cold, uint8_t (*tile)[FS_W + 2 * FR + 2], double (*rows)[FS_W], double (*blur)[FS_W],
                                                  unsigned long long* wmax) {
   const int trigF32 = flags & 1;
   const bool packW = (flags & 2) != 0;
@@ -244,8 +246,9 @@ __device__ __forceinline__ void lsd_front64_tile(const uint8_t* __restrict__ pyr
       }
     }
     const int64_t o = (int64_t)img * dw * dh + (int64_t)y * dw + x;
-    rec[o] = make_float4(a, cx, sy, (packW && !hot) ? tx_unclaimed_norm_word(norm) : 0.f);
+    if (rec) rec[o] = make_float4(a, cx, sy, (packW && !hot) ? tx_unclaimed_norm_word(norm) : 0.f);      // (null: every round runs on the hot records)
     if (hot) hot[o] = make_int2(__float_as_int(a), packW ? __float_as_int(tx_unclaimed_norm_word(norm)) : 0);
+    if (cold) cold[o] = make_float2(a == F64_NOTDEF ? F64_NOTDEF : cx, sy);      // (cos = NOTDEF: no level-line angle)
     mg[o] = norm;
     if (own) own[o] = make_int2(0x7FFFFFFF, 0x7FFFFFFF);
   }
@@ -263,13 +266,14 @@ __global__ __launch_bounds__(256) void k_lsd_front64(const uint8_t* __restrict__
                                                      const double* __restrict__ kern, int radius, const int* __restrict__ tab,
                                                      int dw, int dh, double rho, float4* __restrict__ rec, double* __restrict__ mg,
                                                      int2* __restrict__ own, unsigned long long* __restrict__ maxMg, int img0,
-                                                     int flags /* as k_lsd_grad64 */, int2* __restrict__ hot /* as k_lsd_grad64 */) {
+                                                     int flags /* as k_lsd_grad64 */, int2* __restrict__ hot /* as k_lsd_grad64 */,
+                                                     float2* __restrict__ cold /* as k_lsd_grad64 */) {
   __shared__ uint8_t tile[FS_H + 2 * FR][FS_W + 2 * FR + 2];
   __shared__ double rows[FS_H + 2 * FR][FS_W];               // row-filtered window; afterwards the scaled tile (scl)
   __shared__ double blur[FS_H][FS_W];
   __shared__ unsigned long long wmax[4];
-  if (radius == FR) lsd_front64_tile<FR>(pyr, pyrBlock, sw, sh, pitch, kern, radius, tab, dw, dh, rho, rec, mg, own, maxMg, img0, flags, hot, tile, rows, blur, wmax);
-  else lsd_front64_tile<0>(pyr, pyrBlock, sw, sh, pitch, kern, radius, tab, dw, dh, rho, rec, mg, own, maxMg, img0, flags, hot, tile, rows, blur, wmax);
+  if (radius == FR) lsd_front64_tile<FR>(pyr, pyrBlock, sw, sh, pitch, kern, radius, tab, dw, dh, rho, rec, mg, own, maxMg, img0, flags, hot, cold, tile, rows, blur, wmax);
+  else lsd_front64_tile<0>(pyr, pyrBlock, sw, sh, pitch, kern, radius, tab, dw, dh, rho, rec, mg, own, maxMg, img0, flags, hot, cold, tile, rows, blur, wmax);
 }
 
 }  // namespace pli

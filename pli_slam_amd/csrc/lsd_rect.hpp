@@ -36,7 +36,9 @@ __device__ __forceinline__ void rx_wave_sync() {
 template <int LANES>
 __device__ __forceinline__ void rx_rect_region(bool on, const RxRect& it, const DevParams& P, const float4* __restrict__ rec,
                                                const double* __restrict__ mg, const int* __restrict__ arena,
-                                               float4* __restrict__ rgSeg, double (*st)[64], double (*wc)[64], int (*ec)[64], int rmask) {
+                                               float4* __restrict__ rgSeg, double (*st)[64], double (*wc)[64], int (*ec)[64], int rmask,
+                                               const int2* __restrict__ hot = nullptr /* the 8-byte hot records {angle, ..}, or null */,
+                                               const float2* __restrict__ cold = nullptr /* ... and the exact {cos, sin} beside them, or null: rec */) {
   // wc / ec: the weights and the packed coordinates of the first RX_RECT_CACHE chunks of the list, kept in LDS by the first pass: the
   // second pass and the end-point pass read them there instead of walking list entry -> weight through global memory again (two
   // dependent round trips per chunk and pass; most regions fit the cache: 46 pixels on average)
@@ -125,7 +127,7 @@ __device__ __forceinline__ void rx_rect_region(bool on, const RxRect& it, const 
   // which side of `prec` the inertia axis lies —, so the approximate one decides unless the difference is within rectApproxBand (2e-3 rad)
   // of prec; there (one region in a thousand) the group sums the exact cos / sin of the 16-byte records in list order, as region_grow does.
   {
-    const bool need = on && it.approx != 0 && fabs(adiff - prec) < P.rectApproxBand;
+    const bool need = on && it.approx != 0 && hot != nullptr && fabs(adiff - prec) < P.rectApproxBand;
     if (__builtin_amdgcn_ballot_w64(need)) {
       int cm = need ? cnt : 0;
 #pragma unroll
@@ -136,12 +138,19 @@ __device__ __forceinline__ void rx_rect_region(bool on, const RxRect& it, const 
         float cy = 0.f, cz = 0.f;
         if (need && kk < cnt) {
           const int e = lst[kk];
-          const float4 r = rec[(e >> 16) * W + (e & 0xFFFF)];
-          cy = r.y; cz = r.z;
+          // (approx is only ever set by the growers of the hot records: the angle comes from there, the exact pair from the cold plane —
+          // or from the 16-byte record where the front pass still writes it)
+          const int p = (e >> 16) * W + (e & 0xFFFF);
           if (kk == 0) {                                  // the seed: region_grow starts its sums with cos / sin of the unrounded double angle
             double sn, cs;
-            sincos((double)r.x * RX_DEG2RAD, &sn, &cs);
+            sincos((double)__int_as_float(hot[p].x) * RX_DEG2RAD, &sn, &cs);
             cy = (float)cs; cz = (float)sn;
+          } else if (cold) {
+            const float2 cp = cold[p];
+            cy = cp.x; cz = cp.y;
+          } else {
+            const float4 r = rec[p];
+            cy = r.y; cz = r.z;
           }
         }
         for (int j = 0; j < LANES; ++j) {
@@ -183,7 +192,8 @@ __device__ __forceinline__ void rx_rect_region(bool on, const RxRect& it, const 
 __device__ __forceinline__ void rx_rect_wave(const DevParams& P, const RxCtl& c, const float4* __restrict__ rec, const double* __restrict__ mg,
                                              const int* __restrict__ arena, const RxRect* __restrict__ rects, int rectCap,
                                              float4* __restrict__ rgSeg, int first, int stride, double (*st)[64], double (*wc)[64],
-                                             int (*ec)[64], int rmask = -1) {
+                                             int (*ec)[64], int rmask = -1, const int2* __restrict__ hot = nullptr,
+                                             const float2* __restrict__ cold = nullptr) {
   const int nrect = min((int)(c.rectArena >> RX_ARENA_BITS), rectCap);
   const int lane = threadIdx.x & 63, g = lane >> 4;
   for (int w0 = first * 4; w0 < nrect; w0 += stride * 4) {
@@ -191,7 +201,7 @@ __device__ __forceinline__ void rx_rect_wave(const DevParams& P, const RxCtl& c,
     const bool have = w0 + g < nrect;
     if (have) it = rects[w0 + g];
     const bool small = have && it.cnt <= RX_RECT_GROUP_MAX;
-    if (__builtin_amdgcn_ballot_w64(small)) rx_rect_region<16>(small, it, P, rec, mg, arena, rgSeg, st, wc, ec, rmask);
+    if (__builtin_amdgcn_ballot_w64(small)) rx_rect_region<16>(small, it, P, rec, mg, arena, rgSeg, st, wc, ec, rmask, hot, cold);
     unsigned long long big = __builtin_amdgcn_ballot_w64(have && !small) & 0x0001000100010001ull;   // one bit per group
     while (big) {
       const int gl0 = __ffsll((long long)big) - 1;
@@ -199,7 +209,7 @@ __device__ __forceinline__ void rx_rect_wave(const DevParams& P, const RxCtl& c,
       RxRect bt;
       bt.rank = __shfl(it.rank, gl0, 64); bt.off = __shfl(it.off, gl0, 64); bt.cnt = __shfl(it.cnt, gl0, 64);
       bt.sumdx = __shfl(it.sumdx, gl0, 64); bt.sumdy = __shfl(it.sumdy, gl0, 64); bt.approx = __shfl(it.approx, gl0, 64);
-      rx_rect_region<64>(true, bt, P, rec, mg, arena, rgSeg, st, wc, ec, rmask);
+      rx_rect_region<64>(true, bt, P, rec, mg, arena, rgSeg, st, wc, ec, rmask, hot, cold);
     }
   }
 }

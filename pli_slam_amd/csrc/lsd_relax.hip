@@ -74,6 +74,10 @@ __device__ __forceinline__ int rx_block_append(bool flag, int* counter, int* lds
   return pos;
 }
 
+// Everything from here to k_rx_rect is the LANE relaxation (lsd_mode 1: round 1's schedule, one region per lane / lane group, and its
+// bookkeeping passes, which the tile relaxation's unfused dev switches also launch): kept for cross-checks, compiled into the
+// development build only (make dev, -DPLI_DEV).  The product library has k_rx_rect / k_rx_count / k_rx_emit of this file.
+#ifdef PLI_DEV
 // ---- setup -------------------------------------------------------------------------------------
 // (the rank plane — rank of every pixel, LSD_ID_INF where undefined — is written by k_lsd_scatter, line_kernels.hip)
 
@@ -826,10 +830,14 @@ __global__ __launch_bounds__(64) void k_rx_grow_wave(const DevParams* __restrict
                            rectAll, rectCap, img0, t);
 }
 
+#endif   // PLI_DEV
+
 __global__ __launch_bounds__(64) void k_rx_rect(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
                                                 const float4* __restrict__ recAll, const int* __restrict__ arenaAll,
                                                 int arenaCap, const RxRect* __restrict__ rectAll, int rectCap,
-                                                float4* __restrict__ rgSegAll, int img0, const double* __restrict__ mgAll, int rmask) {
+                                                float4* __restrict__ rgSegAll, int img0, const double* __restrict__ mgAll, int rmask,
+                                                const int2* __restrict__ hotAll /* or null: the hot records (regions with approximate sums) */,
+                                                const float2* __restrict__ coldAll /* or null: the exact {cos, sin} plane beside them */) {
   __shared__ double st[3][64];
   __shared__ double wc[RX_RECT_CACHE][64];
   __shared__ int ec[RX_RECT_CACHE][64];
@@ -839,7 +847,8 @@ __global__ __launch_bounds__(64) void k_rx_rect(const DevParams* __restrict__ Pp
   if (c.state == 2 || c.overflow) return;
   const int64_t npix = (int64_t)P.LW * P.LH;
   rx_rect_wave(P, c, recAll + img * npix, mgAll ? mgAll + img * npix : nullptr /* CV_64F pipeline: the gradient norm as a double plane */,
-               arenaAll + (int64_t)img * arenaCap, rectAll + (int64_t)img * rectCap, rectCap, rgSegAll + img * npix, blockIdx.x, gridDim.x, st, wc, ec, rmask);
+               arenaAll + (int64_t)img * arenaCap, rectAll + (int64_t)img * rectCap, rectCap, rgSegAll + img * npix, blockIdx.x, gridDim.x, st, wc, ec, rmask,
+               hotAll ? hotAll + img * npix : nullptr, coldAll ? coldAll + img * npix : nullptr);
 }
 
 // ---- segments in seed-rank order (= detection order of the sequential algorithm) ------------------------

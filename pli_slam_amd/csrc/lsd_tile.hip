@@ -44,6 +44,11 @@ constexpr double TX_2PI = 2 * TX_PI;
 //   * the same bitmap only to skip the loads of seeds the wave itself has taken: a third of the L2 misses gone (854 M -> 577 M),
 //     time unchanged.  (What binds the round-1 grower, as far as rounds 4 and 5 could separate it: VALU issue time — 71 % of the
 //     chip's —, the two dependent trips of a step at 8 waves per SIMD, and the gather rate, in comparable shares: DESIGN.md 5 "Round 5".)
+// (the diagnostic macros of this file — TX_CLAIM_SCOPE, TX_GROUP, TX_OWN_LOAD, TX_DIAG_PAD, TX_DIAG_NOWAIT, TX_DIAG_HOT_NOFOLD — belong to
+// development builds: tools/build_variant.sh passes -DPLI_DEV with them)
+#if !defined(PLI_DEV) && (defined(TX_CLAIM_SCOPE) || defined(TX_GROUP) || defined(TX_OWN_LOAD) || defined(TX_DIAG_PAD) || defined(TX_DIAG_NOWAIT) || defined(TX_DIAG_HOT_NOFOLD))
+#error "diagnostic builds of lsd_tile.hip need -DPLI_DEV"
+#endif
 #ifndef TX_CLAIM_SCOPE             // (diagnostic builds only: -DTX_CLAIM_SCOPE=__HIP_MEMORY_SCOPE_WORKGROUP times the claims as L2 atomics —
 #define TX_CLAIM_SCOPE __HIP_MEMORY_SCOPE_AGENT   // NOT coherent between the XCDs' L2s, so not exact unless an image stays on one XCD)
 #endif
@@ -59,7 +64,7 @@ constexpr int TX_GQ = 768;        // queue entries of a region kept in LDS
 constexpr int TX_PARK = 4 * 64;   // the parked first-step records of a group: angle, cos, sin, owner_{t-1} per lane
 constexpr int TX_GQ_SPEC = 512;   // ... in the speculative round-1 kernel (its lanes' parked states take 2 KB of the wave's LDS)
 constexpr int TX_SPEC_CAP = 8;    // pixels a lane may take by itself before its region is handed to the whole wave (< minRegSize)
-constexpr int TX_HOT_RESYNC = 1024;   // hot records: pixels after which the filter's sums are replaced by the exact ones (tx_grow_tile)
+constexpr int TX_HOT_RESYNC = 2048;   // hot records: pixels after which the filter's sums are replaced by the exact ones (tx_grow_tile)
 constexpr int TX_BBLK = 256;      // arena block for the overflow of a large region's queue
 constexpr int TX_BMAXBLK = 128;   // => regions of up to TX_GQ + 32768 pixels
 
@@ -304,6 +309,7 @@ __global__ __launch_bounds__(256) void k_tx_sort(const int* __restrict__ rankAll
   else if (ts == 32) tx_sort_tile<4, 256>(rankAll, orderAll, ownAll, listAll, tileCntAll, W, H, ts, ntx, nty, img0, xch, keys);
   else tx_sort_tile<1, 256>(rankAll, orderAll, ownAll, listAll, tileCntAll, W, H, ts, ntx, nty, img0, xch, keys);
 }
+#ifdef PLI_DEV     // (dev switch PLI_TX_TS=128: measured, slower)
 // tiles of 128 x 128 (large batches): 1024 threads x 16 keys, 10 of the 105 stages through LDS
 __global__ __launch_bounds__(1024) void k_tx_sort128(const int* __restrict__ rankAll, const int* __restrict__ orderAll,
                                                      int2* __restrict__ ownAll, int2* __restrict__ listAll,
@@ -311,6 +317,7 @@ __global__ __launch_bounds__(1024) void k_tx_sort128(const int* __restrict__ ran
   __shared__ unsigned xch[16 * 1024 + 1024];
   tx_sort_tile<16, 1024>(rankAll, orderAll, ownAll, listAll, tileCntAll, W, H, ts, ntx, nty, img0, xch, keys);
 }
+#endif
 
 // ---------------------------------------------------------------------------
 // k_tx_diff2 (round 2 only; takes the place of k_rx_diff).  Round 1 ran against the trivial owner_0, so "what changed
@@ -338,6 +345,7 @@ __device__ __forceinline__ void tx_mark_dirty(int o, int t, int* __restrict__ rg
     for (int tx = tx0; tx <= tx1; ++tx) tileAct[ty * TW + tx] = t;
 }
 
+#ifdef PLI_DEV     // (the unfused round 2 of the dev switches PLI_TX_NOFUSE2 / PLI_TX_BOXRULE; the product's round 2 is k_tx_round2)
 __global__ __launch_bounds__(256) void k_tx_diff2(RxCtl* __restrict__ ctl, const int2* __restrict__ ownAll,
                                                   const int* __restrict__ orderAll, const int2* __restrict__ rgBoxAll,
                                                   int* __restrict__ rgDirtyAll, int* __restrict__ tileMinAll,
@@ -391,6 +399,7 @@ __global__ __launch_bounds__(256) void k_tx_diff2(RxCtl* __restrict__ ctl, const
     }
   }
 }
+#endif
 
 // ---------------------------------------------------------------------------
 // k_tx_round2 (round 2, lost-pixel rule): k_tx_diff2 and the round's k_tx_prep in one pass over the owner map.  Whether the
@@ -512,6 +521,7 @@ __global__ __launch_bounds__(256) void k_tx_reset_rect(RxCtl* __restrict__ ctl, 
 // lists the changed pixels of its changed cells in LDS, then spreads (changed pixel, neighbour) pairs over its threads, so the
 // dependent chain neighbour owner -> rgLost -> stamp runs once per block, not once per row of cells.
 // ---------------------------------------------------------------------------
+#ifdef PLI_DEV     // (the unfused marks of the dev switch PLI_TX_NOFUSEDM; the product runs k_tx_diffmark / the cell lists)
 __global__ __launch_bounds__(256) void k_tx_mark(RxCtl* __restrict__ ctl, const int2* __restrict__ ownAll,
                                                  const int* __restrict__ rankAll, const int2* __restrict__ rgBoxAll,
                                                  int* __restrict__ rgDirtyAll, const int* __restrict__ tileMinAll,
@@ -579,6 +589,7 @@ __global__ __launch_bounds__(256) void k_tx_mark(RxCtl* __restrict__ ctl, const 
   }
 }
 
+#endif
 // ---------------------------------------------------------------------------
 // k_tx_diffmark (rounds >= 3): k_rx_diff and k_tx_mark in one pass.  The cells whose two owner components can differ are the
 // ones tileTouch stamps with t-1 — the growers' claims of round t-1 and the cells k_tx_prep rewrote in round t-1 (it stamps
@@ -1055,7 +1066,7 @@ __device__ __forceinline__ int tx_pk_max_u16(int a, int b) {
 // carry the pixels' own ids (k_tx_sort wrote them); 2 (key mode): they carry the gradient norm (the front pass wrote them, LAZY ids).
 template <bool SPARSE, bool SPEC = false, int GQ = TX_GQ, int PACK = 0, bool HOT = false>
 __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
-                                             const float4* __restrict__ recAll, int2* __restrict__ ownAll,
+                                             const float4* recAll /* (no __restrict__: the packed round 1 claims into its fourth words) */, int2* __restrict__ ownAll,
                                              const int2* __restrict__ listAll, const int* __restrict__ tileCntAll,
                                              int ts, int ntx, int nty, int* __restrict__ rgSizeAll,
                                              int2* __restrict__ rgBoxAll, const int* __restrict__ rgDirtyAll,
@@ -1064,7 +1075,8 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
                                              int rectCap, int img, int tile, int t, const int* __restrict__ rankAll,
                                              int* __restrict__ rgLostAll, int* __restrict__ tileTouchAll,
                                              const TxDirtyLists& DL, int* q /* LDS, GQ */, int* gb /* LDS, TX_BMAXBLK */,
-                                             int* park /* LDS, TX_PARK (SPEC: 8 x 64) */, const TxKeys* keysp = nullptr /* PACK == 2 */) {
+                                             int* park /* LDS, TX_PARK (SPEC: 8 x 64) */, const TxKeys* keysp = nullptr /* PACK == 2 */,
+                                             int2* hotAll = nullptr /* HOT */, const float2* coldAll = nullptr /* HOT: or null (rec) */) {
   const DevParams& P = *Pp;
   RxCtl& c = ctl[img];
   if (c.state == 2 || c.overflow) return;
@@ -1112,10 +1124,31 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
     }
     if (!__builtin_amdgcn_ballot_w64(act)) return;
   }
-  static_assert(!HOT || PACK != 0, "the hot records carry round 1's packed owner word");
   const float4* rec = recAll + img * npix;
   int2* own = ownAll + img * npix;
-  int2* hot = HOT ? keysp->hot + img * npix : nullptr;      // (HOT: {level-line angle, owner word} per pixel)
+  // (HOT: {level-line angle, round 1's owner word} per pixel.  Round 1 — PACK — gathers and claims there; the later rounds take the
+  // angle from it and the owner pair from the owner plane: 4 + 8 bytes per neighbour instead of 16 + 8, and nobody reads the 16-byte
+  // records any more, so the front pass does not write them)
+  // APPROX (round 1 on the hot records): the vector filter on v_cos / v_sin of the angle, the exact sums where asked for.  COLDP (the
+  // later rounds): nothing approximate — a test gathers the EXACT {cos, sin} of the cold plane (8 bytes; cos = TX_NOTDEF marks a pixel
+  // without a level-line angle) beside the owner pair, and the angle itself, which only the reference's own expression wants, is
+  // fetched from the hot record for the one candidate that gets there.  Measured first with the later rounds on the approximate
+  // filter too: k_tx_grow_sparse 5.3 -> 5.7 ms on photographs — their steps are few and latency-bound, the filter's extra instructions
+  // buy nothing there.
+  constexpr bool APPROX = HOT && PACK != 0, COLDP = HOT && PACK == 0;
+  int2* hot = HOT ? hotAll + img * npix : nullptr;
+  // (... the exact {cos, sin} of the records, for the pixels whose exact sums are asked for: the cold plane the front pass writes beside
+  // the hot records when it does not write the 16-byte ones, else those)
+  const float2* cold = (HOT && coldAll) ? coldAll + img * npix : nullptr;
+  auto exactPair = [&](const int p, float& cy, float& cz) {
+    if (cold) {
+      const float2 cp = cold[p];
+      cy = cp.x; cz = cp.y;
+    } else {
+      const float4 cr = rec[p];
+      cy = cr.y; cz = cr.z;
+    }
+  };
   const int2* list = listAll + ((int64_t)img * ntile + tile) * ts * ts;
   int* rgSize = rgSizeAll + img * npix;
   int2* rgBox = rgBoxAll + img * npix;
@@ -1220,6 +1253,10 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
   // seeds of the current list row and their pixels, packed (y << 16 | x) (a seed whose pixel is taken leaves the mask).  false: a capacity ran out.
   // grpCand / grpXY / preOct (shared first steps): the candidates of the current group's parked first steps, their pixels, and the
   // octet of lanes that holds THIS region's (-1: the region fetches its first step itself).
+  // (the current list row's seeds: cos / sin of their angles, one seed per lane — declared here so that growRegion can reach them: the
+  // hot-record path re-reads the seed's pair, lane seedLaneOfRow, when it first folds the exact sums)
+  float scos = 0.f, ssin = 0.f;
+  int seedLaneOfRow = 0;
   auto growRegion = [&](const int r, const float sa, float sumdx, float sumdy, int cnt, int k, int bmin, int bmax,
                         unsigned long long& seedMask, const int seedPixV, const int pend0, const int pendRank0,
                         unsigned long long& grpCand, const int grpXY, const int preOct) -> bool {
@@ -1230,19 +1267,20 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
       // HOT: sumdx / sumdy are the FILTER's sums — the seed's exact cos / sin plus v_cos_f32 / v_sin_f32 of every accepted pixel's angle.
       // Where the reference's own expression is evaluated (a candidate inside the filter's margin) the region angle must come from the
       // sums region_grow forms: the exact cos / sin of the 16-byte records added in the order of acceptance.  exSx / exSy hold them for
-      // the first exCnt queue entries and are brought up to date only when asked for (foldQueue: one gather of the records per 64
+      // the first exCnt queue entries and are brought up to date only when asked for (foldQueue: one gather of the records per 128
       // entries, then the adds in order).  Why the filter may run on the approximate sums: an accepted pixel lies within prec + margin
       // of the sum's direction, so |sum| grows by at least cos(prec + margin) >= 0.54 per pixel (prec <= 1 rad, checked by the host), and
-      // the direction of the filter's sums is off the exact one by at most 2 u m + 1.1 d, u = 2^-24 (the roundings of the two
-      // accumulations over the m pixels since the sums last agreed), d = the largest |v_cos - cos| (tests/test_gpu_parity.py measures it
-      // over every float angle: < 4e-6); the sums are made to agree again every TX_HOT_RESYNC = 1024 pixels: below 1.4e-4 rad, and the
-      // candidate's own direction adds 1.5 d.  The margin is 0.05 deg = 8.7e-4 rad, of which fastAtan2 uses 1.7e-4 (NOTEBOOK.md R1).
+      // after m pixels from a point where the two pairs of sums agreed they differ, per component, by at most m d + 2 u m |sum| (d = the
+      // largest |v_cos - cos|, tests/test_gpu_parity.py measures it over every float angle: < 4e-6; u = 2^-24, one rounding per add and
+      // pair) — in direction by sqrt(2) (1.85 d + 2 u m) = 1.05e-5 + 1.7e-7 m rad.  The sums are made to agree at the latest every
+      // TX_HOT_RESYNC = 2048 pixels (and whenever the exact ones are computed): below 3.8e-4 rad with the candidate's own 1.5 d.  The
+      // margin is 0.05 deg = 8.7e-4 rad, of which fastAtan2 uses 1.7e-4 (NOTEBOOK.md R1).
       // (the three words live in LDS — exs = the words behind the queue-block table —: the step loops have neither vector nor scalar
       // registers to spare, and a scalar register the compiler cannot keep costs a v_readlane per use)
       int* const exs = gb + TX_BMAXBLK;                   // [0] exCnt, [1] / [2] the bits of exSx / exSy, [3] the pixel count at which the filter's sums were last exact
-      if (HOT) {
-        exs[0] = cnt; exs[1] = __float_as_int(sumdx); exs[2] = __float_as_int(sumdy); exs[3] = cnt;   // (every lane stores the same values)
-      }
+      // (a region starts with ONE store — exs[0] = 0: nothing folded yet, the exact sums are the seed's, the filter's sums were exact
+      // at pixel count 1 —: three more per region were 0.2 G vector instructions per launch)
+      if (APPROX) exs[0] = 0;
       auto foldQueue = [&](const int upto) {              // (the entries exCnt .. upto - 1 are in the queue)
 #if defined(TX_DIAG_HOT_NOFOLD)      // diagnostic build, NOT exact: what the exact sums cost (events decided on the filter's sums)
         return;
@@ -1250,6 +1288,11 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         int exCnt = __builtin_amdgcn_readfirstlane(tx_lds_read(&exs[0]));
         float ex = __int_as_float(tx_lds_read(&exs[1])), ey = __int_as_float(tx_lds_read(&exs[2]));
+        if (exCnt == 0) {                                 // (the first fold of this region: the seed, as region_grow starts its sums)
+          ex = tx_rlf(scos, seedLaneOfRow); ey = tx_rlf(ssin, seedLaneOfRow);
+          exCnt = 1;
+          exs[3] = 1;
+        }
         while (exCnt < upto) {
           // (2 x 64 entries per trip; the gathers unconditional, from an entry that exists either way, so that they are in flight together)
           const int n4 = min(128, upto - exCnt);
@@ -1257,8 +1300,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             const int e = qget(min(exCnt + 64 * u + lane, upto - 1));
-            const float4 cr = rec[(e >> 16) * W + (e & 0xFFFF)];
-            cy[u] = cr.y; cz[u] = cr.z;
+            exactPair((e >> 16) * W + (e & 0xFFFF), cy[u], cz[u]);
           }
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
@@ -1281,10 +1323,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
         ax = exSx(); ay = exSy();
         if (accSoFar) {
           float cy = 0.f, cz = 0.f;
-          if ((accSoFar >> lane) & 1ull) {
-            const float4 cr = rec[(myxy >> 16) * W + (myxy & 0xFFFF)];
-            cy = cr.y; cz = cr.z;
-          }
+          if ((accSoFar >> lane) & 1ull) exactPair((myxy >> 16) * W + (myxy & 0xFFFF), cy, cz);
           unsigned long long m = accSoFar;
           while (m) {
             const int j = __ffsll((long long)m) - 1;
@@ -1307,6 +1346,12 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
       // prec is decided without the exact sums.  The bound grows with the pixels accepted since the two pairs of sums last agreed (they
       // are made to agree whenever the exact ones are known): a few 1e-5 rad against the margin's 8.7e-4, so few events are left that
       // gather the 16-byte records of the region's pixels.
+      // (the level-line angle of lane j2's candidate: in the lane's register, or — COLDP — in the hot record of its pixel)
+      auto candAngle = [&](const float angReg, const int xyReg, const int j2) -> float {
+        if (!COLDP) return tx_rlf(angReg, j2);
+        const int xy = tx_rl(xyReg, j2);
+        return __int_as_float(hot[(xy >> 16) * W + (xy & 0xFFFF)].x);
+      };
       auto alignedExact = [&](const float angJ, auto&& exactAt) -> bool {
         const double aj = (double)angJ * TX_DEG2RAD;
         auto ntheta = [&](const double ra) -> double {
@@ -1316,13 +1361,14 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
           }
           return n;
         };
-        if (HOT) {
+        if (APPROX) {
           // (nothing cached between the events of a region: they are rare, and the step loops have no registers to spare)
           if (cnt == 1) return ntheta((double)sa * TX_DEG2RAD) <= prec;
           // (the direction bound of the comment above for the m pixels since the sums last agreed: sqrt(2) (1.85 d + 2 u m) = 1.05e-5 +
           // 1.7e-7 m, times the polynomial's slope 1.002, plus 2e-6 for its evaluation — with room to spare)
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          const float dirBound = 1.5e-5f + 1.8e-7f * (float)(cnt + 64 - tx_lds_read(&exs[3]));
+          const int syncCnt = tx_lds_read(&exs[0]) == 0 ? 1 : tx_lds_read(&exs[3]);
+          const float dirBound = 1.5e-5f + 1.8e-7f * (float)(cnt + 64 - syncCnt);
           const float fx = fabsf(sumdx), fy = fabsf(sumdy), mn = fminf(fx, fy), mx = fmaxf(fx, fy);
           if (mn > dirBound * mx && mx - mn > 2.1f * dirBound * mx) {
             const double n1 = ntheta((double)fast_atan2_deg(sumdy, sumdx) * TX_DEG2RAD);
@@ -1380,7 +1426,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
           if (code == 0) break;
           // lane j2 lies inside the margin of the vector filter: the reference's own expression decides
           // (the sums live in vector registers, so the compiler takes this decision for lane-dependent: say it is not)
-          if (!__builtin_amdgcn_readfirstlane((int)alignedExact(tx_rlf(ang, j2), [&](float& ax, float& ay) { exactSums(cnt0, acc, myxy, ax, ay); })))
+          if (!__builtin_amdgcn_readfirstlane((int)alignedExact(candAngle(ang, myxy, j2), [&](float& ax, float& ay) { exactSums(cnt0, acc, myxy, ax, ay); })))
             continue;
           const int xyj = tx_rl(myxy, j2);
           const float cj = tx_rlf(cosv, j2), sj = tx_rlf(sinv, j2);
@@ -1412,7 +1458,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
         stampLosers();
         // (the filter's sums and the exact ones agree again every TX_HOT_RESYNC pixels: a step adds at most 64, so the count cannot
         // pass a multiple of TX_HOT_RESYNC without a step starting in the 64 behind it)
-        if (HOT && cnt >= TX_HOT_RESYNC && (cnt & (TX_HOT_RESYNC - 1)) < 64) {
+        if (APPROX && cnt >= TX_HOT_RESYNC && (cnt & (TX_HOT_RESYNC - 1)) < 64) {
           foldQueue(cnt);
           filterFrom(exSx(), exSy());
         }
@@ -1431,13 +1477,23 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
         rr.w = 0.f;
         if (PACK) asm volatile("" : "=v"(rr.w));
         if (HOT) {
-          if (ok) {
-            const int2 h = tx_load_hot8(hot + (unsigned)qi);
-            rr.x = __int_as_float(h.x);
-            rr.w = __int_as_float(h.y);
+          if (PACK) {
+            if (ok) {
+              const int2 h = tx_load_hot8(hot + (unsigned)qi);
+              rr.x = __int_as_float(h.x);
+              rr.w = __int_as_float(h.y);
+            }
+          } else if (ok) {                                 // (later rounds: the exact pair of the cold plane, the owner pair of the owner plane)
+            const float2 cp = cold[(unsigned)qi];
+            rr.x = cp.x; rr.y = cp.x; rr.z = cp.y;         // (rr.x: TX_NOTDEF or not — the angle is fetched where it is needed)
+            oo = tx_load_own(own + (unsigned)qi);
           }
-          rr.y = tx_hw_cos_deg(rr.x);
-          rr.z = tx_hw_sin_deg(rr.x);
+          // (the filter's cos / sin.  Making the two conditional on "a candidate is left" — a third of the steps have none — was measured:
+          // the branch costs more than the instructions, k_tx_grow 18.7 -> 19.2 ms)
+          if (APPROX) {
+            rr.y = tx_hw_cos_deg(rr.x);
+            rr.z = tx_hw_sin_deg(rr.x);
+          }
         } else if (PACK) {
           if (ok) rr = tx_load_rec16(rec + (unsigned)qi);
         } else if (ok) {
@@ -1464,7 +1520,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
             const unsigned long long sure = __builtin_amdgcn_ballot_w64(sd2 >= alignHi * n2);
             if (__builtin_expect(!((sure >> j2) & 1ull), 0)) {
               // (this loop puts a pixel into the queue as it accepts it)
-              if (!__builtin_amdgcn_readfirstlane((int)alignedExact(tx_rlf(rr.x, j2), [&](float& ax, float& ay) {
+              if (!__builtin_amdgcn_readfirstlane((int)alignedExact(candAngle(rr.x, myxy, j2), [&](float& ax, float& ay) {
                     foldQueue(cnt);
                     ax = exSx(); ay = exSy();
                   })))
@@ -1505,7 +1561,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
 #if defined(TX_DIAG_NOWAIT)     // diagnostic build (NOT exact: contested claims go unnoticed): non-returning claims, nothing to wait for
           (void)__hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
 #else
-          if (HOT) pendOld = (int)__hip_atomic_fetch_min(reinterpret_cast<unsigned*>(&hot[(unsigned)qi].y), (unsigned)r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
+          if (HOT && PACK) pendOld = (int)__hip_atomic_fetch_min(reinterpret_cast<unsigned*>(&hot[(unsigned)qi].y), (unsigned)r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
           else if (PACK) pendOld = (int)__hip_atomic_fetch_min(reinterpret_cast<unsigned*>(tx_rec_owner(rec + (unsigned)qi)), (unsigned)r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
           else pendOld = __hip_atomic_fetch_min(ci ? &own[(unsigned)qi].y : &own[(unsigned)qi].x, r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
 #endif
@@ -1531,7 +1587,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
                       ps = __int_as_float(tx_lds_read(&park[128 + lane]));
           if (acceptBatch(remaining, pa, pc, ps, grpXY)) {
             const int qi = (grpXY >> 16) * W + (grpXY & 0xFFFF);
-            if (HOT) pendOld = (int)__hip_atomic_fetch_min(reinterpret_cast<unsigned*>(&hot[qi].y), (unsigned)r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
+            if (HOT && PACK) pendOld = (int)__hip_atomic_fetch_min(reinterpret_cast<unsigned*>(&hot[qi].y), (unsigned)r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
             else if (PACK) pendOld = (int)__hip_atomic_fetch_min(reinterpret_cast<unsigned*>(tx_rec_owner(&rec[qi])), (unsigned)r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
             else pendOld = __hip_atomic_fetch_min(ci ? &own[qi].y : &own[qi].x, r, __ATOMIC_RELAXED, TX_CLAIM_SCOPE);
             if (noteLost && !PACK) pendRank = (SPARSE || t != 1) ? rankOfPix[qi] : tx_lds_read(&park[192 + lane]);
@@ -1567,7 +1623,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
         if (first) {
           RxRect& it = rects[slot];
           it.rank = r; it.off = off; it.cnt = cnt; it.sumdx = sumdx; it.sumdy = sumdy;
-          it.approx = HOT ? 1 : 0;                        // (HOT: the filter's sums; region2rect asks for the exact ones when it needs them)
+          it.approx = APPROX ? 1 : 0;                     // (the filter's sums; region2rect asks for the exact ones when it needs them)
         }
       }
       return true;
@@ -1879,6 +1935,11 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
         srec.x = rec[se.y].x;
         srec.w = __int_as_float(__hip_atomic_load(tx_rec_owner(&rec[se.y]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
       }
+    } else if (HOT) {
+      if (d) {
+        srec.x = __int_as_float(hot[se.y].x);
+        so = tx_load_own(&own[se.y]);
+      }
     } else if (d) {
       srec = rec[se.y];
       so = tx_load_own(&own[se.y]);
@@ -1887,7 +1948,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
     const bool alive = PACK ? d && __float_as_int(srec.w) < 0 : d && (ci ? so.x : so.y) == se.x && (ci ? so.y : so.x) == se.x;
     const float seedAng = srec.x;
     // region_grow seeds its sums with cos/sin of the unrounded double angle
-    float scos = 0.f, ssin = 0.f;
+    scos = 0.f; ssin = 0.f;
     if (alive) {
       double sn, cn;
       sincos((double)seedAng * TX_DEG2RAD, &sn, &cn);
@@ -1923,13 +1984,21 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
           float4 rr = make_float4(TX_NOTDEF, 0.f, 0.f, 0.f);
           int2 oo = make_int2(0, 0);
           if (HOT) {
-            if (ok) {
-              const int2 h = tx_load_hot8(&hot[ny * W + nx]);
-              rr.x = __int_as_float(h.x);
-              rr.w = __int_as_float(h.y);
+            if (PACK) {
+              if (ok) {
+                const int2 h = tx_load_hot8(&hot[ny * W + nx]);
+                rr.x = __int_as_float(h.x);
+                rr.w = __int_as_float(h.y);
+              }
+            } else if (ok) {
+              const float2 cp = cold[ny * W + nx];
+              rr.x = cp.x; rr.y = cp.x; rr.z = cp.y;
+              oo = tx_load_own(&own[ny * W + nx]);
             }
-            rr.y = tx_hw_cos_deg(rr.x);
-            rr.z = tx_hw_sin_deg(rr.x);
+            if (APPROX) {
+              rr.y = tx_hw_cos_deg(rr.x);
+              rr.z = tx_hw_sin_deg(rr.x);
+            }
           } else if (PACK) {
             if (ok) rr = tx_load_rec16(&rec[ny * W + nx]);
           } else if (ok) {
@@ -1963,6 +2032,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
       const int sxy = tx_rl(sxyv, j);
       q[0] = sxy;                                         // every lane stores the same value
       const int rj = tx_rl(se.x, j);
+      seedLaneOfRow = j;
       if (!growRegion(rj, tx_rlf(seedAng, j), tx_rlf(scos, j), tx_rlf(ssin, j), 1, 0, sxy, sxy, unusedMask, sxyv, rj, rj,
                       grpCand, grpXY, preOct))
         return;
@@ -1976,6 +2046,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
 
 // k_tx_order: the (image, tile) pairs of a launch of k_tx_grow in order of decreasing seed count (64 buckets of 64 seeds; inside a
 // bucket any order), by one workgroup: a histogram, its scan from the top, and a scatter with one cursor per bucket.
+#ifdef PLI_DEV     // (dev switch PLI_TX_ORDER: measured, slower)
 __global__ __launch_bounds__(1024) void k_tx_order(const int* __restrict__ tileCntAll, int ntile, int nimg, int img0, int* __restrict__ perm) {
   __shared__ int hist[64], cursor[64];
   const int tid = threadIdx.x, n = ntile * nimg;
@@ -1990,6 +2061,7 @@ __global__ __launch_bounds__(1024) void k_tx_order(const int* __restrict__ tileC
   __syncthreads();
   for (int i = tid; i < n; i += 1024) perm[atomicAdd(&cursor[min(63, tileCntAll[(int64_t)img0 * ntile + i] >> 6)], 1)] = i;
 }
+#endif
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tx_grow(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
                                                 const float4* __restrict__ recAll, int2* __restrict__ ownAll,
@@ -2021,7 +2093,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 }
 // round 1 with owner_1 packed into the pixel records (CV_64F detector; the host picks it, pli_capi.hip)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tx_grow_p1(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
-                                                const float4* __restrict__ recAll, int2* __restrict__ ownAll,
+                                                float4* recAll /* written: the claims */, int2* __restrict__ ownAll,
                                                 const int2* __restrict__ listAll, const int* __restrict__ tileCntAll,
                                                 int ts, int ntx, int nty, int* __restrict__ rgSizeAll,
                                                 int2* __restrict__ rgBoxAll, const int* __restrict__ rgDirtyAll,
@@ -2044,7 +2116,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 }
 // ... and with LAZY ids (key mode: the front pass wrote the unclaimed words, k_tx_sort touches neither the records nor the owner plane)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tx_grow_p2(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
-                                                const float4* __restrict__ recAll, int2* __restrict__ ownAll,
+                                                float4* recAll /* written: the claims */, int2* __restrict__ ownAll,
                                                 const int2* __restrict__ listAll, const int* __restrict__ tileCntAll,
                                                 int ts, int ntx, int nty, int* __restrict__ rgSizeAll,
                                                 int2* __restrict__ rgBoxAll, const int* __restrict__ rgDirtyAll,
@@ -2087,11 +2159,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   }                                                                                                                                          \
   tx_grow_tile<false, false, TX_GQ, PACKV, true>(Pp, ctl, recAll, ownAll, listAll, tileCntAll, ts, ntx, nty, rgSizeAll, rgBoxAll, rgDirtyAll, \
                                                  tileActAll, TW, TH, arenaAll, arenaCap, rectAll, rectCap, img + img0, tile, 1, rankAll,      \
-                                                 rgLostAll, tileTouchAll, DL, q, gb, park, &keys);                                            \
+                                                 rgLostAll, tileTouchAll, DL, q, gb, park, &keys, keys.hot, keys.cold);                       \
 }
 TX_GROW_HOT_KERNEL(k_tx_grow_h1, 1)
 TX_GROW_HOT_KERNEL(k_tx_grow_h2, 2)
 #undef TX_GROW_HOT_KERNEL
+#ifdef PLI_DEV     // (dev switch PLI_TX_SPEC: round 1 in the speculative lane schedule — exact, measured, slower)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tx_grow_spec(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
                                                 const float4* __restrict__ recAll, int2* __restrict__ ownAll,
                                                 const int2* __restrict__ listAll, const int* __restrict__ tileCntAll,
@@ -2108,6 +2181,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                                         TW, TH, arenaAll, arenaCap, rectAll, rectCap, blockIdx.y + img0, blockIdx.x, t, rankAll, rgLostAll,
                                         tileTouchAll, DL, q, gb, park);
 }
+#endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tx_grow_sparse(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
                                                        const float4* __restrict__ recAll, int2* __restrict__ ownAll,
                                                        const int2* __restrict__ listAll, const int* __restrict__ tileCntAll,
@@ -2122,6 +2196,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   __shared__ int park[TX_PARK];
   tx_grow_tile<true>(Pp, ctl, recAll, ownAll, listAll, tileCntAll, ts, ntx, nty, rgSizeAll, rgBoxAll, rgDirtyAll, tileActAll, TW, TH,
                    arenaAll, arenaCap, rectAll, rectCap, blockIdx.y + img0, blockIdx.x, t, rankAll, rgLostAll, tileTouchAll, DL, q, gb, park);
+}
+// ... on the hot records (round 6): the angle from there, the owner pair from the owner plane; recAll is not read
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tx_grow_sparse_h(const DevParams* __restrict__ Pp, RxCtl* __restrict__ ctl,
+                                                       const float4* __restrict__ recAll, int2* __restrict__ ownAll,
+                                                       const int2* __restrict__ listAll, const int* __restrict__ tileCntAll,
+                                                       int ts, int ntx, int nty, int* __restrict__ rgSizeAll,
+                                                       int2* __restrict__ rgBoxAll, const int* __restrict__ rgDirtyAll,
+                                                       const int* __restrict__ tileActAll, int TW, int TH,
+                                                       int* __restrict__ arenaAll, int arenaCap, RxRect* __restrict__ rectAll,
+                                                       int rectCap, int img0, int t, const int* __restrict__ rankAll,
+                                                       int* __restrict__ rgLostAll, int* __restrict__ tileTouchAll, TxDirtyLists DL,
+                                                       int2* __restrict__ hotAll, const float2* __restrict__ coldAll) {
+  __shared__ int q[TX_GQ];
+  __shared__ int gb[TX_BMAXBLK + 4];
+  __shared__ int park[TX_PARK];
+  tx_grow_tile<true, false, TX_GQ, 0, true>(Pp, ctl, recAll, ownAll, listAll, tileCntAll, ts, ntx, nty, rgSizeAll, rgBoxAll, rgDirtyAll, tileActAll,
+                                            TW, TH, arenaAll, arenaCap, rectAll, rectCap, blockIdx.y + img0, blockIdx.x, t, rankAll, rgLostAll,
+                                            tileTouchAll, DL, q, gb, park, nullptr, hotAll, coldAll);
+}
+
+// ---------------------------------------------------------------------------
+// k_tx_rec_from_hot: with every round on the hot records the front pass does not write the 16-byte records.  The sequential grower —
+// the device-side fallback of an image that ran out of a capacity or did not settle — reads them: written here, for those images only
+// (the workgroups of the others leave at once), from the hot and cold planes: the words the front pass would have written.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tx_rec_from_hot(const RxCtl* __restrict__ ctl, const int2* __restrict__ hotAll,
+                                                         const float2* __restrict__ coldAll, float4* __restrict__ recAll, int64_t npix, int img0) {
+  const int img = blockIdx.y + img0;
+  if (ctl[img].state == 2 && ctl[img].overflow == 0) return;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
+    const float2 cp = coldAll[img * npix + p];
+    recAll[img * npix + p] = make_float4(__int_as_float(hotAll[img * npix + p].x), cp.x == TX_NOTDEF ? 0.f : cp.x, cp.y, 0.f);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -2276,7 +2383,7 @@ __device__ __forceinline__ bool tx_grid_barrier(unsigned* bar, unsigned target) 
 
 __global__ __launch_bounds__(256) void k_tx_tail(TxTailArgs A) {
   __shared__ int qs[4][TX_GQ];
-  __shared__ int gbs[4][TX_BMAXBLK];
+  __shared__ int gbs[4][TX_BMAXBLK + 4];
   __shared__ int parks[4][TX_PARK];
   __shared__ double sts[4][3][64];
   __shared__ double wcs[4][RX_RECT_CACHE][64];
@@ -2387,6 +2494,12 @@ __global__ __launch_bounds__(256) void k_tx_tail(TxTailArgs A) {
       for (int i = wv; i < n; i += 4) {
         const int64_t va = base + (int64_t)s_list[i] * G;
         const int il = (int)(va / ntile);
+        if (A.hot)
+          tx_grow_tile<true, false, TX_GQ, 0, true>(A.Pp, A.ctl, A.rec, A.own, A.list, A.tileCnt, A.ts, A.ntx, A.nty, A.rgSize, A.rgBox, A.rgDirty,
+                                                    A.tileAct, A.TW, A.TH, A.arena, A.arenaCap, A.rects, A.rectCap, A.img0 + il,
+                                                    (int)(va - (int64_t)il * ntile), t, A.rank, A.rgLost, A.tileTouch, A.DL, qs[wv], gbs[wv],
+                                                    parks[wv], nullptr, A.hot, A.cold);
+        else
         tx_grow_tile<true>(A.Pp, A.ctl, A.rec, A.own, A.list, A.tileCnt, A.ts, A.ntx, A.nty, A.rgSize, A.rgBox, A.rgDirty, A.tileAct, A.TW,
                            A.TH, A.arena, A.arenaCap, A.rects, A.rectCap, A.img0 + il, (int)(va - (int64_t)il * ntile), t, A.rank, A.rgLost,
                            A.tileTouch, A.DL, qs[wv], gbs[wv], parks[wv]);
@@ -2403,7 +2516,8 @@ __global__ __launch_bounds__(256) void k_tx_tail(TxTailArgs A) {
         const RxCtl& c = A.ctl[img];
         if (c.state == 2 || c.overflow) continue;
         rx_rect_wave(P, c, A.rec + img * npix, A.mg ? A.mg + img * npix : nullptr, A.arena + (int64_t)img * A.arenaCap,
-                     A.rects + (int64_t)img * A.rectCap, A.rectCap, A.rgSeg + img * npix, gw % per, per, sts[wv], wcs[wv], ecs[wv], A.DL.rmask);
+                     A.rects + (int64_t)img * A.rectCap, A.rectCap, A.rgSeg + img * npix, gw % per, per, sts[wv], wcs[wv], ecs[wv], A.DL.rmask,
+                     A.hot ? A.hot + img * npix : nullptr, A.cold ? A.cold + img * npix : nullptr);
       }
     }
     if (!tx_grid_barrier(A.bar, ++epoch * G)) return;

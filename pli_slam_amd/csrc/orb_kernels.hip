@@ -930,7 +930,7 @@ __global__ __launch_bounds__(64) void k_describe(const DevParams* __restrict__ P
 }
 
 // N (mvKeys.size()) per eye into the frame record
-// k_zero_ranges: up to 8 buffers cleared by ONE launch (what the relaxation zeroes at the start of a call: control blocks, stamp
+// k_zero_ranges: up to 12 buffers (ZeroRanges) cleared by ONE launch (what the relaxation zeroes at the start of a call: control blocks, stamp
 // planes, cell tables, counters — eight hipMemsetAsync launches before; a single pair's call spent 15 of its ~110 launches on fills).
 // blockIdx.y = the range; 16-byte stores on the aligned body, words at both ends.
 __global__ __launch_bounds__(256) void k_zero_ranges(ZeroRanges Z) {

@@ -18,6 +18,19 @@
 
 using namespace pli;
 
+// Development switches (tools/README.md "Environment switches"): schedules and kernels that were measured and shelved, test switches,
+// tuning knobs.  They are read ONLY by the development build of the library (make dev: -DPLI_DEV -> libpli_frontend_dev.so, which the dev-switch
+// tests and the tools load); in the product library DEVENV is a null constant — the variable names are not even in the binary, and a
+// stray variable in an integrator's environment cannot change a schedule.  The product reads four documented variables: PLI_ROCTX (roctx
+// ranges), PLI_SYNC_DEBUG (synchronise after every launch), PLI_TX_TAIL (= 0: no persistent kernel, include/pli_frontend.h "Sharing a
+// device") and PLI_LSD_MODE (overrides pli_frontend_config.lsd_mode).
+#ifdef PLI_DEV
+#define DEVENV(name) getenv(name)
+#else
+static inline const char* pli_no_devenv() { return nullptr; }
+#define DEVENV(name) (pli_no_devenv())
+#endif
+
 namespace {
 
 thread_local std::string g_err;
@@ -96,12 +109,13 @@ struct pli_ctx {
   int* lsdTab64 = nullptr; int lsdRadius = 0;
   bool lsdFront64 = false;                   // the fused blur -> resize -> gradient pass applies (lsd_f64.hip: k_lsd_front64)
   int2* hot = nullptr;                       // tile relaxation, CV_64F detector: round 1's 8-byte hot records {angle, owner word} (lsd_tile.hip)
+  float2* cold = nullptr;                    // ... and the records' exact {cos, sin}: written instead of the 16-byte records when every round runs on the hot ones
   int2* own = nullptr; RxSeed* smallSeeds = nullptr; RxSeed* bigSeeds = nullptr; int bigCap = 0;
   RxHand* hand = nullptr; int handCap = 0; RxRect* rects = nullptr; int rectCap = 0; int* rankOf = nullptr; int2* rgBox = nullptr; float4* rgSeg = nullptr; uint8_t* rgClean = nullptr;
   int* rgLost = nullptr;                     // tile relaxation: round in which a region last lost a contested claim (per rank)
   int* tileTouch = nullptr;                  // tile relaxation: round in which a grower last claimed a pixel of the 8x8 cell
   int* tileMin = nullptr; int* tileAct = nullptr; int* rgDirty = nullptr; int tilesW = 0, tilesH = 0; int* rxChunkCnt = nullptr; int rxChunks = 0;
-  int* lastSize = nullptr; int* arena = nullptr; int arenaCap = 0;
+  int* lastSize = nullptr; int* arena = nullptr; int arenaCap = 0; int arenaFactor = 0;    // (arena words per scaled pixel the context got)
   RxCtl* jrCtl = nullptr;
   int2* txList = nullptr; int* txTileCnt = nullptr; int txTs = 64, txNtx = 0, txNty = 0;   // tile-sequential relaxation (lsd_tile.hip)
   bool txKeys = false; int txPixBits = 0; int* txCand = nullptr; int* txCandCnt = nullptr;  // ... its key mode (region id = gradient bin | seed pixel: no ordered list)
@@ -109,7 +123,7 @@ struct pli_ctx {
   std::vector<RxCtl> jrHost;
   int rxImages = 0;    // images the relaxations' buffers are sized for
   int lsdMode = 0;     // 0 auto, 1 relaxation, 2 sequential, 3 tile-sequential relaxation (cfg.lsd_mode, or PLI_LSD_MODE)
-  bool lsdSpec = !(getenv("PLI_LSD_SPEC") != nullptr && atoi(getenv("PLI_LSD_SPEC")) == 0);  // speculative sequential grower (PLI_LSD_SPEC=0: the plain one)
+  bool lsdSpec = !(DEVENV("PLI_LSD_SPEC") != nullptr && atoi(DEVENV("PLI_LSD_SPEC")) == 0);  // speculative sequential grower (PLI_LSD_SPEC=0: the plain one)
   int rxLastRounds = 0; // rounds the relaxation needed in an earlier call (the last one whose control blocks the host has seen)
   // Rounds without a host look (the default once rxLastRounds is known): the call launches rxLastRounds + rxMargin rounds — kernels
   // of a settled image leave at once —, k_lsd_grow_unsettled redoes, on the device, whatever image did not settle in them, and the
@@ -244,7 +258,7 @@ static hipEvent_t g_tailEv[TAIL_MAX_DEVICES] = {};
 // ... and whether a tail of this process has ever been ABORTED on a device (its grid barrier timed out: somebody else — another
 // process — holds compute units the resident grid needs).  From then on this process runs the planned-rounds schedule on that device
 // instead of stalling a second per call (include/pli_frontend.h "Sharing a device").
-static bool g_tailAborted[TAIL_MAX_DEVICES] = {};
+static std::atomic<bool> g_tailAborted[TAIL_MAX_DEVICES] = {};       // (read without the mutex by every call: relaxed atomics)
 static bool g_tailWarned = false;
 
 struct CtxGuard {
@@ -423,19 +437,19 @@ pli_status buildGeometry(pli_ctx* c) {
     double margin = 0.05 * 3.14159265358979323846 / 180;
     // (test switch PLI_ALIGN_MARGIN_DEG: a wide margin sends many more candidates through the exact expression — and, on the hot records,
     // through the exact sums; the results must not change)
-    if (const char* e = getenv("PLI_ALIGN_MARGIN_DEG")) margin = std::max(0.05, std::min(20.0, atof(e))) * 3.14159265358979323846 / 180;
+    if (const char* e = DEVENV("PLI_ALIGN_MARGIN_DEG")) margin = std::max(0.05, std::min(20.0, atof(e))) * 3.14159265358979323846 / 180;
     P.hotBand2 = 0.0;
-    if (const char* e = getenv("PLI_TX_HOT_BAND2")) P.hotBand2 = std::max(0.0, atof(e));              // test switch: 10 = the exact sums at every event
+    if (const char* e = DEVENV("PLI_TX_HOT_BAND2")) P.hotBand2 = std::max(0.0, atof(e));              // test switch: 10 = the exact sums at every event
     P.rectApproxBand = 2e-3;
-    if (const char* e = getenv("PLI_RECT_APPROX_BAND")) P.rectApproxBand = std::max(2e-3, atof(e));     // test switch: 10 = every region
+    if (const char* e = DEVENV("PLI_RECT_APPROX_BAND")) P.rectApproxBand = std::max(2e-3, atof(e));     // test switch: 10 = every region
     P.alignFilter = (P.prec + margin < 1.5) && (P.prec - margin > 0.01);
     const double cl = std::cos(P.prec + margin), ch = std::cos(P.prec - margin);
     // (without the filter: every candidate is a "maybe", none is "sure")
     P.alignLo = P.alignFilter ? (float)(cl * cl * (1 - 1e-5)) : -INFINITY;
     P.alignHi = P.alignFilter ? (float)(ch * ch * (1 + 1e-5)) : INFINITY;
     P.alignPad = 0;                                       // dev switches of the speculative grower
-    if (const char* e = getenv("PLI_LSD_SPEC")) P.alignPad = atoi(e) == 3 ? 1 : atoi(e) == 4 ? 3 : 0;
-    if (const char* e = getenv("PLI_LSD_SPEC_CAP")) P.alignPad |= std::max(0, std::min(8, atoi(e))) << 4;
+    if (const char* e = DEVENV("PLI_LSD_SPEC")) P.alignPad = atoi(e) == 3 ? 1 : atoi(e) == 4 ? 3 : 0;
+    if (const char* e = DEVENV("PLI_LSD_SPEC_CAP")) P.alignPad |= std::max(0, std::min(8, atoi(e))) << 4;
   }
   {
     const double rho = cfg.lsd_quant / std::sin(P.prec);
@@ -612,7 +626,7 @@ pli_status allocAll(pli_ctx* c) {
         const int a = std::min(std::max(t[3 * P.LW + y0], 0), P.H - 1), b = std::min(std::max(t[3 * P.LW + y1] + 1, 0), P.H - 1);
         fits = b - a + 1 <= 20;
       }
-      c->lsdFront64 = fits && !getenv("PLI_LSD_NOFUSE");
+      c->lsdFront64 = fits && !DEVENV("PLI_LSD_NOFUSE");
     }
   } else {
     A(c->g2, npix * NI);
@@ -623,6 +637,9 @@ pli_status allocAll(pli_ctx* c) {
     if (m < 0 || m > 3) { g_err = "PLI_LSD_MODE must be 0, 1, 2 or 3"; return PLI_ERR_INVALID; }
     c->lsdMode = m;
   }
+#ifndef PLI_DEV
+  if (c->lsdMode == 1) { g_err = "lsd_mode 1 (the lane relaxation, round 1's schedule) is kept for cross-checks in the development build only (libpli_frontend_dev.so)"; return PLI_ERR_INVALID; }
+#endif
   if (c->lsdMode != 2) {     // buffers of the relaxations (in auto mode only batches below RX_AUTO_IMAGES use them)
     // (auto mode: a context sized for the sequential regime keeps the relaxations' buffers — 20-30 MB per image — for 2047 images,
     // as in round 2, and batches above that take the sequential grower: 2048 frames stay at ~160 GB of HBM instead of 289)
@@ -630,7 +647,7 @@ pli_status allocAll(pli_ctx* c) {
     c->rxImages = (int)NR;
     const bool lane = c->lsdMode == 1, tiles = c->lsdMode == 0 || c->lsdMode == 3;
     A(c->own, npix * NR);
-    if (tiles && c->lsdF64) A(c->hot, npix * NR);
+    if (tiles && c->lsdF64) { A(c->hot, npix * NR); A(c->cold, npix * NR); }
     if (lane) {               // lane / lane-group growers of lsd_relax.hip
       A(c->smallSeeds, npix * NR);
       c->bigCap = (int)(npix / RX_HAND + 64);               // a region listed as large had >= RX_HAND pixels of its own
@@ -670,7 +687,8 @@ pli_status allocAll(pli_ctx* c) {
       if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB > 0) budget = std::min(budget, freeB / 4);
       arenaFactor = std::max<size_t>(3, std::min<size_t>(16, budget / (npix * 4 * NR)));
     }
-    if (const char* e = getenv("PLI_RX_ARENA")) arenaFactor = (size_t)std::max(1, atoi(e));     // dev: words of arena per scaled pixel
+    if (const char* e = DEVENV("PLI_RX_ARENA")) arenaFactor = (size_t)std::max(1, atoi(e));     // dev: words of arena per scaled pixel
+    const size_t arenaAsked = arenaFactor;
     for (;;) {
       c->arenaCap = (int)std::min<size_t>(arenaFactor * npix + 65536, (size_t)1 << 30);
       const pli_status as = c->dalloc(&c->arena, (size_t)c->arenaCap * NR);
@@ -679,10 +697,19 @@ pli_status allocAll(pli_ctx* c) {
       (void)hipGetLastError();                              // (the failed allocation's error state)
       arenaFactor = std::max<size_t>(3, arenaFactor / 2);
     }
+    c->arenaFactor = (int)arenaFactor;
+    // (results stay exact below 16 words per pixel, but hostile batches — long parallel structures — then take the ~500 ms fallback: say so once)
+    if (!lane && arenaFactor < 16 && arenaAsked >= arenaFactor && !DEVENV("PLI_RX_ARENA")) {
+      static std::atomic<bool> warned{false};
+      if (!warned.exchange(true))
+        std::fprintf(stderr, "pli_frontend: the LSD relaxation's arena of this context holds %d words per scaled pixel (16 wanted: %zu images, "
+                             "free device memory); results are unchanged, batches of long parallel structures may take the slow fallback "
+                             "(pli_lsd_arena_words)\n", (int)arenaFactor, NR);
+    }
     if (tiles) {
       // (the measure is the number of 64-pixel tile waves the context can put on the chip, not the number of images)
       c->txTs = (int64_t)NI * ((P.LW + 63) / 64) * ((P.LH + 63) / 64) <= TX_SMALL_TILE_WAVES ? 32 : 64;
-      if (const char* e = getenv("PLI_TX_TS")) c->txTs = atoi(e) == 16 ? 16 : atoi(e) == 32 ? 32 : atoi(e) == 128 ? 128 : 64;
+      if (const char* e = DEVENV("PLI_TX_TS")) c->txTs = atoi(e) == 16 ? 16 : atoi(e) == 32 ? 32 : atoi(e) == 128 ? 128 : 64;
       c->txNtx = (P.LW + c->txTs - 1) / c->txTs; c->txNty = (P.LH + c->txTs - 1) / c->txTs;
       A(c->txList, (size_t)c->txNtx * c->txNty * c->txTs * c->txTs * NR);
       A(c->txTileCnt, (size_t)c->txNtx * c->txNty * NR);
@@ -701,7 +728,7 @@ pli_status allocAll(pli_ctx* c) {
       while ((1 << binBits) < P.nBins) ++binBits;
       // (the largest id is (nBins - 1) << pixbits | npix - 1: strictly below 2^31 - 1 unless every bit is used AND the image fills 2^pixbits)
       c->txKeys = c->lsdF64 && P.nBins <= 1024 && (binBits + c->txPixBits < 31 || (binBits + c->txPixBits == 31 && npix < ((size_t)1 << c->txPixBits))) &&
-                  !(getenv("PLI_TX_KEYS") && atoi(getenv("PLI_TX_KEYS")) == 0);
+                  !(DEVENV("PLI_TX_KEYS") && atoi(DEVENV("PLI_TX_KEYS")) == 0);
       if (c->txKeys) {
         A(c->txCand, (size_t)TX_EMIT_CAP * NR);
         A(c->txCandCnt, NR);
@@ -716,7 +743,7 @@ pli_status allocAll(pli_ctx* c) {
   c->nChunks = (int)((npix + LSD_CHUNK - 1) / LSD_CHUNK);
   A(c->chunkHist, (size_t)NI * c->nChunks * P.nBins);
   A(c->chunkBase, (size_t)NI * c->nChunks * P.nBins);
-  if (c->nChunks > 256 && !getenv("PLI_LSD_SCAN1")) {     // (dev switch: the one-block scan)
+  if (c->nChunks > 256 && !DEVENV("PLI_LSD_SCAN1")) {     // (dev switch: the one-block scan)
     c->scanChunksPerGroup = 64;
     c->scanGroups = (c->nChunks + c->scanChunksPerGroup - 1) / c->scanChunksPerGroup;
     A(c->scanGroupOff, (size_t)NI * c->scanGroups * P.nBins);
@@ -778,9 +805,12 @@ int foldRoundStats(pli_ctx* c) {
   // An image that has not settled although the self-terminating tail kernel ran (it walks up to 96 rounds): the tail was aborted —
   // its grid barrier timed out because the resident grid did not fit beside somebody else's work (another PROCESS on the device).
   // This process runs the planned-rounds schedule on that device from now on instead of stalling ~1 s in every call.
-  if (unsettled && c->rxSeenTail && c->device >= 0 && c->device < TAIL_MAX_DEVICES) {
+  // (the abort word of the tail's grid barrier came back with the control blocks: an image that merely needed more than the 96 rounds the
+  // tail walks — or a small PLI_RX_MAXROUNDS — is not an aborted tail and does not switch the process's schedule)
+  const bool aborted = c->rxSeen[4 * (size_t)c->NI] != 0;
+  if (unsettled && c->rxSeenTail && aborted && c->device >= 0 && c->device < TAIL_MAX_DEVICES) {
     std::lock_guard<std::mutex> lk(g_tailMu);
-    g_tailAborted[c->device] = true;
+    g_tailAborted[c->device].store(true, std::memory_order_relaxed);
     if (!g_tailWarned) {
       g_tailWarned = true;
       std::fprintf(stderr, "pli_frontend: the persistent relaxation kernel did not finish on device %d (another process on the device?); "
@@ -798,7 +828,7 @@ pli_status runIngest(pli_ctx* c, const uint8_t* dl, const uint8_t* dr, int64_t s
   const DevParams& P = c->hp;
   const bool aligned16 = !c->rectMap[0] && !c->rectMap[1] && (P.W % 16) == 0 && (stride % 16) == 0 && (frameStride % 16) == 0 &&
                          (reinterpret_cast<uintptr_t>(dl) % 16) == 0 && (reinterpret_cast<uintptr_t>(dr) % 16) == 0 && (P.lv[0].pitch % 16) == 0 &&
-                         (P.pyrBlock % 16) == 0 && !getenv("PLI_INGEST_BYTES");
+                         (P.pyrBlock % 16) == 0 && !DEVENV("PLI_INGEST_BYTES");
   if (aligned16) {
     const int n16 = (P.W / 16) * P.H;
     LAUNCH(c, "k_ingest", k_ingest_copy16, dim3(std::max(1, std::min((n16 + 255) / 256, 64)), nimg), dim3(256), 0, dl, dr, stride, frameStride,
@@ -830,7 +860,7 @@ pli_status runOrb(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     // workgroups of 1024 threads while the (level, image) workgroups do not fill the chip (4K: 32 images x 8 levels; a single pair:
     // 16 workgroups): the passes over a level's keys are the long pole, 4x the threads on them (dev switch PLI_OCTREE_WIDE=0/1)
     bool wide = P.nlevels * nimg <= 1024;
-    if (const char* e = getenv("PLI_OCTREE_WIDE")) wide = atoi(e) != 0;
+    if (const char* e = DEVENV("PLI_OCTREE_WIDE")) wide = atoi(e) != 0;
     const dim3 og(P.nlevels, nimg), ob(wide ? 1024 : 256);
 #define OCTREE_LAUNCH(K) LAUNCH(c, "k_octree", K, og, ob, 0, c->dP, c->cellCand, c->cellCount, c->candAll, c->nodeOf, c->candCount, c->kpSel, c->kpSelCount, img0)
     if (need <= 320) { if (wide) OCTREE_LAUNCH(k_octree_320_w); else OCTREE_LAUNCH(k_octree_320); }
@@ -878,22 +908,30 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   // trivial map for every pixel itself — 8 bytes per scaled pixel less for the front pass to store)
   int2* ownPlane = (sequential || c->lsdMode != 1) ? (int2*)nullptr : c->own;
   // key mode of the tile relaxation (lsd_tile.hip): no ordered list — it is only built, at the end, for images left to the sequential grower
-  const bool lostRule0 = c->lsdMode != 1 && getenv("PLI_TX_BOXRULE") == nullptr;
-  const bool keyMode = !sequential && c->lsdMode != 1 && c->txKeys && !c->debug && lostRule0 && !getenv("PLI_TX_FULL2") &&
-                       !getenv("PLI_TX_OLDMARK") && !getenv("PLI_TX_CELLRULE");   // (k_rx_mark, lsd_relax.hip, indexes the region planes by rank)
+  const bool lostRule0 = c->lsdMode != 1 && DEVENV("PLI_TX_BOXRULE") == nullptr;
+  const bool keyMode = !sequential && c->lsdMode != 1 && c->txKeys && !c->debug && lostRule0 && !DEVENV("PLI_TX_FULL2") &&
+                       !DEVENV("PLI_TX_OLDMARK") && !DEVENV("PLI_TX_CELLRULE");   // (k_rx_mark, lsd_relax.hip, indexes the region planes by rank)
   // packed round 1 (lsd_tile.hip, tx_load_rec16): owner_1 lives in the fourth word of the pixel records during round 1 — one
   // 16-byte gather per neighbour instead of two.  Needs the CV_64F detector (the word is free: the gradient norms have their own
   // plane) and the default schedule (k_tx_round2 moves the result into the owner plane).  In key mode the front pass writes the
   // unclaimed words itself (2: LAZY ids), otherwise k_tx_sort does (1).  Dev switch PLI_TX_PACK1=0 / 1.
   int packMode = 0;
-  if (!sequential && c->lsdMode != 1 && c->lsdF64 && c->mg && lostRule0 && !c->debug && !getenv("PLI_TX_FULL2") && !getenv("PLI_TX_NOFUSE2") &&
-      !(getenv("PLI_TX_SPEC") && atoi(getenv("PLI_TX_SPEC")) != 0) && !(getenv("PLI_TX_ORDER") && atoi(getenv("PLI_TX_ORDER")) != 0))
+  if (!sequential && c->lsdMode != 1 && c->lsdF64 && c->mg && lostRule0 && !c->debug && !DEVENV("PLI_TX_FULL2") && !DEVENV("PLI_TX_NOFUSE2") &&
+      !(DEVENV("PLI_TX_SPEC") && atoi(DEVENV("PLI_TX_SPEC")) != 0) && !(DEVENV("PLI_TX_ORDER") && atoi(DEVENV("PLI_TX_ORDER")) != 0))
     packMode = (keyMode && P.nBins > 128) ? 2 : 1;      // (the lazy form's fixed-point bin width needs maxGrad / (nBins - 1) < 4: tests/test_lazy_ids_cpu.py)
-  if (const char* e = getenv("PLI_TX_PACK1")) packMode = std::min(packMode, std::max(0, atoi(e)));
+  if (const char* e = DEVENV("PLI_TX_PACK1")) packMode = std::min(packMode, std::max(0, atoi(e)));
   // round 6: round 1's words in 8-byte hot records of their own (lsd_tile.hip "HOT RECORDS"); dev switch PLI_TX_HOT=0 / 1
-  bool hotMode = false;                                   // (not the default until the parity sweeps have run on it)
-  if (const char* e = getenv("PLI_TX_HOT")) hotMode = atoi(e) != 0 && packMode != 0 && c->hot != nullptr && P.prec <= 1.0 && P.alignFilter != 0;
+  // 2 (the default): every round — the later rounds take the angle from the hot record and the owner pair from the owner plane, nobody
+  // reads the 16-byte records, and the front pass does not write them (the device-side fallback of an unsettled image rebuilds them
+  // from the hot records first: k_tx_rec_from_hot); 1: round 1 only; 0: the 16-byte records everywhere (round 5's form)
+  int hotLevel = (packMode != 0 && c->hot != nullptr && P.prec <= 1.0 && P.alignFilter != 0) ? 2 : 0;
+  if (const char* e = DEVENV("PLI_TX_HOT")) hotLevel = std::min(hotLevel, std::max(0, atoi(e)));
+  if (hotLevel == 2 && (DEVENV("PLI_RX_FULL") || DEVENV("PLI_TX_NODIRTYLIST"))) hotLevel = 1;     // (dev schedules that keep to the plain later-round kernels)
+  const bool hotMode = hotLevel != 0, hotAll = hotLevel == 2;
   int2* hotPlane = hotMode ? c->hot : (int2*)nullptr;
+  int2* hotLater = hotAll ? c->hot : (int2*)nullptr;
+  float4* recPlane = hotAll ? (float4*)nullptr : c->rec;         // (what the front pass writes: the 16-byte records, or the cold plane)
+  float2* coldPlane = hotAll ? c->cold : (float2*)nullptr;
   const int trigF32 = ((c->cfg.parity_flags & PLI_PARITY_TRIG_F32_LSD) ? 1 : 0) | (packMode == 2 ? 2 : 0);
   if (c->lsdF64) {
     // OpenCV 3.x: the detector works on the CV_64FC1 copy of the image (lsd_f64.hip).  The scaled double image lives in
@@ -904,8 +942,8 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       // blur -> resize -> gradient in one pass over LDS tiles: neither double plane goes to HBM
       HIPCHK(hipMemsetAsync(c->maxMg + img0, 0, sizeof(unsigned long long) * nimg, c->stream));
       LAUNCH(c, "k_lsd_front", k_lsd_front64, dim3((P.LW + 63) / 64, (P.LH + 15) / 16, nimg), dim3(256), 0, c->pyr + P.lv[0].offset,
-             P.pyrBlock, P.W, P.H, P.lv[0].pitch, c->kern64, c->lsdRadius, c->lsdTab64, P.LW, P.LH, P.rho, c->rec, c->mg, ownPlane,
-             c->maxMg, img0, trigF32, hotPlane);
+             P.pyrBlock, P.W, P.H, P.lv[0].pitch, c->kern64, c->lsdRadius, c->lsdTab64, P.LW, P.LH, P.rho, recPlane, c->mg, ownPlane,
+             c->maxMg, img0, trigF32, hotPlane, coldPlane);
     } else {
     if (c->cfg.lsd_scale != 1) {
       LAUNCH(c, "k_blur_lsd", k_lsd_blur64, gb, dim3(256), 0, c->pyr + P.lv[0].offset, P.pyrBlock, P.W, P.H, P.lv[0].pitch,
@@ -921,7 +959,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
                             hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipMemsetAsync(c->maxMg + img0, 0, sizeof(unsigned long long) * nimg, c->stream));
     LAUNCH(c, "k_lsd_grad", k_lsd_grad64, dim3((P.LW + 255) / 256, (P.LH + 15) / 16, nimg), dim3(256), 0, scaled64, P.LW, P.LH, P.rho,
-           c->rec, c->mg, ownPlane, c->maxMg, c->debug ? c->angDbg : (float*)nullptr, img0, trigF32, hotPlane);
+           recPlane, c->mg, ownPlane, c->maxMg, c->debug ? c->angDbg : (float*)nullptr, img0, trigF32, hotPlane, coldPlane);
     }
   } else {
     const uint8_t* scaled;
@@ -968,9 +1006,9 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   if (sequential) {
     // speculative form (line_kernels.hip: lsd_grow_image_spec): the small regions of 64 seeds at a time, one per lane
     const bool spec = c->lsdSpec && P.minRegSize >= 2;
-    const bool two = nimg >= 64 && !getenv("PLI_GROW_WPB1");
+    const bool two = nimg >= 64 && !DEVENV("PLI_GROW_WPB1");
     // region2rect off the grower's serial chain: the spec grower leaves the pixel lists in the arena, k_lsd_rect does the segments
-    LsdRectItem* items = (spec && getenv("PLI_LSD_RECT_OFFLOAD")) ? c->rectItems : (LsdRectItem*)nullptr;      // dev switch: measured, not a gain
+    LsdRectItem* items = (spec && DEVENV("PLI_LSD_RECT_OFFLOAD")) ? c->rectItems : (LsdRectItem*)nullptr;      // dev switch: measured, not a gain
     if (two && spec)
       LAUNCH(c, "k_lsd_grow2", k_lsd_grow2_spec, dim3((nimg + 1) / 2), dim3(128), 0, c->dP, c->rec, c->mg, c->order, c->nDefined,
              c->regScratch, c->seg, c->nSeg, c->maxSeg, img0, nimg, items, c->rectW);
@@ -983,13 +1021,15 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     else
       LAUNCH(c, "k_lsd_grow", k_lsd_grow, dim3(nimg), dim3(64), 0, c->dP, c->rec, c->mg, c->order, c->nDefined,
              c->regScratch, c->seg, c->nSeg, c->maxSeg, img0, nimg);
+#ifdef PLI_DEV
     if (items)
       LAUNCH(c, "k_lsd_rect", k_lsd_rect, dim3(16, nimg), dim3(64), 0, c->dP, (const LsdRectItem*)items, (const uint2*)c->regScratch,
              (const double*)c->mg, (const double*)c->rectW, (const int*)c->nSeg, c->seg, c->maxSeg, img0);     // 16 = RECT_WPI
+#endif
   } else {
-    const bool trace = getenv("PLI_RX_TRACE") != nullptr;
-    const bool fullPasses = getenv("PLI_RX_FULL") != nullptr;      // dev: full-image bookkeeping in every round
-    const bool perRound = getenv("PLI_RX_PROFROUNDS") != nullptr;    // profile names carry the round number
+    const bool trace = DEVENV("PLI_RX_TRACE") != nullptr;
+    const bool fullPasses = DEVENV("PLI_RX_FULL") != nullptr;      // dev: full-image bookkeeping in every round
+    const bool perRound = DEVENV("PLI_RX_PROFROUNDS") != nullptr;    // profile names carry the round number
     int curT = 0;
     auto rxn = [&](const char* n) -> const char* {
       if (!perRound) return n;
@@ -1001,18 +1041,19 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     // incremental rank-ordered relaxation (lsd_relax.hip): rounds until every image's owner map is a fixed point
     const int64_t npix64 = (int64_t)npix;
     int growBlocks = std::max(16, std::min(256, 2048 / nimg));
-    if (const char* e = getenv("PLI_JR_BLOCKS")) growBlocks = std::max(1, atoi(e));
+    if (const char* e = DEVENV("PLI_JR_BLOCKS")) growBlocks = std::max(1, atoi(e));
     int bigBlocks = std::max(64, std::min(1024, 16384 / nimg));
-    if (const char* e = getenv("PLI_JR_BIGBLOCKS")) bigBlocks = std::max(1, atoi(e));
+    if (const char* e = DEVENV("PLI_JR_BIGBLOCKS")) bigBlocks = std::max(1, atoi(e));
     int rectBlocks = std::max(64, std::min(2048, 32768 / nimg));
-    if (const char* e = getenv("PLI_RECT_BLOCKS")) rectBlocks = std::max(1, atoi(e));      // dev: waves per image of k_rx_rect
+    if (const char* e = DEVENV("PLI_RECT_BLOCKS")) rectBlocks = std::max(1, atoi(e));      // dev: waves per image of k_rx_rect
     int bigThresh = RX_HAND;
-    if (const char* e = getenv("PLI_JR_BIG")) bigThresh = atoi(e);
+    if (const char* e = DEVENV("PLI_JR_BIG")) bigThresh = atoi(e);
     int maxRounds = 96;
-    if (const char* e = getenv("PLI_RX_MAXROUNDS")) maxRounds = std::max(1, atoi(e));
+    if (const char* e = DEVENV("PLI_RX_MAXROUNDS")) maxRounds = std::max(1, atoi(e));
     const float precDeg = (float)(P.prec * 180.0 / 3.14159265358979323846);
+    (void)growBlocks; (void)bigBlocks; (void)bigThresh; (void)precDeg;     // (the lane relaxation's: development build)
     if (c->rgClean) HIPCHK(hipMemsetAsync(c->rgClean + (int64_t)img0 * npix, 0, npix64 * nimg, c->stream));   // round stamps
-    const bool lostRule = c->lsdMode != 1 && getenv("PLI_TX_BOXRULE") == nullptr;     // dev switch: the conservative round-2 rule
+    const bool lostRule = c->lsdMode != 1 && DEVENV("PLI_TX_BOXRULE") == nullptr;     // dev switch: the conservative round-2 rule
     {
       // everything the relaxation wants zeroed at the start of a call, in one launch (k_zero_ranges): control blocks, the stamp planes,
       // the cell tables, and the tile relaxation's per-tile dirty counters (cleared by their consumers from then on), the barrier words
@@ -1031,7 +1072,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       };
       add(c->jrCtl + img0, (int64_t)(sizeof(RxCtl) / 4) * nimg);
       // (tile relaxation: k_tx_sort clears the two per-pixel stamp planes while it writes the id plane)
-      if (c->lsdMode == 1 || getenv("PLI_TX_ZERO_BY_FILL")) {
+      if (c->lsdMode == 1 || DEVENV("PLI_TX_ZERO_BY_FILL")) {
         add(c->rgDirty + (int64_t)img0 * npix, npix64 * nimg);
         if (lostRule) add(c->rgLost + (int64_t)img0 * npix, npix64 * nimg);
       }
@@ -1056,18 +1097,18 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_tx_tail, 256, 0));
       HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
       int bpc = 1;
-      if (const char* e = getenv("PLI_TX_TAIL_BPC")) bpc = std::max(1, atoi(e));
+      if (const char* e = DEVENV("PLI_TX_TAIL_BPC")) bpc = std::max(1, atoi(e));
       c->tailBlocks = perCu < 1 ? -1 : std::min(perCu, bpc) * std::max(1, cus);
     }
     c->tailLaunched = false;
-    const bool tailLatched = c->device < 0 || c->device >= TAIL_MAX_DEVICES || g_tailAborted[c->device];   // (no chain slot for the device: no tail)
-    const bool tailPossible = tile && c->tailBar && c->tailBlocks > 0 && !tailLatched && !getenv("PLI_RX_PLAN") && !trace && !perRound && !getenv("PLI_RX_BLOCKING") &&
-                              !(getenv("PLI_TX_TAIL") && atoi(getenv("PLI_TX_TAIL")) == 0) && lostRule && !getenv("PLI_TX_FULL2") &&
-                              !getenv("PLI_TX_CELLRULE") && !getenv("PLI_TX_OLDMARK") && !getenv("PLI_TX_FULLDIFF") &&
-                              !getenv("PLI_TX_NOFUSEDM") && !getenv("PLI_TX_NODIRTYLIST");
-    const bool blocking = !tailPossible && (c->rxLastRounds == 0 || trace || getenv("PLI_RX_BLOCKING") != nullptr);
+    const bool tailLatched = c->device < 0 || c->device >= TAIL_MAX_DEVICES || g_tailAborted[c->device].load(std::memory_order_relaxed);   // (no chain slot for the device: no tail)
+    const bool tailPossible = tile && c->tailBar && c->tailBlocks > 0 && !tailLatched && !DEVENV("PLI_RX_PLAN") && !trace && !perRound && !DEVENV("PLI_RX_BLOCKING") &&
+                              !(getenv("PLI_TX_TAIL") && atoi(getenv("PLI_TX_TAIL")) == 0) && lostRule && !DEVENV("PLI_TX_FULL2") &&
+                              !DEVENV("PLI_TX_CELLRULE") && !DEVENV("PLI_TX_OLDMARK") && !DEVENV("PLI_TX_FULLDIFF") &&
+                              !DEVENV("PLI_TX_NOFUSEDM") && !DEVENV("PLI_TX_NODIRTYLIST");
+    const bool blocking = !tailPossible && (c->rxLastRounds == 0 || trace || DEVENV("PLI_RX_BLOCKING") != nullptr);
     if (!blocking && !tailPossible) maxRounds = std::min(maxRounds, c->rxLastRounds + c->rxMargin);
-    if (!blocking) if (const char* e = getenv("PLI_RX_PLAN")) maxRounds = std::max(1, atoi(e));   // dev / test: a plan that is too short
+    if (!blocking) if (const char* e = DEVENV("PLI_RX_PLAN")) maxRounds = std::max(1, atoi(e));   // dev / test: a plan that is too short
     c->rxPlanned = blocking ? 0 : (tailPossible ? -1 : maxRounds);
     const int firstLook = c->rxLastRounds > 0 ? std::max(4, c->rxLastRounds) : 4;
     auto look = [&](int t) -> pli_status {
@@ -1093,57 +1134,55 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       TxKeys keys{};
       if (keyMode) keys = TxKeys{c->mg, c->maxMg, P.rho, P.nBins, c->txPixBits, c->rankOf};
       const bool pack1 = packMode != 0;
-      if (pack1) { keys.recPack = c->rec; keys.pack = packMode; keys.hot = hotPlane; }
-      if (!getenv("PLI_TX_ZERO_BY_FILL")) { keys.zeroA = c->rgDirty; keys.zeroB = lostRule ? c->rgLost : (int*)nullptr; }
+      if (pack1) { keys.recPack = c->rec; keys.pack = packMode; keys.hot = hotPlane; keys.cold = coldPlane; }
+      if (!DEVENV("PLI_TX_ZERO_BY_FILL")) { keys.zeroA = c->rgDirty; keys.zeroB = lostRule ? c->rgLost : (int*)nullptr; }
       // (test switch: a wide margin sends every unclaimed pixel of the LAZY form through the double plane; the results must not change)
-      if (const char* e = getenv("PLI_TX_LAZY_MARGIN")) keys.lazyMargin = std::max(4, std::min(0x3FFFFFFF, atoi(e)));
+      if (const char* e = DEVENV("PLI_TX_LAZY_MARGIN")) keys.lazyMargin = std::max(4, std::min(0x3FFFFFFF, atoi(e)));
+#ifdef PLI_DEV
       if (ts == 128)
         TRL(c, "k_tx_sort", k_tx_sort128, dim3(ntile, nimg), dim3(1024), 0, c->rankOf, c->order, c->own, c->txList,
             c->txTileCnt, P.LW, P.LH, ts, c->txNtx, c->txNty, img0, keys);
       else
+#endif
         TRL(c, "k_tx_sort", k_tx_sort, dim3(ntile, nimg), dim3(256), 0, c->rankOf, c->order, c->own, c->txList,
             c->txTileCnt, P.LW, P.LH, ts, c->txNtx, c->txNty, img0, keys);
-      const bool fullRound2 = getenv("PLI_TX_FULL2") != nullptr;       // dev: regrow everything in round 2
-      const size_t txPad = getenv("PLI_TX_LDSPAD") ? (size_t)atoi(getenv("PLI_TX_LDSPAD")) : 0;   // dev: occupancy cap of the tile growers
+      const bool fullRound2 = DEVENV("PLI_TX_FULL2") != nullptr;       // dev: regrow everything in round 2
+      const size_t txPad = DEVENV("PLI_TX_LDSPAD") ? (size_t)atoi(DEVENV("PLI_TX_LDSPAD")) : 0;   // dev: occupancy cap of the tile growers
       TxDirtyLists DL{c->txDirtyList, c->txDirtyCnt, c->order, ts, c->txNtx, c->txNty, P.LW, npix64};
       if (keyMode) DL.rmask = (1 << c->txPixBits) - 1;
-      if (getenv("PLI_TX_NODIRTYLIST")) DL.list = nullptr;             // dev: every active tile walks its whole seed list
+      if (DEVENV("PLI_TX_NODIRTYLIST")) DL.list = nullptr;             // dev: every active tile walks its whole seed list
       TxDirtyLists noDL = DL; noDL.list = nullptr;
       // rounds >= 3: k_rx_diff + k_tx_mark as one kernel (k_tx_diffmark; the dev rules keep the separate passes)
-      const bool fusedDM = lostRule && !fullRound2 && !getenv("PLI_TX_CELLRULE") && !getenv("PLI_TX_OLDMARK") && !getenv("PLI_TX_FULLDIFF") &&
-                           !getenv("PLI_TX_NOFUSEDM");
+      const bool fusedDM = lostRule && !fullRound2 && !DEVENV("PLI_TX_CELLRULE") && !DEVENV("PLI_TX_OLDMARK") && !DEVENV("PLI_TX_FULLDIFF") &&
+                           !DEVENV("PLI_TX_NOFUSEDM");
       // rounds >= tailT0 in one persistent launch that ends by itself when every image is at its fixed point (no host look, no
       // planned round count; dev switches: PLI_TX_TAIL=0, PLI_TX_TAIL_T0, PLI_TX_TAIL_BPC)
-      // Where the deferred ORB chain forks from the line chain (pli_batch_run): behind round 1's growth for small batches, behind round 2's
-      // for large ones.  Same-box runs at 256 frames, step in ms for a fork behind round 1 / behind round 2's owner pass (-2) / behind
-      // round 2 / behind round 3: synthetic stream 46.8 / 47.0 / 47.4 / 47.8; frames cut from photographs 33.5 / 31.7 / 30.9 / 31.8 (64 windows)
-      // and 34.7 / 32.7 / 32.1 / 32.8 (256 windows) — round 4's library on that box: 48.9 and 31.3.  k_tx_round2 streams every owner word
-      // once and is what the ORB kernels stretch most (2 -> 6-8 ms); natural images have a short round 1 and long sparse rounds that
-      // host the chain well.  Round 2 loses 1.3 % on the synthetic stream and wins 8 % on photographs: round 2 it is.  PLI_SIDE_FORK_ROUND overrides.
-      const int sideForkEnv = getenv("PLI_SIDE_FORK_ROUND") ? atoi(getenv("PLI_SIDE_FORK_ROUND")) : 0;
-      // (round 5's last builds — cell kernels with small workgroups, the tail from round 12 — moved the balance: what waits now is the END of the
-      // line chain, 1024-thread / 64 KB workgroups (k_tx_emit_sorted, the gated k_lsd_scan, k_keylines) that find no room while the ORB chain
-      // still fills every hole, so the chain should END earlier: same box, fork behind round 1 / round 2's owner pass / round 2 / round 3:
-      // synthetic 45.0 / 45.0 / 45.4-45.5 / 46.2 ms, photographs 28.6 / 28.5 / 29.5 / 30.0.  Behind round 2's owner pass it is.)
+      // Where the deferred ORB chain forks from the line chain (pli_batch_run): behind round 1's growth up to 64 images, behind round 2's
+      // pass over the owner map (-2) above — what waits in a large batch is the END of the line chain (the 1024-thread / 64 KB workgroups
+      // of k_tx_emit_sorted, the gated k_lsd_scan, k_keylines find no room while the ORB chain fills every hole), so the chain should end
+      // early, and k_tx_round2, which the ORB kernels stretch most, should run alone.  Same box, 256 frames, fork behind round 1 /
+      // round 2's owner pass / round 2 / round 3: synthetic 45.0 / 45.0 / 45.4-45.5 / 46.2 ms, photographs 28.6 / 28.5 / 29.5 / 30.0
+      // (DESIGN.md 5 has the history).  Dev switch PLI_SIDE_FORK_ROUND.
+      const int sideForkEnv = DEVENV("PLI_SIDE_FORK_ROUND") ? atoi(DEVENV("PLI_SIDE_FORK_ROUND")) : 0;
       const int sideForkRound = sideForkEnv ? sideForkEnv : (nimg <= 64 ? 1 : -2);
       // (round 1's region2rect pass on a stream of its own beside k_tx_round2: the default schedule only; dev switch PLI_RECT_ASIDE=0)
       // (a single pair pays 0.06 ms for the two events and the reset launch and has nothing to overlap: from 8 images on)
       // (the ORB chain's stream when the chain is waiting to fork behind round 2 or later: idle until then)
-      const bool rectOnSide = c->sideChain && c->aux && (sideForkRound >= 2 || sideForkRound == -2) && !getenv("PLI_RECT_OWN_STREAM");
-      const bool rectAside = lostRule && !fullRound2 && !getenv("PLI_TX_NOFUSE2") && !trace && !perRound && !blocking && maxRounds >= 2 && !c->syncDebug &&
-                             (getenv("PLI_RECT_ASIDE") ? atoi(getenv("PLI_RECT_ASIDE")) != 0 : (nimg >= 8 && (rectOnSide || c->sH2D == nullptr)));
+      const bool rectOnSide = c->sideChain && c->aux && (sideForkRound >= 2 || sideForkRound == -2) && !DEVENV("PLI_RECT_OWN_STREAM");
+      const bool rectAside = lostRule && !fullRound2 && !DEVENV("PLI_TX_NOFUSE2") && !trace && !perRound && !blocking && maxRounds >= 2 && !c->syncDebug &&
+                             (DEVENV("PLI_RECT_ASIDE") ? atoi(DEVENV("PLI_RECT_ASIDE")) != 0 : (nimg >= 8 && (rectOnSide || c->sH2D == nullptr)));
       const bool useTail = tailPossible && fusedDM && DL.list;
       // rounds 3 .. tail start of a large batch by cell lists (six lean launches per round instead of four that walk every block;
       // a small batch keeps the four: launches are what it pays for).  Dev switch PLI_TX_CELLS=0 / 1.
       // (measured: 256 frames of 752 x 480 +2 %, 64 of 1280 x 720 +1 %, 16 of 4K +2 %; 32 frames of 752 x 480 -4 %: a million cells is the line)
       bool useCells = fusedDM && DL.list && c->txCellList && (int64_t)c->tilesW * c->tilesH * nimg >= (1 << 20);
-      if (const char* e = getenv("PLI_TX_CELLS")) useCells = atoi(e) != 0 && fusedDM && DL.list && c->txCellList;
+      if (const char* e = DEVENV("PLI_TX_CELLS")) useCells = atoi(e) != 0 && fusedDM && DL.list && c->txCellList;
       // The persistent kernel takes over at round 8 — at round 12 when the rounds before it run on cell lists: their launches are lean, and
       // a large batch still has the ORB chain on the chip around round 8, beside which the tail's 256 workgroups of 50 KB LDS, which must
       // ALL be resident, wait for their compute units (k_tx_tail 0.7 ms alone, 2.6 ms in the default line).  256 frames, same box, start
       // at 8 / 12 / 14 / 16: synthetic 46.0-46.1 / 45.7 / 45.6 / 45.6 ms, photographs 29.2-29.3 / 29.3 / 29.4 / 29.7.
       int tailT0 = useCells ? 12 : 8;
-      if (const char* e = getenv("PLI_TX_TAIL_T0")) tailT0 = std::max(3, atoi(e));
+      if (const char* e = DEVENV("PLI_TX_TAIL_T0")) tailT0 = std::max(3, atoi(e));
       for (int t = 1; t <= maxRounds && !allDone; ++t) {
         curT = t;
         if (useTail && t == tailT0) {
@@ -1152,10 +1191,11 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
           TxTailArgs ta{c->dP, c->jrCtl, c->rec, c->own, c->txList, c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty,
                         c->tileAct, c->tileTouch, c->tilesW, c->tilesH, c->arena, c->arenaCap, c->rects, c->rectCap, c->rgSeg, c->mg,
                         c->rankOf, c->rgLost, DL, img0, nimg, t, maxRounds, c->tailBar};
+          ta.hot = hotLater; ta.cold = coldPlane;
           // (a grid barrier costs 8 us with 256 workgroups and less with fewer: a few images do not need the whole chip in the late rounds)
           // (single pair: k_tx_tail 149 us with 256 workgroups, 90 with 64)
           int tb = std::min(c->tailBlocks, std::max(64, 8 * nimg));
-          if (const char* e = getenv("PLI_TX_TAIL_BLOCKS")) tb = std::max(1, std::min(c->tailBlocks, atoi(e)));     // dev switch
+          if (const char* e = DEVENV("PLI_TX_TAIL_BLOCKS")) tb = std::max(1, std::min(c->tailBlocks, atoi(e)));     // dev switch
           // k_tx_tail spins on a grid barrier, so its grid must be co-resident; the grid is sized for a device it has to itself.  Two
           // tails in flight at once (two contexts of this process on one device) could each hold a part of the other's slots and spin
           // until the barrier's timeout: tails of one process are chained per device — a tail starts when the previous one has ended.
@@ -1165,7 +1205,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
             std::lock_guard<std::mutex> lk(g_tailMu);
             hipEvent_t& ev = g_tailEv[c->device];             // (0 <= device < TAIL_MAX_DEVICES: tailPossible)
             c->tailLaunched = true;
-            ta.forceAbort = getenv("PLI_TX_TAIL_FORCE_ABORT") ? 1 : 0;   // test switch: the kernel leaves at once, as after a barrier timeout
+            ta.forceAbort = DEVENV("PLI_TX_TAIL_FORCE_ABORT") ? 1 : 0;   // test switch: the kernel leaves at once, as after a barrier timeout
             if (ev) HIPCHK(hipStreamWaitEvent(c->stream, ev, 0));
             else HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             LAUNCH(c, "k_tx_tail", k_tx_tail, dim3(tb), dim3(256), 0, ta);
@@ -1177,7 +1217,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
         // the dev schedule that regrows everything in round 2 does not read the lists it stamped)
         if (t == 3 && DL.list && fullRound2)
           HIPCHK(hipMemsetAsync(c->txDirtyCnt + (int64_t)img0 * ntile, 0, sizeof(int) * (size_t)ntile * nimg, c->stream));
-        const bool fused2 = t == 2 && !fullRound2 && lostRule && !getenv("PLI_TX_NOFUSE2");    // (dev switch: the two passes)
+        const bool fused2 = t == 2 && !fullRound2 && lostRule && !DEVENV("PLI_TX_NOFUSE2");    // (dev switch: the two passes)
         bool cellsDone = false;
         if (fused2) {
           TRL(c, "k_tx_round2", k_tx_round2, dim3((P.LW + 31) / 32, (P.LH + 31) / 32, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->order,
@@ -1213,27 +1253,38 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
         } else if (t >= 3 && fusedDM)
           TRL(c, "k_tx_diffmark", k_tx_diffmark, dim3((P.LW + 31) / 32, (c->tilesH + 7) / 8, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf,
               c->rgBox, c->rgDirty, c->tileAct, (const int*)c->tileTouch, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, (const int*)c->rgLost, DL);
+#ifdef PLI_DEV     // (the unfused passes of the dev switches: the product's round 2 is k_tx_round2, its rounds >= 3 k_tx_diffmark or the cell lists)
         else if (t == 2 && !fullRound2)
           TRL(c, "k_tx_diff2", k_tx_diff2, dim3((P.LW + 31) / 32, c->tilesH, nimg), dim3(256), 0, c->jrCtl, c->own, c->order, c->rgBox,
               c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, ts, t, img0, lostRule ? (const int*)c->rgLost : (const int*)nullptr, DL);
         else if (t >= 2)                     // (round 1 starts from the trivial map: nothing to compare, the control block is zeroed)
           TRL(c, "k_rx_diff", k_rx_diff, dim3((P.LW + 31) / 32, (c->tilesH + 7) / 8, nimg), dim3(256), 0, c->jrCtl, c->own, c->tileMin, c->tileAct,
               P.LW, P.LH, c->tilesW, c->tilesH, t, img0,
-              (t >= 3 && !fullRound2 && !getenv("PLI_TX_FULLDIFF")) ? (const int*)c->tileTouch : (const int*)nullptr);
+              (t >= 3 && !fullRound2 && !DEVENV("PLI_TX_FULLDIFF")) ? (const int*)c->tileTouch : (const int*)nullptr);
+#endif
         if (t >= 3 || (t == 2 && !fullRound2)) {
           // (round 2 under the lost-pixel rule: k_tx_diff2 has stamped the regions itself, k_rx_mark would find nothing)
           if (t >= 3 && fusedDM) {
             // (k_tx_diffmark has done it)
-          } else if (lostRule && t >= 3 && !getenv("PLI_TX_CELLRULE") && !getenv("PLI_TX_OLDMARK"))
+          }
+#ifdef PLI_DEV
+          else if (lostRule && t >= 3 && !DEVENV("PLI_TX_CELLRULE") && !DEVENV("PLI_TX_OLDMARK"))
           TRL(c, "k_rx_mark", k_tx_mark, dim3((P.LW + 31) / 32, (c->tilesH + 7) / 8, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->rgBox,
               c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, (const int*)c->rgLost, DL);
           else if (t >= 3 || !lostRule)
           TRL(c, "k_rx_mark", k_rx_mark, dim3((P.LW + 31) / 32, (c->tilesH + 7) / 8, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf, c->rgBox,
               c->rgDirty, c->tileMin, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, t >= 3 ? 1 : 0,
-              (lostRule && t >= 3 && !getenv("PLI_TX_CELLRULE")) ? (const int*)c->rgLost : (const int*)nullptr, DL);
+              (lostRule && t >= 3 && !DEVENV("PLI_TX_CELLRULE")) ? (const int*)c->rgLost : (const int*)nullptr, DL);
+#endif
           if (!fused2 && !cellsDone)
           TRL(c, "k_tx_prep", k_tx_prep, dim3((P.LW + 31) / 32, (P.LH + 31) / 32, nimg), dim3(256), 0, c->jrCtl, c->own, c->rankOf,
               c->rgDirty, c->tileAct, P.LW, P.LH, c->tilesW, c->tilesH, t, img0, t == 2 ? 1 : 0, fusedDM ? c->tileTouch : (int*)nullptr, DL.rmask);
+          if (hotLater)
+          TRL(c, "k_tx_grow_sparse", k_tx_grow_sparse_h, dim3(ntile, nimg), dim3(64), txPad, c->dP, c->jrCtl, c->rec, c->own, c->txList,
+              c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty, c->tileAct, c->tilesW, c->tilesH, c->arena,
+              c->arenaCap, c->rects, c->rectCap, img0, t, (const int*)c->rankOf, lostRule ? c->rgLost : (int*)nullptr, c->tileTouch,
+              fullRound2 && t == 2 ? noDL : DL, hotLater, (const float2*)coldPlane);
+          else
           TRL(c, "k_tx_grow_sparse", k_tx_grow_sparse, dim3(ntile, nimg), dim3(64), txPad, c->dP, c->jrCtl, c->rec, c->own, c->txList,
               c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty, c->tileAct, c->tilesW, c->tilesH, c->arena,
               c->arenaCap, c->rects, c->rectCap, img0, t, (const int*)c->rankOf, lostRule ? c->rgLost : (int*)nullptr, c->tileTouch,
@@ -1242,21 +1293,26 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
           // round 1 in the speculative schedule (lanes grow the small regions of 64 alive seeds at a time, lsd_tile.hip): exact, built
           // and measured in round 3, NOT the default — 37 ms against 22 ms of the plain schedule at 256 frames (the
           // divergent per-lane accept path costs more instructions than the whole-wave steps it replaces).  Dev switch PLI_TX_SPEC=1.
-          const bool specRound1 = lostRule && P.minRegSize >= 3 && getenv("PLI_TX_SPEC") && atoi(getenv("PLI_TX_SPEC")) != 0;
+#ifdef PLI_DEV
+          const bool specRound1 = lostRule && P.minRegSize >= 3 && DEVENV("PLI_TX_SPEC") && atoi(DEVENV("PLI_TX_SPEC")) != 0;
           if (specRound1)
           TRL(c, "k_tx_grow", k_tx_grow_spec, dim3(ntile, nimg), dim3(64), txPad, c->dP, c->jrCtl, c->rec, c->own, c->txList,
               c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty, c->tileAct, c->tilesW, c->tilesH, c->arena,
               c->arenaCap, c->rects, c->rectCap, img0, t, (const int*)c->rankOf, lostRule ? c->rgLost : (int*)nullptr, c->tileTouch, noDL);
-          else {
+          else
+#endif
+          {
           // dev switch PLI_TX_ORDER=1: the heaviest tiles first (k_tx_order).  Measured, not the default: the launch does end on fewer
           // stragglers, but consecutive workgroups no longer grow neighbouring tiles of one image and k_tx_grow goes from 23.2 to
           // 31.3 ms at 256 frames (4K: 33.1 -> 44.2 ms) — the grid order's locality is worth more than the balance
           TxDirtyLists r1DL = noDL;
-          if ((nimg % 8) == 0 && getenv("PLI_TX_XCD") && atoi(getenv("PLI_TX_XCD")) != 0) r1DL.xcdAffine = 1;
-          if (getenv("PLI_TX_ORDER") && atoi(getenv("PLI_TX_ORDER")) != 0) {
+          if ((nimg % 8) == 0 && DEVENV("PLI_TX_XCD") && atoi(DEVENV("PLI_TX_XCD")) != 0) r1DL.xcdAffine = 1;
+#ifdef PLI_DEV
+          if (DEVENV("PLI_TX_ORDER") && atoi(DEVENV("PLI_TX_ORDER")) != 0) {
             TRL(c, "k_tx_order", k_tx_order, dim3(1), dim3(1024), 0, (const int*)c->txTileCnt, ntile, nimg, img0, c->txPerm + (int64_t)img0 * ntile);
             r1DL.perm = c->txPerm + (int64_t)img0 * ntile;
           }
+#endif
           if (hotPlane && packMode == 2)
           TRL(c, "k_tx_grow", k_tx_grow_h2, dim3(ntile, nimg), dim3(64), txPad, c->dP, c->jrCtl, c->rec, c->own, c->txList,
               c->txTileCnt, ts, c->txNtx, c->txNty, c->lastSize, c->rgBox, c->rgDirty, c->tileAct, c->tilesW, c->tilesH, c->arena,
@@ -1317,7 +1373,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
           {
             auto launchRect = [&]() -> pli_status {
               TRL(c, "k_rx_rect", k_rx_rect, dim3(rectBlocks, nimg), dim3(64), 0, c->dP, c->jrCtl, c->rec, c->arena, c->arenaCap, c->rects,
-                  c->rectCap, c->rgSeg, img0, c->mg, DL.rmask);
+                  c->rectCap, c->rgSeg, img0, c->mg, DL.rmask, (const int2*)hotPlane, (const float2*)coldPlane);
               return PLI_OK;
             };
             const pli_status rs = launchRect();
@@ -1328,7 +1384,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
           HIPCHK(hipEventRecord(c->evRectDone, rectS));
         } else
         TRL(c, "k_rx_rect", k_rx_rect, dim3(rectBlocks, nimg), dim3(64), 0, c->dP, c->jrCtl, c->rec, c->arena, c->arenaCap, c->rects,
-            c->rectCap, c->rgSeg, img0, c->mg, DL.rmask);
+            c->rectCap, c->rgSeg, img0, c->mg, DL.rmask, (const int2*)hotPlane, (const float2*)coldPlane);
         if (trace) {
           HIPCHK(hipMemcpyAsync(c->jrHost.data(), c->jrCtl + img0, sizeof(RxCtl) * nimg, hipMemcpyDeviceToHost, c->stream));
           HIPCHK(hipStreamSynchronize(c->stream));
@@ -1340,6 +1396,10 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
         if (ls != PLI_OK) return ls;
       }
     } else {
+#ifndef PLI_DEV
+      g_err = "lsd_mode 1 (the lane relaxation) is a development schedule: libpli_frontend_dev.so";
+      return PLI_ERR_INVALID;
+#else
     TRL(c, "k_rx_guess", k_rx_guess, raster, dim3(256), 0, c->rec, c->rankOf, c->own, P.LW, P.LH, precDeg, img0);
     for (int t = 1; t <= maxRounds && !allDone; ++t) {
       curT = t;
@@ -1368,7 +1428,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
         TRL(c, "k_rx_grow_big", k_rx_grow_big, dim3(bigBlocks, nimg), dim3(64), 0, c->dP, c->jrCtl, c->rec, c->own, c->bigSeeds,
             c->bigCap, c->hand, c->handCap, c->lastSize, c->rgBox, c->arena, c->arenaCap, c->rects, c->rectCap, img0, t);
       TRL(c, "k_rx_rect", k_rx_rect, dim3(rectBlocks, nimg), dim3(64), 0, c->dP, c->jrCtl, c->rec, c->arena, c->arenaCap, c->rects,
-          c->rectCap, c->rgSeg, img0, c->mg, -1);
+          c->rectCap, c->rgSeg, img0, c->mg, -1, (const int2*)nullptr, (const float2*)nullptr);
       if (trace) {
         HIPCHK(hipMemcpyAsync(c->jrHost.data(), c->jrCtl + img0, sizeof(RxCtl) * nimg, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -1379,10 +1439,11 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       }
       { pli_status ls_ = look(t); if (ls_ != PLI_OK) return ls_; }
     }
+#endif
     }
     if (keyMode) {
       int emitCap = TX_EMIT_CAP;                   // (test switch: a small list, so that images take the overflow path to the sequential grower)
-      if (const char* e = getenv("PLI_TX_EMITCAP")) emitCap = std::max(1, std::min(TX_EMIT_CAP, atoi(e)));
+      if (const char* e = DEVENV("PLI_TX_EMITCAP")) emitCap = std::max(1, std::min(TX_EMIT_CAP, atoi(e)));
       TRL(c, "k_tx_collect", k_tx_collect, dim3(std::max(1, std::min(64, (int)((npix64 + 2047) / 2048))), nimg), dim3(256), 0, c->jrCtl,
           (const int*)c->rankOf, (const int2*)c->own, (const int*)c->lastSize, npix64, P.minRegSize, c->txCand, c->txCandCnt, img0, emitCap);
       TRL(c, "k_tx_emit_sorted", k_tx_emit_sorted, dim3(nimg), dim3(1024), TX_EMIT_CAP * 4, (const RxCtl*)c->jrCtl, (const int*)c->txCand,
@@ -1397,6 +1458,10 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
            c->rgSeg, c->rxChunkCnt, c->rxChunks, npix64, P.minRegSize, c->seg, c->nSeg, c->maxSeg, img0);
     }
     // images that ran out of a capacity (or did not settle) take the sequential grower
+    // (... which reads the 16-byte records: with every round on the hot records nobody has written them — for those images, now)
+    if (hotAll)
+      LAUNCH(c, "k_tx_rec_from_hot", k_tx_rec_from_hot, dim3(std::max(1, std::min(64, (int)((npix64 + 4095) / 4096))), nimg), dim3(256), 0,
+             (const RxCtl*)c->jrCtl, (const int2*)c->hot, (const float2*)c->cold, c->rec, npix64, img0);
     if (blocking && !keyMode) {
       for (int i = 0; i < nimg; ++i) {
         if (c->jrHost[i].overflow || c->jrHost[i].state != 2) {
@@ -1410,11 +1475,15 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
              c->regScratch, c->seg, c->nSeg, c->maxSeg, img0, nimg, c->jrCtl);
       if (!blocking) {
       if (!c->rxSeen) {
-        HIPCHK(hipHostMalloc((void**)&c->rxSeen, sizeof(int) * 4 * (size_t)c->NI, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void**)&c->rxSeen, sizeof(int) * (4 * (size_t)c->NI + 1), hipHostMallocDefault));     // (+ the tail's abort word)
+        c->rxSeen[4 * (size_t)c->NI] = 0;
         HIPCHK(hipEventCreateWithFlags(&c->evRxSeen, hipEventDisableTiming));
       }
       if (c->rxSeenImages == 0) {                       // (an earlier copy still in flight keeps the buffer: this call is not sampled)
         HIPCHK(hipMemcpy2DAsync(c->rxSeen, 16, c->jrCtl + img0, sizeof(RxCtl), 16, nimg, hipMemcpyDeviceToHost, c->stream));
+        if (c->tailBar && c->tailLaunched)
+          HIPCHK(hipMemcpyAsync(c->rxSeen + 4 * (size_t)c->NI, c->tailBar + 32, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        else c->rxSeen[4 * (size_t)c->NI] = 0;
         HIPCHK(hipEventRecord(c->evRxSeen, c->stream));
         c->rxSeenImages = nimg;
         c->rxSeenTail = c->tailLaunched;
@@ -1452,7 +1521,7 @@ pli_status runStereoLines(pli_ctx* c, int nframes, uint8_t* table) {
   const pli_table_layout& Y = c->lay;
   // (many lines per frame: the pair distances by several workgroups per frame, see the kernel)
   const int cap = c->hp.klCap;
-  const int slices = (cap >= 192 && !getenv("PLI_STEREO_LINES_1")) ? std::max(1, std::min(64, (cap * cap) / 8192)) : 1;
+  const int slices = (cap >= 192 && !DEVENV("PLI_STEREO_LINES_1")) ? std::max(1, std::min(64, (cap * cap) / 8192)) : 1;
   for (int phase = slices > 1 ? 1 : 0; phase <= (slices > 1 ? 3 : 0); ++phase)
     LAUNCH(c, "k_stereo_lines", k_stereo_lines, dim3(nframes, phase == 2 ? slices : 1), dim3(256), 0, c->dP, table, Y.record_bytes,
            Y.off_counts, Y.off_kl[0], Y.off_kl[1], Y.off_ldesc[0], Y.off_ldesc[1], Y.off_disp, Y.off_le, c->lmask, c->ldir, c->dmat,
@@ -1648,24 +1717,24 @@ pli_status pli_batch_run(pli_ctx* c, int32_t nframes, const uint8_t* dl, const u
   // 128 frames 3711 -> 3947, 256 frames 4054 -> 4245, 512 frames 4268 -> 4379, 768 frames 4303 -> 4420; sequential grower
   // 1024 frames 4213 -> 4544, 1280 frames 4830 -> 5266; from 1536 frames on the grower's blocks fill the CUs' LDS, the ORB
   // kernels wait for it and stretch the grower: 5170 -> 4287, 2048 frames 6067 -> 4942.
-  static const int sideMax = getenv("PLI_SIDE_MAX") ? atoi(getenv("PLI_SIDE_MAX")) : INT_MAX;    // (dev: images below which the tile relaxation has the ORB chain beside it)
-  static const int sideSeqMax = getenv("PLI_SIDE_SEQ_MAX") ? atoi(getenv("PLI_SIDE_SEQ_MAX")) : 2560;
+  static const int sideMax = DEVENV("PLI_SIDE_MAX") ? atoi(DEVENV("PLI_SIDE_MAX")) : INT_MAX;    // (dev: images below which the tile relaxation has the ORB chain beside it)
+  static const int sideSeqMax = DEVENV("PLI_SIDE_SEQ_MAX") ? atoi(DEVENV("PLI_SIDE_SEQ_MAX")) : 2560;
   const bool seqGrower = c->lsdMode == 2 || (c->lsdMode == 0 && (nimg >= RX_AUTO_IMAGES || nimg > c->rxImages));
   if ((seqGrower ? nimg <= sideSeqMax : nimg < sideMax) && (stages & PLI_RUN_ORB) && (stages & PLI_RUN_LINES) && !c->syncDebug) {
     if (!c->aux) {
       // (the line chain is the longer one: the ORB chain beside it takes what the line kernels leave free)
       int prLow = 0, prHigh = 0;
       HIPCHK(hipDeviceGetStreamPriorityRange(&prLow, &prHigh));
-      if (getenv("PLI_SIDE_NOPRIO")) prLow = 0;            // dev switch: default priority
+      if (DEVENV("PLI_SIDE_NOPRIO")) prLow = 0;            // dev switch: default priority
       HIPCHK(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prLow));
       HIPCHK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&c->evLbdPre, hipEventDisableTiming));
     }
     hipStream_t main = c->stream;
-    static const bool sideStereo = getenv("PLI_SIDE_NOSTEREO") == nullptr;      // (dev switch)
-    static const bool sideLbd = getenv("PLI_SIDE_NOLBD") == nullptr;            // (dev switch)
-    static const bool sideDefer = getenv("PLI_SIDE_NODEFER") == nullptr;        // (dev switch)
+    static const bool sideStereo = DEVENV("PLI_SIDE_NOSTEREO") == nullptr;      // (dev switch)
+    static const bool sideLbd = DEVENV("PLI_SIDE_NOLBD") == nullptr;            // (dev switch)
+    static const bool sideDefer = DEVENV("PLI_SIDE_NODEFER") == nullptr;        // (dev switch)
     stereoPointsDone = (stages & PLI_RUN_STEREO_POINTS) && sideStereo;
     c->lbdPreOnSide = c->lsdF64 && sideLbd;
     // the side chain: forks from the line chain where it is enqueued.  Under the tile relaxation that is right after the
@@ -1693,7 +1762,7 @@ pli_status pli_batch_run(pli_ctx* c, int32_t nframes, const uint8_t* dl, const u
     // 512 frames +0.3 %, 1024 frames -0.4 %; 64 frames of 1280 x 720 (2000 keypoints: a longer ORB chain) still -1.3 %.  So: up to 64
     // images always, up to 1024 images of EuRoC-sized frames (< 0.5 M pixels).  Behind a LATER round (PLI_SIDE_FORK_ROUND = 3 / 4 / 5 / 7)
     // it is 47.4 / 47.5 / 47.9 / 48.4 ms on the synthetic stream; which round it forks behind: runLines (sideForkRound).
-    const int sideDeferMax = getenv("PLI_SIDE_DEFER_MAX") ? atoi(getenv("PLI_SIDE_DEFER_MAX")) : -1;   // (dev: images up to which the ORB chain starts behind round 1)
+    const int sideDeferMax = DEVENV("PLI_SIDE_DEFER_MAX") ? atoi(DEVENV("PLI_SIDE_DEFER_MAX")) : -1;   // (dev: images up to which the ORB chain starts behind round 1)
     const bool deferSide = sideDeferMax >= 0 ? nimg <= sideDeferMax : (nimg <= 64 || (nimg <= 1024 && (int64_t)c->hp.W * c->hp.H < 500000));
     if (sideDefer && !seqGrower && c->lsdMode != 1 && deferSide) c->sideChain = sideChain;
     else if ((st = sideChain()) != PLI_OK) { c->lbdPreOnSide = false; return st; }
@@ -1962,6 +2031,13 @@ pli_status pli_lsd_round_stats(pli_ctx* c, int32_t out[4]) {
   out[0] = c->rxPlanned;
   out[2] = (int32_t)std::min<int64_t>(c->rxSlowImages, INT32_MAX);
   out[3] = c->rxLastRounds;
+  return PLI_OK;
+}
+
+pli_status pli_lsd_arena_words(pli_ctx* c, int32_t* words_per_pixel) {
+  CtxGuard guard__(c);
+  if (!c || !words_per_pixel) { g_err = "bad argument"; return PLI_ERR_INVALID; }
+  *words_per_pixel = c->arenaFactor;
   return PLI_OK;
 }
 

@@ -15,6 +15,7 @@ read like the reference's call sites:
 All arithmetic happens in the HIP library; this file only moves buffers.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -29,12 +30,25 @@ def _u8(img):
     return img
 
 
+PRODUCT_ENV = ("PLI_ROCTX", "PLI_SYNC_DEBUG", "PLI_TX_TAIL", "PLI_LSD_MODE")      # what libpli_frontend.so itself reads
+PYTHON_ENV = ("PLI_LIB_PATH", "PLI_USE_DEV_LIB", "PLI_FUSION_WAIT_MS")             # read by this package / the C++ adapters
+
+
+def needs_dev_library(cfg):
+    """The development build is the one that knows lsd_mode 1 (the lane relaxation) and the environment switches of tools/README.md."""
+    return cfg.lsd_mode == 1 or any(k.startswith("PLI_") and k not in PRODUCT_ENV + PYTHON_ENV for k in os.environ)
+
+
 class Frontend:
     """One pli_ctx: device buffers + stream for up to `max_frames` stereo frames."""
 
-    def __init__(self, cfg, device=0):
+    def __init__(self, cfg, device=0, dev=None):
+        """dev: the development build of the library (libpli_frontend_dev.so) instead of the product one; None = the product build
+        unless the configuration or the environment asks for something only the development build has (the dev-switch tests and
+        tools).  bench.py passes False: its line is the product library's."""
         self.cfg = cfg
-        self.L = capi.lib()
+        self.dev = needs_dev_library(cfg) if dev is None else bool(dev)
+        self.L = capi.lib(dev=self.dev)
         self.h = C.c_void_p()
         check(self.L.pli_ctx_create(C.byref(cfg), device, C.byref(self.h)))
         self.layout = capi.TableLayout()
@@ -319,6 +333,12 @@ class Frontend:
         out = (C.c_int32 * 4)()
         check(self.L.pli_lsd_round_stats(self.h, out))
         return tuple(int(v) for v in out)
+
+    def lsd_arena_words(self):
+        """Arena words per scaled LSD pixel this context got (16 unless it is large or the device was short of memory) — pli_lsd_arena_words."""
+        out = C.c_int32()
+        check(self.L.pli_lsd_arena_words(self.h, C.byref(out)))
+        return out.value
 
     def selftest_hot_trig(self):
         """Largest |v_cos / v_sin - cos / sin| over every float angle in [0, 360] degrees on this device (pli_selftest_hot_trig)."""

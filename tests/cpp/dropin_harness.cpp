@@ -316,6 +316,12 @@ int main(int argc, char** argv) {
             for (int r = 0; r < 3; ++r) { for (int q = 0; q < 3; ++q) Tcw.at<float>(r, q) = Rcw.at<float>(r, q); Tcw.at<float>(r, 3) = tcw.at<float>(r); }
             cur->mTcw = Tcw;
             std::fill(cur->mvpMapPoints.begin(), cur->mvpMapPoints.end(), static_cast<MapPoint*>(NULL));
+            // the sideways case: every fifth keypoint of the current frame already holds a map point with observations, which makes
+            // it unavailable (ORBmatcher.cc:2255-2257)
+            static MapPoint observedElsewhere;
+            observedElsewhere.nObs = 3;
+            if (c == 2)
+              for (int j = 0; j < cur->N; j += 5) cur->mvpMapPoints[j] = &observedElsewhere;
             ORBmatcher matcher(0.9f, c != 2);          // the sideways case also runs without the orientation check
             std::map<int, int> match12;
             const int nm = matcher.SearchByProjection(*cur, *last, bMono ? 15.f : 7.f, bMono, match12);
@@ -357,6 +363,7 @@ int main(int argc, char** argv) {
               std::unique_ptr<MapPoint> mp(new MapPoint());
               mp->mWorldPos = Rwc * x3Dc + Ow;
               mp->mDescriptor = cur->mDescriptors.row(j).clone();
+              mp->nObs = (j % 3 == 0) ? 0 : 2;       // (a third of them like Tracking::UpdateLastFrame's temporal points: no observations)
               cur->mvpMapPoints[j] = mp.get();
               lastPoints.push_back(std::move(mp));
             }

@@ -39,6 +39,24 @@ def test_struct_sizes():
     assert capi.lib().pli_kl_capacity(C.byref(c)) == 500
 
 
+def test_the_product_library_reads_four_environment_variables_and_no_more():
+    """The schedules that were measured and shelved, the test switches and the tuning knobs live in the development build
+    (libpli_frontend_dev.so, -DPLI_DEV): the product library does not even contain their names, so a stray variable in an integrator's
+    environment cannot change a schedule.  Both builds export the whole C ABI."""
+    import re
+    import subprocess
+    csrc = os.path.join(ROOT, "pli_slam_amd", "csrc")
+    names = {}
+    for lib in ("libpli_frontend.so", "libpli_frontend_dev.so"):
+        out = subprocess.run(["strings", "-n", "6", os.path.join(csrc, lib)], capture_output=True, text=True, check=True).stdout
+        names[lib] = sorted({m.group(0) for l in out.splitlines() for m in [re.match(r"PLI_[A-Z0-9_]+", l)] if m})
+    assert set(names["libpli_frontend.so"]) == {"PLI_ROCTX", "PLI_SYNC_DEBUG", "PLI_TX_TAIL", "PLI_LSD_MODE"}, names["libpli_frontend.so"]
+    assert len(names["libpli_frontend.so"]) <= 8 and len(names["libpli_frontend_dev.so"]) > 40
+    dev = capi.lib(dev=True)
+    for name in capi._PROTOS:
+        assert hasattr(dev, name), name
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():

@@ -608,7 +608,7 @@ def test_long_parallel_structures_settle_without_the_fallback(gpu, monkeypatch):
     for arena, falls_back in ((None, False), ("3", True)):
         if arena:
             monkeypatch.setenv("PLI_RX_ARENA", arena)
-        fe = g.Frontend(cfg)
+        fe = g.Frontend(cfg, dev=True)
         for _ in range(2):                                   # (the second call: look-free rounds)
             n, kl, ld = fe.line_extract(0, stripes)
             assert n == want[0] and kl.tobytes() == want[1].tobytes() and np.array_equal(ld, want[2]), arena
@@ -1089,7 +1089,7 @@ def test_sequential_grower_dev_switches(gpu, flags, monkeypatch):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         cfg = g.capi.default_config(W, H, orb_nfeatures=300, lsd_nfeatures=0, max_frames=1, lsd_mode=2, **over)
-        fe = g.Frontend(cfg)
+        fe = g.Frontend(cfg, dev=True)
         m, kl, ld = fe.line_extract(0, L)
         if want is None:
             fr = g.po.Frame(ocfg(g, cfg))
@@ -1117,7 +1117,7 @@ def test_tile_relaxation_dev_switches(gpu, W, H, monkeypatch):
         if on:
             monkeypatch.setenv(on, "1")
         cfg = g.capi.default_config(W, H, orb_nfeatures=300, lsd_nfeatures=0, max_frames=1, lsd_mode=3)
-        fe = g.Frontend(cfg)
+        fe = g.Frontend(cfg, dev=True)
         m, kl, ld = fe.line_extract(0, L)
         if want is None:
             fr = g.po.Frame(ocfg(g, cfg))
@@ -1155,7 +1155,7 @@ def test_look_free_rounds_and_device_side_fallback(gpu, monkeypatch):
     g = gpu
     W, H = 752, 480
     cfg = g.capi.default_config(W, H, orb_nfeatures=1200, lsd_nfeatures=100, max_frames=4)
-    fe = g.Frontend(cfg)
+    fe = g.Frontend(cfg, dev=True)
     pairs = [g.synth.make_stereo_pair(60 + i, W, H) for i in range(4)]
     imgs = np.stack([np.stack(p) for p in pairs])
     first = fe.batch_run_host(imgs)                          # the late rounds in the persistent tail kernel: no look, no plan
@@ -1198,7 +1198,7 @@ def test_key_mode_and_rank_mode_and_the_segment_list_overflow(gpu, monkeypatch):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        fe = g.Frontend(cfg)
+        fe = g.Frontend(cfg, dev=True)
         fe.batch_run_host(imgs)
         out[what] = fe.batch_run_host(imgs)                  # (the second call: look-free rounds)
         st = fe.lsd_round_stats()
@@ -1234,7 +1234,7 @@ def test_round1_owner_word_forms(gpu, monkeypatch):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        fe = g.Frontend(cfg)
+        fe = g.Frontend(cfg, dev=True)
         fe.batch_run_host(imgs)
         out[what] = fe.batch_run_host(imgs)
         assert fe.lsd_round_stats()[2] == 0, (what, fe.lsd_round_stats())      # nobody on the slow path
@@ -1248,6 +1248,29 @@ def test_round1_owner_word_forms(gpu, monkeypatch):
                 assert out[what][f][k].tobytes() == out["lazy"][f][k].tobytes(), (what, f, k)
 
 
+def test_the_product_library_has_no_lane_relaxation_and_ignores_dev_switches(gpu, monkeypatch):
+    """libpli_frontend.so (what an integrator links) refuses lsd_mode 1 — round 1's schedule lives in the development build — and does not
+    read the development switches: with PLI_RX_PLAN=1 in the environment (a plan far too short) the product library still settles every
+    image in its persistent kernel, where the development build does what the switch says."""
+    g = gpu
+    W, H = 376, 240
+    with pytest.raises(g.capi.PliError) as e:
+        g.Frontend(g.capi.default_config(W, H, lsd_mode=1), dev=False)
+    assert e.value.status == -1
+    L, R = g.synth.make_stereo_pair(5, W, H)
+    cfg = g.capi.default_config(W, H, orb_nfeatures=300, lsd_nfeatures=0, max_frames=1)
+    monkeypatch.setenv("PLI_RX_PLAN", "1")
+    stats = {}
+    for dev in (False, True):
+        fe = g.Frontend(cfg, dev=dev)
+        fe.batch_run_host(np.stack([L, R])[None])
+        rec = fe.batch_run_host(np.stack([L, R])[None])[0]
+        stats[dev] = fe.lsd_round_stats()
+        assert_frame_equal(g, rec, g.po.Frame(ocfg(g, cfg)), L, R, "dev=%s" % dev)
+    assert stats[False][0] == -1 and stats[False][2] == 0, stats      # product: the tail kernel, nobody on the slow path
+    assert stats[True][0] == 1 and stats[True][2] >= 1, stats          # development build: one planned round, the device-side fallback
+
+
 def test_hot_records_hardware_trig_error_is_inside_the_budget(gpu):
     """Round 1 on the 8-byte hot records runs its vector filter on v_cos_f32 / v_sin_f32 (lsd_tile.hip "HOT RECORDS"); the error
     budget that keeps the filter's decisions inside the margin of the exact expression assumes |error| < 4e-6 for every float angle."""
@@ -1257,9 +1280,10 @@ def test_hot_records_hardware_trig_error_is_inside_the_budget(gpu):
     assert 0.0 < err < 4e-6, err
 
 
-def test_hot_records_round1(gpu, monkeypatch):
-    """Round 1 of the tile relaxation on 8-byte hot records {level-line angle, owner word} (PLI_TX_HOT; lazy ids / key mode and
-    sort-written ids / rank mode): the oracle's lines, byte for byte — also when a wide filter margin sends a third of the candidates
+def test_hot_records(gpu, monkeypatch):
+    """The tile relaxation on 8-byte hot records {level-line angle, round 1's owner word} — every round (the default: PLI_TX_HOT=2, the
+    16-byte records are not even written) or round 1 only (1), lazy ids / key mode and sort-written ids / rank mode: the oracle's lines,
+    byte for byte — also when a wide filter margin sends a third of the candidates
     through the exact expression (and so through the exact sums folded from the 16-byte records in the middle of a region's growth),
     when region2rect recomputes the exact sums for EVERY region, with 32-pixel tiles, without the tail kernel, on the stripes image
     (regions of thousands of pixels: the queue's overflow blocks and the resynchronisation of the filter's sums), and against the
@@ -1274,18 +1298,19 @@ def test_hot_records_round1(gpu, monkeypatch):
     imgs = np.stack([np.stack(p) for p in pairs])
     keys = ("PLI_TX_HOT", "PLI_TX_KEYS", "PLI_ALIGN_MARGIN_DEG", "PLI_RECT_APPROX_BAND", "PLI_TX_TS", "PLI_TX_TAIL", "PLI_RX_ARENA", "PLI_TX_HOT_BAND2")
     out = {}
-    for what, env in (("rec16", {"PLI_TX_HOT": "0"}), ("hot", {"PLI_TX_HOT": "1"}), ("hot_ranks", {"PLI_TX_HOT": "1", "PLI_TX_KEYS": "0"}),
-                      ("hot_wide_margin", {"PLI_TX_HOT": "1", "PLI_ALIGN_MARGIN_DEG": "4"}),
-                      ("hot_wide_margin_ranks", {"PLI_TX_HOT": "1", "PLI_ALIGN_MARGIN_DEG": "8", "PLI_TX_KEYS": "0", "PLI_TX_TAIL": "0"}),
-                      ("hot_rect_exact", {"PLI_TX_HOT": "1", "PLI_RECT_APPROX_BAND": "10"}),
+    for what, env in (("rec16", {"PLI_TX_HOT": "0"}), ("hot", {}), ("hot_round1_only", {"PLI_TX_HOT": "1"}), ("hot_ranks", {"PLI_TX_KEYS": "0"}),
+                      ("hot_round1_only_ranks_no_tail", {"PLI_TX_HOT": "1", "PLI_TX_KEYS": "0", "PLI_TX_TAIL": "0"}),
+                      ("hot_wide_margin", {"PLI_ALIGN_MARGIN_DEG": "4"}),
+                      ("hot_wide_margin_ranks", {"PLI_ALIGN_MARGIN_DEG": "8", "PLI_TX_KEYS": "0", "PLI_TX_TAIL": "0"}),
+                      ("hot_rect_exact", {"PLI_RECT_APPROX_BAND": "10"}),
                       # (the second band off: every candidate inside the margin takes the exact sums)
-                      ("hot_every_event_exact", {"PLI_TX_HOT": "1", "PLI_TX_HOT_BAND2": "10", "PLI_ALIGN_MARGIN_DEG": "4"}),
-                      ("hot_ts32_arena3", {"PLI_TX_HOT": "1", "PLI_TX_TS": "32", "PLI_RX_ARENA": "3", "PLI_ALIGN_MARGIN_DEG": "1"})):
+                      ("hot_every_event_exact", {"PLI_TX_HOT_BAND2": "10", "PLI_ALIGN_MARGIN_DEG": "4"}),
+                      ("hot_ts32_arena3", {"PLI_TX_TS": "32", "PLI_RX_ARENA": "3", "PLI_ALIGN_MARGIN_DEG": "1"})):
         for k in keys:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        fe = g.Frontend(cfg)
+        fe = g.Frontend(cfg, dev=True)
         fe.batch_run_host(imgs)
         out[what] = fe.batch_run_host(imgs)
         if "arena3" not in what:
@@ -1365,7 +1390,7 @@ def test_an_aborted_tail_kernel_switches_the_process_to_planned_rounds(gpu, tmp_
         cfg = capi.default_config(W, H, orb_nfeatures=300, lsd_nfeatures=0, max_frames=1)
         L, R = synth.make_stereo_pair(321, W, H)
         imgs = np.stack([L, R])[None]
-        fe = Frontend(cfg)
+        fe = Frontend(cfg, dev=True)           # (PLI_TX_TAIL_FORCE_ABORT is a test switch of the development build)
         fr = po.Frame(po.Config.from_buffer_copy(bytes(cfg)))
         want = [fr.line_extract(e, im) for e, im in ((0, L), (1, R))]
         def same(rec):
@@ -1413,7 +1438,7 @@ def test_where_the_orb_chain_forks_does_not_change_a_byte(gpu, monkeypatch):
                 monkeypatch.setenv(k, v)
         if what == "no_side_stream":
             continue                                          # (PLI_SIDE_MAX is read once per process: covered by tools/ab_env.sh runs, not here)
-        fe = g.Frontend(cfg)
+        fe = g.Frontend(cfg, dev=True)
         fe.batch_run_host(imgs)
         out[what] = fe.batch_run_host(imgs)
     for k in ("PLI_SIDE_DEFER_MAX", "PLI_SIDE_FORK_ROUND"):

@@ -134,7 +134,7 @@ def test_photographs_every_lsd_schedule(gpu, mode, monkeypatch):
             img = ph[name]
             H, W = img.shape
             cfg = g.capi.default_config(W, H, orb_nfeatures=300, lsd_nfeatures=0, max_frames=1, lsd_mode=mode)
-            fe = g.Frontend(cfg)
+            fe = g.Frontend(cfg, dev=True)
             n, kl, ld = fe.line_extract(0, img)
             m, okl, old = g.po.Frame(ocfg(g, cfg)).line_extract(0, img)
             assert n == m, "%s mode %d: %d lines vs oracle %d" % (name, mode, n, m)

@@ -1,6 +1,8 @@
 #!/bin/bash
 # GPU box (dev tool): the headline batch under a list of environment settings, "VAR=val[,VAR2=val2] ..." each, kernels alone (PLI_SIDE_MAX=0)
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?}"      # (GPU box: gpurun exports it)
+cd "$GRAFT_REPO_ROOT" || exit 1
+export PLI_USE_DEV_LIB=${PLI_USE_DEV_LIB-1}      # (environment switches are read by the development build of the library only)
 for setting in "$@"; do
   (
     IFS=, ; for kv in $setting; do [ "$kv" != "none" ] && export "$kv"; done; unset IFS

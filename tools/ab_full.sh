@@ -1,11 +1,13 @@
 #!/bin/bash
 # GPU box (dev tool): full per-kernel listing (main + side stream) of one bench line per "lib[:ENV=val,...]" argument ("base" = the shipped library);
 # BENCH_ARGS adds bench.py arguments.   tools/ab_full.sh build/r04 base base:PLI_SIDE_DEFER_MAX=64
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?}"      # (GPU box: gpurun exports it)
+cd "$GRAFT_REPO_ROOT" || exit 1
+export PLI_USE_DEV_LIB=1      # (environment switches are read by the development build of the library only)
 for spec in "$@"; do
   lib=${spec%%:*}; envs=""; [ "$spec" != "$lib" ] && envs=${spec#*:}
   (
-    if [ "$lib" != base ]; then export PLI_LIB_PATH=$GRAFT_REPO_ROOT/$lib/libpli_frontend.so; fi
+    if [ "$lib" != base ]; then export PLI_LIB_PATH=$(ls $GRAFT_REPO_ROOT/$lib/libpli_frontend_dev.so 2>/dev/null || echo $GRAFT_REPO_ROOT/$lib/libpli_frontend.so); fi
     IFS=, ; for kv in $envs; do export "$kv"; done; unset IFS
     python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-host-leg --no-large-batch-leg $BENCH_ARGS > gpurun_out/full.json 2>/dev/null
     python - "$spec" <<'PY'

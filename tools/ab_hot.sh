@@ -4,6 +4,7 @@
 : "${GRAFT_REPO_ROOT:?}"
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" || exit 1
+export PLI_USE_DEV_LIB=${PLI_USE_DEV_LIB-1}      # (environment switches are read by the development build of the library only)
 PAT=${PAT:-"k_tx_grow|k_tx_round2|k_lsd_front|k_tx_sort"}
 tools/ab_env.sh PLI_TX_HOT=0 PLI_TX_HOT=1 PLI_TX_HOT=0 PLI_TX_HOT=1
 for h in 0 1; do

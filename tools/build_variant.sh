@@ -8,5 +8,6 @@ cd "$(dirname "$0")/.."
 D=${VARIANT_DIR:-build/variant}
 mkdir -p "$D"
 cp pli_slam_amd/csrc/*.hip pli_slam_amd/csrc/*.hpp pli_slam_amd/csrc/Makefile "$D/"
-make -C "$D" -j6 EXTRA="$*" >/dev/null
-ls -la "$D/libpli_frontend.so"
+# (diagnostic macros are development-build material: the variant is the development build; "product" as first argument builds that one)
+if [ "$1" = product ]; then shift; make -C "$D" -j6 product EXTRA="$*" >/dev/null; ls -la "$D/libpli_frontend.so"
+else make -C "$D" -j6 dev EXTRA="$*" >/dev/null; ls -la "$D/libpli_frontend_dev.so"; fi

@@ -35,9 +35,10 @@ SETS = {
     # round 6: round 1 on the 8-byte hot records against the 16-byte ones, key and rank mode, a wide filter margin (the exact sums
     # folded in mid-growth), region2rect's exact sums for every region
     "hot": [(n, {"lsd_mode": 3}, e) for n, e in (
-        ("rec16", {"PLI_TX_HOT": "0"}), ("hot", {"PLI_TX_HOT": "1"}), ("hot_ranks", {"PLI_TX_HOT": "1", "PLI_TX_KEYS": "0"}),
-        ("hot_margin2", {"PLI_TX_HOT": "1", "PLI_ALIGN_MARGIN_DEG": "2"}), ("hot_margin2_all_exact", {"PLI_TX_HOT": "1", "PLI_ALIGN_MARGIN_DEG": "2", "PLI_TX_HOT_BAND2": "10"}), ("hot_rect_exact", {"PLI_TX_HOT": "1", "PLI_RECT_APPROX_BAND": "10"}),
-        ("hot_ts32_no_tail", {"PLI_TX_HOT": "1", "PLI_TX_TS": "32", "PLI_TX_TAIL": "0"}))],
+        ("rec16", {"PLI_TX_HOT": "0"}), ("hot_round1_only", {"PLI_TX_HOT": "1"}), ("hot", {"PLI_TX_HOT": "2"}), ("hot_ranks", {"PLI_TX_HOT": "2", "PLI_TX_KEYS": "0"}),
+        ("hot_margin2", {"PLI_TX_HOT": "2", "PLI_ALIGN_MARGIN_DEG": "2"}), ("hot_margin2_all_exact", {"PLI_TX_HOT": "2", "PLI_ALIGN_MARGIN_DEG": "2", "PLI_TX_HOT_BAND2": "10"}),
+        ("hot_rect_exact", {"PLI_TX_HOT": "2", "PLI_RECT_APPROX_BAND": "10"}), ("hot_ts32_no_tail", {"PLI_TX_HOT": "2", "PLI_TX_TS": "32", "PLI_TX_TAIL": "0"}),
+        ("hot_tail_t3", {"PLI_TX_HOT": "2", "PLI_TX_TAIL_T0": "3"}), ("hot_block_rounds", {"PLI_TX_HOT": "2", "PLI_TX_CELLS": "0"}))],
 }
 bad = 0
 if which == "sizes":

@@ -1,5 +1,6 @@
 #!/bin/bash
 # GPU box: rocprofv3 kernel stats of the C++ drop-in harness (10 frames x 3 repetitions, four threads)
+: "${GRAFT_REPO_ROOT:?}"      # (GPU box: gpurun exports it)
 R=$GRAFT_REPO_ROOT
 cd $R && python3 - <<PY
 import os, sys

@@ -11,6 +11,9 @@ from pli_slam_amd.frontend import Frontend
 W, H = 376, 240
 L, R = synth.make_stereo_pair(4, W, H)
 
+FAILED = []
+
+
 def run(name, **over):
     try:
         base = dict(orb_nfeatures=400, lsd_nfeatures=0); base.update(over)
@@ -36,6 +39,8 @@ def run(name, **over):
     if disp.tobytes() != rec["disp"].tobytes():
         bad.append("stereoL")
     print("%-44s kp %4d lines %4d  %s" % (name, len(rec["kpL"]), len(rec["klL"]), "OK" if not bad else "MISMATCH " + " ".join(bad)), flush=True)
+    if bad:
+        FAILED.append(name)
 
 run("one pyramid level", orb_nlevels=1)
 run("two levels, factor 2.0", orb_nlevels=2, orb_scale_factor=2.0)
@@ -59,4 +64,5 @@ run("tiny bf", bf=1.0)
 run("refine = 1 (unsupported)", lsd_refine=1)
 run("zero levels", orb_nlevels=0)
 run("negative features", orb_nfeatures=-5)
-print("done")
+print("done: %d configurations mismatch%s" % (len(FAILED), (" " + repr(FAILED)) if FAILED else ""))
+sys.exit(1 if FAILED else 0)

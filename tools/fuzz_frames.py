@@ -48,3 +48,4 @@ ok &= compare("saturated contrast", capi.default_config(W, H, orb_nfeatures=800,
 grad = (np.add.outer(np.arange(H), np.arange(W)) % 256).astype(np.uint8)
 ok &= compare("sawtooth ramp", capi.default_config(W, H, orb_nfeatures=800, lsd_nfeatures=0), grad, grad)
 print("ALL OK" if ok else "SOME MISMATCH")
+sys.exit(0 if ok else 1)

@@ -11,6 +11,7 @@
 #     real     the headline batch on frames cut from real photographs (bench.py --real-images): rate, relaxation rounds, fallbacks
 #     markers  rocprofv3 --kernel-trace --marker-trace with PLI_ROCTX=1 (F = 32): the library's roctx ranges — entry point > stage > launch
 #     extras   the headline batch with every kernel alone (per-round times), and the real-image batch with round 4's 64 distinct windows
+: "${GRAFT_REPO_ROOT:?}"      # (GPU box: gpurun exports it)
 ROUND=4
 if [[ $1 == --round ]]; then ROUND=$2; shift; shift; fi
 RN=$(printf "r%02d" $ROUND)
@@ -87,7 +88,7 @@ if [[ $WHAT == *real* ]]; then
 fi
 if [[ $WHAT == *extras* ]]; then
   # the headline batch with every kernel alone and in a row, per-round times (name@round); round 4's real-image workload (64 distinct windows)
-  PLI_SIDE_MAX=0 PLI_RX_PROFROUNDS=1 timeout 900 python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-host-leg --no-large-batch-leg 2>/dev/null | grep '^{"metric"' | tail -1 > $O/bench_default_f256_alone_per_round.json
+  PLI_USE_DEV_LIB=1 PLI_SIDE_MAX=0 PLI_RX_PROFROUNDS=1 timeout 900 python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-host-leg --no-large-batch-leg 2>/dev/null | grep '^{"metric"' | tail -1 > $O/bench_default_f256_alone_per_round.json
   timeout 900 python3 bench.py --steps 5 --warmup 1 --real-images --unique-frames 64 --no-cpu-baseline --no-host-leg --no-large-batch-leg 2>/dev/null | grep '^{"metric"' | tail -1 > $O/bench_real_images_64windows_f256.json
 fi
 ls -la $O

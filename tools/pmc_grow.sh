@@ -1,6 +1,8 @@
 #!/bin/bash
 # GPU box: SQ counters of the sequential LSD grower at 1024 frames (written to gpurun_out/pmc_grow.txt).
+: "${GRAFT_REPO_ROOT:?}"      # (GPU box: gpurun exports it)
 R=$GRAFT_REPO_ROOT
+export PLI_USE_DEV_LIB=${PLI_USE_DEV_LIB-1}      # (environment switches are read by the development build of the library only)
 O=$R/gpurun_out/pmc_grow.txt
 cd /tmp && export TMPDIR=/tmp
 : > $O

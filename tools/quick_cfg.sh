@@ -1,6 +1,8 @@
 #!/bin/bash
 # GPU box (dev tool): one bench line per "config[:ENV=val,...]" argument, kernels of the line chain + rate; e.g. tools/quick_cfg.sh 3 3:PLI_TX_KEYS=0 5
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?}"      # (GPU box: gpurun exports it)
+cd "$GRAFT_REPO_ROOT" || exit 1
+export PLI_USE_DEV_LIB=${PLI_USE_DEV_LIB-1}      # (environment switches are read by the development build of the library only)
 for spec in "$@"; do
   cfg=${spec%%:*}; envs=""; [ "$spec" != "$cfg" ] && envs=${spec#*:}
   (

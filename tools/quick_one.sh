@@ -1,4 +1,5 @@
 #!/bin/bash
+export PLI_USE_DEV_LIB=${PLI_USE_DEV_LIB-1}      # (environment switches are read by the development build of the library only)
 # GPU box dev tool: one bench.py line, condensed.  tools/quick_one.sh [bench args]   (environment passes through)
 timeout 300 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-leg "$@" 2>/dev/null | python3 -c "
 import json,sys

@@ -24,3 +24,4 @@ for it in range(N):
         bad += 1
         print("run %d differs in %d bytes" % (it, int((ref != table).sum())), flush=True)
 print("F=%d: %d runs, %d differ from the first" % (F, N, bad))
+sys.exit(1 if bad else 0)

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PLI_USE_DEV_LIB=${PLI_USE_DEV_LIB-1}      # (environment switches are read by the development build of the library only)
 # GPU box dev tool: bench.py under several values of one environment variable.
 #   tools/sweep_env.sh VAR "v1 v2 ..." kernel1,kernel2 [bench args]
 var=$1; vals=$2; kern=$3; shift; shift; shift
