@@ -1323,7 +1323,13 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
         ax = exSx(); ay = exSy();
         if (accSoFar) {
           float cy = 0.f, cz = 0.f;
-          if ((accSoFar >> lane) & 1ull) exactPair((myxy >> 16) * W + (myxy & 0xFFFF), cy, cz);
+          if ((accSoFar >> lane) & 1ull) {
+            // (the pixel index made opaque: the compiler hoisted this rare gather's address arithmetic — four vector instructions — out of
+            // the accept loop into every step)
+            int pxy = myxy;
+            asm volatile("" : "+v"(pxy));
+            exactPair((pxy >> 16) * W + (pxy & 0xFFFF), cy, cz);
+          }
           unsigned long long m = accSoFar;
           while (m) {
             const int j = __ffsll((long long)m) - 1;
