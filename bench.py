@@ -617,7 +617,7 @@ def main():
         sector = None      # the growers are gather kernels: their ceiling is the rate of random 128-byte line requests the chip
         counters_note = None   # why a counter-derived field is null, or which committed workload stood in for this one
         try:               # sustains (tools/probes/gather_rate.hip, profiles/r02_gather_rate_probe.txt: 49 G/s), not the stream peak
-            tpath = [p_ for p_ in (os.path.join(ROOT, "profiles", "r%02d_traffic.json" % n_) for n_ in (5, 4, 3, 2)) if os.path.exists(p_)][0]
+            tpath = [p_ for p_ in (os.path.join(ROOT, "profiles", "r%02d_traffic.json" % n_) for n_ in (6, 5, 4, 3, 2)) if os.path.exists(p_)][0]
             tr = json.load(open(tpath))
             wkey = "%dx%d_F%d" % (W, H, F)
             src_F = F
@@ -699,10 +699,11 @@ def main():
         # null, with `counters_note`, when there are none
         roof = {"bound": "latency (wave slots)" if grower else "hbm", "kernel": name, "achieved": achieved, "peak": peak, "unit": "GB/s",
                 "frac": (achieved / peak) if achieved is not None else None, "traffic": traffic, "traffic_GBps": traffic_rate, "sector_requests": sector,
-                "limiter": "dependent trips at 8 waves per SIMD / VALU issue / 128-byte lines for 16-byte gathers (DESIGN.md 5)" if grower else "hbm",
+                "limiter": "VALU issue / dependent trips at 8 waves per SIMD / 128-byte lines for 8-byte gathers (DESIGN.md 5)" if grower else "hbm",
                 "counters_note": counters_note,
                 "issue": issue, "step_traffic": step_traffic,
                 "avg_launch_ms": avg_s * 1e3, "launches": calls,
+                "kernel_launches_per_step": round(sum(v[0] for v in prof.values()) / max(args.steps, 1), 1),
                 "path_achieved": fps / world * b_frame / 1e9, "path_frac": fps / world * b_frame / 1e9 / peak,
                 "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in
                                        sorted(prof.items(), key=lambda kv: -kv[1][1]) if k not in side},
@@ -712,9 +713,9 @@ def main():
                 "kernel_ms_note": "HIP-event time between the launch's two events on the stream it ran on, summed per step.  "
                                   "side_stream_kernel_ms_per_step: the ORB chain, the stereo point matcher and the LBD's blur + Sobel run on a "
                                   "low-priority side stream beside the line chain: their event times INCLUDE the wait for wave slots behind the "
-                                  "line kernels (alone, PLI_SIDE_MAX=0, 256 frames: k_resize_level 0.7 ms, k_fast_cells 3.4, k_octree 1.5, "
+                                  "line kernels (alone, PLI_SIDE_MAX=0, 256 frames: k_resize_level 0.7 ms, k_fast_cells 3.0, k_octree 1.5, "
                                   "k_blur_orb 1.0, k_describe 1.0) and are not comparable with the main stream's; the line chain's kernels are "
-                                  "stretched by them in turn (alone: k_tx_round2 2.1 ms, k_tx_grow_sparse 2.9; the chain forks behind round 2's owner pass of a "
+                                  "stretched by them in turn (alone: k_tx_round2 1.8 ms, k_tx_grow_sparse 3.0; the chain forks behind round 2's owner pass of a "
                                   "large batch).  DESIGN.md 5 / 7 have every kernel alone"}
         what = C_["what"] if args.config else ("752x480 stereo pairs, extract + stereo Hamming match (BASELINE configs[1] shape, "
                                                "batched)")

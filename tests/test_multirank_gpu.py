@@ -33,6 +33,13 @@ def test_config4_two_ranks_real_kernels_gather_and_parity():
     p = d["parity"]
     assert p["ok"] is True and p["ranks_checked"] == 2 and p["records_gathered"] == 256 and p["empty_records"] == 0
     assert p["pairs_checked_against_oracle"] == 4 and p["pairs_mismatching"] == 0
+    # the line proves who took part: two ranks counted by an all-reduce, their devices gathered — ONE distinct device here
+    # (--share-device), so the line calls itself a rehearsal —, every rank's own time
+    g_ = d["gather"]
+    assert g_["ranks_seen"] == 2 and len(g_["devices"]) == 2 and g_["distinct_devices"] == 1
+    assert g_["one_device_per_rank"] is False and g_["rehearsal_on_shared_device"] is True
+    pr = d["per_rank_ms"]
+    assert len(pr["all"]) == 2 and pr["min"] <= pr["max"] == pr["all"][pr["slowest_rank"]] and pr["min"] > 0
 
 
 def test_config3_two_ranks_halo_tracks_equal_the_oracle():

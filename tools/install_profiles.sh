@@ -1,7 +1,7 @@
 #!/bin/bash
 # copies the summaries written by tools/make_profiles.sh --round N (gpurun_out/prof_rNN) into profiles/ as rNN_* and builds
 # rNN_traffic.json (read back by bench.py for roofline.traffic / roofline.issue):   tools/install_profiles.sh --round N
-ROUND=4
+ROUND=6
 if [[ $1 == --round ]]; then ROUND=$2; fi
 RN=$(printf "r%02d" $ROUND)
 R=$(cd "$(dirname "$0")/.." && pwd); O=$R/gpurun_out/prof_$RN; P=$R/profiles

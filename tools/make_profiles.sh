@@ -12,7 +12,7 @@
 #     markers  rocprofv3 --kernel-trace --marker-trace with PLI_ROCTX=1 (F = 32): the library's roctx ranges — entry point > stage > launch
 #     extras   the headline batch with every kernel alone (per-round times), and the real-image batch with round 4's 64 distinct windows
 : "${GRAFT_REPO_ROOT:?}"      # (GPU box: gpurun exports it)
-ROUND=4
+ROUND=6
 if [[ $1 == --round ]]; then ROUND=$2; shift; shift; fi
 RN=$(printf "r%02d" $ROUND)
 R=$GRAFT_REPO_ROOT

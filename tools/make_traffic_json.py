@@ -11,7 +11,9 @@ ALIAS = {"k_lsd_grow2_spec": "k_lsd_grow2", "k_lsd_grow_spec": "k_lsd_grow", "k_
          "k_lsd_resize64": "k_resize_lsd", "k_lsd_front64": "k_lsd_front",
          # round 5: round 1 of the tile relaxation has three instances (lazy ids / sort-written ids / owner plane) and the later
          # rounds' bookkeeping two forms; bench.py's profile names are the left-hand kernels' roles
-         "k_tx_grow_p2": "k_tx_grow", "k_tx_grow_p1": "k_tx_grow", "k_tx_diffmark_cells": "k_tx_diffmark", "k_tx_prep_cells": "k_tx_prep"}
+         "k_tx_grow_p2": "k_tx_grow", "k_tx_grow_p1": "k_tx_grow", "k_tx_diffmark_cells": "k_tx_diffmark", "k_tx_prep_cells": "k_tx_prep",
+         # round 6: round 1 on the 8-byte hot records (key / rank mode), the later rounds on the cold pair
+         "k_tx_grow_h2": "k_tx_grow", "k_tx_grow_h1": "k_tx_grow", "k_tx_grow_sparse_h": "k_tx_grow_sparse"}
 
 
 def rows(path, counters):
