@@ -227,6 +227,9 @@ __device__ __forceinline__ void tx_sort_tile(const int* __restrict__ rankAll, co
   // previous pixel's stores made this phase KPT dependent round trips)
   double vIn[KPT];
   int rIn[KPT];
+  // (sort-written ids on the hot records are 4-byte stores into the records' second words.  Rewriting the whole 8-byte record — the
+  // angle loaded here with the rest — was measured: k_tx_sort 3.2 -> 3.8 ms at 752 x 480, the sixteen extra loads per thread cost more
+  // than the partial sectors)
   // (unconditional, from clamped coordinates: a load under a lane predicate is waited for at the end of its branch)
   if (keys.mg) {
 #pragma unroll

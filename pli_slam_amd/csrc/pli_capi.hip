@@ -919,7 +919,7 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   if (!sequential && c->lsdMode != 1 && c->lsdF64 && c->mg && lostRule0 && !c->debug && !DEVENV("PLI_TX_FULL2") && !DEVENV("PLI_TX_NOFUSE2") &&
       !(DEVENV("PLI_TX_SPEC") && atoi(DEVENV("PLI_TX_SPEC")) != 0) && !(DEVENV("PLI_TX_ORDER") && atoi(DEVENV("PLI_TX_ORDER")) != 0))
     packMode = (keyMode && P.nBins > 128) ? 2 : 1;      // (the lazy form's fixed-point bin width needs maxGrad / (nBins - 1) < 4: tests/test_lazy_ids_cpu.py)
-  if (const char* e = DEVENV("PLI_TX_PACK1")) packMode = std::min(packMode, std::max(0, atoi(e)));
+  const int packCap = packMode;                           // (what this call could do: the choice follows the hot-record level below)
   // round 6: round 1's words in 8-byte hot records of their own (lsd_tile.hip "HOT RECORDS"); dev switch PLI_TX_HOT=0 / 1
   // 2 (the default): every round — the later rounds take the angle from the hot record and the owner pair from the owner plane, nobody
   // reads the 16-byte records, and the front pass does not write them (the device-side fallback of an unsettled image rebuilds them
@@ -927,6 +927,14 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
   int hotLevel = (packMode != 0 && c->hot != nullptr && P.prec <= 1.0 && P.alignFilter != 0) ? 2 : 0;
   if (const char* e = DEVENV("PLI_TX_HOT")) hotLevel = std::min(hotLevel, std::max(0, atoi(e)));
   if (hotLevel == 2 && (DEVENV("PLI_RX_FULL") || DEVENV("PLI_TX_NODIRTYLIST"))) hotLevel = 1;     // (dev schedules that keep to the plain later-round kernels)
+  // On the hot records the ids are SORT-WRITTEN (1) by default, in key mode too: k_tx_sort rewrites the whole 8-byte record — angle and
+  // `unclaimed | id`, full sectors — and round 1 does without the lazy-id test, ~23 of a step's ~150 vector instructions: k_tx_grow
+  // 18.6 -> 17.1 ms, k_tx_sort 2.1 -> 3.2 with 4-byte stores into the records' second words (read-modify-writes of sectors) and less
+  // with whole records (DESIGN.md 5 "Round 6").  On the 16-byte records the same trade was a wash (round 5) and lazy ids stay the
+  // default there.  Dev switch PLI_TX_PACK1 = 0 / 1 / 2.
+  if (hotLevel != 0 && packMode == 2) packMode = 1;
+  if (const char* e = DEVENV("PLI_TX_PACK1")) packMode = std::min(packCap, std::max(0, atoi(e)));
+  if (packMode == 0) hotLevel = 0;
   const bool hotMode = hotLevel != 0, hotAll = hotLevel == 2;
   int2* hotPlane = hotMode ? c->hot : (int2*)nullptr;
   int2* hotLater = hotAll ? c->hot : (int2*)nullptr;

@@ -1222,10 +1222,13 @@ def test_round1_owner_word_forms(gpu, monkeypatch):
     cfg = g.capi.default_config(W, H, orb_nfeatures=300, lsd_nfeatures=0, max_frames=2)
     pairs = [g.synth.make_stereo_pair(190 + i, W, H) for i in range(2)]
     imgs = np.stack([np.stack(p) for p in pairs])
-    keys = ("PLI_TX_PACK1", "PLI_TX_LAZY_MARGIN", "PLI_TX_KEYS", "PLI_TX_TAIL", "PLI_TX_CELLS")
+    keys = ("PLI_TX_PACK1", "PLI_TX_LAZY_MARGIN", "PLI_TX_KEYS", "PLI_TX_TAIL", "PLI_TX_CELLS", "PLI_TX_HOT")
     out = {}
-    for what, env in (("lazy", {}), ("lazy_all_exact", {"PLI_TX_LAZY_MARGIN": "2000000"}), ("lazy_margin4", {"PLI_TX_LAZY_MARGIN": "4"}),
-                      ("sort_written_keys", {"PLI_TX_PACK1": "1"}), ("sort_written_ranks", {"PLI_TX_KEYS": "0"}),
+    # (round 6: on the hot records the default is sort-written ids; "lazy" names the default of the run, whatever it is)
+    for what, env in (("lazy", {}), ("lazy_on_hot", {"PLI_TX_PACK1": "2"}), ("lazy_rec16", {"PLI_TX_HOT": "0"}),
+                      ("lazy_all_exact", {"PLI_TX_PACK1": "2", "PLI_TX_LAZY_MARGIN": "2000000"}), ("lazy_margin4", {"PLI_TX_PACK1": "2", "PLI_TX_LAZY_MARGIN": "4"}),
+                      ("lazy_all_exact_rec16", {"PLI_TX_HOT": "0", "PLI_TX_LAZY_MARGIN": "2000000"}),
+                      ("sort_written_keys", {"PLI_TX_PACK1": "1"}), ("sort_written_keys_rec16", {"PLI_TX_PACK1": "1", "PLI_TX_HOT": "0"}), ("sort_written_ranks", {"PLI_TX_KEYS": "0"}),
                       ("owner_plane", {"PLI_TX_PACK1": "0"}), ("owner_plane_ranks_no_tail", {"PLI_TX_PACK1": "0", "PLI_TX_KEYS": "0", "PLI_TX_TAIL": "0"}),
                       # rounds >= 3 on cell lists (k_tx_cells + a wave per listed cell; the default from a million cells per call up), up to
                       # the tail kernel's round 8 and without the tail kernel
@@ -1296,9 +1299,10 @@ def test_hot_records(gpu, monkeypatch):
     stripes = (((xx + yy // 3) // 7) % 2 * 170 + 40).astype(np.uint8)
     pairs.append((stripes, np.ascontiguousarray(stripes[:, ::-1])))
     imgs = np.stack([np.stack(p) for p in pairs])
-    keys = ("PLI_TX_HOT", "PLI_TX_KEYS", "PLI_ALIGN_MARGIN_DEG", "PLI_RECT_APPROX_BAND", "PLI_TX_TS", "PLI_TX_TAIL", "PLI_RX_ARENA", "PLI_TX_HOT_BAND2")
+    keys = ("PLI_TX_HOT", "PLI_TX_KEYS", "PLI_ALIGN_MARGIN_DEG", "PLI_RECT_APPROX_BAND", "PLI_TX_TS", "PLI_TX_TAIL", "PLI_RX_ARENA", "PLI_TX_HOT_BAND2", "PLI_TX_PACK1")
     out = {}
     for what, env in (("rec16", {"PLI_TX_HOT": "0"}), ("hot", {}), ("hot_round1_only", {"PLI_TX_HOT": "1"}), ("hot_ranks", {"PLI_TX_KEYS": "0"}),
+                      ("hot_lazy_ids", {"PLI_TX_PACK1": "2"}), ("hot_lazy_ids_wide_margin", {"PLI_TX_PACK1": "2", "PLI_ALIGN_MARGIN_DEG": "4", "PLI_TX_HOT_BAND2": "10"}),
                       ("hot_round1_only_ranks_no_tail", {"PLI_TX_HOT": "1", "PLI_TX_KEYS": "0", "PLI_TX_TAIL": "0"}),
                       ("hot_wide_margin", {"PLI_ALIGN_MARGIN_DEG": "4"}),
                       ("hot_wide_margin_ranks", {"PLI_ALIGN_MARGIN_DEG": "8", "PLI_TX_KEYS": "0", "PLI_TX_TAIL": "0"}),

@@ -30,7 +30,8 @@ SETS = {
         ("default", {}), ("tail_t3", {"PLI_TX_TAIL_T0": "3"}), ("no_tail", {"PLI_TX_TAIL": "0"}), ("spec", {"PLI_TX_SPEC": "1"}),
         ("spec_tail_t3_ts32", {"PLI_TX_SPEC": "1", "PLI_TX_TAIL_T0": "3", "PLI_TX_TS": "32"}), ("ts16", {"PLI_TX_TS": "16"}),
         ("ranks", {"PLI_TX_KEYS": "0"}), ("ranks_no_tail_ts32", {"PLI_TX_KEYS": "0", "PLI_TX_TAIL": "0", "PLI_TX_TS": "32"}),
-        ("owner_plane", {"PLI_TX_PACK1": "0"}), ("sort_written", {"PLI_TX_PACK1": "1"}), ("lazy_all_exact", {"PLI_TX_LAZY_MARGIN": "2000000"}),
+        ("owner_plane", {"PLI_TX_PACK1": "0"}), ("sort_written", {"PLI_TX_PACK1": "1"}), ("lazy_all_exact", {"PLI_TX_PACK1": "2", "PLI_TX_LAZY_MARGIN": "2000000"}),
+        ("lazy_all_exact_rec16", {"PLI_TX_HOT": "0", "PLI_TX_LAZY_MARGIN": "2000000"}),
         ("block_rounds", {"PLI_TX_CELLS": "0"}), ("cells_no_tail", {"PLI_TX_CELLS": "1", "PLI_TX_TAIL": "0"}))],
     # round 6: round 1 on the 8-byte hot records against the 16-byte ones, key and rank mode, a wide filter margin (the exact sums
     # folded in mid-growth), region2rect's exact sums for every region
@@ -38,7 +39,8 @@ SETS = {
         ("rec16", {"PLI_TX_HOT": "0"}), ("hot_round1_only", {"PLI_TX_HOT": "1"}), ("hot", {"PLI_TX_HOT": "2"}), ("hot_ranks", {"PLI_TX_HOT": "2", "PLI_TX_KEYS": "0"}),
         ("hot_margin2", {"PLI_TX_HOT": "2", "PLI_ALIGN_MARGIN_DEG": "2"}), ("hot_margin2_all_exact", {"PLI_TX_HOT": "2", "PLI_ALIGN_MARGIN_DEG": "2", "PLI_TX_HOT_BAND2": "10"}),
         ("hot_rect_exact", {"PLI_TX_HOT": "2", "PLI_RECT_APPROX_BAND": "10"}), ("hot_ts32_no_tail", {"PLI_TX_HOT": "2", "PLI_TX_TS": "32", "PLI_TX_TAIL": "0"}),
-        ("hot_tail_t3", {"PLI_TX_HOT": "2", "PLI_TX_TAIL_T0": "3"}), ("hot_block_rounds", {"PLI_TX_HOT": "2", "PLI_TX_CELLS": "0"}))],
+        ("hot_tail_t3", {"PLI_TX_HOT": "2", "PLI_TX_TAIL_T0": "3"}), ("hot_block_rounds", {"PLI_TX_HOT": "2", "PLI_TX_CELLS": "0"}),
+        ("hot_lazy_ids", {"PLI_TX_HOT": "2", "PLI_TX_PACK1": "2"}), ("hot_lazy_ids_margin2", {"PLI_TX_HOT": "2", "PLI_TX_PACK1": "2", "PLI_ALIGN_MARGIN_DEG": "2"}))],
 }
 bad = 0
 if which == "sizes":
