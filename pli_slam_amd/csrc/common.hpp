@@ -47,7 +47,8 @@ struct DevParams {
   int kpCap, klCap;
   int umax[16];
   // LSD
-  int LW, LH, lpitch;        // scaled image
+  int LW, LH, lpitch;        // scaled image: LW = the row PITCH of the detector's per-pixel planes (LWt rounded up to 16), lpitch: the u8 plane's
+  int LWt;                   // true width of the scaled image (front pass, resize tables, LOG_NT, debug getters: nothing else)
   int g2Thresh;              // defined  <=>  g2 > g2Thresh   (norm > rho)
   int nBins;
   int minRegSize;

@@ -33,6 +33,7 @@ constexpr double D_2PI = 2 * D_PI;
 constexpr int LSD_GRAD_ROWS = 16;   // rows per block: one atomicMax per block (same-line atomics serialise in L2)
 
 __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ scaled, int64_t imgStride, int W, int H,
+                                                  int WP /* row pitch of the planes written (>= W: the pad columns are undefined pixels) */,
                                                   int pitch, int g2Thresh, float4* __restrict__ rec,
                                                   int* __restrict__ g2o, int2* __restrict__ own,
                                                   int* __restrict__ maxG2, float* __restrict__ angDbg, int img0, int trigF32) {
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ sc
   const int img = blockIdx.z + img0;
   const int x = blockIdx.x * 256 + threadIdx.x;
   int m = 0;
-  if (x < W) {
+  if (x < WP) {
     const int yEnd = min((int)(blockIdx.y + 1) * LSD_GRAD_ROWS, H);
     for (int y = blockIdx.y * LSD_GRAD_ROWS; y < yEnd; ++y) {
       int g2 = 0;
@@ -60,11 +61,11 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ sc
           sincos_of_float((float)((double)a * D_DEG2RAD), trigF32 != 0, &sy, &cx);
         }
       }
-      const int64_t o = (int64_t)img * W * H + (int64_t)y * W + x;
+      const int64_t o = (int64_t)img * WP * H + (int64_t)y * WP + x;
       rec[o] = make_float4(a, cx, sy, __int_as_float(g2));
       g2o[o] = g2;
       if (own) own[o] = make_int2(0x7FFFFFFF, 0x7FFFFFFF);   // owner planes of the relaxation (lsd_relax.hip): undefined pixels never belong to a region
-      if (angDbg) angDbg[o] = a;
+      if (angDbg && x < W) angDbg[(int64_t)img * W * H + (int64_t)y * W + x] = a;      // (the debug plane: rows of the true width)
     }
   }
 #pragma unroll

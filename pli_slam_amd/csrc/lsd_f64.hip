@@ -16,7 +16,7 @@ constexpr double F64_DEG2RAD = 3.14159265358979323846 / 180;
 // one 64 x 16 output tile per workgroup; u8 tile with halo and the row-filtered doubles staged in LDS
 __global__ __launch_bounds__(256) void k_lsd_blur64(const uint8_t* __restrict__ pyr, int64_t pyrBlock, int W, int H, int pitch,
                                                     const double* __restrict__ kern, int radius, double* __restrict__ out,
-                                                    int img0) {
+                                                    int64_t outImgStride, int img0) {
   __shared__ uint8_t tile[22][72];
   __shared__ double rows[22][64];
   const int img = blockIdx.z + img0, tid = threadIdx.x;
@@ -46,13 +46,13 @@ __global__ __launch_bounds__(256) void k_lsd_blur64(const uint8_t* __restrict__ 
     if (x >= W || y >= H) continue;
     double s = k[r] * rows[ty + r][tx];
     for (int j = 1; j <= r; ++j) s += k[r + j] * (rows[ty + r + j][tx] + rows[ty + r - j][tx]);
-    out[(int64_t)img * W * H + (int64_t)y * W + x] = s;
+    out[(int64_t)img * outImgStride + (int64_t)y * W + x] = s;
   }
 }
 
 // tab: xofs[dw] | alpha[2*dw] (float bits) | yofs[dh] | beta[2*dh] (float bits)
 __global__ __launch_bounds__(256) void k_lsd_resize64(const double* __restrict__ src, int sw, int sh, double* __restrict__ dst,
-                                                      int dw, int dh, const int* __restrict__ tab, int img0) {
+                                                      int dw, int dh, int64_t dstImgStride, const int* __restrict__ tab, int img0) {
   const int img = blockIdx.z + img0, dy = blockIdx.y, dx = blockIdx.x * 256 + threadIdx.x;
   if (dx >= dw) return;
   const int sx = tab[dx], sx1 = min(sx + 1, sw - 1);
@@ -64,11 +64,12 @@ __global__ __launch_bounds__(256) void k_lsd_resize64(const double* __restrict__
   const double* S1 = src + (int64_t)img * sw * sh + (int64_t)sy1 * sw;
   const double t0 = S0[sx] * a0 + S0[sx1] * a1;
   const double t1 = S1[sx] * a0 + S1[sx1] * a1;
-  dst[(int64_t)img * dw * dh + (int64_t)dy * dw + dx] = t0 * b0 + t1 * b1;
+  dst[(int64_t)img * dstImgStride + (int64_t)dy * dw + dx] = t0 * b0 + t1 * b1;
 }
 
 // rec = { ang, c, s, 0 } (rec.w only carries the speculative grower's tags here), mg = modgrad (double)
-__global__ __launch_bounds__(256) void k_lsd_grad64(const double* __restrict__ scaled, int W, int H, double rho,
+// (W: the true width, the scaled plane's row length; WP >= W: the row pitch of the planes written — the pad columns are undefined pixels)
+__global__ __launch_bounds__(256) void k_lsd_grad64(const double* __restrict__ scaled, int W, int H, int WP, int64_t scaledImgStride, double rho,
                                                     float4* __restrict__ rec, double* __restrict__ mg, int2* __restrict__ own,
                                                     unsigned long long* __restrict__ maxMg, float* __restrict__ angDbg, int img0,
                                                     int flags /* bit 0: PLI_PARITY_TRIG_F32_LSD; bit 1: rec.w = tx_unclaimed_norm_word */,
@@ -80,9 +81,9 @@ __global__ __launch_bounds__(256) void k_lsd_grad64(const double* __restrict__ s
   const int img = blockIdx.z + img0;
   const int x = blockIdx.x * 256 + threadIdx.x;
   unsigned long long m = 0ull;                            // bits of the largest norm (non-negative doubles order like their bits)
-  if (x < W) {
+  if (x < WP) {
     const int yEnd = min((int)(blockIdx.y + 1) * 16, H);
-    const double* S = scaled + (int64_t)img * W * H;
+    const double* S = scaled + (int64_t)img * scaledImgStride;
     for (int y = blockIdx.y * 16; y < yEnd; ++y) {
       double norm = 0.0;
       float a = F64_NOTDEF, cx = 0.f, sy = 0.f;
@@ -99,13 +100,13 @@ __global__ __launch_bounds__(256) void k_lsd_grad64(const double* __restrict__ s
           sincos_of_float((float)((double)a * F64_DEG2RAD), trigF32 != 0, &sy, &cx);
         }
       }
-      const int64_t o = (int64_t)img * W * H + (int64_t)y * W + x;
+      const int64_t o = (int64_t)img * WP * H + (int64_t)y * WP + x;
       if (rec) rec[o] = make_float4(a, cx, sy, (packW && !hot) ? tx_unclaimed_norm_word(norm) : 0.f);
       if (hot) hot[o] = make_int2(__float_as_int(a), packW ? __float_as_int(tx_unclaimed_norm_word(norm)) : 0);
       if (cold) cold[o] = make_float2(a == F64_NOTDEF ? F64_NOTDEF : cx, sy);      // (cos = NOTDEF: no level-line angle)
       mg[o] = norm;
       if (own) own[o] = make_int2(0x7FFFFFFF, 0x7FFFFFFF);
-      if (angDbg) angDbg[o] = a;
+      if (angDbg && x < W) angDbg[(int64_t)img * W * H + (int64_t)y * W + x] = a;      // (the debug plane: rows of the true width)
     }
   }
 #pragma unroll
@@ -136,7 +137,7 @@ constexpr int FR = 3;                      // largest blur radius
 template <int R>
 __device__ __forceinline__ void lsd_front64_tile(const uint8_t* __restrict__ pyr, int64_t pyrBlock, int sw, int sh, int pitch,
                                                  const double* __restrict__ kern, int radius, const int* __restrict__ tab,
-                                                 int dw, int dh, double rho, float4* __restrict__ rec, double* __restrict__ mg,
+                                                 int dw, int dh, int dp, double rho, float4* __restrict__ rec, double* __restrict__ mg,
                                                  int2* __restrict__ own, unsigned long long* __restrict__ maxMg, int img0, int flags,
                                                  int2* __restrict__ hot, float2* __restrict__ cold, uint8_t (*tile)[FS_W + 2 * FR + 2], double (*rows)[FS_W], double (*blur)[FS_W],
                                                  unsigned long long* wmax) {
@@ -231,7 +232,7 @@ __device__ __forceinline__ void lsd_front64_tile(const uint8_t* __restrict__ pyr
   for (int i = tid; i < FT_W * FT_H; i += 256) {
     const int ty = i >> 6, tx = i & 63;
     const int x = x0 + tx, y = y0 + ty;
-    if (x >= dw || y >= dh) continue;
+    if (x >= dp || y >= dh) continue;                      // (columns dw .. dp - 1: the pad of the planes' row pitch, undefined pixels)
     double norm = 0.0;
     float a = F64_NOTDEF, cx = 0.f, sy = 0.f;
     if (x < dw - 1 && y < dh - 1) {
@@ -245,7 +246,7 @@ __device__ __forceinline__ void lsd_front64_tile(const uint8_t* __restrict__ pyr
         sincos_of_float((float)((double)a * F64_DEG2RAD), trigF32 != 0, &sy, &cx);
       }
     }
-    const int64_t o = (int64_t)img * dw * dh + (int64_t)y * dw + x;
+    const int64_t o = (int64_t)img * dp * dh + (int64_t)y * dp + x;
     if (rec) rec[o] = make_float4(a, cx, sy, (packW && !hot) ? tx_unclaimed_norm_word(norm) : 0.f);      // (null: every round runs on the hot records)
     if (hot) hot[o] = make_int2(__float_as_int(a), packW ? __float_as_int(tx_unclaimed_norm_word(norm)) : 0);
     if (cold) cold[o] = make_float2(a == F64_NOTDEF ? F64_NOTDEF : cx, sy);      // (cos = NOTDEF: no level-line angle)
@@ -264,7 +265,8 @@ __device__ __forceinline__ void lsd_front64_tile(const uint8_t* __restrict__ pyr
 
 __global__ __launch_bounds__(256) void k_lsd_front64(const uint8_t* __restrict__ pyr, int64_t pyrBlock, int sw, int sh, int pitch,
                                                      const double* __restrict__ kern, int radius, const int* __restrict__ tab,
-                                                     int dw, int dh, double rho, float4* __restrict__ rec, double* __restrict__ mg,
+                                                     int dw, int dh, int dp /* row pitch of the planes written, >= dw */, double rho,
+                                                     float4* __restrict__ rec, double* __restrict__ mg,
                                                      int2* __restrict__ own, unsigned long long* __restrict__ maxMg, int img0,
                                                      int flags /* as k_lsd_grad64 */, int2* __restrict__ hot /* as k_lsd_grad64 */,
                                                      float2* __restrict__ cold /* as k_lsd_grad64 */) {
@@ -272,8 +274,8 @@ __global__ __launch_bounds__(256) void k_lsd_front64(const uint8_t* __restrict__
   __shared__ double rows[FS_H + 2 * FR][FS_W];               // row-filtered window; afterwards the scaled tile (scl)
   __shared__ double blur[FS_H][FS_W];
   __shared__ unsigned long long wmax[4];
-  if (radius == FR) lsd_front64_tile<FR>(pyr, pyrBlock, sw, sh, pitch, kern, radius, tab, dw, dh, rho, rec, mg, own, maxMg, img0, flags, hot, cold, tile, rows, blur, wmax);
-  else lsd_front64_tile<0>(pyr, pyrBlock, sw, sh, pitch, kern, radius, tab, dw, dh, rho, rec, mg, own, maxMg, img0, flags, hot, cold, tile, rows, blur, wmax);
+  if (radius == FR) lsd_front64_tile<FR>(pyr, pyrBlock, sw, sh, pitch, kern, radius, tab, dw, dh, dp, rho, rec, mg, own, maxMg, img0, flags, hot, cold, tile, rows, blur, wmax);
+  else lsd_front64_tile<0>(pyr, pyrBlock, sw, sh, pitch, kern, radius, tab, dw, dh, dp, rho, rec, mg, own, maxMg, img0, flags, hot, cold, tile, rows, blur, wmax);
 }
 
 }  // namespace pli

@@ -425,9 +425,16 @@ pli_status buildGeometry(pli_ctx* c) {
   }
   // LSD (OpenCV lsd.cpp flsd)
   P.lsdScale = cfg.lsd_scale;
-  P.LW = cfg.lsd_scale != 1 ? cvRoundd(P.W * cfg.lsd_scale) : P.W;
+  P.LWt = cfg.lsd_scale != 1 ? cvRoundd(P.W * cfg.lsd_scale) : P.W;
   P.LH = cfg.lsd_scale != 1 ? cvRoundd(P.H * cfg.lsd_scale) : P.H;
-  P.lpitch = (int)alignUp(P.LW, 64);
+  // LW is the ROW PITCH, in pixels, of every per-pixel plane of the detector (records, norms, owner pairs, region tables' pixel
+  // indices): the true width LWt rounded up to 16 pixels, so that a row of 8-byte records starts on a 128-byte line and a row of 4-byte
+  // words on a 64-byte sector (902 -> 912 at 752 x 480 x 1.2: k_tx_sort's id stores and the row-wise passes touch whole sectors).  The
+  // pad columns are undefined pixels — as the image's last column already is — written by the front pass; nothing after it knows the
+  // true width.  Pixel indices (seed order within a bin, region ids in key mode) keep their order: (y, x) lexicographic either way.
+  P.LW = (int)alignUp(P.LWt, 16);
+  if (DEVENV("PLI_LSD_NOPAD")) P.LW = P.LWt;                 // dev switch (A/B)
+  P.lpitch = (int)alignUp(P.LWt, 64);
   P.prec = 3.14159265358979323846 * cfg.lsd_ang_th / 180;
   {
     // Vector form of isAligned (lsd.cpp region_grow): the angle between the region's (sumdx, sumdy) and a pixel's
@@ -462,7 +469,7 @@ pli_status buildGeometry(pli_ctx* c) {
   P.rho = cfg.lsd_quant / std::sin(P.prec);
   {
     const double p = cfg.lsd_ang_th / 180;
-    const double LOG_NT = 5 * (std::log10(double(P.LW)) + std::log10(double(P.LH))) / 2 + std::log10(11.0);
+    const double LOG_NT = 5 * (std::log10(double(P.LWt)) + std::log10(double(P.LH))) / 2 + std::log10(11.0);
     P.minRegSize = (int)size_t(-LOG_NT / std::log10(p));
   }
   P.maxLines = cfg.max_lines;
@@ -566,7 +573,7 @@ pli_status allocAll(pli_ctx* c) {
   c->lsdStride = alignUp((int64_t)P.lpitch * P.LH, 256);
   A(c->lsdScaled, (size_t)c->lsdStride * NI);
   if (c->cfg.lsd_scale != 1) {
-    std::vector<int> t = buildResizeTab(P.W, P.H, P.LW, P.LH, 1. / c->cfg.lsd_scale, 1. / c->cfg.lsd_scale);
+    std::vector<int> t = buildResizeTab(P.W, P.H, P.LWt, P.LH, 1. / c->cfg.lsd_scale, 1. / c->cfg.lsd_scale);
     A(c->lsdTab, t.size());
     HIPCHK(hipMemcpy(c->lsdTab, t.data(), t.size() * 4, hipMemcpyHostToDevice));
   }
@@ -596,34 +603,34 @@ pli_status allocAll(pli_ctx* c) {
     if (c->cfg.lsd_scale != 1) {
       A(c->tmp64, (size_t)P.W * P.H * NI);
       // cv::resize coefficient tables for CV_64F (imgwarp.cpp): float weights (1 - f, f), x clamped at the borders, y not
-      std::vector<int> t((size_t)3 * P.LW + 3 * P.LH);
+      std::vector<int> t((size_t)3 * P.LWt + 3 * P.LH);
       const double sc = 1. / c->cfg.lsd_scale;
       auto fbits = [](float f) { int b; std::memcpy(&b, &f, 4); return b; };
-      for (int d = 0; d < P.LW; ++d) {
+      for (int d = 0; d < P.LWt; ++d) {
         float f = (float)((d + 0.5) * sc - 0.5);
         int sidx = cvFloorf(f);
         f -= sidx;
         if (sidx < 0) { f = 0; sidx = 0; }
         if (sidx >= P.W - 1) { f = 0; sidx = P.W - 1; }
-        t[d] = sidx; t[P.LW + 2 * d] = fbits(1.f - f); t[P.LW + 2 * d + 1] = fbits(f);
+        t[d] = sidx; t[P.LWt + 2 * d] = fbits(1.f - f); t[P.LWt + 2 * d + 1] = fbits(f);
       }
       for (int d = 0; d < P.LH; ++d) {
         float f = (float)((d + 0.5) * sc - 0.5);
         int sidx = cvFloorf(f);
         f -= sidx;
-        t[3 * P.LW + d] = sidx; t[3 * P.LW + P.LH + 2 * d] = fbits(1.f - f); t[3 * P.LW + P.LH + 2 * d + 1] = fbits(f);
+        t[3 * P.LWt + d] = sidx; t[3 * P.LWt + P.LH + 2 * d] = fbits(1.f - f); t[3 * P.LWt + P.LH + 2 * d + 1] = fbits(f);
       }
       A(c->lsdTab64, t.size());
       HIPCHK(hipMemcpy(c->lsdTab64, t.data(), t.size() * 4, hipMemcpyHostToDevice));
       // the fused front (k_lsd_front64) stages the source window of a 64 x 16 tile of the scaled image in LDS: 64 x 20 at most
       bool fits = (int)h <= 3;
-      for (int x0 = 0; x0 < P.LW && fits; x0 += 64) {
-        const int x1 = std::min(x0 + 64, P.LW - 1);
+      for (int x0 = 0; x0 < P.LWt && fits; x0 += 64) {
+        const int x1 = std::min(x0 + 64, P.LWt - 1);
         fits = std::min(t[x1] + 1, P.W - 1) - t[x0] + 1 <= 64;
       }
       for (int y0 = 0; y0 < P.LH && fits; y0 += 16) {
         const int y1 = std::min(y0 + 16, P.LH - 1);
-        const int a = std::min(std::max(t[3 * P.LW + y0], 0), P.H - 1), b = std::min(std::max(t[3 * P.LW + y1] + 1, 0), P.H - 1);
+        const int a = std::min(std::max(t[3 * P.LWt + y0], 0), P.H - 1), b = std::min(std::max(t[3 * P.LWt + y1] + 1, 0), P.H - 1);
         fits = b - a + 1 <= 20;
       }
       c->lsdFront64 = fits && !DEVENV("PLI_LSD_NOFUSE");
@@ -950,24 +957,25 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
       // blur -> resize -> gradient in one pass over LDS tiles: neither double plane goes to HBM
       HIPCHK(hipMemsetAsync(c->maxMg + img0, 0, sizeof(unsigned long long) * nimg, c->stream));
       LAUNCH(c, "k_lsd_front", k_lsd_front64, dim3((P.LW + 63) / 64, (P.LH + 15) / 16, nimg), dim3(256), 0, c->pyr + P.lv[0].offset,
-             P.pyrBlock, P.W, P.H, P.lv[0].pitch, c->kern64, c->lsdRadius, c->lsdTab64, P.LW, P.LH, P.rho, recPlane, c->mg, ownPlane,
+             P.pyrBlock, P.W, P.H, P.lv[0].pitch, c->kern64, c->lsdRadius, c->lsdTab64, P.LWt, P.LH, P.LW, P.rho, recPlane, c->mg, ownPlane,
              c->maxMg, img0, trigF32, hotPlane, coldPlane);
     } else {
     if (c->cfg.lsd_scale != 1) {
       LAUNCH(c, "k_blur_lsd", k_lsd_blur64, gb, dim3(256), 0, c->pyr + P.lv[0].offset, P.pyrBlock, P.W, P.H, P.lv[0].pitch,
-             c->kern64, c->lsdRadius, c->tmp64, img0);
-      LAUNCH(c, "k_resize_lsd", k_lsd_resize64, dim3((P.LW + 255) / 256, P.LH, nimg), dim3(256), 0, c->tmp64, P.W, P.H, scaled64, P.LW,
-             P.LH, c->lsdTab64, img0);
+             c->kern64, c->lsdRadius, c->tmp64, (int64_t)P.W * P.H, img0);
+      LAUNCH(c, "k_resize_lsd", k_lsd_resize64, dim3((P.LWt + 255) / 256, P.LH, nimg), dim3(256), 0, c->tmp64, P.W, P.H, scaled64, P.LWt,
+             P.LH, (int64_t)npix, c->lsdTab64, img0);
     } else {
       LAUNCH(c, "k_blur_lsd", k_lsd_blur64, gb, dim3(256), 0, c->pyr + P.lv[0].offset, P.pyrBlock, P.W, P.H, P.lv[0].pitch,
-             c->kern64, 0, scaled64, img0);
+             c->kern64, 0, scaled64, (int64_t)npix, img0);
     }
+    // (the scaled double plane: rows of the TRUE width, images npix = pitch x height apart)
     if (c->debug && c->scaled64Dbg)                    // the plane becomes the growers' arena: keep a copy for PLI_DBG_LSD_SCALED
       HIPCHK(hipMemcpyAsync(c->scaled64Dbg + (int64_t)img0 * npix, scaled64 + (int64_t)img0 * npix, (size_t)nimg * npix * 8,
                             hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipMemsetAsync(c->maxMg + img0, 0, sizeof(unsigned long long) * nimg, c->stream));
-    LAUNCH(c, "k_lsd_grad", k_lsd_grad64, dim3((P.LW + 255) / 256, (P.LH + 15) / 16, nimg), dim3(256), 0, scaled64, P.LW, P.LH, P.rho,
-           recPlane, c->mg, ownPlane, c->maxMg, c->debug ? c->angDbg : (float*)nullptr, img0, trigF32, hotPlane, coldPlane);
+    LAUNCH(c, "k_lsd_grad", k_lsd_grad64, dim3((P.LW + 255) / 256, (P.LH + 15) / 16, nimg), dim3(256), 0, scaled64, P.LWt, P.LH, P.LW,
+           (int64_t)npix, P.rho, recPlane, c->mg, ownPlane, c->maxMg, c->debug ? c->angDbg : (float*)nullptr, img0, trigF32, hotPlane, coldPlane);
     }
   } else {
     const uint8_t* scaled;
@@ -975,16 +983,16 @@ pli_status runLines(pli_ctx* c, int img0, int nimg, uint8_t* table) {
     int sPitch;
     if (c->cfg.lsd_scale != 1) {
       LAUNCH(c, "k_blur_lsd", k_blur, dim3(c->l0Tiles, nimg), dim3(256), 0, c->jobLsd, c->pyr, P.pyrBlock, c->tmp8, c->tmp8Stride, img0);
-      dim3 g((P.LW + 255) / 256, (P.LH + 15) / 16, nimg);
+      dim3 g((P.LWt + 255) / 256, (P.LH + 15) / 16, nimg);
       LAUNCH(c, "k_resize_lsd", k_resize_level, g, dim3(256), 0, c->tmp8, c->tmp8Stride, P.W, P.H, c->tmpPitch, c->lsdScaled,
-             c->lsdStride, P.LW, P.LH, P.lpitch, c->lsdTab, img0);
+             c->lsdStride, P.LWt, P.LH, P.lpitch, c->lsdTab, img0);
       scaled = c->lsdScaled; sStride = c->lsdStride; sPitch = P.lpitch;
     } else {
       scaled = c->pyr + P.lv[0].offset; sStride = P.pyrBlock; sPitch = P.lv[0].pitch;
     }
     HIPCHK(hipMemsetAsync(c->maxG2 + img0, 0, sizeof(int) * nimg, c->stream));
     dim3 g((P.LW + 255) / 256, (P.LH + 15) / 16, nimg);   // 16 = LSD_GRAD_ROWS
-    LAUNCH(c, "k_lsd_grad", k_lsd_grad, g, dim3(256), 0, scaled, sStride, P.LW, P.LH, sPitch, P.g2Thresh, c->rec, c->g2, ownPlane,
+    LAUNCH(c, "k_lsd_grad", k_lsd_grad, g, dim3(256), 0, scaled, sStride, P.LWt, P.LH, P.LW, sPitch, P.g2Thresh, c->rec, c->g2, ownPlane,
            c->maxG2, c->debug ? c->angDbg : (float*)nullptr, img0, trigF32);
   }
   auto orderPasses = [&](const RxCtl* only) -> pli_status {
@@ -2780,24 +2788,24 @@ pli_status pli_debug_fetch(pli_ctx* c, int32_t image, int32_t what, int32_t arg,
     }
     case PLI_DBG_LSD_SCALED: {
       if (c->lsdF64) {     // CV_64F pipeline: doubles (the debug copy: the plane itself is the growers' arena)
-        if (!need((int64_t)P.LW * P.LH * 8)) return dst ? PLI_ERR_CAPACITY : PLI_OK;
+        if (!need((int64_t)P.LWt * P.LH * 8)) return dst ? PLI_ERR_CAPACITY : PLI_OK;
         if (!c->scaled64Dbg) { g_err = "pli_debug_enable was not on during the run"; return PLI_ERR_STATE; }
-        const double* src64 = c->scaled64Dbg;
-        HIPCHK(hipMemcpy(dst, src64 + (int64_t)image * P.LW * P.LH, (size_t)P.LW * P.LH * 8, hipMemcpyDeviceToHost));
+        const double* src64 = c->scaled64Dbg;     // (rows of the true width, images pitch x height apart: runLines)
+        HIPCHK(hipMemcpy(dst, src64 + (int64_t)image * P.LW * P.LH, (size_t)P.LWt * P.LH * 8, hipMemcpyDeviceToHost));
         return PLI_OK;
       }
-      if (!need((int64_t)P.LW * P.LH)) return dst ? PLI_ERR_CAPACITY : PLI_OK;
+      if (!need((int64_t)P.LWt * P.LH)) return dst ? PLI_ERR_CAPACITY : PLI_OK;
       if (c->cfg.lsd_scale != 1)
-        HIPCHK(hipMemcpy2D(dst, P.LW, c->lsdScaled + (int64_t)image * c->lsdStride, P.lpitch, P.LW, P.LH, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy2D(dst, P.LWt, c->lsdScaled + (int64_t)image * c->lsdStride, P.lpitch, P.LWt, P.LH, hipMemcpyDeviceToHost));
       else
         HIPCHK(hipMemcpy2D(dst, P.W, c->pyr + (int64_t)image * P.pyrBlock, P.lv[0].pitch, P.W, P.H, hipMemcpyDeviceToHost));
       return PLI_OK;
     }
     case PLI_DBG_LSD_ANGLE: {
       if (!c->angDbg) { g_err = "pli_debug_enable was not on during the run"; return PLI_ERR_STATE; }
-      const int64_t n = (int64_t)P.LW * P.LH * 4;
+      const int64_t n = (int64_t)P.LWt * P.LH * 4;   // (the debug plane has rows of the true width)
       if (!need(n)) return dst ? PLI_ERR_CAPACITY : PLI_OK;
-      HIPCHK(hipMemcpy(dst, c->angDbg + (int64_t)image * P.LW * P.LH, n, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(dst, c->angDbg + (int64_t)image * P.LWt * P.LH, n, hipMemcpyDeviceToHost));
       return PLI_OK;
     }
     case PLI_DBG_LSD_SEGMENTS: {
@@ -2814,6 +2822,10 @@ pli_status pli_debug_fetch(pli_ctx* c, int32_t image, int32_t what, int32_t arg,
       if (!need(4 + (int64_t)n * 4)) return dst ? PLI_ERR_CAPACITY : PLI_OK;
       *(int*)dst = n;
       if (n) HIPCHK(hipMemcpy((char*)dst + 4, c->order + (int64_t)image * P.LW * P.LH, (size_t)n * 4, hipMemcpyDeviceToHost));
+      if (P.LW != P.LWt) {     // device pixel indices are y * pitch + x: the caller gets y * width + x
+        int* o = (int*)dst + 1;
+        for (int i = 0; i < n; ++i) o[i] = (o[i] / P.LW) * P.LWt + o[i] % P.LW;
+      }
       return PLI_OK;
     }
     case PLI_DBG_LBD_DXDY: {
@@ -2835,7 +2847,7 @@ pli_status pli_debug_fetch(pli_ctx* c, int32_t image, int32_t what, int32_t arg,
     }
     case PLI_DBG_LSD_OWNER: {
       const int64_t np = (int64_t)P.LW * P.LH;
-      if (!need(4 + np * 4)) return dst ? PLI_ERR_CAPACITY : PLI_OK;
+      if (!need(4 + (int64_t)P.LWt * P.LH * 4)) return dst ? PLI_ERR_CAPACITY : PLI_OK;
       RxCtl ctl;
       HIPCHK(hipMemcpy(&ctl, c->jrCtl + image, sizeof(ctl), hipMemcpyDeviceToHost));
       std::vector<int2> own(np);
@@ -2843,7 +2855,8 @@ pli_status pli_debug_fetch(pli_ctx* c, int32_t image, int32_t what, int32_t arg,
       int* o = (int*)dst;
       o[0] = ctl.rounds;
       const int comp = (ctl.rounds - 1) & 1;          // owner_{t-1} of the round that detected the fixed point
-      for (int64_t i = 0; i < np; ++i) o[1 + i] = comp ? own[i].y : own[i].x;
+      for (int y = 0; y < P.LH; ++y)
+        for (int x = 0; x < P.LWt; ++x) { const int2 w = own[(int64_t)y * P.LW + x]; o[1 + (int64_t)y * P.LWt + x] = comp ? w.y : w.x; }
       return PLI_OK;
     }
     case 15: {   // debug: raw owner pairs
