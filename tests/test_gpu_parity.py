@@ -1274,6 +1274,48 @@ def test_the_product_library_has_no_lane_relaxation_and_ignores_dev_switches(gpu
     assert stats[True][0] == 1 and stats[True][2] >= 1, stats          # development build: one planned round, the device-side fallback
 
 
+@pytest.mark.parametrize("W", [640, 641, 666, 752])          # scaled widths 768 / 769 / 799 / 902: pads of 0 / 15 / 1 / 10 columns
+def test_the_row_pitch_of_the_lsd_planes_does_not_show(gpu, W, monkeypatch):
+    """The detector's per-pixel planes have a row pitch of the scaled width rounded up to 16 pixels (the pad columns are undefined
+    pixels the front pass writes).  Nothing may depend on it: the oracle's lines in the default schedule (key mode), the sequential
+    grower, the CV_8U pipeline and a debug context (rank mode, the unfused front pass, every debug plane in the caller's layout) — and
+    the same bytes from a development build that runs on the true width (PLI_LSD_NOPAD)."""
+    g = gpu
+    capi = g.capi
+    H = 200
+    L, R = g.synth.make_stereo_pair(31 + W, W, H)
+    for mode, flags, debug in ((0, None, False), (2, None, False), (0, capi.default_config(64, 64).parity_flags & ~capi.PARITY_LSD_F64, False), (0, None, True)):
+        kw = dict(orb_nfeatures=300, lsd_nfeatures=0, max_frames=1, lsd_mode=mode)
+        if flags is not None:
+            kw["parity_flags"] = flags
+        cfg = capi.default_config(W, H, **kw)
+        fr = g.po.Frame(ocfg(g, cfg))
+        want = fr.line_extract(0, L)
+        assert want[0] > 50
+        got = {}
+        for nopad in (False, True):
+            if nopad:
+                monkeypatch.setenv("PLI_LSD_NOPAD", "1")
+            else:
+                monkeypatch.delenv("PLI_LSD_NOPAD", raising=False)
+            fe = g.Frontend(cfg, dev=True)
+            if debug:
+                fe.debug_enable(True)
+            m, kl, ld = fe.line_extract(0, L)
+            assert m == want[0] and kl.tobytes() == want[1].tobytes() and np.array_equal(ld, want[2]), (mode, flags, debug, nopad)
+            if debug:
+                oang = fr.lsd_angle(0).ravel()
+                assert np.array_equal(fe.debug_fetch(0, capi.DBG_LSD_ANGLE).view(np.float32), oang), nopad
+                assert np.array_equal(fe.debug_fetch(0, capi.DBG_LSD_SCALED).view(np.float64), fr.lsd_scaled64(0).ravel()), nopad
+                raw = fe.debug_fetch(0, capi.DBG_LSD_ORDER).view(np.int32)
+                oo = fr.lsd_order(0)
+                assert np.array_equal(raw[1:1 + raw[0]], oo[oang[oo] != -1024]), nopad
+                got[nopad] = fe.debug_fetch(0, capi.DBG_LSD_OWNER).tobytes()
+        if debug:
+            assert got[False] == got[True]            # the owner map of the fixed point, in the caller's layout
+        monkeypatch.delenv("PLI_LSD_NOPAD", raising=False)
+
+
 def test_hot_records_hardware_trig_error_is_inside_the_budget(gpu):
     """Round 1 on the 8-byte hot records runs its vector filter on v_cos_f32 / v_sin_f32 (lsd_tile.hip "HOT RECORDS"); the error
     budget that keeps the filter's decisions inside the margin of the exact expression assumes |error| < 4e-6 for every float angle."""
