@@ -299,7 +299,12 @@ __device__ __forceinline__ void tx_sort_tile(const int* __restrict__ rankAll, co
   for (int m = 0; m < KPT; ++m) {
     const int i = m * NT + tid;
     const unsigned k = xch[pad(i)];
-    if (k != 0xFFFFFFFFu) list[i] = make_int2((int)k, keys.mg ? (int)(k & ((1u << keys.pixbits) - 1u)) : order[k]);
+    // (key mode: the id's low bits ARE the seed pixel — 4-byte entries, at the start of the tile's slot of the list buffer: half the
+    // bytes for this kernel to store and for the growers to fetch)
+    if (k != 0xFFFFFFFFu) {
+      if (keys.mg) reinterpret_cast<int*>(listAll)[((int64_t)img * ntx * nty + tile) * n2 + i] = (int)k;
+      else list[i] = make_int2((int)k, order[k]);
+    }
   }
   if (tid == 0) tileCntAll[(int64_t)img * ntx * nty + tile] = s_cnt;
 }
@@ -1153,6 +1158,12 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
     }
   };
   const int2* list = listAll + ((int64_t)img * ntile + tile) * ts * ts;
+  // (key mode: 4-byte entries — the id, whose low bits are the seed pixel — at the start of the tile's slot: k_tx_sort)
+  const int* listK = reinterpret_cast<const int*>(listAll) + ((int64_t)img * ntile + tile) * ts * ts;
+  auto seedEntry = [&](int i) -> int2 {
+    if (DL.rmask != -1) { const int v = listK[i]; return make_int2(v, v & DL.rmask); }
+    return list[i];
+  };
   int* rgSize = rgSizeAll + img * npix;
   int2* rgBox = rgBoxAll + img * npix;
   const int* rgDirty = rgDirtyAll + img * npix;
@@ -1678,7 +1689,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
         for (int u = 0; u < 4; ++u) {
           const int idx = pos + 64 * u + lane;
           se4[u] = make_int2(TX_INF, -1);
-          if (u < R && idx < n) se4[u] = list[idx];
+          if (u < R && idx < n) se4[u] = seedEntry(idx);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -1925,7 +1936,7 @@ __device__ __forceinline__ void tx_grow_tile(const DevParams* __restrict__ Pp, R
     const bool valid = base + lane < n;
     if (!useDirty) {                                      // (the dirty list: n <= 64, one row, already there)
       se = make_int2(TX_INF, -1);
-      if (valid) se = list[base + lane];
+      if (valid) se = seedEntry(base + lane);
     }
     bool d = valid;
     if (SPARSE && !useDirty) d = valid && rgDirty[se.x & DL.rmask] == t;
